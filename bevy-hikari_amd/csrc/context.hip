@@ -1,0 +1,849 @@
+// context.hip - the C ABI of libhikari_hip.so: context, uploads, per-frame dispatch order.
+//
+// Reference call sites this file stands in for (cryscan/bevy-hikari v0.3.15):
+//   uploads        src/mesh_material/mesh.rs:43-64, material.rs:201-202, instance.rs:82-108, src/lib.rs:189-219
+//   resources      src/light.rs:307-383 (render/variance/albedo textures, 10 reservoir buffers),
+//                  src/prepass.rs:285-318 (G-buffer), src/post_process.rs:621-633 (denoise textures)
+//   dispatch order src/prepass.rs:769-852, src/light.rs:590-702, src/post_process.rs:1190-1234
+//   ping-pong      src/light.rs:376,480-481,518-546
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "hk_internal.hpp"
+#include "hk_kernels.hpp"
+
+using namespace hk;
+using namespace hkd;
+
+#define HK_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ::hk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return HK_E_HIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+namespace {
+
+template <typename T>
+struct DevArray {
+  T* p = nullptr;
+  size_t n = 0;
+  int upload(const std::vector<T>& h) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = h.size();
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HK_HIP(hipMalloc((void**)&p, bytes));
+    if (n) HK_HIP(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return HK_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+struct TimedLaunch {
+  uint32_t slot;
+  hipEvent_t start, stop;
+};
+
+// IEEE minNum / maxNum with -0 < +0 (the numeric contract of hk_device_math.hpp) on the host
+inline float hmin(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return signbit(a) ? a : b;
+  return a < b ? a : b;
+}
+inline float hmax(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return signbit(a) ? b : a;
+  return a > b ? a : b;
+}
+inline uint32_t hash_u32(uint32_t value) {  // utils.wgsl:15-24
+  uint32_t state = value;
+  state = state ^ 2747636419u;
+  state = state * 2654435769u;
+  state = state ^ (state >> 16u);
+  state = state * 2654435769u;
+  state = state ^ (state >> 16u);
+  state = state * 2654435769u;
+  return state;
+}
+inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+struct hk_ctx {
+  int device = 0;
+  uint32_t flags = 0;
+  hipStream_t stream = nullptr;
+
+  // host copies of the reference-layout scene (kept for the layout conversion)
+  std::vector<HkVertex> vertices;
+  std::vector<HkPrimitive> primitives;
+  std::vector<HkNode> asset_nodes;
+  std::vector<HkMaterial> materials;
+  std::vector<HkInstance> instances;
+  std::vector<HkNode> instance_nodes;
+  std::vector<HkEmissive> emissives;
+  std::vector<HkNode> emissive_nodes;
+  std::vector<HkAliasEntry> alias_table;
+  bool have_meshes = false, have_materials = false, have_instances = false, have_noise = false;
+  bool scene_dirty = true;
+
+  // device scene
+  DevArray<float4> tlas_lo, tlas_hi, blas_lo, blas_hi, tri_v0, tri_v1, tri_v2, vtx_normal, d_materials, light_lo, light_hi;
+  DevArray<float2> vtx_uv, d_alias;
+  DevArray<DInstance> d_instances;
+  DevArray<DEmissive> d_emissives;
+  DevArray<uint32_t> d_noise;
+  DScene scene{};
+
+  // screen-space resources
+  int W = 0, H = 0, RW = 0, RH = 0;
+  float ratio = 1.0f;
+  void* buf[HK_BUF_COUNT] = {};
+  size_t buf_bytes[HK_BUF_COUNT] = {};
+
+  // uniforms
+  HkFrame frame{};
+  HkView view{};
+  HkPreviousView pview{};
+  HkLights lights{};
+  bool have_frame = false;
+  uint32_t taa = HK_TAA_JASMINE, upscale_kind = HK_UPSCALE_SMAA_TU4X;
+
+  uint32_t band_index = 0, band_count = 1;
+
+  // statistics
+  unsigned long long* d_counters = nullptr;  // primary, tlas, blas
+  uint64_t frames = 0;
+  uint32_t timing_mask = 0;
+  std::vector<TimedLaunch> pending;
+  std::vector<hipEvent_t> event_pool;
+  double slot_ms[HK_TIMING_SLOTS] = {};
+  uint64_t slot_launches[HK_TIMING_SLOTS] = {};
+  hipEvent_t frame_start = nullptr, frame_stop = nullptr;
+  bool frame_timed = false;
+  float last_frame_ms = 0.0f;
+};
+
+namespace {
+
+int free_screen(hk_ctx* c) {
+  for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
+    if (c->buf[b]) (void)hipFree(c->buf[b]);
+    c->buf[b] = nullptr;
+    c->buf_bytes[b] = 0;
+  }
+  return HK_OK;
+}
+
+hipEvent_t get_event(hk_ctx* c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+// resolve finished timed launches into the per-slot accumulators (stream must be idle)
+void drain_timers(hk_ctx* c) {
+  for (TimedLaunch& t : c->pending) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      c->slot_ms[t.slot] += (double)ms;
+      c->slot_launches[t.slot] += 1;
+    }
+    c->event_pool.push_back(t.start);
+    c->event_pool.push_back(t.stop);
+  }
+  c->pending.clear();
+  if (c->frame_timed) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, c->frame_start, c->frame_stop) == hipSuccess) c->last_frame_ms = ms;
+    c->frame_timed = false;
+  }
+}
+
+struct ScopedTimer {
+  hk_ctx* c;
+  bool on;
+  TimedLaunch t{};
+  ScopedTimer(hk_ctx* ctx, uint32_t slot) : c(ctx), on((ctx->timing_mask >> slot) & 1u) {
+    if (on) {
+      t.slot = slot;
+      t.start = get_event(c);
+      t.stop = get_event(c);
+      (void)hipEventRecord(t.start, c->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (on) {
+      (void)hipEventRecord(t.stop, c->stream);
+      c->pending.push_back(t);
+    }
+  }
+};
+
+// Convert the reference-layout scene to the device layout (hk_device.hpp header comment).
+int finalize_scene(hk_ctx* c) {
+  if (!c->scene_dirty) return HK_OK;
+  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
+  const size_t n_nodes = c->asset_nodes.size(), n_prims = c->primitives.size(), n_verts = c->vertices.size();
+  // which mesh (primitive offset) owns each BLAS node, from the instances' mesh records
+  std::vector<int64_t> node_prim_offset(n_nodes, -1);
+  for (const HkInstance& in : c->instances) {
+    HK_REQUIRE((size_t)in.mesh.node_offset + in.mesh.node_count <= n_nodes, HK_E_INVALID, "instance mesh node range out of bounds");
+    HK_REQUIRE(in.material < c->materials.size(), HK_E_INVALID, "instance material out of bounds");
+    for (uint32_t k = 0; k < in.mesh.node_count; ++k) node_prim_offset[in.mesh.node_offset + k] = in.mesh.primitive;
+  }
+  std::vector<float4> lo(n_nodes), hi(n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const HkNode& n = c->asset_nodes[i];
+    float mn[3] = {n.min[0], n.min[1], n.min[2]}, mx[3] = {n.max[0], n.max[1], n.max[2]};
+    if (n.entry_index >= HK_BVH_LEAF_FLAG && node_prim_offset[i] >= 0) {  // light.wgsl:408-412
+      size_t prim = (size_t)node_prim_offset[i] + (n.entry_index - HK_BVH_LEAF_FLAG);
+      HK_REQUIRE(prim < n_prims, HK_E_INVALID, "BLAS leaf primitive out of bounds");
+      const HkPrimitiveVertex* v = c->primitives[prim].vertices;
+      for (int k = 0; k < 3; ++k) {
+        mn[k] = hmin(v[0].position[k], hmin(v[1].position[k], v[2].position[k]));
+        mx[k] = hmax(v[0].position[k], hmax(v[1].position[k], v[2].position[k]));
+      }
+    }
+    lo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
+    hi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
+  }
+  int rc;
+  if ((rc = c->blas_lo.upload(lo))) return rc;
+  if ((rc = c->blas_hi.upload(hi))) return rc;
+
+  std::vector<float4> v0(n_prims), v1(n_prims), v2(n_prims);
+  for (size_t i = 0; i < n_prims; ++i) {
+    const HkPrimitiveVertex* v = c->primitives[i].vertices;
+    v0[i] = make_float4(v[0].position[0], v[0].position[1], v[0].position[2], as_f(v[0].index));
+    v1[i] = make_float4(v[1].position[0], v[1].position[1], v[1].position[2], as_f(v[1].index));
+    v2[i] = make_float4(v[2].position[0], v[2].position[1], v[2].position[2], as_f(v[2].index));
+  }
+  if ((rc = c->tri_v0.upload(v0))) return rc;
+  if ((rc = c->tri_v1.upload(v1))) return rc;
+  if ((rc = c->tri_v2.upload(v2))) return rc;
+
+  std::vector<float4> vn(n_verts);
+  std::vector<float2> vuv(n_verts);
+  for (size_t i = 0; i < n_verts; ++i) {
+    vn[i] = make_float4(c->vertices[i].normal[0], c->vertices[i].normal[1], c->vertices[i].normal[2], 0.0f);
+    vuv[i] = make_float2(c->vertices[i].u, c->vertices[i].v);
+  }
+  if ((rc = c->vtx_normal.upload(vn))) return rc;
+  if ((rc = c->vtx_uv.upload(vuv))) return rc;
+
+  std::vector<DInstance> di(c->instances.size());
+  for (size_t i = 0; i < di.size(); ++i) {
+    const HkInstance& in = c->instances[i];
+    const float* t = in.inverse_transpose_model;
+    const float* m = in.model;
+    DInstance& d = di[i];
+    d.im0 = make_float4(t[0], t[4], t[8], t[12]);  // column j of transpose(itm) = row j of itm
+    d.im1 = make_float4(t[1], t[5], t[9], t[13]);
+    d.im2 = make_float4(t[2], t[6], t[10], t[14]);
+    d.im3 = make_float4(t[3], t[7], t[11], t[15]);
+    d.m0 = make_float4(m[0], m[1], m[2], m[3]);
+    d.m1 = make_float4(m[4], m[5], m[6], m[7]);
+    d.m2 = make_float4(m[8], m[9], m[10], m[11]);
+    d.m3 = make_float4(m[12], m[13], m[14], m[15]);
+    d.n0 = make_float4(t[0], t[1], t[2], 0.0f);
+    d.n1 = make_float4(t[4], t[5], t[6], 0.0f);
+    d.n2 = make_float4(t[8], t[9], t[10], 0.0f);
+    d.material = in.material;
+    d.vertex = in.mesh.vertex;
+    d.primitive = in.mesh.primitive;
+    d.node_offset = in.mesh.node_offset;
+    d.node_count = in.mesh.node_count;
+    d.pad0 = d.pad1 = d.pad2 = 0;
+  }
+  if ((rc = c->d_instances.upload(di))) return rc;
+
+  const size_t n_tlas = c->instance_nodes.size();
+  std::vector<float4> tlo(n_tlas), thi(n_tlas);
+  for (size_t i = 0; i < n_tlas; ++i) {
+    const HkNode& n = c->instance_nodes[i];
+    const float* mn = n.min;
+    const float* mx = n.max;
+    if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:454-457: the leaf box is the instance's world AABB
+      uint32_t inst = n.entry_index - HK_BVH_LEAF_FLAG;
+      HK_REQUIRE(inst < c->instances.size(), HK_E_INVALID, "TLAS leaf instance out of bounds");
+      mn = c->instances[inst].min;
+      mx = c->instances[inst].max;
+    }
+    tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
+    thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
+  }
+  if ((rc = c->tlas_lo.upload(tlo))) return rc;
+  if ((rc = c->tlas_hi.upload(thi))) return rc;
+
+  std::vector<float4> mats(3 * c->materials.size());
+  for (size_t i = 0; i < c->materials.size(); ++i) {
+    const HkMaterial& m = c->materials[i];
+    mats[3 * i] = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
+    mats[3 * i + 1] = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
+    mats[3 * i + 2] = make_float4(m.perceptual_roughness, m.metallic, m.reflectance, 0.0f);
+  }
+  if ((rc = c->d_materials.upload(mats))) return rc;
+
+  const size_t n_light = c->emissive_nodes.size();
+  std::vector<float4> llo(n_light), lhi(n_light);
+  for (size_t i = 0; i < n_light; ++i) {
+    const HkNode& n = c->emissive_nodes[i];
+    float mn[3] = {n.min[0], n.min[1], n.min[2]}, mx[3] = {n.max[0], n.max[1], n.max[2]};
+    if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:633-636: position -/+ radius
+      uint32_t e = n.entry_index - HK_BVH_LEAF_FLAG;
+      HK_REQUIRE(e < c->emissives.size(), HK_E_INVALID, "light BVH leaf out of bounds");
+      for (int k = 0; k < 3; ++k) {
+        mn[k] = c->emissives[e].position[k] - c->emissives[e].radius;
+        mx[k] = c->emissives[e].position[k] + c->emissives[e].radius;
+      }
+    }
+    llo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
+    lhi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
+  }
+  if ((rc = c->light_lo.upload(llo))) return rc;
+  if ((rc = c->light_hi.upload(lhi))) return rc;
+
+  std::vector<DEmissive> de(c->emissives.size());
+  for (size_t i = 0; i < de.size(); ++i) {
+    const HkEmissive& e = c->emissives[i];
+    HK_REQUIRE(e.instance < c->instances.size(), HK_E_INVALID, "emissive instance out of bounds");
+    HK_REQUIRE((size_t)e.alias_table[0] + e.alias_table[1] <= c->alias_table.size() && e.alias_table[1] > 0, HK_E_INVALID, "emissive alias slice out of bounds");
+    de[i].position_radius = make_float4(e.position[0], e.position[1], e.position[2], e.radius);
+    de[i].instance = e.instance;
+    de[i].alias_offset = e.alias_table[0];
+    de[i].alias_count = e.alias_table[1];
+    de[i].surface_area = e.surface_area;
+  }
+  if ((rc = c->d_emissives.upload(de))) return rc;
+  std::vector<float2> al(c->alias_table.size());
+  for (size_t i = 0; i < al.size(); ++i) al[i] = make_float2(c->alias_table[i].prob, as_f(c->alias_table[i].index));
+  if ((rc = c->d_alias.upload(al))) return rc;
+
+  DScene& s = c->scene;
+  s.tlas_lo = c->tlas_lo.p; s.tlas_hi = c->tlas_hi.p; s.instances = c->d_instances.p;
+  s.blas_lo = c->blas_lo.p; s.blas_hi = c->blas_hi.p;
+  s.tri_v0 = c->tri_v0.p; s.tri_v1 = c->tri_v1.p; s.tri_v2 = c->tri_v2.p;
+  s.vtx_normal = c->vtx_normal.p; s.vtx_uv = c->vtx_uv.p;
+  s.materials = c->d_materials.p;
+  s.light_lo = c->light_lo.p; s.light_hi = c->light_hi.p;
+  s.emissives = c->d_emissives.p; s.alias = c->d_alias.p;
+  s.noise = c->d_noise.p;
+  s.tlas_count = (uint32_t)n_tlas;
+  s.light_count = (uint32_t)n_light;
+  c->scene_dirty = false;
+  return HK_OK;
+}
+
+DFrame make_dframe(const hk_ctx* c) {
+  DFrame f;
+  memset(&f, 0, sizeof(f));
+  const HkFrame& h = c->frame;
+  for (int col = 0; col < 3; ++col)
+    for (int row = 0; row < 3; ++row) f.kernel[col * 3 + row] = h.kernel[col][row];
+  f.number = h.number;
+  f.direct_validate_interval = h.direct_validate_interval;
+  f.emissive_validate_interval = h.emissive_validate_interval;
+  f.indirect_bounces = h.indirect_bounces;
+  f.temporal_reuse = h.temporal_reuse;
+  f.max_temporal_reuse_count = h.max_temporal_reuse_count;
+  f.max_spatial_reuse_count = h.max_spatial_reuse_count;
+  f.max_reservoir_lifetime = h.max_reservoir_lifetime;
+  f.solar_angle = h.solar_angle;
+  f.max_indirect_luminance = h.max_indirect_luminance;
+  f.upscale_ratio = h.upscale_ratio;
+  f.random_float_number = (float)hash_u32(h.number) / 4294967295.0f;
+  f.number_golden = (float)h.number * 1.618033989f;
+  f.cam_x = c->view.world_position[0]; f.cam_y = c->view.world_position[1]; f.cam_z = c->view.world_position[2];
+  f.ortho_x = c->view.view_proj[2]; f.ortho_y = c->view.view_proj[6]; f.ortho_z = c->view.view_proj[10];
+  f.is_ortho = c->view.projection[15] == 1.0f ? 1u : 0u;
+  f.sun_r = c->lights.directional_color[0]; f.sun_g = c->lights.directional_color[1]; f.sun_b = c->lights.directional_color[2];
+  f.sun_dx = c->lights.direction_to_light[0]; f.sun_dy = c->lights.direction_to_light[1]; f.sun_dz = c->lights.direction_to_light[2];
+  f.amb_r = c->lights.ambient_color[0]; f.amb_g = c->lights.ambient_color[1]; f.amb_b = c->lights.ambient_color[2];
+  f.clear_r = h.clear_color[0]; f.clear_g = h.clear_color[1]; f.clear_b = h.clear_color[2]; f.clear_a = h.clear_color[3];
+  f.dw = c->W; f.dh = c->H; f.rw = c->RW; f.rh = c->RH;
+  return f;
+}
+GBuffer make_gbuffer(const hk_ctx* c) {
+  GBuffer g;
+  g.position = (float4*)c->buf[HK_BUF_POSITION];
+  g.normal = (uint32_t*)c->buf[HK_BUF_NORMAL];
+  g.depth_gradient = (float2*)c->buf[HK_BUF_DEPTH_GRADIENT];
+  g.instance_material = (float2*)c->buf[HK_BUF_INSTANCE_MATERIAL];
+  g.velocity_uv = (float4*)c->buf[HK_BUF_VELOCITY_UV];
+  return g;
+}
+// group 6 ping-pong, light.rs:376,480-481,518-546
+LightTargets make_light_targets(const hk_ctx* c, int channel) {
+  static const int T[3] = {0, 2, 6}, S[3] = {4, 4, 8};
+  const uint32_t cur = c->frame.number % 2u, prev = 1u - cur;
+  LightTargets t;
+  t.previous = (const PackedReservoir*)c->buf[HK_BUF_RESERVOIR0 + cur + T[channel]];
+  t.current = (PackedReservoir*)c->buf[HK_BUF_RESERVOIR0 + prev + T[channel]];
+  t.previous_spatial = (PackedReservoir*)c->buf[HK_BUF_RESERVOIR0 + cur + S[channel]];
+  t.spatial = (PackedReservoir*)c->buf[HK_BUF_RESERVOIR0 + prev + S[channel]];
+  t.variance = (float*)c->buf[HK_BUF_VARIANCE0 + channel];
+  t.render = (uint2*)c->buf[HK_BUF_RENDER0 + channel];
+  return t;
+}
+
+int ready(hk_ctx* c) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_REQUIRE(c->W > 0, HK_E_NOT_READY, "hk_resize has not been called");
+  HK_REQUIRE(c->have_frame, HK_E_NOT_READY, "hk_frame_begin has not been called");
+  HK_REQUIRE(c->have_noise, HK_E_NOT_READY, "noise textures not uploaded");
+  HK_HIP(hipSetDevice(c->device));
+  return finalize_scene(c);
+}
+
+struct Jitter { float x, y; };
+Jitter prepass_jitter(const hk_ctx* c) {  // prepass.wgsl:30-38,52-54,71
+  Jitter j{0.0f, 0.0f};
+  if (c->taa == HK_TAA_NONE) return j;
+  const uint32_t n = c->frame.number;
+  const uint32_t index = (c->upscale_kind == HK_UPSCALE_SMAA_TU4X) ? ((n >> 1u) & 15u) : (n & 15u);
+  const float* h = c->frame.halton[index >> 1u];
+  const float hx = (index & 1u) == 0u ? h[0] : h[2], hy = (index & 1u) == 0u ? h[1] : h[3];
+  j.x = 2.0f * hx * (1.0f / c->view.viewport[2]);
+  j.y = -(2.0f * hy * (1.0f / c->view.viewport[3]));
+  return j;
+}
+
+void full_rows_for(const hk_ctx* c, int ry0, int ry1, int* fy0, int* fy1) {
+  if (c->RH == c->H) {
+    *fy0 = ry0;
+    *fy1 = ry1;
+    return;
+  }
+  *fy0 = std::max(0, (int)floorf((float)ry0 * (float)c->H / (float)c->RH) - 1);
+  *fy1 = std::min(c->H, (int)ceilf((float)ry1 * (float)c->H / (float)c->RH) + 1);
+}
+
+int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
+  const DFrame fr = make_dframe(c);
+  const GBuffer g = make_gbuffer(c);
+  unsigned long long* counters = (c->flags & HK_CTX_COUNT_RAYS) ? c->d_counters : nullptr;
+  ScopedTimer timer(c, pass);
+  switch (pass) {
+    case HK_PASS_PREPASS: {
+      Jitter j = prepass_jitter(c);
+      launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, j.x, j.y, g, y0, y1, counters);
+      break;
+    }
+    case HK_PASS_FULL_SCREEN_ALBEDO: launch_albedo(c->stream, c->scene, fr, g, c->buf[HK_BUF_ALBEDO], y0, y1); break;
+    case HK_PASS_DIRECT_LIT: launch_direct(c->stream, false, c->scene, fr, g, make_light_targets(c, 0), y0, y1, counters); break;
+    case HK_PASS_DIRECT_EMISSIVE: launch_direct(c->stream, true, c->scene, fr, g, make_light_targets(c, 1), y0, y1, counters); break;
+    case HK_PASS_INDIRECT:  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
+      launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, make_light_targets(c, 2), y0, y1, counters);
+      break;
+    case HK_PASS_EMISSIVE_SPATIAL_REUSE: launch_spatial(c->stream, true, c->scene, fr, g, make_light_targets(c, 1), y0, y1); break;
+    case HK_PASS_INDIRECT_SPATIAL_REUSE: launch_spatial(c->stream, false, c->scene, fr, g, make_light_targets(c, 2), y0, y1); break;
+    case HK_PASS_DEMODULATION: {
+      HK_REQUIRE(arg < 3, HK_E_INVALID, "channel out of range");
+      DenoiseTargets d{};
+      d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
+      d.variance = (const float*)c->buf[HK_BUF_VARIANCE0 + arg];
+      d.render = (const uint2*)c->buf[HK_BUF_RENDER0 + arg];
+      d.input = nullptr;
+      d.output = (uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0];
+      d.internal_variance = (float*)c->buf[HK_BUF_DENOISE_INTERNAL_VARIANCE];
+      launch_demodulation(c->stream, fr, d, y0, y1);
+      break;
+    }
+    case HK_PASS_DENOISE_L0: case HK_PASS_DENOISE_L1: case HK_PASS_DENOISE_L2: case HK_PASS_DENOISE_L3: {
+      HK_REQUIRE(arg < 3, HK_E_INVALID, "channel out of range");
+      const int level = (int)(pass - HK_PASS_DENOISE_L0);
+      DenoiseTargets d{};
+      d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
+      d.variance = nullptr;
+      d.render = nullptr;
+      d.input = (const uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level];
+      d.output = level == 3 ? (uint2*)c->buf[HK_BUF_DENOISE_RENDER0 + arg] : (uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level + 1];
+      d.internal_variance = (float*)c->buf[HK_BUF_DENOISE_INTERNAL_VARIANCE];
+      // denoise_direct has no FIREFLY_FILTERING, post_process.rs:773-783,1193-1197
+      launch_denoise(c->stream, level, arg != 0, fr, g, d, y0, y1);
+      break;
+    }
+    case HK_PASS_TONE_MAPPING: {  // inputs per post_process.rs:941-954
+      const uint32_t base = arg ? HK_BUF_DENOISE_RENDER0 : HK_BUF_RENDER0;
+      const void* indirect = c->frame.indirect_bounces != 0u ? c->buf[base + 2] : nullptr;
+      launch_tone_mapping(c->stream, fr, c->buf[base], c->buf[base + 1], indirect, c->buf[HK_BUF_TONE_MAPPED], y0, y1);
+      break;
+    }
+    default: HK_REQUIRE(false, HK_E_INVALID, "unknown pass %u", pass);
+  }
+  HK_HIP(hipGetLastError());
+  return HK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hk_device_count(int* count) {
+  HK_REQUIRE(count, HK_E_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    return HK_E_NO_DEVICE;
+  }
+  *count = n;
+  return HK_OK;
+}
+
+int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
+  HK_REQUIRE(out, HK_E_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  HK_REQUIRE(e == hipSuccess && n > 0, HK_E_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
+  HK_REQUIRE(device_id >= 0 && device_id < n, HK_E_NO_DEVICE, "device id %d out of range (0..%d)", device_id, n - 1);
+  HK_HIP(hipSetDevice(device_id));
+  hk_ctx* c = new (std::nothrow) hk_ctx();
+  HK_REQUIRE(c, HK_E_NOMEM, "allocation failed");
+  c->device = device_id;
+  c->flags = flags;
+  c->timing_mask = (flags & HK_CTX_TIME_PASSES) ? 0xFFFFFFFFu : 0u;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&c->frame_start) != hipSuccess ||
+      hipEventCreate(&c->frame_stop) != hipSuccess) {
+    set_error("HIP resource creation failed: %s", hipGetErrorString(hipGetLastError()));
+    hk_destroy(c);
+    return HK_E_HIP;
+  }
+  *out = c;
+  return HK_OK;
+}
+
+void hk_destroy(hk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drain_timers(c);
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->frame_start) (void)hipEventDestroy(c->frame_start);
+  if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
+  free_screen(c);
+  c->tlas_lo.release(); c->tlas_hi.release(); c->blas_lo.release(); c->blas_hi.release();
+  c->tri_v0.release(); c->tri_v1.release(); c->tri_v2.release(); c->vtx_normal.release(); c->vtx_uv.release();
+  c->d_materials.release(); c->light_lo.release(); c->light_hi.release(); c->d_alias.release();
+  c->d_instances.release(); c->d_emissives.release(); c->d_noise.release();
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int hk_upload_meshes(hk_ctx* c, const HkVertex* v, uint32_t nv, const HkPrimitive* p, uint32_t np, const HkNode* n, uint32_t nn) {
+  HK_REQUIRE(c && v && p && n && nv && np && nn, HK_E_INVALID, "NULL or empty mesh buffers");
+  c->vertices.assign(v, v + nv);
+  c->primitives.assign(p, p + np);
+  c->asset_nodes.assign(n, n + nn);
+  c->have_meshes = true;
+  c->scene_dirty = true;
+  return HK_OK;
+}
+int hk_upload_materials(hk_ctx* c, const HkMaterial* m, uint32_t n) {
+  HK_REQUIRE(c && m && n, HK_E_INVALID, "NULL or empty material buffer");
+  for (uint32_t i = 0; i < n; ++i)
+    HK_REQUIRE(m[i].base_color_texture == HK_NO_TEXTURE && m[i].emissive_texture == HK_NO_TEXTURE && m[i].metallic_roughness_texture == HK_NO_TEXTURE &&
+                   m[i].occlusion_texture == HK_NO_TEXTURE,
+               HK_E_UNSUPPORTED, "material %u references a texture; only the NO_TEXTURE pipelines (light.wgsl:729-747) are implemented", i);
+  c->materials.assign(m, m + n);
+  c->have_materials = true;
+  c->scene_dirty = true;
+  return HK_OK;
+}
+int hk_upload_instances(hk_ctx* c, const HkInstance* inst, uint32_t ni, const HkNode* inodes, uint32_t nin, const HkEmissive* em, uint32_t ne,
+                        const HkNode* enodes, uint32_t nen, const HkAliasEntry* alias, uint32_t na) {
+  HK_REQUIRE(c && inst && inodes && ni && nin, HK_E_INVALID, "NULL or empty instance buffers");
+  HK_REQUIRE((em || !ne) && (enodes || !nen) && (alias || !na), HK_E_INVALID, "NULL emissive buffers");
+  c->instances.assign(inst, inst + ni);
+  c->instance_nodes.assign(inodes, inodes + nin);
+  c->emissives.assign(em, em + ne);
+  c->emissive_nodes.assign(enodes, enodes + nen);
+  c->alias_table.assign(alias, alias + na);
+  c->have_instances = true;
+  c->scene_dirty = true;
+  return HK_OK;
+}
+int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
+  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
+  const HkVertex* v; const HkPrimitive* p; const HkNode *an, *in_, *en; const HkMaterial* m; const HkInstance* inst; const HkEmissive* em; const HkAliasEntry* al;
+  uint32_t nv, np, nan_, nm, ni, nin, ne, nen, nal;
+  int rc;
+  if ((rc = hk_scene_builder_vertices(b, &v, &nv))) return rc;
+  if ((rc = hk_scene_builder_primitives(b, &p, &np))) return rc;
+  if ((rc = hk_scene_builder_asset_nodes(b, &an, &nan_))) return rc;
+  if ((rc = hk_scene_builder_materials(b, &m, &nm))) return rc;
+  if ((rc = hk_scene_builder_instances(b, &inst, &ni))) return rc;
+  if ((rc = hk_scene_builder_instance_nodes(b, &in_, &nin))) return rc;
+  if ((rc = hk_scene_builder_emissives(b, &em, &ne))) return rc;
+  if ((rc = hk_scene_builder_emissive_nodes(b, &en, &nen))) return rc;
+  if ((rc = hk_scene_builder_alias_table(b, &al, &nal))) return rc;
+  if ((rc = hk_upload_meshes(c, v, nv, p, np, an, nan_))) return rc;
+  if ((rc = hk_upload_materials(c, m, nm))) return rc;
+  return hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal);
+}
+int hk_upload_noise(hk_ctx* c, const uint8_t* rgba, size_t bytes) {
+  HK_REQUIRE(c && rgba && bytes == 16u * 64u * 64u * 4u, HK_E_INVALID, "noise must be 16 tiles of 64x64 RGBA8 (262144 bytes)");
+  HK_HIP(hipSetDevice(c->device));
+  std::vector<uint32_t> words(16u * 64u * 64u);
+  memcpy(words.data(), rgba, bytes);
+  int rc = c->d_noise.upload(words);
+  if (rc) return rc;
+  c->scene.noise = c->d_noise.p;
+  c->have_noise = true;
+  return HK_OK;
+}
+
+int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
+  HK_REQUIRE(c && width && height, HK_E_INVALID, "bad size");
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipStreamSynchronize(c->stream));
+  free_screen(c);
+  uint32_t rw, rh;
+  int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
+  if (rc) return rc;
+  c->W = (int)width; c->H = (int)height; c->RW = (int)rw; c->RH = (int)rh;
+  c->ratio = upscale_ratio < 1.0f ? 1.0f : (upscale_ratio > 2.0f ? 2.0f : upscale_ratio);
+  for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
+    size_t n = buffer_is_full_size(b) ? (size_t)c->W * c->H : (size_t)c->RW * c->RH;
+    size_t bytes = n * buffer_bpp(b);
+    HK_HIP(hipMalloc(&c->buf[b], bytes));
+    HK_HIP(hipMemset(c->buf[b], 0, bytes));  // zeroed reservoirs, light.rs:352-360
+    c->buf_bytes[b] = bytes;
+  }
+  HK_HIP(hipDeviceSynchronize());
+  return HK_OK;
+}
+
+int hk_set_view_options(hk_ctx* c, uint32_t taa, uint32_t upscale_kind) {
+  HK_REQUIRE(c && taa <= HK_TAA_NONE && upscale_kind <= HK_UPSCALE_SMAA_TU4X, HK_E_INVALID, "bad argument");
+  c->taa = taa;
+  c->upscale_kind = upscale_kind;
+  return HK_OK;
+}
+
+int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l) {
+  HK_REQUIRE(c && f && v && pv && l, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(f->direct_validate_interval > 0 && f->emissive_validate_interval > 0, HK_E_INVALID, "validate intervals must be > 0");
+  c->frame = *f;
+  c->view = *v;
+  c->pview = *pv;
+  c->lights = *l;
+  c->have_frame = true;
+  return HK_OK;
+}
+
+int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint32_t row_end) {
+  int rc = ready(c);
+  if (rc) return rc;
+  const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
+  const int rows = full_grid ? c->H : c->RH;
+  const int y0 = (int)row_begin, y1 = row_end == 0 ? rows : (int)row_end;
+  HK_REQUIRE(y0 >= 0 && y1 <= rows && y0 <= y1, HK_E_INVALID, "row range [%d,%d) outside 0..%d", y0, y1, rows);
+  return run_pass(c, pass, arg, y0, y1);
+}
+
+int hk_set_band(hk_ctx* c, uint32_t band_index, uint32_t band_count) {
+  HK_REQUIRE(c && band_count > 0 && band_index < band_count, HK_E_INVALID, "bad band");
+  c->band_index = band_index;
+  c->band_count = band_count;
+  return HK_OK;
+}
+
+int hk_band_plan(hk_ctx* c, uint32_t stage, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
+  HK_REQUIRE(c && c->W > 0, HK_E_NOT_READY, "hk_resize has not been called");
+  HK_REQUIRE(c->have_frame, HK_E_NOT_READY, "hk_frame_begin has not been called");
+  return hk_band_plan_for((uint32_t)c->W, (uint32_t)c->H, c->ratio, c->band_index, c->band_count, stage, c->frame.number, st, ops, n_ops);
+}
+
+int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t flags) {
+  int rc = ready(c);
+  if (rc) return rc;
+  HK_REQUIRE(st, HK_E_INVALID, "settings is NULL");
+  HK_REQUIRE(c->band_count <= (uint32_t)c->RH, HK_E_INVALID, "more bands than rows");
+  c->taa = st->taa;
+  c->upscale_kind = st->upscale_kind;
+  uint32_t ub0, ub1;
+  band_rows((uint32_t)c->RH, c->band_index, c->band_count, &ub0, &ub1);
+  const int b0 = (int)ub0, b1 = (int)ub1;
+  auto clampr = [&](int v) { return std::min(std::max(v, 0), c->RH); };
+  const Aprons ap = band_aprons(st);
+  const int den = (int)ap.denoise, sp = (int)ap.spatial;
+#define HK_RUN(pass, arg, y0, y1)                    \
+  do {                                               \
+    int a_ = (y0), b_ = (y1);                        \
+    if (b_ > a_ && (rc = run_pass(c, pass, arg, a_, b_))) return rc; \
+  } while (0)
+  if (stage == HK_STAGE_TEMPORAL) {
+    if (c->timing_mask) {
+      (void)hipEventRecord(c->frame_start, c->stream);
+    }
+    int f0, f1;
+    full_rows_for(c, clampr(b0 - den - sp), clampr(b1 + den + sp), &f0, &f1);
+    if (!(flags & HK_FRAME_EXTERNAL_GBUFFER)) HK_RUN(HK_PASS_PREPASS, 0, f0, f1);
+    int a0, a1;
+    full_rows_for(c, clampr(b0 - den), clampr(b1 + den), &a0, &a1);
+    HK_RUN(HK_PASS_FULL_SCREEN_ALBEDO, 0, a0, a1);  // light.rs:646-653
+    HK_RUN(HK_PASS_DIRECT_LIT, 0, b0, b1);          // light.rs:656-688
+    HK_RUN(HK_PASS_DIRECT_EMISSIVE, 0, b0, b1);
+    HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
+  } else if (stage == HK_STAGE_SPATIAL) {            // light.rs:689-697
+    if (st->emissive_spatial_reuse) HK_RUN(HK_PASS_EMISSIVE_SPATIAL_REUSE, 0, b0, b1);
+    if (st->indirect_spatial_reuse) HK_RUN(HK_PASS_INDIRECT_SPATIAL_REUSE, 0, b0, b1);
+  } else if (stage == HK_STAGE_POST_PROCESS) {
+    if (st->denoise) {                               // post_process.rs:1190-1224
+      const uint32_t nch = st->indirect_bounces == 0 ? 2u : 3u;  // post_process.rs:949-954
+      for (uint32_t ch = 0; ch < nch; ++ch) {
+        HK_RUN(HK_PASS_DEMODULATION, ch, clampr(b0 - 15), clampr(b1 + 15));
+        HK_RUN(HK_PASS_DENOISE_L0, ch, clampr(b0 - 7), clampr(b1 + 7));
+        HK_RUN(HK_PASS_DENOISE_L1, ch, clampr(b0 - 3), clampr(b1 + 3));
+        HK_RUN(HK_PASS_DENOISE_L2, ch, clampr(b0 - 1), clampr(b1 + 1));
+        HK_RUN(HK_PASS_DENOISE_L3, ch, b0, b1);
+      }
+    }
+    HK_RUN(HK_PASS_TONE_MAPPING, st->denoise ? 1u : 0u, b0, b1);  // post_process.rs:1226-1234
+    if (c->timing_mask) {
+      (void)hipEventRecord(c->frame_stop, c->stream);
+      c->frame_timed = true;
+    }
+    c->frames += 1;
+  } else {
+    HK_REQUIRE(false, HK_E_INVALID, "unknown stage %u", stage);
+  }
+#undef HK_RUN
+  return HK_OK;
+}
+
+int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
+  int rc = hk_frame_begin(c, f, v, pv, l);
+  if (rc) return rc;
+  for (uint32_t s = 0; s < HK_STAGE_COUNT; ++s)
+    if ((rc = hk_frame_stage(c, s, st, flags))) return rc;
+  return HK_OK;
+}
+
+int hk_frame_wait(hk_ctx* c) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  return HK_OK;
+}
+
+int hk_buffer_info(hk_ctx* c, uint32_t buffer, uint32_t* w, uint32_t* h, uint32_t* bpp) {
+  HK_REQUIRE(c && buffer < HK_BUF_COUNT && buffer_bpp(buffer), HK_E_INVALID, "bad buffer id");
+  const bool full = buffer_is_full_size(buffer);
+  if (w) *w = (uint32_t)(full ? c->W : c->RW);
+  if (h) *h = (uint32_t)(full ? c->H : c->RH);
+  if (bpp) *bpp = buffer_bpp(buffer);
+  return HK_OK;
+}
+int hk_read_buffer(hk_ctx* c, uint32_t buffer, void* dst, size_t bytes) {
+  HK_REQUIRE(c && dst && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
+  HK_REQUIRE(bytes == c->buf_bytes[buffer], HK_E_INVALID, "size mismatch: buffer has %zu bytes", c->buf_bytes[buffer]);
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipStreamSynchronize(c->stream));
+  HK_HIP(hipMemcpy(dst, c->buf[buffer], bytes, hipMemcpyDeviceToHost));
+  return HK_OK;
+}
+int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
+  HK_REQUIRE(c && src && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
+  HK_REQUIRE(bytes == c->buf_bytes[buffer], HK_E_INVALID, "size mismatch: buffer has %zu bytes", c->buf_bytes[buffer]);
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipStreamSynchronize(c->stream));
+  HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
+  return HK_OK;
+}
+int hk_device_ptr(hk_ctx* c, uint32_t buffer, void** ptr, size_t* bytes) {
+  HK_REQUIRE(c && ptr && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
+  *ptr = c->buf[buffer];
+  if (bytes) *bytes = c->buf_bytes[buffer];
+  return HK_OK;
+}
+int hk_stream(hk_ctx* c, void** s) {
+  HK_REQUIRE(c && s, HK_E_INVALID, "bad argument");
+  *s = (void*)c->stream;
+  return HK_OK;
+}
+int hk_set_timing_mask(hk_ctx* c, uint32_t mask) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  c->timing_mask = mask;
+  return HK_OK;
+}
+int hk_get_stats(hk_ctx* c, HkStats* out) {
+  HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  memset(out, 0, sizeof(*out));
+  unsigned long long h[3] = {0, 0, 0};
+  HK_HIP(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  out->rays_primary = h[0];
+  out->rays_tlas = h[1];
+  out->rays_blas = h[2];
+  out->frames = c->frames;
+  out->last_frame_ms = c->last_frame_ms;
+  for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
+    out->pass_ms_total[i] = c->slot_ms[i];
+    out->pass_launches[i] = c->slot_launches[i];
+  }
+  return HK_OK;
+}
+int hk_reset_stats(hk_ctx* c) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  HK_HIP(hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)));
+  c->frames = 0;
+  for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
+    c->slot_ms[i] = 0.0;
+    c->slot_launches[i] = 0;
+  }
+  return HK_OK;
+}
+
+int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float* out, size_t n) {
+  HK_REQUIRE(c && x && out && op <= 10, HK_E_INVALID, "bad argument");
+  if (n == 0) return HK_OK;
+  HK_HIP(hipSetDevice(c->device));
+  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  HK_HIP(hipMalloc((void**)&dx, n * 4));
+  HK_HIP(hipMalloc((void**)&dout, n * 4));
+  HK_HIP(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  if (y) {
+    HK_HIP(hipMalloc((void**)&dy, n * 4));
+    HK_HIP(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+  }
+  launch_debug_math(c->stream, op, dx, dy, dout, n);
+  HK_HIP(hipStreamSynchronize(c->stream));
+  HK_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(dx);
+  (void)hipFree(dout);
+  if (dy) (void)hipFree(dy);
+  return HK_OK;
+}
+
+}  // extern "C"

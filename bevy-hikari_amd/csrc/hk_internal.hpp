@@ -1,0 +1,39 @@
+// hk_internal.hpp - shared host-side declarations of libhikari_hip.so (not part of the ABI).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/hikari_hip.h"
+
+namespace hk {
+
+void set_error(const char* fmt, ...);
+
+#define HK_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      ::hk::set_error(__VA_ARGS__);  \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+// flat skip-link BVH over n boxes (min xyz, max xyz) in the `bvh` 0.7.1 flatten_custom format
+std::vector<HkNode> build_flat_bvh(const std::vector<float>& boxes_min_max);
+
+// bytes per pixel / full-size flag of an HkBuffer id (0 = invalid id)
+uint32_t buffer_bpp(uint32_t buffer);
+bool buffer_is_full_size(uint32_t buffer);
+
+// rows [b0,b1) of band i of n over `height` rows
+void band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32_t* b0, uint32_t* b1);
+
+// apron rows (in scaled render rows) each stage needs around a band, from the kernel footprints
+struct Aprons {
+  uint32_t spatial;   // rows of temporal reservoirs + G-buffer the spatial stage reads beyond the band
+  uint32_t denoise;   // rows of render/variance the post-process stage reads beyond the band
+};
+Aprons band_aprons(const HkSettings* settings);
+
+}  // namespace hk

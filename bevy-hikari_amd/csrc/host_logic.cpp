@@ -1,0 +1,205 @@
+// host_logic.cpp - host-side mirrors of reference logic that need no GPU:
+//   HikariSettings::default            src/lib.rs:435-455
+//   FrameUniform::extract_component    src/view.rs:125-193
+//   scaled render size                 src/light.rs:318-319,623-624
+//   band partition + halo plan         (this repo's multi-GPU design)
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "hk_internal.hpp"
+
+namespace hk {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+uint32_t buffer_bpp(uint32_t b) {
+  if (b == HK_BUF_POSITION || b == HK_BUF_VELOCITY_UV) return 16;
+  if (b == HK_BUF_NORMAL) return 4;
+  if (b == HK_BUF_DEPTH_GRADIENT || b == HK_BUF_INSTANCE_MATERIAL) return 8;
+  if (b == HK_BUF_ALBEDO) return 8;
+  if (b >= HK_BUF_VARIANCE0 && b < HK_BUF_VARIANCE0 + 3) return 4;
+  if (b >= HK_BUF_RENDER0 && b < HK_BUF_RENDER0 + 3) return 8;
+  if (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10) return 64;
+  if (b >= HK_BUF_DENOISE_INTERNAL0 && b < HK_BUF_DENOISE_INTERNAL0 + 4) return 8;
+  if (b == HK_BUF_DENOISE_INTERNAL_VARIANCE) return 4;
+  if (b >= HK_BUF_DENOISE_RENDER0 && b < HK_BUF_DENOISE_RENDER0 + 3) return 8;
+  if (b == HK_BUF_TONE_MAPPED) return 8;
+  return 0;
+}
+bool buffer_is_full_size(uint32_t b) { return b <= HK_BUF_ALBEDO || (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10); }
+
+void band_rows(uint32_t height, uint32_t i, uint32_t n, uint32_t* b0, uint32_t* b1) {
+  uint32_t base = height / n, rem = height % n;
+  *b0 = i * base + std::min(i, rem);
+  *b1 = *b0 + base + (i < rem ? 1u : 0u);
+}
+
+// Kernel footprints in scaled render rows:
+//  spatial_reuse reads neighbour reservoirs within SPATIAL_REUSE_RANGE px (20 indirect / 10
+//  emissive, light.wgsl:246-252); its depth ray-march taps (light.wgsl:1609-1625) can land one
+//  more row out after truncation, which only concerns the locally ray-cast G-buffer apron.
+//  The four a-trous levels reach 8+4+2+1 = 15 rows (denoise.wgsl:101-114), the variance
+//  prefilter one more (denoise.wgsl:152-160).
+Aprons band_aprons(const HkSettings* st) {
+  Aprons a{0, 0};
+  a.spatial = st->indirect_spatial_reuse ? 21u : (st->emissive_spatial_reuse ? 11u : 0u);  // the dispatch runs regardless of bounces (light.rs:676)
+  a.denoise = st->denoise ? 16 : 0;
+  return a;
+}
+
+}  // namespace hk
+
+using namespace hk;
+
+extern "C" {
+
+uint32_t hk_abi_version(void) { return HK_ABI_VERSION; }
+const char* hk_last_error(void) { return g_error; }
+
+int hk_settings_default(HkSettings* s) {  // lib.rs:435-455
+  HK_REQUIRE(s, HK_E_INVALID, "settings is NULL");
+  memset(s, 0, sizeof(*s));
+  s->direct_validate_interval = 3;
+  s->emissive_validate_interval = 5;
+  s->max_temporal_reuse_count = 50;
+  s->max_spatial_reuse_count = 800;
+  s->max_reservoir_lifetime = 100.0f;
+  s->solar_angle = 0.046f;
+  s->indirect_bounces = 1;
+  s->max_indirect_luminance = 10.0f;
+  s->clear_color[0] = 0.4f;
+  s->clear_color[1] = 0.4f;
+  s->clear_color[2] = 0.4f;
+  s->clear_color[3] = 1.0f;
+  s->temporal_reuse = 1;
+  s->emissive_spatial_reuse = 0;
+  s->indirect_spatial_reuse = 1;
+  s->denoise = 1;
+  s->taa = HK_TAA_JASMINE;
+  s->upscale_kind = HK_UPSCALE_SMAA_TU4X;  // Upscale::SMAA_TU_2_0, lib.rs:491-495
+  s->upscale_ratio = 2.0f;
+  s->upscale_sharpness = 0.0f;
+  return HK_OK;
+}
+
+static float clamp_ratio(float r) { return r < 1.0f ? 1.0f : (r > 2.0f ? 2.0f : r); }  // Upscale::ratio, lib.rs:500-504
+
+int hk_frame_from_settings(const HkSettings* s, uint32_t frame_number, HkFrame* f) {  // view.rs:125-193
+  HK_REQUIRE(s && f, HK_E_INVALID, "NULL argument");
+  memset(f, 0, sizeof(*f));
+  static const float KERNEL[3][3] = {{0.0625f, 0.125f, 0.0625f}, {0.125f, 0.25f, 0.125f}, {0.0625f, 0.125f, 0.0625f}};
+  static const float HALTON[8][4] = {
+      {0.000000f, 0.000000f, 0.500000f, 0.333333f}, {0.250000f, 0.666667f, 0.750000f, 0.111111f},
+      {0.125000f, 0.444444f, 0.625000f, 0.777778f}, {0.375000f, 0.222222f, 0.875000f, 0.555556f},
+      {0.062500f, 0.888889f, 0.562500f, 0.037037f}, {0.312500f, 0.370370f, 0.812500f, 0.703704f},
+      {0.187500f, 0.148148f, 0.687500f, 0.481481f}, {0.437500f, 0.814815f, 0.937500f, 0.259259f}};
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) f->kernel[c][r] = KERNEL[c][r];
+  memcpy(f->halton, HALTON, sizeof(HALTON));
+  memcpy(f->clear_color, s->clear_color, 16);
+  f->number = frame_number;
+  f->direct_validate_interval = s->direct_validate_interval;
+  f->emissive_validate_interval = s->emissive_validate_interval;
+  f->indirect_bounces = s->indirect_bounces;
+  f->temporal_reuse = s->temporal_reuse ? 1u : 0u;
+  f->emissive_spatial_reuse = s->emissive_spatial_reuse ? 1u : 0u;
+  f->indirect_spatial_reuse = s->indirect_spatial_reuse ? 1u : 0u;
+  f->max_temporal_reuse_count = s->max_temporal_reuse_count;
+  f->max_spatial_reuse_count = s->max_spatial_reuse_count;
+  f->max_reservoir_lifetime = s->max_reservoir_lifetime;
+  f->solar_angle = s->solar_angle;
+  f->max_indirect_luminance = s->max_indirect_luminance;
+  f->upscale_ratio = clamp_ratio(s->upscale_ratio);
+  return HK_OK;
+}
+
+int hk_scaled_size(uint32_t width, uint32_t height, float upscale_ratio, uint32_t* sw, uint32_t* sh) {  // light.rs:318-319
+  HK_REQUIRE(sw && sh && width && height, HK_E_INVALID, "bad argument");
+  float scale = 1.0f / clamp_ratio(upscale_ratio);
+  *sw = (uint32_t)ceilf(scale * (float)width);
+  *sh = (uint32_t)ceilf(scale * (float)height);
+  return HK_OK;
+}
+
+int hk_band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32_t* row_begin, uint32_t* row_end) {
+  HK_REQUIRE(row_begin && row_end && band_count > 0 && band_index < band_count && height >= band_count, HK_E_INVALID, "bad band");
+  band_rows(height, band_index, band_count, row_begin, row_end);
+  return HK_OK;
+}
+
+// Rows [lo,hi) of `buffer` are needed by band `band_index`; emit one op per other band that owns a
+// piece of them.
+static void emit(uint32_t buffer, uint32_t width, uint32_t height, uint32_t lo, uint32_t hi, uint32_t band_index, uint32_t band_count,
+                 HkHaloOp* ops, uint32_t* n, uint32_t cap) {
+  for (uint32_t j = 0; j < band_count; ++j) {
+    if (j == band_index) continue;
+    uint32_t o0, o1;
+    band_rows(height, j, band_count, &o0, &o1);
+    uint32_t a = std::max(lo, o0), b = std::min(hi, o1);
+    if (a >= b) continue;
+    if (ops && *n < cap) {
+      ops[*n].buffer = buffer;
+      ops[*n].peer = j;
+      ops[*n].row_begin = a;
+      ops[*n].row_end = b;
+      ops[*n].row_bytes = (uint64_t)width * buffer_bpp(buffer);
+    }
+    *n += 1;
+  }
+}
+
+int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count, uint32_t stage,
+                     uint32_t frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
+  HK_REQUIRE(st && n_ops && band_count > 0 && band_index < band_count && stage < HK_STAGE_COUNT, HK_E_INVALID, "bad argument");
+  uint32_t rw, rh;
+  int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
+  if (rc) return rc;
+  HK_REQUIRE(rh >= band_count, HK_E_INVALID, "more bands than rows");
+  const uint32_t cap = ops ? *n_ops : 0;
+  uint32_t n = 0;
+  uint32_t b0, b1;
+  band_rows(rh, band_index, band_count, &b0, &b1);
+  auto lo = [&](uint32_t a) { return b0 > a ? b0 - a : 0u; };
+  auto hi = [&](uint32_t a) { return std::min(rh, b1 + a); };
+  // reservoir ping-pong, light.rs:376,480-481: the temporal dispatch writes buf[previous + T]
+  const uint32_t previous = 1u - (frame_number % 2u);
+  if (stage == HK_STAGE_SPATIAL) {
+    // reservoirs are allocated at full width (light.rs:344) but indexed with the scaled width
+    // (light.wgsl:1061): a "row" of the exchange is rw reservoirs
+    if (st->emissive_spatial_reuse) {
+      uint32_t buf = HK_BUF_RESERVOIR0 + previous + 2;
+      emit(buf, rw, rh, lo(10), hi(10), band_index, band_count, ops, &n, cap);
+    }
+    if (st->indirect_spatial_reuse) {
+      uint32_t buf = HK_BUF_RESERVOIR0 + previous + 6;
+      emit(buf, rw, rh, lo(20), hi(20), band_index, band_count, ops, &n, cap);
+    }
+  } else if (stage == HK_STAGE_POST_PROCESS) {
+    if (st->denoise) {
+      uint32_t nch = st->indirect_bounces == 0 ? 2u : 3u;  // post_process.rs:949-954
+      for (uint32_t ch = 0; ch < nch; ++ch) {
+        emit(HK_BUF_RENDER0 + ch, rw, rh, lo(15), hi(15), band_index, band_count, ops, &n, cap);
+        emit(HK_BUF_VARIANCE0 + ch, rw, rh, lo(16), hi(16), band_index, band_count, ops, &n, cap);
+      }
+    }
+  }
+  if (ops && n > cap) {
+    *n_ops = n;
+    HK_REQUIRE(false, HK_E_INVALID, "ops array too small: need %u", n);
+  }
+  *n_ops = n;
+  return HK_OK;
+}
+
+}  // extern "C"

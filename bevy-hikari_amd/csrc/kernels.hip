@@ -1,0 +1,799 @@
+// kernels.hip - the compute dispatches of the path as HIP kernels for gfx950.
+//
+// One kernel per reference entry point; the shader-def specialisations of the
+// reference (light.rs:139-152, post_process.rs:409-423) are template parameters here.
+//   k_prepass            prepass.wgsl:40-100 semantics by primary rays (no rasteriser in HIP)
+//   k_full_screen_albedo light.wgsl:1019-1042
+//   k_direct_lit         light.wgsl:1044-1261   <EMISSIVE_LIT>
+//   k_indirect           light.wgsl:1263-1498   <MULTIPLE_BOUNCES>
+//   k_spatial_reuse      light.wgsl:1503-1684   <EMISSIVE_LIT>
+//   k_demodulation       denoise.wgsl:135-162
+//   k_denoise            denoise.wgsl:215-319   <LEVEL, FIREFLY_FILTERING>
+//   k_tone_mapping       tone_mapping.wgsl:21-32
+//
+// Thread mapping: the reference dispatches 8x8 workgroups = one wave64 per tile.  Here a
+// workgroup is 256 threads = four 8x8 wave tiles arranged 2x2 (16x16 pixels), so every wave still
+// owns a compact 8x8 tile (coherent rays, coalesced 8-pixel row segments) while a CU gets four
+// waves per workgroup slot.  Workgroup ids are remapped so that the tiles an XCD receives
+// (dispatcher: block b -> XCD b % 8) form a contiguous range of the image and neighbouring tiles
+// share that XCD's L2 for the gather passes.
+#include <hip/hip_runtime.h>
+
+#include "hk_device.hpp"
+#include "hk_kernels.hpp"
+
+namespace hkd {
+
+struct Pixel { int x, y; bool valid; };
+
+__device__ __forceinline__ Pixel pixel_of_thread(int width, int row_begin, int row_end) {
+  const int tiles_x = (width + 15) >> 4;
+  // XCD-aware remap of the linear workgroup id
+  const uint32_t nb = gridDim.x;
+  uint32_t b = blockIdx.x;
+  const uint32_t per = nb >> 3;
+  if (per > 0 && b < per * 8u) b = (b & 7u) * per + (b >> 3);
+  const int tile_x = (int)(b % (uint32_t)tiles_x), tile_y = (int)(b / (uint32_t)tiles_x);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Pixel p;
+  p.x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+  p.y = row_begin + tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  p.valid = p.x < width && p.y < row_end;
+  return p;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(const RayCounters& rc, uint32_t primary, unsigned long long* counters) {
+  if (!COUNT) return;
+  uint32_t a = rc.tlas, b = rc.blas, c = primary;
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_down(a, off);
+    b += __shfl_down(b, off);
+    c += __shfl_down(c, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (c) atomicAdd(&counters[0], (unsigned long long)c);
+    if (a) atomicAdd(&counters[1], (unsigned long long)a);
+    if (b) atomicAdd(&counters[2], (unsigned long long)b);
+  }
+}
+
+// ------------------------------------------------------------------ prepass by primary rays
+struct PrepassParams {
+  float4 ivp0, ivp1, ivp2, ivp3;  // inverse_view_proj columns
+  float4 vp0, vp1, vp2, vp3;      // view_proj columns
+  float4 pvp0, pvp1, pvp2, pvp3;  // previous view_proj columns
+  float jitter_x, jitter_y;       // NDC shift of the geometry (prepass.wgsl:52-54,71)
+};
+__device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams& pp, float px, float py) {
+  float ndc_x = (px + 0.5f) / (float)fr.dw * 2.0f - 1.0f - pp.jitter_x;
+  float ndc_y = 1.0f - (py + 0.5f) / (float)fr.dh * 2.0f - pp.jitter_y;
+  f4 pn = mul(pp.ivp0, pp.ivp1, pp.ivp2, pp.ivp3, F4(ndc_x, ndc_y, 1.0f, 1.0f));
+  f3 near_point = xyz(pn) / pn.w;
+  Ray ray;
+  if (fr.is_ortho) {
+    ray.origin = near_point;
+    ray.direction = -normalize(F3(fr.ortho_x, fr.ortho_y, fr.ortho_z));
+  } else {
+    ray.origin = F3(fr.cam_x, fr.cam_y, fr.cam_z);
+    ray.direction = normalize(near_point - ray.origin);
+  }
+  ray.inv_direction = 1.0f / ray.direction;
+  return ray;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_prepass(DScene sc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
+                                                  unsigned long long* counters) {
+  const Pixel px = pixel_of_thread(fr.dw, row_begin, row_end);
+  RayCounters rc{0, 0};
+  uint32_t primary = 0;
+  if (px.valid) {
+    const int idx = px.x + fr.dw * px.y;
+    Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
+    Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+    rc.tlas = 0;  // counted as a primary ray
+    primary = 1;
+    if (hit.instance_index == HK_U32_MAX) {
+      g.position[idx] = make_float4(0, 0, 0, 0);
+      g.normal[idx] = 0u;
+      g.depth_gradient[idx] = make_float2(0, 0);
+      g.instance_material[idx] = make_float2(0, 0);
+      g.velocity_uv[idx] = make_float4(0, 0, 0, 0);
+    } else {
+      const DInstance& in = sc.instances[hit.instance_index];
+      const float4 q0 = sc.tri_v0[hit.primitive_index], q1 = sc.tri_v1[hit.primitive_index], q2 = sc.tri_v2[hit.primitive_index];
+      const uint32_t i0 = in.vertex + f2u(q0.w), i1 = in.vertex + f2u(q1.w), i2 = in.vertex + f2u(q2.w);
+      const f2 b = hit.uv;
+      const f3 world_position = ray.origin + ray.direction * hit.distance;
+      const f4 clip = mul(pp.vp0, pp.vp1, pp.vp2, pp.vp3, F4(world_position, 1.0f));
+      const float depth = clip.z / clip.w;
+      const f3 n0 = local_to_world_normal(in, xyz(sc.vtx_normal[i0]));
+      const f3 n1 = local_to_world_normal(in, xyz(sc.vtx_normal[i1]));
+      const f3 n2 = local_to_world_normal(in, xyz(sc.vtx_normal[i2]));
+      const f3 wn = n0 + b.x * (n1 - n0) + b.y * (n2 - n0);
+      const float2 t0 = sc.vtx_uv[i0], t1 = sc.vtx_uv[i1], t2 = sc.vtx_uv[i2];
+      const f2 uv = F2(t0.x, t0.y) + b.x * (F2(t1.x, t1.y) - F2(t0.x, t0.y)) + b.y * (F2(t2.x, t2.y) - F2(t0.x, t0.y));
+      const f3 p0 = local_to_world_position(in, xyz(q0));
+      const f3 p1 = local_to_world_position(in, xyz(q1));
+      const f3 p2 = local_to_world_position(in, xyz(q2));
+      const f3 ng = cross(p1 - p0, p2 - p0);
+      float grad[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        Ray rn = primary_ray(fr, pp, (float)px.x + (k == 0 ? 1.0f : 0.0f), (float)px.y + (k == 1 ? 1.0f : 0.0f));
+        float tn = dot(ng, p0 - rn.origin) / dot(ng, rn.direction);
+        f3 wp = rn.origin + rn.direction * tn;
+        f4 cn = mul(pp.vp0, pp.vp1, pp.vp2, pp.vp3, F4(wp, 1.0f));
+        grad[k] = cn.z / cn.w - depth;
+      }
+      const f2 velocity = clip_to_uv(clip) - clip_to_uv(mul(pp.pvp0, pp.pvp1, pp.pvp2, pp.pvp3, F4(world_position, 1.0f)));
+      g.position[idx] = make_float4(world_position.x, world_position.y, world_position.z, depth);
+      g.normal[idx] = pack4x8snorm(F4(wn, 1.0f));
+      g.depth_gradient[idx] = make_float2(grad[0], grad[1]);
+      g.instance_material[idx] = make_float2((float)hit.instance_index + 0.5f, (float)in.material + 0.5f);
+      g.velocity_uv[idx] = make_float4(velocity.x, velocity.y, uv.x, uv.y);
+    }
+  }
+  flush_counters<COUNT>(rc, primary, counters);
+}
+
+// ------------------------------------------------------------------ full_screen_albedo
+__global__ __launch_bounds__(256) void k_full_screen_albedo(DScene sc, DFrame fr, GBuffer g, uint2* __restrict__ albedo, int row_begin, int row_end) {
+  const Pixel px = pixel_of_thread(fr.dw, row_begin, row_end);
+  if (!px.valid) return;
+  const int idx = px.x + fr.dw * px.y;
+  const float4 position_depth = g.position[idx];
+  if (position_depth.w < HK_F32_EPSILON) {
+    albedo[idx] = make_uint2(0u, 0u);
+    return;
+  }
+  const f3 normal = xyz(unpack4x8snorm(g.normal[idx]));
+  const uint32_t material = f32_to_u32(g.instance_material[idx].y);
+  Surface surface = retreive_surface(sc, material);
+  f3 view_direction = calculate_view(fr, xyz(position_depth));
+  albedo[idx] = pack_f16x4(F4(env_brdf(view_direction, normal, surface), 1.0f));
+}
+
+// ------------------------------------------------------------------ direct_lit
+template <bool EMISSIVE_LIT, bool COUNT>
+__global__ __launch_bounds__(256) void k_direct_lit(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+                                                     unsigned long long* counters) {
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  RayCounters rc{0, 0};
+  if (px.valid) {
+    const int x = px.x, y = px.y;
+    const int index = x + fr.rw * y;
+    const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+    Sample s = zero_sample();
+    int dcx, dcy;
+    jittered_deferred_coords(fr, uv, &dcx, &dcy);
+    const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh);
+    const int didx = dcx + fr.dw * dcy;
+    const float4 position_depth = din ? g.position[didx] : make_float4(0, 0, 0, 0);
+    const f3 position = xyz(position_depth);
+    const float depth = position_depth.w;
+
+    if (depth < HK_F32_EPSILON) {  // light.wgsl:1058-1069
+      Reservoir r = zero_reservoir();
+      set_reservoir(r, s, 0.0f);
+      const PackedReservoir pr = pack_reservoir(r);
+      store_packed(t.current, index, pr);
+      store_packed(t.spatial, index, pr);
+      store_packed(t.previous_spatial, index, pr);
+      t.variance[index] = 0.0f;
+      t.render[index] = make_uint2(0u, 0u);
+    } else {
+      const f3 normal = xyz(unpack4x8snorm(g.normal[didx]));
+      const float2 imf = g.instance_material[didx];
+      const uint32_t im_x = f32_to_u32(imf.x), im_y = f32_to_u32(imf.y);
+      const float4 velocity_uv = g.velocity_uv[didx];
+
+      s.random = noise_fetch(sc, x, y, fr.number);
+      s.random = fract(s.random + fr.number_golden);
+      s.visible_position = F4(position, depth);
+      s.visible_normal = normal;
+      s.visible_instance = im_x;
+
+      Ray ray;
+      ray.origin = F3(0, 0, 0); ray.direction = F3(0, 0, 0); ray.inv_direction = F3(0, 0, 0);
+      HitInfo info = empty_hit_info(F3(0, 0, 0), F3(0, 0, 0));
+      info.position = F4(0, 0, 0, 0); info.instance_index = 0u; info.material_index = 0u;  // WGSL zero-init
+
+      const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
+      Reservoir r = load_reservoir_uv(t.previous, previous_uv, fr.rw, fr.rh);
+      const bool prev_on_screen = fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f;
+      const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
+
+      if (!check_previous_reservoir(r, s) && prev_on_screen) store_packed(t.previous_spatial, previous_index, pack_reservoir(r));
+
+      const uint32_t validate_interval = EMISSIVE_LIT ? fr.emissive_validate_interval : fr.direct_validate_interval;
+      const uint32_t select_light_instance = EMISSIVE_LIT ? im_x : HK_DONT_SAMPLE_EMISSIVE;
+      const bool validation_frame = (fr.number % validate_interval) == 0u;
+
+      if (!validation_frame || r.count < 4.0f) {  // light.wgsl:1108-1153
+        LightCandidate candidate = select_light_candidate(sc, fr, s.random, xyz(s.visible_position), s.visible_normal, select_light_instance, info, rc);
+        ray.origin = position + normal * HK_RAY_BIAS;
+        ray.direction = candidate.direction;
+        ray.inv_direction = 1.0f / ray.direction;
+        bool trace_condition = dot(candidate.direction, normal) > 0.0f;
+        trace_condition = trace_condition && candidate.p > 0.0f;
+        if (EMISSIVE_LIT) trace_condition = trace_condition && candidate.emissive_instance != HK_DONT_SAMPLE_EMISSIVE;
+        if (trace_condition) {
+          Hit hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+          occlude_hit_info(ray, hit, info);
+          s.radiance = EMISSIVE_LIT ? input_radiance(sc, fr, ray, info, false, candidate.emissive_instance, false)
+                                    : input_radiance(sc, fr, ray, info, true, HK_DONT_SAMPLE_EMISSIVE, false);
+        }
+        s.sample_position = info.position;
+        s.sample_normal = info.normal;
+        float w_new = (candidate.p > 0.0f) ? luminance(xyz(s.radiance)) / candidate.p : 0.0f;
+        temporal_restir(r, s, w_new, fr.max_temporal_reuse_count);
+      }
+
+      if (validation_frame) {  // light.wgsl:1156-1214
+        LightCandidate candidate = select_light_candidate(sc, fr, r.s.random, xyz(r.s.visible_position), r.s.visible_normal, select_light_instance, info, rc);
+        ray.origin = xyz(s.visible_position) + s.visible_normal * HK_RAY_BIAS;
+        ray.direction = normalize(xyz(r.s.sample_position) - xyz(s.visible_position));
+        ray.inv_direction = 1.0f / ray.direction;
+        f4 validate_radiance = F4(0, 0, 0, 0);
+        bool trace_condition = dot(candidate.direction, r.s.visible_normal) > 0.0f;
+        trace_condition = trace_condition && candidate.p > 0.0f;
+        if (EMISSIVE_LIT) trace_condition = trace_condition && candidate.emissive_instance != HK_DONT_SAMPLE_EMISSIVE;
+        if (trace_condition) {
+          Hit hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+          occlude_hit_info(ray, hit, info);
+          validate_radiance = EMISSIVE_LIT ? input_radiance(sc, fr, ray, info, false, candidate.emissive_instance, false)
+                                           : input_radiance(sc, fr, ray, info, true, HK_DONT_SAMPLE_EMISSIVE, false);
+        }
+        if (r.count >= 4.0f) {
+          s.random = r.s.random;
+          s.sample_position = info.position;
+          s.sample_normal = info.normal;
+          s.radiance = validate_radiance;
+        }
+        float luminance_ratio = luminance(xyz(validate_radiance)) / fmax_(luminance(xyz(r.s.radiance)), 0.0001f);
+        if (luminance_ratio > 1.25f || luminance_ratio < 0.8f) {
+          if (prev_on_screen) store_packed(t.previous_spatial, previous_index, pack_reservoir(r));
+          float w_new = (candidate.p > 0.0f) ? luminance(xyz(s.radiance)) / candidate.p : 0.0f;
+          set_reservoir(r, s, w_new);
+        }
+      }
+
+      float total_lum = r.count * luminance(xyz(r.s.radiance));
+      r.w = (total_lum > 0.0f) ? r.w_sum / total_lum : 0.0f;
+      r.s.visible_position = s.visible_position;
+      r.s.visible_normal = s.visible_normal;
+      r.lifetime += 1.0f;
+
+      t.variance[index] = reservoir_variance(r);
+      if (fr.temporal_reuse > 0u) store_packed(t.current, index, pack_reservoir(r));
+
+      Surface surface = retreive_surface(sc, im_y);
+      f3 view_direction = calculate_view(fr, position);
+      f3 out_radiance = shading(fr, view_direction, r.s.visible_normal, normalize(xyz(r.s.sample_position) - xyz(r.s.visible_position)), surface, r.s.radiance);
+      out_radiance = out_radiance * r.w;
+      f3 out_color = EMISSIVE_LIT ? out_radiance : out_radiance + compute_emissive_radiance(surface.emissive);
+      t.render[index] = pack_f16x4(F4(out_color, 1.0f));
+    }
+  }
+  flush_counters<COUNT>(rc, 0, counters);
+}
+
+// ------------------------------------------------------------------ indirect_lit_ambient
+template <bool MULTIPLE_BOUNCES, bool COUNT>
+__global__ __launch_bounds__(256) void k_indirect(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+                                                   unsigned long long* counters) {
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  RayCounters rc{0, 0};
+  if (px.valid) {
+    const int x = px.x, y = px.y;
+    const int index = x + fr.rw * y;
+    const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+    int dcx, dcy;
+    jittered_deferred_coords(fr, uv, &dcx, &dcy);
+    const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh);
+    const int didx = dcx + fr.dw * dcy;
+    const float4 position_depth = din ? g.position[didx] : make_float4(0, 0, 0, 0);
+    const f3 position = xyz(position_depth);
+    const float depth = position_depth.w;
+
+    Sample s = zero_sample();
+    Reservoir r = zero_reservoir();
+
+    if (fr.indirect_bounces == 0u || depth < HK_F32_EPSILON) {  // light.wgsl:1279-1287
+      const PackedReservoir pr = pack_reservoir(r);
+      store_packed(t.current, index, pr);
+      store_packed(t.spatial, index, pr);
+      store_packed(t.previous_spatial, index, pr);
+      t.variance[index] = 0.0f;
+      t.render[index] = make_uint2(0u, 0u);
+    } else {
+      const f3 normal = normalize(xyz(unpack4x8snorm(g.normal[didx])));
+      const float2 imf = g.instance_material[didx];
+      const uint32_t im_x = f32_to_u32(imf.x), im_y = f32_to_u32(imf.y);
+      const float4 velocity_uv = g.velocity_uv[didx];
+
+      s.random = noise_fetch(sc, x, y, fr.number);
+      s.random = fract(s.random + fr.number_golden);
+      s.visible_position = F4(position, depth);
+      s.visible_normal = normal;
+      s.visible_instance = im_x;
+
+      Ray ray;
+      float pdf = 0.0f;
+      Surface surface;
+
+      if (MULTIPLE_BOUNCES) {  // light.wgsl:1309-1394
+        Sample bounce_sample = s;
+        f3 color_transport = F3(1.0f, 1.0f, 1.0f);
+        for (uint32_t n = 0u; n < fr.indirect_bounces && (color_transport.x > 0.01f || color_transport.y > 0.01f || color_transport.z > 0.01f); n += 1u) {
+          f4 rand_sample = sample_cosine_hemisphere(F2(bounce_sample.random.x, bounce_sample.random.y));
+          ray.origin = xyz(bounce_sample.visible_position) + bounce_sample.visible_normal * HK_RAY_BIAS;
+          ray.direction = mul(normal_basis(bounce_sample.visible_normal), xyz(rand_sample));
+          ray.inv_direction = 1.0f / ray.direction;
+
+          Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+          HitInfo info = hit_info(sc, ray, hit);
+
+          if (n == 0u) {
+            s.sample_position = info.position;
+            s.sample_normal = info.normal;
+            pdf = rand_sample.w;
+          }
+          bounce_sample.sample_position = info.position;
+          bounce_sample.sample_normal = info.normal;
+
+          if (hit.instance_index != HK_U32_MAX) {
+            f3 out_radiance = F3(0, 0, 0);
+            surface = retreive_surface(sc, info.material_index);
+            surface.roughness = 1.0f;
+            const uint32_t info_instance = info.instance_index;
+            LightCandidate candidate = select_light_candidate(sc, fr, bounce_sample.random, xyz(bounce_sample.sample_position),
+                                                              bounce_sample.sample_normal, info_instance, info, rc);
+            const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
+            const f3 bounce_view_direction = normalize(xyz(bounce_sample.visible_position) - xyz(bounce_sample.sample_position));
+
+            if (dot(candidate.direction, bounce_sample.sample_normal) > 0.0f && candidate.p > 0.0f) {
+              ray.origin = xyz(bounce_sample.sample_position) + bounce_sample.sample_normal * HK_RAY_BIAS;
+              ray.direction = candidate.direction;
+              ray.inv_direction = 1.0f / ray.direction;
+              hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+              occlude_hit_info(ray, hit, info);
+              f4 in_radiance = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
+              out_radiance = shading(fr, bounce_view_direction, bounce_sample.sample_normal, ray.direction, surface, in_radiance);
+              out_radiance = out_radiance / candidate.p;
+              if (n > 0u) out_radiance = (rand_sample.w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample.w;
+              float out_luminance = luminance(out_radiance);
+              if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
+              s.radiance = s.radiance + F4(color_transport * out_radiance, 1.0f);
+            }
+            color_transport = color_transport * env_brdf(bounce_view_direction, bounce_sample.sample_normal, surface);
+            bounce_sample.random = fract(bounce_sample.random + fr.number_golden);
+            bounce_sample.visible_position = bounce_sample.sample_position;
+            bounce_sample.visible_normal = bounce_sample.sample_normal;
+          } else {
+            f3 out_radiance = xyz(input_radiance(sc, fr, ray, info, false, HK_DONT_SAMPLE_EMISSIVE, true));
+            s.radiance = s.radiance + F4(color_transport * out_radiance, 0.0f);
+            break;
+          }
+        }
+      } else {  // light.wgsl:1395-1450
+        f4 rand_sample = sample_cosine_hemisphere(F2(s.random.x, s.random.y));
+        ray.origin = xyz(s.visible_position) + s.visible_normal * HK_RAY_BIAS;
+        ray.direction = mul(normal_basis(s.visible_normal), xyz(rand_sample));
+        ray.inv_direction = 1.0f / ray.direction;
+        Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+        HitInfo info = hit_info(sc, ray, hit);
+        s.sample_position = info.position;
+        s.sample_normal = info.normal;
+        pdf = rand_sample.w;
+        if (hit.instance_index != HK_U32_MAX) {
+          f3 out_radiance = F3(0, 0, 0);
+          surface = retreive_surface(sc, info.material_index);
+          surface.roughness = 1.0f;
+          const uint32_t info_instance = info.instance_index;
+          LightCandidate candidate = select_light_candidate(sc, fr, s.random, xyz(s.sample_position), s.sample_normal, info_instance, info, rc);
+          const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
+          if (dot(candidate.direction, s.sample_normal) > 0.0f && candidate.p > 0.0f) {
+            ray.origin = xyz(s.sample_position) + s.sample_normal * HK_RAY_BIAS;
+            ray.direction = candidate.direction;
+            ray.inv_direction = 1.0f / ray.direction;
+            hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+            occlude_hit_info(ray, hit, info);
+            f4 in_radiance = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
+            out_radiance = shading(fr, normalize(xyz(s.visible_position) - xyz(s.sample_position)), s.sample_normal, ray.direction, surface, in_radiance);
+            out_radiance = out_radiance / candidate.p;
+            s.radiance = s.radiance + F4(out_radiance, 1.0f);
+          }
+        } else {
+          f3 out_radiance = xyz(input_radiance(sc, fr, ray, info, false, HK_DONT_SAMPLE_EMISSIVE, true));
+          s.radiance = s.radiance + F4(out_radiance, 0.0f);
+        }
+      }
+
+      // ReSTIR: temporal, light.wgsl:1452-1497
+      const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
+      r = load_reservoir_uv(t.previous, previous_uv, fr.rw, fr.rh);
+      if (!check_previous_reservoir(r, s) && fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f) {
+        const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
+        store_packed(t.previous_spatial, previous_index, pack_reservoir(r));
+      }
+      surface = retreive_surface(sc, im_y);
+      const f3 view_direction = calculate_view(fr, position);
+      f3 sample_radiance = shading(fr, view_direction, s.visible_normal, normalize(xyz(s.sample_position) - xyz(s.visible_position)), surface, s.radiance);
+      float w_new = (pdf > 0.0f) ? luminance(sample_radiance) / pdf : 0.0f;
+      temporal_restir(r, s, w_new, fr.max_temporal_reuse_count);
+
+      f3 out_radiance = shading(fr, view_direction, r.s.visible_normal, normalize(xyz(r.s.sample_position) - xyz(r.s.visible_position)), surface, r.s.radiance);
+      float total_lum = r.count * luminance(out_radiance);
+      r.w = (total_lum > 0.0f) ? r.w_sum / total_lum : 0.0f;
+      r.s.visible_position = s.visible_position;
+      r.s.visible_normal = s.visible_normal;
+      r.lifetime += 1.0f;
+
+      t.variance[index] = reservoir_variance(r);
+      if (fr.temporal_reuse > 0u) store_packed(t.current, index, pack_reservoir(r));
+      t.render[index] = pack_f16x4(F4(out_radiance * r.w, 1.0f));
+    }
+  }
+  flush_counters<COUNT>(rc, 0, counters);
+}
+
+// ------------------------------------------------------------------ spatial_reuse
+// The reference caches the workgroup's own 8x8 reservoirs + depths in workgroup memory
+// (light.wgsl:1500-1501,1522-1524,1584-1591); the cached values are exactly what the buffer
+// loads return, so reading neighbours from L2 is result-identical.
+template <bool EMISSIVE_LIT>
+__global__ __launch_bounds__(256) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end) {
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  if (!px.valid) return;
+  constexpr uint32_t SPATIAL_REUSE_COUNT = EMISSIVE_LIT ? 8u : 16u;
+  constexpr float SPATIAL_REUSE_RANGE = EMISSIVE_LIT ? 10.0f : 20.0f;
+  const int x = px.x, y = px.y;
+  const int index = x + fr.rw * y;
+  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  int dcx, dcy;
+  jittered_deferred_coords(fr, uv, &dcx, &dcy);
+  const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh);
+  const int didx = dcx + fr.dw * dcy;
+  const float4 position_depth = din ? g.position[didx] : make_float4(0, 0, 0, 0);
+  const f3 position = xyz(position_depth);
+  const float depth = position_depth.w;
+
+  Reservoir r = unpack_reservoir(load_packed(t.current, index));
+  if (depth < HK_F32_EPSILON) {
+    store_packed(t.spatial, index, pack_reservoir(r));
+    t.render[index] = make_uint2(0u, 0u);
+    return;
+  }
+  const uint32_t im_y = f32_to_u32(g.instance_material[didx].y);
+  const float4 velocity_uv = g.velocity_uv[didx];
+  const Surface surface = retreive_surface(sc, im_y);
+  const bool use_spatial_variance = r.count <= 4.0f;
+  const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
+
+  Reservoir q = r;
+  const Sample s = q.s;
+  const float max_lifetime = (fr.max_reservoir_lifetime <= 1.0f) ? HK_F32_MAX : fr.max_reservoir_lifetime;  // light.wgsl:913-915
+  if (r.lifetime <= max_lifetime) r = load_reservoir_uv(t.previous_spatial, previous_uv, fr.rw, fr.rh);
+
+  const f3 view_direction = calculate_view(fr, position);
+  if (EMISSIVE_LIT) {
+    merge_reservoir(r, q, luminance(xyz(q.s.radiance)));
+  } else {
+    f3 out_radiance = shading(fr, view_direction, s.visible_normal, normalize(xyz(s.sample_position) - xyz(s.visible_position)), surface, s.radiance);
+    merge_reservoir(r, q, luminance(out_radiance));
+  }
+  r.s.visible_position = s.visible_position;
+  r.s.visible_normal = s.visible_normal;
+
+  const float rot = dot(s.random, F4(1.0f, 1.0f, 1.0f, 1.0f));
+  for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
+    const float angle = HK_TAU * fract((float)i * HK_GOLDEN_RATIO + rot + fr.random_float_number);
+    const float radius = sqrtf((float)i / (float)SPATIAL_REUSE_COUNT) * SPATIAL_REUSE_RANGE;
+    float sn, cs;
+    sincos_(angle, &sn, &cs);
+    const f2 offset = radius * F2(cs, sn);
+
+    const int scx = f32_to_i32(offset.x + (float)x), scy = f32_to_i32(offset.y + (float)y);
+    const f2 sample_uv = coords_to_uv(scx, scy, fr.rw, fr.rh);
+    if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
+    int sdx, sdy;
+    jittered_deferred_coords(fr, sample_uv, &sdx, &sdy);
+    const float sample_depth = in_bounds(sdx, sdy, fr.dw, fr.dh) ? g.position[sdx + fr.dw * sdy].w : 0.0f;
+
+    const float depth_ratio = depth / sample_depth;
+    if (depth_ratio < 0.9f || depth_ratio > 1.1f) continue;
+
+    q = unpack_reservoir(load_packed(t.current, scx + fr.rw * scy));
+    const bool normal_miss = dot(s.visible_normal, q.s.visible_normal) < 0.866f;
+    if (q.count < HK_F32_EPSILON || normal_miss) continue;
+
+    const f3 sample_direction = normalize(xyz(q.s.sample_position) - xyz(s.visible_position));
+    if (dot(sample_direction, s.visible_normal) < 0.0f) continue;
+
+    const float tap_interval = fmax_(1.0f, radius / 5.0f);
+    const uint32_t tap_count = f32_to_u32(radius / tap_interval);
+    bool occluded = false;
+    const f2 dir = normalize(offset);
+    for (uint32_t j = 1u; j <= tap_count; j += 1u) {
+      const float tap_dist = (float)j * tap_interval;
+      const f2 tap_offset = tap_dist * dir;
+      const f2 tap_uv = uv + tap_offset / F2((float)fr.rw, (float)fr.rh);
+      int tdx, tdy;
+      jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
+      const float tap_depth = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.position[tdx + fr.dw * tdy].w : 0.0f;
+      const float ref_depth = mix(depth, sample_depth, (float)j / (float)(tap_count + 1u));
+      if (tap_depth > ref_depth + 0.00001f) {
+        occluded = true;
+        break;
+      }
+    }
+    if (occluded) continue;
+
+    const float jacobian = (q.s.sample_position.w > 0.5f) ? compute_jacobian(q.s, s) : 1.0f;
+    if (EMISSIVE_LIT) {
+      merge_reservoir(r, q, luminance(xyz(q.s.radiance)) / jacobian);
+    } else {
+      f3 out_radiance = shading(fr, view_direction, s.visible_normal, sample_direction, surface, q.s.radiance);
+      merge_reservoir(r, q, luminance(out_radiance) / jacobian);
+    }
+  }
+
+  const float m = (float)fr.max_spatial_reuse_count;
+  if (r.count > m) {
+    r.w_sum *= m / r.count;
+    r.w2_sum *= m / r.count;
+    r.count = m;
+  }
+  const f3 out_radiance = shading(fr, view_direction, s.visible_normal, normalize(xyz(r.s.sample_position) - xyz(s.visible_position)), surface, r.s.radiance);
+  const float total_lum = EMISSIVE_LIT ? r.count * luminance(xyz(r.s.radiance)) : r.count * luminance(out_radiance);
+  r.w = (total_lum > 0.0f) ? r.w_sum / total_lum : 0.0f;
+  r.lifetime += 1.0f;
+  store_packed(t.spatial, index, pack_reservoir(r));
+  if (use_spatial_variance) t.variance[index] = reservoir_variance(r);
+  t.render[index] = pack_f16x4(F4(r.w * out_radiance, 1.0f));
+}
+
+// ------------------------------------------------------------------ denoise
+__global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:135-162
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  if (!px.valid) return;
+  const int x = px.x, y = px.y, index = x + fr.rw * y;
+  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
+  int ax, ay, rx, ry;
+  nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
+  const f3 albedo = xyz(unpack_f16x4(d.albedo[ax + fr.dw * ay]));
+  nearest_coords(uv, fr.rw, fr.rh, &rx, &ry);
+  f3 irradiance = xyz(unpack_f16x4(d.render[rx + fr.rw * ry]));
+  const f3 qd = irradiance / albedo;
+  irradiance = F3(albedo.x < 0.01f ? 0.0f : qd.x, albedo.y < 0.01f ? 0.0f : qd.y, albedo.z < 0.01f ? 0.0f : qd.z);
+  d.output[index] = pack_f16x4(F4(irradiance, 1.0f));  // internal_texture_0
+
+  float sum_variance = 0.0f;
+#pragma unroll
+  for (int ox = -1; ox <= 1; ++ox) {
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy) {  // call order of denoise.wgsl:152-160: x outer, y inner
+      const f2 sample_uv = uv + F2((float)ox, (float)oy) / F2((float)fr.rw, (float)fr.rh);
+      if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
+      int sx, sy;
+      nearest_coords(sample_uv, fr.rw, fr.rh, &sx, &sy);
+      const float variance = d.variance[sx + fr.rw * sy];
+      if (variance > HK_F32_MAX) continue;
+      sum_variance += fr.kernel[(oy + 1) * 3 + (ox + 1)] * fmax_(variance, 0.0f);
+    }
+  }
+  d.internal_variance[index] = sum_variance;
+}
+
+template <int LEVEL, bool FIREFLY>
+__global__ __launch_bounds__(256) void k_denoise(DFrame fr, GBuffer g, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:164-319
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  if (!px.valid) return;
+  constexpr int STEP = 8 >> LEVEL;
+  const int x = px.x, y = px.y, index = x + fr.rw * y;
+  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
+  int dx, dy;
+  nearest_coords(deferred_uv, fr.dw, fr.dh, &dx, &dy);
+  const int didx = dx + fr.dw * dy;
+  const float depth = g.position[didx].w;
+  if (depth < HK_F32_EPSILON) {
+    d.output[index] = make_uint2(0u, 0u);
+    return;
+  }
+  const float2 dg = g.depth_gradient[didx];
+  const f2 depth_gradient = F2(dg.x, dg.y);
+  const f3 normal = normalize(xyz(unpack4x8snorm(g.normal[didx])));
+  const float instance = g.instance_material[didx].x;
+  const float variance = d.internal_variance[index];
+  f3 irradiance = xyz(unpack_f16x4(d.input[index]));
+  f3 sum_irradiance = irradiance * fr.kernel[4];
+  float sum_w = fr.kernel[4];
+  if (any_is_nan(irradiance) || irradiance.x > HK_F32_MAX || irradiance.y > HK_F32_MAX || irradiance.z > HK_F32_MAX) {
+    irradiance = F3(0, 0, 0);
+    sum_irradiance = F3(0, 0, 0);
+    sum_w = 0.0f;
+  }
+  const float lum = luminance(irradiance);
+  const float lum_denominator = 4.0f * pow_(variance, 0.25f) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
+  float ff_moment_1 = 0.0f, ff_moment_2 = 0.0f, ff_count = 0.0f;
+
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    constexpr int OX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    constexpr int OY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    const int ox = OX[k], oy = OY[k];
+    const int sx = x + ox * STEP, sy = y + oy * STEP;
+    const f2 sample_uv = coords_to_uv(sx, sy, fr.rw, fr.rh);
+    if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
+    const f2 sample_deferred_uv = jittered_deferred_uv(fr, sample_uv, 0.5f);
+    const f3 irr = xyz(unpack_f16x4(d.input[sx + fr.rw * sy]));
+    if (any_is_nan(irr) || irr.x > HK_F32_MAX || irr.y > HK_F32_MAX || irr.z > HK_F32_MAX) continue;
+    int gx, gy;
+    nearest_coords(sample_deferred_uv, fr.dw, fr.dh, &gx, &gy);
+    const int gidx = gx + fr.dw * gy;
+    const f3 sample_normal = normalize(xyz(unpack4x8snorm(g.normal[gidx])));
+    const float sample_depth = g.position[gidx].w;
+    const float sample_instance = g.instance_material[gidx].x;
+    const float sample_luminance = luminance(irr);
+
+    const float w_normal = pow_(fmax_(0.0f, dot(normal, sample_normal)), 16.0f);
+    const float w_depth = exp_((-fabsf(depth - sample_depth)) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
+    const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - sample_instance));
+    const float w_luminance = exp_((-fabsf(lum - sample_luminance)) / lum_denominator);
+    const float w = clamp_(w_normal * w_depth * w_instance * w_luminance, 0.0f, 1.0f) * fr.kernel[(oy + 1) * 3 + (ox + 1)];
+    sum_irradiance = sum_irradiance + irr * w;
+    sum_w += w;
+    if (FIREFLY) {
+      ff_moment_1 += sample_luminance;
+      ff_moment_2 += sample_luminance * sample_luminance;
+      ff_count += 1.0f;
+    }
+  }
+  const f3 qd = sum_irradiance / sum_w;
+  irradiance = (sum_w < 0.0001f) ? F3(0, 0, 0) : qd;
+  if (FIREFLY) {
+    const float ff_mean = ff_moment_1 / ff_count;
+    const float ff_var = ff_moment_2 / ff_count - ff_mean * ff_mean;
+    if (lum > ff_mean + 3.0f * sqrtf(ff_var)) irradiance = ff_mean / lum * irradiance;
+  }
+  f4 color = F4(irradiance, 1.0f);
+  if (LEVEL == 3) {
+    int ax, ay;
+    nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
+    color = color * unpack_f16x4(d.albedo[ax + fr.dw * ay]);
+  }
+  d.output[index] = pack_f16x4(color);
+}
+
+__global__ __launch_bounds__(256) void k_tone_mapping(DFrame fr, const uint2* __restrict__ direct, const uint2* __restrict__ emissive,
+                                                       const uint2* __restrict__ indirect, uint2* __restrict__ out, int row_begin, int row_end) {  // tone_mapping.wgsl:21-32
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  if (!px.valid) return;
+  const int index = px.x + fr.rw * px.y;
+  f4 color = unpack_f16x4(direct[index]);
+  color = color + unpack_f16x4(emissive[index]);
+  if (indirect) color = color + unpack_f16x4(indirect[index]);
+  const f3 c = F3(fmax_(color.x, 0.0039f), fmax_(color.y, 0.0039f), fmax_(color.z, 0.0039f));
+  const float l_old = dot(c, F3(0.2126f, 0.7152f, 0.0722f));  // bevy_core_pipeline 0.9.1 reinhard_luminance
+  const float l_new = l_old / (1.0f + l_old);
+  const f3 rgb = c * (l_new / l_old);
+  f4 o = F4(rgb, color.w);
+  if (!(color.w > 0.0f)) o = F4(fr.clear_r, fr.clear_g, fr.clear_b, fr.clear_a);
+  out[index] = pack_f16x4(o);
+}
+
+__global__ void k_debug_math(uint32_t op, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = x[i], b = y ? y[i] : 0.0f, r = 0.0f;
+  switch (op) {
+    case 0: r = sin_(a); break;
+    case 1: r = cos_(a); break;
+    case 2: r = exp_(a); break;
+    case 3: r = exp2_(a); break;
+    case 4: r = log2_(a); break;
+    case 5: r = pow_(a, b); break;
+    case 6: r = fmin_(a, b); break;
+    case 7: r = fmax_(a, b); break;
+    case 8: r = f16_to_f32(f32_to_f16(a)); break;
+    case 9: r = a / b; break;
+    case 10: r = sqrtf(a); break;
+    default: break;
+  }
+  out[i] = r;
+}
+
+}  // namespace hkd
+
+// ------------------------------------------------------------------ host launchers
+namespace hk {
+using namespace hkd;
+
+static inline dim3 grid_for(int width, int rows) {
+  int tiles_x = (width + 15) / 16, tiles_y = (rows + 15) / 16;
+  return dim3((unsigned)(tiles_x * tiles_y), 1, 1);
+}
+
+void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj,
+                    const float* prev_view_proj, float jitter_x, float jitter_y, const GBuffer& g, int y0, int y1, unsigned long long* counters) {
+  if (y1 <= y0) return;
+  PrepassParams pp;
+  auto col = [](const float* m, int c) { return make_float4(m[4 * c], m[4 * c + 1], m[4 * c + 2], m[4 * c + 3]); };
+  pp.ivp0 = col(inverse_view_proj, 0); pp.ivp1 = col(inverse_view_proj, 1); pp.ivp2 = col(inverse_view_proj, 2); pp.ivp3 = col(inverse_view_proj, 3);
+  pp.vp0 = col(view_proj, 0); pp.vp1 = col(view_proj, 1); pp.vp2 = col(view_proj, 2); pp.vp3 = col(view_proj, 3);
+  pp.pvp0 = col(prev_view_proj, 0); pp.pvp1 = col(prev_view_proj, 1); pp.pvp2 = col(prev_view_proj, 2); pp.pvp3 = col(prev_view_proj, 3);
+  pp.jitter_x = jitter_x;
+  pp.jitter_y = jitter_y;
+  dim3 grid = grid_for(fr.dw, y1 - y0);
+  if (counters)
+    hipLaunchKernelGGL(k_prepass<true>, grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+  else
+    hipLaunchKernelGGL(k_prepass<false>, grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+}
+void launch_albedo(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, void* albedo, int y0, int y1) {
+  if (y1 <= y0) return;
+  hipLaunchKernelGGL(k_full_screen_albedo, grid_for(fr.dw, y1 - y0), dim3(256), 0, st, sc, fr, g, (uint2*)albedo, y0, y1);
+}
+void launch_direct(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1,
+                   unsigned long long* counters) {
+  if (y1 <= y0) return;
+  dim3 grid = grid_for(fr.rw, y1 - y0);
+  if (emissive_lit) {
+    if (counters) hipLaunchKernelGGL((k_direct_lit<true, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+    else hipLaunchKernelGGL((k_direct_lit<true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+  } else {
+    if (counters) hipLaunchKernelGGL((k_direct_lit<false, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+    else hipLaunchKernelGGL((k_direct_lit<false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+  }
+}
+void launch_indirect(hipStream_t st, bool multiple_bounces, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1,
+                     unsigned long long* counters) {
+  if (y1 <= y0) return;
+  dim3 grid = grid_for(fr.rw, y1 - y0);
+  if (multiple_bounces) {
+    if (counters) hipLaunchKernelGGL((k_indirect<true, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+    else hipLaunchKernelGGL((k_indirect<true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+  } else {
+    if (counters) hipLaunchKernelGGL((k_indirect<false, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+    else hipLaunchKernelGGL((k_indirect<false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+  }
+}
+void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1) {
+  if (y1 <= y0) return;
+  dim3 grid = grid_for(fr.rw, y1 - y0);
+  if (emissive_lit) hipLaunchKernelGGL(k_spatial_reuse<true>, grid, dim3(256), 0, st, sc, fr, g, t, y0, y1);
+  else hipLaunchKernelGGL(k_spatial_reuse<false>, grid, dim3(256), 0, st, sc, fr, g, t, y0, y1);
+}
+void launch_demodulation(hipStream_t st, const DFrame& fr, const DenoiseTargets& d, int y0, int y1) {
+  if (y1 <= y0) return;
+  hipLaunchKernelGGL(k_demodulation, grid_for(fr.rw, y1 - y0), dim3(256), 0, st, fr, d, y0, y1);
+}
+void launch_denoise(hipStream_t st, int level, bool firefly, const DFrame& fr, const GBuffer& g, const DenoiseTargets& d, int y0, int y1) {
+  if (y1 <= y0) return;
+  dim3 grid = grid_for(fr.rw, y1 - y0);
+#define HK_DN(L)                                                                                             \
+  if (firefly) hipLaunchKernelGGL((k_denoise<L, true>), grid, dim3(256), 0, st, fr, g, d, y0, y1);            \
+  else hipLaunchKernelGGL((k_denoise<L, false>), grid, dim3(256), 0, st, fr, g, d, y0, y1);
+  switch (level) {
+    case 0: HK_DN(0) break;
+    case 1: HK_DN(1) break;
+    case 2: HK_DN(2) break;
+    default: HK_DN(3) break;
+  }
+#undef HK_DN
+}
+void launch_tone_mapping(hipStream_t st, const DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1) {
+  if (y1 <= y0) return;
+  hipLaunchKernelGGL(k_tone_mapping, grid_for(fr.rw, y1 - y0), dim3(256), 0, st, fr, (const uint2*)direct, (const uint2*)emissive,
+                     (const uint2*)indirect, (uint2*)out, y0, y1);
+}
+void launch_debug_math(hipStream_t st, uint32_t op, const float* x, const float* y, float* out, size_t n) {
+  hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, x, y, out, n);
+}
+
+}  // namespace hk

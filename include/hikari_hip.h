@@ -1,0 +1,414 @@
+/*
+ * hikari_hip.h - C ABI of libhikari_hip.so, the MI355X-native (HIP / gfx950) replacement for the
+ * compute path of cryscan/bevy-hikari v0.3.15 (reference paths below are relative to that repo).
+ *
+ * What this boundary replaces
+ * ---------------------------
+ * In the reference the path sits behind three Bevy render-graph nodes that record wgpu compute /
+ * raster work:  PrepassNode::run (src/prepass.rs:769-852), LightNode::run (src/light.rs:590-702)
+ * and PostProcessNode::run (src/post_process.rs:1140-1234, denoise + tone mapping part).  Their
+ * inputs are the storage buffers written in the Prepare stage (src/mesh_material/mesh.rs:43-64,
+ * material.rs:139-203, instance.rs:82-108), the noise images (src/lib.rs:189-219) and the four
+ * dynamic uniforms (src/prepass.rs:546-553).  A Rust `HikariPlugin` keeps all of that host code
+ * and calls the functions below instead of creating wgpu pipelines (see INTEGRATION.md for the
+ * `extern "C"` block).
+ *
+ * Conventions
+ * -----------
+ *  - plain C, no C++/torch types; every function returns HK_OK (0) or a negative HK_E* code and
+ *    never throws.  The reference's nodes silently return Ok(()) when a resource is missing
+ *    (light.rs:606-617); here the same situation is reported as HK_E_NOT_READY and nothing runs.
+ *  - the library owns all device memory.  Host arrays passed to hk_upload_* are copied before
+ *    the call returns.
+ *  - one hk_ctx is bound to one HIP device and is used from one host thread at a time (Bevy runs
+ *    the render graph sequentially on the render thread).  All kernels are enqueued on the
+ *    context's HIP stream; hk_frame_wait() is the only synchronisation point.
+ *  - Hk* data structs are byte-for-byte the std430 / std140 layouts the reference writes with
+ *    encase (src/mesh_material/mod.rs:60-299, src/view.rs:105-123) so the Rust side can hand over
+ *    its existing buffers unchanged.  Conversion to the device layout happens inside hk_upload_*.
+ */
+#ifndef HIKARI_HIP_H
+#define HIKARI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HK_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ error codes */
+#define HK_OK 0
+#define HK_E_INVALID (-1)    /* bad argument (NULL, size mismatch, out-of-range enum) */
+#define HK_E_NO_DEVICE (-2)  /* no HIP device / device id out of range */
+#define HK_E_HIP (-3)        /* a HIP runtime call failed; see hk_last_error() */
+#define HK_E_NOT_READY (-4)  /* scene / noise / size / uniforms not uploaded yet */
+#define HK_E_NOMEM (-5)
+#define HK_E_UNSUPPORTED (-6)
+
+/* ------------------------------------------------------------------ scene data (std430) */
+
+/* mesh_material_types.wgsl:3-8, mod.rs:67-73 (GpuVertexCompact), 32 B */
+typedef struct HkVertex {
+  float position[3];
+  float u;
+  float normal[3];
+  float v;
+} HkVertex;
+
+/* mesh_material_types.wgsl:10-17, mod.rs:115-145 (GpuPrimitiveCompact), 48 B */
+typedef struct HkPrimitiveVertex {
+  float position[3];
+  uint32_t index;
+} HkPrimitiveVertex;
+typedef struct HkPrimitive {
+  HkPrimitiveVertex vertices[3];
+} HkPrimitive;
+
+/* mesh_material_types.wgsl:35-40, mod.rs:177-201 (GpuNode), 32 B.
+ * Skip-link flat BVH node.  entry_index >= 0x80000000 marks a leaf (low bits = shape index);
+ * leaf boxes are EMPTY (min=+inf, max=-inf) exactly as `bvh` 0.7.1 flatten_custom emits them. */
+typedef struct HkNode {
+  float min[3];
+  uint32_t entry_index;
+  float max[3];
+  uint32_t exit_index;
+} HkNode;
+#define HK_BVH_LEAF_FLAG 0x80000000u
+
+/* mesh_material_types.wgsl:19-23, mod.rs:469-476 (GpuMeshIndex), 16 B */
+typedef struct HkMeshIndex {
+  uint32_t vertex;
+  uint32_t primitive;
+  uint32_t node_offset;
+  uint32_t node_count;
+} HkMeshIndex;
+
+/* mesh_material_types.wgsl:25-33, mod.rs:147-156 (GpuInstance), 176 B. Matrices column-major. */
+typedef struct HkInstance {
+  float min[3];
+  uint32_t material;
+  float max[3];
+  uint32_t node_index;
+  float model[16];
+  float inverse_transpose_model[16];
+  HkMeshIndex mesh;
+} HkInstance;
+
+/* mesh_material_types.wgsl:42-56, mod.rs:203-218 (GpuStandardMaterial), 80 B */
+typedef struct HkMaterial {
+  float base_color[4];
+  uint32_t base_color_texture;
+  uint32_t _pad0[3];
+  float emissive[4];
+  uint32_t emissive_texture;
+  float perceptual_roughness;
+  float metallic;
+  uint32_t metallic_roughness_texture;
+  float reflectance;
+  uint32_t normal_map_texture;
+  uint32_t occlusion_texture;
+  uint32_t _pad1;
+} HkMaterial;
+#define HK_NO_TEXTURE 0xFFFFFFFFu
+
+/* mesh_material_types.wgsl:58-61, mod.rs:220-226, 8 B */
+typedef struct HkAliasEntry {
+  float prob;
+  uint32_t index;
+} HkAliasEntry;
+
+/* mesh_material_types.wgsl:63-71, mod.rs:228-237 (GpuEmissive), 64 B */
+typedef struct HkEmissive {
+  float emissive[4];
+  float position[3];
+  float radius;
+  uint32_t instance;
+  uint32_t _pad0;
+  uint32_t alias_table[2]; /* x = offset, y = count */
+  float surface_area;
+  uint32_t node_index;
+  uint32_t _pad1[2];
+} HkEmissive;
+
+/* ------------------------------------------------------------------ uniforms */
+
+/* mesh_view_types.wgsl:3-20, view.rs:105-123 (FrameUniform), std140: 244 B -> 256 B */
+typedef struct HkFrame {
+  float kernel[3][4]; /* mat3x3, each column padded to vec4 */
+  float halton[8][4];
+  float clear_color[4];
+  uint32_t number;
+  uint32_t direct_validate_interval;
+  uint32_t emissive_validate_interval;
+  uint32_t indirect_bounces;
+  uint32_t temporal_reuse;
+  uint32_t emissive_spatial_reuse;
+  uint32_t indirect_spatial_reuse;
+  uint32_t max_temporal_reuse_count;
+  uint32_t max_spatial_reuse_count;
+  float max_reservoir_lifetime;
+  float solar_angle;
+  float max_indirect_luminance;
+  float upscale_ratio;
+  uint32_t _pad[3];
+} HkFrame;
+
+/* bevy_pbr 0.9.1 `View` uniform (bevy_pbr::mesh_view_types; used at light.wgsl:721-724,1040 and
+ * prepass.wgsl:45,71,96).  Matrices column-major. 416 B. */
+typedef struct HkView {
+  float view_proj[16];
+  float inverse_view_proj[16];
+  float view[16];
+  float inverse_view[16];
+  float projection[16];
+  float inverse_projection[16];
+  float world_position[3];
+  float _pad0;
+  float viewport[4]; /* x, y, width, height in physical pixels */
+} HkView;
+
+/* mesh_view_types.wgsl:22-25, view.rs:31-35 (PreviousViewUniform), 128 B */
+typedef struct HkPreviousView {
+  float view_proj[16];
+  float inverse_view_proj[16];
+} HkPreviousView;
+
+/* The three fields of bevy_pbr 0.9.1 `Lights` the path reads (light.wgsl:611,832,847-855):
+ * directional_lights[0].{color, direction_to_light} and ambient_color.  With no directional light
+ * bevy zero-fills entry 0; pass n_directional_lights = 0 and zeros to reproduce that. */
+typedef struct HkLights {
+  float directional_color[4];
+  float direction_to_light[3];
+  uint32_t n_directional_lights;
+  float ambient_color[4];
+} HkLights;
+
+/* HikariSettings (src/lib.rs:400-455), field for field.  hk_settings_default() fills the
+ * reference defaults (lib.rs:435-455). */
+typedef enum HkTaa { HK_TAA_JASMINE = 0, HK_TAA_NONE = 1 } HkTaa;           /* lib.rs:466-472 */
+typedef enum HkUpscaleKind { HK_UPSCALE_FSR1 = 0, HK_UPSCALE_SMAA_TU4X = 1 } HkUpscaleKind; /* lib.rs:474-487 */
+typedef struct HkSettings {
+  uint32_t direct_validate_interval;
+  uint32_t emissive_validate_interval;
+  uint32_t max_temporal_reuse_count;
+  uint32_t max_spatial_reuse_count;
+  float max_reservoir_lifetime;
+  float solar_angle;
+  uint32_t indirect_bounces;
+  float max_indirect_luminance;
+  float clear_color[4];
+  uint32_t temporal_reuse;
+  uint32_t emissive_spatial_reuse;
+  uint32_t indirect_spatial_reuse;
+  uint32_t denoise;
+  uint32_t taa;           /* HkTaa */
+  uint32_t upscale_kind;  /* HkUpscaleKind */
+  float upscale_ratio;    /* clamped to [1,2] like Upscale::ratio(), lib.rs:500-504 */
+  float upscale_sharpness;
+} HkSettings;
+
+/* ------------------------------------------------------------------ buffers & passes */
+
+/* Screen-space resources (group 1, 5, 6 of the light pipeline and group 3/4 of the denoise
+ * pipeline: deferred_bindings.wgsl:3-20, light.wgsl:26-31,68-75, denoise.wgsl:10-28). Formats are
+ * the reference's texture formats flattened row-major (prepass.rs:43-47, light.rs:29-31,
+ * post_process.rs:29): rgba32f = 16 B, rgba8snorm = 4 B, rg32f = 8 B, rgba16f = 8 B, r32f = 4 B,
+ * PackedReservoir = 64 B (light.wgsl:35-43). */
+typedef enum HkBuffer {
+  HK_BUF_POSITION = 0,          /* rgba32f, full size: world xyz, w = clip depth (0 = background) */
+  HK_BUF_NORMAL = 1,            /* rgba8snorm, full */
+  HK_BUF_DEPTH_GRADIENT = 2,    /* rg32f, full */
+  HK_BUF_INSTANCE_MATERIAL = 3, /* rg32f (id + 0.5), full */
+  HK_BUF_VELOCITY_UV = 4,       /* rgba32f, full */
+  HK_BUF_ALBEDO = 5,            /* rgba16f, full */
+  HK_BUF_VARIANCE0 = 6,         /* r32f, scaled; +channel (0 sun, 1 emissive, 2 indirect) */
+  HK_BUF_RENDER0 = 9,           /* rgba16f, scaled; +channel */
+  HK_BUF_RESERVOIR0 = 12,       /* 64 B x full W*H; +k, k in 0..9 (light.rs:342-363) */
+  HK_BUF_DENOISE_INTERNAL0 = 22,/* rgba16f, scaled; +level 0..3 */
+  HK_BUF_DENOISE_INTERNAL_VARIANCE = 26, /* r32f, scaled */
+  HK_BUF_DENOISE_RENDER0 = 27,  /* rgba16f, scaled; +channel */
+  HK_BUF_TONE_MAPPED = 30,      /* rgba16f, scaled (tone_mapping.wgsl:21-32) */
+  HK_BUF_COUNT = 31
+} HkBuffer;
+
+/* One compute dispatch of the reference.  `arg` selects the render channel for
+ * the denoise passes and the a-trous level is part of the pass id. */
+typedef enum HkPass {
+  HK_PASS_PREPASS = 0,             /* prepass.wgsl:40-100 semantics, produced by primary rays */
+  HK_PASS_FULL_SCREEN_ALBEDO = 1,  /* light.wgsl:1019-1042 */
+  HK_PASS_DIRECT_LIT = 2,          /* light.wgsl:1044-1261, RENDER_EMISSIVE (sun) */
+  HK_PASS_DIRECT_EMISSIVE = 3,     /* light.wgsl:1044-1261, EMISSIVE_LIT */
+  HK_PASS_INDIRECT = 4,            /* light.wgsl:1263-1498; MULTIPLE_BOUNCES iff bounces >= 2 (light.rs:663-666) */
+  HK_PASS_EMISSIVE_SPATIAL_REUSE = 5, /* light.wgsl:1503-1684, EMISSIVE_LIT */
+  HK_PASS_INDIRECT_SPATIAL_REUSE = 6, /* light.wgsl:1503-1684 */
+  HK_PASS_DEMODULATION = 7,        /* denoise.wgsl:135-162; arg = channel */
+  HK_PASS_DENOISE_L0 = 8,          /* denoise.wgsl:215-319; arg = channel; +level 0..3 */
+  HK_PASS_DENOISE_L1 = 9,
+  HK_PASS_DENOISE_L2 = 10,
+  HK_PASS_DENOISE_L3 = 11,
+  HK_PASS_TONE_MAPPING = 12,       /* tone_mapping.wgsl:21-32 */
+  HK_PASS_COUNT = 13
+} HkPass;
+
+/* Frame stages for band-sharded (multi-GPU) rendering: the host exchanges halo rows between
+ * stages (hk_band_plan).  A single-GPU frame is the three stages back to back. */
+typedef enum HkStage {
+  HK_STAGE_TEMPORAL = 0,     /* prepass (+apron), albedo, direct_lit x2, indirect on the band */
+  HK_STAGE_SPATIAL = 1,      /* spatial_reuse dispatches that are enabled */
+  HK_STAGE_POST_PROCESS = 2, /* demodulation + a-trous x4 per channel, tone mapping */
+  HK_STAGE_COUNT = 3
+} HkStage;
+
+/* One halo transfer the host must perform BEFORE running `stage`: rows [row_begin,row_end) of
+ * `buffer` (row = `row_bytes` bytes at device offset row*row_bytes) travel from the rank that owns
+ * them to this rank.  peer = band index of the owner. */
+typedef struct HkHaloOp {
+  uint32_t buffer;     /* HkBuffer */
+  uint32_t peer;       /* band index (= rank) that owns the rows */
+  uint32_t row_begin;
+  uint32_t row_end;
+  uint64_t row_bytes;
+} HkHaloOp;
+
+#define HK_TIMING_SLOTS 16
+typedef struct HkStats {
+  uint64_t rays_primary;      /* G-buffer rays */
+  uint64_t rays_tlas;         /* traverse_top invocations (light.wgsl:442) */
+  uint64_t rays_blas;         /* stand-alone traverse_bottom invocations (light.wgsl:687) */
+  uint64_t frames;
+  /* HIP-event timing on the context's stream.  Slot = HkPass id.  Only passes selected by
+   * hk_set_timing_mask() (all, with HK_CTX_TIME_PASSES) are bracketed by events. */
+  double pass_ms_total[HK_TIMING_SLOTS];
+  uint64_t pass_launches[HK_TIMING_SLOTS];
+  float last_frame_ms;        /* first dispatch of TEMPORAL .. last dispatch of POST_PROCESS */
+  uint32_t _pad;
+} HkStats;
+
+typedef struct hk_ctx hk_ctx;
+
+/* ------------------------------------------------------------------ lifetime */
+uint32_t hk_abi_version(void);
+const char* hk_last_error(void); /* thread-local description of the last failure */
+int hk_device_count(int* count);
+/* Creates a context on HIP device `device_id`; flags: bit0 = count rays (HK_CTX_COUNT_RAYS),
+ * bit1 = time every dispatch with HIP events (HK_CTX_TIME_PASSES). */
+#define HK_CTX_COUNT_RAYS 1u
+#define HK_CTX_TIME_PASSES 2u
+int hk_create(int device_id, uint32_t flags, hk_ctx** out);
+void hk_destroy(hk_ctx* ctx);
+
+/* ------------------------------------------------------------------ host-side mirrors of reference logic (no GPU needed) */
+int hk_settings_default(HkSettings* out);                                        /* lib.rs:435-455 */
+/* FrameUniform::extract_component, view.rs:141-193 (+ KERNEL / HALTON consts view.rs:125-139) */
+int hk_frame_from_settings(const HkSettings* settings, uint32_t frame_number, HkFrame* out);
+/* scaled render size = ceil(size / ratio), light.rs:318-319,623-624 */
+int hk_scaled_size(uint32_t width, uint32_t height, float upscale_ratio, uint32_t* sw, uint32_t* sh);
+
+/* Scene builder: the Prepare-stage host work of the reference, re-implemented in C++.
+ *   add_mesh      -> TryFrom<Mesh> for GpuMesh, mod.rs:379-467 (triangle list / strip rules,
+ *                    BLAS via `bvh` 0.7.1 BVH::build + flatten_custom(GpuNode::pack))
+ *   add_material  -> material.rs:168-199 (values are passed through unchanged)
+ *   add_instance  -> instance.rs:286-325 (world AABB from the 8 transformed half-extent corners)
+ *   finish        -> mesh.rs:106-166 (concatenate + offsets), instance.rs:352-428 (TLAS, emissive
+ *                    list, per-instance alias tables mod.rs:330-376, light BVH)
+ * Arrays returned by the getters stay valid until the builder is destroyed. */
+typedef struct hk_scene_builder hk_scene_builder;
+#define HK_TOPOLOGY_TRIANGLE_LIST 0u
+#define HK_TOPOLOGY_TRIANGLE_STRIP 1u
+int hk_scene_builder_create(hk_scene_builder** out);
+void hk_scene_builder_destroy(hk_scene_builder* b);
+int hk_scene_builder_add_mesh(hk_scene_builder* b, const float* positions, const float* normals, const float* uvs,
+                              uint32_t n_vertices, const uint32_t* indices, uint32_t n_indices, uint32_t topology,
+                              uint32_t* mesh_id);
+int hk_scene_builder_add_material(hk_scene_builder* b, const HkMaterial* material, uint32_t* material_id);
+int hk_scene_builder_add_instance(hk_scene_builder* b, uint32_t mesh_id, uint32_t material_id,
+                                  const float transform[16], uint32_t* instance_id);
+int hk_scene_builder_finish(hk_scene_builder* b);
+int hk_scene_builder_vertices(const hk_scene_builder* b, const HkVertex** p, uint32_t* n);
+int hk_scene_builder_primitives(const hk_scene_builder* b, const HkPrimitive** p, uint32_t* n);
+int hk_scene_builder_asset_nodes(const hk_scene_builder* b, const HkNode** p, uint32_t* n);
+int hk_scene_builder_materials(const hk_scene_builder* b, const HkMaterial** p, uint32_t* n);
+int hk_scene_builder_instances(const hk_scene_builder* b, const HkInstance** p, uint32_t* n);
+int hk_scene_builder_instance_nodes(const hk_scene_builder* b, const HkNode** p, uint32_t* n);
+int hk_scene_builder_emissives(const hk_scene_builder* b, const HkEmissive** p, uint32_t* n);
+int hk_scene_builder_emissive_nodes(const hk_scene_builder* b, const HkNode** p, uint32_t* n);
+int hk_scene_builder_alias_table(const hk_scene_builder* b, const HkAliasEntry** p, uint32_t* n);
+
+/* ------------------------------------------------------------------ uploads (Prepare stage) */
+/* MeshRenderAssets::set + write_buffer, mesh.rs:43-64 (3 global buffers) */
+int hk_upload_meshes(hk_ctx* ctx, const HkVertex* vertices, uint32_t n_vertices, const HkPrimitive* primitives,
+                     uint32_t n_primitives, const HkNode* asset_nodes, uint32_t n_asset_nodes);
+/* MaterialRenderAssets, material.rs:201-202 */
+int hk_upload_materials(hk_ctx* ctx, const HkMaterial* materials, uint32_t n_materials);
+/* InstanceRenderAssets::set + write_buffer, instance.rs:82-108 */
+int hk_upload_instances(hk_ctx* ctx, const HkInstance* instances, uint32_t n_instances, const HkNode* instance_nodes,
+                        uint32_t n_instance_nodes, const HkEmissive* emissives, uint32_t n_emissives,
+                        const HkNode* emissive_nodes, uint32_t n_emissive_nodes, const HkAliasEntry* alias_table,
+                        uint32_t n_alias);
+/* convenience: the three uploads above from a finished builder */
+int hk_upload_scene(hk_ctx* ctx, const hk_scene_builder* b);
+/* NoiseTextures, lib.rs:189-219,515-598: 16 tiles of 64x64 RGBA8, tile-major */
+int hk_upload_noise(hk_ctx* ctx, const uint8_t* rgba, size_t bytes);
+/* prepare_light_textures / prepare_prepass_textures / post-process textures: (re)allocate all
+ * screen-space resources and ZERO the 10 reservoir buffers (light.rs:307-383). */
+int hk_resize(hk_ctx* ctx, uint32_t width, uint32_t height, float upscale_ratio);
+
+/* ------------------------------------------------------------------ per-frame */
+/* the four dynamic uniforms of bind group 0 (prepass.rs:546-553) */
+/* TAA / upscale variant that selects the prepass sub-pixel jitter (prepass.rs:489-490,
+ * prepass.wgsl:30-38); hk_frame_stage sets it from HkSettings, hk_pass_run uses the last value. */
+int hk_set_view_options(hk_ctx* ctx, uint32_t taa, uint32_t upscale_kind);
+int hk_frame_begin(hk_ctx* ctx, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
+                   const HkLights* lights);
+/* One dispatch over rows [row_begin,row_end) of its grid (row_end = 0 means "all rows").  The
+ * reservoir ping-pong (light.rs:376,480-481,518-546) follows frame.number of hk_frame_begin. */
+int hk_pass_run(hk_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, uint32_t row_end);
+/* The node order of the reference for the band of this context (whole image by default):
+ *   TEMPORAL     = PrepassNode::run + LightNode::run up to and including the temporal dispatches
+ *   SPATIAL      = the spatial_reuse dispatches of LightNode::run (light.rs:689-697)
+ *   POST_PROCESS = PostProcessNode::run denoise loop + tone mapping (post_process.rs:1190-1234)
+ * flags bit0: the G-buffer was supplied by the host (hk_write_buffer), skip the primary-ray prepass. */
+#define HK_FRAME_EXTERNAL_GBUFFER 1u
+int hk_frame_stage(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, uint32_t flags);
+/* hk_frame_begin + the three stages (single GPU / no halo exchange) */
+int hk_frame_render(hk_ctx* ctx, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
+                    const HkLights* lights, const HkSettings* settings, uint32_t flags);
+int hk_frame_wait(hk_ctx* ctx);
+
+/* ------------------------------------------------------------------ band sharding (multi-GPU) */
+/* Restrict this context to band `band_index` of `band_count` horizontal bands of the render image
+ * (bands are contiguous row ranges, remainder rows spread over the first bands). */
+int hk_set_band(hk_ctx* ctx, uint32_t band_index, uint32_t band_count);
+int hk_band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32_t* row_begin, uint32_t* row_end);
+/* Halo transfers that must complete before `stage` runs on this context.  Pure host logic.
+ * ops may be NULL to query the count. */
+int hk_band_plan(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, HkHaloOp* ops, uint32_t* n_ops);
+/* Same plan without a context (used by hosts that only schedule): */
+int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count,
+                     uint32_t stage, uint32_t frame_number, const HkSettings* settings, HkHaloOp* ops, uint32_t* n_ops);
+
+/* ------------------------------------------------------------------ buffer access */
+int hk_buffer_info(hk_ctx* ctx, uint32_t buffer, uint32_t* width, uint32_t* height, uint32_t* bytes_per_pixel);
+/* synchronous copies (wait for the stream first) */
+int hk_read_buffer(hk_ctx* ctx, uint32_t buffer, void* dst, size_t bytes);
+int hk_write_buffer(hk_ctx* ctx, uint32_t buffer, const void* src, size_t bytes);
+/* raw device pointer for zero-copy views (halo exchange through RCCL / torch.distributed) */
+int hk_device_ptr(hk_ctx* ctx, uint32_t buffer, void** ptr, size_t* bytes);
+int hk_stream(hk_ctx* ctx, void** hip_stream);
+/* bit i set = bracket every dispatch of HkPass i with HIP events (see HkStats) */
+int hk_set_timing_mask(hk_ctx* ctx, uint32_t pass_mask);
+int hk_get_stats(hk_ctx* ctx, HkStats* out);
+int hk_reset_stats(hk_ctx* ctx);
+
+/* Test hook: evaluate one of the library's device math routines elementwise (op: 0 sin, 1 cos,
+ * 2 exp, 3 exp2, 4 log2, 5 pow(x, y), 6 min(x,y), 7 max(x,y), 8 f32->f16->f32, 9 x/y, 10 sqrt).
+ * x, y, out are HOST arrays. */
+int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIKARI_HIP_H */
