@@ -1,0 +1,249 @@
+"""ctypes binding of the C ABI in include/hikari_hip.h.
+
+This is the stub a host language binds (INTEGRATION.md shows the Rust `extern "C"` equivalent).
+The structs are field-for-field the ones in the header; `Api` resolves every entry point once and
+turns negative return codes into `HikariError`.
+
+`Api` takes the symbol prefix as an argument because the CPU oracle under oracle/ exports the same
+entry points with the prefix `orc_` (tests drive both through this one class).  The product only
+ever instantiates it with `hk_` on libhikari_hip.so; there is no fallback: if the HIP library is
+missing or no GPU is present the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhikari_hip.so")
+
+HK_OK = 0
+HK_E_INVALID, HK_E_NO_DEVICE, HK_E_HIP, HK_E_NOT_READY, HK_E_NOMEM, HK_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
+
+# HkBuffer
+BUF_POSITION, BUF_NORMAL, BUF_DEPTH_GRADIENT, BUF_INSTANCE_MATERIAL, BUF_VELOCITY_UV, BUF_ALBEDO = range(6)
+BUF_VARIANCE0, BUF_RENDER0, BUF_RESERVOIR0 = 6, 9, 12
+BUF_DENOISE_INTERNAL0, BUF_DENOISE_INTERNAL_VARIANCE, BUF_DENOISE_RENDER0, BUF_TONE_MAPPED, BUF_COUNT = 22, 26, 27, 30, 31
+# HkPass
+(PASS_PREPASS, PASS_FULL_SCREEN_ALBEDO, PASS_DIRECT_LIT, PASS_DIRECT_EMISSIVE, PASS_INDIRECT, PASS_EMISSIVE_SPATIAL_REUSE,
+ PASS_INDIRECT_SPATIAL_REUSE, PASS_DEMODULATION, PASS_DENOISE_L0, PASS_DENOISE_L1, PASS_DENOISE_L2, PASS_DENOISE_L3,
+ PASS_TONE_MAPPING, PASS_COUNT) = range(14)
+PASS_NAMES = ["prepass", "full_screen_albedo", "direct_lit", "direct_emissive", "indirect_lit_ambient", "emissive_spatial_reuse",
+              "indirect_spatial_reuse", "demodulation", "denoise_l0", "denoise_l1", "denoise_l2", "denoise_l3", "tone_mapping"]
+# HkStage
+STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_COUNT = range(4)
+CTX_COUNT_RAYS, CTX_TIME_PASSES = 1, 2
+FRAME_EXTERNAL_GBUFFER = 1
+TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
+TAA_JASMINE, TAA_NONE = 0, 1
+UPSCALE_FSR1, UPSCALE_SMAA_TU4X = 0, 1
+NO_TEXTURE = 0xFFFFFFFF
+TIMING_SLOTS = 16
+
+f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
+
+
+class HkVertex(C.Structure):
+    _fields_ = [("position", f32 * 3), ("u", f32), ("normal", f32 * 3), ("v", f32)]
+
+
+class HkPrimitiveVertex(C.Structure):
+    _fields_ = [("position", f32 * 3), ("index", u32)]
+
+
+class HkPrimitive(C.Structure):
+    _fields_ = [("vertices", HkPrimitiveVertex * 3)]
+
+
+class HkNode(C.Structure):
+    _fields_ = [("min", f32 * 3), ("entry_index", u32), ("max", f32 * 3), ("exit_index", u32)]
+
+
+class HkMeshIndex(C.Structure):
+    _fields_ = [("vertex", u32), ("primitive", u32), ("node_offset", u32), ("node_count", u32)]
+
+
+class HkInstance(C.Structure):
+    _fields_ = [("min", f32 * 3), ("material", u32), ("max", f32 * 3), ("node_index", u32), ("model", f32 * 16),
+                ("inverse_transpose_model", f32 * 16), ("mesh", HkMeshIndex)]
+
+
+class HkMaterial(C.Structure):
+    _fields_ = [("base_color", f32 * 4), ("base_color_texture", u32), ("_pad0", u32 * 3), ("emissive", f32 * 4),
+                ("emissive_texture", u32), ("perceptual_roughness", f32), ("metallic", f32), ("metallic_roughness_texture", u32),
+                ("reflectance", f32), ("normal_map_texture", u32), ("occlusion_texture", u32), ("_pad1", u32)]
+
+
+class HkAliasEntry(C.Structure):
+    _fields_ = [("prob", f32), ("index", u32)]
+
+
+class HkEmissive(C.Structure):
+    _fields_ = [("emissive", f32 * 4), ("position", f32 * 3), ("radius", f32), ("instance", u32), ("_pad0", u32),
+                ("alias_table", u32 * 2), ("surface_area", f32), ("node_index", u32), ("_pad1", u32 * 2)]
+
+
+class HkFrame(C.Structure):
+    _fields_ = [("kernel", (f32 * 4) * 3), ("halton", (f32 * 4) * 8), ("clear_color", f32 * 4), ("number", u32),
+                ("direct_validate_interval", u32), ("emissive_validate_interval", u32), ("indirect_bounces", u32),
+                ("temporal_reuse", u32), ("emissive_spatial_reuse", u32), ("indirect_spatial_reuse", u32),
+                ("max_temporal_reuse_count", u32), ("max_spatial_reuse_count", u32), ("max_reservoir_lifetime", f32),
+                ("solar_angle", f32), ("max_indirect_luminance", f32), ("upscale_ratio", f32), ("_pad", u32 * 3)]
+
+
+class HkView(C.Structure):
+    _fields_ = [("view_proj", f32 * 16), ("inverse_view_proj", f32 * 16), ("view", f32 * 16), ("inverse_view", f32 * 16),
+                ("projection", f32 * 16), ("inverse_projection", f32 * 16), ("world_position", f32 * 3), ("_pad0", f32),
+                ("viewport", f32 * 4)]
+
+
+class HkPreviousView(C.Structure):
+    _fields_ = [("view_proj", f32 * 16), ("inverse_view_proj", f32 * 16)]
+
+
+class HkLights(C.Structure):
+    _fields_ = [("directional_color", f32 * 4), ("direction_to_light", f32 * 3), ("n_directional_lights", u32),
+                ("ambient_color", f32 * 4)]
+
+
+class HkSettings(C.Structure):
+    _fields_ = [("direct_validate_interval", u32), ("emissive_validate_interval", u32), ("max_temporal_reuse_count", u32),
+                ("max_spatial_reuse_count", u32), ("max_reservoir_lifetime", f32), ("solar_angle", f32), ("indirect_bounces", u32),
+                ("max_indirect_luminance", f32), ("clear_color", f32 * 4), ("temporal_reuse", u32), ("emissive_spatial_reuse", u32),
+                ("indirect_spatial_reuse", u32), ("denoise", u32), ("taa", u32), ("upscale_kind", u32), ("upscale_ratio", f32),
+                ("upscale_sharpness", f32)]
+
+
+class HkHaloOp(C.Structure):
+    _fields_ = [("buffer", u32), ("peer", u32), ("row_begin", u32), ("row_end", u32), ("row_bytes", u64)]
+
+
+class HkStats(C.Structure):
+    _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
+                ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
+                ("_pad", u32)]
+
+
+assert C.sizeof(HkVertex) == 32 and C.sizeof(HkPrimitive) == 48 and C.sizeof(HkNode) == 32 and C.sizeof(HkInstance) == 176
+assert C.sizeof(HkMaterial) == 80 and C.sizeof(HkEmissive) == 64 and C.sizeof(HkFrame) == 256 and C.sizeof(HkView) == 416
+assert C.sizeof(HkPreviousView) == 128 and C.sizeof(HkAliasEntry) == 8
+
+
+class HikariError(RuntimeError):
+    def __init__(self, code, fn, message):
+        super().__init__(f"{fn} failed with code {code}: {message}")
+        self.code = code
+
+
+P = C.POINTER
+_vp = C.c_void_p
+
+# name -> (argtypes); every function returns int unless listed in _NON_INT
+_SIGNATURES = {
+    "create": [C.c_int, u32, P(_vp)],
+    "upload_meshes": [_vp, P(HkVertex), u32, P(HkPrimitive), u32, P(HkNode), u32],
+    "upload_materials": [_vp, P(HkMaterial), u32],
+    "upload_instances": [_vp, P(HkInstance), u32, P(HkNode), u32, P(HkEmissive), u32, P(HkNode), u32, P(HkAliasEntry), u32],
+    "upload_noise": [_vp, _vp, C.c_size_t],
+    "resize": [_vp, u32, u32, f32],
+    "set_view_options": [_vp, u32, u32],
+    "frame_begin": [_vp, P(HkFrame), P(HkView), P(HkPreviousView), P(HkLights)],
+    "pass_run": [_vp, u32, u32, u32, u32],
+    "frame_stage": [_vp, u32, P(HkSettings), u32],
+    "frame_render": [_vp, P(HkFrame), P(HkView), P(HkPreviousView), P(HkLights), P(HkSettings), u32],
+    "frame_wait": [_vp],
+    "set_band": [_vp, u32, u32],
+    "buffer_info": [_vp, u32, P(u32), P(u32), P(u32)],
+    "read_buffer": [_vp, u32, _vp, C.c_size_t],
+    "write_buffer": [_vp, u32, _vp, C.c_size_t],
+    "device_ptr": [_vp, u32, P(_vp), P(C.c_size_t)],
+    "get_stats": [_vp, P(HkStats)],
+    "reset_stats": [_vp],
+    "debug_math": [_vp, u32, P(f32), P(f32), P(f32), C.c_size_t],
+}
+# entry points only the product library exports (host logic + builders + GPU-only hooks)
+_PRODUCT_ONLY = {
+    "device_count": [P(C.c_int)],
+    "settings_default": [P(HkSettings)],
+    "frame_from_settings": [P(HkSettings), u32, P(HkFrame)],
+    "scaled_size": [u32, u32, f32, P(u32), P(u32)],
+    "scene_builder_create": [P(_vp)],
+    "scene_builder_add_mesh": [_vp, P(f32), P(f32), P(f32), u32, P(u32), u32, u32, P(u32)],
+    "scene_builder_add_material": [_vp, P(HkMaterial), P(u32)],
+    "scene_builder_add_instance": [_vp, u32, u32, P(f32), P(u32)],
+    "scene_builder_finish": [_vp],
+    "scene_builder_vertices": [_vp, P(P(HkVertex)), P(u32)],
+    "scene_builder_primitives": [_vp, P(P(HkPrimitive)), P(u32)],
+    "scene_builder_asset_nodes": [_vp, P(P(HkNode)), P(u32)],
+    "scene_builder_materials": [_vp, P(P(HkMaterial)), P(u32)],
+    "scene_builder_instances": [_vp, P(P(HkInstance)), P(u32)],
+    "scene_builder_instance_nodes": [_vp, P(P(HkNode)), P(u32)],
+    "scene_builder_emissives": [_vp, P(P(HkEmissive)), P(u32)],
+    "scene_builder_emissive_nodes": [_vp, P(P(HkNode)), P(u32)],
+    "scene_builder_alias_table": [_vp, P(P(HkAliasEntry)), P(u32)],
+    "upload_scene": [_vp, _vp],
+    "band_rows": [u32, u32, u32, P(u32), P(u32)],
+    "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
+    "band_plan_for": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],
+    "stream": [_vp, P(_vp)],
+    "set_timing_mask": [_vp, u32],
+}
+_VOID = {"destroy": [_vp], "scene_builder_destroy": [_vp]}
+
+#: every symbol include/hikari_hip.h declares (checked by tests/test_abi.py)
+DECLARED_SYMBOLS = sorted(["hk_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY) + list(_VOID)] + ["hk_abi_version", "hk_last_error"])
+
+
+class Api:
+    """Resolved entry points of one shared library."""
+
+    def __init__(self, path, prefix="hk_"):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                f"{path} not found - build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "There is no CPU fallback for the product path.")
+        self.path, self.prefix = path, prefix
+        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self._fns = {}
+        names = dict(_SIGNATURES)
+        if prefix == "hk_":
+            names.update(_PRODUCT_ONLY)
+        for name, argtypes in names.items():
+            fn = getattr(self.dll, prefix + name)
+            fn.argtypes, fn.restype = argtypes, C.c_int
+            self._fns[name] = fn
+        for name, argtypes in _VOID.items():
+            if prefix != "hk_" and name.startswith("scene_builder"):
+                continue
+            fn = getattr(self.dll, prefix + name)
+            fn.argtypes, fn.restype = argtypes, None
+            self._fns[name] = fn
+        self._last_error = getattr(self.dll, prefix + "last_error")
+        self._last_error.restype = C.c_char_p
+        self._abi = getattr(self.dll, prefix + "abi_version")
+        self._abi.restype = u32
+
+    def abi_version(self):
+        return int(self._abi())
+
+    def last_error(self):
+        msg = self._last_error()
+        return msg.decode() if msg else ""
+
+    def raw(self, name):
+        return self._fns[name]
+
+    def call(self, name, *args):
+        rc = self._fns[name](*args)
+        if rc is not None and rc != HK_OK:
+            raise HikariError(rc, self.prefix + name, self.last_error())
+        return rc
+
+
+_API = None
+
+
+def api():
+    """The product library (loaded once)."""
+    global _API
+    if _API is None:
+        _API = Api(LIB_PATH, "hk_")
+    return _API

@@ -1,0 +1,548 @@
+"""Host-side mirror of the reference's operator interface for the path.
+
+The reference is a Rust Bevy plugin (no Rust toolchain exists in this image, so the host side
+above the C ABI is Python; INTEGRATION.md shows the Rust binding).  Names, fields, defaults and
+call order follow cryscan/bevy-hikari v0.3.15:
+
+  HikariSettings / Taa / Upscale / HikariUniversalSettings   src/lib.rs:373-513
+  graph.NAME + node names                                     src/lib.rs:43-51
+  PrepassNode / LightNode / PostProcessNode  .run()           src/prepass.rs:769, src/light.rs:590, src/post_process.rs:1140
+  FrameCounter                                                src/view.rs:75-103
+  HikariPlugin                                                src/lib.rs:95-370
+
+All arithmetic of the path runs in libhikari_hip.so; this module only marshals.
+"""
+import ctypes as C
+import dataclasses
+import json
+import math
+import os
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi as F
+
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+WORKGROUP_SIZE = 8        # lib.rs:53
+NOISE_TEXTURE_COUNT = 16  # lib.rs:54
+
+
+class graph:  # lib.rs:43-51
+    NAME = "hikari"
+
+    class node:
+        PREPASS = "hikari_prepass"
+        LIGHT = "hikari_light"
+        POST_PROCESS = "hikari_post_process"
+        OVERLAY = "hikari_overlay"
+
+
+class Taa:  # lib.rs:466-472
+    Jasmine = F.TAA_JASMINE
+    NONE = F.TAA_NONE
+
+
+@dataclass(frozen=True)
+class Upscale:  # lib.rs:474-513
+    kind: int = F.UPSCALE_SMAA_TU4X
+    ratio_: float = 2.0
+    sharpness_: float = 0.0
+
+    @staticmethod
+    def Fsr1(ratio, sharpness):
+        return Upscale(F.UPSCALE_FSR1, ratio, sharpness)
+
+    @staticmethod
+    def SmaaTu4x(ratio):
+        return Upscale(F.UPSCALE_SMAA_TU4X, ratio, 0.0)
+
+    def ratio(self):
+        return min(max(self.ratio_, 1.0), 2.0)
+
+    def sharpness(self):
+        return self.sharpness_ if self.kind == F.UPSCALE_FSR1 else 0.0
+
+
+Upscale.SMAA_TU_1_0 = Upscale.SmaaTu4x(1.0)
+Upscale.SMAA_TU_2_0 = Upscale.SmaaTu4x(2.0)
+
+
+@dataclass
+class HikariUniversalSettings:  # lib.rs:373-389
+    build_mesh_acceleration_structure: bool = True
+    build_instance_acceleration_structure: bool = True
+
+
+@dataclass
+class HikariSettings:  # lib.rs:400-455 (field order and defaults)
+    direct_validate_interval: int = 3
+    emissive_validate_interval: int = 5
+    max_temporal_reuse_count: int = 50
+    max_spatial_reuse_count: int = 800
+    max_reservoir_lifetime: float = 100.0
+    solar_angle: float = 0.046
+    indirect_bounces: int = 1
+    max_indirect_luminance: float = 10.0
+    clear_color: tuple = (0.4, 0.4, 0.4, 1.0)
+    temporal_reuse: bool = True
+    emissive_spatial_reuse: bool = False
+    indirect_spatial_reuse: bool = True
+    denoise: bool = True
+    taa: int = Taa.Jasmine
+    upscale: Upscale = Upscale.SMAA_TU_2_0
+
+    def to_c(self):
+        s = F.HkSettings()
+        s.direct_validate_interval = self.direct_validate_interval
+        s.emissive_validate_interval = self.emissive_validate_interval
+        s.max_temporal_reuse_count = self.max_temporal_reuse_count
+        s.max_spatial_reuse_count = self.max_spatial_reuse_count
+        s.max_reservoir_lifetime = self.max_reservoir_lifetime
+        s.solar_angle = self.solar_angle
+        s.indirect_bounces = self.indirect_bounces
+        s.max_indirect_luminance = self.max_indirect_luminance
+        s.clear_color[:] = list(self.clear_color)
+        s.temporal_reuse = int(self.temporal_reuse)
+        s.emissive_spatial_reuse = int(self.emissive_spatial_reuse)
+        s.indirect_spatial_reuse = int(self.indirect_spatial_reuse)
+        s.denoise = int(self.denoise)
+        s.taa = self.taa
+        s.upscale_kind = self.upscale.kind
+        s.upscale_ratio = self.upscale.ratio_
+        s.upscale_sharpness = self.upscale.sharpness_
+        return s
+
+
+# ---------------------------------------------------------------------------------------------
+# small f64 -> f32 matrix helpers (glam conventions, column-major flat arrays)
+# ---------------------------------------------------------------------------------------------
+def look_at_transform(eye, target, up=(0.0, 1.0, 0.0)):
+    """Transform::from_translation(eye).looking_at(target, up) as a 4x4 camera-to-world matrix."""
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    fwd = target - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, up)
+    right /= np.linalg.norm(right)
+    upv = np.cross(right, fwd)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, upv, -fwd, eye
+    return m
+
+
+def perspective_infinite_reverse_rh(fov_y, aspect, near):
+    f = 1.0 / math.tan(0.5 * fov_y)
+    m = np.zeros((4, 4))
+    m[0, 0] = f / aspect
+    m[1, 1] = f
+    m[3, 2] = -1.0
+    m[2, 3] = near
+    return m
+
+
+def _flat(m):  # row/col numpy matrix -> column-major 16 floats
+    return np.asarray(m, dtype=np.float64).T.reshape(-1).astype(np.float32)
+
+
+@dataclass
+class Camera:
+    """Camera3dBundle with bevy's default PerspectiveProjection (fov pi/4, near 0.1, infinite reverse-Z)."""
+    transform: np.ndarray  # 4x4 camera-to-world
+    width: int
+    height: int
+    fov: float = math.pi / 4.0
+    near: float = 0.1
+
+    def view_uniform(self):
+        proj = perspective_infinite_reverse_rh(self.fov, self.width / self.height, self.near)
+        view = self.transform
+        inv_view = np.linalg.inv(view)
+        view_proj = proj @ inv_view
+        v = F.HkView()
+        v.view_proj[:] = _flat(view_proj)
+        v.inverse_view_proj[:] = _flat(view @ _inv_proj(proj))  # (P * V^-1)^-1 = V * P^-1
+        v.view[:] = _flat(view)
+        v.inverse_view[:] = _flat(inv_view)
+        v.projection[:] = _flat(proj)
+        v.inverse_projection[:] = _flat(_inv_proj(proj))
+        v.world_position[:] = view[:3, 3].astype(np.float32)
+        v.viewport[:] = [0.0, 0.0, float(self.width), float(self.height)]
+        return v
+
+    def previous_view_uniform(self, previous: Optional["Camera"] = None):
+        cam = previous or self
+        v = cam.view_uniform()
+        p = F.HkPreviousView()
+        p.view_proj[:] = list(v.view_proj)
+        p.inverse_view_proj[:] = list(v.inverse_view_proj)
+        return p
+
+
+def _inv_proj(proj):
+    """Inverse of perspective_infinite_reverse_rh (singular for numpy's generic inverse is not an issue, but keep it exact)."""
+    fa, f, near = proj[0, 0], proj[1, 1], proj[2, 3]
+    m = np.zeros((4, 4))
+    m[0, 0] = 1.0 / fa
+    m[1, 1] = 1.0 / f
+    m[2, 3] = -1.0
+    m[3, 2] = 1.0 / near
+    return m
+
+
+def lights_uniform(directional=None, ambient_color=(1.0, 1.0, 1.0), ambient_brightness=0.05):
+    """bevy AmbientLight default (white, 0.05) and an optional DirectionalLight
+    dict(color=(r,g,b) linear, illuminance=lux, direction_to_light=(x,y,z)); bevy scales the colour
+    by illuminance / 4800 (exposure of the default camera) before upload."""
+    l = F.HkLights()
+    l.ambient_color[:] = [c * ambient_brightness for c in ambient_color] + [ambient_brightness]
+    if directional:
+        scale = directional.get("illuminance", 100000.0) / 4800.0  # bevy_pbr 0.9.1 light.rs exposure
+        col = [c * scale for c in directional.get("color", (1.0, 1.0, 1.0))]
+        l.directional_color[:] = col + [1.0]
+        d = np.asarray(directional["direction_to_light"], dtype=np.float64)
+        d = d / np.linalg.norm(d)
+        l.direction_to_light[:] = d.astype(np.float32)
+        l.n_directional_lights = 1
+    return l
+
+
+# ---------------------------------------------------------------------------------------------
+# scene description -> builder
+# ---------------------------------------------------------------------------------------------
+def linear_to_srgb(c):
+    c = float(c)
+    return 12.92 * c if c <= 0.0031308 else 1.055 * (c ** (1.0 / 2.4)) - 0.055
+
+
+def standard_material(base_color_linear=(1, 1, 1, 1), emissive_linear=(0, 0, 0), perceptual_roughness=0.5, metallic=0.0,
+                      reflectance=0.5, nonlinear=False):
+    """StandardMaterial -> GpuStandardMaterial as material.rs:168-199 does it: `Color -> Vec4` goes
+    through bevy 0.9's `From<Color> for Vec4` = as_rgba_f32().  bevy_gltf 0.9.1 builds the colours
+    with `Color::rgba(factor)`, for which as_rgba_f32() is the identity, so glTF factors reach the
+    GPU buffer unchanged (default).  `nonlinear=True` applies the linear->sRGB encoding that the same
+    conversion performs for `Color::rgba_linear` inputs.  Either way these values are INPUTS of the
+    boundary; the library never converts colours."""
+    m = F.HkMaterial()
+    enc = linear_to_srgb if nonlinear else float
+    bc = list(base_color_linear) + [1.0] * (4 - len(base_color_linear))
+    m.base_color[:] = [enc(bc[0]), enc(bc[1]), enc(bc[2]), float(bc[3])]
+    em = list(emissive_linear)
+    m.emissive[:] = [enc(em[0]), enc(em[1]), enc(em[2]), 1.0]
+    m.base_color_texture = m.emissive_texture = m.metallic_roughness_texture = F.NO_TEXTURE
+    m.normal_map_texture = m.occlusion_texture = F.NO_TEXTURE
+    m.perceptual_roughness, m.metallic, m.reflectance = perceptual_roughness, metallic, reflectance
+    return m
+
+
+class SceneData:
+    """The nine storage buffers of bind group 2 (mesh_material_bindings.wgsl:5-22) as ctypes arrays."""
+
+    FIELDS = ("vertices", "primitives", "asset_nodes", "materials", "instances", "instance_nodes", "emissives", "emissive_nodes",
+              "alias_table")
+
+    def __init__(self, **arrays):
+        for k in self.FIELDS:
+            setattr(self, k, arrays[k])
+
+    def upload(self, api, ctx):
+        n = lambda a: len(a)
+        api.call("upload_meshes", ctx, self.vertices, n(self.vertices), self.primitives, n(self.primitives), self.asset_nodes, n(self.asset_nodes))
+        api.call("upload_materials", ctx, self.materials, n(self.materials))
+        api.call("upload_instances", ctx, self.instances, n(self.instances), self.instance_nodes, n(self.instance_nodes), self.emissives,
+                 n(self.emissives), self.emissive_nodes, n(self.emissive_nodes), self.alias_table, n(self.alias_table))
+
+
+class SceneBuilder:
+    """hk_scene_builder_*: the Prepare-stage host work (mesh -> BLAS, TLAS, emissives, alias tables)."""
+
+    def __init__(self):
+        self.api = F.api()
+        self.h = C.c_void_p()
+        self.api.call("scene_builder_create", C.byref(self.h))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.api.raw("scene_builder_destroy")(self.h)
+            self.h = None
+
+    def add_mesh(self, positions, normals, uvs, indices=None, topology=F.TOPOLOGY_TRIANGLE_LIST):
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        uv = np.ascontiguousarray(uvs, dtype=np.float32).reshape(-1, 2)
+        out = F.u32()
+        fp = lambda a: a.ctypes.data_as(C.POINTER(F.f32))
+        if indices is None:
+            self.api.call("scene_builder_add_mesh", self.h, fp(pos), fp(nrm), fp(uv), len(pos), None, 0, topology, C.byref(out))
+        else:
+            idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+            self.api.call("scene_builder_add_mesh", self.h, fp(pos), fp(nrm), fp(uv), len(pos), idx.ctypes.data_as(C.POINTER(F.u32)), len(idx),
+                          topology, C.byref(out))
+        return out.value
+
+    def add_material(self, material):
+        out = F.u32()
+        self.api.call("scene_builder_add_material", self.h, C.byref(material), C.byref(out))
+        return out.value
+
+    def add_instance(self, mesh_id, material_id, transform):
+        t = np.ascontiguousarray(transform, dtype=np.float32).reshape(-1)
+        out = F.u32()
+        self.api.call("scene_builder_add_instance", self.h, mesh_id, material_id, t.ctypes.data_as(C.POINTER(F.f32)), C.byref(out))
+        return out.value
+
+    def finish(self):
+        self.api.call("scene_builder_finish", self.h)
+        arrays = {}
+        for name, typ in (("vertices", F.HkVertex), ("primitives", F.HkPrimitive), ("asset_nodes", F.HkNode), ("materials", F.HkMaterial),
+                          ("instances", F.HkInstance), ("instance_nodes", F.HkNode), ("emissives", F.HkEmissive),
+                          ("emissive_nodes", F.HkNode), ("alias_table", F.HkAliasEntry)):
+            p, n = C.POINTER(typ)(), F.u32()
+            self.api.call("scene_builder_" + name, self.h, C.byref(p), C.byref(n))
+            arr = (typ * n.value)()
+            if n.value:
+                C.memmove(arr, p, n.value * C.sizeof(typ))
+            arrays[name] = arr
+        return SceneData(**arrays)
+
+
+def load_cornell(nonlinear_colors=False):
+    """examples/cornell.rs:37-41: the glTF scene, flattened by tools/make_fixtures.py."""
+    with open(os.path.join(ASSETS, "cornell.json")) as f:
+        j = json.load(f)
+    b = SceneBuilder()
+    mats = []
+    for m in j["materials"]:
+        # bevy_gltf 0.9.1 load_material: base_color = Color::rgba_linear(factor), emissive = Color::rgb_linear(factor),
+        # perceptual_roughness = roughness factor, metallic = metallic factor, reflectance default 0.5
+        mats.append(b.add_material(standard_material(m["base_color_factor"], m["emissive_factor"], m["roughness_factor"],
+                                                     m["metallic_factor"], 0.5, nonlinear_colors)))
+    meshes = [b.add_mesh(m["positions"], m["normals"], m["uvs"], m["indices"]) for m in j["meshes"]]
+    for inst in j["instances"]:
+        b.add_instance(meshes[inst["mesh"]], mats[j["meshes"][inst["mesh"]]["material"]], inst["transform"])
+    return b.finish()
+
+
+def cornell_camera(width, height):  # examples/cornell.rs:49-50
+    return Camera(look_at_transform((0.0, 1.0, 4.0), (0.0, 1.0, 0.0)), width, height)
+
+
+def load_noise():
+    path = os.path.join(ASSETS, "noise_rgba8_16x64x64.bin")
+    data = np.fromfile(path, dtype=np.uint8)
+    assert data.size == 16 * 64 * 64 * 4
+    return data
+
+
+# ---------------------------------------------------------------------------------------------
+# engine: one hk_ctx
+# ---------------------------------------------------------------------------------------------
+_BUF_DTYPES = {16: (np.float32, 4), 4: (np.uint32, 1), 8: (np.uint16, 4), 64: (np.uint32, 16)}
+
+
+class Engine:
+    """One context of the C ABI (`hk_ctx`).  `api` defaults to the product library."""
+
+    def __init__(self, api=None, device=0, flags=0):
+        self.api = api or F.api()
+        self.ctx = C.c_void_p()
+        self.api.call("create", device, flags, C.byref(self.ctx))
+        self.width = self.height = 0
+
+    def close(self):
+        if self.ctx:
+            self.api.raw("destroy")(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- Prepare stage
+    def upload_scene(self, scene: SceneData):
+        scene.upload(self.api, self.ctx)
+
+    def upload_noise(self, noise=None):
+        noise = load_noise() if noise is None else np.ascontiguousarray(noise, dtype=np.uint8)
+        self.api.call("upload_noise", self.ctx, noise.ctypes.data, noise.size)
+
+    def resize(self, width, height, upscale_ratio=1.0):
+        self.api.call("resize", self.ctx, width, height, upscale_ratio)
+        self.width, self.height = width, height
+
+    # -- per frame
+    def frame_begin(self, frame, view, previous_view, lights):
+        self.api.call("frame_begin", self.ctx, C.byref(frame), C.byref(view), C.byref(previous_view), C.byref(lights))
+
+    def set_view_options(self, taa, upscale_kind):
+        self.api.call("set_view_options", self.ctx, taa, upscale_kind)
+
+    def pass_run(self, pass_id, arg=0, row_begin=0, row_end=0):
+        self.api.call("pass_run", self.ctx, pass_id, arg, row_begin, row_end)
+
+    def frame_stage(self, stage, settings_c, flags=0):
+        self.api.call("frame_stage", self.ctx, stage, C.byref(settings_c), flags)
+
+    def frame_render(self, frame, view, previous_view, lights, settings_c, flags=0):
+        self.api.call("frame_render", self.ctx, C.byref(frame), C.byref(view), C.byref(previous_view), C.byref(lights), C.byref(settings_c), flags)
+
+    def wait(self):
+        self.api.call("frame_wait", self.ctx)
+
+    def set_band(self, index, count):
+        self.api.call("set_band", self.ctx, index, count)
+
+    # -- buffers
+    def buffer_info(self, buf):
+        w, h, bpp = F.u32(), F.u32(), F.u32()
+        self.api.call("buffer_info", self.ctx, buf, C.byref(w), C.byref(h), C.byref(bpp))
+        return w.value, h.value, bpp.value
+
+    def read(self, buf):
+        """Raw contents as a numpy array [h, w, k] (f32 for 16/8-byte float formats, u16 for rgba16f, u32 otherwise)."""
+        w, h, bpp = self.buffer_info(buf)
+        if buf in (F.BUF_DEPTH_GRADIENT, F.BUF_INSTANCE_MATERIAL):
+            dt, k = np.float32, 2
+        elif bpp == 4 and buf != F.BUF_NORMAL:
+            dt, k = np.float32, 1
+        else:
+            dt, k = _BUF_DTYPES[bpp]
+        out = np.empty((h, w, k), dtype=dt)
+        self.api.call("read_buffer", self.ctx, buf, out.ctypes.data, out.nbytes)
+        return out
+
+    def read_f16(self, buf):
+        return self.read(buf).view(np.float16).astype(np.float32)
+
+    def write(self, buf, array):
+        a = np.ascontiguousarray(array)
+        self.api.call("write_buffer", self.ctx, buf, a.ctypes.data, a.nbytes)
+
+    def device_ptr(self, buf):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.api.call("device_ptr", self.ctx, buf, C.byref(p), C.byref(n))
+        return p.value, n.value
+
+    def stats(self):
+        s = F.HkStats()
+        self.api.call("get_stats", self.ctx, C.byref(s))
+        return s
+
+    def reset_stats(self):
+        self.api.call("reset_stats", self.ctx)
+
+    def set_timing_mask(self, mask):
+        self.api.call("set_timing_mask", self.ctx, mask)
+
+    def debug_math(self, op, x, y=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(F.f32))
+        yy = None if y is None else np.ascontiguousarray(y, dtype=np.float32)
+        self.api.call("debug_math", self.ctx, op, fp(x), None if yy is None else fp(yy), fp(out), x.size)
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's nodes and plugin
+# ---------------------------------------------------------------------------------------------
+class FrameCounter:  # view.rs:75-103: inserted as 0 on a new camera, +1 every frame
+    def __init__(self, value=0):
+        self.value = value
+
+    def tick(self):
+        self.value += 1
+        return self.value
+
+
+def frame_uniform(settings: HikariSettings, frame_number: int):
+    """FrameUniform::extract_component (view.rs:141-193), evaluated by the library."""
+    f = F.HkFrame()
+    s = settings.to_c()
+    F.api().call("frame_from_settings", C.byref(s), frame_number, C.byref(f))
+    return f
+
+
+class _Node:
+    IN_VIEW = "view"  # light.rs:572
+
+    def __init__(self, engine: Engine):
+        self.engine = engine
+
+
+class PrepassNode(_Node):  # prepass.rs:736-852
+    def run(self, settings: HikariSettings):
+        self.engine.set_view_options(settings.taa, settings.upscale.kind)
+        self.engine.pass_run(F.PASS_PREPASS)
+
+
+class LightNode(_Node):  # light.rs:557-703
+    def run(self, settings: HikariSettings):
+        e = self.engine
+        e.pass_run(F.PASS_FULL_SCREEN_ALBEDO)                      # light.rs:646-653
+        e.pass_run(F.PASS_DIRECT_LIT)                              # light.rs:656-688, render[0], reservoirs (0,4)
+        e.pass_run(F.PASS_DIRECT_EMISSIVE)                         # render[1], reservoirs (2,4)
+        if settings.emissive_spatial_reuse:                        # light.rs:675,689-697
+            e.pass_run(F.PASS_EMISSIVE_SPATIAL_REUSE)
+        e.pass_run(F.PASS_INDIRECT)                                # render[2], reservoirs (6,8)
+        if settings.indirect_spatial_reuse:                        # light.rs:676
+            e.pass_run(F.PASS_INDIRECT_SPATIAL_REUSE)
+
+
+class PostProcessNode(_Node):  # post_process.rs:1107-1312 (denoise + tone mapping part)
+    def run(self, settings: HikariSettings):
+        e = self.engine
+        if settings.denoise:                                       # post_process.rs:1190-1224
+            channels = 2 if settings.indirect_bounces == 0 else 3  # post_process.rs:949-954
+            for ch in range(channels):
+                e.pass_run(F.PASS_DEMODULATION, ch)
+                for level in range(4):
+                    e.pass_run(F.PASS_DENOISE_L0 + level, ch)
+        e.pass_run(F.PASS_TONE_MAPPING, int(settings.denoise))     # post_process.rs:1226-1234
+
+
+class HikariPlugin:
+    """App::add_plugin(HikariPlugin): owns the context, uploads the noise tiles at start-up
+    (lib.rs:189-219) and renders one camera with the `hikari` sub-graph order
+    PREPASS -> LIGHT -> POST_PROCESS (lib.rs:252-367)."""
+
+    def __init__(self, device=0, universal_settings: Optional[HikariUniversalSettings] = None, flags=0, api=None):
+        self.universal_settings = universal_settings or HikariUniversalSettings()
+        self.engine = Engine(api=api, device=device, flags=flags)
+        self.engine.upload_noise()
+        self.prepass, self.light, self.post_process = PrepassNode(self.engine), LightNode(self.engine), PostProcessNode(self.engine)
+        self.counter = FrameCounter(0)
+        self._size = None
+        self._previous_camera = None
+
+    def set_scene(self, scene: SceneData):
+        self.engine.upload_scene(scene)
+
+    def render(self, camera: Camera, settings: HikariSettings, lights=None, frame_number=None, by_nodes=False):
+        """One frame of the camera's render graph.  Returns the frame number used."""
+        size = (camera.width, camera.height, settings.upscale.ratio())
+        if size != self._size:  # prepare_light_textures, light.rs:342-363: reallocate + zero on size change
+            self.engine.resize(*size)
+            self._size = size
+        n = self.counter.tick() if frame_number is None else frame_number
+        frame = frame_uniform(settings, n)
+        view = camera.view_uniform()
+        pview = camera.previous_view_uniform(self._previous_camera)
+        lights = lights or lights_uniform()
+        if by_nodes:
+            self.engine.frame_begin(frame, view, pview, lights)
+            self.prepass.run(settings)
+            self.light.run(settings)
+            self.post_process.run(settings)
+        else:
+            self.engine.frame_render(frame, view, pview, lights, settings.to_c())
+        self._previous_camera = camera
+        return n
+
+    def output(self, settings: HikariSettings):
+        """The three radiance channels the tone-mapping pass sums (tone_mapping.wgsl:25-27), as f32 [3][H][W][4]."""
+        base = F.BUF_DENOISE_RENDER0 if settings.denoise else F.BUF_RENDER0
+        return np.stack([self.engine.read_f16(base + i) for i in range(3)])
