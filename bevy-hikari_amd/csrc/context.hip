@@ -826,13 +826,14 @@ int hk_reset_stats(hk_ctx* c) {
 }
 
 int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float* out, size_t n) {
-  HK_REQUIRE(c && x && out && op <= 10, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(c && x && out && op <= 19, HK_E_INVALID, "bad argument");
+  const size_t xin = (op >= 16 ? 16 : 1) * n;
   if (n == 0) return HK_OK;
   HK_HIP(hipSetDevice(c->device));
   float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-  HK_HIP(hipMalloc((void**)&dx, n * 4));
+  HK_HIP(hipMalloc((void**)&dx, xin * 4));
   HK_HIP(hipMalloc((void**)&dout, n * 4));
-  HK_HIP(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  HK_HIP(hipMemcpy(dx, x, xin * 4, hipMemcpyHostToDevice));
   if (y) {
     HK_HIP(hipMalloc((void**)&dy, n * 4));
     HK_HIP(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));

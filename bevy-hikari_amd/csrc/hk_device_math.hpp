@@ -216,7 +216,13 @@ HKD float pow_(float x, float y) {
 }
 
 // ---- f16 storage (v_cvt_f16_f32 / v_cvt_f32_f16: round-to-nearest-even, denormals kept)
-HKD uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// The empty asm keeps the f32 value opaque: without it the backend folds a preceding multiply into
+// v_fma_mixlo_f16 (f16(a*b + 0), ONE rounding and -0 + 0 = +0), which is not what storing an f32
+// result to an rgba16float texture does (two roundings) and breaks the numeric contract.
+HKD uint16_t f32_to_f16(float f) {
+  asm("" : "+v"(f));
+  return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
 HKD float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 HKD uint32_t pack2x16float(float x, float y) { return (uint32_t)f32_to_f16(x) | ((uint32_t)f32_to_f16(y) << 16); }
 HKD f2 unpack2x16float(uint32_t u) { return {f16_to_f32((uint16_t)(u & 0xffffu)), f16_to_f32((uint16_t)(u >> 16))}; }

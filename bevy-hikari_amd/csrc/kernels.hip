@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void k_tone_mapping(DFrame fr, const uint2* __
 __global__ void k_debug_math(uint32_t op, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float a = x[i], b = y ? y[i] : 0.0f, r = 0.0f;
+  float a = (op >= 16) ? 0.0f : x[i], b = y ? y[i] : 0.0f, r = 0.0f;
   switch (op) {
     case 0: r = sin_(a); break;
     case 1: r = cos_(a); break;
@@ -703,6 +703,22 @@ __global__ void k_debug_math(uint32_t op, const float* __restrict__ x, const flo
     case 8: r = f16_to_f32(f32_to_f16(a)); break;
     case 9: r = a / b; break;
     case 10: r = sqrtf(a); break;
+    case 11: r = saturate(a); break;
+    case 12: r = clamp_(a, -1.0f, 1.0f); break;
+    case 13: r = saturate(a * b); break;
+    case 16: case 17: case 18: case 19: {  // shading()/env_brdf() on 16 floats per item: V N L base_color radiance
+      const float* q = x + 16 * i;
+      DFrame fr;
+      fr.amb_r = fr.amb_g = fr.amb_b = 0.05f;
+      Surface sf;
+      sf.base_color = F4(q[9], q[10], q[11], 1.0f);
+      sf.emissive = F4(0, 0, 0, 0);
+      sf.reflectance = 0.5f; sf.metallic = 0.0f; sf.roughness = perceptualRoughnessToRoughness(b); sf.occlusion = 1.0f;
+      f3 V = normalize(F3(q[0], q[1], q[2])), N = normalize(F3(q[3], q[4], q[5])), L = normalize(F3(q[6], q[7], q[8]));
+      f3 o = (op == 19) ? env_brdf(V, N, sf) : shading(fr, V, N, L, sf, F4(q[12], q[13], q[14], q[15]));
+      r = (op == 17) ? o.y : ((op == 18) ? o.z : o.x);
+      break;
+    }
     default: break;
   }
   out[i] = r;

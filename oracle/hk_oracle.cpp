@@ -1931,7 +1931,7 @@ int orc_reset_stats(orc_ctx* ctx) {
 int orc_debug_math(orc_ctx* ctx, uint32_t op, const float* x, const float* y, float* out, size_t n) {
   (void)ctx;
   for (size_t i = 0; i < n; ++i) {
-    float a = x[i], b = y ? y[i] : 0.0f, r = 0.0f;
+    float a = (op >= 16) ? 0.0f : x[i], b = y ? y[i] : 0.0f, r = 0.0f;
     switch (op) {
       case 0: r = sin_(a); break;
       case 1: r = cos_(a); break;
@@ -1944,6 +1944,24 @@ int orc_debug_math(orc_ctx* ctx, uint32_t op, const float* x, const float* y, fl
       case 8: r = f16_to_f32(f32_to_f16(a)); break;
       case 9: r = a / b; break;
       case 10: r = sqrtf(a); break;
+      case 11: r = saturate(a); break;
+      case 12: r = clamp_(a, -1.0f, 1.0f); break;
+      case 13: r = saturate(a * b); break;
+      case 16: case 17: case 18: case 19: {
+        const float* q = x + 16 * i;
+        HkLights lights{};
+        lights.ambient_color[0] = lights.ambient_color[1] = lights.ambient_color[2] = 0.05f;
+        Scene sc{};
+        sc.lights = &lights;
+        Surface sf;
+        sf.base_color = V4(q[9], q[10], q[11], 1.0f);
+        sf.emissive = V4(0, 0, 0, 0);
+        sf.reflectance = 0.5f; sf.metallic = 0.0f; sf.roughness = perceptualRoughnessToRoughness(b); sf.occlusion = 1.0f;
+        v3 V = normalize(V3(q[0], q[1], q[2])), N = normalize(V3(q[3], q[4], q[5])), L = normalize(V3(q[6], q[7], q[8]));
+        v3 o = (op == 19) ? env_brdf(V, N, sf) : shading(sc, V, N, L, sf, V4(q[12], q[13], q[14], q[15]));
+        r = (op == 17) ? o.y : ((op == 18) ? o.z : o.x);
+        break;
+      }
       default: return HK_E_INVALID;
     }
     out[i] = r;

@@ -1,0 +1,108 @@
+"""The numeric contract: oracle math == libm within a few ulp (CPU), and the HIP
+library's device math == the oracle's bit for bit (GPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from bevy_hikari_amd import _ffi as F
+from oracle_lib import oracle_api
+
+OPS = {"sin": 0, "cos": 1, "exp": 2, "exp2": 3, "log2": 4, "pow": 5, "min": 6, "max": 7, "f16": 8, "div": 9, "sqrt": 10}
+
+
+def oracle_math(op, x, y=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(F.f32))
+    yy = None if y is None else np.ascontiguousarray(y, dtype=np.float32)
+    oracle_api().call("debug_math", None, OPS[op], fp(x), None if yy is None else fp(yy), fp(out), x.size)
+    return out
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    ia = a.view(np.int32).astype(np.int64)
+    ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)
+
+
+def inputs(rng, n=200_000):
+    return {
+        "sin": (rng.uniform(-10.0, 10.0, n),),
+        "cos": (rng.uniform(-10.0, 10.0, n),),
+        "exp": (rng.uniform(-90.0, 20.0, n),),
+        "exp2": (rng.uniform(-130.0, 30.0, n),),
+        "log2": (np.exp(rng.uniform(-60.0, 60.0, n)),),
+        "pow": (rng.uniform(0.0, 2.0, n), rng.choice([0.25, 2.0, 5.0, 16.0], n)),
+        "min": (rng.choice([-0.0, 0.0, 1.0, -1.0, np.nan, np.inf, -np.inf, 0.5], n), rng.choice([-0.0, 0.0, 1.0, -1.0, np.nan, np.inf, 2.0], n)),
+        "max": (rng.choice([-0.0, 0.0, 1.0, -1.0, np.nan, np.inf, -np.inf, 0.5], n), rng.choice([-0.0, 0.0, 1.0, -1.0, np.nan, np.inf, 2.0], n)),
+        "f16": (np.concatenate([rng.uniform(-70000, 70000, n // 2), np.exp(rng.uniform(-30, 12, n // 2))]),),
+        "div": (rng.normal(0, 100, n), np.concatenate([rng.normal(0, 10, n // 2), np.exp(rng.uniform(-40, 40, n // 2))])),
+        "sqrt": (np.exp(rng.uniform(-80, 80, n)),),
+    }
+
+
+def test_oracle_math_close_to_libm():
+    rng = np.random.default_rng(1)
+    data = inputs(rng, 100_000)
+    x = data["sin"][0].astype(np.float32)
+    assert np.abs(oracle_math("sin", x) - np.sin(x.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(oracle_math("cos", x) - np.cos(x.astype(np.float64))).max() < 2.5e-7
+    x = data["exp"][0].astype(np.float32)
+    x = x[x > -85.0]  # below that the result is an f32 denormal
+    ref = np.exp(x.astype(np.float64))
+    assert (np.abs(oracle_math("exp", x) - ref) / ref).max() < 4e-7
+    x = data["exp2"][0].astype(np.float32)
+    x = x[x > -125]
+    ref = np.exp2(x.astype(np.float64))
+    assert (np.abs(oracle_math("exp2", x) - ref) / ref).max() < 3e-7
+    x = data["log2"][0].astype(np.float32)
+    ref = np.log2(x.astype(np.float64))
+    assert np.abs(oracle_math("log2", x) - ref).max() / 1.0 < 2e-5  # absolute; relative error below
+    big = np.abs(ref) > 1
+    assert (np.abs(oracle_math("log2", x) - ref)[big] / np.abs(ref[big])).max() < 3e-7
+    xb, yb = (a.astype(np.float32) for a in data["pow"])
+    ref = np.power(xb.astype(np.float64), yb.astype(np.float64))
+    got = oracle_math("pow", xb, yb)
+    ok = ref > 1e-30
+    assert (np.abs(got - ref)[ok] / ref[ok]).max() < 4e-6  # WGSL: pow inherits exp2(y*log2(x))
+    assert (got[xb == 0] == 0).all()
+
+
+def test_oracle_f16_roundtrip_matches_numpy():
+    rng = np.random.default_rng(2)
+    x = inputs(rng, 200_000)["f16"][0].astype(np.float32)
+    x = np.concatenate([x, np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e-8, 6e-8, 5.96e-8, 2.98e-8, 2.99e-8, np.inf, -np.inf], np.float32)])
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).astype(np.float32)
+    got = oracle_math("f16", x)
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+def test_oracle_div_sqrt_are_ieee():
+    rng = np.random.default_rng(3)
+    d = inputs(rng, 100_000)
+    a, b = (v.astype(np.float32) for v in d["div"])
+    assert (oracle_math("div", a, b).view(np.uint32) == (a / b).view(np.uint32)).all()
+    s = d["sqrt"][0].astype(np.float32)
+    assert (oracle_math("sqrt", s).view(np.uint32) == np.sqrt(s).view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", list(OPS))
+def test_device_math_bit_exact_vs_oracle(op):
+    import bevy_hikari_amd as hk
+
+    rng = np.random.default_rng(7)
+    args = [a.astype(np.float32) for a in inputs(rng)[op]]
+    eng = hk.Engine(device=0)
+    got = eng.debug_math(OPS[op], *args)
+    want = oracle_math(op, *args)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    if not same.all():
+        i = np.nonzero(~same)[0][:5]
+        raise AssertionError(f"{op}: {(~same).sum()} of {same.size} differ, e.g. x={[a[i] for a in args]} gpu={got[i]} cpu={want[i]}")
