@@ -184,6 +184,7 @@ _PRODUCT_ONLY = {
     "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
     "band_plan_for": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],
     "stream": [_vp, P(_vp)],
+    "set_stream": [_vp, _vp],
     "set_timing_mask": [_vp, u32],
 }
 _VOID = {"destroy": [_vp], "scene_builder_destroy": [_vp]}

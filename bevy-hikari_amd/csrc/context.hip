@@ -85,7 +85,8 @@ inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 struct hk_ctx {
   int device = 0;
   uint32_t flags = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless hk_set_stream)
+  hipStream_t own_stream = nullptr;
 
   // host copies of the reference-layout scene (kept for the layout conversion)
   std::vector<HkVertex> vertices;
@@ -524,13 +525,14 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   c->device = device_id;
   c->flags = flags;
   c->timing_mask = (flags & HK_CTX_TIME_PASSES) ? 0xFFFFFFFFu : 0u;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&c->frame_start) != hipSuccess ||
       hipEventCreate(&c->frame_stop) != hipSuccess) {
     set_error("HIP resource creation failed: %s", hipGetErrorString(hipGetLastError()));
     hk_destroy(c);
     return HK_E_HIP;
   }
+  c->stream = c->own_stream;
   *out = c;
   return HK_OK;
 }
@@ -549,7 +551,7 @@ void hk_destroy(hk_ctx* c) {
   c->d_materials.release(); c->light_lo.release(); c->light_hi.release(); c->d_alias.release();
   c->d_instances.release(); c->d_emissives.release(); c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -780,6 +782,14 @@ int hk_device_ptr(hk_ctx* c, uint32_t buffer, void** ptr, size_t* bytes) {
   HK_REQUIRE(c && ptr && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
   *ptr = c->buf[buffer];
   if (bytes) *bytes = c->buf_bytes[buffer];
+  return HK_OK;
+}
+int hk_set_stream(hk_ctx* c, void* s) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipStreamSynchronize(c->stream));
+  drain_timers(c);
+  c->stream = s ? (hipStream_t)s : c->own_stream;
   return HK_OK;
 }
 int hk_stream(hk_ctx* c, void** s) {

@@ -1,0 +1,118 @@
+"""Band-sharded rendering across GPUs: one process per GPU (torch.distributed; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The frame is cut into horizontal bands of the render image, one per rank, with the scene
+replicated.  Every pass is per-pixel with a bounded screen-space footprint, so the only
+data that crosses ranks are halo rows, exchanged point-to-point between neighbouring bands twice
+per frame:
+
+    stage TEMPORAL      prepass (+apron), albedo, direct_lit x2, indirect on the band
+    exchange A          temporal reservoirs, 20 rows (10 for the emissive channel)   -> spatial_reuse
+    stage SPATIAL       spatial_reuse on the band
+    exchange B          render (15 rows) + variance (16 rows) per denoised channel   -> denoiser
+    stage POST_PROCESS  demodulation + 4 a-trous levels on band + shrinking apron, tone mapping
+
+Which rows of which buffer move is decided by the library (`hk_band_plan_for`, pure host logic);
+this module only executes that plan with isend/irecv on zero-copy views of the library's device
+buffers.  Buffers are allocated full-frame on every rank (288 GB HBM makes the 1.6 GB @1080p /
+6.6 GB @4K irrelevant), so a halo row lands at the same address it has on its owner and no
+coordinate translation exists anywhere.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi as F
+
+
+class _DevView:
+    """Expose a raw device pointer through __cuda_array_interface__ so torch can wrap it zero-copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def halo_plan(width, height, upscale_ratio, band_index, band_count, stage, frame_number, settings_c):
+    """Halo transfers band `band_index` must RECEIVE before `stage` (list of HkHaloOp)."""
+    api = F.api()
+    n = F.u32(0)
+    api.call("band_plan_for", width, height, upscale_ratio, band_index, band_count, stage, frame_number, C.byref(settings_c), None, C.byref(n))
+    ops = (F.HkHaloOp * max(n.value, 1))()
+    n2 = F.u32(n.value)
+    if n.value:
+        api.call("band_plan_for", width, height, upscale_ratio, band_index, band_count, stage, frame_number, C.byref(settings_c), ops, C.byref(n2))
+    return [ops[i] for i in range(n2.value)]
+
+
+class BandRenderer:
+    """Drives one rank's band of the frame; `engine` is a bevy_hikari_amd.Engine (or, in the CPU
+    tests, the oracle behind the same class)."""
+
+    def __init__(self, engine, rank, world_size, backend_device="cuda"):
+        import torch
+
+        self.torch = torch
+        self.engine, self.rank, self.world = engine, rank, world_size
+        self.device = backend_device
+        self._views = {}
+        engine.set_band(rank, world_size)
+
+    def _view(self, buf):
+        if buf not in self._views:
+            torch = self.torch
+            ptr, nbytes = self.engine.device_ptr(buf)
+            if self.device == "cuda":
+                t = torch.as_tensor(_DevView(ptr, nbytes), device="cuda")
+            else:
+                t = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)))
+            self._views[buf] = t
+        return self._views[buf]
+
+    def invalidate_views(self):  # after hk_resize
+        self._views = {}
+
+    def exchange(self, stage, frame_number, settings_c, width, height, upscale_ratio):
+        """Execute the halo plan of `stage` for every rank pair this rank takes part in."""
+        if self.world == 1:
+            return 0
+        import torch.distributed as dist
+
+        ops, nbytes = [], 0
+        for peer_rank in range(self.world):  # fixed global order: plans of rank 0, 1, ...
+            for op in halo_plan(width, height, upscale_ratio, peer_rank, self.world, stage, frame_number, settings_c):
+                lo, hi = op.row_begin * op.row_bytes, op.row_end * op.row_bytes
+                if peer_rank == self.rank:       # I receive rows owned by op.peer
+                    ops.append(dist.P2POp(dist.irecv, self._view(op.buffer)[lo:hi], op.peer))
+                    nbytes += hi - lo
+                elif op.peer == self.rank:       # peer_rank needs rows I own
+                    ops.append(dist.P2POp(dist.isend, self._view(op.buffer)[lo:hi], peer_rank))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return nbytes
+
+    def render(self, frame, view, previous_view, lights, settings, width, height):
+        """One frame: three stages with the two halo exchanges in between."""
+        e = self.engine
+        sc = settings.to_c()
+        ratio = settings.upscale.ratio()
+        e.frame_begin(frame, view, previous_view, lights)
+        e.frame_stage(F.STAGE_TEMPORAL, sc)
+        self._sync_before_exchange()
+        self.exchange(F.STAGE_SPATIAL, frame.number, sc, width, height, ratio)
+        e.frame_stage(F.STAGE_SPATIAL, sc)
+        self._sync_before_exchange()
+        self.exchange(F.STAGE_POST_PROCESS, frame.number, sc, width, height, ratio)
+        e.frame_stage(F.STAGE_POST_PROCESS, sc)
+
+    def _sync_before_exchange(self):
+        # When the engine runs on torch's current stream (Engine.set_stream), RCCL orders itself
+        # against that stream and nothing is needed.  On the engine's own stream (or the CPU
+        # oracle) wait for the stage to finish first.
+        if not getattr(self.engine, "on_host_stream", False):
+            self.engine.wait()
+
+    def band(self, rows):
+        base, rem = divmod(rows, self.world)
+        b0 = self.rank * base + min(self.rank, rem)
+        return b0, b0 + base + (1 if self.rank < rem else 0)

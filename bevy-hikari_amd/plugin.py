@@ -434,6 +434,10 @@ class Engine:
     def reset_stats(self):
         self.api.call("reset_stats", self.ctx)
 
+    def set_stream(self, hip_stream_ptr):
+        """Run all subsequent work on a host-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self.api.call("set_stream", self.ctx, C.c_void_p(hip_stream_ptr))
+
     def set_timing_mask(self, mask):
         self.api.call("set_timing_mask", self.ctx, mask)
 

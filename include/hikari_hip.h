@@ -398,6 +398,9 @@ int hk_write_buffer(hk_ctx* ctx, uint32_t buffer, const void* src, size_t bytes)
 /* raw device pointer for zero-copy views (halo exchange through RCCL / torch.distributed) */
 int hk_device_ptr(hk_ctx* ctx, uint32_t buffer, void** ptr, size_t* bytes);
 int hk_stream(hk_ctx* ctx, void** hip_stream);
+/* Enqueue all subsequent work on a HIP stream owned by the host (e.g. the stream its RCCL calls
+ * are ordered against) instead of the context's own stream; NULL restores the context's stream. */
+int hk_set_stream(hk_ctx* ctx, void* hip_stream);
 /* bit i set = bracket every dispatch of HkPass i with HIP events (see HkStats) */
 int hk_set_timing_mask(hk_ctx* ctx, uint32_t pass_mask);
 int hk_get_stats(hk_ctx* ctx, HkStats* out);

@@ -29,7 +29,21 @@ def oracle_api():
         }.items():
             fn = getattr(_API.dll, name)
             fn.argtypes, fn.restype = argtypes, C.c_int
+        _API.dll.orc_set_threads(default_threads())
     return _API
+
+
+def default_threads():
+    """Usable cores: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256 CPUs
+    but grants 16; running 256 OpenMP threads there is 50x slower than 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def oracle_engine():
