@@ -1,0 +1,90 @@
+"""Shared parity cases: (scene, camera, settings, lights, frame numbers).  Used by the golden
+generator, the oracle tests and the GPU parity tests."""
+import numpy as np
+
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+from bevy_hikari_amd.scenes import synthetic_camera, synthetic_scene
+
+ALL_BUFFERS = {F.BUF_POSITION: "position", F.BUF_NORMAL: "normal", F.BUF_DEPTH_GRADIENT: "depth_gradient",
+               F.BUF_INSTANCE_MATERIAL: "instance_material", F.BUF_VELOCITY_UV: "velocity_uv", F.BUF_ALBEDO: "albedo",
+               F.BUF_DENOISE_INTERNAL_VARIANCE: "internal_variance", F.BUF_TONE_MAPPED: "tone_mapped"}
+for _i in range(3):
+    ALL_BUFFERS[F.BUF_VARIANCE0 + _i] = f"variance{_i}"
+    ALL_BUFFERS[F.BUF_RENDER0 + _i] = f"render{_i}"
+    ALL_BUFFERS[F.BUF_DENOISE_RENDER0 + _i] = f"denoise_render{_i}"
+for _i in range(10):
+    ALL_BUFFERS[F.BUF_RESERVOIR0 + _i] = f"reservoir{_i}"
+for _i in range(4):
+    ALL_BUFFERS[F.BUF_DENOISE_INTERNAL0 + _i] = f"internal{_i}"
+
+
+class Case:
+    def __init__(self, name, scene, camera, settings, lights=None, frames=(1, 2, 3, 4)):
+        self.name, self.scene, self.camera, self.settings, self.frames = name, scene, camera, settings, list(frames)
+        self.lights = lights or hk.lights_uniform()
+
+
+_CACHE = {}
+
+
+def cornell_scene():
+    if "cornell" not in _CACHE:
+        _CACHE["cornell"] = hk.load_cornell()
+    return _CACHE["cornell"]
+
+
+def yard_scene():
+    if "yard" not in _CACHE:
+        _CACHE["yard"] = synthetic_scene(n_boxes=14, n_spheres=4, n_emitters=3, sphere_rings=6, sphere_segs=8)
+    return _CACHE["yard"]
+
+
+def make_case(name):
+    S, U = hk.HikariSettings, hk.Upscale
+    if name == "cornell_b2":       # BASELINE config 2 at a test size
+        return Case(name, cornell_scene(), hk.cornell_camera(96, 64), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0), frames=range(1, 7))
+    if name == "cornell_b1":       # BASELINE config 1 (1 bounce, defaults otherwise) at a test size, odd size: guards the grid rounding
+        return Case(name, cornell_scene(), hk.cornell_camera(100, 76), S(upscale=U.SMAA_TU_1_0), frames=range(1, 6))
+    if name == "cornell_upscale2":  # default Upscale (ratio 2.0, SMAA jitter) + emissive spatial reuse
+        return Case(name, cornell_scene(), hk.cornell_camera(128, 96), S(emissive_spatial_reuse=True), frames=range(1, 6))
+    if name == "cornell_ratio15_fsr":
+        return Case(name, cornell_scene(), hk.cornell_camera(90, 66), S(indirect_bounces=3, upscale=U.Fsr1(1.5, 0.2), taa=hk.Taa.NONE), frames=range(3, 7))
+    if name == "cornell_b0_nodenoise":
+        return Case(name, cornell_scene(), hk.cornell_camera(64, 64), S(indirect_bounces=0, denoise=False, upscale=U.SMAA_TU_1_0), frames=range(1, 4))
+    if name == "cornell_notemporal":
+        return Case(name, cornell_scene(), hk.cornell_camera(64, 48), S(temporal_reuse=False, indirect_spatial_reuse=False, upscale=U.SMAA_TU_1_0,
+                                                                       max_reservoir_lifetime=1.0), frames=range(1, 4))
+    if name == "yard_sun":          # several emitters (light-BVH pick, alias tables), sun cone, strips, scaled/rotated instances
+        scene, sun = yard_scene()
+        return Case(name, scene, synthetic_camera(96, 72), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0, emissive_spatial_reuse=True),
+                    lights=hk.lights_uniform(directional=sun), frames=range(1, 8))
+    raise KeyError(name)
+
+
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "yard_sun"]
+
+
+def run_case(plugin, case, on_frame=None):
+    plugin.set_scene(case.scene)
+    for n in case.frames:
+        plugin.render(case.camera, case.settings, lights=case.lights, frame_number=n)
+        if on_frame:
+            on_frame(n)
+    plugin.engine.wait()
+
+
+def snapshot(plugin):
+    return {name: plugin.engine.read(b) for b, name in ALL_BUFFERS.items()}
+
+
+def diff_buffers(a, b):
+    """Names of buffers whose bytes differ, with the first differing pixel."""
+    bad = {}
+    for name in a:
+        x, y = a[name], b[name]
+        ne = (x.view(np.uint8).reshape(x.shape[0], x.shape[1], -1) != y.view(np.uint8).reshape(y.shape[0], y.shape[1], -1)).any(axis=2)
+        if ne.any():
+            ys, xs = np.nonzero(ne)
+            bad[name] = f"{int(ne.sum())} px, first (x={xs[0]}, y={ys[0]}): {x[ys[0], xs[0]]} vs {y[ys[0], xs[0]]}"
+    return bad

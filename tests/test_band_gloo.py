@@ -1,0 +1,84 @@
+"""Multi-rank path on CPU: world_size 2 and 3 over gloo.  Each rank renders its band with the
+product's BandRenderer / halo plan (hk_band_plan_for) and torch.distributed P2P; the compute behind
+the C ABI is the oracle here (no GPU in this container), which is exactly what makes this a test
+of the sharding + exchange logic: the union of the bands must equal the single-rank frame bit for
+bit, for a static camera."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case_name, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bevy_hikari_amd as hk
+    from bevy_hikari_amd import _ffi as F
+    from bevy_hikari_amd.distributed import BandRenderer
+    from cases import ALL_BUFFERS, make_case
+    from oracle_lib import oracle_engine, set_threads
+
+    set_threads(2)
+    case = make_case(case_name)
+    s = case.settings
+    e = oracle_engine()
+    e.upload_noise()
+    e.upload_scene(case.scene)
+    w, h = case.camera.width, case.camera.height
+    e.resize(w, h, s.upscale.ratio())
+    r = BandRenderer(e, rank, world, backend_device="cpu")
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    for n in case.frames:
+        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h)
+    _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
+    b0, b1 = r.band(rh)
+    want = [F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2]
+    cur, prev = case.frames[-1] % 2, 1 - case.frames[-1] % 2
+    want += [F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8, F.BUF_RESERVOIR0 + prev + 2]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b0=b0, b1=b1, **{ALL_BUFFERS[b]: e.read(b)[b0:b1] for b in want if e.buffer_info(b)[1] == rh})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun")])
+def test_bands_equal_single_rank(tmp_path, world, case_name):
+    from cases import make_case, run_case, snapshot
+    from oracle_lib import oracle_plugin
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
+    case = make_case(case_name)
+    ref = oracle_plugin()
+    run_case(ref, case)
+    full = snapshot(ref)
+    rows = 0
+    for rank in range(world):
+        d = np.load(tmp_path / f"rank{rank}.npz")
+        b0, b1 = int(d["b0"]), int(d["b1"])
+        rows += b1 - b0
+        for key in d.files:
+            if key in ("b0", "b1"):
+                continue
+            a = full[key]
+            if a.shape[0] != full["tone_mapped"].shape[0]:
+                continue
+            assert (d[key].view(np.uint8) == a[b0:b1].view(np.uint8)).all(), f"rank {rank} band [{b0},{b1}) differs in {key}"
+    assert rows == full["tone_mapped"].shape[0]
