@@ -114,6 +114,14 @@ struct hk_ctx {
   float ratio = 1.0f;
   void* buf[HK_BUF_COUNT] = {};
   size_t buf_bytes[HK_BUF_COUNT] = {};
+  // private planes (no HkBuffer id): derived G-buffer planes and the denoiser's per-channel sets used
+  // when all channels of a level run in one launch (the exposed internals hold the LAST channel, which
+  // is what they hold after the reference's channel-by-channel loop)
+  float* depth_plane = nullptr;
+  void* dn_g = nullptr;
+  void* dn_extra[2][4] = {};
+  float* dn_extra_var[2] = {};
+  bool derived_dirty = false;
 
   // uniforms
   HkFrame frame{};
@@ -145,6 +153,18 @@ int free_screen(hk_ctx* c) {
     if (c->buf[b]) (void)hipFree(c->buf[b]);
     c->buf[b] = nullptr;
     c->buf_bytes[b] = 0;
+  }
+  if (c->depth_plane) (void)hipFree(c->depth_plane);
+  if (c->dn_g) (void)hipFree(c->dn_g);
+  c->depth_plane = nullptr;
+  c->dn_g = nullptr;
+  for (int k = 0; k < 2; ++k) {
+    for (int l = 0; l < 4; ++l) {
+      if (c->dn_extra[k][l]) (void)hipFree(c->dn_extra[k][l]);
+      c->dn_extra[k][l] = nullptr;
+    }
+    if (c->dn_extra_var[k]) (void)hipFree(c->dn_extra_var[k]);
+    c->dn_extra_var[k] = nullptr;
   }
   return HK_OK;
 }
@@ -390,6 +410,8 @@ GBuffer make_gbuffer(const hk_ctx* c) {
   g.depth_gradient = (float2*)c->buf[HK_BUF_DEPTH_GRADIENT];
   g.instance_material = (float2*)c->buf[HK_BUF_INSTANCE_MATERIAL];
   g.velocity_uv = (float4*)c->buf[HK_BUF_VELOCITY_UV];
+  g.depth = c->depth_plane;
+  g.dn_g = (uint4*)c->dn_g;
   return g;
 }
 // group 6 ping-pong, light.rs:376,480-481,518-546
@@ -438,10 +460,56 @@ void full_rows_for(const hk_ctx* c, int ry0, int ry1, int* fy0, int* fy1) {
   *fy1 = std::min(c->H, (int)ceilf((float)ry1 * (float)c->H / (float)c->RH) + 1);
 }
 
+// All denoised channels of one step in a single launch (kernels_denoise.hip).  Channel ch's internal
+// textures: the exposed HK_BUF_DENOISE_INTERNAL* for the last channel, private sets for the others.
+void* dn_internal(hk_ctx* c, uint32_t nch, uint32_t ch, int level) {
+  return ch + 1 == nch ? c->buf[HK_BUF_DENOISE_INTERNAL0 + level] : c->dn_extra[ch][level];
+}
+float* dn_variance(hk_ctx* c, uint32_t nch, uint32_t ch) {
+  return ch + 1 == nch ? (float*)c->buf[HK_BUF_DENOISE_INTERNAL_VARIANCE] : c->dn_extra_var[ch];
+}
+int run_demodulation_fused(hk_ctx* c, uint32_t nch, int y0, int y1) {
+  if (y1 <= y0) return HK_OK;
+  const DFrame fr = make_dframe(c);
+  ScopedTimer timer(c, HK_PASS_DEMODULATION);
+  DemodTargets d{};
+  d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
+  for (uint32_t ch = 0; ch < nch; ++ch) {
+    d.variance[ch] = (const float*)c->buf[HK_BUF_VARIANCE0 + ch];
+    d.render[ch] = (const uint2*)c->buf[HK_BUF_RENDER0 + ch];
+    d.output[ch] = (uint2*)dn_internal(c, nch, ch, 0);
+    d.internal_variance[ch] = dn_variance(c, nch, ch);
+  }
+  launch_demodulation(c->stream, (int)nch, fr, d, y0, y1);
+  HK_HIP(hipGetLastError());
+  return HK_OK;
+}
+int run_denoise_fused(hk_ctx* c, uint32_t nch, int level, int y0, int y1) {
+  if (y1 <= y0) return HK_OK;
+  const DFrame fr = make_dframe(c);
+  ScopedTimer timer(c, HK_PASS_DENOISE_L0 + (uint32_t)level);
+  DenoiseTargets d{};
+  d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
+  d.dn_g = (const uint4*)c->dn_g;
+  d.depth_gradient = (const float2*)c->buf[HK_BUF_DEPTH_GRADIENT];
+  for (uint32_t ch = 0; ch < nch; ++ch) {
+    d.input[ch] = (const uint2*)dn_internal(c, nch, ch, level);
+    d.output[ch] = level == 3 ? (uint2*)c->buf[HK_BUF_DENOISE_RENDER0 + ch] : (uint2*)dn_internal(c, nch, ch, level + 1);
+    d.internal_variance[ch] = dn_variance(c, nch, ch);
+  }
+  launch_denoise(c->stream, level, (int)nch, 0, fr, d, y0, y1);
+  HK_HIP(hipGetLastError());
+  return HK_OK;
+}
+
 int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
   const DFrame fr = make_dframe(c);
   const GBuffer g = make_gbuffer(c);
   unsigned long long* counters = (c->flags & HK_CTX_COUNT_RAYS) ? c->d_counters : nullptr;
+  if (c->derived_dirty && pass != HK_PASS_PREPASS) {  // G-buffer planes were written by the host: refresh the derived planes
+    launch_derive_planes(c->stream, g, c->depth_plane, c->dn_g, c->W, 0, c->H);
+    c->derived_dirty = false;
+  }
   ScopedTimer timer(c, pass);
   switch (pass) {
     case HK_PASS_PREPASS: {
@@ -459,14 +527,13 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     case HK_PASS_INDIRECT_SPATIAL_REUSE: launch_spatial(c->stream, false, c->scene, fr, g, make_light_targets(c, 2), y0, y1); break;
     case HK_PASS_DEMODULATION: {
       HK_REQUIRE(arg < 3, HK_E_INVALID, "channel out of range");
-      DenoiseTargets d{};
+      DemodTargets d{};
       d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
-      d.variance = (const float*)c->buf[HK_BUF_VARIANCE0 + arg];
-      d.render = (const uint2*)c->buf[HK_BUF_RENDER0 + arg];
-      d.input = nullptr;
-      d.output = (uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0];
-      d.internal_variance = (float*)c->buf[HK_BUF_DENOISE_INTERNAL_VARIANCE];
-      launch_demodulation(c->stream, fr, d, y0, y1);
+      d.variance[0] = (const float*)c->buf[HK_BUF_VARIANCE0 + arg];
+      d.render[0] = (const uint2*)c->buf[HK_BUF_RENDER0 + arg];
+      d.output[0] = (uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0];
+      d.internal_variance[0] = (float*)c->buf[HK_BUF_DENOISE_INTERNAL_VARIANCE];
+      launch_demodulation(c->stream, 1, fr, d, y0, y1);
       break;
     }
     case HK_PASS_DENOISE_L0: case HK_PASS_DENOISE_L1: case HK_PASS_DENOISE_L2: case HK_PASS_DENOISE_L3: {
@@ -474,13 +541,13 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       const int level = (int)(pass - HK_PASS_DENOISE_L0);
       DenoiseTargets d{};
       d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
-      d.variance = nullptr;
-      d.render = nullptr;
-      d.input = (const uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level];
-      d.output = level == 3 ? (uint2*)c->buf[HK_BUF_DENOISE_RENDER0 + arg] : (uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level + 1];
-      d.internal_variance = (float*)c->buf[HK_BUF_DENOISE_INTERNAL_VARIANCE];
+      d.dn_g = (const uint4*)c->dn_g;
+      d.depth_gradient = (const float2*)c->buf[HK_BUF_DEPTH_GRADIENT];
+      d.input[0] = (const uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level];
+      d.output[0] = level == 3 ? (uint2*)c->buf[HK_BUF_DENOISE_RENDER0 + arg] : (uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level + 1];
+      d.internal_variance[0] = (const float*)c->buf[HK_BUF_DENOISE_INTERNAL_VARIANCE];
       // denoise_direct has no FIREFLY_FILTERING, post_process.rs:773-783,1193-1197
-      launch_denoise(c->stream, level, arg != 0, fr, g, d, y0, y1);
+      launch_denoise(c->stream, level, 1, arg != 0 ? 1 : 0, fr, d, y0, y1);
       break;
     }
     case HK_PASS_TONE_MAPPING: {  // inputs per post_process.rs:941-954
@@ -635,6 +702,20 @@ int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
     HK_HIP(hipMemset(c->buf[b], 0, bytes));  // zeroed reservoirs, light.rs:352-360
     c->buf_bytes[b] = bytes;
   }
+  const size_t nf = (size_t)c->W * c->H, nr = (size_t)c->RW * c->RH;
+  HK_HIP(hipMalloc((void**)&c->depth_plane, nf * 4));
+  HK_HIP(hipMemset(c->depth_plane, 0, nf * 4));
+  HK_HIP(hipMalloc(&c->dn_g, nf * 16));
+  HK_HIP(hipMemset(c->dn_g, 0, nf * 16));
+  for (int k = 0; k < 2; ++k) {
+    for (int l = 0; l < 4; ++l) {
+      HK_HIP(hipMalloc(&c->dn_extra[k][l], nr * 8));
+      HK_HIP(hipMemset(c->dn_extra[k][l], 0, nr * 8));
+    }
+    HK_HIP(hipMalloc((void**)&c->dn_extra_var[k], nr * 4));
+    HK_HIP(hipMemset(c->dn_extra_var[k], 0, nr * 4));
+  }
+  c->derived_dirty = false;
   HK_HIP(hipDeviceSynchronize());
   return HK_OK;
 }
@@ -704,7 +785,12 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     }
     int f0, f1;
     full_rows_for(c, clampr(b0 - den - sp), clampr(b1 + den + sp), &f0, &f1);
-    if (!(flags & HK_FRAME_EXTERNAL_GBUFFER)) HK_RUN(HK_PASS_PREPASS, 0, f0, f1);
+    if (!(flags & HK_FRAME_EXTERNAL_GBUFFER)) {
+      HK_RUN(HK_PASS_PREPASS, 0, f0, f1);
+    } else if (f1 > f0) {  // host-rasterised G-buffer: only the derived planes are ours to fill
+      launch_derive_planes(c->stream, make_gbuffer(c), c->depth_plane, c->dn_g, c->W, f0, f1);
+      c->derived_dirty = false;
+    }
     int a0, a1;
     full_rows_for(c, clampr(b0 - den), clampr(b1 + den), &a0, &a1);
     HK_RUN(HK_PASS_FULL_SCREEN_ALBEDO, 0, a0, a1);  // light.rs:646-653
@@ -717,13 +803,16 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
   } else if (stage == HK_STAGE_POST_PROCESS) {
     if (st->denoise) {                               // post_process.rs:1190-1224
       const uint32_t nch = st->indirect_bounces == 0 ? 2u : 3u;  // post_process.rs:949-954
-      for (uint32_t ch = 0; ch < nch; ++ch) {
-        HK_RUN(HK_PASS_DEMODULATION, ch, clampr(b0 - 15), clampr(b1 + 15));
-        HK_RUN(HK_PASS_DENOISE_L0, ch, clampr(b0 - 7), clampr(b1 + 7));
-        HK_RUN(HK_PASS_DENOISE_L1, ch, clampr(b0 - 3), clampr(b1 + 3));
-        HK_RUN(HK_PASS_DENOISE_L2, ch, clampr(b0 - 1), clampr(b1 + 1));
-        HK_RUN(HK_PASS_DENOISE_L3, ch, b0, b1);
+      if (c->derived_dirty) {
+        launch_derive_planes(c->stream, make_gbuffer(c), c->depth_plane, c->dn_g, c->W, 0, c->H);
+        c->derived_dirty = false;
       }
+      // the reference's per-channel loop, with the channels of each step fused into one launch
+      if ((rc = run_demodulation_fused(c, nch, clampr(b0 - 15), clampr(b1 + 15)))) return rc;
+      if ((rc = run_denoise_fused(c, nch, 0, clampr(b0 - 7), clampr(b1 + 7)))) return rc;
+      if ((rc = run_denoise_fused(c, nch, 1, clampr(b0 - 3), clampr(b1 + 3)))) return rc;
+      if ((rc = run_denoise_fused(c, nch, 2, clampr(b0 - 1), clampr(b1 + 1)))) return rc;
+      if ((rc = run_denoise_fused(c, nch, 3, b0, b1))) return rc;
     }
     HK_RUN(HK_PASS_TONE_MAPPING, st->denoise ? 1u : 0u, b0, b1);  // post_process.rs:1226-1234
     if (c->timing_mask) {
@@ -776,6 +865,7 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
   HK_HIP(hipSetDevice(c->device));
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
+  if (buffer == HK_BUF_POSITION || buffer == HK_BUF_NORMAL || buffer == HK_BUF_INSTANCE_MATERIAL) c->derived_dirty = true;
   return HK_OK;
 }
 int hk_device_ptr(hk_ctx* c, uint32_t buffer, void** ptr, size_t* bytes) {

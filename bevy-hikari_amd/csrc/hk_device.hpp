@@ -400,7 +400,12 @@ HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t no
   }
   return intersected;
 }
-// stackless TLAS walk, light.wgsl:442-486
+// Two-level stackless walk, light.wgsl:442-486 (TLAS) with light.wgsl:400-440 (BLAS) inlined as ONE
+// loop: every iteration each live lane takes exactly one node step - of the TLAS or of the BLAS it
+// is currently inside - so lanes that sit in different instances (or still in the TLAS) execute the
+// same load + slab-test stream instead of serialising nested loops under partial exec masks.  Only
+// the two rare events diverge: entering an instance (ray transform) and a triangle test.  Each
+// lane's own visit order, and therefore every result bit, is that of the reference's nested loops.
 HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, RayCounters& rc) {
   rc.tlas++;
   Hit hit;
@@ -408,28 +413,84 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
   hit.distance = max_distance;
   hit.instance_index = HK_U32_MAX;
   hit.primitive_index = HK_U32_MAX;
-  uint32_t index = 0u;
-  while (index < sc.tlas_count) {
-    const float4 lo = sc.tlas_lo[index];
-    const float4 hi = sc.tlas_hi[index];
-    const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
-    const bool box_hit = intersects_aabb(ray, xyz(lo), xyz(hi)) < hit.distance;
-    if (entry >= HK_LEAF) {
-      const uint32_t instance_index = entry - HK_LEAF;
-      if (instance_index != exclude_instance && box_hit) {
-        const DInstance& in = sc.instances[instance_index];
-        Ray r;
-        r.origin = world_to_local_position(in, ray.origin);
-        r.direction = world_to_local_direction(in, ray.direction);
-        r.inv_direction = 1.0f / r.direction;
-        if (traverse_bottom(sc, hit, r, in.node_offset, in.node_count, in.primitive, early_distance)) {
-          hit.instance_index = instance_index;
+  uint32_t t_index = 0u;                 // next TLAS node
+  uint32_t b_index = 0u, b_count = 0u;   // BLAS cursor; b_count == 0 <=> walking the TLAS
+  uint32_t node_base = 0u, prim_base = 0u, cur_instance = 0u;
+  bool intersected = false;
+  f3 co = ray.origin, cinv = ray.inv_direction;  // origin / inverse direction of the level being walked
+  f3 ld = ray.direction;                          // local direction while inside a BLAS
+  for (;;) {
+    const bool in_blas = b_count != 0u;
+    if (in_blas) {
+      if (b_index >= b_count) {  // traverse_bottom returned, light.wgsl:465-470
+        if (intersected) {
+          hit.instance_index = cur_instance;
           if (hit.distance < early_distance) return hit;
         }
+        b_count = 0u;
+        co = ray.origin;
+        cinv = ray.inv_direction;
+        continue;
       }
-      index = exit_;
+    } else if (t_index >= sc.tlas_count) {
+      break;
+    }
+    const uint32_t idx = in_blas ? node_base + b_index : t_index;
+    const float4 lo = (in_blas ? sc.blas_lo : sc.tlas_lo)[idx];
+    const float4 hi = (in_blas ? sc.blas_hi : sc.tlas_hi)[idx];
+    const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
+    // intersects_aabb, light.wgsl:344-362, on the current level's ray
+    const f3 t1 = (xyz(lo) - co) * cinv;
+    const f3 t2 = (xyz(hi) - co) * cinv;
+    float t_min = fmin_(t1.x, t2.x);
+    float t_max = fmax_(t1.x, t2.x);
+    t_min = fmax_(t_min, fmin_(t1.y, t2.y));
+    t_max = fmin_(t_max, fmax_(t1.y, t2.y));
+    t_min = fmax_(t_min, fmin_(t1.z, t2.z));
+    t_max = fmin_(t_max, fmax_(t1.z, t2.z));
+    const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
+    const bool box_hit = t_box < hit.distance;
+    if (entry >= HK_LEAF) {
+      if (in_blas) {
+        b_index = exit_;
+        if (box_hit) {
+          const uint32_t primitive_index = prim_base + entry - HK_LEAF;
+          Ray lr;
+          lr.origin = co;
+          lr.direction = ld;
+          lr.inv_direction = cinv;
+          f2 uv;
+          const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+          if (d < hit.distance) {
+            hit.uv = uv;
+            hit.distance = d;
+            hit.primitive_index = primitive_index;
+            intersected = true;
+            if (d < early_distance) {  // light.wgsl:421-423 then 466-469
+              hit.instance_index = cur_instance;
+              return hit;
+            }
+          }
+        }
+      } else {
+        t_index = exit_;
+        const uint32_t instance_index = entry - HK_LEAF;
+        if (instance_index != exclude_instance && box_hit) {
+          const DInstance& in = sc.instances[instance_index];
+          co = world_to_local_position(in, ray.origin);
+          ld = world_to_local_direction(in, ray.direction);
+          cinv = 1.0f / ld;
+          node_base = in.node_offset;
+          prim_base = in.primitive;
+          b_count = in.node_count;
+          b_index = 0u;
+          cur_instance = instance_index;
+          intersected = false;
+        }
+      }
     } else {
-      index = box_hit ? entry : exit_;
+      const uint32_t next = box_hit ? entry : exit_;
+      if (in_blas) b_index = next; else t_index = next;
     }
   }
   return hit;

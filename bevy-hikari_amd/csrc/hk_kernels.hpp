@@ -13,6 +13,9 @@ struct GBuffer {
   float2* __restrict__ depth_gradient;    // rg32f
   float2* __restrict__ instance_material; // rg32f, id + 0.5
   float4* __restrict__ velocity_uv;       // rgba32f
+  // derived planes (not part of the reference's bindings): written by k_prepass / k_derive_planes
+  float* __restrict__ depth;              // position.w alone: 4-B taps for the spatial-reuse ray march
+  uint4* __restrict__ dn_g;               // bits of (depth, snorm8 normal, instance id, 0): one 16-B tap for the denoiser
 };
 // groups 5 + 6 for one light channel (light.wgsl:26-31,68-75; ping-pong light.rs:518-546)
 struct LightTargets {
@@ -23,19 +26,49 @@ struct LightTargets {
   float* variance;                               // r32f
   uint2* render;                                 // rgba16f
 };
-// groups 3 + 4 of the denoise pipeline (denoise.wgsl:10-28)
-struct DenoiseTargets {
+// groups 3 + 4 of the denoise pipeline (denoise.wgsl:10-28), for up to three channels per launch
+struct DemodTargets {
   const uint2* __restrict__ albedo;     // rgba16f, full size
-  const float* __restrict__ variance;   // light variance of this channel
-  const uint2* __restrict__ render;     // light render of this channel
-  const uint2* __restrict__ input;      // internal_texture_<level>
-  uint2* __restrict__ output;           // internal_texture_<level+1> / denoise_render[channel] / internal_texture_0 (demodulation)
-  float* internal_variance;
+  const float* variance[3];             // light variance per channel
+  const uint2* render[3];               // light render per channel
+  uint2* output[3];                     // internal_texture_0 per channel
+  float* internal_variance[3];
 };
+struct DenoiseTargets {
+  const uint2* __restrict__ albedo;
+  const uint4* __restrict__ dn_g;               // bits of (depth, snorm8 normal, instance id, 0) per full-size pixel
+  const float2* __restrict__ depth_gradient;
+  const uint2* input[3];                        // internal_texture_<level> per channel
+  uint2* output[3];                             // internal_texture_<level+1> / denoise_render[channel]
+  const float* internal_variance[3];
+};
+
+struct Pixel { int x, y; bool valid; };
+
+__device__ __forceinline__ Pixel pixel_of_thread(int width, int row_begin, int row_end) {
+  const int tiles_x = (width + 15) >> 4;
+  // XCD-aware remap of the linear workgroup id
+  const uint32_t nb = gridDim.x;
+  uint32_t b = blockIdx.x;
+  const uint32_t per = nb >> 3;
+  if (per > 0 && b < per * 8u) b = (b & 7u) * per + (b >> 3);
+  const int tile_x = (int)(b % (uint32_t)tiles_x), tile_y = (int)(b / (uint32_t)tiles_x);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Pixel p;
+  p.x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+  p.y = row_begin + tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  p.valid = p.x < width && p.y < row_end;
+  return p;
+}
 
 }  // namespace hkd
 
 namespace hk {
+static inline dim3 grid_for(int width, int rows) {
+  int tiles_x = (width + 15) / 16, tiles_y = (rows + 15) / 16;
+  return dim3((unsigned)(tiles_x * tiles_y), 1, 1);
+}
+
 void launch_prepass(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const float* inverse_view_proj, const float* view_proj,
                     const float* prev_view_proj, float jitter_x, float jitter_y, const hkd::GBuffer& g, int y0, int y1, unsigned long long* counters);
 void launch_albedo(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, void* albedo, int y0, int y1);
@@ -45,8 +78,9 @@ void launch_indirect(hipStream_t st, bool multiple_bounces, const hkd::DScene& s
                      const hkd::LightTargets& t, int y0, int y1, unsigned long long* counters);
 void launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                     int y0, int y1);
-void launch_demodulation(hipStream_t st, const hkd::DFrame& fr, const hkd::DenoiseTargets& d, int y0, int y1);
-void launch_denoise(hipStream_t st, int level, bool firefly, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::DenoiseTargets& d, int y0, int y1);
+void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);
+void launch_demodulation(hipStream_t st, int nch, const hkd::DFrame& fr, const hkd::DemodTargets& d, int y0, int y1);
+void launch_denoise(hipStream_t st, int level, int nch, int ffmask, const hkd::DFrame& fr, const hkd::DenoiseTargets& d, int y0, int y1);
 void launch_tone_mapping(hipStream_t st, const hkd::DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1);
 void launch_debug_math(hipStream_t st, uint32_t op, const float* x, const float* y, float* out, size_t n);
 }  // namespace hk

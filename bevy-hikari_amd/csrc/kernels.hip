@@ -24,24 +24,6 @@
 
 namespace hkd {
 
-struct Pixel { int x, y; bool valid; };
-
-__device__ __forceinline__ Pixel pixel_of_thread(int width, int row_begin, int row_end) {
-  const int tiles_x = (width + 15) >> 4;
-  // XCD-aware remap of the linear workgroup id
-  const uint32_t nb = gridDim.x;
-  uint32_t b = blockIdx.x;
-  const uint32_t per = nb >> 3;
-  if (per > 0 && b < per * 8u) b = (b & 7u) * per + (b >> 3);
-  const int tile_x = (int)(b % (uint32_t)tiles_x), tile_y = (int)(b / (uint32_t)tiles_x);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  Pixel p;
-  p.x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-  p.y = row_begin + tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);
-  p.valid = p.x < width && p.y < row_end;
-  return p;
-}
-
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const RayCounters& rc, uint32_t primary, unsigned long long* counters) {
   if (!COUNT) return;
@@ -100,6 +82,8 @@ __global__ __launch_bounds__(256) void k_prepass(DScene sc, DFrame fr, PrepassPa
       g.depth_gradient[idx] = make_float2(0, 0);
       g.instance_material[idx] = make_float2(0, 0);
       g.velocity_uv[idx] = make_float4(0, 0, 0, 0);
+      g.depth[idx] = 0.0f;
+      g.dn_g[idx] = make_uint4(0u, 0u, 0u, 0u);
     } else {
       const DInstance& in = sc.instances[hit.instance_index];
       const float4 q0 = sc.tri_v0[hit.primitive_index], q1 = sc.tri_v1[hit.primitive_index], q2 = sc.tri_v2[hit.primitive_index];
@@ -129,10 +113,13 @@ __global__ __launch_bounds__(256) void k_prepass(DScene sc, DFrame fr, PrepassPa
       }
       const f2 velocity = clip_to_uv(clip) - clip_to_uv(mul(pp.pvp0, pp.pvp1, pp.pvp2, pp.pvp3, F4(world_position, 1.0f)));
       g.position[idx] = make_float4(world_position.x, world_position.y, world_position.z, depth);
-      g.normal[idx] = pack4x8snorm(F4(wn, 1.0f));
+      const uint32_t packed_normal = pack4x8snorm(F4(wn, 1.0f));
+      g.normal[idx] = packed_normal;
       g.depth_gradient[idx] = make_float2(grad[0], grad[1]);
       g.instance_material[idx] = make_float2((float)hit.instance_index + 0.5f, (float)in.material + 0.5f);
       g.velocity_uv[idx] = make_float4(velocity.x, velocity.y, uv.x, uv.y);
+      g.depth[idx] = depth;
+      g.dn_g[idx] = make_uint4(f2u(depth), packed_normal, f2u((float)hit.instance_index + 0.5f), 0u);
     }
   }
   flush_counters<COUNT>(rc, primary, counters);
@@ -501,7 +488,7 @@ __global__ __launch_bounds__(256) void k_spatial_reuse(DScene sc, DFrame fr, GBu
     if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
     int sdx, sdy;
     jittered_deferred_coords(fr, sample_uv, &sdx, &sdy);
-    const float sample_depth = in_bounds(sdx, sdy, fr.dw, fr.dh) ? g.position[sdx + fr.dw * sdy].w : 0.0f;
+    const float sample_depth = in_bounds(sdx, sdy, fr.dw, fr.dh) ? g.depth[sdx + fr.dw * sdy] : 0.0f;
 
     const float depth_ratio = depth / sample_depth;
     if (depth_ratio < 0.9f || depth_ratio > 1.1f) continue;
@@ -523,7 +510,7 @@ __global__ __launch_bounds__(256) void k_spatial_reuse(DScene sc, DFrame fr, GBu
       const f2 tap_uv = uv + tap_offset / F2((float)fr.rw, (float)fr.rh);
       int tdx, tdy;
       jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
-      const float tap_depth = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.position[tdx + fr.dw * tdy].w : 0.0f;
+      const float tap_depth = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.depth[tdx + fr.dw * tdy] : 0.0f;
       const float ref_depth = mix(depth, sample_depth, (float)j / (float)(tap_count + 1u));
       if (tap_depth > ref_depth + 0.00001f) {
         occluded = true;
@@ -556,119 +543,7 @@ __global__ __launch_bounds__(256) void k_spatial_reuse(DScene sc, DFrame fr, GBu
   t.render[index] = pack_f16x4(F4(r.w * out_radiance, 1.0f));
 }
 
-// ------------------------------------------------------------------ denoise
-__global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:135-162
-  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
-  if (!px.valid) return;
-  const int x = px.x, y = px.y, index = x + fr.rw * y;
-  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
-  const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
-  int ax, ay, rx, ry;
-  nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
-  const f3 albedo = xyz(unpack_f16x4(d.albedo[ax + fr.dw * ay]));
-  nearest_coords(uv, fr.rw, fr.rh, &rx, &ry);
-  f3 irradiance = xyz(unpack_f16x4(d.render[rx + fr.rw * ry]));
-  const f3 qd = irradiance / albedo;
-  irradiance = F3(albedo.x < 0.01f ? 0.0f : qd.x, albedo.y < 0.01f ? 0.0f : qd.y, albedo.z < 0.01f ? 0.0f : qd.z);
-  d.output[index] = pack_f16x4(F4(irradiance, 1.0f));  // internal_texture_0
-
-  float sum_variance = 0.0f;
-#pragma unroll
-  for (int ox = -1; ox <= 1; ++ox) {
-#pragma unroll
-    for (int oy = -1; oy <= 1; ++oy) {  // call order of denoise.wgsl:152-160: x outer, y inner
-      const f2 sample_uv = uv + F2((float)ox, (float)oy) / F2((float)fr.rw, (float)fr.rh);
-      if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
-      int sx, sy;
-      nearest_coords(sample_uv, fr.rw, fr.rh, &sx, &sy);
-      const float variance = d.variance[sx + fr.rw * sy];
-      if (variance > HK_F32_MAX) continue;
-      sum_variance += fr.kernel[(oy + 1) * 3 + (ox + 1)] * fmax_(variance, 0.0f);
-    }
-  }
-  d.internal_variance[index] = sum_variance;
-}
-
-template <int LEVEL, bool FIREFLY>
-__global__ __launch_bounds__(256) void k_denoise(DFrame fr, GBuffer g, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:164-319
-  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
-  if (!px.valid) return;
-  constexpr int STEP = 8 >> LEVEL;
-  const int x = px.x, y = px.y, index = x + fr.rw * y;
-  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
-  const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
-  int dx, dy;
-  nearest_coords(deferred_uv, fr.dw, fr.dh, &dx, &dy);
-  const int didx = dx + fr.dw * dy;
-  const float depth = g.position[didx].w;
-  if (depth < HK_F32_EPSILON) {
-    d.output[index] = make_uint2(0u, 0u);
-    return;
-  }
-  const float2 dg = g.depth_gradient[didx];
-  const f2 depth_gradient = F2(dg.x, dg.y);
-  const f3 normal = normalize(xyz(unpack4x8snorm(g.normal[didx])));
-  const float instance = g.instance_material[didx].x;
-  const float variance = d.internal_variance[index];
-  f3 irradiance = xyz(unpack_f16x4(d.input[index]));
-  f3 sum_irradiance = irradiance * fr.kernel[4];
-  float sum_w = fr.kernel[4];
-  if (any_is_nan(irradiance) || irradiance.x > HK_F32_MAX || irradiance.y > HK_F32_MAX || irradiance.z > HK_F32_MAX) {
-    irradiance = F3(0, 0, 0);
-    sum_irradiance = F3(0, 0, 0);
-    sum_w = 0.0f;
-  }
-  const float lum = luminance(irradiance);
-  const float lum_denominator = 4.0f * pow_(variance, 0.25f) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
-  float ff_moment_1 = 0.0f, ff_moment_2 = 0.0f, ff_count = 0.0f;
-
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    constexpr int OX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-    constexpr int OY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
-    const int ox = OX[k], oy = OY[k];
-    const int sx = x + ox * STEP, sy = y + oy * STEP;
-    const f2 sample_uv = coords_to_uv(sx, sy, fr.rw, fr.rh);
-    if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
-    const f2 sample_deferred_uv = jittered_deferred_uv(fr, sample_uv, 0.5f);
-    const f3 irr = xyz(unpack_f16x4(d.input[sx + fr.rw * sy]));
-    if (any_is_nan(irr) || irr.x > HK_F32_MAX || irr.y > HK_F32_MAX || irr.z > HK_F32_MAX) continue;
-    int gx, gy;
-    nearest_coords(sample_deferred_uv, fr.dw, fr.dh, &gx, &gy);
-    const int gidx = gx + fr.dw * gy;
-    const f3 sample_normal = normalize(xyz(unpack4x8snorm(g.normal[gidx])));
-    const float sample_depth = g.position[gidx].w;
-    const float sample_instance = g.instance_material[gidx].x;
-    const float sample_luminance = luminance(irr);
-
-    const float w_normal = pow_(fmax_(0.0f, dot(normal, sample_normal)), 16.0f);
-    const float w_depth = exp_((-fabsf(depth - sample_depth)) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
-    const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - sample_instance));
-    const float w_luminance = exp_((-fabsf(lum - sample_luminance)) / lum_denominator);
-    const float w = clamp_(w_normal * w_depth * w_instance * w_luminance, 0.0f, 1.0f) * fr.kernel[(oy + 1) * 3 + (ox + 1)];
-    sum_irradiance = sum_irradiance + irr * w;
-    sum_w += w;
-    if (FIREFLY) {
-      ff_moment_1 += sample_luminance;
-      ff_moment_2 += sample_luminance * sample_luminance;
-      ff_count += 1.0f;
-    }
-  }
-  const f3 qd = sum_irradiance / sum_w;
-  irradiance = (sum_w < 0.0001f) ? F3(0, 0, 0) : qd;
-  if (FIREFLY) {
-    const float ff_mean = ff_moment_1 / ff_count;
-    const float ff_var = ff_moment_2 / ff_count - ff_mean * ff_mean;
-    if (lum > ff_mean + 3.0f * sqrtf(ff_var)) irradiance = ff_mean / lum * irradiance;
-  }
-  f4 color = F4(irradiance, 1.0f);
-  if (LEVEL == 3) {
-    int ax, ay;
-    nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
-    color = color * unpack_f16x4(d.albedo[ax + fr.dw * ay]);
-  }
-  d.output[index] = pack_f16x4(color);
-}
+// (demodulation + a-trous kernels live in kernels_denoise.hip)
 
 __global__ __launch_bounds__(256) void k_tone_mapping(DFrame fr, const uint2* __restrict__ direct, const uint2* __restrict__ emissive,
                                                        const uint2* __restrict__ indirect, uint2* __restrict__ out, int row_begin, int row_end) {  // tone_mapping.wgsl:21-32
@@ -730,10 +605,6 @@ __global__ void k_debug_math(uint32_t op, const float* __restrict__ x, const flo
 namespace hk {
 using namespace hkd;
 
-static inline dim3 grid_for(int width, int rows) {
-  int tiles_x = (width + 15) / 16, tiles_y = (rows + 15) / 16;
-  return dim3((unsigned)(tiles_x * tiles_y), 1, 1);
-}
 
 void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj,
                     const float* prev_view_proj, float jitter_x, float jitter_y, const GBuffer& g, int y0, int y1, unsigned long long* counters) {
@@ -784,24 +655,6 @@ void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const D
   dim3 grid = grid_for(fr.rw, y1 - y0);
   if (emissive_lit) hipLaunchKernelGGL(k_spatial_reuse<true>, grid, dim3(256), 0, st, sc, fr, g, t, y0, y1);
   else hipLaunchKernelGGL(k_spatial_reuse<false>, grid, dim3(256), 0, st, sc, fr, g, t, y0, y1);
-}
-void launch_demodulation(hipStream_t st, const DFrame& fr, const DenoiseTargets& d, int y0, int y1) {
-  if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_demodulation, grid_for(fr.rw, y1 - y0), dim3(256), 0, st, fr, d, y0, y1);
-}
-void launch_denoise(hipStream_t st, int level, bool firefly, const DFrame& fr, const GBuffer& g, const DenoiseTargets& d, int y0, int y1) {
-  if (y1 <= y0) return;
-  dim3 grid = grid_for(fr.rw, y1 - y0);
-#define HK_DN(L)                                                                                             \
-  if (firefly) hipLaunchKernelGGL((k_denoise<L, true>), grid, dim3(256), 0, st, fr, g, d, y0, y1);            \
-  else hipLaunchKernelGGL((k_denoise<L, false>), grid, dim3(256), 0, st, fr, g, d, y0, y1);
-  switch (level) {
-    case 0: HK_DN(0) break;
-    case 1: HK_DN(1) break;
-    case 2: HK_DN(2) break;
-    default: HK_DN(3) break;
-  }
-#undef HK_DN
 }
 void launch_tone_mapping(hipStream_t st, const DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1) {
   if (y1 <= y0) return;

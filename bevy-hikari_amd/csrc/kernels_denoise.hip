@@ -1,0 +1,212 @@
+// kernels_denoise.hip - demodulation + 4-level a-trous filter (denoise.wgsl:135-319) for gfx950.
+//
+// The reference runs, per render channel, demodulation then denoise L0..L3 (post_process.rs:
+// 1190-1224): 15 dispatches per frame, each re-reading the same G-buffer taps (normal, depth,
+// instance) from three planes.  Here
+//   * the per-tap geometry lives in ONE 16-B record per pixel (`dn_g` = depth, snorm8 normal bits,
+//     instance id), derived once per frame (k_derive_planes / k_prepass), so a tap costs one
+//     dwordx4 instead of a 16-B-strided depth read + two more loads;
+//   * all channels of one level run in ONE launch (template NCH): the geometric weights
+//     w_normal * w_depth * w_instance of a tap are channel-independent and computed once, only the
+//     luminance weight and the accumulation are per channel.  5 launches per frame instead of 15.
+// Per channel the arithmetic and its order are exactly the reference's, so results are bit-identical
+// to running the channels one after another (tests: nodes path == frame path, GPU == oracle).
+#include <hip/hip_runtime.h>
+
+#include "hk_device.hpp"
+#include "hk_kernels.hpp"
+
+namespace hkd {
+
+// depth plane (f32) for the spatial-reuse ray march + packed denoise geometry, from the G-buffer
+__global__ __launch_bounds__(256) void k_derive_planes(GBuffer g, float* __restrict__ depth_plane, uint4* __restrict__ dn_g, int width, int row_begin,
+                                                       int row_end) {
+  const Pixel px = pixel_of_thread(width, row_begin, row_end);
+  if (!px.valid) return;
+  const int idx = px.x + width * px.y;
+  const float depth = g.position[idx].w;
+  depth_plane[idx] = depth;
+  dn_g[idx] = make_uint4(f2u(depth), g.normal[idx], f2u(g.instance_material[idx].x), 0u);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d, int row_begin, int row_end) {  // denoise.wgsl:135-162
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  if (!px.valid) return;
+  const int x = px.x, y = px.y, index = x + fr.rw * y;
+  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
+  int ax, ay, rx, ry;
+  nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
+  const f3 albedo = xyz(unpack_f16x4(d.albedo[ax + fr.dw * ay]));
+  nearest_coords(uv, fr.rw, fr.rh, &rx, &ry);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    f3 irradiance = xyz(unpack_f16x4(d.render[ch][rx + fr.rw * ry]));
+    const f3 qd = irradiance / albedo;
+    irradiance = F3(albedo.x < 0.01f ? 0.0f : qd.x, albedo.y < 0.01f ? 0.0f : qd.y, albedo.z < 0.01f ? 0.0f : qd.z);
+    d.output[ch][index] = pack_f16x4(F4(irradiance, 1.0f));  // internal_texture_0
+  }
+  float sum_variance[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) sum_variance[ch] = 0.0f;
+#pragma unroll
+  for (int ox = -1; ox <= 1; ++ox) {
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy) {  // call order of denoise.wgsl:152-160: x outer, y inner
+      const f2 sample_uv = uv + F2((float)ox, (float)oy) / F2((float)fr.rw, (float)fr.rh);
+      if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
+      int sx, sy;
+      nearest_coords(sample_uv, fr.rw, fr.rh, &sx, &sy);
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const float variance = d.variance[ch][sx + fr.rw * sy];
+        if (variance > HK_F32_MAX) continue;
+        sum_variance[ch] += fr.kernel[(oy + 1) * 3 + (ox + 1)] * fmax_(variance, 0.0f);
+      }
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) d.internal_variance[ch][index] = sum_variance[ch];
+}
+
+// FFMASK bit ch = FIREFLY_FILTERING for channel ch (post_process.rs:773-783,1193-1197)
+template <int LEVEL, int NCH, int FFMASK>
+__global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:164-319
+  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  if (!px.valid) return;
+  constexpr int STEP = 8 >> LEVEL;
+  const int x = px.x, y = px.y, index = x + fr.rw * y;
+  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
+  int dx, dy;
+  nearest_coords(deferred_uv, fr.dw, fr.dh, &dx, &dy);
+  const int didx = dx + fr.dw * dy;
+  const uint4 gc = d.dn_g[didx];
+  const float depth = u2f(gc.x);
+  if (depth < HK_F32_EPSILON) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) d.output[ch][index] = make_uint2(0u, 0u);
+    return;
+  }
+  const float2 dg = d.depth_gradient[didx];
+  const f2 depth_gradient = F2(dg.x, dg.y);
+  const f3 normal = normalize(xyz(unpack4x8snorm(gc.y)));
+  const float instance = u2f(gc.z);
+
+  f3 sum_irradiance[NCH];
+  float sum_w[NCH], lum[NCH], lum_denominator[NCH], ff_moment_1[NCH], ff_moment_2[NCH], ff_count[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const float variance = d.internal_variance[ch][index];
+    f3 irradiance = xyz(unpack_f16x4(d.input[ch][index]));
+    sum_irradiance[ch] = irradiance * fr.kernel[4];
+    sum_w[ch] = fr.kernel[4];
+    if (any_is_nan(irradiance) || irradiance.x > HK_F32_MAX || irradiance.y > HK_F32_MAX || irradiance.z > HK_F32_MAX) {
+      irradiance = F3(0, 0, 0);
+      sum_irradiance[ch] = F3(0, 0, 0);
+      sum_w[ch] = 0.0f;
+    }
+    lum[ch] = luminance(irradiance);
+    lum_denominator[ch] = 4.0f * pow_(variance, 0.25f) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
+    ff_moment_1[ch] = 0.0f;
+    ff_moment_2[ch] = 0.0f;
+    ff_count[ch] = 0.0f;
+  }
+
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    constexpr int OX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    constexpr int OY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+    const int ox = OX[k], oy = OY[k];
+    const int sx = x + ox * STEP, sy = y + oy * STEP;
+    const f2 sample_uv = coords_to_uv(sx, sy, fr.rw, fr.rh);
+    if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
+    const f2 sample_deferred_uv = jittered_deferred_uv(fr, sample_uv, 0.5f);
+    int gx, gy;
+    nearest_coords(sample_deferred_uv, fr.dw, fr.dh, &gx, &gy);
+    const uint4 gs = d.dn_g[gx + fr.dw * gy];
+    const f3 sample_normal = normalize(xyz(unpack4x8snorm(gs.y)));
+    // channel-independent part of the weight, evaluated once
+    const float w_normal = pow_(fmax_(0.0f, dot(normal, sample_normal)), 16.0f);
+    const float w_depth = exp_((-fabsf(depth - u2f(gs.x))) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
+    const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - u2f(gs.z)));
+    const float w_geometry = w_normal * w_depth * w_instance;
+    const float kernel_w = fr.kernel[(oy + 1) * 3 + (ox + 1)];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const f3 irr = xyz(unpack_f16x4(d.input[ch][sx + fr.rw * sy]));
+      if (any_is_nan(irr) || irr.x > HK_F32_MAX || irr.y > HK_F32_MAX || irr.z > HK_F32_MAX) continue;
+      const float sample_luminance = luminance(irr);
+      const float w_luminance = exp_((-fabsf(lum[ch] - sample_luminance)) / lum_denominator[ch]);
+      const float w = clamp_(w_geometry * w_luminance, 0.0f, 1.0f) * kernel_w;
+      sum_irradiance[ch] = sum_irradiance[ch] + irr * w;
+      sum_w[ch] += w;
+      if ((FFMASK >> ch) & 1) {
+        ff_moment_1[ch] += sample_luminance;
+        ff_moment_2[ch] += sample_luminance * sample_luminance;
+        ff_count[ch] += 1.0f;
+      }
+    }
+  }
+  f4 albedo = F4(0, 0, 0, 0);
+  if (LEVEL == 3) {
+    int ax, ay;
+    nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
+    albedo = unpack_f16x4(d.albedo[ax + fr.dw * ay]);
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const f3 qd = sum_irradiance[ch] / sum_w[ch];
+    f3 irradiance = (sum_w[ch] < 0.0001f) ? F3(0, 0, 0) : qd;
+    if ((FFMASK >> ch) & 1) {
+      const float ff_mean = ff_moment_1[ch] / ff_count[ch];
+      const float ff_var = ff_moment_2[ch] / ff_count[ch] - ff_mean * ff_mean;
+      if (lum[ch] > ff_mean + 3.0f * sqrtf(ff_var)) irradiance = ff_mean / lum[ch] * irradiance;
+    }
+    f4 color = F4(irradiance, 1.0f);
+    if (LEVEL == 3) color = color * albedo;
+    d.output[ch][index] = pack_f16x4(color);
+  }
+}
+
+}  // namespace hkd
+
+namespace hk {
+using namespace hkd;
+
+void launch_derive_planes(hipStream_t st, const GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1) {
+  if (y1 <= y0) return;
+  hipLaunchKernelGGL(k_derive_planes, grid_for(width, y1 - y0), dim3(256), 0, st, g, depth_plane, (uint4*)dn_g, width, y0, y1);
+}
+
+void launch_demodulation(hipStream_t st, int nch, const DFrame& fr, const DemodTargets& d, int y0, int y1) {
+  if (y1 <= y0) return;
+  dim3 grid = grid_for(fr.rw, y1 - y0);
+  switch (nch) {
+    case 1: hipLaunchKernelGGL(k_demodulation<1>, grid, dim3(256), 0, st, fr, d, y0, y1); break;
+    case 2: hipLaunchKernelGGL(k_demodulation<2>, grid, dim3(256), 0, st, fr, d, y0, y1); break;
+    default: hipLaunchKernelGGL(k_demodulation<3>, grid, dim3(256), 0, st, fr, d, y0, y1); break;
+  }
+}
+
+template <int LEVEL>
+static void launch_denoise_level(hipStream_t st, int nch, int ffmask, const DFrame& fr, const DenoiseTargets& d, int y0, int y1) {
+  dim3 grid = grid_for(fr.rw, y1 - y0);
+  if (nch == 1 && ffmask == 0) hipLaunchKernelGGL((k_denoise<LEVEL, 1, 0>), grid, dim3(256), 0, st, fr, d, y0, y1);
+  else if (nch == 1) hipLaunchKernelGGL((k_denoise<LEVEL, 1, 1>), grid, dim3(256), 0, st, fr, d, y0, y1);
+  else if (nch == 2) hipLaunchKernelGGL((k_denoise<LEVEL, 2, 2>), grid, dim3(256), 0, st, fr, d, y0, y1);  // sun, emissive
+  else hipLaunchKernelGGL((k_denoise<LEVEL, 3, 6>), grid, dim3(256), 0, st, fr, d, y0, y1);                  // sun, emissive, indirect
+}
+// nch == 1: single channel with firefly filtering iff ffmask != 0; nch 2/3: the reference's channel order
+void launch_denoise(hipStream_t st, int level, int nch, int ffmask, const DFrame& fr, const DenoiseTargets& d, int y0, int y1) {
+  if (y1 <= y0) return;
+  switch (level) {
+    case 0: launch_denoise_level<0>(st, nch, ffmask, fr, d, y0, y1); break;
+    case 1: launch_denoise_level<1>(st, nch, ffmask, fr, d, y0, y1); break;
+    case 2: launch_denoise_level<2>(st, nch, ffmask, fr, d, y0, y1); break;
+    default: launch_denoise_level<3>(st, nch, ffmask, fr, d, y0, y1); break;
+  }
+}
+
+}  // namespace hk
