@@ -13,7 +13,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libhikari_hip.so")
+# HIKARI_HIP_LIB: development override for A/B-ing builds of the SAME library (tools/ab.sh)
+LIB_PATH = os.environ.get("HIKARI_HIP_LIB", os.path.join(HERE, "libhikari_hip.so"))
 
 HK_OK = 0
 HK_E_INVALID, HK_E_NO_DEVICE, HK_E_HIP, HK_E_NOT_READY, HK_E_NOMEM, HK_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6

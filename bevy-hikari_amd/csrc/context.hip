@@ -50,6 +50,18 @@ struct DevArray {
   }
 };
 
+// One device allocation for all scene arrays, each 16-B aligned.
+struct Blob {
+  std::vector<uint8_t> bytes;
+  template <typename T>
+  size_t add(const std::vector<T>& v) {
+    size_t off = (bytes.size() + 15) & ~(size_t)15;
+    bytes.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T), 0);
+    if (!v.empty()) memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+};
+
 struct TimedLaunch {
   uint32_t slot;
   hipEvent_t start, stop;
@@ -102,10 +114,7 @@ struct hk_ctx {
   bool scene_dirty = true;
 
   // device scene
-  DevArray<float4> tlas_lo, tlas_hi, blas_lo, blas_hi, tri_v0, tri_v1, tri_v2, vtx_normal, d_materials, light_lo, light_hi;
-  DevArray<float2> vtx_uv, d_alias;
-  DevArray<DInstance> d_instances;
-  DevArray<DEmissive> d_emissives;
+  DevArray<uint8_t> scene_blob;  // every scene array in one allocation (so small scenes can be staged in LDS by one copy loop)
   DevArray<uint32_t> d_noise;
   DScene scene{};
 
@@ -231,6 +240,7 @@ int finalize_scene(hk_ctx* c) {
     HK_REQUIRE(in.material < c->materials.size(), HK_E_INVALID, "instance material out of bounds");
     for (uint32_t k = 0; k < in.mesh.node_count; ++k) node_prim_offset[in.mesh.node_offset + k] = in.mesh.primitive;
   }
+  Blob blob;
   std::vector<float4> lo(n_nodes), hi(n_nodes);
   for (size_t i = 0; i < n_nodes; ++i) {
     const HkNode& n = c->asset_nodes[i];
@@ -247,9 +257,8 @@ int finalize_scene(hk_ctx* c) {
     lo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     hi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
-  int rc;
-  if ((rc = c->blas_lo.upload(lo))) return rc;
-  if ((rc = c->blas_hi.upload(hi))) return rc;
+  const size_t off_blas_lo = blob.add(lo);
+  const size_t off_blas_hi = blob.add(hi);
 
   std::vector<float4> v0(n_prims), v1(n_prims), v2(n_prims);
   for (size_t i = 0; i < n_prims; ++i) {
@@ -258,9 +267,9 @@ int finalize_scene(hk_ctx* c) {
     v1[i] = make_float4(v[1].position[0], v[1].position[1], v[1].position[2], as_f(v[1].index));
     v2[i] = make_float4(v[2].position[0], v[2].position[1], v[2].position[2], as_f(v[2].index));
   }
-  if ((rc = c->tri_v0.upload(v0))) return rc;
-  if ((rc = c->tri_v1.upload(v1))) return rc;
-  if ((rc = c->tri_v2.upload(v2))) return rc;
+  const size_t off_tri_v0 = blob.add(v0);
+  const size_t off_tri_v1 = blob.add(v1);
+  const size_t off_tri_v2 = blob.add(v2);
 
   std::vector<float4> vn(n_verts);
   std::vector<float2> vuv(n_verts);
@@ -268,8 +277,8 @@ int finalize_scene(hk_ctx* c) {
     vn[i] = make_float4(c->vertices[i].normal[0], c->vertices[i].normal[1], c->vertices[i].normal[2], 0.0f);
     vuv[i] = make_float2(c->vertices[i].u, c->vertices[i].v);
   }
-  if ((rc = c->vtx_normal.upload(vn))) return rc;
-  if ((rc = c->vtx_uv.upload(vuv))) return rc;
+  const size_t off_vtx_normal = blob.add(vn);
+  const size_t off_vtx_uv = blob.add(vuv);
 
   std::vector<DInstance> di(c->instances.size());
   for (size_t i = 0; i < di.size(); ++i) {
@@ -295,7 +304,7 @@ int finalize_scene(hk_ctx* c) {
     d.node_count = in.mesh.node_count;
     d.pad0 = d.pad1 = d.pad2 = 0;
   }
-  if ((rc = c->d_instances.upload(di))) return rc;
+  const size_t off_d_instances = blob.add(di);
 
   const size_t n_tlas = c->instance_nodes.size();
   std::vector<float4> tlo(n_tlas), thi(n_tlas);
@@ -312,8 +321,8 @@ int finalize_scene(hk_ctx* c) {
     tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
-  if ((rc = c->tlas_lo.upload(tlo))) return rc;
-  if ((rc = c->tlas_hi.upload(thi))) return rc;
+  const size_t off_tlas_lo = blob.add(tlo);
+  const size_t off_tlas_hi = blob.add(thi);
 
   std::vector<float4> mats(3 * c->materials.size());
   for (size_t i = 0; i < c->materials.size(); ++i) {
@@ -322,7 +331,7 @@ int finalize_scene(hk_ctx* c) {
     mats[3 * i + 1] = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
     mats[3 * i + 2] = make_float4(m.perceptual_roughness, m.metallic, m.reflectance, 0.0f);
   }
-  if ((rc = c->d_materials.upload(mats))) return rc;
+  const size_t off_d_materials = blob.add(mats);
 
   const size_t n_light = c->emissive_nodes.size();
   std::vector<float4> llo(n_light), lhi(n_light);
@@ -340,8 +349,8 @@ int finalize_scene(hk_ctx* c) {
     llo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     lhi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
-  if ((rc = c->light_lo.upload(llo))) return rc;
-  if ((rc = c->light_hi.upload(lhi))) return rc;
+  const size_t off_light_lo = blob.add(llo);
+  const size_t off_light_hi = blob.add(lhi);
 
   std::vector<DEmissive> de(c->emissives.size());
   for (size_t i = 0; i < de.size(); ++i) {
@@ -354,19 +363,27 @@ int finalize_scene(hk_ctx* c) {
     de[i].alias_count = e.alias_table[1];
     de[i].surface_area = e.surface_area;
   }
-  if ((rc = c->d_emissives.upload(de))) return rc;
+  const size_t off_d_emissives = blob.add(de);
   std::vector<float2> al(c->alias_table.size());
   for (size_t i = 0; i < al.size(); ++i) al[i] = make_float2(c->alias_table[i].prob, as_f(c->alias_table[i].index));
-  if ((rc = c->d_alias.upload(al))) return rc;
+  const size_t off_d_alias = blob.add(al);
 
+  // traversal-hot arrays were added first; pad to a whole float4 count
+  blob.bytes.resize((blob.bytes.size() + 15) & ~(size_t)15, 0);
+  int rc;
+  if ((rc = c->scene_blob.upload(blob.bytes))) return rc;
+  const uint8_t* base = c->scene_blob.p;
   DScene& s = c->scene;
-  s.tlas_lo = c->tlas_lo.p; s.tlas_hi = c->tlas_hi.p; s.instances = c->d_instances.p;
-  s.blas_lo = c->blas_lo.p; s.blas_hi = c->blas_hi.p;
-  s.tri_v0 = c->tri_v0.p; s.tri_v1 = c->tri_v1.p; s.tri_v2 = c->tri_v2.p;
-  s.vtx_normal = c->vtx_normal.p; s.vtx_uv = c->vtx_uv.p;
-  s.materials = c->d_materials.p;
-  s.light_lo = c->light_lo.p; s.light_hi = c->light_hi.p;
-  s.emissives = c->d_emissives.p; s.alias = c->d_alias.p;
+  s.blob = (const float4*)base;
+  s.blob_f4 = (uint32_t)(blob.bytes.size() / 16);
+  s.tlas_lo = (const float4*)(base + off_tlas_lo); s.tlas_hi = (const float4*)(base + off_tlas_hi);
+  s.instances = (const DInstance*)(base + off_d_instances);
+  s.blas_lo = (const float4*)(base + off_blas_lo); s.blas_hi = (const float4*)(base + off_blas_hi);
+  s.tri_v0 = (const float4*)(base + off_tri_v0); s.tri_v1 = (const float4*)(base + off_tri_v1); s.tri_v2 = (const float4*)(base + off_tri_v2);
+  s.vtx_normal = (const float4*)(base + off_vtx_normal); s.vtx_uv = (const float2*)(base + off_vtx_uv);
+  s.materials = (const float4*)(base + off_d_materials);
+  s.light_lo = (const float4*)(base + off_light_lo); s.light_hi = (const float4*)(base + off_light_hi);
+  s.emissives = (const DEmissive*)(base + off_d_emissives); s.alias = (const float2*)(base + off_d_alias);
   s.noise = c->d_noise.p;
   s.tlas_count = (uint32_t)n_tlas;
   s.light_count = (uint32_t)n_light;
@@ -613,10 +630,8 @@ void hk_destroy(hk_ctx* c) {
   if (c->frame_start) (void)hipEventDestroy(c->frame_start);
   if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
   free_screen(c);
-  c->tlas_lo.release(); c->tlas_hi.release(); c->blas_lo.release(); c->blas_hi.release();
-  c->tri_v0.release(); c->tri_v1.release(); c->tri_v2.release(); c->vtx_normal.release(); c->vtx_uv.release();
-  c->d_materials.release(); c->light_lo.release(); c->light_hi.release(); c->d_alias.release();
-  c->d_instances.release(); c->d_emissives.release(); c->d_noise.release();
+  c->scene_blob.release();
+  c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;

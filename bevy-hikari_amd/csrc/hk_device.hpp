@@ -70,6 +70,8 @@ struct DScene {
   const float2* __restrict__ alias;      // (prob, index bits)
   const uint32_t* __restrict__ noise;    // 16 x 64 x 64 RGBA8
   uint32_t tlas_count, light_count;
+  const float4* __restrict__ blob;       // all arrays above (except noise) live in [blob, blob + blob_f4)
+  uint32_t blob_f4;
 };
 // per-frame constants, passed by value (lands in SGPRs / scalar cache)
 struct DFrame {

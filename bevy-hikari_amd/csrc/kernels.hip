@@ -24,6 +24,29 @@
 
 namespace hkd {
 
+// Small scenes (the whole Cornell box is 9 KB) are copied into LDS once per workgroup and traversed
+// from there: a node step is then a ds_read_b128 pair (~64-cycle latency, 128+ B/clk/CU) instead of
+// an L1-hit global load (~120+ cycles) in the dependent load -> slab test -> next-index chain.
+template <bool LDS>
+__device__ __forceinline__ DScene stage_scene(const DScene& sc) {
+  if constexpr (!LDS) {
+    return sc;
+  } else {
+    extern __shared__ __attribute__((aligned(16))) float4 hk_smem[];
+    for (uint32_t i = threadIdx.x; i < sc.blob_f4; i += 256u) hk_smem[i] = sc.blob[i];
+    __syncthreads();
+    DScene l = sc;
+    const char* gb = reinterpret_cast<const char*>(sc.blob);
+    const char* lb = reinterpret_cast<const char*>(hk_smem);
+#define HK_REBASE(field) l.field = reinterpret_cast<decltype(l.field)>(lb + (reinterpret_cast<const char*>(sc.field) - gb))
+    HK_REBASE(tlas_lo); HK_REBASE(tlas_hi); HK_REBASE(instances); HK_REBASE(blas_lo); HK_REBASE(blas_hi);
+    HK_REBASE(tri_v0); HK_REBASE(tri_v1); HK_REBASE(tri_v2); HK_REBASE(vtx_normal); HK_REBASE(vtx_uv);
+    HK_REBASE(materials); HK_REBASE(light_lo); HK_REBASE(light_hi); HK_REBASE(emissives); HK_REBASE(alias);
+#undef HK_REBASE
+    return l;
+  }
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const RayCounters& rc, uint32_t primary, unsigned long long* counters) {
   if (!COUNT) return;
@@ -64,9 +87,10 @@ __device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams
   return ray;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(256) void k_prepass(DScene sc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
+template <bool COUNT, bool LDS>
+__global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
                                                   unsigned long long* counters) {
+  const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread(fr.dw, row_begin, row_end);
   RayCounters rc{0, 0};
   uint32_t primary = 0;
@@ -143,9 +167,10 @@ __global__ __launch_bounds__(256) void k_full_screen_albedo(DScene sc, DFrame fr
 }
 
 // ------------------------------------------------------------------ direct_lit
-template <bool EMISSIVE_LIT, bool COUNT>
-__global__ __launch_bounds__(256) void k_direct_lit(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+template <bool EMISSIVE_LIT, bool COUNT, bool LDS>
+__global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                      unsigned long long* counters) {
+  const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
   RayCounters rc{0, 0};
   if (px.valid) {
@@ -268,9 +293,10 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene sc, DFrame fr, GBuffe
 }
 
 // ------------------------------------------------------------------ indirect_lit_ambient
-template <bool MULTIPLE_BOUNCES, bool COUNT>
-__global__ __launch_bounds__(256) void k_indirect(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+template <bool MULTIPLE_BOUNCES, bool COUNT, bool LDS>
+__global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                    unsigned long long* counters) {
+  const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
   RayCounters rc{0, 0};
   if (px.valid) {
@@ -432,7 +458,7 @@ __global__ __launch_bounds__(256) void k_indirect(DScene sc, DFrame fr, GBuffer 
 // (light.wgsl:1500-1501,1522-1524,1584-1591); the cached values are exactly what the buffer
 // loads return, so reading neighbours from L2 is result-identical.
 template <bool EMISSIVE_LIT>
-__global__ __launch_bounds__(256) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end) {
+__global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end) {
   const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
   if (!px.valid) return;
   constexpr uint32_t SPATIAL_REUSE_COUNT = EMISSIVE_LIT ? 8u : 16u;
@@ -606,6 +632,9 @@ namespace hk {
 using namespace hkd;
 
 
+// LDS staging is used when the whole scene blob fits comfortably (4 workgroups per CU stay resident)
+static inline size_t lds_bytes_for(const DScene& sc) { return (size_t)sc.blob_f4 * 16 <= 32768 ? (size_t)sc.blob_f4 * 16 : 0; }
+
 void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj,
                     const float* prev_view_proj, float jitter_x, float jitter_y, const GBuffer& g, int y0, int y1, unsigned long long* counters) {
   if (y1 <= y0) return;
@@ -617,10 +646,13 @@ void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const fl
   pp.jitter_x = jitter_x;
   pp.jitter_y = jitter_y;
   dim3 grid = grid_for(fr.dw, y1 - y0);
+  const size_t lds = lds_bytes_for(sc);
   if (counters)
-    hipLaunchKernelGGL(k_prepass<true>, grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+    hipLaunchKernelGGL((k_prepass<true, false>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+  else if (lds)
+    hipLaunchKernelGGL((k_prepass<false, true>), grid, dim3(256), lds, st, sc, fr, pp, g, y0, y1, counters);
   else
-    hipLaunchKernelGGL(k_prepass<false>, grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+    hipLaunchKernelGGL((k_prepass<false, false>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
 }
 void launch_albedo(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, void* albedo, int y0, int y1) {
   if (y1 <= y0) return;
@@ -630,25 +662,25 @@ void launch_direct(hipStream_t st, bool emissive_lit, const DScene& sc, const DF
                    unsigned long long* counters) {
   if (y1 <= y0) return;
   dim3 grid = grid_for(fr.rw, y1 - y0);
-  if (emissive_lit) {
-    if (counters) hipLaunchKernelGGL((k_direct_lit<true, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-    else hipLaunchKernelGGL((k_direct_lit<true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-  } else {
-    if (counters) hipLaunchKernelGGL((k_direct_lit<false, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-    else hipLaunchKernelGGL((k_direct_lit<false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-  }
+  const size_t lds = lds_bytes_for(sc);
+#define HK_LAUNCH(E)                                                                                                           \
+  if (counters) hipLaunchKernelGGL((k_direct_lit<E, true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);      \
+  else if (lds) hipLaunchKernelGGL((k_direct_lit<E, false, true>), grid, dim3(256), lds, st, sc, fr, g, t, y0, y1, counters);    \
+  else hipLaunchKernelGGL((k_direct_lit<E, false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+  if (emissive_lit) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
+#undef HK_LAUNCH
 }
 void launch_indirect(hipStream_t st, bool multiple_bounces, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1,
                      unsigned long long* counters) {
   if (y1 <= y0) return;
   dim3 grid = grid_for(fr.rw, y1 - y0);
-  if (multiple_bounces) {
-    if (counters) hipLaunchKernelGGL((k_indirect<true, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-    else hipLaunchKernelGGL((k_indirect<true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-  } else {
-    if (counters) hipLaunchKernelGGL((k_indirect<false, true>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-    else hipLaunchKernelGGL((k_indirect<false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
-  }
+  const size_t lds = lds_bytes_for(sc);
+#define HK_LAUNCH(M)                                                                                                         \
+  if (counters) hipLaunchKernelGGL((k_indirect<M, true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);      \
+  else if (lds) hipLaunchKernelGGL((k_indirect<M, false, true>), grid, dim3(256), lds, st, sc, fr, g, t, y0, y1, counters);    \
+  else hipLaunchKernelGGL((k_indirect<M, false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+  if (multiple_bounces) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
+#undef HK_LAUNCH
 }
 void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1) {
   if (y1 <= y0) return;
