@@ -67,6 +67,8 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        torch.cuda.set_stream(torch.cuda.Stream())  # a real stream handle (the default stream's is 0)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -91,8 +93,9 @@ def main():
         e.resize(W, H, 1.0)
         r = None
         if world > 1:
+            # run the library on the (non-default) torch stream RCCL orders itself against
             e.set_stream(torch.cuda.current_stream().cuda_stream)
-            e.on_host_stream = True
+            e.on_host_stream = torch.cuda.current_stream().cuda_stream != 0
             r = BandRenderer(e, rank, world)
         return e, r
 

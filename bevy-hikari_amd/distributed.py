@@ -77,18 +77,30 @@ class BandRenderer:
             return 0
         import torch.distributed as dist
 
-        ops, nbytes = [], 0
+        # RCCL moves device memory directly; gloo (CPU tests, and the one-GPU two-rank test) cannot
+        # address device memory, so device views are staged through host tensors there.
+        staged = self.device == "cuda" and dist.get_backend() != "nccl"
+        ops, nbytes, landing = [], 0, []
         for peer_rank in range(self.world):  # fixed global order: plans of rank 0, 1, ...
             for op in halo_plan(width, height, upscale_ratio, peer_rank, self.world, stage, frame_number, settings_c):
                 lo, hi = op.row_begin * op.row_bytes, op.row_end * op.row_bytes
+                view = self._view(op.buffer)[lo:hi]
                 if peer_rank == self.rank:       # I receive rows owned by op.peer
-                    ops.append(dist.P2POp(dist.irecv, self._view(op.buffer)[lo:hi], op.peer))
+                    if staged:
+                        tmp = self.torch.empty(hi - lo, dtype=self.torch.uint8)
+                        landing.append((view, tmp))
+                        view = tmp
+                    ops.append(dist.P2POp(dist.irecv, view, op.peer))
                     nbytes += hi - lo
                 elif op.peer == self.rank:       # peer_rank needs rows I own
-                    ops.append(dist.P2POp(dist.isend, self._view(op.buffer)[lo:hi], peer_rank))
+                    ops.append(dist.P2POp(dist.isend, view.cpu() if staged else view, peer_rank))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        for view, tmp in landing:
+            view.copy_(tmp)
+        if landing:
+            self.torch.cuda.synchronize()
         return nbytes
 
     def render(self, frame, view, previous_view, lights, settings, width, height):

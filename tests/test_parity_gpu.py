@@ -170,3 +170,70 @@ def test_band_renderer_single_gpu_views():
     host = p.engine.read(F.BUF_TONE_MAPPED)
     assert t.is_cuda and t.numel() == host.nbytes
     assert (t.cpu().numpy() == host.view(np.uint8).reshape(-1)).all()
+
+
+def _gpu_band_worker(rank, world, port, case_name, out_dir):
+    import sys
+
+    import torch.distributed as dist
+
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch
+
+    import bevy_hikari_amd as hk
+    from bevy_hikari_amd.distributed import BandRenderer
+    from cases import ALL_BUFFERS, make_case
+
+    case = make_case(case_name)
+    s = case.settings
+    e = hk.Engine(device=0)
+    e.upload_noise()
+    e.upload_scene(case.scene)
+    w, h = case.camera.width, case.camera.height
+    e.resize(w, h, s.upscale.ratio())
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    e.set_stream(stream.cuda_stream)  # same stream discipline as bench.py
+    r = BandRenderer(e, rank, world)
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    for n in case.frames:
+        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h)
+    e.wait()
+    _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
+    b0, b1 = r.band(rh)
+    prev = 1 - case.frames[-1] % 2
+    want = [F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2,
+            F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8]
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b0=b0, b1=b1, **{ALL_BUFFERS[b]: e.read(b)[b0:b1] for b in want})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun")])
+def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
+    """The band-sharded GPU path (hk_set_band + hk_frame_stage + halo exchange) on ONE GPU: every
+    rank renders its band on device 0, halos travel over gloo (staged through host memory because
+    RCCL refuses two ranks on one device); the union must equal the single-context frame."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gpu_band_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
+    case = make_case(case_name)
+    ref = hk.HikariPlugin(device=0)
+    run_case(ref, case)
+    full = snapshot(ref)
+    for rank in range(world):
+        d = np.load(tmp_path / f"rank{rank}.npz")
+        b0, b1 = int(d["b0"]), int(d["b1"])
+        for key in d.files:
+            if key not in ("b0", "b1"):
+                assert (d[key].view(np.uint8) == full[key][b0:b1].view(np.uint8)).all(), f"rank {rank} [{b0},{b1}) differs in {key}"
