@@ -709,14 +709,50 @@ HKD f4 input_radiance(const DScene& sc, const DFrame& fr, const Ray& ray, const 
   }
   return F4(radiance, 1.0f - ambient_);
 }
-HKD f3 shading(const DFrame& fr, f3 V, f3 N, f3 L, const Surface& surface, f4 in_radiance) {  // light.wgsl:869-888
+// shading() split into the part that depends only on (V, N, surface) and the part that depends on
+// the light direction, so kernels that shade one site against many directions (spatial_reuse: up to
+// 18 per pixel) evaluate the view/ambient terms once.  Same operations in the same order as
+// lit() + ambient() + the mix of light.wgsl:869-888 - only evaluated once instead of per call.
+struct ShadingSite {
+  f3 V, N, F0, diffuse_color, ambient_radiance;
+  float roughness, NdotV, view_pow5, fresnel_f90;
+};
+HKD ShadingSite make_site(const DFrame& fr, f3 V, f3 N, const Surface& surface) {
+  ShadingSite st;
   f3 base_color = xyz(surface.base_color);
-  float reflectance = surface.reflectance, roughness = surface.roughness, metallic = surface.metallic, occlusion = surface.occlusion;
-  f3 F0 = F3s(0.16f * reflectance * reflectance * (1.0f - metallic)) + base_color * metallic;
-  f3 diffuse_color = base_color * (1.0f - metallic);
-  f3 lit_radiance = lit(xyz(in_radiance), diffuse_color, roughness, F0, L, N, V);
-  f3 ambient_radiance = env_brdf_terms(diffuse_color, roughness, occlusion, F0, N, V) * F3(fr.amb_r, fr.amb_g, fr.amb_b);
-  return mix(lit_radiance, ambient_radiance, 1.0f - in_radiance.w);
+  float reflectance = surface.reflectance, metallic = surface.metallic, occlusion = surface.occlusion;
+  st.V = V;
+  st.N = N;
+  st.roughness = surface.roughness;
+  st.F0 = F3s(0.16f * reflectance * reflectance * (1.0f - metallic)) + base_color * metallic;
+  st.diffuse_color = base_color * (1.0f - metallic);
+  st.NdotV = fmax_(dot(N, V), 0.0001f);
+  st.view_pow5 = pow_(1.0f - st.NdotV, 5.0f);                    // F_Schlick(1, f90, NoV) of Fd_Burley
+  st.fresnel_f90 = saturate(dot(st.F0, F3s(50.0f * 0.33f)));     // fresnel()
+  st.ambient_radiance = env_brdf_terms(st.diffuse_color, st.roughness, occlusion, st.F0, N, V) * F3(fr.amb_r, fr.amb_g, fr.amb_b);
+  return st;
+}
+HKD f3 shade(const ShadingSite& st, f3 L, f4 in_radiance) {
+  f3 Hh = normalize(L + st.V);
+  float NoL = saturate(dot(st.N, L));
+  float NoH = saturate(dot(st.N, Hh));
+  float LoH = saturate(dot(L, Hh));
+  // Fd_Burley
+  float f90 = 0.5f + 2.0f * st.roughness * LoH * LoH;
+  float lightScatter = 1.0f + (f90 - 1.0f) * pow_(1.0f - NoL, 5.0f);
+  float viewScatter = 1.0f + (f90 - 1.0f) * st.view_pow5;
+  f3 diffuse = st.diffuse_color * (lightScatter * viewScatter * (1.0f / HK_PI));
+  // specular
+  float D = D_GGX(st.roughness, NoH);
+  float Vs = V_SmithGGXCorrelated(st.roughness, st.NdotV, NoL);
+  float p = pow_(1.0f - LoH, 5.0f);
+  f3 F = st.F0 + (F3s(st.fresnel_f90) - st.F0) * p;
+  f3 specular_light = (1.0f * D * Vs) * F;
+  f3 lit_radiance = (specular_light + diffuse) * xyz(in_radiance) * NoL;
+  return mix(lit_radiance, st.ambient_radiance, 1.0f - in_radiance.w);
+}
+HKD f3 shading(const DFrame& fr, f3 V, f3 N, f3 L, const Surface& surface, f4 in_radiance) {  // light.wgsl:869-888
+  return shade(make_site(fr, V, N, surface), L, in_radiance);
 }
 HKD f3 env_brdf(f3 V, f3 N, const Surface& surface) {  // light.wgsl:890-908
   f3 base_color = xyz(surface.base_color);

@@ -492,10 +492,11 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
   if (r.lifetime <= max_lifetime) r = load_reservoir_uv(t.previous_spatial, previous_uv, fr.rw, fr.rh);
 
   const f3 view_direction = calculate_view(fr, position);
+  const ShadingSite site = make_site(fr, view_direction, s.visible_normal, surface);  // one site, up to 18 light directions
   if (EMISSIVE_LIT) {
     merge_reservoir(r, q, luminance(xyz(q.s.radiance)));
   } else {
-    f3 out_radiance = shading(fr, view_direction, s.visible_normal, normalize(xyz(s.sample_position) - xyz(s.visible_position)), surface, s.radiance);
+    f3 out_radiance = shade(site, normalize(xyz(s.sample_position) - xyz(s.visible_position)), s.radiance);
     merge_reservoir(r, q, luminance(out_radiance));
   }
   r.s.visible_position = s.visible_position;
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     if (EMISSIVE_LIT) {
       merge_reservoir(r, q, luminance(xyz(q.s.radiance)) / jacobian);
     } else {
-      f3 out_radiance = shading(fr, view_direction, s.visible_normal, sample_direction, surface, q.s.radiance);
+      f3 out_radiance = shade(site, sample_direction, q.s.radiance);
       merge_reservoir(r, q, luminance(out_radiance) / jacobian);
     }
   }
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     r.w2_sum *= m / r.count;
     r.count = m;
   }
-  const f3 out_radiance = shading(fr, view_direction, s.visible_normal, normalize(xyz(r.s.sample_position) - xyz(s.visible_position)), surface, r.s.radiance);
+  const f3 out_radiance = shade(site, normalize(xyz(r.s.sample_position) - xyz(s.visible_position)), r.s.radiance);
   const float total_lum = EMISSIVE_LIT ? r.count * luminance(xyz(r.s.radiance)) : r.count * luminance(out_radiance);
   r.w = (total_lum > 0.0f) ? r.w_sum / total_lum : 0.0f;
   r.lifetime += 1.0f;
