@@ -257,8 +257,6 @@ int finalize_scene(hk_ctx* c) {
     lo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     hi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
-  const size_t off_blas_lo = blob.add(lo);
-  const size_t off_blas_hi = blob.add(hi);
 
   std::vector<float4> v0(n_prims), v1(n_prims), v2(n_prims);
   for (size_t i = 0; i < n_prims; ++i) {
@@ -321,8 +319,12 @@ int finalize_scene(hk_ctx* c) {
     tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
-  const size_t off_tlas_lo = blob.add(tlo);
-  const size_t off_tlas_hi = blob.add(thi);
+  // unified node array: TLAS first, then every BLAS; lo/hi interleaved (32 B per node)
+  std::vector<float4> nodes;
+  nodes.reserve(2 * (n_tlas + n_nodes));
+  for (size_t i = 0; i < n_tlas; ++i) { nodes.push_back(tlo[i]); nodes.push_back(thi[i]); }
+  for (size_t i = 0; i < n_nodes; ++i) { nodes.push_back(lo[i]); nodes.push_back(hi[i]); }
+  const size_t off_nodes = blob.add(nodes);
 
   std::vector<float4> mats(3 * c->materials.size());
   for (size_t i = 0; i < c->materials.size(); ++i) {
@@ -376,9 +378,9 @@ int finalize_scene(hk_ctx* c) {
   DScene& s = c->scene;
   s.blob = (const float4*)base;
   s.blob_f4 = (uint32_t)(blob.bytes.size() / 16);
-  s.tlas_lo = (const float4*)(base + off_tlas_lo); s.tlas_hi = (const float4*)(base + off_tlas_hi);
+  s.nodes = (const float4*)(base + off_nodes);
+  s.blas_base = (uint32_t)n_tlas;
   s.instances = (const DInstance*)(base + off_d_instances);
-  s.blas_lo = (const float4*)(base + off_blas_lo); s.blas_hi = (const float4*)(base + off_blas_hi);
   s.tri_v0 = (const float4*)(base + off_tri_v0); s.tri_v1 = (const float4*)(base + off_tri_v1); s.tri_v2 = (const float4*)(base + off_tri_v2);
   s.vtx_normal = (const float4*)(base + off_vtx_normal); s.vtx_uv = (const float2*)(base + off_vtx_uv);
   s.materials = (const float4*)(base + off_d_materials);

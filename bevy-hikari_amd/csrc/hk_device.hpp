@@ -53,11 +53,11 @@ struct DEmissive {
   float surface_area;
 };
 struct DScene {
-  const float4* __restrict__ tlas_lo;
-  const float4* __restrict__ tlas_hi;
+  // TLAS nodes [0, tlas_count) followed by all BLAS nodes [blas_base, ...), 32 B each:
+  // nodes[2i] = (min.xyz, entry bits), nodes[2i+1] = (max.xyz, exit bits) - one cache sector /
+  // two adjacent ds_read_b128 per node step, one base register for both levels
+  const float4* __restrict__ nodes;
   const DInstance* __restrict__ instances;
-  const float4* __restrict__ blas_lo;
-  const float4* __restrict__ blas_hi;
   const float4* __restrict__ tri_v0;
   const float4* __restrict__ tri_v1;
   const float4* __restrict__ tri_v2;
@@ -69,7 +69,7 @@ struct DScene {
   const DEmissive* __restrict__ emissives;
   const float2* __restrict__ alias;      // (prob, index bits)
   const uint32_t* __restrict__ noise;    // 16 x 64 x 64 RGBA8
-  uint32_t tlas_count, light_count;
+  uint32_t tlas_count, blas_base, light_count;
   const float4* __restrict__ blob;       // all arrays above (except noise) live in [blob, blob + blob_f4)
   uint32_t blob_f4;
 };
@@ -378,8 +378,9 @@ HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t no
   bool intersected = false;
   uint32_t index = 0u;
   while (index < node_count) {
-    const float4 lo = sc.blas_lo[node_offset + index];
-    const float4 hi = sc.blas_hi[node_offset + index];
+    const float4* __restrict__ nd = sc.nodes + 2u * (sc.blas_base + node_offset + index);
+    const float4 lo = nd[0];
+    const float4 hi = nd[1];
     const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
     const bool box_hit = intersects_aabb(ray, xyz(lo), xyz(hi)) < hit.distance;
     if (entry >= HK_LEAF) {
@@ -415,31 +416,32 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
   hit.distance = max_distance;
   hit.instance_index = HK_U32_MAX;
   hit.primitive_index = HK_U32_MAX;
-  uint32_t t_index = 0u;                 // next TLAS node
-  uint32_t b_index = 0u, b_count = 0u;   // BLAS cursor; b_count == 0 <=> walking the TLAS
-  uint32_t node_base = 0u, prim_base = 0u, cur_instance = 0u;
-  bool intersected = false;
+  // cursor of the level being walked: node = nodes[base + index], index < limit
+  uint32_t index = 0u, limit = sc.tlas_count, base = 0u;
+  uint32_t t_resume = 0u;  // TLAS index to continue with when the current BLAS is exhausted
+  uint32_t prim_base = 0u, cur_instance = 0u;
+  bool in_blas = false, intersected = false;
   f3 co = ray.origin, cinv = ray.inv_direction;  // origin / inverse direction of the level being walked
   f3 ld = ray.direction;                          // local direction while inside a BLAS
   for (;;) {
-    const bool in_blas = b_count != 0u;
-    if (in_blas) {
-      if (b_index >= b_count) {  // traverse_bottom returned, light.wgsl:465-470
-        if (intersected) {
-          hit.instance_index = cur_instance;
-          if (hit.distance < early_distance) return hit;
-        }
-        b_count = 0u;
-        co = ray.origin;
-        cinv = ray.inv_direction;
-        continue;
+    if (index >= limit) {
+      if (!in_blas) break;
+      // traverse_bottom returned, light.wgsl:465-470
+      if (intersected) {
+        hit.instance_index = cur_instance;
+        if (hit.distance < early_distance) return hit;
       }
-    } else if (t_index >= sc.tlas_count) {
-      break;
+      in_blas = false;
+      index = t_resume;
+      limit = sc.tlas_count;
+      base = 0u;
+      co = ray.origin;
+      cinv = ray.inv_direction;
+      continue;
     }
-    const uint32_t idx = in_blas ? node_base + b_index : t_index;
-    const float4 lo = (in_blas ? sc.blas_lo : sc.tlas_lo)[idx];
-    const float4 hi = (in_blas ? sc.blas_hi : sc.tlas_hi)[idx];
+    const float4* __restrict__ nd = sc.nodes + 2u * (base + index);
+    const float4 lo = nd[0];
+    const float4 hi = nd[1];
     const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
     // intersects_aabb, light.wgsl:344-362, on the current level's ray
     const f3 t1 = (xyz(lo) - co) * cinv;
@@ -452,47 +454,45 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
     t_max = fmin_(t_max, fmax_(t1.z, t2.z));
     const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
     const bool box_hit = t_box < hit.distance;
-    if (entry >= HK_LEAF) {
+    const bool leaf = entry >= HK_LEAF;
+    // inner node: descend on a hit, skip the subtree otherwise; leaf: always continue at its exit
+    index = (leaf || !box_hit) ? exit_ : entry;
+    if (leaf && box_hit) {  // the two rare events
       if (in_blas) {
-        b_index = exit_;
-        if (box_hit) {
-          const uint32_t primitive_index = prim_base + entry - HK_LEAF;
-          Ray lr;
-          lr.origin = co;
-          lr.direction = ld;
-          lr.inv_direction = cinv;
-          f2 uv;
-          const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
-          if (d < hit.distance) {
-            hit.uv = uv;
-            hit.distance = d;
-            hit.primitive_index = primitive_index;
-            intersected = true;
-            if (d < early_distance) {  // light.wgsl:421-423 then 466-469
-              hit.instance_index = cur_instance;
-              return hit;
-            }
+        const uint32_t primitive_index = prim_base + entry - HK_LEAF;
+        Ray lr;
+        lr.origin = co;
+        lr.direction = ld;
+        lr.inv_direction = cinv;
+        f2 uv;
+        const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+        if (d < hit.distance) {
+          hit.uv = uv;
+          hit.distance = d;
+          hit.primitive_index = primitive_index;
+          intersected = true;
+          if (d < early_distance) {  // light.wgsl:421-423 then 466-469
+            hit.instance_index = cur_instance;
+            return hit;
           }
         }
       } else {
-        t_index = exit_;
         const uint32_t instance_index = entry - HK_LEAF;
-        if (instance_index != exclude_instance && box_hit) {
+        if (instance_index != exclude_instance) {
           const DInstance& in = sc.instances[instance_index];
           co = world_to_local_position(in, ray.origin);
           ld = world_to_local_direction(in, ray.direction);
           cinv = 1.0f / ld;
-          node_base = in.node_offset;
+          t_resume = index;
+          base = sc.blas_base + in.node_offset;
+          index = 0u;
+          limit = in.node_count;
           prim_base = in.primitive;
-          b_count = in.node_count;
-          b_index = 0u;
           cur_instance = instance_index;
+          in_blas = true;
           intersected = false;
         }
       }
-    } else {
-      const uint32_t next = box_hit ? entry : exit_;
-      if (in_blas) b_index = next; else t_index = next;
     }
   }
   return hit;

@@ -39,7 +39,7 @@ __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
     const char* gb = reinterpret_cast<const char*>(sc.blob);
     const char* lb = reinterpret_cast<const char*>(hk_smem);
 #define HK_REBASE(field) l.field = reinterpret_cast<decltype(l.field)>(lb + (reinterpret_cast<const char*>(sc.field) - gb))
-    HK_REBASE(tlas_lo); HK_REBASE(tlas_hi); HK_REBASE(instances); HK_REBASE(blas_lo); HK_REBASE(blas_hi);
+    HK_REBASE(nodes); HK_REBASE(instances);
     HK_REBASE(tri_v0); HK_REBASE(tri_v1); HK_REBASE(tri_v2); HK_REBASE(vtx_normal); HK_REBASE(vtx_uv);
     HK_REBASE(materials); HK_REBASE(light_lo); HK_REBASE(light_hi); HK_REBASE(emissives); HK_REBASE(alias);
 #undef HK_REBASE
