@@ -103,3 +103,49 @@ def synthetic_camera(width, height, extent=4.0):
     from .plugin import Camera, look_at_transform
 
     return Camera(look_at_transform((1.6 * extent, 1.1 * extent, 2.0 * extent), (0.0, 0.6, 0.0)), width, height)
+
+
+def _rock(rng, rings, segs):
+    """A sphere displaced by a few random low-frequency lobes: a unique closed mesh per seed."""
+    p, n, uv, idx = _sphere(rings, segs)
+    d = p / np.linalg.norm(p, axis=1, keepdims=True)
+    disp = np.ones(len(p))
+    for _ in range(6):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        disp += rng.uniform(0.05, 0.25) * np.sin(rng.uniform(1.5, 5.0) * (d @ axis) + rng.uniform(0, 6.28))
+    p = (d * (0.5 * disp)[:, None]).astype(np.float32)
+    # smooth normals from the displaced surface (area-weighted face normals)
+    nrm = np.zeros_like(p, dtype=np.float64)
+    tri = idx.reshape(-1, 3)
+    fn = np.cross(p[tri[:, 1]] - p[tri[:, 0]], p[tri[:, 2]] - p[tri[:, 0]])
+    for k in range(3):
+        np.add.at(nrm, tri[:, k], fn)
+    ln = np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm = np.where(ln > 1e-12, nrm / np.maximum(ln, 1e-12), d)
+    return p, nrm.astype(np.float32), uv, idx
+
+
+def synthetic_large(seed=0x5EED0003, n_meshes=40, rings=40, segs=80, n_instances=400, n_materials=50, n_emitters=8, extent=12.0):
+    """Sponza-class stand-in (~260 k unique triangles, ~400 instances, 50
+    materials, 8 emissive quads, sun 100 000 lux).  `rings x segs x 2` triangles per unique mesh.
+    City-class (config 4): synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder()
+    box = b.add_mesh(*_box())
+    rocks = [b.add_mesh(*_rock(rng, rings, segs)) for _ in range(n_meshes)]
+    qp, qn, quv = _quad_strip(4)
+    quad = b.add_mesh(qp, qn, quv, None, F.TOPOLOGY_TRIANGLE_STRIP)
+    mats = [b.add_material(standard_material(tuple(rng.uniform(0.15, 0.9, 3)) + (1.0,), (0, 0, 0), float(rng.uniform(0.25, 1.0)),
+                                             float(rng.choice([0.0, 0.0, 0.0, 1.0])), 0.5)) for _ in range(n_materials)]
+    emat = [b.add_material(standard_material((0.8, 0.8, 0.8, 1.0), tuple(rng.uniform(0.3, 1.0, 3)), 1.0, 0.0, 0.5)) for _ in range(max(1, n_emitters))]
+    b.add_instance(box, mats[0], _trs((0, -0.25, 0), (0, 0, 0), (2.5 * extent, 0.5, 2.5 * extent)))
+    for i in range(n_instances):
+        t = (rng.uniform(-extent, extent), rng.uniform(0.3, 2.5), rng.uniform(-extent, extent))
+        s = rng.uniform(0.6, 2.2, 3)
+        b.add_instance(rocks[int(rng.integers(0, n_meshes))], mats[int(rng.integers(1, n_materials))], _trs(t, rng.uniform(-3.1, 3.1, 3), s))
+    for i in range(n_emitters):
+        t = (rng.uniform(-extent, extent) * 0.8, rng.uniform(3.5, 5.0), rng.uniform(-extent, extent) * 0.8)
+        b.add_instance(quad, emat[i], _trs(t, (math.pi + rng.uniform(-0.3, 0.3), rng.uniform(-1, 1), 0.0), (rng.uniform(0.8, 2.0), 1.0, rng.uniform(0.8, 2.0))))
+    sun = dict(color=(1.0, 0.96, 0.9), illuminance=100000.0, direction_to_light=(0.35, 0.8, 0.45))
+    return b.finish(), sun

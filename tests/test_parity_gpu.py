@@ -237,3 +237,60 @@ def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
         for key in d.files:
             if key not in ("b0", "b1"):
                 assert (d[key].view(np.uint8) == full[key][b0:b1].view(np.uint8)).all(), f"rank {rank} [{b0},{b1}) differs in {key}"
+
+
+def test_sponza_class_vs_oracle():
+    """BASELINE config 3 stand-in (seeded synthetic, ~256 k unique triangles, 409 instances, 50
+    materials, 8 emitters, sun 100 000 lux, 3 bounces + denoise): too big for LDS staging, so this
+    is the global-memory traversal path; compared with the oracle at a reduced resolution."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large()
+    s = hk.HikariSettings(indirect_bounces=3, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = synthetic_camera(320, 180, extent=9.0)
+    lights = hk.lights_uniform(directional=sun)
+    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    for n in (1, 2, 3):
+        for p in (gpu, cpu):
+            p.render(cam, s, lights=lights, frame_number=n)
+    bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+    assert bad == {}, bad
+    sg, sc = gpu.engine.stats(), cpu.engine.stats()
+    assert (sg.rays_tlas, sg.rays_blas) == (sc.rays_tlas, sc.rays_blas) and sg.rays_tlas > 320 * 180 * 3
+    out = gpu.output(s)
+    assert np.isfinite(out).all() and out[..., :3].max() > 0.05
+
+
+def test_city_class_4k_properties():
+    """BASELINE config 4 stand-in at its full size on one GPU (seeded synthetic, ~1.5 M unique
+    triangles, 2002 instances, 3840x2160, 2 bounces): determinism, dispatch row-range independence
+    (what the 8-band split relies on), finite output, sane ray counts."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+    sun = dict(sun, illuminance=10000.0)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = synthetic_camera(3840, 2160, extent=30.0)
+    lights = hk.lights_uniform(directional=sun)
+    runs = []
+    for rep in range(2):
+        p = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS if rep == 0 else 0)
+        p.set_scene(scene)
+        for n in (1, 2):
+            p.render(cam, s, lights=lights, frame_number=n)
+        runs.append(p)
+    a = snapshot(runs[0])
+    assert diff_buffers(a, snapshot(runs[1])) == {}
+    out = runs[0].output(s)
+    assert np.isfinite(out).all() and out[..., :3].max() > 0.05
+    st = runs[0].engine.stats()
+    px = 3840 * 2160 * 2
+    assert st.rays_primary == px and px < st.rays_tlas <= px * 7 and st.rays_blas <= px * 4
+    e = runs[1].engine
+    for b0, b1 in ((0, 270), (270, 1000), (1000, 2160)):
+        e.pass_run(F.PASS_INDIRECT, 0, b0, b1)
+    for b0, b1 in ((0, 1111), (1111, 2160)):
+        e.pass_run(F.PASS_INDIRECT_SPATIAL_REUSE, 0, b0, b1)
+    assert diff_buffers(snapshot(runs[1]), a) == {}
