@@ -37,6 +37,7 @@ TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1
 UPSCALE_FSR1, UPSCALE_SMAA_TU4X = 0, 1
 NO_TEXTURE = 0xFFFFFFFF
+ADDRESS_CLAMP_TO_EDGE, ADDRESS_REPEAT, ADDRESS_MIRROR_REPEAT = 0, 1, 2
 TIMING_SLOTS = 16
 
 f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
@@ -113,6 +114,11 @@ class HkSettings(C.Structure):
                 ("upscale_sharpness", f32)]
 
 
+class HkImageDesc(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", u32), ("height", u32), ("is_srgb", u32), ("address_u", u32), ("address_v", u32),
+                ("filter_linear", u32)]
+
+
 class HkHaloOp(C.Structure):
     _fields_ = [("buffer", u32), ("peer", u32), ("row_begin", u32), ("row_end", u32), ("row_bytes", u64)]
 
@@ -144,6 +150,7 @@ _SIGNATURES = {
     "upload_materials": [_vp, P(HkMaterial), u32],
     "upload_instances": [_vp, P(HkInstance), u32, P(HkNode), u32, P(HkEmissive), u32, P(HkNode), u32, P(HkAliasEntry), u32],
     "upload_noise": [_vp, _vp, C.c_size_t],
+    "upload_textures": [_vp, P(HkImageDesc), u32],
     "resize": [_vp, u32, u32, f32],
     "set_view_options": [_vp, u32, u32],
     "frame_begin": [_vp, P(HkFrame), P(HkView), P(HkPreviousView), P(HkLights)],

@@ -110,12 +110,15 @@ struct hk_ctx {
   std::vector<HkEmissive> emissives;
   std::vector<HkNode> emissive_nodes;
   std::vector<HkAliasEntry> alias_table;
+  struct HostTexture { std::vector<uint32_t> texels; uint32_t w, h, flags; };
+  std::vector<HostTexture> textures;
   bool have_meshes = false, have_materials = false, have_instances = false, have_noise = false;
   bool scene_dirty = true;
 
   // device scene
   DevArray<uint8_t> scene_blob;  // every scene array in one allocation (so small scenes can be staged in LDS by one copy loop)
   DevArray<uint32_t> d_noise;
+  DevArray<uint32_t> d_tex_data;
   DScene scene{};
 
   // screen-space resources
@@ -326,13 +329,33 @@ int finalize_scene(hk_ctx* c) {
   for (size_t i = 0; i < n_nodes; ++i) { nodes.push_back(lo[i]); nodes.push_back(hi[i]); }
   const size_t off_nodes = blob.add(nodes);
 
-  std::vector<float4> mats(3 * c->materials.size());
+  const uint32_t n_tex = (uint32_t)c->textures.size();
+  std::vector<float4> mats(4 * c->materials.size());
   for (size_t i = 0; i < c->materials.size(); ++i) {
     const HkMaterial& m = c->materials[i];
-    mats[3 * i] = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
-    mats[3 * i + 1] = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
-    mats[3 * i + 2] = make_float4(m.perceptual_roughness, m.metallic, m.reflectance, 0.0f);
+    const uint32_t ids[4] = {m.base_color_texture, m.emissive_texture, m.metallic_roughness_texture, m.occlusion_texture};
+    for (uint32_t id : ids)  // MaterialTextures::id, material.rs:76-86: an index into the texture array or u32::MAX
+      HK_REQUIRE(id == HK_NO_TEXTURE || id < n_tex, HK_E_INVALID, "material %zu references texture %u but only %u textures are uploaded", i, id, n_tex);
+    mats[4 * i] = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
+    mats[4 * i + 1] = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
+    mats[4 * i + 2] = make_float4(m.perceptual_roughness, m.metallic, m.reflectance, 0.0f);
+    mats[4 * i + 3] = make_float4(as_f(ids[0]), as_f(ids[1]), as_f(ids[2]), as_f(ids[3]));
   }
+  // material textures: one texel buffer + a 16-B descriptor per texture + the sRGB decode table
+  std::vector<uint4> tex_info(n_tex);
+  std::vector<uint32_t> tex_data;
+  for (uint32_t i = 0; i < n_tex; ++i) {
+    const hk_ctx::HostTexture& t = c->textures[i];
+    tex_info[i] = make_uint4((uint32_t)tex_data.size(), t.w, t.h, t.flags);
+    tex_data.insert(tex_data.end(), t.texels.begin(), t.texels.end());
+  }
+  std::vector<float> srgb_lut(256);
+  for (int i = 0; i < 256; ++i) {  // sRGB EOTF in double, rounded once
+    double v = i / 255.0;
+    srgb_lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
+  }
+  const size_t off_tex_info = blob.add(tex_info);
+  const size_t off_srgb_lut = blob.add(srgb_lut);
   const size_t off_d_materials = blob.add(mats);
 
   const size_t n_light = c->emissive_nodes.size();
@@ -373,6 +396,7 @@ int finalize_scene(hk_ctx* c) {
   // traversal-hot arrays were added first; pad to a whole float4 count
   blob.bytes.resize((blob.bytes.size() + 15) & ~(size_t)15, 0);
   int rc;
+  if ((rc = c->d_tex_data.upload(tex_data))) return rc;
   if ((rc = c->scene_blob.upload(blob.bytes))) return rc;
   const uint8_t* base = c->scene_blob.p;
   DScene& s = c->scene;
@@ -384,6 +408,10 @@ int finalize_scene(hk_ctx* c) {
   s.tri_v0 = (const float4*)(base + off_tri_v0); s.tri_v1 = (const float4*)(base + off_tri_v1); s.tri_v2 = (const float4*)(base + off_tri_v2);
   s.vtx_normal = (const float4*)(base + off_vtx_normal); s.vtx_uv = (const float2*)(base + off_vtx_uv);
   s.materials = (const float4*)(base + off_d_materials);
+  s.tex_info = (const uint4*)(base + off_tex_info);
+  s.srgb_lut = (const float*)(base + off_srgb_lut);
+  s.tex_data = c->d_tex_data.p;
+  s.n_textures = n_tex;
   s.light_lo = (const float4*)(base + off_light_lo); s.light_hi = (const float4*)(base + off_light_hi);
   s.emissives = (const DEmissive*)(base + off_d_emissives); s.alias = (const float2*)(base + off_d_alias);
   s.noise = c->d_noise.p;
@@ -633,6 +661,7 @@ void hk_destroy(hk_ctx* c) {
   if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
   free_screen(c);
   c->scene_blob.release();
+  c->d_tex_data.release();
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -650,10 +679,6 @@ int hk_upload_meshes(hk_ctx* c, const HkVertex* v, uint32_t nv, const HkPrimitiv
 }
 int hk_upload_materials(hk_ctx* c, const HkMaterial* m, uint32_t n) {
   HK_REQUIRE(c && m && n, HK_E_INVALID, "NULL or empty material buffer");
-  for (uint32_t i = 0; i < n; ++i)
-    HK_REQUIRE(m[i].base_color_texture == HK_NO_TEXTURE && m[i].emissive_texture == HK_NO_TEXTURE && m[i].metallic_roughness_texture == HK_NO_TEXTURE &&
-                   m[i].occlusion_texture == HK_NO_TEXTURE,
-               HK_E_UNSUPPORTED, "material %u references a texture; only the NO_TEXTURE pipelines (light.wgsl:729-747) are implemented", i);
   c->materials.assign(m, m + n);
   c->have_materials = true;
   c->scene_dirty = true;
@@ -689,6 +714,23 @@ int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
   if ((rc = hk_upload_meshes(c, v, nv, p, np, an, nan_))) return rc;
   if ((rc = hk_upload_materials(c, m, nm))) return rc;
   return hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal);
+}
+int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
+  HK_REQUIRE(c && (images || !n), HK_E_INVALID, "NULL argument");
+  std::vector<hk_ctx::HostTexture> tex(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const HkImageDesc& d = images[i];
+    HK_REQUIRE(d.rgba8 && d.width && d.height && d.width <= 16384 && d.height <= 16384, HK_E_INVALID, "image %u: bad pointer or size", i);
+    HK_REQUIRE(d.address_u <= HK_ADDRESS_MIRROR_REPEAT && d.address_v <= HK_ADDRESS_MIRROR_REPEAT, HK_E_INVALID, "image %u: bad address mode", i);
+    tex[i].w = d.width;
+    tex[i].h = d.height;
+    tex[i].flags = (d.is_srgb ? 1u : 0u) | (d.filter_linear ? 2u : 0u) | (d.address_u << 4) | (d.address_v << 6);
+    tex[i].texels.resize((size_t)d.width * d.height);
+    memcpy(tex[i].texels.data(), d.rgba8, tex[i].texels.size() * 4);
+  }
+  c->textures.swap(tex);
+  c->scene_dirty = true;
+  return HK_OK;
 }
 int hk_upload_noise(hk_ctx* c, const uint8_t* rgba, size_t bytes) {
   HK_REQUIRE(c && rgba && bytes == 16u * 64u * 64u * 4u, HK_E_INVALID, "noise must be 16 tiles of 64x64 RGBA8 (262144 bytes)");

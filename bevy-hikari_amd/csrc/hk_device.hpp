@@ -63,12 +63,17 @@ struct DScene {
   const float4* __restrict__ tri_v2;
   const float4* __restrict__ vtx_normal;
   const float2* __restrict__ vtx_uv;
-  const float4* __restrict__ materials;  // 3 x float4 per material: base_color, emissive, (perceptual_roughness, metallic, reflectance, 0)
+  const float4* __restrict__ materials;  // 4 x float4 per material: base_color, emissive, (perceptual_roughness, metallic, reflectance, 0),
+                                         // texture ids as bits (base_color, emissive, metallic_roughness, occlusion)
   const float4* __restrict__ light_lo;
   const float4* __restrict__ light_hi;
   const DEmissive* __restrict__ emissives;
   const float2* __restrict__ alias;      // (prob, index bits)
   const uint32_t* __restrict__ noise;    // 16 x 64 x 64 RGBA8
+  const uint32_t* __restrict__ tex_data; // all material textures, RGBA8 texels
+  const uint4* __restrict__ tex_info;    // per texture: (texel offset, width, height, flags: bit0 sRGB, bit1 bilinear, bits 4-5 / 6-7 address u / v)
+  const float* __restrict__ srgb_lut;    // 256-entry sRGB -> linear table
+  uint32_t n_textures;
   uint32_t tlas_count, blas_base, light_count;
   const float4* __restrict__ blob;       // all arrays above (except noise) live in [blob, blob + blob_f4)
   uint32_t blob_f4;
@@ -663,16 +668,66 @@ HKD f3 calculate_view(const DFrame& fr, f3 world_position) {  // light.wgsl:714-
   if (fr.is_ortho) return normalize(F3(fr.ortho_x, fr.ortho_y, fr.ortho_z));
   return normalize(F3(fr.cam_x, fr.cam_y, fr.cam_z) - world_position);
 }
-HKD Surface retreive_surface(const DScene& sc, uint32_t material_index) {  // light.wgsl:730-742 (NO_TEXTURE)
+// textureSampleLevel(textures[id], samplers[id], uv, 0.0), light.wgsl:756-789: texel centres at
+// (i + 0.5) / size, f32 bilinear weights, sRGB rgb decoded to linear per texel before filtering.
+HKD int wrap_coord(int i, int n, uint32_t mode) {
+  if (mode == 1u) { int m = i % n; return m < 0 ? m + n : m; }                                            // repeat
+  if (mode == 2u) { int p = 2 * n; int m = i % p; if (m < 0) m += p; return m < n ? m : p - 1 - m; }      // mirror repeat
+  return min(max(i, 0), n - 1);                                                                            // clamp to edge
+}
+HKD f4 texel(const DScene& sc, uint4 ti, int x, int y) {
+  const uint32_t t = sc.tex_data[ti.x + (uint32_t)y * ti.y + (uint32_t)x];
+  const uint32_t r = t & 0xffu, g = (t >> 8) & 0xffu, b = (t >> 16) & 0xffu, a = t >> 24;
+  if (ti.w & 1u) return F4(sc.srgb_lut[r], sc.srgb_lut[g], sc.srgb_lut[b], (float)a / 255.0f);
+  return F4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
+}
+HKD f4 mix4(f4 a, f4 b, float t) { return F4(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t), mix(a.w, b.w, t)); }
+HKD f4 sample_texture(const DScene& sc, uint32_t id, f2 uv) {
+  const uint4 ti = sc.tex_info[id];
+  const int w = (int)ti.y, h = (int)ti.z;
+  const uint32_t au = (ti.w >> 4) & 3u, av = (ti.w >> 6) & 3u;
+  if (!(ti.w & 2u)) {
+    const int x = wrap_coord(f32_to_i32(floorf(uv.x * (float)w)), w, au), y = wrap_coord(f32_to_i32(floorf(uv.y * (float)h)), h, av);
+    return texel(sc, ti, x, y);
+  }
+  const float x = uv.x * (float)w - 0.5f, y = uv.y * (float)h - 0.5f;
+  const float x0 = floorf(x), y0 = floorf(y);
+  const float fx = x - x0, fy = y - y0;
+  const int ix = f32_to_i32(x0), iy = f32_to_i32(y0);
+  const int xa = wrap_coord(ix, w, au), xb = wrap_coord(ix + 1, w, au), ya = wrap_coord(iy, h, av), yb = wrap_coord(iy + 1, h, av);
+  const f4 top = mix4(texel(sc, ti, xa, ya), texel(sc, ti, xb, ya), fx);
+  const f4 bot = mix4(texel(sc, ti, xa, yb), texel(sc, ti, xb, yb), fx);
+  return mix4(top, bot, fy);
+}
+HKD Surface retreive_surface(const DScene& sc, uint32_t material_index, f2 uv) {  // light.wgsl:730-742 (NO_TEXTURE) / 749-781
   Surface s;
-  const float4 bc = sc.materials[3 * material_index], em = sc.materials[3 * material_index + 1], pr = sc.materials[3 * material_index + 2];
+  const float4 bc = sc.materials[4 * material_index], em = sc.materials[4 * material_index + 1], pr = sc.materials[4 * material_index + 2];
   s.base_color = F4(bc);
   s.emissive = F4(em);
   s.metallic = pr.y;
   s.occlusion = 1.0f;
+  if (sc.n_textures) {  // scene-uniform: the NO_TEXTURE pipelines pay nothing
+    const float4 ids = sc.materials[4 * material_index + 3];
+    uint32_t id = f2u(ids.x);
+    if (id != HK_U32_MAX) s.base_color = s.base_color * sample_texture(sc, id, uv);
+    id = f2u(ids.y);
+    if (id != HK_U32_MAX) s.emissive = s.emissive * sample_texture(sc, id, uv);
+    id = f2u(ids.z);
+    if (id != HK_U32_MAX) s.metallic *= sample_texture(sc, id, uv).x;
+    id = f2u(ids.w);
+    if (id != HK_U32_MAX) s.occlusion = sample_texture(sc, id, uv).x;
+  }
   s.roughness = perceptualRoughnessToRoughness(pr.x);
   s.reflectance = pr.z;
   return s;
+}
+HKD f4 retreive_emissive(const DScene& sc, uint32_t material_index, f2 uv) {  // light.wgsl:744-747 / 783-793
+  f4 emissive = F4(sc.materials[4 * material_index + 1]);
+  if (sc.n_textures) {
+    const uint32_t id = f2u(sc.materials[4 * material_index + 3].y);
+    if (id != HK_U32_MAX) emissive = emissive * sample_texture(sc, id, uv);
+  }
+  return emissive;
 }
 HKD f3 lit(f3 radiance, f3 diffuse_color, float roughness, f3 F0, f3 L, f3 N, f3 V) {  // light.wgsl:796-818
   f3 Hh = normalize(L + V);
@@ -705,7 +760,7 @@ HKD f4 input_radiance(const DScene& sc, const DFrame& fr, const Ray& ray, const 
       ambient_ = 1.0f;
     }
   } else if (sample_emissive == info.instance_index) {
-    radiance = compute_emissive_radiance(F4(sc.materials[3 * info.material_index + 1]));  // retreive_emissive, light.wgsl:744-747
+    radiance = compute_emissive_radiance(retreive_emissive(sc, info.material_index, info.uv));
   }
   return F4(radiance, 1.0f - ambient_);
 }

@@ -41,7 +41,7 @@ __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
 #define HK_REBASE(field) l.field = reinterpret_cast<decltype(l.field)>(lb + (reinterpret_cast<const char*>(sc.field) - gb))
     HK_REBASE(nodes); HK_REBASE(instances);
     HK_REBASE(tri_v0); HK_REBASE(tri_v1); HK_REBASE(tri_v2); HK_REBASE(vtx_normal); HK_REBASE(vtx_uv);
-    HK_REBASE(materials); HK_REBASE(light_lo); HK_REBASE(light_hi); HK_REBASE(emissives); HK_REBASE(alias);
+    HK_REBASE(materials); HK_REBASE(tex_info); HK_REBASE(srgb_lut); HK_REBASE(light_lo); HK_REBASE(light_hi); HK_REBASE(emissives); HK_REBASE(alias);
 #undef HK_REBASE
     return l;
   }
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void k_full_screen_albedo(DScene sc, DFrame fr
   }
   const f3 normal = xyz(unpack4x8snorm(g.normal[idx]));
   const uint32_t material = f32_to_u32(g.instance_material[idx].y);
-  Surface surface = retreive_surface(sc, material);
+  const float4 velocity_uv = g.velocity_uv[idx];
+  Surface surface = retreive_surface(sc, material, F2(velocity_uv.z, velocity_uv.w));
   f3 view_direction = calculate_view(fr, xyz(position_depth));
   albedo[idx] = pack_f16x4(F4(env_brdf(view_direction, normal, surface), 1.0f));
 }
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
       t.variance[index] = reservoir_variance(r);
       if (fr.temporal_reuse > 0u) store_packed(t.current, index, pack_reservoir(r));
 
-      Surface surface = retreive_surface(sc, im_y);
+      Surface surface = retreive_surface(sc, im_y, F2(velocity_uv.z, velocity_uv.w));
       f3 view_direction = calculate_view(fr, position);
       f3 out_radiance = shading(fr, view_direction, r.s.visible_normal, normalize(xyz(r.s.sample_position) - xyz(r.s.visible_position)), surface, r.s.radiance);
       out_radiance = out_radiance * r.w;
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
 
           if (hit.instance_index != HK_U32_MAX) {
             f3 out_radiance = F3(0, 0, 0);
-            surface = retreive_surface(sc, info.material_index);
+            surface = retreive_surface(sc, info.material_index, info.uv);
             surface.roughness = 1.0f;
             const uint32_t info_instance = info.instance_index;
             LightCandidate candidate = select_light_candidate(sc, fr, bounce_sample.random, xyz(bounce_sample.sample_position),
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
         pdf = rand_sample.w;
         if (hit.instance_index != HK_U32_MAX) {
           f3 out_radiance = F3(0, 0, 0);
-          surface = retreive_surface(sc, info.material_index);
+          surface = retreive_surface(sc, info.material_index, info.uv);
           surface.roughness = 1.0f;
           const uint32_t info_instance = info.instance_index;
           LightCandidate candidate = select_light_candidate(sc, fr, s.random, xyz(s.sample_position), s.sample_normal, info_instance, info, rc);
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
         const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
         store_packed(t.previous_spatial, previous_index, pack_reservoir(r));
       }
-      surface = retreive_surface(sc, im_y);
+      surface = retreive_surface(sc, im_y, F2(velocity_uv.z, velocity_uv.w));
       const f3 view_direction = calculate_view(fr, position);
       f3 sample_radiance = shading(fr, view_direction, s.visible_normal, normalize(xyz(s.sample_position) - xyz(s.visible_position)), surface, s.radiance);
       float w_new = (pdf > 0.0f) ? luminance(sample_radiance) / pdf : 0.0f;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
   }
   const uint32_t im_y = f32_to_u32(g.instance_material[didx].y);
   const float4 velocity_uv = g.velocity_uv[didx];
-  const Surface surface = retreive_surface(sc, im_y);
+  const Surface surface = retreive_surface(sc, im_y, F2(velocity_uv.z, velocity_uv.w));
   const bool use_spatial_variance = r.count <= 4.0f;
   const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
 

@@ -55,6 +55,7 @@ class BandRenderer:
         self.engine, self.rank, self.world = engine, rank, world_size
         self.device = backend_device
         self._views = {}
+        self._plans = {}
         engine.set_band(rank, world_size)
 
     def _view(self, buf):
@@ -70,6 +71,28 @@ class BandRenderer:
 
     def invalidate_views(self):  # after hk_resize
         self._views = {}
+        self._plans = {}
+
+    def _transfers(self, stage, frame_number, settings_c, width, height, upscale_ratio):
+        """(is_recv, view slice, peer) for every transfer of `stage` this rank takes part in, in a
+        global order all ranks agree on.  The plan depends on the frame number only through its
+        parity (reservoir ping-pong), so it is built once per (stage, parity, settings) and reused:
+        at 8 GPUs a band's frame is a few hundred microseconds and per-frame host work would
+        otherwise dominate."""
+        key = (stage, frame_number & 1, width, height, upscale_ratio, bytes(settings_c))
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit
+        out = []
+        for peer_rank in range(self.world):  # fixed global order: plans of rank 0, 1, ...
+            for op in halo_plan(width, height, upscale_ratio, peer_rank, self.world, stage, frame_number, settings_c):
+                lo, hi = op.row_begin * op.row_bytes, op.row_end * op.row_bytes
+                if peer_rank == self.rank:       # I receive rows owned by op.peer
+                    out.append((True, self._view(op.buffer)[lo:hi], op.peer))
+                elif op.peer == self.rank:       # peer_rank needs rows I own
+                    out.append((False, self._view(op.buffer)[lo:hi], peer_rank))
+        self._plans[key] = out
+        return out
 
     def exchange(self, stage, frame_number, settings_c, width, height, upscale_ratio):
         """Execute the halo plan of `stage` for every rank pair this rank takes part in."""
@@ -77,23 +100,20 @@ class BandRenderer:
             return 0
         import torch.distributed as dist
 
-        # RCCL moves device memory directly; gloo (CPU tests, and the one-GPU two-rank test) cannot
+        # RCCL moves device memory directly; gloo (CPU tests, and the one-GPU multi-rank test) cannot
         # address device memory, so device views are staged through host tensors there.
         staged = self.device == "cuda" and dist.get_backend() != "nccl"
         ops, nbytes, landing = [], 0, []
-        for peer_rank in range(self.world):  # fixed global order: plans of rank 0, 1, ...
-            for op in halo_plan(width, height, upscale_ratio, peer_rank, self.world, stage, frame_number, settings_c):
-                lo, hi = op.row_begin * op.row_bytes, op.row_end * op.row_bytes
-                view = self._view(op.buffer)[lo:hi]
-                if peer_rank == self.rank:       # I receive rows owned by op.peer
-                    if staged:
-                        tmp = self.torch.empty(hi - lo, dtype=self.torch.uint8)
-                        landing.append((view, tmp))
-                        view = tmp
-                    ops.append(dist.P2POp(dist.irecv, view, op.peer))
-                    nbytes += hi - lo
-                elif op.peer == self.rank:       # peer_rank needs rows I own
-                    ops.append(dist.P2POp(dist.isend, view.cpu() if staged else view, peer_rank))
+        for is_recv, view, peer in self._transfers(stage, frame_number, settings_c, width, height, upscale_ratio):
+            if is_recv:
+                if staged:
+                    tmp = self.torch.empty(view.numel(), dtype=self.torch.uint8)
+                    landing.append((view, tmp))
+                    view = tmp
+                ops.append(dist.P2POp(dist.irecv, view, peer))
+                nbytes += view.numel()
+            else:
+                ops.append(dist.P2POp(dist.isend, view.cpu() if staged else view, peer))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

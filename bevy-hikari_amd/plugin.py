@@ -363,7 +363,22 @@ class Engine:
 
     # -- Prepare stage
     def upload_scene(self, scene: SceneData):
+        self.upload_textures(getattr(scene, "textures", []))
         scene.upload(self.api, self.ctx)
+
+    def upload_textures(self, images):
+        """images: list of dict(rgba=uint8[h][w][4], srgb=bool, address_u/address_v=F.ADDRESS_*, linear=bool) -
+        the `textures` / `samplers` binding arrays (mod.rs:760-782).  Material *_texture ids index this list."""
+        descs = (F.HkImageDesc * max(len(images), 1))()
+        keep = []
+        for d, im in zip(descs, images):
+            a = np.ascontiguousarray(im["rgba"], dtype=np.uint8)
+            assert a.ndim == 3 and a.shape[2] == 4
+            keep.append(a)
+            d.rgba8, d.height, d.width = a.ctypes.data, a.shape[0], a.shape[1]
+            d.is_srgb, d.filter_linear = int(im.get("srgb", True)), int(im.get("linear", True))
+            d.address_u, d.address_v = im.get("address_u", F.ADDRESS_REPEAT), im.get("address_v", F.ADDRESS_REPEAT)
+        self.api.call("upload_textures", self.ctx, descs, len(images))
 
     def upload_noise(self, noise=None):
         noise = load_noise() if noise is None else np.ascontiguousarray(noise, dtype=np.uint8)

@@ -69,10 +69,32 @@ def _trs(t, angles, s):
     return m.T.astype(np.float32).reshape(-1)  # column-major
 
 
-def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, extent=4.0, sphere_rings=8, sphere_segs=12):
+def _test_textures(rng):
+    """Four small procedural RGBA8 images covering the sampler variants (sRGB / linear format,
+    bilinear / nearest, repeat / mirror / clamp)."""
+    yy, xx = np.mgrid[0:16, 0:32]
+    checker = np.where(((xx // 4 + yy // 4) % 2)[..., None] == 0, np.array([230, 60, 40, 255]), np.array([40, 90, 220, 255])).astype(np.uint8)
+    stripes = np.zeros((8, 8, 4), np.uint8)
+    stripes[..., 3] = 255
+    stripes[:, ::2, :3] = (200, 200, 190)
+    stripes[:, 1::2, :3] = (90, 120, 60)
+    noise = rng.integers(0, 256, (16, 16, 4), dtype=np.uint8)
+    glow = np.zeros((4, 16, 4), np.uint8)
+    glow[..., 3] = 255
+    glow[..., 0] = np.linspace(40, 255, 16).astype(np.uint8)[None, :]
+    glow[..., 1] = 180
+    glow[..., 2] = np.linspace(255, 30, 16).astype(np.uint8)[None, :]
+    return [dict(rgba=checker, srgb=True, linear=True, address_u=F.ADDRESS_REPEAT, address_v=F.ADDRESS_REPEAT),
+            dict(rgba=stripes, srgb=True, linear=False, address_u=F.ADDRESS_MIRROR_REPEAT, address_v=F.ADDRESS_CLAMP_TO_EDGE),
+            dict(rgba=noise, srgb=False, linear=True, address_u=F.ADDRESS_CLAMP_TO_EDGE, address_v=F.ADDRESS_MIRROR_REPEAT),
+            dict(rgba=glow, srgb=True, linear=True, address_u=F.ADDRESS_REPEAT, address_v=F.ADDRESS_CLAMP_TO_EDGE)]
+
+
+def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, extent=4.0, sphere_rings=8, sphere_segs=12, textured=False):
     """A room-less yard: ground slab, random boxes and spheres with rotated / non-uniformly scaled
     instances of a few shared meshes, `n_emitters` emissive strip-quads above it.  Returns
-    (SceneData, suggested sun dict)."""
+    (SceneData, suggested sun dict).  textured=True binds four procedural textures (base colour,
+    metallic, occlusion, emissive; light.wgsl:749-793)."""
     rng = np.random.default_rng(seed)
     b = SceneBuilder()
     box = b.add_mesh(*_box())
@@ -83,6 +105,21 @@ def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, exte
     mats = [b.add_material(standard_material(tuple(rng.uniform(0.2, 0.9, 3)) + (1.0,), (0, 0, 0), float(rng.uniform(0.3, 1.0)),
                                              float(rng.choice([0.0, 0.0, 1.0])), 0.5)) for _ in range(8)]
     emat = [b.add_material(standard_material((0.8, 0.8, 0.8, 1.0), tuple(rng.uniform(0.2, 1.0, 3)), 1.0, 0.0, 0.5)) for _ in range(max(1, n_emitters))]
+    textures = []
+    if textured:
+        textures = _test_textures(rng)
+
+        def mat(base=(1, 1, 1, 1), emissive=(0, 0, 0), rough=0.6, metallic=0.0, **ids):
+            m = standard_material(base, emissive, rough, metallic, 0.5)
+            for k, v in ids.items():
+                setattr(m, k, v)
+            return b.add_material(m)
+
+        mats[0] = mat((0.9, 0.9, 0.9, 1), base_color_texture=1)                                   # ground: nearest / mirror / clamp
+        mats[1] = mat((1, 1, 1, 1), base_color_texture=0)                                         # checker, bilinear repeat
+        mats[2] = mat((0.8, 0.7, 0.6, 1), rough=0.4, metallic=1.0, metallic_roughness_texture=2)  # metallic *= noise.r
+        mats[3] = mat((0.7, 0.8, 0.9, 1), base_color_texture=0, occlusion_texture=2)
+        emat[0] = mat((0.8, 0.8, 0.8, 1), (1.0, 0.9, 0.8), 1.0, emissive_texture=3)
     # ground
     b.add_instance(box, mats[0], _trs((0, -0.25, 0), (0, 0, 0), (2.5 * extent, 0.5, 2.5 * extent)))
     for _ in range(n_boxes):
@@ -96,7 +133,9 @@ def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, exte
         # flipped so the strip's +Y normal faces down
         b.add_instance(quad, emat[i], _trs(t, (math.pi + rng.uniform(-0.3, 0.3), rng.uniform(-1, 1), 0.0), (rng.uniform(0.4, 1.0), 1.0, rng.uniform(0.4, 1.0))))
     sun = dict(color=(1.0, 0.96, 0.9), illuminance=20000.0, direction_to_light=(0.35, 0.8, 0.45))
-    return b.finish(), sun
+    scene = b.finish()
+    scene.textures = textures
+    return scene, sun
 
 
 def synthetic_camera(width, height, extent=4.0):

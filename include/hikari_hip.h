@@ -341,8 +341,22 @@ int hk_scene_builder_alias_table(const hk_scene_builder* b, const HkAliasEntry**
 /* MeshRenderAssets::set + write_buffer, mesh.rs:43-64 (3 global buffers) */
 int hk_upload_meshes(hk_ctx* ctx, const HkVertex* vertices, uint32_t n_vertices, const HkPrimitive* primitives,
                      uint32_t n_primitives, const HkNode* asset_nodes, uint32_t n_asset_nodes);
-/* MaterialRenderAssets, material.rs:201-202 */
+/* MaterialRenderAssets, material.rs:201-202.  The *_texture fields index the array given to
+ * hk_upload_textures (HK_NO_TEXTURE = none), exactly like MaterialTextures::id (material.rs:76-86). */
 int hk_upload_materials(hk_ctx* ctx, const HkMaterial* materials, uint32_t n_materials);
+/* The `textures` / `samplers` binding arrays of group 3 (light.wgsl:15-18, mod.rs:760-782): one
+ * RGBA8 image + its sampler per entry, sampled at LOD 0 (light.wgsl:749-793).  is_srgb = the image
+ * format is Rgba8UnormSrgb (bevy loads base-colour / emissive images that way): rgb is decoded to
+ * linear BEFORE filtering, alpha is linear.  n = 0 selects the NO_TEXTURE pipelines. */
+typedef enum HkAddressMode { HK_ADDRESS_CLAMP_TO_EDGE = 0, HK_ADDRESS_REPEAT = 1, HK_ADDRESS_MIRROR_REPEAT = 2 } HkAddressMode;
+typedef struct HkImageDesc {
+  const uint8_t* rgba8; /* width * height * 4 bytes, row-major, row 0 = v = 0 */
+  uint32_t width, height;
+  uint32_t is_srgb;
+  uint32_t address_u, address_v; /* HkAddressMode */
+  uint32_t filter_linear;        /* 0 = nearest, 1 = bilinear (mag/min filter of the image's sampler) */
+} HkImageDesc;
+int hk_upload_textures(hk_ctx* ctx, const HkImageDesc* images, uint32_t n_images);
 /* InstanceRenderAssets::set + write_buffer, instance.rs:82-108 */
 int hk_upload_instances(hk_ctx* ctx, const HkInstance* instances, uint32_t n_instances, const HkNode* instance_nodes,
                         uint32_t n_instance_nodes, const HkEmissive* emissives, uint32_t n_emissives,

@@ -84,6 +84,9 @@ struct Ctx {
   std::vector<HkNode> emissive_nodes;
   std::vector<HkAliasEntry> alias_table;
   std::vector<uint8_t> noise;  // [16][64][64][4]
+  struct Texture { std::vector<uint8_t> rgba; uint32_t w, h, is_srgb, au, av, linear; };
+  std::vector<Texture> textures;
+  float srgb_lut[256];
 
   int W = 0, H = 0;    // full (deferred / albedo / reservoir allocation) size
   int RW = 0, RH = 0;  // scaled render size
@@ -433,6 +436,7 @@ struct Scene {
   const HkMaterial* material_buffer;
   const HkNode* emissive_node_buffer; uint32_t emissive_node_count;
   const HkEmissive* emissive_buffer;
+  const Ctx::Texture* textures; uint32_t n_textures; const float* srgb_lut;
   const HkFrame* frame;
   const HkView* view;
   const HkLights* lights;
@@ -737,21 +741,63 @@ static v3 calculate_view(const Scene& sc, v4 world_position, bool is_orthographi
   return normalize(P3(sc.view->world_position) - xyz(world_position));
 }
 static inline v4 P4(const float* p) { return V4(p[0], p[1], p[2], p[3]); }
-static Surface retreive_surface(const Scene& sc, uint32_t material_index, v2 uv) {  // light.wgsl:730-742 (NO_TEXTURE)
-  (void)uv;
+// textureSampleLevel(textures[id], samplers[id], uv, 0.0) (light.wgsl:756-789).  WebGPU leaves the
+// filtering arithmetic to the implementation; the contract here: texel centres at (i + 0.5) / size,
+// f32 bilinear weights, sRGB rgb decoded to linear per texel before filtering (as texture units do),
+// mix() of the numeric contract.
+static int wrap_coord(int i, int n, uint32_t mode) {
+  if (mode == HK_ADDRESS_REPEAT) { int m = i % n; return m < 0 ? m + n : m; }
+  if (mode == HK_ADDRESS_MIRROR_REPEAT) { int p = 2 * n; int m = i % p; if (m < 0) m += p; return m < n ? m : p - 1 - m; }
+  return std::min(std::max(i, 0), n - 1);
+}
+static v4 texel(const Scene& sc, const Ctx::Texture& t, int x, int y) {
+  const uint8_t* p = t.rgba.data() + ((size_t)y * t.w + x) * 4;
+  if (t.is_srgb) return V4(sc.srgb_lut[p[0]], sc.srgb_lut[p[1]], sc.srgb_lut[p[2]], (float)p[3] / 255.0f);
+  return V4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
+}
+static inline v4 mix4(v4 a, v4 b, float t) { return V4(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t), mix(a.w, b.w, t)); }
+static v4 sample_texture(const Scene& sc, uint32_t id, v2 uv) {
+  const Ctx::Texture& t = sc.textures[id];
+  const int w = (int)t.w, h = (int)t.h;
+  if (!t.linear) {
+    int x = wrap_coord(f32_to_i32(floorf(uv.x * (float)w)), w, t.au), y = wrap_coord(f32_to_i32(floorf(uv.y * (float)h)), h, t.av);
+    return texel(sc, t, x, y);
+  }
+  float x = uv.x * (float)w - 0.5f, y = uv.y * (float)h - 0.5f;
+  float x0 = floorf(x), y0 = floorf(y);
+  float fx = x - x0, fy = y - y0;
+  int ix = f32_to_i32(x0), iy = f32_to_i32(y0);
+  int xa = wrap_coord(ix, w, t.au), xb = wrap_coord(ix + 1, w, t.au), ya = wrap_coord(iy, h, t.av), yb = wrap_coord(iy + 1, h, t.av);
+  v4 top = mix4(texel(sc, t, xa, ya), texel(sc, t, xb, ya), fx);
+  v4 bot = mix4(texel(sc, t, xa, yb), texel(sc, t, xb, yb), fx);
+  return mix4(top, bot, fy);
+}
+static Surface retreive_surface(const Scene& sc, uint32_t material_index, v2 uv) {  // light.wgsl:730-742 (NO_TEXTURE) / 749-781
   Surface surface;
   const HkMaterial& material = sc.material_buffer[material_index];
   surface.base_color = P4(material.base_color);
   surface.emissive = P4(material.emissive);
   surface.metallic = material.metallic;
   surface.occlusion = 1.0f;
+  if (sc.n_textures) {
+    uint32_t id = material.base_color_texture;
+    if (id != U32_MAX) surface.base_color = surface.base_color * sample_texture(sc, id, uv);
+    id = material.emissive_texture;
+    if (id != U32_MAX) surface.emissive = surface.emissive * sample_texture(sc, id, uv);
+    id = material.metallic_roughness_texture;
+    if (id != U32_MAX) surface.metallic *= sample_texture(sc, id, uv).x;
+    id = material.occlusion_texture;
+    if (id != U32_MAX) surface.occlusion = sample_texture(sc, id, uv).x;
+  }
   surface.roughness = perceptualRoughnessToRoughness(material.perceptual_roughness);
   surface.reflectance = material.reflectance;
   return surface;
 }
-static v4 retreive_emissive(const Scene& sc, uint32_t material_index, v2 uv) {  // light.wgsl:744-747
-  (void)uv;
-  return P4(sc.material_buffer[material_index].emissive);
+static v4 retreive_emissive(const Scene& sc, uint32_t material_index, v2 uv) {  // light.wgsl:744-747 / 783-793
+  const HkMaterial& material = sc.material_buffer[material_index];
+  v4 emissive = P4(material.emissive);
+  if (sc.n_textures && material.emissive_texture != U32_MAX) emissive = emissive * sample_texture(sc, material.emissive_texture, uv);
+  return emissive;
 }
 static v3 lit(v3 radiance, v3 diffuse_color, float roughness, v3 F0, v3 L, v3 N, v3 V) {  // light.wgsl:796-818
   v3 Hh = normalize(L + V);
@@ -883,6 +929,9 @@ static Scene make_scene(Ctx* c) {
   sc.emissive_node_buffer = c->emissive_nodes.data();
   sc.emissive_node_count = (uint32_t)c->emissive_nodes.size();
   sc.emissive_buffer = c->emissives.data();
+  sc.textures = c->textures.data();
+  sc.n_textures = (uint32_t)c->textures.size();
+  sc.srgb_lut = c->srgb_lut;
   sc.frame = &c->frame;
   sc.view = &c->view;
   sc.lights = &c->lights;
@@ -1732,6 +1781,23 @@ int orc_upload_instances(orc_ctx* ctx, const HkInstance* inst, uint32_t ni, cons
   ctx->c.emissives.assign(em, em + ne);
   ctx->c.emissive_nodes.assign(enodes, enodes + nen);
   ctx->c.alias_table.assign(alias, alias + na);
+  return HK_OK;
+}
+int orc_upload_textures(orc_ctx* ctx, const HkImageDesc* images, uint32_t n) {
+  ORC_CHECK(ctx && (images || !n), HK_E_INVALID, "null argument");
+  ctx->c.textures.clear();
+  for (uint32_t i = 0; i < n; ++i) {
+    const HkImageDesc& d = images[i];
+    ORC_CHECK(d.rgba8 && d.width && d.height && d.address_u <= 2 && d.address_v <= 2, HK_E_INVALID, "bad image");
+    Ctx::Texture t;
+    t.rgba.assign(d.rgba8, d.rgba8 + (size_t)d.width * d.height * 4);
+    t.w = d.width; t.h = d.height; t.is_srgb = d.is_srgb; t.au = d.address_u; t.av = d.address_v; t.linear = d.filter_linear;
+    ctx->c.textures.push_back(std::move(t));
+  }
+  for (int i = 0; i < 256; ++i) {  // sRGB EOTF, evaluated in double and rounded once
+    double c = i / 255.0;
+    ctx->c.srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+  }
   return HK_OK;
 }
 int orc_upload_noise(orc_ctx* ctx, const uint8_t* rgba, size_t bytes) {

@@ -40,6 +40,12 @@ def yard_scene():
     return _CACHE["yard"]
 
 
+def yard_textured_scene():
+    if "yard_tex" not in _CACHE:
+        _CACHE["yard_tex"] = synthetic_scene(n_boxes=14, n_spheres=4, n_emitters=3, sphere_rings=6, sphere_segs=8, textured=True)
+    return _CACHE["yard_tex"]
+
+
 def make_case(name):
     S, U = hk.HikariSettings, hk.Upscale
     if name == "cornell_b2":       # BASELINE config 2 at a test size
@@ -59,10 +65,14 @@ def make_case(name):
         scene, sun = yard_scene()
         return Case(name, scene, synthetic_camera(96, 72), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0, emissive_spatial_reuse=True),
                     lights=hk.lights_uniform(directional=sun), frames=range(1, 8))
+    if name == "yard_textured":     # the textured pipelines (light.wgsl:749-793): base colour / metallic / occlusion / emissive textures
+        scene, sun = yard_textured_scene()
+        return Case(name, scene, synthetic_camera(96, 72), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0),
+                    lights=hk.lights_uniform(directional=sun), frames=range(1, 6))
     raise KeyError(name)
 
 
-CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "yard_sun"]
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "yard_sun", "yard_textured"]
 
 
 def run_case(plugin, case, on_frame=None):
