@@ -139,11 +139,18 @@ def test_error_paths():
     with pytest.raises(hk.HikariError) as e:
         eng.pass_run(F.PASS_INDIRECT)
     assert e.value.code == F.HK_E_NOT_READY      # reference: node silently returns Ok(()) (light.rs:606-617)
-    m = hk.standard_material()
-    m.base_color_texture = 3
+    # a material that references a texture which was never uploaded is rejected when the scene is finalised
+    bad = hk.Engine(device=0)
+    bad.upload_noise()
+    scene = hk.load_cornell()
+    scene.materials[2].base_color_texture = 3
+    bad.upload_scene(scene)
+    bad.resize(32, 32, 1.0)
+    cam = hk.cornell_camera(32, 32)
+    bad.frame_begin(hk.frame_uniform(hk.HikariSettings(), 1), cam.view_uniform(), cam.previous_view_uniform(), hk.lights_uniform())
     with pytest.raises(hk.HikariError) as e:
-        eng.api.call("upload_materials", eng.ctx, C.byref(m), 1)
-    assert e.value.code == F.HK_E_UNSUPPORTED
+        bad.pass_run(F.PASS_PREPASS)
+    assert e.value.code == F.HK_E_INVALID and "texture" in str(e.value)
     with pytest.raises(hk.HikariError) as e:
         eng.api.call("upload_noise", eng.ctx, None, 0)
     assert e.value.code == F.HK_E_INVALID
