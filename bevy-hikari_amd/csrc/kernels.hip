@@ -293,6 +293,68 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   flush_counters<COUNT>(rc, 0, counters);
 }
 
+// One iteration of the MULTIPLE_BOUNCES loop (light.wgsl:1313-1394) on the state a path carries from
+// bounce to bounce.  Returns false when the path ends at this bounce (miss -> ambient, `break`).
+struct PathState {
+  f4 random;                   // bounce_sample.random
+  f3 position, normal;         // bounce_sample.visible_position.xyz / visible_normal
+  f3 transport;                // color_transport
+  f4 radiance;                 // s.radiance
+  f4 first_position;           // s.sample_position (bounce 0)
+  f3 first_normal;             // s.sample_normal   (bounce 0)
+  float pdf;                   // rand_sample.w of bounce 0
+};
+__device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, uint32_t n, PathState& p, RayCounters& rc) {
+  f4 rand_sample = sample_cosine_hemisphere(F2(p.random.x, p.random.y));
+  Ray ray;
+  ray.origin = p.position + p.normal * HK_RAY_BIAS;
+  ray.direction = mul(normal_basis(p.normal), xyz(rand_sample));
+  ray.inv_direction = 1.0f / ray.direction;
+
+  Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+  HitInfo info = hit_info(sc, ray, hit);
+  if (n == 0u) {
+    p.first_position = info.position;
+    p.first_normal = info.normal;
+    p.pdf = rand_sample.w;
+  }
+  const f3 sample_position = xyz(info.position);
+  const f3 sample_normal = info.normal;
+
+  if (hit.instance_index != HK_U32_MAX) {
+    f3 out_radiance = F3(0, 0, 0);
+    Surface surface = retreive_surface(sc, info.material_index, info.uv);
+    surface.roughness = 1.0f;
+    const uint32_t info_instance = info.instance_index;
+    LightCandidate candidate = select_light_candidate(sc, fr, p.random, sample_position, sample_normal, info_instance, info, rc);
+    const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
+    const f3 bounce_view_direction = normalize(p.position - sample_position);
+
+    if (dot(candidate.direction, sample_normal) > 0.0f && candidate.p > 0.0f) {
+      ray.origin = sample_position + sample_normal * HK_RAY_BIAS;
+      ray.direction = candidate.direction;
+      ray.inv_direction = 1.0f / ray.direction;
+      hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+      occlude_hit_info(ray, hit, info);
+      f4 in_radiance = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
+      out_radiance = shading(fr, bounce_view_direction, sample_normal, ray.direction, surface, in_radiance);
+      out_radiance = out_radiance / candidate.p;
+      if (n > 0u) out_radiance = (rand_sample.w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample.w;
+      float out_luminance = luminance(out_radiance);
+      if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
+      p.radiance = p.radiance + F4(p.transport * out_radiance, 1.0f);
+    }
+    p.transport = p.transport * env_brdf(bounce_view_direction, sample_normal, surface);
+    p.random = fract(p.random + fr.number_golden);
+    p.position = sample_position;
+    p.normal = sample_normal;
+    return true;
+  }
+  f3 out_radiance = xyz(input_radiance(sc, fr, ray, info, false, HK_DONT_SAMPLE_EMISSIVE, true));
+  p.radiance = p.radiance + F4(p.transport * out_radiance, 0.0f);
+  return false;
+}
+
 // ------------------------------------------------------------------ indirect_lit_ambient
 template <bool MULTIPLE_BOUNCES, bool COUNT, bool LDS>
 __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
@@ -339,59 +401,22 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
       Surface surface;
 
       if (MULTIPLE_BOUNCES) {  // light.wgsl:1309-1394
-        Sample bounce_sample = s;
-        f3 color_transport = F3(1.0f, 1.0f, 1.0f);
-        for (uint32_t n = 0u; n < fr.indirect_bounces && (color_transport.x > 0.01f || color_transport.y > 0.01f || color_transport.z > 0.01f); n += 1u) {
-          f4 rand_sample = sample_cosine_hemisphere(F2(bounce_sample.random.x, bounce_sample.random.y));
-          ray.origin = xyz(bounce_sample.visible_position) + bounce_sample.visible_normal * HK_RAY_BIAS;
-          ray.direction = mul(normal_basis(bounce_sample.visible_normal), xyz(rand_sample));
-          ray.inv_direction = 1.0f / ray.direction;
-
-          Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
-          HitInfo info = hit_info(sc, ray, hit);
-
-          if (n == 0u) {
-            s.sample_position = info.position;
-            s.sample_normal = info.normal;
-            pdf = rand_sample.w;
-          }
-          bounce_sample.sample_position = info.position;
-          bounce_sample.sample_normal = info.normal;
-
-          if (hit.instance_index != HK_U32_MAX) {
-            f3 out_radiance = F3(0, 0, 0);
-            surface = retreive_surface(sc, info.material_index, info.uv);
-            surface.roughness = 1.0f;
-            const uint32_t info_instance = info.instance_index;
-            LightCandidate candidate = select_light_candidate(sc, fr, bounce_sample.random, xyz(bounce_sample.sample_position),
-                                                              bounce_sample.sample_normal, info_instance, info, rc);
-            const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
-            const f3 bounce_view_direction = normalize(xyz(bounce_sample.visible_position) - xyz(bounce_sample.sample_position));
-
-            if (dot(candidate.direction, bounce_sample.sample_normal) > 0.0f && candidate.p > 0.0f) {
-              ray.origin = xyz(bounce_sample.sample_position) + bounce_sample.sample_normal * HK_RAY_BIAS;
-              ray.direction = candidate.direction;
-              ray.inv_direction = 1.0f / ray.direction;
-              hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
-              occlude_hit_info(ray, hit, info);
-              f4 in_radiance = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
-              out_radiance = shading(fr, bounce_view_direction, bounce_sample.sample_normal, ray.direction, surface, in_radiance);
-              out_radiance = out_radiance / candidate.p;
-              if (n > 0u) out_radiance = (rand_sample.w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample.w;
-              float out_luminance = luminance(out_radiance);
-              if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
-              s.radiance = s.radiance + F4(color_transport * out_radiance, 1.0f);
-            }
-            color_transport = color_transport * env_brdf(bounce_view_direction, bounce_sample.sample_normal, surface);
-            bounce_sample.random = fract(bounce_sample.random + fr.number_golden);
-            bounce_sample.visible_position = bounce_sample.sample_position;
-            bounce_sample.visible_normal = bounce_sample.sample_normal;
-          } else {
-            f3 out_radiance = xyz(input_radiance(sc, fr, ray, info, false, HK_DONT_SAMPLE_EMISSIVE, true));
-            s.radiance = s.radiance + F4(color_transport * out_radiance, 0.0f);
-            break;
-          }
+        PathState p;
+        p.random = s.random;
+        p.position = xyz(s.visible_position);
+        p.normal = s.visible_normal;
+        p.transport = F3(1.0f, 1.0f, 1.0f);
+        p.radiance = s.radiance;
+        p.first_position = s.sample_position;
+        p.first_normal = s.sample_normal;
+        p.pdf = 0.0f;
+        for (uint32_t n = 0u; n < fr.indirect_bounces && (p.transport.x > 0.01f || p.transport.y > 0.01f || p.transport.z > 0.01f); n += 1u) {
+          if (!bounce_step(sc, fr, n, p, rc)) break;
         }
+        s.radiance = p.radiance;
+        s.sample_position = p.first_position;
+        s.sample_normal = p.first_normal;
+        pdf = p.pdf;
       } else {  // light.wgsl:1395-1450
         f4 rand_sample = sample_cosine_hemisphere(F2(s.random.x, s.random.y));
         ray.origin = xyz(s.visible_position) + s.visible_normal * HK_RAY_BIAS;

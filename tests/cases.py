@@ -61,6 +61,9 @@ def make_case(name):
     if name == "cornell_notemporal":
         return Case(name, cornell_scene(), hk.cornell_camera(64, 48), S(temporal_reuse=False, indirect_spatial_reuse=False, upscale=U.SMAA_TU_1_0,
                                                                        max_reservoir_lifetime=1.0), frames=range(1, 4))
+    if name == "cornell_b8":       # BASELINE config 5 at a test size: 8 bounces (path compaction kernel), both spatial passes, no denoise
+        return Case(name, cornell_scene(), hk.cornell_camera(112, 80), S(indirect_bounces=8, emissive_spatial_reuse=True, denoise=False,
+                                                                       upscale=U.SMAA_TU_1_0), frames=range(1, 5))
     if name == "yard_sun":          # several emitters (light-BVH pick, alias tables), sun cone, strips, scaled/rotated instances
         scene, sun = yard_scene()
         return Case(name, scene, synthetic_camera(96, 72), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0, emissive_spatial_reuse=True),
@@ -72,7 +75,7 @@ def make_case(name):
     raise KeyError(name)
 
 
-CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "yard_sun", "yard_textured"]
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured"]
 
 
 def run_case(plugin, case, on_frame=None):
