@@ -117,57 +117,86 @@ class HikariSettings:  # lib.rs:400-455 (field order and defaults)
 
 
 # ---------------------------------------------------------------------------------------------
-# small f64 -> f32 matrix helpers (glam conventions, column-major flat arrays)
+# 4x4 helpers in plain IEEE doubles, column-major flat lists m[c*4+r] (glam conventions).  Written
+# with explicit loops in a fixed order so that the C++ host mirror (include/hikari.hpp) produces the
+# SAME f32 uniforms - no BLAS/LAPACK whose summation order could differ in the last bit.
 # ---------------------------------------------------------------------------------------------
+def _mul4(a, b):
+    o = [0.0] * 16
+    for c in range(4):
+        for r in range(4):
+            s = 0.0
+            for k in range(4):
+                s += a[k * 4 + r] * b[c * 4 + k]
+            o[c * 4 + r] = s
+    return o
+
+
 def look_at_transform(eye, target, up=(0.0, 1.0, 0.0)):
-    """Transform::from_translation(eye).looking_at(target, up) as a 4x4 camera-to-world matrix."""
-    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
-    fwd = target - eye
-    fwd /= np.linalg.norm(fwd)
-    right = np.cross(fwd, up)
-    right /= np.linalg.norm(right)
-    upv = np.cross(right, fwd)
-    m = np.eye(4)
-    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = right, upv, -fwd, eye
-    return m
+    """Transform::from_translation(eye).looking_at(target, up) as a column-major camera-to-world matrix."""
+    eye, target, up = ([float(x) for x in v] for v in (eye, target, up))
+
+    def norm(v):
+        l = math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+        return [v[0] / l, v[1] / l, v[2] / l]
+
+    def cross(a, b):
+        return [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]]
+
+    f = norm([target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]])
+    r = norm(cross(f, up))
+    u = cross(r, f)
+    return [r[0], r[1], r[2], 0.0, u[0], u[1], u[2], 0.0, -f[0], -f[1], -f[2], 0.0, eye[0], eye[1], eye[2], 1.0]
 
 
-def perspective_infinite_reverse_rh(fov_y, aspect, near):
-    f = 1.0 / math.tan(0.5 * fov_y)
-    m = np.zeros((4, 4))
-    m[0, 0] = f / aspect
-    m[1, 1] = f
-    m[3, 2] = -1.0
-    m[2, 3] = near
-    return m
-
-
-def _flat(m):  # row/col numpy matrix -> column-major 16 floats
-    return np.asarray(m, dtype=np.float64).T.reshape(-1).astype(np.float32)
+def _f32(m):
+    return np.asarray(m, dtype=np.float64).astype(np.float32)
 
 
 @dataclass
 class Camera:
     """Camera3dBundle with bevy's default PerspectiveProjection (fov pi/4, near 0.1, infinite reverse-Z)."""
-    transform: np.ndarray  # 4x4 camera-to-world
+    transform: list  # column-major 4x4 camera-to-world (16 doubles)
     width: int
     height: int
-    fov: float = math.pi / 4.0
+    fov: float = 0.78539816339744830962
     near: float = 0.1
 
-    def view_uniform(self):
-        proj = perspective_infinite_reverse_rh(self.fov, self.width / self.height, self.near)
-        view = self.transform
-        inv_view = np.linalg.inv(view)
-        view_proj = proj @ inv_view
+    def projection(self):  # Mat4::perspective_infinite_reverse_rh
+        f = 1.0 / math.tan(0.5 * self.fov)
+        aspect = float(self.width) / float(self.height)
+        m = [0.0] * 16
+        m[0], m[5], m[11], m[14] = f / aspect, f, -1.0, self.near
+        return m
+
+    def inverse_projection(self):
+        p = self.projection()
+        m = [0.0] * 16
+        m[0], m[5], m[11], m[14] = 1.0 / p[0], 1.0 / p[5], 1.0 / p[14], -1.0
+        return m
+
+    def inverse_view(self):  # rigid inverse: [R^T | -R^T t]
+        t = [float(x) for x in np.asarray(self.transform, dtype=np.float64).reshape(-1)]
+        m = [0.0] * 16
+        for c in range(3):
+            for r in range(3):
+                m[c * 4 + r] = t[r * 4 + c]
+        for r in range(3):
+            m[12 + r] = -(t[r * 4 + 0] * t[12] + t[r * 4 + 1] * t[13] + t[r * 4 + 2] * t[14])
+        m[15] = 1.0
+        return m
+
+    def view_uniform(self):  # bevy_render 0.9.1 ViewUniform
+        t = [float(x) for x in np.asarray(self.transform, dtype=np.float64).reshape(-1)]
+        proj, inv_view, inv_proj = self.projection(), self.inverse_view(), self.inverse_projection()
         v = F.HkView()
-        v.view_proj[:] = _flat(view_proj)
-        v.inverse_view_proj[:] = _flat(view @ _inv_proj(proj))  # (P * V^-1)^-1 = V * P^-1
-        v.view[:] = _flat(view)
-        v.inverse_view[:] = _flat(inv_view)
-        v.projection[:] = _flat(proj)
-        v.inverse_projection[:] = _flat(_inv_proj(proj))
-        v.world_position[:] = view[:3, 3].astype(np.float32)
+        v.view_proj[:] = _f32(_mul4(proj, inv_view))
+        v.inverse_view_proj[:] = _f32(_mul4(t, inv_proj))  # (P * V^-1)^-1 = V * P^-1
+        v.view[:] = _f32(t)
+        v.inverse_view[:] = _f32(inv_view)
+        v.projection[:] = _f32(proj)
+        v.inverse_projection[:] = _f32(inv_proj)
+        v.world_position[:] = _f32(t[12:15])
         v.viewport[:] = [0.0, 0.0, float(self.width), float(self.height)]
         return v
 
@@ -178,17 +207,6 @@ class Camera:
         p.view_proj[:] = list(v.view_proj)
         p.inverse_view_proj[:] = list(v.inverse_view_proj)
         return p
-
-
-def _inv_proj(proj):
-    """Inverse of perspective_infinite_reverse_rh (singular for numpy's generic inverse is not an issue, but keep it exact)."""
-    fa, f, near = proj[0, 0], proj[1, 1], proj[2, 3]
-    m = np.zeros((4, 4))
-    m[0, 0] = 1.0 / fa
-    m[1, 1] = 1.0 / f
-    m[2, 3] = -1.0
-    m[3, 2] = 1.0 / near
-    return m
 
 
 def lights_uniform(directional=None, ambient_color=(1.0, 1.0, 1.0), ambient_brightness=0.05):

@@ -1,0 +1,136 @@
+// examples/cornell.cpp - the C++ twin of the reference's examples/cornell.rs (setup(): spawn
+// models/cornell.glb, camera at (0,1,4) looking at (0,1,0), HikariSettings::default()), driving
+// libhikari_hip.so through the C++ host mirror include/hikari.hpp.  Headless: renders N frames and
+// writes the tone-mapped image as a PPM and/or the raw rgba16f words.
+//
+//   cornell [--size W H] [--frames N] [--bounces B] [--ratio R] [--by-nodes] [--ppm out.ppm] [--raw out.bin] [--describe]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "hikari.hpp"
+
+using namespace hikari;
+
+static std::vector<uint8_t> read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+// assets/cornell.hkscene (tools/make_fixtures.py: make_cornell_bin) -> builder
+static void load_cornell(const std::string& path, SceneBuilder& b) {
+  std::vector<uint8_t> d = read_file(path);
+  size_t off = 0;
+  auto u32 = [&]() { uint32_t v; std::memcpy(&v, d.data() + off, 4); off += 4; return v; };
+  auto floats = [&](size_t n) { std::vector<float> v(n); std::memcpy(v.data(), d.data() + off, n * 4); off += n * 4; return v; };
+  if (std::memcmp(d.data(), "HKSC", 4) != 0) throw std::runtime_error("not an HKSC file");
+  off = 4;
+  uint32_t version = u32(), n_meshes = u32(), n_materials = u32(), n_instances = u32();
+  if (version != 1) throw std::runtime_error("unsupported HKSC version");
+  struct MeshData { std::vector<float> p, n, uv; std::vector<uint32_t> idx; uint32_t material; };
+  std::vector<MeshData> meshes(n_meshes);
+  for (auto& m : meshes) {
+    uint32_t nv = u32(), ni = u32();
+    m.material = u32();
+    m.p = floats(nv * 3);
+    m.n = floats(nv * 3);
+    m.uv = floats(nv * 2);
+    m.idx.resize(ni);
+    std::memcpy(m.idx.data(), d.data() + off, ni * 4);
+    off += ni * 4;
+  }
+  std::vector<uint32_t> material_ids;
+  for (uint32_t i = 0; i < n_materials; ++i) {
+    std::vector<float> v = floats(9);  // base_color[4], emissive[3], roughness, metallic
+    material_ids.push_back(b.add_material(standard_material(&v[0], &v[4], v[7], v[8])));
+  }
+  std::vector<uint32_t> mesh_ids;
+  for (auto& m : meshes) mesh_ids.push_back(b.add_mesh(m.p, m.n, m.uv, m.idx));
+  for (uint32_t i = 0; i < n_instances; ++i) {
+    uint32_t mesh = u32();
+    std::vector<float> t = floats(16);
+    b.add_instance(mesh_ids[mesh], material_ids[meshes[mesh].material], t.data());
+  }
+  b.finish();
+}
+
+static float half_to_float(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
+  if (e == 0) {
+    float v = (float)m * 5.9604644775390625e-8f;
+    return sign ? -v : v;
+  }
+  u = e == 31 ? (sign | 0x7f800000u | (m << 13)) : (sign | ((e + 112u) << 23) | (m << 13));
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+int main(int argc, char** argv) {
+  uint32_t w = 256, h = 256;
+  size_t frames = 8;
+  HikariSettings settings;  // HikariSettings::default(), examples/cornell.rs:53
+  bool by_nodes = false, describe = false;
+  std::string ppm, raw, assets = "bevy-hikari_amd/assets";
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a == "--size" && i + 2 < argc) { w = (uint32_t)atoi(argv[++i]); h = (uint32_t)atoi(argv[++i]); }
+    else if (a == "--frames" && i + 1 < argc) frames = (size_t)atoi(argv[++i]);
+    else if (a == "--bounces" && i + 1 < argc) settings.indirect_bounces = (size_t)atoi(argv[++i]);
+    else if (a == "--ratio" && i + 1 < argc) settings.upscale = Upscale::SmaaTu4x((float)atof(argv[++i]));
+    else if (a == "--by-nodes") by_nodes = true;
+    else if (a == "--ppm" && i + 1 < argc) ppm = argv[++i];
+    else if (a == "--raw" && i + 1 < argc) raw = argv[++i];
+    else if (a == "--assets" && i + 1 < argc) assets = argv[++i];
+    else if (a == "--describe") describe = true;
+    else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+  }
+  if (describe) {  // no GPU needed: host-side mirrors only
+    HkSettings c = settings.to_c(), d;
+    hk_settings_default(&d);
+    std::printf("graph=%s nodes=%s,%s,%s,%s workgroup=%u noise=%u\n", graph::NAME, graph::node::PREPASS, graph::node::LIGHT, graph::node::POST_PROCESS,
+                graph::node::OVERLAY, WORKGROUP_SIZE, NOISE_TEXTURE_COUNT);
+    std::printf("defaults_match_library=%d ratio=%.1f abi=%u\n", std::memcmp(&c, &d, sizeof(c)) == 0, settings.upscale.ratio(), hk_abi_version());
+    SceneBuilder b;
+    load_cornell(assets + "/cornell.hkscene", b);
+    const HkNode* nodes; uint32_t n_nodes; const HkEmissive* em; uint32_t n_em;
+    check(hk_scene_builder_instance_nodes(b.handle(), &nodes, &n_nodes), "instance_nodes");
+    check(hk_scene_builder_emissives(b.handle(), &em, &n_em), "emissives");
+    std::printf("tlas_nodes=%u emissives=%u\n", n_nodes, n_em);
+    return 0;
+  }
+  try {
+    HikariPlugin plugin(read_file(assets + "/noise_rgba8_16x64x64.bin"));  // App::new().add_plugin(HikariPlugin)
+    SceneBuilder scene;
+    load_cornell(assets + "/cornell.hkscene", scene);                      // asset_server.load("models/cornell.glb#Scene0")
+    plugin.set_scene(scene);
+    Camera camera = Camera::looking_at({0.0, 1.0, 4.0}, {0.0, 1.0, 0.0}, {0.0, 1.0, 0.0}, w, h);  // cornell.rs:49-50
+    for (size_t n = 1; n <= frames; ++n) plugin.render(camera, settings, n, by_nodes);
+    plugin.wait();
+    std::vector<uint8_t> tm = plugin.context().read(HK_BUF_TONE_MAPPED);
+    uint32_t rw, rh, bpp;
+    check(hk_buffer_info(plugin.context().get(), HK_BUF_TONE_MAPPED, &rw, &rh, &bpp), "hk_buffer_info");
+    if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)tm.data(), (std::streamsize)tm.size());
+    if (!ppm.empty()) {
+      std::ofstream f(ppm, std::ios::binary);
+      f << "P6\n" << rw << " " << rh << "\n255\n";
+      const uint16_t* px = (const uint16_t*)tm.data();
+      for (size_t i = 0; i < (size_t)rw * rh; ++i)
+        for (int k = 0; k < 3; ++k) {
+          float v = half_to_float(px[4 * i + k]);
+          v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+          f.put((char)(unsigned char)(std::pow(v, 1.0f / 2.2f) * 255.0f + 0.5f));
+        }
+    }
+    std::printf("rendered %zu frames at %ux%u (render size %ux%u)\n", frames, w, h, rw, rh);
+  } catch (const Error& e) {
+    std::fprintf(stderr, "hikari error %d: %s\n", e.code, e.what());
+    return e.code == HK_E_NO_DEVICE ? 3 : 1;
+  }
+  return 0;
+}

@@ -61,6 +61,6 @@ def test_camera_uniform_is_bevy_reverse_z():
 
     vp = np.array(v.view_proj, dtype=np.float64).reshape(4, 4).T
     clip = vp @ np.array([0.0, 1.0, 0.0, 1.0])  # the look-at target, 4 units away
-    assert abs(clip[2] / clip[3] - 0.1 / 4.0) < 1e-7 and abs(clip[0]) < 1e-7
+    assert abs(clip[2] / clip[3] - 0.1 / 4.0) < 1e-7 and abs(clip[0]) < 1e-7 and abs(clip[1]) < 1e-7
     ivp = np.array(v.inverse_view_proj, dtype=np.float64).reshape(4, 4).T
     assert np.allclose(ivp @ vp, np.eye(4), atol=1e-5)

@@ -156,9 +156,29 @@ def make_cornell():
     print(f"cornell: {len(meshes)} meshes, {ntri} tris, {nv} verts, {len(materials)} materials, {len(instances)} instances")
 
 
+def make_cornell_bin():
+    """Binary twin of cornell.json (same numbers) for hosts without a JSON parser (examples/cornell.cpp):
+    'HKSC' u32 version, n_meshes, n_materials, n_instances; per mesh: n_vertices, n_indices, material,
+    positions f32x3[], normals f32x3[], uvs f32x2[], indices u32[]; per material: base_color f32x4,
+    emissive f32x3, roughness, metallic; per instance: mesh u32, transform f32x16 (column-major)."""
+    j = json.load(open(os.path.join(OUT, "cornell.json")))
+    out = bytearray(struct.pack("<4sIIII", b"HKSC", 1, len(j["meshes"]), len(j["materials"]), len(j["instances"])))
+    for m in j["meshes"]:
+        pos, nrm = np.asarray(m["positions"], np.float32), np.asarray(m["normals"], np.float32)
+        uv, idx = np.asarray(m["uvs"], np.float32), np.asarray(m["indices"], np.uint32)
+        out += struct.pack("<III", len(pos), len(idx), m["material"]) + pos.tobytes() + nrm.tobytes() + uv.tobytes() + idx.tobytes()
+    for m in j["materials"]:
+        out += np.asarray(list(m["base_color_factor"]) + list(m["emissive_factor"]) + [m["roughness_factor"], m["metallic_factor"]], np.float32).tobytes()
+    for i in j["instances"]:
+        out += struct.pack("<I", i["mesh"]) + np.asarray(i["transform"], np.float32).tobytes()
+    open(os.path.join(OUT, "cornell.hkscene"), "wb").write(out)
+    print("cornell.hkscene:", len(out), "bytes")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present; fixtures are already committed")
     os.makedirs(OUT, exist_ok=True)
     make_noise()
     make_cornell()
+    make_cornell_bin()
