@@ -231,6 +231,31 @@ struct ScopedTimer {
   }
 };
 
+// `bvh` 0.7.1's flat format puts a "navigator" node (child box, entry = next) in front of EVERY subtree,
+// including single-leaf subtrees, and the reference then tests the leaf's own (re-derived) box again:
+// two steps with the same box for every leaf reached.  With leaf boxes filled in at upload, a navigator
+// whose subtree is one leaf with an equal box can take over the leaf's role (entry := leaf entry): the
+// walk performs box test -> leaf action -> continue at the same exit index, i.e. exactly the outcomes
+// of the two-step sequence, and the original leaf slot is simply never visited.  No index changes.
+// entry/exit are LOCAL to [begin, begin + count).  Returns the number of folded navigators.
+size_t fold_leaf_navigators(std::vector<float4>& lo, std::vector<float4>& hi, size_t begin, size_t count) {
+  auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+  size_t folded = 0;
+  for (size_t k = 0; k + 1 < count; ++k) {
+    float4& nlo = lo[begin + k];
+    const float4& nhi = hi[begin + k];
+    const uint32_t entry = bits(nlo.w), exit_ = bits(nhi.w);
+    if (entry >= HK_BVH_LEAF_FLAG || entry != k + 1) continue;
+    const float4& clo = lo[begin + k + 1];
+    const float4& chi = hi[begin + k + 1];
+    if (bits(clo.w) < HK_BVH_LEAF_FLAG || bits(chi.w) != exit_) continue;
+    if (!(nlo.x == clo.x && nlo.y == clo.y && nlo.z == clo.z && nhi.x == chi.x && nhi.y == chi.y && nhi.z == chi.z)) continue;
+    nlo.w = clo.w;
+    ++folded;
+  }
+  return folded;
+}
+
 // Convert the reference-layout scene to the device layout (hk_device.hpp header comment).
 int finalize_scene(hk_ctx* c) {
   if (!c->scene_dirty) return HK_OK;
@@ -322,6 +347,15 @@ int finalize_scene(hk_ctx* c) {
     tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
+  {  // fold single-leaf navigators: once per distinct mesh range, and for the TLAS
+    std::vector<uint8_t> done(n_nodes + 1, 0);
+    for (const HkInstance& in : c->instances) {
+      if (in.mesh.node_count == 0 || done[in.mesh.node_offset]) continue;
+      done[in.mesh.node_offset] = 1;
+      fold_leaf_navigators(lo, hi, in.mesh.node_offset, in.mesh.node_count);
+    }
+    fold_leaf_navigators(tlo, thi, 0, n_tlas);
+  }
   // unified node array: TLAS first, then every BLAS; lo/hi interleaved (32 B per node)
   std::vector<float4> nodes;
   nodes.reserve(2 * (n_tlas + n_nodes));
@@ -374,6 +408,7 @@ int finalize_scene(hk_ctx* c) {
     llo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     lhi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
+  fold_leaf_navigators(llo, lhi, 0, n_light);
   const size_t off_light_lo = blob.add(llo);
   const size_t off_light_hi = blob.add(lhi);
 

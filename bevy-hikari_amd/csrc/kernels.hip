@@ -19,6 +19,8 @@
 // share that XCD's L2 for the gather passes.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 
@@ -483,12 +485,17 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
 // The reference caches the workgroup's own 8x8 reservoirs + depths in workgroup memory
 // (light.wgsl:1500-1501,1522-1524,1584-1591); the cached values are exactly what the buffer
 // loads return, so reading neighbours from L2 is result-identical.
+// per-tap constants of the Fibonacci spiral (light.wgsl:1568-1571,1609-1610): functions of the tap
+// index only, evaluated once on the host with the same IEEE operations (f32 divide, sqrt, multiply)
+struct SpatialTaps {
+  float radius[16], tap_interval[16];
+  uint32_t tap_count[16];
+};
 template <bool EMISSIVE_LIT>
-__global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end) {
+__global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, SpatialTaps taps, int row_begin, int row_end) {
   const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
   if (!px.valid) return;
   constexpr uint32_t SPATIAL_REUSE_COUNT = EMISSIVE_LIT ? 8u : 16u;
-  constexpr float SPATIAL_REUSE_RANGE = EMISSIVE_LIT ? 10.0f : 20.0f;
   const int x = px.x, y = px.y;
   const int index = x + fr.rw * y;
   const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
@@ -531,7 +538,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
   const float rot = dot(s.random, F4(1.0f, 1.0f, 1.0f, 1.0f));
   for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
     const float angle = HK_TAU * fract((float)i * HK_GOLDEN_RATIO + rot + fr.random_float_number);
-    const float radius = sqrtf((float)i / (float)SPATIAL_REUSE_COUNT) * SPATIAL_REUSE_RANGE;
+    const float radius = taps.radius[i - 1u];
     float sn, cs;
     sincos_(angle, &sn, &cs);
     const f2 offset = radius * F2(cs, sn);
@@ -553,8 +560,8 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     const f3 sample_direction = normalize(xyz(q.s.sample_position) - xyz(s.visible_position));
     if (dot(sample_direction, s.visible_normal) < 0.0f) continue;
 
-    const float tap_interval = fmax_(1.0f, radius / 5.0f);
-    const uint32_t tap_count = f32_to_u32(radius / tap_interval);
+    const float tap_interval = taps.tap_interval[i - 1u];
+    const uint32_t tap_count = taps.tap_count[i - 1u];
     bool occluded = false;
     const f2 dir = normalize(offset);
     for (uint32_t j = 1u; j <= tap_count; j += 1u) {
@@ -712,8 +719,18 @@ void launch_indirect(hipStream_t st, bool multiple_bounces, const DScene& sc, co
 void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1) {
   if (y1 <= y0) return;
   dim3 grid = grid_for(fr.rw, y1 - y0);
-  if (emissive_lit) hipLaunchKernelGGL(k_spatial_reuse<true>, grid, dim3(256), 0, st, sc, fr, g, t, y0, y1);
-  else hipLaunchKernelGGL(k_spatial_reuse<false>, grid, dim3(256), 0, st, sc, fr, g, t, y0, y1);
+  SpatialTaps taps{};
+  const uint32_t count = emissive_lit ? 8u : 16u;           // light.wgsl:246-252
+  const float range = emissive_lit ? 10.0f : 20.0f;
+  for (uint32_t i = 1; i <= count; ++i) {
+    const float radius = sqrtf((float)i / (float)count) * range;           // light.wgsl:1570
+    const float interval = std::fmax(1.0f, radius / 5.0f);                  // light.wgsl:1609 (SPATIAL_REUSE_TAPS + 1 = 5)
+    taps.radius[i - 1] = radius;
+    taps.tap_interval[i - 1] = interval;
+    taps.tap_count[i - 1] = (uint32_t)(radius / interval);                 // light.wgsl:1610
+  }
+  if (emissive_lit) hipLaunchKernelGGL(k_spatial_reuse<true>, grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
+  else hipLaunchKernelGGL(k_spatial_reuse<false>, grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
 }
 void launch_tone_mapping(hipStream_t st, const DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1) {
   if (y1 <= y0) return;
