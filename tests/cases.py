@@ -68,6 +68,17 @@ def make_case(name):
         scene, sun = yard_scene()
         return Case(name, scene, synthetic_camera(96, 72), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0, emissive_spatial_reuse=True),
                     lights=hk.lights_uniform(directional=sun), frames=range(1, 8))
+    if name == "yard_no_emitters":  # empty emissive list / light BVH: every light pick falls back to the sun cone
+        if "yard_dark" not in _CACHE:
+            _CACHE["yard_dark"] = synthetic_scene(n_boxes=10, n_spheres=3, n_emitters=0, sphere_rings=5, sphere_segs=6)
+        scene, sun = _CACHE["yard_dark"]
+        return Case(name, scene, synthetic_camera(72, 40), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0), lights=hk.lights_uniform(directional=sun),
+                    frames=range(1, 5))
+    if name == "background_only":   # camera looks away from the box: every pixel takes the depth < eps paths
+        cam = hk.Camera(hk.look_at_transform((0.0, 1.0, 4.0), (0.0, 1.0, 9.0)), 40, 24)
+        return Case(name, cornell_scene(), cam, S(indirect_bounces=2, upscale=U.SMAA_TU_1_0), frames=range(1, 4))
+    if name == "tiny_3x5":          # smaller than one 8x8 tile, odd in both axes
+        return Case(name, cornell_scene(), hk.cornell_camera(3, 5), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0, emissive_spatial_reuse=True), frames=range(1, 5))
     if name == "yard_textured":     # the textured pipelines (light.wgsl:749-793): base colour / metallic / occlusion / emissive textures
         scene, sun = yard_textured_scene()
         return Case(name, scene, synthetic_camera(96, 72), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0),
@@ -75,7 +86,7 @@ def make_case(name):
     raise KeyError(name)
 
 
-CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured"]
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5"]
 
 
 def run_case(plugin, case, on_frame=None):

@@ -36,7 +36,7 @@ def test_oracle_matches_golden(name):
     st = p.engine.stats()
     assert [st.rays_primary, st.rays_tlas, st.rays_blas] == list(g["rays"])
     out = p.output(case.settings)
-    assert np.isfinite(out).all() and out[..., :3].max() > 0.05
+    assert np.isfinite(out).all() and (name == "background_only" or out[..., :3].max() > 0.05)
 
 
 def test_oracle_is_thread_count_invariant():
