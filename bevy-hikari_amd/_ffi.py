@@ -126,7 +126,7 @@ class HkHaloOp(C.Structure):
 class HkStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
-                ("_pad", u32)]
+                ("_pad", u32), ("scene_mesh_builds", u64), ("scene_instance_builds", u64)]
 
 
 assert C.sizeof(HkVertex) == 32 and C.sizeof(HkPrimitive) == 48 and C.sizeof(HkNode) == 32 and C.sizeof(HkInstance) == 176
@@ -149,6 +149,7 @@ _SIGNATURES = {
     "upload_meshes": [_vp, P(HkVertex), u32, P(HkPrimitive), u32, P(HkNode), u32],
     "upload_materials": [_vp, P(HkMaterial), u32],
     "upload_instances": [_vp, P(HkInstance), u32, P(HkNode), u32, P(HkEmissive), u32, P(HkNode), u32, P(HkAliasEntry), u32],
+    "upload_previous_transforms": [_vp, P(f32), u32],
     "upload_noise": [_vp, _vp, C.c_size_t],
     "upload_textures": [_vp, P(HkImageDesc), u32],
     "resize": [_vp, u32, u32, f32],
@@ -178,6 +179,8 @@ _PRODUCT_ONLY = {
     "scene_builder_add_material": [_vp, P(HkMaterial), P(u32)],
     "scene_builder_add_instance": [_vp, u32, u32, P(f32), P(u32)],
     "scene_builder_finish": [_vp],
+    "scene_builder_set_instance_transform": [_vp, u32, P(f32)],
+    "scene_builder_previous_transforms": [_vp, P(P(f32)), P(u32)],
     "scene_builder_vertices": [_vp, P(P(HkVertex)), P(u32)],
     "scene_builder_primitives": [_vp, P(P(HkPrimitive)), P(u32)],
     "scene_builder_asset_nodes": [_vp, P(P(HkNode)), P(u32)],
@@ -188,6 +191,7 @@ _PRODUCT_ONLY = {
     "scene_builder_emissive_nodes": [_vp, P(P(HkNode)), P(u32)],
     "scene_builder_alias_table": [_vp, P(P(HkAliasEntry)), P(u32)],
     "upload_scene": [_vp, _vp],
+    "upload_scene_instances": [_vp, _vp],
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
     "band_plan_for": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],

@@ -113,10 +113,17 @@ struct hk_ctx {
   struct HostTexture { std::vector<uint32_t> texels; uint32_t w, h, flags; };
   std::vector<HostTexture> textures;
   bool have_meshes = false, have_materials = false, have_instances = false, have_noise = false;
-  bool scene_dirty = true;
+  // what finalize_scene has to redo: the mesh-level region, the instance-level region, the texel buffer
+  bool mesh_dirty = true, dynamic_dirty = true, textures_dirty = true;
+  std::vector<float> prev_models;          // PreviousMeshUniform::transform per instance (optional)
+  std::vector<int64_t> node_prim_offset;   // primitive offset each BLAS node's leaves index (from the last mesh-level build)
 
   // device scene
-  DevArray<uint8_t> scene_blob;  // every scene array in one allocation (so small scenes can be staged in LDS by one copy loop)
+  uint8_t* scene_mem = nullptr;  // every scene array in one allocation (so small scenes can be staged in LDS by one copy loop)
+  size_t dyn_capacity = 0, static_bytes = 0;
+  size_t st_nodes = 0, st_v0 = 0, st_v1 = 0, st_v2 = 0, st_vn = 0, st_vuv = 0;  // offsets inside the mesh-level region
+  uint64_t static_rebuilds = 0, dynamic_rebuilds = 0;
+  const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
   DevArray<uint32_t> d_noise;
   DevArray<uint32_t> d_tex_data;
   DScene scene{};
@@ -257,18 +264,25 @@ size_t fold_leaf_navigators(std::vector<float4>& lo, std::vector<float4>& hi, si
 }
 
 // Convert the reference-layout scene to the device layout (hk_device.hpp header comment).
-int finalize_scene(hk_ctx* c) {
-  if (!c->scene_dirty) return HK_OK;
-  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
+//
+// One device allocation, two regions:
+//   [ instance-level region, `dyn_capacity` bytes ][ mesh-level region, `static_bytes` bytes ]
+// The instance-level region (TLAS nodes first, instances, light BVH, emissives, alias tables,
+// materials, texture descriptors) is what prepare_instances / prepare_material_assets rewrite when
+// something moves (instance.rs:352-437); it is small (0.6 MB at 2 000 instances) and is the only part
+// rebuilt and re-sent for an instance-only change.  The mesh-level region (BLAS nodes with their leaf
+// boxes, triangle planes, vertex planes) changes only with the mesh assets (mesh.rs:106-166).
+// Node indices are in 32-B units from the start of the allocation: TLAS node i is node i, BLAS node k
+// of a mesh is node blas_base + node_offset + k with blas_base = dyn_capacity / 32.
+
+// mesh-level region; fills c->node_prim_offset.  Needs the instances' mesh records to know which
+// primitive range a BLAS leaf indexes (GpuMeshIndex travels with the instance, mod.rs:147-156).
+int build_static_region(hk_ctx* c, Blob& blob, size_t& off_nodes, size_t& off_v0, size_t& off_v1, size_t& off_v2, size_t& off_vn, size_t& off_vuv) {
   const size_t n_nodes = c->asset_nodes.size(), n_prims = c->primitives.size(), n_verts = c->vertices.size();
-  // which mesh (primitive offset) owns each BLAS node, from the instances' mesh records
-  std::vector<int64_t> node_prim_offset(n_nodes, -1);
-  for (const HkInstance& in : c->instances) {
-    HK_REQUIRE((size_t)in.mesh.node_offset + in.mesh.node_count <= n_nodes, HK_E_INVALID, "instance mesh node range out of bounds");
-    HK_REQUIRE(in.material < c->materials.size(), HK_E_INVALID, "instance material out of bounds");
+  std::vector<int64_t>& node_prim_offset = c->node_prim_offset;
+  node_prim_offset.assign(n_nodes, -1);
+  for (const HkInstance& in : c->instances)
     for (uint32_t k = 0; k < in.mesh.node_count; ++k) node_prim_offset[in.mesh.node_offset + k] = in.mesh.primitive;
-  }
-  Blob blob;
   std::vector<float4> lo(n_nodes), hi(n_nodes);
   for (size_t i = 0; i < n_nodes; ++i) {
     const HkNode& n = c->asset_nodes[i];
@@ -285,6 +299,18 @@ int finalize_scene(hk_ctx* c) {
     lo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
     hi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
+  {  // fold single-leaf navigators, once per distinct mesh range
+    std::vector<uint8_t> done(n_nodes + 1, 0);
+    for (const HkInstance& in : c->instances) {
+      if (in.mesh.node_count == 0 || done[in.mesh.node_offset]) continue;
+      done[in.mesh.node_offset] = 1;
+      fold_leaf_navigators(lo, hi, in.mesh.node_offset, in.mesh.node_count);
+    }
+  }
+  std::vector<float4> nodes;
+  nodes.reserve(2 * n_nodes);
+  for (size_t i = 0; i < n_nodes; ++i) { nodes.push_back(lo[i]); nodes.push_back(hi[i]); }
+  off_nodes = blob.add(nodes);  // offset 0: the region itself starts on a 32-B boundary
 
   std::vector<float4> v0(n_prims), v1(n_prims), v2(n_prims);
   for (size_t i = 0; i < n_prims; ++i) {
@@ -293,20 +319,49 @@ int finalize_scene(hk_ctx* c) {
     v1[i] = make_float4(v[1].position[0], v[1].position[1], v[1].position[2], as_f(v[1].index));
     v2[i] = make_float4(v[2].position[0], v[2].position[1], v[2].position[2], as_f(v[2].index));
   }
-  const size_t off_tri_v0 = blob.add(v0);
-  const size_t off_tri_v1 = blob.add(v1);
-  const size_t off_tri_v2 = blob.add(v2);
-
+  off_v0 = blob.add(v0);
+  off_v1 = blob.add(v1);
+  off_v2 = blob.add(v2);
   std::vector<float4> vn(n_verts);
   std::vector<float2> vuv(n_verts);
   for (size_t i = 0; i < n_verts; ++i) {
     vn[i] = make_float4(c->vertices[i].normal[0], c->vertices[i].normal[1], c->vertices[i].normal[2], 0.0f);
     vuv[i] = make_float2(c->vertices[i].u, c->vertices[i].v);
   }
-  const size_t off_vtx_normal = blob.add(vn);
-  const size_t off_vtx_uv = blob.add(vuv);
+  off_vn = blob.add(vn);
+  off_vuv = blob.add(vuv);
+  blob.bytes.resize((blob.bytes.size() + 15) & ~(size_t)15, 0);
+  return HK_OK;
+}
 
+struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emissives, alias, materials, tex_info, srgb_lut; };
+
+int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o) {
+  const size_t n_tlas = c->instance_nodes.size();
+  std::vector<float4> tlo(n_tlas), thi(n_tlas);
+  for (size_t i = 0; i < n_tlas; ++i) {
+    const HkNode& n = c->instance_nodes[i];
+    const float* mn = n.min;
+    const float* mx = n.max;
+    if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:454-457: the leaf box is the instance's world AABB
+      uint32_t inst = n.entry_index - HK_BVH_LEAF_FLAG;
+      HK_REQUIRE(inst < c->instances.size(), HK_E_INVALID, "TLAS leaf instance out of bounds");
+      mn = c->instances[inst].min;
+      mx = c->instances[inst].max;
+    }
+    tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
+    thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
+  }
+  fold_leaf_navigators(tlo, thi, 0, n_tlas);
+  std::vector<float4> tlas;
+  tlas.reserve(2 * n_tlas);
+  for (size_t i = 0; i < n_tlas; ++i) { tlas.push_back(tlo[i]); tlas.push_back(thi[i]); }
+  o.tlas = blob.add(tlas);  // offset 0
+
+  const bool have_prev = c->prev_models.size() == 16 * c->instances.size();
   std::vector<DInstance> di(c->instances.size());
+  std::vector<float4> pm;
+  bool any_moved = false;
   for (size_t i = 0; i < di.size(); ++i) {
     const HkInstance& in = c->instances[i];
     const float* t = in.inverse_transpose_model;
@@ -328,69 +383,20 @@ int finalize_scene(hk_ctx* c) {
     d.primitive = in.mesh.primitive;
     d.node_offset = in.mesh.node_offset;
     d.node_count = in.mesh.node_count;
-    d.pad0 = d.pad1 = d.pad2 = 0;
+    d.moved = (have_prev && memcmp(&c->prev_models[16 * i], m, 64) != 0) ? 1u : 0u;
+    any_moved = any_moved || d.moved;
+    d.pad1 = d.pad2 = 0;
   }
-  const size_t off_d_instances = blob.add(di);
-
-  const size_t n_tlas = c->instance_nodes.size();
-  std::vector<float4> tlo(n_tlas), thi(n_tlas);
-  for (size_t i = 0; i < n_tlas; ++i) {
-    const HkNode& n = c->instance_nodes[i];
-    const float* mn = n.min;
-    const float* mx = n.max;
-    if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:454-457: the leaf box is the instance's world AABB
-      uint32_t inst = n.entry_index - HK_BVH_LEAF_FLAG;
-      HK_REQUIRE(inst < c->instances.size(), HK_E_INVALID, "TLAS leaf instance out of bounds");
-      mn = c->instances[inst].min;
-      mx = c->instances[inst].max;
-    }
-    tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
-    thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
+  if (any_moved) {  // previous model matrices, 4 columns per instance (only when something moves)
+    pm.resize(4 * di.size());
+    for (size_t i = 0; i < di.size(); ++i)
+      for (int col = 0; col < 4; ++col) {
+        const float* q = &c->prev_models[16 * i + 4 * col];
+        pm[4 * i + col] = make_float4(q[0], q[1], q[2], q[3]);
+      }
   }
-  {  // fold single-leaf navigators: once per distinct mesh range, and for the TLAS
-    std::vector<uint8_t> done(n_nodes + 1, 0);
-    for (const HkInstance& in : c->instances) {
-      if (in.mesh.node_count == 0 || done[in.mesh.node_offset]) continue;
-      done[in.mesh.node_offset] = 1;
-      fold_leaf_navigators(lo, hi, in.mesh.node_offset, in.mesh.node_count);
-    }
-    fold_leaf_navigators(tlo, thi, 0, n_tlas);
-  }
-  // unified node array: TLAS first, then every BLAS; lo/hi interleaved (32 B per node)
-  std::vector<float4> nodes;
-  nodes.reserve(2 * (n_tlas + n_nodes));
-  for (size_t i = 0; i < n_tlas; ++i) { nodes.push_back(tlo[i]); nodes.push_back(thi[i]); }
-  for (size_t i = 0; i < n_nodes; ++i) { nodes.push_back(lo[i]); nodes.push_back(hi[i]); }
-  const size_t off_nodes = blob.add(nodes);
-
-  const uint32_t n_tex = (uint32_t)c->textures.size();
-  std::vector<float4> mats(4 * c->materials.size());
-  for (size_t i = 0; i < c->materials.size(); ++i) {
-    const HkMaterial& m = c->materials[i];
-    const uint32_t ids[4] = {m.base_color_texture, m.emissive_texture, m.metallic_roughness_texture, m.occlusion_texture};
-    for (uint32_t id : ids)  // MaterialTextures::id, material.rs:76-86: an index into the texture array or u32::MAX
-      HK_REQUIRE(id == HK_NO_TEXTURE || id < n_tex, HK_E_INVALID, "material %zu references texture %u but only %u textures are uploaded", i, id, n_tex);
-    mats[4 * i] = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
-    mats[4 * i + 1] = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
-    mats[4 * i + 2] = make_float4(m.perceptual_roughness, m.metallic, m.reflectance, 0.0f);
-    mats[4 * i + 3] = make_float4(as_f(ids[0]), as_f(ids[1]), as_f(ids[2]), as_f(ids[3]));
-  }
-  // material textures: one texel buffer + a 16-B descriptor per texture + the sRGB decode table
-  std::vector<uint4> tex_info(n_tex);
-  std::vector<uint32_t> tex_data;
-  for (uint32_t i = 0; i < n_tex; ++i) {
-    const hk_ctx::HostTexture& t = c->textures[i];
-    tex_info[i] = make_uint4((uint32_t)tex_data.size(), t.w, t.h, t.flags);
-    tex_data.insert(tex_data.end(), t.texels.begin(), t.texels.end());
-  }
-  std::vector<float> srgb_lut(256);
-  for (int i = 0; i < 256; ++i) {  // sRGB EOTF in double, rounded once
-    double v = i / 255.0;
-    srgb_lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
-  }
-  const size_t off_tex_info = blob.add(tex_info);
-  const size_t off_srgb_lut = blob.add(srgb_lut);
-  const size_t off_d_materials = blob.add(mats);
+  o.instances = blob.add(di);
+  o.prev_models = blob.add(pm);
 
   const size_t n_light = c->emissive_nodes.size();
   std::vector<float4> llo(n_light), lhi(n_light);
@@ -409,8 +415,8 @@ int finalize_scene(hk_ctx* c) {
     lhi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
   }
   fold_leaf_navigators(llo, lhi, 0, n_light);
-  const size_t off_light_lo = blob.add(llo);
-  const size_t off_light_hi = blob.add(lhi);
+  o.light_lo = blob.add(llo);
+  o.light_hi = blob.add(lhi);
 
   std::vector<DEmissive> de(c->emissives.size());
   for (size_t i = 0; i < de.size(); ++i) {
@@ -423,36 +429,112 @@ int finalize_scene(hk_ctx* c) {
     de[i].alias_count = e.alias_table[1];
     de[i].surface_area = e.surface_area;
   }
-  const size_t off_d_emissives = blob.add(de);
+  o.emissives = blob.add(de);
   std::vector<float2> al(c->alias_table.size());
   for (size_t i = 0; i < al.size(); ++i) al[i] = make_float2(c->alias_table[i].prob, as_f(c->alias_table[i].index));
-  const size_t off_d_alias = blob.add(al);
+  o.alias = blob.add(al);
 
-  // traversal-hot arrays were added first; pad to a whole float4 count
-  blob.bytes.resize((blob.bytes.size() + 15) & ~(size_t)15, 0);
+  const uint32_t n_tex = (uint32_t)c->textures.size();
+  std::vector<float4> mats(4 * c->materials.size());
+  for (size_t i = 0; i < c->materials.size(); ++i) {
+    const HkMaterial& m = c->materials[i];
+    const uint32_t ids[4] = {m.base_color_texture, m.emissive_texture, m.metallic_roughness_texture, m.occlusion_texture};
+    for (uint32_t id : ids)  // MaterialTextures::id, material.rs:76-86: an index into the texture array or u32::MAX
+      HK_REQUIRE(id == HK_NO_TEXTURE || id < n_tex, HK_E_INVALID, "material %zu references texture %u but only %u textures are uploaded", i, id, n_tex);
+    mats[4 * i] = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
+    mats[4 * i + 1] = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
+    mats[4 * i + 2] = make_float4(m.perceptual_roughness, m.metallic, m.reflectance, 0.0f);
+    mats[4 * i + 3] = make_float4(as_f(ids[0]), as_f(ids[1]), as_f(ids[2]), as_f(ids[3]));
+  }
+  o.materials = blob.add(mats);
+  // material textures: a 16-B descriptor per texture + the sRGB decode table (texels live in their own buffer)
+  std::vector<uint4> tex_info(n_tex);
+  size_t texel_offset = 0;
+  for (uint32_t i = 0; i < n_tex; ++i) {
+    const hk_ctx::HostTexture& t = c->textures[i];
+    tex_info[i] = make_uint4((uint32_t)texel_offset, t.w, t.h, t.flags);
+    texel_offset += t.texels.size();
+  }
+  std::vector<float> srgb_lut(256);
+  for (int i = 0; i < 256; ++i) {  // sRGB EOTF in double, rounded once
+    double v = i / 255.0;
+    srgb_lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
+  }
+  o.tex_info = blob.add(tex_info);
+  o.srgb_lut = blob.add(srgb_lut);
+  blob.bytes.resize((blob.bytes.size() + 31) & ~(size_t)31, 0);
+  return HK_OK;
+}
+
+int finalize_scene(hk_ctx* c) {
+  if (!c->mesh_dirty && !c->dynamic_dirty && !c->textures_dirty) return HK_OK;
+  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
+  const size_t n_nodes = c->asset_nodes.size();
+  bool need_static = c->mesh_dirty || !c->scene_mem || c->node_prim_offset.size() != n_nodes;
+  for (const HkInstance& in : c->instances) {
+    HK_REQUIRE((size_t)in.mesh.node_offset + in.mesh.node_count <= n_nodes, HK_E_INVALID, "instance mesh node range out of bounds");
+    HK_REQUIRE(in.material < c->materials.size(), HK_E_INVALID, "instance material out of bounds");
+    // a mesh range no earlier instance used: its leaf boxes have not been derived yet
+    if (!need_static && in.mesh.node_count && (c->node_prim_offset[in.mesh.node_offset] != (int64_t)in.mesh.primitive ||
+                                                c->node_prim_offset[in.mesh.node_offset + in.mesh.node_count - 1] != (int64_t)in.mesh.primitive))
+      need_static = true;
+  }
   int rc;
-  if ((rc = c->d_tex_data.upload(tex_data))) return rc;
-  if ((rc = c->scene_blob.upload(blob.bytes))) return rc;
-  const uint8_t* base = c->scene_blob.p;
+  if (c->textures_dirty) {
+    std::vector<uint32_t> tex_data;
+    for (const hk_ctx::HostTexture& t : c->textures) tex_data.insert(tex_data.end(), t.texels.begin(), t.texels.end());
+    HK_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = c->d_tex_data.upload(tex_data))) return rc;
+    c->textures_dirty = false;
+  }
+  Blob dyn;
+  DynOffsets o{};
+  if ((rc = build_dynamic_region(c, dyn, o))) return rc;
+  HK_HIP(hipStreamSynchronize(c->stream));  // frames in flight still read the old arrays
+  if (need_static) {
+    Blob st;
+    if ((rc = build_static_region(c, st, c->st_nodes, c->st_v0, c->st_v1, c->st_v2, c->st_vn, c->st_vuv))) return rc;
+    if (c->scene_mem) { (void)hipFree(c->scene_mem); c->scene_mem = nullptr; }
+    c->dyn_capacity = dyn.bytes.size();  // exact: a small scene stays small enough for the LDS copy
+    c->static_bytes = st.bytes.size();
+    HK_HIP(hipMalloc((void**)&c->scene_mem, c->dyn_capacity + c->static_bytes));
+    HK_HIP(hipMemcpy(c->scene_mem + c->dyn_capacity, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
+  } else if (dyn.bytes.size() > c->dyn_capacity) {  // instance count grew: move the mesh region behind a larger slot, device to device
+    const size_t cap = ((dyn.bytes.size() + dyn.bytes.size() / 2) + 31) & ~(size_t)31;
+    uint8_t* mem = nullptr;
+    HK_HIP(hipMalloc((void**)&mem, cap + c->static_bytes));
+    HK_HIP(hipMemcpy(mem + cap, c->scene_mem + c->dyn_capacity, c->static_bytes, hipMemcpyDeviceToDevice));
+    (void)hipFree(c->scene_mem);
+    c->scene_mem = mem;
+    c->dyn_capacity = cap;
+  }
+  HK_HIP(hipMemcpy(c->scene_mem, dyn.bytes.data(), dyn.bytes.size(), hipMemcpyHostToDevice));
+  if (dyn.bytes.size() < c->dyn_capacity) HK_HIP(hipMemset(c->scene_mem + dyn.bytes.size(), 0, c->dyn_capacity - dyn.bytes.size()));
+
+  const uint8_t* base = c->scene_mem;
+  const uint8_t* sbase = base + c->dyn_capacity;
   DScene& s = c->scene;
   s.blob = (const float4*)base;
-  s.blob_f4 = (uint32_t)(blob.bytes.size() / 16);
-  s.nodes = (const float4*)(base + off_nodes);
-  s.blas_base = (uint32_t)n_tlas;
-  s.instances = (const DInstance*)(base + off_d_instances);
-  s.tri_v0 = (const float4*)(base + off_tri_v0); s.tri_v1 = (const float4*)(base + off_tri_v1); s.tri_v2 = (const float4*)(base + off_tri_v2);
-  s.vtx_normal = (const float4*)(base + off_vtx_normal); s.vtx_uv = (const float2*)(base + off_vtx_uv);
-  s.materials = (const float4*)(base + off_d_materials);
-  s.tex_info = (const uint4*)(base + off_tex_info);
-  s.srgb_lut = (const float*)(base + off_srgb_lut);
+  s.blob_f4 = (uint32_t)((c->dyn_capacity + c->static_bytes) / 16);
+  s.nodes = (const float4*)base;
+  s.blas_base = (uint32_t)((c->dyn_capacity + c->st_nodes) / 32);
+  s.instances = (const DInstance*)(base + o.instances);
+  c->d_prev_models = (const float4*)(base + o.prev_models);
+  s.tri_v0 = (const float4*)(sbase + c->st_v0); s.tri_v1 = (const float4*)(sbase + c->st_v1); s.tri_v2 = (const float4*)(sbase + c->st_v2);
+  s.vtx_normal = (const float4*)(sbase + c->st_vn); s.vtx_uv = (const float2*)(sbase + c->st_vuv);
+  s.materials = (const float4*)(base + o.materials);
+  s.tex_info = (const uint4*)(base + o.tex_info);
+  s.srgb_lut = (const float*)(base + o.srgb_lut);
   s.tex_data = c->d_tex_data.p;
-  s.n_textures = n_tex;
-  s.light_lo = (const float4*)(base + off_light_lo); s.light_hi = (const float4*)(base + off_light_hi);
-  s.emissives = (const DEmissive*)(base + off_d_emissives); s.alias = (const float2*)(base + off_d_alias);
+  s.n_textures = (uint32_t)c->textures.size();
+  s.light_lo = (const float4*)(base + o.light_lo); s.light_hi = (const float4*)(base + o.light_hi);
+  s.emissives = (const DEmissive*)(base + o.emissives); s.alias = (const float2*)(base + o.alias);
   s.noise = c->d_noise.p;
-  s.tlas_count = (uint32_t)n_tlas;
-  s.light_count = (uint32_t)n_light;
-  c->scene_dirty = false;
+  s.tlas_count = (uint32_t)c->instance_nodes.size();
+  s.light_count = (uint32_t)c->emissive_nodes.size();
+  c->mesh_dirty = c->dynamic_dirty = false;
+  c->static_rebuilds += need_static ? 1 : 0;
+  c->dynamic_rebuilds += 1;
   return HK_OK;
 }
 
@@ -596,7 +678,7 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
   switch (pass) {
     case HK_PASS_PREPASS: {
       Jitter j = prepass_jitter(c);
-      launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, j.x, j.y, g, y0, y1, counters);
+      launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, y0, y1, counters);
       break;
     }
     case HK_PASS_FULL_SCREEN_ALBEDO: launch_albedo(c->stream, c->scene, fr, g, c->buf[HK_BUF_ALBEDO], y0, y1); break;
@@ -695,7 +777,7 @@ void hk_destroy(hk_ctx* c) {
   if (c->frame_start) (void)hipEventDestroy(c->frame_start);
   if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
   free_screen(c);
-  c->scene_blob.release();
+  if (c->scene_mem) (void)hipFree(c->scene_mem);
   c->d_tex_data.release();
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -709,14 +791,14 @@ int hk_upload_meshes(hk_ctx* c, const HkVertex* v, uint32_t nv, const HkPrimitiv
   c->primitives.assign(p, p + np);
   c->asset_nodes.assign(n, n + nn);
   c->have_meshes = true;
-  c->scene_dirty = true;
+  c->mesh_dirty = true;
   return HK_OK;
 }
 int hk_upload_materials(hk_ctx* c, const HkMaterial* m, uint32_t n) {
   HK_REQUIRE(c && m && n, HK_E_INVALID, "NULL or empty material buffer");
   c->materials.assign(m, m + n);
   c->have_materials = true;
-  c->scene_dirty = true;
+  c->dynamic_dirty = true;
   return HK_OK;
 }
 int hk_upload_instances(hk_ctx* c, const HkInstance* inst, uint32_t ni, const HkNode* inodes, uint32_t nin, const HkEmissive* em, uint32_t ne,
@@ -728,8 +810,16 @@ int hk_upload_instances(hk_ctx* c, const HkInstance* inst, uint32_t ni, const Hk
   c->emissives.assign(em, em + ne);
   c->emissive_nodes.assign(enodes, enodes + nen);
   c->alias_table.assign(alias, alias + na);
+  c->prev_models.clear();
   c->have_instances = true;
-  c->scene_dirty = true;
+  c->dynamic_dirty = true;
+  return HK_OK;
+}
+int hk_upload_previous_transforms(hk_ctx* c, const float* models, uint32_t n) {
+  HK_REQUIRE(c && (models || !n), HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(c->have_instances && n == c->instances.size(), HK_E_INVALID, "previous transforms must match the %zu uploaded instances", c->instances.size());
+  c->prev_models.assign(models, models + 16 * (size_t)n);
+  c->dynamic_dirty = true;
   return HK_OK;
 }
 int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
@@ -748,7 +838,25 @@ int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
   if ((rc = hk_scene_builder_alias_table(b, &al, &nal))) return rc;
   if ((rc = hk_upload_meshes(c, v, nv, p, np, an, nan_))) return rc;
   if ((rc = hk_upload_materials(c, m, nm))) return rc;
-  return hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal);
+  if ((rc = hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal))) return rc;
+  const float* pm; uint32_t npm;
+  if ((rc = hk_scene_builder_previous_transforms(b, &pm, &npm))) return rc;
+  return hk_upload_previous_transforms(c, pm, npm);
+}
+int hk_upload_scene_instances(hk_ctx* c, const hk_scene_builder* b) {
+  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(c->have_meshes && c->have_materials, HK_E_NOT_READY, "hk_upload_scene must come first");
+  const HkNode *in_, *en; const HkInstance* inst; const HkEmissive* em; const HkAliasEntry* al; const float* pm;
+  uint32_t ni, nin, ne, nen, nal, npm;
+  int rc;
+  if ((rc = hk_scene_builder_instances(b, &inst, &ni))) return rc;
+  if ((rc = hk_scene_builder_instance_nodes(b, &in_, &nin))) return rc;
+  if ((rc = hk_scene_builder_emissives(b, &em, &ne))) return rc;
+  if ((rc = hk_scene_builder_emissive_nodes(b, &en, &nen))) return rc;
+  if ((rc = hk_scene_builder_alias_table(b, &al, &nal))) return rc;
+  if ((rc = hk_scene_builder_previous_transforms(b, &pm, &npm))) return rc;
+  if ((rc = hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal))) return rc;
+  return hk_upload_previous_transforms(c, pm, npm);
 }
 int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
   HK_REQUIRE(c && (images || !n), HK_E_INVALID, "NULL argument");
@@ -764,7 +872,8 @@ int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
     memcpy(tex[i].texels.data(), d.rgba8, tex[i].texels.size() * 4);
   }
   c->textures.swap(tex);
-  c->scene_dirty = true;
+  c->textures_dirty = true;
+  c->dynamic_dirty = true;
   return HK_OK;
 }
 int hk_upload_noise(hk_ctx* c, const uint8_t* rgba, size_t bytes) {
@@ -999,6 +1108,8 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   out->rays_blas = h[2];
   out->frames = c->frames;
   out->last_frame_ms = c->last_frame_ms;
+  out->scene_mesh_builds = c->static_rebuilds;
+  out->scene_instance_builds = c->dynamic_rebuilds;
   for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
     out->pass_ms_total[i] = c->slot_ms[i];
     out->pass_launches[i] = c->slot_launches[i];

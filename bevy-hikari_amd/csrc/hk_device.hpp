@@ -45,7 +45,7 @@ struct DInstance {
   float4 m0, m1, m2, m3;      // model, columns
   float4 n0, n1, n2;          // inverse_transpose_model columns (xyz) = normal matrix
   uint32_t material, vertex, primitive, node_offset;
-  uint32_t node_count, pad0, pad1, pad2;
+  uint32_t node_count, moved /* previous model differs: see PrepassParams::prev_models */, pad1, pad2;
 };
 struct DEmissive {
   float4 position_radius;

@@ -71,6 +71,7 @@ struct PrepassParams {
   float4 vp0, vp1, vp2, vp3;      // view_proj columns
   float4 pvp0, pvp1, pvp2, pvp3;  // previous view_proj columns
   float jitter_x, jitter_y;       // NDC shift of the geometry (prepass.wgsl:52-54,71)
+  const float4* prev_models;      // previous model matrix (4 columns) per instance, read where DInstance::moved
 };
 __device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams& pp, float px, float py) {
   float ndc_x = (px + 0.5f) / (float)fr.dw * 2.0f - 1.0f - pp.jitter_x;
@@ -137,7 +138,14 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
         f4 cn = mul(pp.vp0, pp.vp1, pp.vp2, pp.vp3, F4(wp, 1.0f));
         grad[k] = cn.z / cn.w - depth;
       }
-      const f2 velocity = clip_to_uv(clip) - clip_to_uv(mul(pp.pvp0, pp.pvp1, pp.pvp2, pp.pvp3, F4(world_position, 1.0f)));
+      // prepass.wgsl:50,96: previous_world_position = previous_mesh.model * vertex, interpolated over the triangle
+      f4 previous_world = F4(world_position, 1.0f);
+      if (in.moved) {
+        const float4* pm = pp.prev_models + 4u * hit.instance_index;
+        const f3 local = xyz(q0) + b.x * (xyz(q1) - xyz(q0)) + b.y * (xyz(q2) - xyz(q0));
+        previous_world = mul(pm[0], pm[1], pm[2], pm[3], F4(local, 1.0f));
+      }
+      const f2 velocity = clip_to_uv(clip) - clip_to_uv(mul(pp.pvp0, pp.pvp1, pp.pvp2, pp.pvp3, previous_world));
       g.position[idx] = make_float4(world_position.x, world_position.y, world_position.z, depth);
       const uint32_t packed_normal = pack4x8snorm(F4(wn, 1.0f));
       g.normal[idx] = packed_normal;
@@ -670,9 +678,11 @@ using namespace hkd;
 static inline size_t lds_bytes_for(const DScene& sc) { return (size_t)sc.blob_f4 * 16 <= 32768 ? (size_t)sc.blob_f4 * 16 : 0; }
 
 void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj,
-                    const float* prev_view_proj, float jitter_x, float jitter_y, const GBuffer& g, int y0, int y1, unsigned long long* counters) {
+                    const float* prev_view_proj, const float4* prev_models, float jitter_x, float jitter_y, const GBuffer& g, int y0, int y1,
+                    unsigned long long* counters) {
   if (y1 <= y0) return;
   PrepassParams pp;
+  pp.prev_models = prev_models;
   auto col = [](const float* m, int c) { return make_float4(m[4 * c], m[4 * c + 1], m[4 * c + 2], m[4 * c + 3]); };
   pp.ivp0 = col(inverse_view_proj, 0); pp.ivp1 = col(inverse_view_proj, 1); pp.ivp2 = col(inverse_view_proj, 2); pp.ivp3 = col(inverse_view_proj, 3);
   pp.vp0 = col(view_proj, 0); pp.vp1 = col(view_proj, 1); pp.vp2 = col(view_proj, 2); pp.vp3 = col(view_proj, 3);

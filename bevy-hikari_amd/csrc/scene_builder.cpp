@@ -219,6 +219,9 @@ struct hk_scene_builder {
   std::vector<HkMaterial> materials;
   std::vector<hk::BuilderInstance> instance_decl;
   bool finished = false;
+  bool meshes_dirty = true;               // the concatenated mesh buffers must be rebuilt
+  std::vector<float> finished_transforms;  // transforms at the last finish ...
+  std::vector<float> previous_transforms;  // ... and at the one before (PreviousMeshUniform)
   // outputs
   std::vector<HkVertex> vertices;
   std::vector<HkPrimitive> primitives;
@@ -337,7 +340,7 @@ void hk_scene_builder_destroy(hk_scene_builder* b) { delete b; }
 
 int hk_scene_builder_add_mesh(hk_scene_builder* b, const float* positions, const float* normals, const float* uvs, uint32_t n_vertices,
                               const uint32_t* indices, uint32_t n_indices, uint32_t topology, uint32_t* mesh_id) {
-  HK_REQUIRE(b && !b->finished, HK_E_INVALID, "builder is NULL or already finished");
+  HK_REQUIRE(b, HK_E_INVALID, "builder is NULL");
   // mod.rs:383-397: position, normal and uv0 are all required
   HK_REQUIRE(positions && normals && uvs && n_vertices > 0, HK_E_INVALID, "mesh needs position, normal and uv attributes");
   HK_REQUIRE(topology == HK_TOPOLOGY_TRIANGLE_LIST || topology == HK_TOPOLOGY_TRIANGLE_STRIP, HK_E_UNSUPPORTED, "incompatible primitive topology");
@@ -398,44 +401,66 @@ int hk_scene_builder_add_mesh(hk_scene_builder* b, const float* positions, const
   }
   mesh.nodes = build_flat_bvh(boxes);  // mod.rs:458-459
   b->meshes.push_back(std::move(mesh));
+  b->meshes_dirty = true;
+  b->finished = false;
   if (mesh_id) *mesh_id = (uint32_t)b->meshes.size() - 1;
   return HK_OK;
 }
 
 int hk_scene_builder_add_material(hk_scene_builder* b, const HkMaterial* material, uint32_t* material_id) {
-  HK_REQUIRE(b && material && !b->finished, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(b && material, HK_E_INVALID, "bad argument");
   b->materials.push_back(*material);
+  b->finished = false;
   if (material_id) *material_id = (uint32_t)b->materials.size() - 1;
   return HK_OK;
 }
 
 int hk_scene_builder_add_instance(hk_scene_builder* b, uint32_t mesh_id, uint32_t material_id, const float transform[16], uint32_t* instance_id) {
-  HK_REQUIRE(b && transform && !b->finished, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(b && transform, HK_E_INVALID, "bad argument");
   HK_REQUIRE(mesh_id < b->meshes.size() && material_id < b->materials.size(), HK_E_INVALID, "unknown mesh or material id");
   BuilderInstance inst;
   inst.mesh = mesh_id;
   inst.material = material_id;
   memcpy(inst.transform, transform, 64);
   b->instance_decl.push_back(inst);
+  b->finished = false;
   if (instance_id) *instance_id = (uint32_t)b->instance_decl.size() - 1;
+  return HK_OK;
+}
+
+int hk_scene_builder_set_instance_transform(hk_scene_builder* b, uint32_t instance_id, const float transform[16]) {
+  HK_REQUIRE(b && transform, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(instance_id < b->instance_decl.size(), HK_E_INVALID, "unknown instance id");
+  memcpy(b->instance_decl[instance_id].transform, transform, 64);
+  b->finished = false;
   return HK_OK;
 }
 
 int hk_scene_builder_finish(hk_scene_builder* b) {
   HK_REQUIRE(b, HK_E_INVALID, "builder is NULL");
-  b->vertices.clear(); b->primitives.clear(); b->asset_nodes.clear(); b->mesh_index.clear();
+  if (b->meshes_dirty) {  // mesh.rs:141-163: concatenate, remember offsets (only when a mesh was added)
+    b->vertices.clear(); b->primitives.clear(); b->asset_nodes.clear(); b->mesh_index.clear();
+    for (const BuilderMesh& m : b->meshes) {
+      HkMeshIndex mi;
+      mi.vertex = (uint32_t)b->vertices.size();
+      mi.primitive = (uint32_t)b->primitives.size();
+      mi.node_offset = (uint32_t)b->asset_nodes.size();
+      mi.node_count = (uint32_t)m.nodes.size();
+      b->vertices.insert(b->vertices.end(), m.vertices.begin(), m.vertices.end());
+      b->primitives.insert(b->primitives.end(), m.primitives.begin(), m.primitives.end());
+      b->asset_nodes.insert(b->asset_nodes.end(), m.nodes.begin(), m.nodes.end());
+      b->mesh_index.push_back(mi);
+    }
+    b->meshes_dirty = false;
+  }
   b->instances.clear(); b->instance_nodes.clear(); b->emissives.clear(); b->emissive_nodes.clear(); b->alias_table.clear();
-  // mesh.rs:141-163: concatenate, remember offsets
-  for (const BuilderMesh& m : b->meshes) {
-    HkMeshIndex mi;
-    mi.vertex = (uint32_t)b->vertices.size();
-    mi.primitive = (uint32_t)b->primitives.size();
-    mi.node_offset = (uint32_t)b->asset_nodes.size();
-    mi.node_count = (uint32_t)m.nodes.size();
-    b->vertices.insert(b->vertices.end(), m.vertices.begin(), m.vertices.end());
-    b->primitives.insert(b->primitives.end(), m.primitives.begin(), m.primitives.end());
-    b->asset_nodes.insert(b->asset_nodes.end(), m.nodes.begin(), m.nodes.end());
-    b->mesh_index.push_back(mi);
+  {  // PreviousMeshUniform: what the transforms were at the last finish (new instances: their own)
+    std::vector<float> now(b->instance_decl.size() * 16);
+    for (size_t i = 0; i < b->instance_decl.size(); ++i) memcpy(&now[16 * i], b->instance_decl[i].transform, 64);
+    b->previous_transforms = now;
+    const size_t common = std::min(now.size(), b->finished_transforms.size());
+    if (common) memcpy(b->previous_transforms.data(), b->finished_transforms.data(), common * sizeof(float));
+    b->finished_transforms.swap(now);
   }
   // instance.rs:286-325
   std::vector<float> boxes;
@@ -529,5 +554,13 @@ HK_BUILDER_GETTER(instance_nodes, instance_nodes, HkNode)
 HK_BUILDER_GETTER(emissives, emissives, HkEmissive)
 HK_BUILDER_GETTER(emissive_nodes, emissive_nodes, HkNode)
 HK_BUILDER_GETTER(alias_table, alias_table, HkAliasEntry)
+
+int hk_scene_builder_previous_transforms(const hk_scene_builder* b, const float** p, uint32_t* n) {
+  HK_REQUIRE(b && p && n, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(b->finished, HK_E_NOT_READY, "call hk_scene_builder_finish first");
+  *p = b->previous_transforms.data();
+  *n = (uint32_t)(b->previous_transforms.size() / 16);
+  return HK_OK;
+}
 
 }  // extern "C"

@@ -260,16 +260,27 @@ class SceneData:
     FIELDS = ("vertices", "primitives", "asset_nodes", "materials", "instances", "instance_nodes", "emissives", "emissive_nodes",
               "alias_table")
 
-    def __init__(self, **arrays):
+    def __init__(self, previous_transforms=None, **arrays):
         for k in self.FIELDS:
             setattr(self, k, arrays[k])
+        #: float32[n_instances][16] or None: PreviousMeshUniform::transform per instance (instance.rs:111-128)
+        self.previous_transforms = previous_transforms
 
     def upload(self, api, ctx):
         n = lambda a: len(a)
         api.call("upload_meshes", ctx, self.vertices, n(self.vertices), self.primitives, n(self.primitives), self.asset_nodes, n(self.asset_nodes))
         api.call("upload_materials", ctx, self.materials, n(self.materials))
+        self.upload_instances(api, ctx)
+
+    def upload_instances(self, api, ctx):
+        """The instance-level buffers only (what prepare_instances rewrites when something moves)."""
+        n = lambda a: len(a)
         api.call("upload_instances", ctx, self.instances, n(self.instances), self.instance_nodes, n(self.instance_nodes), self.emissives,
                  n(self.emissives), self.emissive_nodes, n(self.emissive_nodes), self.alias_table, n(self.alias_table))
+        if self.previous_transforms is not None:
+            pt = np.ascontiguousarray(self.previous_transforms, dtype=np.float32).reshape(-1, 16)
+            assert len(pt) == n(self.instances)
+            api.call("upload_previous_transforms", ctx, pt.ctypes.data_as(C.POINTER(F.f32)), len(pt))
 
 
 class SceneBuilder:
@@ -310,6 +321,11 @@ class SceneBuilder:
         self.api.call("scene_builder_add_instance", self.h, mesh_id, material_id, t.ctypes.data_as(C.POINTER(F.f32)), C.byref(out))
         return out.value
 
+    def set_instance_transform(self, instance_id, transform):
+        """Move an instance; the next finish() redoes the instance-level work only."""
+        t = np.ascontiguousarray(transform, dtype=np.float32).reshape(-1)
+        self.api.call("scene_builder_set_instance_transform", self.h, instance_id, t.ctypes.data_as(C.POINTER(F.f32)))
+
     def finish(self):
         self.api.call("scene_builder_finish", self.h)
         arrays = {}
@@ -322,7 +338,10 @@ class SceneBuilder:
             if n.value:
                 C.memmove(arr, p, n.value * C.sizeof(typ))
             arrays[name] = arr
-        return SceneData(**arrays)
+        p, n = C.POINTER(F.f32)(), F.u32()
+        self.api.call("scene_builder_previous_transforms", self.h, C.byref(p), C.byref(n))
+        prev = np.ctypeslib.as_array(p, shape=(n.value, 16)).copy() if n.value else np.zeros((0, 16), np.float32)
+        return SceneData(previous_transforms=prev, **arrays)
 
 
 def load_cornell(nonlinear_colors=False):
@@ -383,6 +402,10 @@ class Engine:
     def upload_scene(self, scene: SceneData):
         self.upload_textures(getattr(scene, "textures", []))
         scene.upload(self.api, self.ctx)
+
+    def upload_instances(self, scene: SceneData):
+        """Instance-level update of a scene whose meshes and materials are already uploaded."""
+        scene.upload_instances(self.api, self.ctx)
 
     def upload_textures(self, images):
         """images: list of dict(rgba=uint8[h][w][4], srgb=bool, address_u/address_v=F.ADDRESS_*, linear=bool) -
@@ -557,6 +580,10 @@ class HikariPlugin:
 
     def set_scene(self, scene: SceneData):
         self.engine.upload_scene(scene)
+
+    def update_instances(self, scene: SceneData):
+        """Instances moved (prepare_instances, instance.rs:352-437): rewrite the instance-level buffers only."""
+        self.engine.upload_instances(scene)
 
     def render(self, camera: Camera, settings: HikariSettings, lights=None, frame_number=None, by_nodes=False):
         """One frame of the camera's render graph.  Returns the frame number used."""

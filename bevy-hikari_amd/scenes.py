@@ -135,7 +135,33 @@ def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, exte
     sun = dict(color=(1.0, 0.96, 0.9), illuminance=20000.0, direction_to_light=(0.35, 0.8, 0.45))
     scene = b.finish()
     scene.textures = textures
+    scene.builder = b  # kept for dynamic-scene use: builder.set_instance_transform(i, ..) + builder.finish()
     return scene, sun
+
+
+def animate(scene, frame, movers=(3, 9, 26, 31)):
+    """Move a few instances of a synthetic_scene (two boxes, a sphere, an emitter) to their pose at
+    `frame` and re-finish the builder.  Returns the new SceneData (meshes and materials unchanged;
+    previous_transforms = the poses of the previous call).  Frame 0 is the rest pose."""
+    b = scene.builder
+    if not hasattr(scene, "rest_pose"):
+        scene.rest_pose = np.array([np.ctypeslib.as_array(inst.model).copy() for inst in scene.instances], dtype=np.float32)
+    for k, i in enumerate(movers):
+        if i >= len(scene.rest_pose):
+            continue
+        m = scene.rest_pose[i].reshape(4, 4).T.astype(np.float64)  # column-major -> math layout
+        ang = 0.05 * frame * (1 + k)
+        c, s_ = math.cos(ang), math.sin(ang)
+        rot = np.array([[c, 0, s_, 0], [0, 1, 0, 0], [-s_, 0, c, 0], [0, 0, 0, 1]], dtype=np.float64)
+        shift = np.eye(4)
+        shift[0, 3] = 0.04 * frame * (1 if k % 2 == 0 else -1)
+        shift[1, 3] = 0.02 * frame * (k % 3 == 0)
+        t = shift @ m @ rot  # spin about the local Y axis, drift in world space
+        b.set_instance_transform(i, t.T.astype(np.float32).reshape(-1))
+    new = b.finish()
+    new.textures = getattr(scene, "textures", [])
+    new.builder, new.rest_pose = b, scene.rest_pose
+    return new
 
 
 def synthetic_camera(width, height, extent=4.0):
@@ -187,4 +213,6 @@ def synthetic_large(seed=0x5EED0003, n_meshes=40, rings=40, segs=80, n_instances
         t = (rng.uniform(-extent, extent) * 0.8, rng.uniform(3.5, 5.0), rng.uniform(-extent, extent) * 0.8)
         b.add_instance(quad, emat[i], _trs(t, (math.pi + rng.uniform(-0.3, 0.3), rng.uniform(-1, 1), 0.0), (rng.uniform(0.8, 2.0), 1.0, rng.uniform(0.8, 2.0))))
     sun = dict(color=(1.0, 0.96, 0.9), illuminance=100000.0, direction_to_light=(0.35, 0.8, 0.45))
-    return b.finish(), sun
+    scene = b.finish()
+    scene.builder = b
+    return scene, sun

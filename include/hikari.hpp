@@ -250,6 +250,11 @@ class SceneBuilder {  // the Prepare-stage host work: mesh -> BLAS, TLAS, emissi
     check(hk_scene_builder_add_instance(h_, mesh, material, transform, &id), "hk_scene_builder_add_instance");
     return id;
   }
+  // move an instance (GlobalTransform change -> InstanceEvent::Modified, instance.rs:137-176); the next
+  // finish() redoes the instance-level work only and records the old transform as the previous one
+  void set_instance_transform(uint32_t instance, const float transform[16]) {
+    check(hk_scene_builder_set_instance_transform(h_, instance, transform), "hk_scene_builder_set_instance_transform");
+  }
   void finish() { check(hk_scene_builder_finish(h_), "hk_scene_builder_finish"); }
   const hk_scene_builder* handle() const { return h_; }
 
@@ -322,6 +327,8 @@ class HikariPlugin {
   }
   Context& context() { return ctx_; }
   void set_scene(const SceneBuilder& b) { check(hk_upload_scene(ctx_.get(), b.handle()), "hk_upload_scene"); }
+  // after SceneBuilder::set_instance_transform + finish: rewrite the instance-level device arrays only
+  void update_instances(const SceneBuilder& b) { check(hk_upload_scene_instances(ctx_.get(), b.handle()), "hk_upload_scene_instances"); }
 
   // one frame of the camera's render graph; by_nodes = dispatch by dispatch through the three nodes,
   // otherwise one hk_frame_render call.  Returns the frame number used.

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 1
+#define HK_ABI_VERSION 2
 
 /* ------------------------------------------------------------------ error codes */
 #define HK_OK 0
@@ -285,6 +285,11 @@ typedef struct HkStats {
   uint64_t pass_launches[HK_TIMING_SLOTS];
   float last_frame_ms;        /* first dispatch of TEMPORAL .. last dispatch of POST_PROCESS */
   uint32_t _pad;
+  /* how often the device scene was (re)built since hk_create: the mesh-level arrays (BLAS nodes,
+   * triangles, vertices) and the instance-level arrays (TLAS, instances, lights, materials).  An
+   * instance-only update must leave scene_mesh_builds unchanged. */
+  uint64_t scene_mesh_builds;
+  uint64_t scene_instance_builds;
 } HkStats;
 
 typedef struct hk_ctx hk_ctx;
@@ -327,6 +332,14 @@ int hk_scene_builder_add_material(hk_scene_builder* b, const HkMaterial* materia
 int hk_scene_builder_add_instance(hk_scene_builder* b, uint32_t mesh_id, uint32_t material_id,
                                   const float transform[16], uint32_t* instance_id);
 int hk_scene_builder_finish(hk_scene_builder* b);
+/* Dynamic scenes (instance.rs:352-437 re-runs whenever an instance changes): replace an instance's
+ * transform after a finish; the next finish redoes only the instance-level work (world AABBs, TLAS,
+ * emissive list, alias tables, light BVH) - meshes and their BLAS are kept.  The transform the
+ * instance had at the previous finish becomes its "previous transform" (PreviousMeshUniform,
+ * instance.rs:111-128), which the G-buffer's velocity output needs. */
+int hk_scene_builder_set_instance_transform(hk_scene_builder* b, uint32_t instance_id, const float transform[16]);
+/* n instances x 16 floats (column-major): each instance's transform at the finish before the last one */
+int hk_scene_builder_previous_transforms(const hk_scene_builder* b, const float** p, uint32_t* n);
 int hk_scene_builder_vertices(const hk_scene_builder* b, const HkVertex** p, uint32_t* n);
 int hk_scene_builder_primitives(const hk_scene_builder* b, const HkPrimitive** p, uint32_t* n);
 int hk_scene_builder_asset_nodes(const hk_scene_builder* b, const HkNode** p, uint32_t* n);
@@ -362,8 +375,17 @@ int hk_upload_instances(hk_ctx* ctx, const HkInstance* instances, uint32_t n_ins
                         uint32_t n_instance_nodes, const HkEmissive* emissives, uint32_t n_emissives,
                         const HkNode* emissive_nodes, uint32_t n_emissive_nodes, const HkAliasEntry* alias_table,
                         uint32_t n_alias);
+/* PreviousMeshUniform::transform per instance (instance.rs:111-128; prepass.wgsl:50,96):
+ * n_instances x 16 floats, column-major, the model matrices of the PREVIOUS frame.  Optional: without
+ * it every instance is static (previous = current).  Applies to the instances of the last
+ * hk_upload_instances call and is dropped by the next one, so a host with moving objects uploads both
+ * every frame, as the reference extracts both every frame. */
+int hk_upload_previous_transforms(hk_ctx* ctx, const float* models, uint32_t n_instances);
 /* convenience: the three uploads above from a finished builder */
 int hk_upload_scene(hk_ctx* ctx, const hk_scene_builder* b);
+/* convenience: hk_upload_instances + hk_upload_previous_transforms from a re-finished builder whose
+ * meshes and materials are unchanged.  Only the instance-level device arrays are rewritten. */
+int hk_upload_scene_instances(hk_ctx* ctx, const hk_scene_builder* b);
 /* NoiseTextures, lib.rs:189-219,515-598: 16 tiles of 64x64 RGBA8, tile-major */
 int hk_upload_noise(hk_ctx* ctx, const uint8_t* rgba, size_t bytes);
 /* prepare_light_textures / prepare_prepass_textures / post-process textures: (re)allocate all

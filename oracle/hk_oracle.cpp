@@ -83,6 +83,7 @@ struct Ctx {
   std::vector<HkEmissive> emissives;
   std::vector<HkNode> emissive_nodes;
   std::vector<HkAliasEntry> alias_table;
+  std::vector<float> prev_models;  // PreviousMeshUniform::transform per instance (optional)
   std::vector<uint8_t> noise;  // [16][64][64][4]
   struct Texture { std::vector<uint8_t> rgba; uint32_t w, h, is_srgb, au, av, linear; };
   std::vector<Texture> textures;
@@ -962,7 +963,7 @@ static void apply_scatter(std::vector<std::vector<ScatterStore>>& rows, PackedRe
 // per-vertex world normal (normalised per vertex as bevy_pbr::mesh_functions does, not
 // re-normalised after interpolation) stored as rgba8snorm, depth = clip z/w, analytic per-pixel
 // depth gradient on the hit triangle's plane, ids + 0.5, velocity from un-jittered reprojection
-// with the camera's previous view-projection (instances are static within a frame pair).
+// with the camera's previous view-projection and, for instances that moved, their previous model.
 // ------------------------------------------------------------------------------------------
 static v2 frame_jitter(Ctx* c) {  // prepass.wgsl:30-38
   uint32_t index = (c->upscale_kind == HK_UPSCALE_SMAA_TU4X) ? ((c->frame.number >> 1u) & 15u) : (c->frame.number & 15u);
@@ -1041,7 +1042,16 @@ static void pass_prepass(Ctx* c, int y0, int y1) {
         v4 cn = mul(view_proj, V4(wp, 1.0f));
         grad[k] = cn.z / cn.w - depth;
       }
-      v2 velocity = clip_to_uv(clip) - clip_to_uv(mul(prev_view_proj, V4(world_position, 1.0f)));
+      // prepass.wgsl:50,96: previous_world_position = previous_mesh.model * vertex, interpolated over the
+      // triangle; only evaluated for instances whose previous model differs (else it IS world_position)
+      v4 previous_world = V4(world_position, 1.0f);
+      if (c->prev_models.size() == 16 * c->instances.size() &&
+          memcmp(&c->prev_models[16 * (size_t)hit.instance_index], instance.model, 64) != 0) {
+        m4 pm = load_m4(&c->prev_models[16 * (size_t)hit.instance_index]);
+        v3 local = P3(pv[0].position) + b.x * (P3(pv[1].position) - P3(pv[0].position)) + b.y * (P3(pv[2].position) - P3(pv[0].position));
+        previous_world = mul(pm, V4(local, 1.0f));
+      }
+      v2 velocity = clip_to_uv(clip) - clip_to_uv(mul(prev_view_proj, previous_world));
       position.store_f32x4(x, y, V4(world_position, depth));
       normal.store_u32(x, y, pack4x8snorm(V4(wn, 1.0f)));
       dgrad.store_f32x2(x, y, V2(grad[0], grad[1]));
@@ -1781,6 +1791,13 @@ int orc_upload_instances(orc_ctx* ctx, const HkInstance* inst, uint32_t ni, cons
   ctx->c.emissives.assign(em, em + ne);
   ctx->c.emissive_nodes.assign(enodes, enodes + nen);
   ctx->c.alias_table.assign(alias, alias + na);
+  ctx->c.prev_models.clear();
+  return HK_OK;
+}
+int orc_upload_previous_transforms(orc_ctx* ctx, const float* models, uint32_t n) {
+  ORC_CHECK(ctx && (models || !n), HK_E_INVALID, "null argument");
+  ORC_CHECK(n == ctx->c.instances.size(), HK_E_INVALID, "previous transforms must match the uploaded instances");
+  ctx->c.prev_models.assign(models, models + 16 * (size_t)n);
   return HK_OK;
 }
 int orc_upload_textures(orc_ctx* ctx, const HkImageDesc* images, uint32_t n) {

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Cost of an instance-only scene update (prepare_instances re-runs whenever an
+instance changes, instance.rs:352-437) at the city-class scale of BASELINE config 4:
+host builder re-finish (world AABBs, TLAS, emissives, alias tables, light BVH), upload + device
+layout conversion, against the full scene upload."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+if __name__ == "__main__":
+    small = "--small" in sys.argv
+    t0 = time.perf_counter()
+    scene, sun = synthetic_large() if small else synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+    t_build = time.perf_counter() - t0
+    cam = synthetic_camera(1280, 720, extent=9.0 if small else 30.0)
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)
+    lights = hk.lights_uniform(directional=sun)
+    p = hk.HikariPlugin(device=0)
+    t0 = time.perf_counter()
+    p.set_scene(scene)
+    p.render(cam, s, lights=lights, frame_number=1)
+    p.engine.wait()
+    t_full = time.perf_counter() - t0
+    b = scene.builder
+    rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in scene.instances], dtype=np.float32)
+    rng = np.random.default_rng(1)
+    movers = rng.choice(len(rest), size=min(200, len(rest)), replace=False)
+    t_finish, t_upload, t_frame = [], [], []
+    for n in range(2, 12):
+        t0 = time.perf_counter()
+        for i in movers:
+            m = rest[i].copy()
+            m[12] += 0.01 * n
+            b.api.raw("scene_builder_set_instance_transform")(b.h, int(i), m.ctypes.data_as(__import__("ctypes").POINTER(F.f32)))
+        b.api.call("scene_builder_finish", b.h)
+        t1 = time.perf_counter()
+        p.engine.api.call("upload_scene_instances", p.engine.ctx, b.h)
+        p.engine.frame_begin(hk.frame_uniform(s, n), cam.view_uniform(), cam.previous_view_uniform(), lights)
+        p.engine.pass_run(F.PASS_PREPASS)   # first dispatch converts + uploads the instance-level arrays
+        t2 = time.perf_counter()
+        p.engine.wait()
+        t3 = time.perf_counter()
+        t_finish.append(t1 - t0)
+        t_upload.append(t2 - t1)
+        t_frame.append(t3 - t2)
+    st = p.engine.stats()
+    med = lambda v: round(float(np.median(v)) * 1e3, 3)
+    print(json.dumps({"instances": len(rest), "triangles": len(scene.primitives), "moved_per_update": int(len(movers)),
+                      "builder_initial_s": round(t_build, 2), "full_upload_plus_first_frame_ms": round(t_full * 1e3, 1),
+                      "builder_refinish_ms": med(t_finish), "instance_upload_ms": med(t_upload),
+                      "scene_mesh_builds": int(st.scene_mesh_builds), "scene_instance_builds": int(st.scene_instance_builds)}))
