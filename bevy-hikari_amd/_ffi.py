@@ -22,17 +22,20 @@ HK_E_INVALID, HK_E_NO_DEVICE, HK_E_HIP, HK_E_NOT_READY, HK_E_NOMEM, HK_E_UNSUPPO
 # HkBuffer
 BUF_POSITION, BUF_NORMAL, BUF_DEPTH_GRADIENT, BUF_INSTANCE_MATERIAL, BUF_VELOCITY_UV, BUF_ALBEDO = range(6)
 BUF_VARIANCE0, BUF_RENDER0, BUF_RESERVOIR0 = 6, 9, 12
-BUF_DENOISE_INTERNAL0, BUF_DENOISE_INTERNAL_VARIANCE, BUF_DENOISE_RENDER0, BUF_TONE_MAPPED, BUF_COUNT = 22, 26, 27, 30, 31
+BUF_DENOISE_INTERNAL0, BUF_DENOISE_INTERNAL_VARIANCE, BUF_DENOISE_RENDER0, BUF_TONE_MAPPED = 22, 26, 27, 30
+(BUF_PREVIOUS_POSITION, BUF_PREVIOUS_VELOCITY_UV, BUF_PREVIOUS_TONE_MAPPED, BUF_UPSCALE_OUTPUT, BUF_TAA_OUTPUT, BUF_PREVIOUS_TAA_OUTPUT,
+ BUF_COUNT) = range(31, 38)
 # HkPass
 (PASS_PREPASS, PASS_FULL_SCREEN_ALBEDO, PASS_DIRECT_LIT, PASS_DIRECT_EMISSIVE, PASS_INDIRECT, PASS_EMISSIVE_SPATIAL_REUSE,
  PASS_INDIRECT_SPATIAL_REUSE, PASS_DEMODULATION, PASS_DENOISE_L0, PASS_DENOISE_L1, PASS_DENOISE_L2, PASS_DENOISE_L3,
- PASS_TONE_MAPPING, PASS_COUNT) = range(14)
+ PASS_TONE_MAPPING, PASS_SMAA_TU4X, PASS_SMAA_TU4X_EXTRAPOLATE, PASS_TAA_JASMINE, PASS_COUNT) = range(17)
 PASS_NAMES = ["prepass", "full_screen_albedo", "direct_lit", "direct_emissive", "indirect_lit_ambient", "emissive_spatial_reuse",
-              "indirect_spatial_reuse", "demodulation", "denoise_l0", "denoise_l1", "denoise_l2", "denoise_l3", "tone_mapping"]
+              "indirect_spatial_reuse", "demodulation", "denoise_l0", "denoise_l1", "denoise_l2", "denoise_l3", "tone_mapping",
+              "smaa_tu4x", "smaa_tu4x_extrapolate", "taa_jasmine"]
 # HkStage
-STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_COUNT = range(4)
+STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_ANTIALIAS, STAGE_COUNT = range(5)
 CTX_COUNT_RAYS, CTX_TIME_PASSES = 1, 2
-FRAME_EXTERNAL_GBUFFER = 1
+FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS = 1, 2
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1
 UPSCALE_FSR1, UPSCALE_SMAA_TU4X = 0, 1

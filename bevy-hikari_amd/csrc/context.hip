@@ -130,6 +130,8 @@ struct hk_ctx {
 
   // screen-space resources
   int W = 0, H = 0, RW = 0, RH = 0;
+  int UW = 0, UH = 0;           // SMAA Tu4x output size, ceil(size * 2 / ratio) (post_process.rs:718-722)
+  uint32_t mapped_parity = 0;   // frame parity whose planes the non-PREVIOUS ids of the double-buffered set name
   float ratio = 1.0f;
   void* buf[HK_BUF_COUNT] = {};
   size_t buf_bytes[HK_BUF_COUNT] = {};
@@ -166,6 +168,20 @@ struct hk_ctx {
 };
 
 namespace {
+
+// logical size of a buffer: upscale_output is created at scale 2/ratio for SMAA Tu4x and taa_output at the
+// scale in effect after the upscale match (post_process.rs:712-733): 2/ratio for SMAA Tu4x, 1/ratio for FSR1
+void buffer_dims(const hk_ctx* c, uint32_t b, int* w, int* h) {
+  if (buffer_is_full_size(b)) { *w = c->W; *h = c->H; return; }
+  if (b == HK_BUF_UPSCALE_OUTPUT || (buffer_is_upscaled(b) && c->upscale_kind == HK_UPSCALE_SMAA_TU4X)) { *w = c->UW; *h = c->UH; return; }
+  *w = c->RW;
+  *h = c->RH;
+}
+size_t buffer_logical_bytes(const hk_ctx* c, uint32_t b) {
+  int w, h;
+  buffer_dims(c, b, &w, &h);
+  return (size_t)w * h * buffer_bpp(b);
+}
 
 int free_screen(hk_ctx* c) {
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
@@ -720,6 +736,32 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       launch_tone_mapping(c->stream, fr, c->buf[base], c->buf[base + 1], indirect, c->buf[HK_BUF_TONE_MAPPED], y0, y1);
       break;
     }
+    case HK_PASS_SMAA_TU4X:
+    case HK_PASS_TAA_JASMINE: {  // bindings post_process.rs:983-1035
+      AaBuffers ab{};
+      ab.position = c->buf[HK_BUF_POSITION]; ab.velocity_uv = c->buf[HK_BUF_VELOCITY_UV];
+      ab.previous_position = c->buf[HK_BUF_PREVIOUS_POSITION]; ab.previous_velocity_uv = c->buf[HK_BUF_PREVIOUS_VELOCITY_UV];
+      ab.instance_material = c->buf[HK_BUF_INSTANCE_MATERIAL];
+      ab.full_w = c->W; ab.full_h = c->H;
+      if (pass == HK_PASS_SMAA_TU4X) {
+        ab.render = c->buf[HK_BUF_TONE_MAPPED]; ab.render_w = c->RW; ab.render_h = c->RH;
+        ab.previous_render = c->buf[HK_BUF_PREVIOUS_TONE_MAPPED]; ab.previous_w = c->RW; ab.previous_h = c->RH;
+        ab.output = c->buf[HK_BUF_UPSCALE_OUTPUT]; ab.out_w = c->UW; ab.out_h = c->UH;
+        launch_smaa_tu4x(c->stream, ab, c->frame.number, y0, y1);
+      } else {
+        const uint32_t in = c->upscale_kind == HK_UPSCALE_SMAA_TU4X ? HK_BUF_UPSCALE_OUTPUT : HK_BUF_TONE_MAPPED;  // post_process.rs:1010-1013
+        buffer_dims(c, in, &ab.render_w, &ab.render_h);
+        ab.render = c->buf[in];
+        buffer_dims(c, HK_BUF_TAA_OUTPUT, &ab.out_w, &ab.out_h);
+        ab.previous_render = c->buf[HK_BUF_PREVIOUS_TAA_OUTPUT]; ab.previous_w = ab.out_w; ab.previous_h = ab.out_h;
+        ab.output = c->buf[HK_BUF_TAA_OUTPUT];
+        launch_taa_jasmine(c->stream, ab, 0.1f / c->frame.upscale_ratio, c->frame.clear_color, y0, y1);
+      }
+      break;
+    }
+    case HK_PASS_SMAA_TU4X_EXTRAPOLATE:
+      launch_smaa_tu4x_extrapolate(c->stream, c->buf[HK_BUF_UPSCALE_OUTPUT], c->UW, c->UH, c->RW, y0, y1);
+      break;
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown pass %u", pass);
   }
   HK_HIP(hipGetLastError());
@@ -898,8 +940,14 @@ int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
   if (rc) return rc;
   c->W = (int)width; c->H = (int)height; c->RW = (int)rw; c->RH = (int)rh;
   c->ratio = upscale_ratio < 1.0f ? 1.0f : (upscale_ratio > 2.0f ? 2.0f : upscale_ratio);
+  {
+    const float scale2 = (1.0f / c->ratio) * 2.0f;
+    c->UW = (int)ceilf((float)width * scale2);
+    c->UH = (int)ceilf((float)height * scale2);
+    c->mapped_parity = 0;
+  }
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
-    size_t n = buffer_is_full_size(b) ? (size_t)c->W * c->H : (size_t)c->RW * c->RH;
+    size_t n = buffer_is_full_size(b) ? (size_t)c->W * c->H : (buffer_is_upscaled(b) ? (size_t)c->UW * c->UH : (size_t)c->RW * c->RH);
     size_t bytes = n * buffer_bpp(b);
     HK_HIP(hipMalloc(&c->buf[b], bytes));
     HK_HIP(hipMemset(c->buf[b], 0, bytes));  // zeroed reservoirs, light.rs:352-360
@@ -938,6 +986,15 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
   c->pview = *pv;
   c->lights = *l;
   c->have_frame = true;
+  // double-buffered planes follow frame.number % 2 (hikari_hip.h, HkBuffer): idempotent per frame number.
+  // Work already enqueued captured its pointers at launch, so swapping here needs no synchronisation.
+  if ((f->number & 1u) != c->mapped_parity) {
+    std::swap(c->buf[HK_BUF_POSITION], c->buf[HK_BUF_PREVIOUS_POSITION]);
+    std::swap(c->buf[HK_BUF_VELOCITY_UV], c->buf[HK_BUF_PREVIOUS_VELOCITY_UV]);
+    std::swap(c->buf[HK_BUF_TONE_MAPPED], c->buf[HK_BUF_PREVIOUS_TONE_MAPPED]);
+    std::swap(c->buf[HK_BUF_TAA_OUTPUT], c->buf[HK_BUF_PREVIOUS_TAA_OUTPUT]);
+    c->mapped_parity = f->number & 1u;
+  }
   return HK_OK;
 }
 
@@ -945,7 +1002,8 @@ int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint
   int rc = ready(c);
   if (rc) return rc;
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
-  const int rows = full_grid ? c->H : c->RH;
+  int rows = full_grid ? c->H : c->RH;
+  if (pass == HK_PASS_TAA_JASMINE) { int w; buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &rows); }
   const int y0 = (int)row_begin, y1 = row_end == 0 ? rows : (int)row_end;
   HK_REQUIRE(y0 >= 0 && y1 <= rows && y0 <= y1, HK_E_INVALID, "row range [%d,%d) outside 0..%d", y0, y1, rows);
   return run_pass(c, pass, arg, y0, y1);
@@ -1023,6 +1081,17 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       c->frame_timed = true;
     }
     c->frames += 1;
+  } else if (stage == HK_STAGE_ANTIALIAS) {            // post_process.rs:1236-1272
+    HK_REQUIRE(c->band_count == 1, HK_E_UNSUPPORTED, "the antialias stage runs on the whole image (band_count 1)");
+    if (st->upscale_kind == HK_UPSCALE_SMAA_TU4X) {
+      HK_RUN(HK_PASS_SMAA_TU4X, 0, 0, c->RH);
+      HK_RUN(HK_PASS_SMAA_TU4X_EXTRAPOLATE, 0, 0, c->RH);
+    }
+    if (st->taa == HK_TAA_JASMINE) {
+      int w, h;
+      buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &h);
+      HK_RUN(HK_PASS_TAA_JASMINE, 0, 0, h);
+    }
   } else {
     HK_REQUIRE(false, HK_E_INVALID, "unknown stage %u", stage);
   }
@@ -1033,8 +1102,9 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
 int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   int rc = hk_frame_begin(c, f, v, pv, l);
   if (rc) return rc;
-  for (uint32_t s = 0; s < HK_STAGE_COUNT; ++s)
+  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s)
     if ((rc = hk_frame_stage(c, s, st, flags))) return rc;
+  if (flags & HK_FRAME_ANTIALIAS) return hk_frame_stage(c, HK_STAGE_ANTIALIAS, st, flags);
   return HK_OK;
 }
 
@@ -1048,15 +1118,16 @@ int hk_frame_wait(hk_ctx* c) {
 
 int hk_buffer_info(hk_ctx* c, uint32_t buffer, uint32_t* w, uint32_t* h, uint32_t* bpp) {
   HK_REQUIRE(c && buffer < HK_BUF_COUNT && buffer_bpp(buffer), HK_E_INVALID, "bad buffer id");
-  const bool full = buffer_is_full_size(buffer);
-  if (w) *w = (uint32_t)(full ? c->W : c->RW);
-  if (h) *h = (uint32_t)(full ? c->H : c->RH);
+  int bw, bh;
+  buffer_dims(c, buffer, &bw, &bh);
+  if (w) *w = (uint32_t)bw;
+  if (h) *h = (uint32_t)bh;
   if (bpp) *bpp = buffer_bpp(buffer);
   return HK_OK;
 }
 int hk_read_buffer(hk_ctx* c, uint32_t buffer, void* dst, size_t bytes) {
   HK_REQUIRE(c && dst && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
-  HK_REQUIRE(bytes == c->buf_bytes[buffer], HK_E_INVALID, "size mismatch: buffer has %zu bytes", c->buf_bytes[buffer]);
+  HK_REQUIRE(bytes == buffer_logical_bytes(c, buffer), HK_E_INVALID, "size mismatch: buffer has %zu bytes", buffer_logical_bytes(c, buffer));
   HK_HIP(hipSetDevice(c->device));
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(dst, c->buf[buffer], bytes, hipMemcpyDeviceToHost));
@@ -1064,7 +1135,7 @@ int hk_read_buffer(hk_ctx* c, uint32_t buffer, void* dst, size_t bytes) {
 }
 int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
   HK_REQUIRE(c && src && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
-  HK_REQUIRE(bytes == c->buf_bytes[buffer], HK_E_INVALID, "size mismatch: buffer has %zu bytes", c->buf_bytes[buffer]);
+  HK_REQUIRE(bytes == buffer_logical_bytes(c, buffer), HK_E_INVALID, "size mismatch: buffer has %zu bytes", buffer_logical_bytes(c, buffer));
   HK_HIP(hipSetDevice(c->device));
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
@@ -1074,7 +1145,7 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
 int hk_device_ptr(hk_ctx* c, uint32_t buffer, void** ptr, size_t* bytes) {
   HK_REQUIRE(c && ptr && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
   *ptr = c->buf[buffer];
-  if (bytes) *bytes = c->buf_bytes[buffer];
+  if (bytes) *bytes = buffer_logical_bytes(c, buffer);
   return HK_OK;
 }
 int hk_set_stream(hk_ctx* c, void* s) {

@@ -25,6 +25,7 @@ std::vector<HkNode> build_flat_bvh(const std::vector<float>& boxes_min_max);
 // bytes per pixel / full-size flag of an HkBuffer id (0 = invalid id)
 uint32_t buffer_bpp(uint32_t buffer);
 bool buffer_is_full_size(uint32_t buffer);
+bool buffer_is_upscaled(uint32_t buffer);  // allocated at the SMAA Tu4x output size ceil(size * 2 / ratio)
 
 // rows [b0,b1) of band i of n over `height` rows
 void band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32_t* b0, uint32_t* b1);

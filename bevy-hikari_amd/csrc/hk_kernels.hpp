@@ -83,5 +83,19 @@ void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_pl
 void launch_demodulation(hipStream_t st, int nch, const hkd::DFrame& fr, const hkd::DemodTargets& d, int y0, int y1);
 void launch_denoise(hipStream_t st, int level, int nch, int ffmask, const hkd::DFrame& fr, const hkd::DenoiseTargets& d, int y0, int y1);
 void launch_tone_mapping(hipStream_t st, const hkd::DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1);
+// anti-aliasing tail (kernels_aa.hip): raw plane pointers + sizes of one dispatch's bindings
+struct AaBuffers {
+  const void *position, *velocity_uv, *previous_position, *previous_velocity_uv, *instance_material;  // full size
+  int full_w, full_h;
+  const void* render;           // rgba16f: tone_mapping_output[current] (SMAA) / TAA input
+  int render_w, render_h;
+  const void* previous_render;  // rgba16f: tone_mapping_output[previous] (SMAA) / taa_output[previous] (TAA)
+  int previous_w, previous_h;
+  void* output;                 // rgba16f
+  int out_w, out_h;
+};
+void launch_smaa_tu4x(hipStream_t st, const AaBuffers& b, uint32_t frame_number, int y0, int y1);
+void launch_smaa_tu4x_extrapolate(hipStream_t st, void* output, int out_w, int out_h, int render_w, int y0, int y1);
+void launch_taa_jasmine(hipStream_t st, const AaBuffers& b, float blend, const float clear_color[4], int y0, int y1);
 void launch_debug_math(hipStream_t st, uint32_t op, const float* x, const float* y, float* out, size_t n);
 }  // namespace hk

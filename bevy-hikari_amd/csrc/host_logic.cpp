@@ -34,10 +34,16 @@ uint32_t buffer_bpp(uint32_t b) {
   if (b >= HK_BUF_DENOISE_INTERNAL0 && b < HK_BUF_DENOISE_INTERNAL0 + 4) return 8;
   if (b == HK_BUF_DENOISE_INTERNAL_VARIANCE) return 4;
   if (b >= HK_BUF_DENOISE_RENDER0 && b < HK_BUF_DENOISE_RENDER0 + 3) return 8;
-  if (b == HK_BUF_TONE_MAPPED) return 8;
+  if (b == HK_BUF_TONE_MAPPED || b == HK_BUF_PREVIOUS_TONE_MAPPED) return 8;
+  if (b == HK_BUF_PREVIOUS_POSITION || b == HK_BUF_PREVIOUS_VELOCITY_UV) return 16;
+  if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT) return 8;
   return 0;
 }
-bool buffer_is_full_size(uint32_t b) { return b <= HK_BUF_ALBEDO || (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10); }
+bool buffer_is_full_size(uint32_t b) {
+  return b <= HK_BUF_ALBEDO || (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10) || b == HK_BUF_PREVIOUS_POSITION ||
+         b == HK_BUF_PREVIOUS_VELOCITY_UV;
+}
+bool buffer_is_upscaled(uint32_t b) { return b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT; }
 
 void band_rows(uint32_t height, uint32_t i, uint32_t n, uint32_t* b0, uint32_t* b1) {
   uint32_t base = height / n, rem = height % n;
@@ -162,6 +168,7 @@ static void emit(uint32_t buffer, uint32_t width, uint32_t height, uint32_t lo, 
 int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count, uint32_t stage,
                      uint32_t frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
   HK_REQUIRE(st && n_ops && band_count > 0 && band_index < band_count && stage < HK_STAGE_COUNT, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(stage != HK_STAGE_ANTIALIAS || band_count == 1, HK_E_UNSUPPORTED, "the antialias stage runs on the whole image (band_count 1)");
   uint32_t rw, rh;
   int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
   if (rc) return rc;

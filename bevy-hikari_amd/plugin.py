@@ -552,8 +552,8 @@ class LightNode(_Node):  # light.rs:557-703
             e.pass_run(F.PASS_INDIRECT_SPATIAL_REUSE)
 
 
-class PostProcessNode(_Node):  # post_process.rs:1107-1312 (denoise + tone mapping part)
-    def run(self, settings: HikariSettings):
+class PostProcessNode(_Node):  # post_process.rs:1107-1312
+    def run(self, settings: HikariSettings, antialias=False):
         e = self.engine
         if settings.denoise:                                       # post_process.rs:1190-1224
             channels = 2 if settings.indirect_bounces == 0 else 3  # post_process.rs:949-954
@@ -562,6 +562,17 @@ class PostProcessNode(_Node):  # post_process.rs:1107-1312 (denoise + tone mappi
                 for level in range(4):
                     e.pass_run(F.PASS_DENOISE_L0 + level, ch)
         e.pass_run(F.PASS_TONE_MAPPING, int(settings.denoise))     # post_process.rs:1226-1234
+        if antialias:
+            self.run_antialias(settings)
+
+    def run_antialias(self, settings: HikariSettings):
+        e = self.engine
+        e.set_view_options(settings.taa, settings.upscale.kind)
+        if settings.upscale.kind == F.UPSCALE_SMAA_TU4X:           # post_process.rs:1236-1258
+            e.pass_run(F.PASS_SMAA_TU4X)
+            e.pass_run(F.PASS_SMAA_TU4X_EXTRAPOLATE)
+        if settings.taa == Taa.Jasmine:                            # post_process.rs:1260-1275
+            e.pass_run(F.PASS_TAA_JASMINE)
 
 
 class HikariPlugin:
@@ -585,8 +596,9 @@ class HikariPlugin:
         """Instances moved (prepare_instances, instance.rs:352-437): rewrite the instance-level buffers only."""
         self.engine.upload_instances(scene)
 
-    def render(self, camera: Camera, settings: HikariSettings, lights=None, frame_number=None, by_nodes=False):
-        """One frame of the camera's render graph.  Returns the frame number used."""
+    def render(self, camera: Camera, settings: HikariSettings, lights=None, frame_number=None, by_nodes=False, antialias=False):
+        """One frame of the camera's render graph.  Returns the frame number used.  antialias=True also runs the
+        SMAA Tu4x / TAA dispatches of PostProcessNode::run (the north-star frame ends at tone mapping)."""
         size = (camera.width, camera.height, settings.upscale.ratio())
         if size != self._size:  # prepare_light_textures, light.rs:342-363: reallocate + zero on size change
             self.engine.resize(*size)
@@ -600,11 +612,19 @@ class HikariPlugin:
             self.engine.frame_begin(frame, view, pview, lights)
             self.prepass.run(settings)
             self.light.run(settings)
-            self.post_process.run(settings)
+            self.post_process.run(settings, antialias)
         else:
-            self.engine.frame_render(frame, view, pview, lights, settings.to_c())
+            self.engine.frame_render(frame, view, pview, lights, settings.to_c(), F.FRAME_ANTIALIAS if antialias else 0)
         self._previous_camera = camera
         return n
+
+    def final_image(self, settings: HikariSettings):
+        """What OverlayNode samples (overlay.rs:226-231), as f32 [H][W][4]."""
+        if settings.upscale.kind == F.UPSCALE_SMAA_TU4X:
+            buf = F.BUF_TAA_OUTPUT if settings.taa == Taa.Jasmine else F.BUF_UPSCALE_OUTPUT
+        else:  # FSR1 EASU/RCAS are not part of this library: the image that would enter them
+            buf = F.BUF_TAA_OUTPUT if settings.taa == Taa.Jasmine else F.BUF_TONE_MAPPED
+        return self.engine.read_f16(buf)
 
     def output(self, settings: HikariSettings):
         """The three radiance channels the tone-mapping pass sums (tone_mapping.wgsl:25-27), as f32 [3][H][W][4]."""

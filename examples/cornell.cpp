@@ -3,7 +3,7 @@
 // libhikari_hip.so through the C++ host mirror include/hikari.hpp.  Headless: renders N frames and
 // writes the tone-mapped image as a PPM and/or the raw rgba16f words.
 //
-//   cornell [--size W H] [--frames N] [--bounces B] [--ratio R] [--by-nodes] [--ppm out.ppm] [--raw out.bin] [--describe]
+//   cornell [--size W H] [--frames N] [--bounces B] [--ratio R] [--by-nodes] [--antialias] [--ppm out.ppm] [--raw out.bin] [--describe]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
   uint32_t w = 256, h = 256;
   size_t frames = 8;
   HikariSettings settings;  // HikariSettings::default(), examples/cornell.rs:53
-  bool by_nodes = false, describe = false;
+  bool by_nodes = false, describe = false, antialias = false;
   std::string ppm, raw, assets = "bevy-hikari_amd/assets";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -84,6 +84,7 @@ int main(int argc, char** argv) {
     else if (a == "--bounces" && i + 1 < argc) settings.indirect_bounces = (size_t)atoi(argv[++i]);
     else if (a == "--ratio" && i + 1 < argc) settings.upscale = Upscale::SmaaTu4x((float)atof(argv[++i]));
     else if (a == "--by-nodes") by_nodes = true;
+    else if (a == "--antialias") antialias = true;  // SMAA Tu4x + TAA as the settings say; output = what the overlay presents
     else if (a == "--ppm" && i + 1 < argc) ppm = argv[++i];
     else if (a == "--raw" && i + 1 < argc) raw = argv[++i];
     else if (a == "--assets" && i + 1 < argc) assets = argv[++i];
@@ -110,11 +111,12 @@ int main(int argc, char** argv) {
     load_cornell(assets + "/cornell.hkscene", scene);                      // asset_server.load("models/cornell.glb#Scene0")
     plugin.set_scene(scene);
     Camera camera = Camera::looking_at({0.0, 1.0, 4.0}, {0.0, 1.0, 0.0}, {0.0, 1.0, 0.0}, w, h);  // cornell.rs:49-50
-    for (size_t n = 1; n <= frames; ++n) plugin.render(camera, settings, n, by_nodes);
+    for (size_t n = 1; n <= frames; ++n) plugin.render(camera, settings, n, by_nodes, nullptr, antialias);
     plugin.wait();
-    std::vector<uint8_t> tm = plugin.context().read(HK_BUF_TONE_MAPPED);
+    const uint32_t out_buffer = HikariPlugin::final_buffer(settings, antialias);
+    std::vector<uint8_t> tm = plugin.context().read(out_buffer);
     uint32_t rw, rh, bpp;
-    check(hk_buffer_info(plugin.context().get(), HK_BUF_TONE_MAPPED, &rw, &rh, &bpp), "hk_buffer_info");
+    check(hk_buffer_info(plugin.context().get(), out_buffer, &rw, &rh, &bpp), "hk_buffer_info");
     if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)tm.data(), (std::streamsize)tm.size());
     if (!ppm.empty()) {
       std::ofstream f(ppm, std::ios::binary);
@@ -127,7 +129,7 @@ int main(int argc, char** argv) {
           f.put((char)(unsigned char)(std::pow(v, 1.0f / 2.2f) * 255.0f + 0.5f));
         }
     }
-    std::printf("rendered %zu frames at %ux%u (render size %ux%u)\n", frames, w, h, rw, rh);
+    std::printf("rendered %zu frames at %ux%u (output size %ux%u)\n", frames, w, h, rw, rh);
   } catch (const Error& e) {
     std::fprintf(stderr, "hikari error %d: %s\n", e.code, e.what());
     return e.code == HK_E_NO_DEVICE ? 3 : 1;

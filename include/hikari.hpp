@@ -302,9 +302,10 @@ struct LightNode {  // light.rs:557-703
     if (s.indirect_spatial_reuse) ctx.pass_run(HK_PASS_INDIRECT_SPATIAL_REUSE);  // light.rs:676
   }
 };
-struct PostProcessNode {  // post_process.rs:1107-1312 (denoise + tone mapping part)
+struct PostProcessNode {  // post_process.rs:1107-1312
   Context& ctx;
-  void run(const HikariSettings& s) {
+  // antialias = also the SMAA Tu4x / TAA dispatches (post_process.rs:1236-1272); the north-star frame ends at tone mapping
+  void run(const HikariSettings& s, bool antialias = false) {
     if (s.denoise) {                                                  // post_process.rs:1190-1224
       const uint32_t channels = s.indirect_bounces == 0 ? 2u : 3u;    // post_process.rs:949-954
       for (uint32_t ch = 0; ch < channels; ++ch) {
@@ -313,6 +314,12 @@ struct PostProcessNode {  // post_process.rs:1107-1312 (denoise + tone mapping p
       }
     }
     ctx.pass_run(HK_PASS_TONE_MAPPING, s.denoise ? 1u : 0u);          // post_process.rs:1226-1234
+    if (!antialias) return;
+    if (s.upscale.kind == HK_UPSCALE_SMAA_TU4X) {                     // post_process.rs:1236-1258
+      ctx.pass_run(HK_PASS_SMAA_TU4X);
+      ctx.pass_run(HK_PASS_SMAA_TU4X_EXTRAPOLATE);
+    }
+    if (s.taa == Taa::Jasmine) ctx.pass_run(HK_PASS_TAA_JASMINE);     // post_process.rs:1260-1275
   }
 };
 
@@ -333,7 +340,7 @@ class HikariPlugin {
   // one frame of the camera's render graph; by_nodes = dispatch by dispatch through the three nodes,
   // otherwise one hk_frame_render call.  Returns the frame number used.
   size_t render(const Camera& camera, const HikariSettings& settings, std::optional<size_t> frame_number = std::nullopt, bool by_nodes = false,
-                const HkLights* lights = nullptr) {
+                const HkLights* lights = nullptr, bool antialias = false) {
     if (camera.width != width_ || camera.height != height_ || settings.upscale.ratio() != ratio_) {  // light.rs:342-363
       check(hk_resize(ctx_.get(), camera.width, camera.height, settings.upscale.ratio()), "hk_resize");
       width_ = camera.width;
@@ -351,14 +358,21 @@ class HikariPlugin {
       check(hk_frame_begin(ctx_.get(), &frame, &view, &pview, &l), "hk_frame_begin");
       prepass_.run(settings);
       light_.run(settings);
-      post_process_.run(settings);
+      post_process_.run(settings, antialias);
     } else {
-      check(hk_frame_render(ctx_.get(), &frame, &view, &pview, &l, &sc, 0), "hk_frame_render");
+      check(hk_frame_render(ctx_.get(), &frame, &view, &pview, &l, &sc, antialias ? HK_FRAME_ANTIALIAS : 0u), "hk_frame_render");
     }
     previous_ = camera;
     return n;
   }
   void wait() { check(hk_frame_wait(ctx_.get()), "hk_frame_wait"); }
+  // the image OverlayNode presents (overlay.rs:226-231); FSR1's EASU/RCAS are outside this library, so for
+  // Upscale::Fsr1 this is the image that would enter them
+  static uint32_t final_buffer(const HikariSettings& s, bool antialias) {
+    if (!antialias) return HK_BUF_TONE_MAPPED;
+    if (s.taa == Taa::Jasmine) return HK_BUF_TAA_OUTPUT;
+    return s.upscale.kind == HK_UPSCALE_SMAA_TU4X ? HK_BUF_UPSCALE_OUTPUT : HK_BUF_TONE_MAPPED;
+  }
 
  private:
   Context ctx_;

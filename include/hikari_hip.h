@@ -230,8 +230,21 @@ typedef enum HkBuffer {
   HK_BUF_DENOISE_INTERNAL0 = 22,/* rgba16f, scaled; +level 0..3 */
   HK_BUF_DENOISE_INTERNAL_VARIANCE = 26, /* r32f, scaled */
   HK_BUF_DENOISE_RENDER0 = 27,  /* rgba16f, scaled; +channel */
-  HK_BUF_TONE_MAPPED = 30,      /* rgba16f, scaled (tone_mapping.wgsl:21-32) */
-  HK_BUF_COUNT = 31
+  HK_BUF_TONE_MAPPED = 30,      /* rgba16f, scaled (tone_mapping.wgsl:21-32): tone_mapping_output[current] */
+  /* Temporal anti-aliasing / upscale inputs and outputs (post_process.rs:621-748, prepass.rs:285-318).
+   * The reference double-buffers these by frame: position / velocity_uv swap every frame
+   * (prepass.rs:308-317), tone_mapping_output and taa_output are indexed by frame.number % 2
+   * (post_process.rs:737,866-867).  Here all four follow frame.number % 2 of hk_frame_begin: ids
+   * without PREVIOUS name the plane frame n writes, PREVIOUS_* the plane frame n-1 wrote.
+   * hk_device_ptr of these ids is therefore only valid until the next hk_frame_begin, and a host
+   * that supplies its own G-buffer writes it AFTER hk_frame_begin of that frame. */
+  HK_BUF_PREVIOUS_POSITION = 31,
+  HK_BUF_PREVIOUS_VELOCITY_UV = 32,
+  HK_BUF_PREVIOUS_TONE_MAPPED = 33,
+  HK_BUF_UPSCALE_OUTPUT = 34,   /* rgba16f, ceil(size * 2 / ratio): upscale_output[0] of the SMAA Tu4x path */
+  HK_BUF_TAA_OUTPUT = 35,       /* rgba16f: taa_output[current]; size of UPSCALE_OUTPUT (SMAA) or scaled (FSR1) */
+  HK_BUF_PREVIOUS_TAA_OUTPUT = 36,
+  HK_BUF_COUNT = 37
 } HkBuffer;
 
 /* One compute dispatch of the reference.  `arg` selects the render channel for
@@ -250,7 +263,10 @@ typedef enum HkPass {
   HK_PASS_DENOISE_L2 = 10,
   HK_PASS_DENOISE_L3 = 11,
   HK_PASS_TONE_MAPPING = 12,       /* tone_mapping.wgsl:21-32 */
-  HK_PASS_COUNT = 13
+  HK_PASS_SMAA_TU4X = 13,          /* smaa.wgsl:81-188: current + reprojected previous sample of each output quad */
+  HK_PASS_SMAA_TU4X_EXTRAPOLATE = 14, /* smaa.wgsl:239-271: the other two pixels of each quad */
+  HK_PASS_TAA_JASMINE = 15,        /* taa.wgsl:75-170 */
+  HK_PASS_COUNT = 16
 } HkPass;
 
 /* Frame stages for band-sharded (multi-GPU) rendering: the host exchanges halo rows between
@@ -259,7 +275,10 @@ typedef enum HkStage {
   HK_STAGE_TEMPORAL = 0,     /* prepass (+apron), albedo, direct_lit x2, indirect on the band */
   HK_STAGE_SPATIAL = 1,      /* spatial_reuse dispatches that are enabled */
   HK_STAGE_POST_PROCESS = 2, /* demodulation + a-trous x4 per channel, tone mapping */
-  HK_STAGE_COUNT = 3
+  HK_STAGE_ANTIALIAS = 3,    /* the rest of PostProcessNode::run (post_process.rs:1236-1272): SMAA Tu4x (+extrapolate)
+                                when upscale_kind is SMAA_TU4X, then TAA when taa is JASMINE.  Whole image only
+                                (band_count must be 1); not part of hk_frame_render unless HK_FRAME_ANTIALIAS. */
+  HK_STAGE_COUNT = 4
 } HkStage;
 
 /* One halo transfer the host must perform BEFORE running `stage`: rows [row_begin,row_end) of
@@ -408,8 +427,10 @@ int hk_pass_run(hk_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, ui
  *   POST_PROCESS = PostProcessNode::run denoise loop + tone mapping (post_process.rs:1190-1234)
  * flags bit0: the G-buffer was supplied by the host (hk_write_buffer), skip the primary-ray prepass. */
 #define HK_FRAME_EXTERNAL_GBUFFER 1u
+/* flags bit1 (hk_frame_render): also run HK_STAGE_ANTIALIAS */
+#define HK_FRAME_ANTIALIAS 2u
 int hk_frame_stage(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, uint32_t flags);
-/* hk_frame_begin + the three stages (single GPU / no halo exchange) */
+/* hk_frame_begin + TEMPORAL, SPATIAL, POST_PROCESS (+ ANTIALIAS with HK_FRAME_ANTIALIAS): single GPU, no halo exchange */
 int hk_frame_render(hk_ctx* ctx, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
                     const HkLights* lights, const HkSettings* settings, uint32_t flags);
 int hk_frame_wait(hk_ctx* ctx);

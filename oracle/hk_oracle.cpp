@@ -91,6 +91,8 @@ struct Ctx {
 
   int W = 0, H = 0;    // full (deferred / albedo / reservoir allocation) size
   int RW = 0, RH = 0;  // scaled render size
+  int UW = 0, UH = 0;  // SMAA Tu4x output size, ceil(size * 2 / ratio)
+  uint32_t mapped_parity = 0;  // frame parity whose planes the non-PREVIOUS ids of the double-buffered set name
   float ratio = 1.0f;
   std::vector<uint8_t> buf[HK_BUF_COUNT];
 
@@ -119,12 +121,16 @@ static int buf_bpp(uint32_t b) {
   if (b >= HK_BUF_DENOISE_INTERNAL0 && b < HK_BUF_DENOISE_INTERNAL0 + 4) return 8;
   if (b == HK_BUF_DENOISE_INTERNAL_VARIANCE) return 4;
   if (b >= HK_BUF_DENOISE_RENDER0 && b < HK_BUF_DENOISE_RENDER0 + 3) return 8;
-  if (b == HK_BUF_TONE_MAPPED) return 8;
+  if (b == HK_BUF_TONE_MAPPED || b == HK_BUF_PREVIOUS_TONE_MAPPED) return 8;
+  if (b == HK_BUF_PREVIOUS_POSITION || b == HK_BUF_PREVIOUS_VELOCITY_UV) return 16;
+  if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT) return 8;
   return 0;
 }
 static bool buf_full_size(uint32_t b) {
-  return b <= HK_BUF_ALBEDO || (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10);
+  return b <= HK_BUF_ALBEDO || (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10) || b == HK_BUF_PREVIOUS_POSITION ||
+         b == HK_BUF_PREVIOUS_VELOCITY_UV;
 }
+static bool buf_upscaled(uint32_t b) { return b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT; }
 
 // texture access helpers.  Out-of-bounds textureLoad returns zeros (wgpu robust access).
 struct Tex {
@@ -184,10 +190,59 @@ struct Tex {
     *x = std::min(std::max(cx, 0), w - 1);
     *y = std::min(std::max(cy, 0), h - 1);
   }
+  // The 2x2 footprint of the linear sampler (post_process.rs:685-690: mag/min Linear, address mode
+  // clamp-to-edge): texel centres at integer + 0.5.  The numeric contract fixes what WGSL leaves to the
+  // implementation: weights are the exact f32 fractions, the blend is mix(mix(t00,t10,fx), mix(t01,t11,fx), fy).
+  struct Footprint { int x0, x1, y0, y1; float fx, fy; };
+  Footprint footprint(v2 uv) const {
+    float px = uv.x * (float)w - 0.5f, py = uv.y * (float)h - 0.5f;
+    float flx = floorf(px), fly = floorf(py);
+    Footprint f;
+    f.fx = px - flx;
+    f.fy = py - fly;
+    int ix = (int)flx, iy = (int)fly;
+    f.x0 = std::min(std::max(ix, 0), w - 1);
+    f.x1 = std::min(std::max(ix + 1, 0), w - 1);
+    f.y0 = std::min(std::max(iy, 0), h - 1);
+    f.y1 = std::min(std::max(iy + 1, 0), h - 1);
+    return f;
+  }
+  v4 texel(int x, int y) const { return bpp == 16 ? load_f32x4(x, y) : load_f16x4(x, y); }
+  v4 sample_nearest(v2 uv) const {
+    int x, y;
+    nearest_coords(uv, &x, &y);
+    return texel(x, y);
+  }
+  v2 sample_nearest_f32x2(v2 uv) const {
+    int x, y;
+    nearest_coords(uv, &x, &y);
+    return load_f32x2(x, y);
+  }
+  v4 sample_linear(v2 uv) const {
+    Footprint f = footprint(uv);
+    v4 t00 = texel(f.x0, f.y0), t10 = texel(f.x1, f.y0), t01 = texel(f.x0, f.y1), t11 = texel(f.x1, f.y1);
+    auto mix4 = [](v4 a, v4 b, float t) { return V4(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t), mix(a.w, b.w, t)); };
+    return mix4(mix4(t00, t10, f.fx), mix4(t01, t11, f.fx), f.fy);
+  }
+  // textureGather(component, ..): x = (u_min, v_max), y = (u_max, v_max), z = (u_max, v_min), w = (u_min, v_min)
+  v4 gather(int component, v2 uv) const {
+    Footprint f = footprint(uv);
+    auto comp = [&](int x, int y) { v4 t = texel(x, y); return component == 0 ? t.x : component == 1 ? t.y : component == 2 ? t.z : t.w; };
+    return V4(comp(f.x0, f.y1), comp(f.x1, f.y1), comp(f.x1, f.y0), comp(f.x0, f.y0));
+  }
 };
+// Logical size of a buffer.  upscale_output is created at scale 2/ratio for SMAA Tu4x and taa_output at
+// the scale in effect after the upscale match (post_process.rs:712-733): 2/ratio for SMAA Tu4x, 1/ratio for FSR1.
+static void buf_dims(const Ctx* c, uint32_t b, int* w, int* h) {
+  if (buf_full_size(b)) { *w = c->W; *h = c->H; return; }
+  if (b == HK_BUF_UPSCALE_OUTPUT || (buf_upscaled(b) && c->upscale_kind == HK_UPSCALE_SMAA_TU4X)) { *w = c->UW; *h = c->UH; return; }
+  *w = c->RW;
+  *h = c->RH;
+}
 static Tex tex(Ctx* c, uint32_t b) {
-  bool full = buf_full_size(b);
-  return Tex{c->buf[b].data(), full ? c->W : c->RW, full ? c->H : c->RH, buf_bpp(b)};
+  int w, h;
+  buf_dims(c, b, &w, &h);
+  return Tex{c->buf[b].data(), w, h, buf_bpp(b)};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1745,6 +1800,263 @@ static void pass_tone_mapping(Ctx* c, bool denoise, int y0, int y1) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Temporal anti-aliasing and SMAA Tu4x upscaling: taa.wgsl, smaa.wgsl.
+// Run after tone mapping by PostProcessNode::run (post_process.rs:1236-1272); bindings
+// post_process.rs:983-1035: SMAA reads tone_mapping_output[previous / current] and writes
+// upscale_output[0]; TAA reads taa_output[previous] and upscale_output[0] (SMAA) or
+// tone_mapping_output[current] (FSR1) and writes taa_output[current].
+// ------------------------------------------------------------------------------------------
+static inline v3 rgb(v4 a) { return V3(a.x, a.y, a.z); }
+static inline v3 clamp01(v3 c) { return V3(clamp_(c.x, 0.0f, 1.0f), clamp_(c.y, 0.0f, 1.0f), clamp_(c.z, 0.0f, 1.0f)); }
+static inline v3 sqrt3(v3 a) { return V3(sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)); }
+static inline v3 abs3(v3 a) { return V3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+static inline v3 RGB_to_YCoCg(v3 c) {  // taa.wgsl:20-25, smaa.wgsl:23-28
+  float y = (c.x / 4.0f) + (c.y / 2.0f) + (c.z / 4.0f);
+  float co = (c.x / 2.0f) - (c.z / 2.0f);
+  float cg = (-c.x / 4.0f) + (c.y / 2.0f) - (c.z / 4.0f);
+  return V3(y, co, cg);
+}
+static inline v3 YCoCg_to_RGB(v3 y) {  // taa.wgsl:27-32
+  float r = y.x + y.y - y.z;
+  float g = y.x + y.z;
+  float b = y.x - y.y - y.z;
+  return clamp01(V3(r, g, b));
+}
+static inline v3 clip_towards_aabb_center(v3 previous_color, v3 aabb_min, v3 aabb_max) {  // taa.wgsl:34-42 (current_color is unused there)
+  v3 p_clip = 0.5f * (aabb_max + aabb_min);
+  v3 e_clip = 0.5f * (aabb_max - aabb_min);
+  v3 v_clip = previous_color - p_clip;
+  v3 v_unit = v_clip / e_clip;
+  v3 a_unit = abs3(v_unit);
+  float ma_unit = fmax_(a_unit.x, fmax_(a_unit.y, a_unit.z));
+  return (ma_unit > 1.0f) ? p_clip + v_clip / ma_unit : previous_color;
+}
+static inline float distance2(v2 a, v2 b) { return length(a - b); }
+static inline float distance3(v3 a, v3 b) { return length(a - b); }
+static inline bool any_lt(v4 a, float s) { return a.x < s || a.y < s || a.z < s || a.w < s; }
+static inline bool any_gt(v4 a, float s) { return a.x > s || a.y > s || a.z > s || a.w > s; }
+// select(current / previous, 1.0, previous == 0.0), taa.wgsl:111, smaa.wgsl:146
+static inline v4 depth_ratio4(float current, v4 previous) {
+  auto r = [&](float p) { return p == 0.0f ? 1.0f : current / p; };
+  return V4(r(previous.x), r(previous.y), r(previous.z), r(previous.w));
+}
+// taa.wgsl:54-73, smaa.wgsl:54-73: velocity of the nearest (largest reverse-Z depth) of the 4 diagonal neighbours
+static v2 nearest_velocity(const Tex& position, const Tex& velocity_uv, v2 uv, v2 texel_size) {
+  v4 depths;
+  depths.x = position.sample_nearest(uv + V2(texel_size.x, texel_size.y)).w;
+  depths.y = position.sample_nearest(uv + V2(-texel_size.x, texel_size.y)).w;
+  depths.z = position.sample_nearest(uv + V2(texel_size.x, -texel_size.y)).w;
+  depths.w = position.sample_nearest(uv + V2(-texel_size.x, -texel_size.y)).w;
+  float max_depth = fmax_(fmax_(depths.x, depths.y), fmax_(depths.z, depths.w));
+  float depth = position.sample_nearest(uv).w;
+  v2 offset = V2(0.0f, 0.0f);
+  if (depth < max_depth) {
+    v4 eq = V4(depths.x == max_depth ? 1.0f : 0.0f, depths.y == max_depth ? 1.0f : 0.0f, depths.z == max_depth ? 1.0f : 0.0f,
+               depths.w == max_depth ? 1.0f : 0.0f);
+    float x = dot(V4(texel_size.x, texel_size.x, texel_size.x, texel_size.x), V4(eq.x, -eq.y, eq.z, -eq.w));
+    float y = dot(V4(texel_size.y, texel_size.y, texel_size.y, texel_size.y), V4(eq.x, eq.y, -eq.z, -eq.w));
+    offset = V2(x, y);
+  }
+  v4 v = velocity_uv.sample_nearest(uv + offset);
+  return V2(v.x, v.y);
+}
+
+static void pass_taa_jasmine(Ctx* c, int y0, int y1) {  // taa.wgsl:75-170
+  Tex output = tex(c, HK_BUF_TAA_OUTPUT), previous_render = tex(c, HK_BUF_PREVIOUS_TAA_OUTPUT);
+  Tex render = tex(c, c->upscale_kind == HK_UPSCALE_SMAA_TU4X ? HK_BUF_UPSCALE_OUTPUT : HK_BUF_TONE_MAPPED);  // post_process.rs:1010-1013
+  Tex position = tex(c, HK_BUF_POSITION), velocity_uv = tex(c, HK_BUF_VELOCITY_UV);
+  Tex previous_position = tex(c, HK_BUF_PREVIOUS_POSITION), previous_velocity_uv = tex(c, HK_BUF_PREVIOUS_VELOCITY_UV);
+  const v2 size = V2((float)output.w, (float)output.h);
+  const v2 texel_size = V2(1.0f / size.x, 1.0f / size.y);
+  const v2 render_texel = V2(1.0f / (float)render.w, 1.0f / (float)render.h);
+  const float blend = 0.1f / c->frame.upscale_ratio;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y)
+    for (int x = 0; x < output.w; ++x) {
+      v2 uv = V2(((float)x + 0.5f) / size.x, ((float)y + 0.5f) / size.y);
+      v4 original_color = render.sample_nearest(uv);
+      v3 current_color = rgb(original_color);
+      v2 velocity = nearest_velocity(position, velocity_uv, uv, render_texel);
+      v2 previous_uv = uv - velocity;
+      bool boundary_miss = fabsf(previous_uv.x - 0.5f) > 0.5f || fabsf(previous_uv.y - 0.5f) > 0.5f;
+      v2 uv_biases[5] = {V2(0.0f, 0.0f), V2(1.5f, 1.5f) * texel_size, V2(-1.5f, 1.5f) * texel_size, V2(1.5f, -1.5f) * texel_size,
+                         V2(-1.5f, -1.5f) * texel_size};
+      v4 current_position_depth = position.sample_nearest(uv);
+      bool has_content = current_position_depth.w > 0.0f;
+      bool depth_miss = current_position_depth.w == 0.0f;
+      bool position_miss = current_position_depth.w == 0.0f;
+      for (int i = 0; i < 5; ++i) {
+        v4 previous_depths = previous_position.gather(3, previous_uv + uv_biases[i]);
+        v4 depth_ratio = depth_ratio4(current_position_depth.w, previous_depths);
+        has_content = has_content || any_gt(previous_depths, 0.0f);
+        depth_miss = depth_miss || any_lt(depth_ratio, 0.95f);
+        v3 pp = xyz(previous_position.sample_nearest(previous_uv + uv_biases[i]));
+        position_miss = position_miss || distance3(xyz(current_position_depth), pp) > 0.5f;
+      }
+      if (!has_content) {
+        output.store_f16x4(x, y, P4(c->frame.clear_color));
+        continue;
+      }
+      v4 pv = previous_velocity_uv.sample_nearest(previous_uv);
+      bool velocity_miss = distance2(velocity, V2(pv.x, pv.y)) > 0.00005f;
+      // 5-tap Catmull-Rom reprojection, taa.wgsl:127-144
+      v2 sample_position = (uv - velocity) * size;
+      v2 texel_position_1 = V2(floorf(sample_position.x - 0.5f) + 0.5f, floorf(sample_position.y - 0.5f) + 0.5f);
+      v2 f = sample_position - texel_position_1;
+      auto poly = [](float fx, float a, float b, float cc) { return a + fx * (b + cc * fx); };  // a + f*(b + c*f)
+      v2 w0 = V2(f.x * poly(f.x, -0.5f, 1.0f, -0.5f), f.y * poly(f.y, -0.5f, 1.0f, -0.5f));
+      v2 w1 = V2(1.0f + f.x * f.x * (-2.5f + 1.5f * f.x), 1.0f + f.y * f.y * (-2.5f + 1.5f * f.y));
+      v2 w2 = V2(f.x * poly(f.x, 0.5f, 2.0f, -1.5f), f.y * poly(f.y, 0.5f, 2.0f, -1.5f));
+      v2 w3 = V2(f.x * f.x * (-0.5f + 0.5f * f.x), f.y * f.y * (-0.5f + 0.5f * f.y));
+      v2 w12 = w1 + w2;
+      v2 offset12 = w2 / (w1 + w2);
+      v2 tp0 = (texel_position_1 - 1.0f) * texel_size;
+      v2 tp3 = (texel_position_1 + 2.0f) * texel_size;
+      v2 tp12 = (texel_position_1 + offset12) * texel_size;
+      auto prev = [&](float u, float v) { return clamp01(rgb(previous_render.sample_linear(V2(u, v)))); };  // taa.wgsl:44-47
+      v3 previous_color = V3(0.0f, 0.0f, 0.0f);
+      previous_color = previous_color + prev(tp12.x, tp0.y) * w12.x * w0.y;
+      previous_color = previous_color + prev(tp0.x, tp12.y) * w0.x * w12.y;
+      previous_color = previous_color + prev(tp12.x, tp12.y) * w12.x * w12.y;
+      previous_color = previous_color + prev(tp3.x, tp12.y) * w3.x * w12.y;
+      previous_color = previous_color + prev(tp12.x, tp3.y) * w12.x * w3.y;
+      if (boundary_miss || (position_miss && velocity_miss && depth_miss)) {  // 3x3 YCoCg variance clipping, taa.wgsl:146-164
+        auto smp = [&](v2 p) { return RGB_to_YCoCg(clamp01(rgb(render.sample_nearest(p)))); };  // taa.wgsl:49-52
+        v3 s_tl = smp(uv + V2(-texel_size.x, texel_size.y));
+        v3 s_tm = smp(uv + V2(0.0f, texel_size.y));
+        v3 s_tr = smp(uv + texel_size);
+        v3 s_ml = smp(uv - V2(texel_size.x, 0.0f));
+        v3 s_mm = RGB_to_YCoCg(current_color);
+        v3 s_mr = smp(uv + V2(texel_size.x, 0.0f));
+        v3 s_bl = smp(uv - texel_size);
+        v3 s_bm = smp(uv - V2(0.0f, texel_size.y));
+        v3 s_br = smp(uv + V2(texel_size.x, -texel_size.y));
+        v3 moment_1 = s_tl + s_tm + s_tr + s_ml + s_mm + s_mr + s_bl + s_bm + s_br;
+        v3 moment_2 = (s_tl * s_tl) + (s_tm * s_tm) + (s_tr * s_tr) + (s_ml * s_ml) + (s_mm * s_mm) + (s_mr * s_mr) + (s_bl * s_bl) + (s_bm * s_bm) +
+                      (s_br * s_br);
+        v3 mean = moment_1 / 9.0f;
+        v3 variance = sqrt3((moment_2 / 9.0f) - (mean * mean));
+        previous_color = RGB_to_YCoCg(previous_color);
+        previous_color = clip_towards_aabb_center(previous_color, mean - variance, mean + variance);
+        previous_color = YCoCg_to_RGB(previous_color);
+      }
+      v3 out = mix(previous_color, current_color, blend);  // taa.wgsl:167
+      output.store_f16x4(x, y, V4(out, original_color.w));
+    }
+}
+
+static void pass_smaa_tu4x(Ctx* c, int y0, int y1) {  // smaa.wgsl:81-188; one thread per render pixel = one 2x2 output quad
+  Tex output = tex(c, HK_BUF_UPSCALE_OUTPUT), render = tex(c, HK_BUF_TONE_MAPPED), previous_render = tex(c, HK_BUF_PREVIOUS_TONE_MAPPED);
+  Tex position = tex(c, HK_BUF_POSITION), velocity_uv = tex(c, HK_BUF_VELOCITY_UV), instance_material = tex(c, HK_BUF_INSTANCE_MATERIAL);
+  Tex previous_position = tex(c, HK_BUF_PREVIOUS_POSITION), previous_velocity_uv = tex(c, HK_BUF_PREVIOUS_VELOCITY_UV);
+  const v2 input_size = V2((float)render.w, (float)render.h), output_size = V2((float)output.w, (float)output.h);
+  const v2 texel_size = V2(1.0f / output_size.x, 1.0f / output_size.y);
+  const v2 deferred_texel = V2(1.0f / (float)position.w, 1.0f / (float)position.h);  // smaa.wgsl:55
+  const int current_jitter = (c->frame.number & 1u) == 0u ? 0 : 1;   // smaa.wgsl:75-77
+  const int previous_jitter = (c->frame.number & 1u) == 0u ? 1 : 0;  // smaa.wgsl:79-81
+  const float TAU = 6.283185307f;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y)
+    for (int x = 0; x < render.w; ++x) {
+      v2 uv = V2(((float)x + 0.5f) / input_size.x, ((float)y + 0.5f) / input_size.y);
+      v2 uv_biases[5] = {V2(0.0f, 0.0f), V2(2.5f, 2.5f) * texel_size, V2(-2.5f, 2.5f) * texel_size, V2(2.5f, -2.5f) * texel_size,
+                         V2(-2.5f, -2.5f) * texel_size};
+      const int cox = 2 * x + current_jitter, coy = 2 * y + current_jitter;
+      v3 current_color = rgb(render.sample_nearest(uv));
+      const int pox = 2 * x + previous_jitter, poy = 2 * y + previous_jitter;
+      v2 previous_output_uv = V2(((float)pox + 0.5f) / output_size.x, ((float)poy + 0.5f) / output_size.y);
+      v2 velocity = nearest_velocity(position, velocity_uv, previous_output_uv, deferred_texel);
+      v2 previous_reprojected_uv = previous_output_uv - velocity;
+      v3 previous_color = rgb(previous_render.sample_nearest(previous_reprojected_uv));
+      bool boundary_miss = fabsf(previous_reprojected_uv.x - 0.5f) > 0.5f || fabsf(previous_reprojected_uv.y - 0.5f) > 0.5f;
+      float current_instance = instance_material.sample_nearest_f32x2(previous_output_uv).x;
+      bool instance_miss = false;
+      float current_depth = position.sample_nearest(previous_output_uv).w;
+      bool depth_miss = current_depth == 0.0f;
+      for (int i = 0; i < 5; ++i) {
+        v4 previous_depths = previous_position.gather(3, previous_reprojected_uv + uv_biases[i]);
+        v4 depth_ratio = depth_ratio4(current_depth, previous_depths);
+        bool any_ratio = any_lt(depth_ratio, 0.95f);
+        depth_miss = depth_miss || any_ratio;
+        // the reference samples the CURRENT instance texture here (smaa.wgsl:149)
+        float previous_instance = instance_material.sample_nearest_f32x2(previous_reprojected_uv + uv_biases[i]).x;
+        instance_miss = instance_miss || (any_ratio && fabsf(previous_instance - current_instance) > 1.0f);
+      }
+      v4 pv = previous_velocity_uv.sample_nearest(previous_reprojected_uv);
+      bool velocity_miss = distance2(velocity, V2(pv.x, pv.y)) > 0.0001f;
+      if (boundary_miss || ((depth_miss || instance_miss) && velocity_miss)) {  // 2x2 YCoCg variance clipping, smaa.wgsl:156-184
+        v2 uv_bias = V2(0.0f, 0.0f);
+        float min_ds = 10.0f;
+        for (int i = 0; i < 5; ++i) {
+          v4 ds = position.gather(3, previous_output_uv + uv_biases[i]);
+          v4 d = V4(current_depth - ds.x, current_depth - ds.y, current_depth - ds.z, current_depth - ds.w);
+          float dds = sqrtf(dot(d, d));
+          if (dds < min_ds) uv_bias = uv_biases[i];
+          min_ds = fmin_(min_ds, dds);
+        }
+        v4 cr = render.gather(0, previous_output_uv + uv_bias);
+        v4 cg = render.gather(1, previous_output_uv + uv_bias);
+        v4 cb = render.gather(2, previous_output_uv + uv_bias);
+        v3 s1 = RGB_to_YCoCg(V3(cr.x, cg.x, cb.x));
+        v3 s2 = RGB_to_YCoCg(V3(cr.y, cg.y, cb.y));
+        v3 s3 = RGB_to_YCoCg(V3(cr.z, cg.z, cb.z));
+        v3 s4 = RGB_to_YCoCg(V3(cr.w, cg.w, cb.w));
+        v3 moment_1 = s1 + s2 + s3 + s4;
+        v3 moment_2 = s1 * s1 + s2 * s2 + s3 * s3 + s4 * s4;
+        v3 mean = moment_1 / 4.0f;
+        v3 variance = sqrt3((moment_2 / 4.0f) - (mean * mean));
+        previous_color = RGB_to_YCoCg(previous_color);
+        previous_color = clip_towards_aabb_center(previous_color, mean - variance, mean + variance);
+        previous_color = YCoCg_to_RGB(previous_color);
+      }
+      // sub-pixel velocity blend, smaa.wgsl:186-193
+      v2 sv = V2(fract(velocity.x / (2.0f * texel_size.x)), fract(velocity.y / (2.0f * texel_size.y)));
+      float blend_factor = fmax_(sv.x, sv.y);
+      blend_factor = clamp_(-cos_(blend_factor * TAU), 0.0f, 1.0f);
+      v3 remix_color = rgb(render.sample_linear(previous_output_uv));
+      previous_color = mix(previous_color, remix_color, blend_factor);
+      output.store_f16x4(cox, coy, V4(current_color, 1.0f));
+      output.store_f16x4(pox, poy, V4(previous_color, 1.0f));
+    }
+}
+
+static inline v3 differential_blend_factor(v4 t, v4 b, v4 n, v4 e, v4 s, v4 w) {  // smaa.wgsl:198-222
+  v2 dh = V2(luminance(abs3(rgb(w) - rgb(b))), luminance(abs3(rgb(t) - rgb(e))));
+  v2 dv = V2(luminance(abs3(rgb(t) - rgb(s))), luminance(abs3(rgb(n) - rgb(b))));
+  v2 factor_xy = V2(fmax_(dv.x, 0.001f) * fmax_(dv.y, 0.001f), fmax_(dh.x, 0.001f) * fmax_(dh.y, 0.001f));
+  float factor_z = 1.0f / (factor_xy.x + factor_xy.y);
+  return V3(factor_xy.x, factor_xy.y, factor_z);
+}
+static inline v4 differential_blend(v4 t, v4 b, v4 l, v4 r, v3 factor) {  // smaa.wgsl:224-235
+  v4 color = V4(0.0f, 0.0f, 0.0f, 0.0f);
+  color = color + (l + r) * factor.x;
+  color = color + (t + b) * factor.y;
+  return (0.5f * factor.z) * color;
+}
+static void pass_smaa_tu4x_extrapolate(Ctx* c, int y0, int y1) {  // smaa.wgsl:239-271; in place on upscale_output[0]
+  Tex output = tex(c, HK_BUF_UPSCALE_OUTPUT);
+  const int rw = c->RW;
+  // every thread reads only pixels smaa_tu4x wrote (both diagonals' (0,0)/(1,1) slots) and writes only (0,1)/(1,0)
+  // slots: no thread reads what another writes, so the in-place update is order-independent.
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y)
+    for (int x = 0; x < rw; ++x) {
+      const int bx = 2 * x, by = 2 * y;
+      v4 t_color = output.load_f16x4(bx, by);
+      v4 b_color = output.load_f16x4(bx + 1, by + 1);
+      v4 n_color = output.load_f16x4(bx + 1, by - 1);
+      v4 e_color = output.load_f16x4(bx + 2, by);
+      v4 s_color = output.load_f16x4(bx, by + 2);
+      v4 w_color = output.load_f16x4(bx - 1, by + 1);
+      v3 factor = differential_blend_factor(t_color, b_color, n_color, e_color, s_color, w_color);
+      v4 x_color = differential_blend(t_color, s_color, w_color, b_color, factor);
+      v4 y_color = differential_blend(n_color, b_color, t_color, e_color, factor);
+      output.store_f16x4(bx, by + 1, x_color);
+      output.store_f16x4(bx + 1, by, y_color);
+    }
+}
+
 }  // namespace orc
 
 // ==========================================================================================
@@ -1832,10 +2144,13 @@ int orc_resize(orc_ctx* ctx, uint32_t width, uint32_t height, float upscale_rati
   float scale = 1.0f / ratio;                        // light.rs:318-319
   c.RW = (int)ceilf(scale * (float)width);
   c.RH = (int)ceilf(scale * (float)height);
+  c.UW = (int)ceilf((float)width * (scale * 2.0f));  // post_process.rs:718-722
+  c.UH = (int)ceilf((float)height * (scale * 2.0f));
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
-    size_t n = buf_full_size(b) ? (size_t)c.W * c.H : (size_t)c.RW * c.RH;
+    size_t n = buf_full_size(b) ? (size_t)c.W * c.H : (buf_upscaled(b) ? (size_t)c.UW * c.UH : (size_t)c.RW * c.RH);
     c.buf[b].assign(n * buf_bpp(b), 0);
   }
+  c.mapped_parity = 0;
   return HK_OK;
 }
 int orc_set_view_options(orc_ctx* ctx, uint32_t taa, uint32_t upscale_kind) {
@@ -1851,6 +2166,15 @@ int orc_frame_begin(orc_ctx* ctx, const HkFrame* f, const HkView* v, const HkPre
   ctx->c.pview = *pv;
   ctx->c.lights = *l;
   ctx->c.have_frame = true;
+  // double-buffered planes follow frame.number % 2 (hikari_hip.h, HkBuffer): idempotent per frame number
+  if ((f->number & 1u) != ctx->c.mapped_parity) {
+    Ctx& c = ctx->c;
+    c.buf[HK_BUF_POSITION].swap(c.buf[HK_BUF_PREVIOUS_POSITION]);
+    c.buf[HK_BUF_VELOCITY_UV].swap(c.buf[HK_BUF_PREVIOUS_VELOCITY_UV]);
+    c.buf[HK_BUF_TONE_MAPPED].swap(c.buf[HK_BUF_PREVIOUS_TONE_MAPPED]);
+    c.buf[HK_BUF_TAA_OUTPUT].swap(c.buf[HK_BUF_PREVIOUS_TAA_OUTPUT]);
+    c.mapped_parity = f->number & 1u;
+  }
   return HK_OK;
 }
 static int ready(orc_ctx* ctx) {
@@ -1865,10 +2189,14 @@ int orc_pass_run(orc_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, 
   Ctx& c = ctx->c;
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
   int rows = full_grid ? c.H : c.RH;
+  if (pass == HK_PASS_TAA_JASMINE) { int w; buf_dims(&c, HK_BUF_TAA_OUTPUT, &w, &rows); }
   int y0 = (int)row_begin, y1 = row_end == 0 ? rows : (int)row_end;
   ORC_CHECK(y0 >= 0 && y1 <= rows && y0 <= y1, HK_E_INVALID, "row range");
   switch (pass) {
     case HK_PASS_PREPASS: pass_prepass(&c, y0, y1); break;
+    case HK_PASS_SMAA_TU4X: pass_smaa_tu4x(&c, y0, y1); break;
+    case HK_PASS_SMAA_TU4X_EXTRAPOLATE: pass_smaa_tu4x_extrapolate(&c, y0, y1); break;
+    case HK_PASS_TAA_JASMINE: pass_taa_jasmine(&c, y0, y1); break;
     case HK_PASS_FULL_SCREEN_ALBEDO: pass_full_screen_albedo(&c, y0, y1); break;
     case HK_PASS_DIRECT_LIT: pass_direct_lit(&c, false, y0, y1); break;
     case HK_PASS_DIRECT_EMISSIVE: pass_direct_lit(&c, true, y0, y1); break;
@@ -1934,6 +2262,17 @@ int orc_frame_stage_rows(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uin
     }
     pass_tone_mapping(&c, st->denoise != 0, b0, b1);
     c.stats.frames++;
+  } else if (stage == HK_STAGE_ANTIALIAS) {  // post_process.rs:1236-1272
+    ORC_CHECK(c.band_count == 1 && b0 == 0 && b1 == c.RH, HK_E_UNSUPPORTED, "the antialias stage runs on the whole image");
+    if (st->upscale_kind == HK_UPSCALE_SMAA_TU4X) {
+      pass_smaa_tu4x(&c, 0, c.RH);
+      pass_smaa_tu4x_extrapolate(&c, 0, c.RH);
+    }
+    if (st->taa == HK_TAA_JASMINE) {
+      int w, h;
+      buf_dims(&c, HK_BUF_TAA_OUTPUT, &w, &h);
+      pass_taa_jasmine(&c, 0, h);
+    }
   } else {
     ORC_CHECK(false, HK_E_INVALID, "unknown stage");
   }
@@ -1959,38 +2298,45 @@ int orc_frame_stage(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uint32_t
 int orc_frame_render(orc_ctx* ctx, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   int rc = orc_frame_begin(ctx, f, v, pv, l);
   if (rc) return rc;
-  for (uint32_t s = 0; s < HK_STAGE_COUNT; ++s) {
+  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) {
     rc = orc_frame_stage(ctx, s, st, flags);
     if (rc) return rc;
   }
+  if (flags & HK_FRAME_ANTIALIAS) return orc_frame_stage(ctx, HK_STAGE_ANTIALIAS, st, flags);
   return HK_OK;
 }
 int orc_frame_wait(orc_ctx* ctx) { (void)ctx; return HK_OK; }
+static size_t logical_bytes(const Ctx* c, uint32_t buffer) {
+  int w, h;
+  buf_dims(c, buffer, &w, &h);
+  return (size_t)w * h * buf_bpp(buffer);
+}
 
 int orc_buffer_info(orc_ctx* ctx, uint32_t buffer, uint32_t* w, uint32_t* h, uint32_t* bpp) {
   ORC_CHECK(ctx && buffer < HK_BUF_COUNT && buf_bpp(buffer), HK_E_INVALID, "buffer id");
-  bool full = buf_full_size(buffer);
-  if (w) *w = (uint32_t)(full ? ctx->c.W : ctx->c.RW);
-  if (h) *h = (uint32_t)(full ? ctx->c.H : ctx->c.RH);
+  int bw, bh;
+  buf_dims(&ctx->c, buffer, &bw, &bh);
+  if (w) *w = (uint32_t)bw;
+  if (h) *h = (uint32_t)bh;
   if (bpp) *bpp = (uint32_t)buf_bpp(buffer);
   return HK_OK;
 }
 int orc_read_buffer(orc_ctx* ctx, uint32_t buffer, void* dst, size_t bytes) {
   ORC_CHECK(ctx && dst && buffer < HK_BUF_COUNT, HK_E_INVALID, "argument");
-  ORC_CHECK(bytes == ctx->c.buf[buffer].size(), HK_E_INVALID, "size mismatch");
+  ORC_CHECK(bytes == logical_bytes(&ctx->c, buffer), HK_E_INVALID, "size mismatch");
   memcpy(dst, ctx->c.buf[buffer].data(), bytes);
   return HK_OK;
 }
 int orc_write_buffer(orc_ctx* ctx, uint32_t buffer, const void* src, size_t bytes) {
   ORC_CHECK(ctx && src && buffer < HK_BUF_COUNT, HK_E_INVALID, "argument");
-  ORC_CHECK(bytes == ctx->c.buf[buffer].size(), HK_E_INVALID, "size mismatch");
+  ORC_CHECK(bytes == logical_bytes(&ctx->c, buffer), HK_E_INVALID, "size mismatch");
   memcpy(ctx->c.buf[buffer].data(), src, bytes);
   return HK_OK;
 }
 int orc_device_ptr(orc_ctx* ctx, uint32_t buffer, void** ptr, size_t* bytes) {  // host pointer (the oracle's "device" is the CPU)
   ORC_CHECK(ctx && ptr && buffer < HK_BUF_COUNT, HK_E_INVALID, "argument");
   *ptr = ctx->c.buf[buffer].data();
-  if (bytes) *bytes = ctx->c.buf[buffer].size();
+  if (bytes) *bytes = logical_bytes(&ctx->c, buffer);
   return HK_OK;
 }
 int orc_get_stats(orc_ctx* ctx, HkStats* out) {

@@ -17,12 +17,16 @@ for _i in range(10):
     ALL_BUFFERS[F.BUF_RESERVOIR0 + _i] = f"reservoir{_i}"
 for _i in range(4):
     ALL_BUFFERS[F.BUF_DENOISE_INTERNAL0 + _i] = f"internal{_i}"
+ALL_BUFFERS.update({F.BUF_PREVIOUS_POSITION: "previous_position", F.BUF_PREVIOUS_VELOCITY_UV: "previous_velocity_uv",
+                    F.BUF_PREVIOUS_TONE_MAPPED: "previous_tone_mapped", F.BUF_UPSCALE_OUTPUT: "upscale_output",
+                    F.BUF_TAA_OUTPUT: "taa_output", F.BUF_PREVIOUS_TAA_OUTPUT: "previous_taa_output"})
 
 
 class Case:
-    def __init__(self, name, scene, camera, settings, lights=None, frames=(1, 2, 3, 4)):
+    def __init__(self, name, scene, camera, settings, lights=None, frames=(1, 2, 3, 4), antialias=False):
         self.name, self.scene, self.camera, self.settings, self.frames = name, scene, camera, settings, list(frames)
         self.lights = lights or hk.lights_uniform()
+        self.antialias = antialias   # also run the SMAA Tu4x / TAA dispatches of PostProcessNode::run
 
 
 _CACHE = {}
@@ -83,16 +87,22 @@ def make_case(name):
         scene, sun = yard_textured_scene()
         return Case(name, scene, synthetic_camera(96, 72), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0),
                     lights=hk.lights_uniform(directional=sun), frames=range(1, 6))
+    if name == "cornell_aa_default":   # the reference's default settings end to end: ratio 2, SMAA Tu4x to the window size, TAA
+        return Case(name, cornell_scene(), hk.cornell_camera(120, 88), S(indirect_bounces=2), frames=range(1, 7), antialias=True)
+    if name == "yard_aa_smaa2x":       # SMAA Tu4x at ratio 1 (2x the window) + TAA on the textured yard with a sun
+        scene, sun = yard_textured_scene()
+        return Case(name, scene, synthetic_camera(80, 56), S(indirect_bounces=1, upscale=U.SMAA_TU_1_0), lights=hk.lights_uniform(directional=sun),
+                    frames=range(1, 6), antialias=True)
     raise KeyError(name)
 
 
-CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5"]
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5", "cornell_aa_default", "yard_aa_smaa2x"]
 
 
 def run_case(plugin, case, on_frame=None):
     plugin.set_scene(case.scene)
     for n in case.frames:
-        plugin.render(case.camera, case.settings, lights=case.lights, frame_number=n)
+        plugin.render(case.camera, case.settings, lights=case.lights, frame_number=n, antialias=case.antialias)
         if on_frame:
             on_frame(n)
     plugin.engine.wait()

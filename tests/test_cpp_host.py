@@ -46,3 +46,21 @@ def test_cpp_host_renders_the_same_frame_as_the_python_host(tmp_path, by_nodes):
         p.render(hk.cornell_camera(96, 64), s, frame_number=n)
     want = p.engine.read(F.BUF_TONE_MAPPED)
     assert (got == want).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("by_nodes", [False, True])
+def test_cpp_host_antialias_matches_the_python_host(tmp_path, by_nodes):
+    """--antialias: SMAA Tu4x (ratio 2 -> window size) + TAA through the C++ PostProcessNode / hk_frame_render(HK_FRAME_ANTIALIAS)."""
+    raw = tmp_path / "aa.bin"
+    args = ["--size", "96", "64", "--frames", "5", "--bounces", "1", "--ratio", "2.0", "--antialias", "--raw", str(raw)] + (["--by-nodes"] if by_nodes else [])
+    r = run(*args)
+    assert r.returncode == 0, r.stderr
+    assert "output size 96x64" in r.stdout
+    got = np.fromfile(raw, dtype=np.uint16).reshape(64, 96, 4)
+    p = hk.HikariPlugin(device=0)
+    p.set_scene(hk.load_cornell())
+    s = hk.HikariSettings(indirect_bounces=1)
+    for n in range(1, 6):
+        p.render(hk.cornell_camera(96, 64), s, frame_number=n, antialias=True)
+    assert (got == p.engine.read(F.BUF_TAA_OUTPUT)).all()

@@ -87,5 +87,5 @@ def test_nodes_equal_frame_render():
     for p, by_nodes in ((a, False), (b, True)):
         p.set_scene(case.scene)
         for n in case.frames:
-            p.render(case.camera, case.settings, lights=case.lights, frame_number=n, by_nodes=by_nodes)
+            p.render(case.camera, case.settings, lights=case.lights, frame_number=n, by_nodes=by_nodes, antialias=case.antialias)
     assert diff_buffers(snapshot(a), snapshot(b)) == {}

@@ -12,20 +12,20 @@ from bevy_hikari_amd import _ffi as F
 from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
 
 
-def run(name, scene, cam, settings, lights, warm=8, steps=16):
+def run(name, scene, cam, settings, lights, warm=8, steps=16, antialias=False):
     res = {}
     for flags in (0, F.CTX_COUNT_RAYS):
         p = hk.HikariPlugin(device=0, flags=flags)
         p.set_scene(scene)
         for n in range(1, warm + 1):
-            p.render(cam, settings, lights=lights, frame_number=n)
+            p.render(cam, settings, lights=lights, frame_number=n, antialias=antialias)
         p.engine.wait()
         p.engine.reset_stats()
         if flags == 0:
             p.engine.set_timing_mask(0xFFFF)
         t0 = time.perf_counter()
         for n in range(warm + 1, warm + steps + 1):
-            p.render(cam, settings, lights=lights, frame_number=n)
+            p.render(cam, settings, lights=lights, frame_number=n, antialias=antialias)
         p.engine.wait()
         dt = time.perf_counter() - t0
         st = p.engine.stats()
@@ -49,6 +49,11 @@ if __name__ == "__main__":
         scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
         run("4: city-class 3840x2160, 2 bounces, ONE GPU", scene, synthetic_camera(3840, 2160, extent=30.0), hk.HikariSettings(indirect_bounces=2, upscale=U),
             hk.lights_uniform(directional=dict(sun, illuminance=10000.0)))
+    if "aa" in which:   # the reference's full post-process tail on BASELINE config 2: SMAA Tu4x to 3840x2160 + TAA there
+        run("2+aa: cornell 1920x1080 traced, 2 bounces, SMAA Tu4x -> 3840x2160 + TAA", hk.load_cornell(), hk.cornell_camera(1920, 1080),
+            hk.HikariSettings(indirect_bounces=2, upscale=U), hk.lights_uniform(), warm=16, steps=32, antialias=True)
+        run("default settings at a 1920x1080 window: 960x540 traced, SMAA Tu4x -> 1920x1080 + TAA", hk.load_cornell(), hk.cornell_camera(1920, 1080),
+            hk.HikariSettings(indirect_bounces=2), hk.lights_uniform(), warm=16, steps=32, antialias=True)
     if "5" in which:
         run("5: cornell 3840x2160, 8 bounces, emissive+indirect spatial, denoise off", hk.load_cornell(), hk.cornell_camera(3840, 2160),
             hk.HikariSettings(indirect_bounces=8, emissive_spatial_reuse=True, denoise=False, upscale=U), hk.lights_uniform())

@@ -18,7 +18,10 @@ from oracle_lib import oracle_plugin
 
 out_dir = os.path.join(ROOT, "tests", "golden")
 os.makedirs(out_dir, exist_ok=True)
+only = sys.argv[1:]   # optional: regenerate just these cases (npz bytes are not reproducible, so do not rewrite the others)
 for name in CASE_NAMES:
+    if only and name not in only:
+        continue
     case = make_case(name)
     p = oracle_plugin()
     run_case(p, case)
@@ -26,6 +29,9 @@ for name in CASE_NAMES:
     data = {"sha256_" + k: np.frombuffer(hashlib.sha256(v.tobytes()).digest(), dtype=np.uint8) for k, v in snap.items()}
     for k in ("tone_mapped", "denoise_render0", "denoise_render1", "denoise_render2", "render2", "variance2"):
         data[k] = snap[k]
+    if case.antialias:
+        for k in ("upscale_output", "taa_output"):
+            data[k] = snap[k]
     st = p.engine.stats()
     data["rays"] = np.array([st.rays_primary, st.rays_tlas, st.rays_blas], dtype=np.uint64)
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), **data)
