@@ -216,3 +216,51 @@ def synthetic_large(seed=0x5EED0003, n_meshes=40, rings=40, segs=80, n_instances
     scene = b.finish()
     scene.builder = b
     return scene, sun
+
+
+def flight_helmet_scene():
+    """The reference's textured glTF asset (assets/models/FlightHelmet, flattened by
+    tools/make_fixtures.py: 6 meshes, 94 722 triangles, base-colour + occlusion/roughness/metal
+    textures at 256^2) on a ground slab under one emissive quad and a sun.  Materials are what
+    bevy_gltf 0.9.1 builds: factors, texture ids, reflectance 0.5; glTF samplers are linear + repeat.
+    Returns (SceneData with .textures, sun dict, Camera factory)."""
+    import os
+
+    from .plugin import ASSETS, Camera, look_at_transform
+
+    d = np.load(os.path.join(ASSETS, "flight_helmet.npz"))
+    b = SceneBuilder()
+    textures = [dict(rgba=d["textures"][i], srgb=bool(d["texture_srgb"][i]), address_u=F.ADDRESS_REPEAT, address_v=F.ADDRESS_REPEAT, linear=True)
+                for i in range(len(d["textures"]))]
+    mats = []
+    for row in d["materials"]:
+        m = standard_material(tuple(row[:4]), (0, 0, 0), float(row[4]), float(row[5]), 0.5)
+        m.base_color_texture, m.metallic_roughness_texture, m.occlusion_texture = int(row[6]), int(row[7]), int(row[8])
+        mats.append(b.add_material(m))
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for inst in d["instances"]:
+        k = int(inst[0])
+        mesh = b.add_mesh(d[f"mesh{k}_positions"], d[f"mesh{k}_normals"], d[f"mesh{k}_uvs"], d[f"mesh{k}_indices"])
+        b.add_instance(mesh, mats[int(d[f"mesh{k}_material"][0])], inst[1:17])
+        t = inst[1:17].reshape(4, 4).T
+        p = d[f"mesh{k}_positions"] @ t[:3, :3].T + t[:3, 3]
+        lo, hi = np.minimum(lo, p.min(axis=0)), np.maximum(hi, p.max(axis=0))
+    centre, extent = 0.5 * (lo + hi), float((hi - lo).max())
+    ground = b.add_material(standard_material((0.55, 0.55, 0.6, 1.0), (0, 0, 0), 0.7, 0.0, 0.5))
+    lamp = b.add_material(standard_material((0.8, 0.8, 0.8, 1.0), (1.0, 0.95, 0.85), 1.0, 0.0, 0.5))
+    box = b.add_mesh(*_box())
+    qp, qn, quv = _quad_strip(2)
+    quad = b.add_mesh(qp, qn, quv, None, F.TOPOLOGY_TRIANGLE_STRIP)
+    b.add_instance(box, ground, _trs((centre[0], lo[1] - 0.05 * extent, centre[2]), (0, 0, 0), (4 * extent, 0.1 * extent, 4 * extent)))
+    b.add_instance(quad, lamp, _trs((centre[0] + 0.4 * extent, hi[1] + 0.6 * extent, centre[2] + 0.5 * extent), (math.pi, 0.3, 0.0),
+                                    (0.6 * extent, 1.0, 0.6 * extent)))
+    scene = b.finish()
+    scene.textures = textures
+    scene.builder = b
+    sun = dict(color=(1.0, 0.96, 0.9), illuminance=15000.0, direction_to_light=(0.4, 0.8, 0.5))
+
+    def camera(width, height):
+        eye = (centre[0] + 0.9 * extent, centre[1] + 0.35 * extent, centre[2] + 1.5 * extent)
+        return Camera(look_at_transform(eye, tuple(centre)), width, height)
+
+    return scene, sun, camera

@@ -93,10 +93,18 @@ def make_case(name):
         scene, sun = yard_textured_scene()
         return Case(name, scene, synthetic_camera(80, 56), S(indirect_bounces=1, upscale=U.SMAA_TU_1_0), lights=hk.lights_uniform(directional=sun),
                     frames=range(1, 6), antialias=True)
+    if name == "flight_helmet":        # the reference's textured glTF asset: 94 722 triangles, 10 textures
+        if "helmet" not in _CACHE:
+            from bevy_hikari_amd.scenes import flight_helmet_scene
+
+            _CACHE["helmet"] = flight_helmet_scene()
+        scene, sun, camera = _CACHE["helmet"]
+        return Case(name, scene, camera(96, 96), S(indirect_bounces=2, upscale=U.SMAA_TU_1_0), lights=hk.lights_uniform(directional=sun),
+                    frames=range(1, 5))
     raise KeyError(name)
 
 
-CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5", "cornell_aa_default", "yard_aa_smaa2x"]
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5", "cornell_aa_default", "yard_aa_smaa2x", "flight_helmet"]
 
 
 def run_case(plugin, case, on_frame=None):

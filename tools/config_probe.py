@@ -54,6 +54,12 @@ if __name__ == "__main__":
             hk.HikariSettings(indirect_bounces=2, upscale=U), hk.lights_uniform(), warm=16, steps=32, antialias=True)
         run("default settings at a 1920x1080 window: 960x540 traced, SMAA Tu4x -> 1920x1080 + TAA", hk.load_cornell(), hk.cornell_camera(1920, 1080),
             hk.HikariSettings(indirect_bounces=2), hk.lights_uniform(), warm=16, steps=32, antialias=True)
+    if "helmet" in which:   # the reference's textured glTF asset: 94 722 triangles in 6 BLAS, 10 textures
+        from bevy_hikari_amd.scenes import flight_helmet_scene
+
+        scene, sun, camera = flight_helmet_scene()
+        run("FlightHelmet 1920x1080, 2 bounces, textured", scene, camera(1920, 1080), hk.HikariSettings(indirect_bounces=2, upscale=U),
+            hk.lights_uniform(directional=sun))
     if "5" in which:
         run("5: cornell 3840x2160, 8 bounces, emissive+indirect spatial, denoise off", hk.load_cornell(), hk.cornell_camera(3840, 2160),
             hk.HikariSettings(indirect_bounces=8, emissive_spatial_reuse=True, denoise=False, upscale=U), hk.lights_uniform())

@@ -15,6 +15,9 @@ Outputs (committed):
       plain arrays: per mesh positions/normals/uvs/indices, per node the world transform,
       per material the glTF factors.  No reference *source code* is copied - these are the
       reference's data assets, which a drop-in for the path has to consume unchanged.
+  bevy-hikari_amd/assets/flight_helmet.npz
+      assets/models/FlightHelmet: the reference's textured glTF asset, geometry
+      unchanged, textures box-filtered to 256^2.
 """
 import json
 import os
@@ -175,6 +178,79 @@ def make_cornell_bin():
     print("cornell.hkscene:", len(out), "bytes")
 
 
+def make_flight_helmet(tex_size=256):
+    """assets/models/FlightHelmet (glTF + .bin + 2048^2 PNGs) -> bevy-hikari_amd/assets/flight_helmet.npz.
+    Geometry is kept as is (6 single-primitive meshes, 46 k triangles, u16 indices widened to u32);
+    the base-colour (sRGB) and occlusion/roughness/metal (linear) images are box-filtered to
+    tex_size^2 RGBA8 to keep the fixture small; normal maps are dropped (the reference binds them but
+    never samples them in the light passes).  Material = what bevy_gltf 0.9.1 load_material produces:
+    base_color / metallic / roughness factors (defaults 1), textures by index, reflectance 0.5."""
+    from PIL import Image
+
+    base = os.path.join(REF, "assets", "models", "FlightHelmet")
+    j = json.load(open(os.path.join(base, "FlightHelmet.gltf")))
+    blob = open(os.path.join(base, j["buffers"][0]["uri"]), "rb").read()
+
+    def accessor(i):
+        a = j["accessors"][i]
+        bv = j["bufferViews"][a["bufferView"]]
+        fmt, n = _COMP[a["componentType"]], _NCOMP[a["type"]]
+        start = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        stride = bv.get("byteStride", 0)
+        assert stride in (0, n * np.dtype(fmt).itemsize), "interleaved views are not expected in this asset"
+        arr = np.frombuffer(blob, dtype="<" + fmt, count=a["count"] * n, offset=start)
+        return arr.reshape(a["count"], n) if n > 1 else arr
+
+    out = {}
+    images, image_index = [], {}
+
+    def image(tex_idx, srgb):
+        src = j["textures"][tex_idx]["source"]
+        if src not in image_index:
+            im = Image.open(os.path.join(base, j["images"][src]["uri"])).convert("RGBA")
+            im = im.resize((tex_size, tex_size), Image.BOX)
+            image_index[src] = len(images)
+            images.append((np.asarray(im, dtype=np.uint8), srgb, j["images"][src]["uri"]))
+        return image_index[src]
+
+    mats = []
+    for m in j["materials"]:
+        pbr = m.get("pbrMetallicRoughness", {})
+        mats.append(list(pbr.get("baseColorFactor", [1, 1, 1, 1])) + [pbr.get("roughnessFactor", 1.0), pbr.get("metallicFactor", 1.0),
+                    image(pbr["baseColorTexture"]["index"], True), image(pbr["metallicRoughnessTexture"]["index"], False),
+                    image(m["occlusionTexture"]["index"], False)])
+    out["materials"] = np.asarray(mats, dtype=np.float32)  # base rgba, roughness, metallic, base tex, metallic-roughness tex, occlusion tex
+    out["textures"] = np.stack([im for im, _, _ in images])
+    out["texture_srgb"] = np.asarray([s for _, s, _ in images], dtype=np.uint8)
+    instances = []
+
+    def walk(idx, parent):
+        n = j["nodes"][idx]
+        world = parent @ node_local(n)
+        if "mesh" in n:
+            instances.append([n["mesh"]] + world.T.astype(np.float32).reshape(-1).tolist())
+        for c in n.get("children", []):
+            walk(c, world)
+
+    for root in j["scenes"][j.get("scene", 0)]["nodes"]:
+        walk(root, np.eye(4))
+    out["instances"] = np.asarray(instances, dtype=np.float32)  # mesh id, 16 floats column-major
+    ntri = 0
+    for k, m in enumerate(j["meshes"]):
+        assert len(m["primitives"]) == 1
+        p = m["primitives"][0]
+        assert p.get("mode", 4) == 4
+        out[f"mesh{k}_positions"] = accessor(p["attributes"]["POSITION"]).astype(np.float32)
+        out[f"mesh{k}_normals"] = accessor(p["attributes"]["NORMAL"]).astype(np.float32)
+        out[f"mesh{k}_uvs"] = accessor(p["attributes"]["TEXCOORD_0"]).astype(np.float32)
+        out[f"mesh{k}_indices"] = accessor(p["indices"]).astype(np.uint32)
+        out[f"mesh{k}_material"] = np.asarray([p["material"]], dtype=np.uint32)
+        ntri += len(out[f"mesh{k}_indices"]) // 3
+    path = os.path.join(OUT, "flight_helmet.npz")
+    np.savez_compressed(path, **out)
+    print(f"flight_helmet: {len(j['meshes'])} meshes, {ntri} tris, {len(images)} textures {tex_size}^2, {os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present; fixtures are already committed")
@@ -182,3 +258,4 @@ if __name__ == "__main__":
     make_noise()
     make_cornell()
     make_cornell_bin()
+    make_flight_helmet()
