@@ -131,6 +131,7 @@ struct hk_ctx {
   // screen-space resources
   int W = 0, H = 0, RW = 0, RH = 0;
   int UW = 0, UH = 0;           // SMAA Tu4x output size, ceil(size * 2 / ratio) (post_process.rs:718-722)
+  bool uv_fast = false;         // (k + 0.5) / size certified for div_by() on all four sizes (certify_uv_division)
   uint32_t mapped_parity = 0;   // frame parity whose planes the non-PREVIOUS ids of the double-buffered set name
   float ratio = 1.0f;
   void* buf[HK_BUF_COUNT] = {};
@@ -181,6 +182,19 @@ size_t buffer_logical_bytes(const hk_ctx* c, uint32_t b) {
   int w, h;
   buffer_dims(c, b, &w, &h);
   return (size_t)w * h * buffer_bpp(b);
+}
+
+// The kernels take (k + 0.5) / size - pixel centre to uv, utils.wgsl:36-38, and the primary-ray NDC - through
+// q = x * RN(1/size) plus one exact-residual correction (hk_device.hpp div_by) when this returns true: every
+// numerator the kernels can form (pixel coordinates, spiral taps up to 20 px and a-trous taps up to 8 px beyond
+// the edge) is compared with the IEEE quotient here, with the same three operations the device executes.
+bool certify_uv_division(int size) {
+  const float b = (float)size, c = 1.0f / b;
+  for (int k = -64; k < size + 64; ++k) {
+    const float x = (float)k + 0.5f, want = x / b, q = x * c, got = fmaf(fmaf(-q, b, x), c, q);
+    if (memcmp(&want, &got, 4) != 0) return false;
+  }
+  return true;
 }
 
 int free_screen(hk_ctx* c) {
@@ -581,6 +595,8 @@ DFrame make_dframe(const hk_ctx* c) {
   f.amb_r = c->lights.ambient_color[0]; f.amb_g = c->lights.ambient_color[1]; f.amb_b = c->lights.ambient_color[2];
   f.clear_r = h.clear_color[0]; f.clear_g = h.clear_color[1]; f.clear_b = h.clear_color[2]; f.clear_a = h.clear_color[3];
   f.dw = c->W; f.dh = c->H; f.rw = c->RW; f.rh = c->RH;
+  f.inv_dw = 1.0f / (float)c->W; f.inv_dh = 1.0f / (float)c->H; f.inv_rw = 1.0f / (float)c->RW; f.inv_rh = 1.0f / (float)c->RH;
+  f.uv_fast = c->uv_fast ? 1u : 0u;
   return f;
 }
 GBuffer make_gbuffer(const hk_ctx* c) {
@@ -967,6 +983,7 @@ int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
     HK_HIP(hipMemset(c->dn_extra_var[k], 0, nr * 4));
   }
   c->derived_dirty = false;
+  c->uv_fast = !(c->flags & HK_CTX_PLAIN_DIVISION) && certify_uv_division(c->W) && certify_uv_division(c->H) && certify_uv_division(c->RW) && certify_uv_division(c->RH);
   HK_HIP(hipDeviceSynchronize());
   return HK_OK;
 }
@@ -1202,8 +1219,8 @@ int hk_reset_stats(hk_ctx* c) {
 }
 
 int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float* out, size_t n) {
-  HK_REQUIRE(c && x && out && op <= 19, HK_E_INVALID, "bad argument");
-  const size_t xin = (op >= 16 ? 16 : 1) * n;
+  HK_REQUIRE(c && x && out && op <= 20, HK_E_INVALID, "bad argument");
+  const size_t xin = (op >= 16 && op <= 19 ? 16 : 1) * n;
   if (n == 0) return HK_OK;
   HK_HIP(hipSetDevice(c->device));
   float *dx = nullptr, *dy = nullptr, *dout = nullptr;

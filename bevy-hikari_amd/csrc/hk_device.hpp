@@ -94,6 +94,11 @@ struct DFrame {
   float amb_r, amb_g, amb_b;
   float clear_r, clear_g, clear_b, clear_a;
   int dw, dh, rw, rh;         // deferred (full) size, scaled render size
+  // 1/size as the host's IEEE division gives it, and whether (k + 0.5) / size may be taken through
+  // div_by() for every pixel coordinate k in [-64, size + 64): hk_resize checks ALL of them against the
+  // IEEE quotient (context.hip certify_uv_division), so the flag only selects a cheaper route to the same bits
+  float inv_dw, inv_dh, inv_rw, inv_rh;
+  uint32_t uv_fast;
 };
 struct PackedReservoir {  // light.wgsl:35-43
   uint2 radiance;
@@ -151,7 +156,17 @@ HKD f2 clip_to_uv(f4 clip) {
   uv.y = 1.0f - uv.y;
   return uv;
 }
+// x / b through c = RN(1/b): q = x * c, then one correction with the exact residual.  Correctly rounded for the
+// operands it is certified for (see DFrame::uv_fast); 3 VALU instead of the ~11 of the IEEE division sequence.
+HKD float div_by(float x, float b, float c) {
+  const float q = x * c;
+  return fmaf(fmaf(-q, b, x), c, q);
+}
 HKD f2 coords_to_uv(int cx, int cy, int sx, int sy) { return F2(((float)cx + 0.5f) / (float)sx, ((float)cy + 0.5f) / (float)sy); }
+HKD f2 coords_to_uv(const DFrame& fr, int cx, int cy) {  // utils.wgsl:36-38 on the scaled render size
+  if (fr.uv_fast) return F2(div_by((float)cx + 0.5f, (float)fr.rw, fr.inv_rw), div_by((float)cy + 0.5f, (float)fr.rh, fr.inv_rh));
+  return coords_to_uv(cx, cy, fr.rw, fr.rh);
+}
 HKD mat3 normal_basis(f3 n) {
   float s = fmin_(sign_(n.z) * 2.0f + 1.0f, 1.0f);
   float u = -1.0f / (s + n.z);
@@ -678,8 +693,8 @@ HKD int wrap_coord(int i, int n, uint32_t mode) {
 HKD f4 texel(const DScene& sc, uint4 ti, int x, int y) {
   const uint32_t t = sc.tex_data[ti.x + (uint32_t)y * ti.y + (uint32_t)x];
   const uint32_t r = t & 0xffu, g = (t >> 8) & 0xffu, b = (t >> 16) & 0xffu, a = t >> 24;
-  if (ti.w & 1u) return F4(sc.srgb_lut[r], sc.srgb_lut[g], sc.srgb_lut[b], (float)a / 255.0f);
-  return F4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
+  if (ti.w & 1u) return F4(sc.srgb_lut[r], sc.srgb_lut[g], sc.srgb_lut[b], unorm8(a));
+  return F4(unorm8(r), unorm8(g), unorm8(b), unorm8(a));
 }
 HKD f4 mix4(f4 a, f4 b, float t) { return F4(mix(a.x, b.x, t), mix(a.y, b.y, t), mix(a.z, b.z, t), mix(a.w, b.w, t)); }
 HKD f4 sample_texture(const DScene& sc, uint32_t id, f2 uv) {
@@ -819,7 +834,7 @@ HKD f3 env_brdf(f3 V, f3 N, const Surface& surface) {  // light.wgsl:890-908
 
 // ------------------------------------------------------------------ deferred addressing
 HKD f2 jittered_deferred_uv(const DFrame& fr, f2 uv, float amount) {  // light.wgsl:1007-1011 (0.25) / denoise.wgsl:37-41 (0.5)
-  f2 texel_size = F2(1.0f / (float)fr.dw, 1.0f / (float)fr.dh);
+  f2 texel_size = F2(fr.inv_dw, fr.inv_dh);
   float ratio = fr.upscale_ratio - 1.0f;
   float sgn = ((fr.number & 1u) == 0u) ? -amount : amount;
   return uv + sgn * texel_size * ratio;
@@ -840,7 +855,7 @@ HKD f4 noise_fetch(const DScene& sc, int x, int y, uint32_t n) {  // light.wgsl:
   float fx = ((float)x + (float)n + 0.5f) / 64.0f, fy = ((float)y + (float)n + 0.5f) / 64.0f;
   int tx = (int)floorf(fract(fx) * 64.0f) & 63, ty = (int)floorf(fract(fy) * 64.0f) & 63;
   uint32_t t = sc.noise[(noise_id * 64u + (uint32_t)ty) * 64u + (uint32_t)tx];
-  return F4((float)(t & 0xffu) / 255.0f, (float)((t >> 8) & 0xffu) / 255.0f, (float)((t >> 16) & 0xffu) / 255.0f, (float)(t >> 24) / 255.0f);
+  return F4(unorm8(t), unorm8(t >> 8), unorm8(t >> 16), unorm8(t >> 24));
 }
 
 }  // namespace hkd

@@ -228,10 +228,22 @@ HKD uint32_t pack2x16float(float x, float y) { return (uint32_t)f32_to_f16(x) | 
 HKD f2 unpack2x16float(uint32_t u) { return {f16_to_f32((uint16_t)(u & 0xffffu)), f16_to_f32((uint16_t)(u >> 16))}; }
 HKD uint32_t unorm16(float x) { return (uint32_t)floorf(0.5f + 65535.0f * clamp_(x, 0.0f, 1.0f)); }
 HKD uint32_t pack2x16unorm(float x, float y) { return unorm16(x) | (unorm16(y) << 16); }
-HKD f2 unpack2x16unorm(uint32_t u) { return {(float)(u & 0xffffu) / 65535.0f, (float)(u >> 16) / 65535.0f}; }
+// x / B for the integer-valued x of the norm formats (|x| <= 65535): q = x * RN(1/B) followed by one correction
+// with the exact residual, q + fma(-q, B, x) * RN(1/B).  For B = 65535, 127 and 255 this equals the correctly
+// rounded IEEE quotient for EVERY input of the format (checked exhaustively on the host by
+// tests/test_math_contract.py and on the device against the oracle's plain division), at 3 VALU
+// instructions instead of the ~11 of the v_div_scale / v_rcp / v_div_fmas / v_div_fixup sequence.
+template <int B>
+HKD float div_norm(float x) {
+  constexpr float b = (float)B, c = 1.0f / (float)B;
+  const float q = x * c;
+  return fmaf(fmaf(-q, b, x), c, q);
+}
+HKD f2 unpack2x16unorm(uint32_t u) { return {div_norm<65535>((float)(u & 0xffffu)), div_norm<65535>((float)(u >> 16))}; }
 HKD uint32_t snorm8(float x) { return (uint32_t)(int32_t)floorf(0.5f + 127.0f * clamp_(x, -1.0f, 1.0f)) & 0xffu; }
 HKD uint32_t pack4x8snorm(f4 v) { return snorm8(v.x) | (snorm8(v.y) << 8) | (snorm8(v.z) << 16) | (snorm8(v.w) << 24); }
-HKD float unsnorm8(uint32_t b) { return fmax_((float)(int32_t)(int8_t)(uint8_t)b / 127.0f, -1.0f); }
+HKD float unsnorm8(uint32_t b) { return fmax_(div_norm<127>((float)(int32_t)(int8_t)(uint8_t)b), -1.0f); }
+HKD float unorm8(uint32_t b) { return div_norm<255>((float)(b & 0xffu)); }
 HKD f4 unpack4x8snorm(uint32_t u) { return {unsnorm8(u & 0xffu), unsnorm8((u >> 8) & 0xffu), unsnorm8((u >> 16) & 0xffu), unsnorm8(u >> 24)}; }
 HKD uint2 pack_f16x4(f4 v) { return make_uint2(pack2x16float(v.x, v.y), pack2x16float(v.z, v.w)); }
 HKD f4 unpack_f16x4(uint2 u) {

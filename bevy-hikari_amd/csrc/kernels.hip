@@ -74,8 +74,10 @@ struct PrepassParams {
   const float4* prev_models;      // previous model matrix (4 columns) per instance, read where DInstance::moved
 };
 __device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams& pp, float px, float py) {
-  float ndc_x = (px + 0.5f) / (float)fr.dw * 2.0f - 1.0f - pp.jitter_x;
-  float ndc_y = 1.0f - (py + 0.5f) / (float)fr.dh * 2.0f - pp.jitter_y;
+  const float ux = fr.uv_fast ? div_by(px + 0.5f, (float)fr.dw, fr.inv_dw) : (px + 0.5f) / (float)fr.dw;
+  const float uy = fr.uv_fast ? div_by(py + 0.5f, (float)fr.dh, fr.inv_dh) : (py + 0.5f) / (float)fr.dh;
+  float ndc_x = ux * 2.0f - 1.0f - pp.jitter_x;
+  float ndc_y = 1.0f - uy * 2.0f - pp.jitter_y;
   f4 pn = mul(pp.ivp0, pp.ivp1, pp.ivp2, pp.ivp3, F4(ndc_x, ndc_y, 1.0f, 1.0f));
   f3 near_point = xyz(pn) / pn.w;
   Ray ray;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   if (px.valid) {
     const int x = px.x, y = px.y;
     const int index = x + fr.rw * y;
-    const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+    const f2 uv = coords_to_uv(fr, x, y);
     Sample s = zero_sample();
     int dcx, dcy;
     jittered_deferred_coords(fr, uv, &dcx, &dcy);
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
   if (px.valid) {
     const int x = px.x, y = px.y;
     const int index = x + fr.rw * y;
-    const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+    const f2 uv = coords_to_uv(fr, x, y);
     int dcx, dcy;
     jittered_deferred_coords(fr, uv, &dcx, &dcy);
     const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh);
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
 struct SpatialTaps {
   float radius[16], tap_interval[16];
   uint32_t tap_count[16];
+  float march_frac[16][6];  // f32(j) / f32(tap_count + 1), j = 1..tap_count (light.wgsl:1619)
 };
 template <bool EMISSIVE_LIT>
 __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, SpatialTaps taps, int row_begin, int row_end) {
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
   constexpr uint32_t SPATIAL_REUSE_COUNT = EMISSIVE_LIT ? 8u : 16u;
   const int x = px.x, y = px.y;
   const int index = x + fr.rw * y;
-  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  const f2 uv = coords_to_uv(fr, x, y);
   int dcx, dcy;
   jittered_deferred_coords(fr, uv, &dcx, &dcy);
   const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh);
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     const f2 offset = radius * F2(cs, sn);
 
     const int scx = f32_to_i32(offset.x + (float)x), scy = f32_to_i32(offset.y + (float)y);
-    const f2 sample_uv = coords_to_uv(scx, scy, fr.rw, fr.rh);
+    const f2 sample_uv = coords_to_uv(fr, scx, scy);
     if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
     int sdx, sdy;
     jittered_deferred_coords(fr, sample_uv, &sdx, &sdy);
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
       int tdx, tdy;
       jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
       const float tap_depth = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.depth[tdx + fr.dw * tdy] : 0.0f;
-      const float ref_depth = mix(depth, sample_depth, (float)j / (float)(tap_count + 1u));
+      const float ref_depth = mix(depth, sample_depth, taps.march_frac[i - 1u][j - 1u]);
       if (tap_depth > ref_depth + 0.00001f) {
         occluded = true;
         break;
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(256) void k_tone_mapping(DFrame fr, const uint2* __
 __global__ void k_debug_math(uint32_t op, const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float a = (op >= 16) ? 0.0f : x[i], b = y ? y[i] : 0.0f, r = 0.0f;
+  float a = (op >= 16 && op <= 19) ? 0.0f : x[i], b = y ? y[i] : 0.0f, r = 0.0f;
   switch (op) {
     case 0: r = sin_(a); break;
     case 1: r = cos_(a); break;
@@ -649,6 +652,9 @@ __global__ void k_debug_math(uint32_t op, const float* __restrict__ x, const flo
     case 11: r = saturate(a); break;
     case 12: r = clamp_(a, -1.0f, 1.0f); break;
     case 13: r = saturate(a * b); break;
+    case 14: r = unpack2x16unorm(f32_to_u32(a)).x; break;        // decode of the integer a in 0..65535
+    case 15: r = unsnorm8(f32_to_u32(a)); break;                 // a = the byte 0..255
+    case 20: r = unorm8(f32_to_u32(a)); break;                   // a = the byte 0..255
     case 16: case 17: case 18: case 19: {  // shading()/env_brdf() on 16 floats per item: V N L base_color radiance
       const float* q = x + 16 * i;
       DFrame fr;
@@ -738,6 +744,7 @@ void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const D
     taps.radius[i - 1] = radius;
     taps.tap_interval[i - 1] = interval;
     taps.tap_count[i - 1] = (uint32_t)(radius / interval);                 // light.wgsl:1610
+    for (uint32_t j = 1; j <= taps.tap_count[i - 1] && j <= 6u; ++j) taps.march_frac[i - 1][j - 1] = (float)j / (float)(taps.tap_count[i - 1] + 1u);
   }
   if (emissive_lit) hipLaunchKernelGGL(k_spatial_reuse<true>, grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
   else hipLaunchKernelGGL(k_spatial_reuse<false>, grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);

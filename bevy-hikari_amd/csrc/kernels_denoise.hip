@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d,
   const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
   if (!px.valid) return;
   const int x = px.x, y = px.y, index = x + fr.rw * y;
-  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  const f2 uv = coords_to_uv(fr, x, y);
   const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
   int ax, ay, rx, ry;
   nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d,
   for (int ox = -1; ox <= 1; ++ox) {
 #pragma unroll
     for (int oy = -1; oy <= 1; ++oy) {  // call order of denoise.wgsl:152-160: x outer, y inner
-      const f2 sample_uv = uv + F2((float)ox, (float)oy) / F2((float)fr.rw, (float)fr.rh);
+      const f2 sample_uv = uv + F2((float)ox * fr.inv_rw, (float)oy * fr.inv_rh);  // ox, oy in {-1, 0, 1}: +-RN(1/size) or 0, exactly the quotient
       if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
       int sx, sy;
       nearest_coords(sample_uv, fr.rw, fr.rh, &sx, &sy);
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
   if (!px.valid) return;
   constexpr int STEP = 8 >> LEVEL;
   const int x = px.x, y = px.y, index = x + fr.rw * y;
-  const f2 uv = coords_to_uv(x, y, fr.rw, fr.rh);
+  const f2 uv = coords_to_uv(fr, x, y);
   const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
   int dx, dy;
   nearest_coords(deferred_uv, fr.dw, fr.dh, &dx, &dy);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     constexpr int OY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
     const int ox = OX[k], oy = OY[k];
     const int sx = x + ox * STEP, sy = y + oy * STEP;
-    const f2 sample_uv = coords_to_uv(sx, sy, fr.rw, fr.rh);
+    const f2 sample_uv = coords_to_uv(fr, sx, sy);
     if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
     const f2 sample_deferred_uv = jittered_deferred_uv(fr, sample_uv, 0.5f);
     int gx, gy;

@@ -318,9 +318,12 @@ uint32_t hk_abi_version(void);
 const char* hk_last_error(void); /* thread-local description of the last failure */
 int hk_device_count(int* count);
 /* Creates a context on HIP device `device_id`; flags: bit0 = count rays (HK_CTX_COUNT_RAYS),
- * bit1 = time every dispatch with HIP events (HK_CTX_TIME_PASSES). */
+ * bit1 = time every dispatch with HIP events (HK_CTX_TIME_PASSES), bit2 = take every (k + 0.5) / size through
+ * the IEEE division sequence instead of the certified 3-instruction route (HK_CTX_PLAIN_DIVISION; the results
+ * are identical bit for bit, the flag exists so that tests can show it). */
 #define HK_CTX_COUNT_RAYS 1u
 #define HK_CTX_TIME_PASSES 2u
+#define HK_CTX_PLAIN_DIVISION 4u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);
 

@@ -2360,7 +2360,7 @@ int orc_reset_stats(orc_ctx* ctx) {
 int orc_debug_math(orc_ctx* ctx, uint32_t op, const float* x, const float* y, float* out, size_t n) {
   (void)ctx;
   for (size_t i = 0; i < n; ++i) {
-    float a = (op >= 16) ? 0.0f : x[i], b = y ? y[i] : 0.0f, r = 0.0f;
+    float a = (op >= 16 && op <= 19) ? 0.0f : x[i], b = y ? y[i] : 0.0f, r = 0.0f;
     switch (op) {
       case 0: r = sin_(a); break;
       case 1: r = cos_(a); break;
@@ -2376,6 +2376,9 @@ int orc_debug_math(orc_ctx* ctx, uint32_t op, const float* x, const float* y, fl
       case 11: r = saturate(a); break;
       case 12: r = clamp_(a, -1.0f, 1.0f); break;
       case 13: r = saturate(a * b); break;
+      case 14: r = unpack2x16unorm((uint32_t)a).x; break;
+      case 15: r = unsnorm8((uint32_t)a); break;
+      case 20: r = (float)((uint32_t)a & 0xffu) / 255.0f; break;
       case 16: case 17: case 18: case 19: {
         const float* q = x + 16 * i;
         HkLights lights{};

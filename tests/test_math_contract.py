@@ -106,3 +106,35 @@ def test_device_math_bit_exact_vs_oracle(op):
     if not same.all():
         i = np.nonzero(~same)[0][:5]
         raise AssertionError(f"{op}: {(~same).sum()} of {same.size} differ, e.g. x={[a[i] for a in args]} gpu={got[i]} cpu={want[i]}")
+
+
+NORM_OPS = {"unorm16": (14, 65536), "snorm8": (15, 256), "unorm8": (20, 256)}
+
+
+def oracle_norm(op, n):
+    x = np.arange(n, dtype=np.float32)
+    out = np.empty_like(x)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(F.f32))
+    oracle_api().call("debug_math", None, op, fp(x), None, fp(out), x.size)
+    return out
+
+
+def test_oracle_norm_decodes_are_plain_ieee_divisions():
+    """unpack2x16unorm / unpack4x8snorm / the unorm8 texel decode, for EVERY input of the format."""
+    u = np.arange(65536, dtype=np.float32)
+    assert (oracle_norm(14, 65536).view(np.uint32) == (u / np.float32(65535.0)).view(np.uint32)).all()
+    b = np.arange(256).astype(np.uint8).view(np.int8).astype(np.float32)
+    assert (oracle_norm(15, 256).view(np.uint32) == np.maximum(b / np.float32(127.0), np.float32(-1.0)).view(np.uint32)).all()
+    assert (oracle_norm(20, 256).view(np.uint32) == (np.arange(256, dtype=np.float32) / np.float32(255.0)).view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(NORM_OPS))
+def test_device_norm_decodes_exhaustive(name):
+    """The device replaces x / 65535, x / 127, x / 255 by a 3-instruction multiply + exact-residual correction
+    (hk_device_math.hpp div_norm); it must equal the IEEE quotient for every input of the format."""
+    import bevy_hikari_amd as hk
+
+    op, n = NORM_OPS[name]
+    got = hk.Engine(device=0).debug_math(op, np.arange(n, dtype=np.float32))
+    assert (got.view(np.uint32) == oracle_norm(op, n).view(np.uint32)).all()

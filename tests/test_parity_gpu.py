@@ -444,3 +444,24 @@ def test_antialias_kernels_under_motion_on_identical_inputs():
             vel = cpu.engine.read(F.BUF_VELOCITY_UV)[..., :2]
             clipped += int((np.abs(vel).max(axis=2) > 1e-4).sum())
         assert clipped > 1000      # the motion branches really ran
+
+
+def test_certified_division_route_changes_no_bit():
+    """(k + 0.5) / size goes through a multiply + exact-residual correction that hk_resize certifies against
+    the IEEE quotient for every coordinate; HK_CTX_PLAIN_DIVISION forces the IEEE sequence.  Same frames."""
+    case = make_case("cornell_upscale2")
+    snaps = []
+    for flags in (0, F.CTX_PLAIN_DIVISION):
+        p = hk.HikariPlugin(device=0, flags=flags)
+        run_case(p, case)
+        snaps.append(snapshot(p))
+    assert diff_buffers(snaps[0], snaps[1]) == {}
+    odd = hk.HikariPlugin(device=0)          # sizes that are not powers of two or multiples of eight
+    odd.set_scene(case.scene)
+    plain = hk.HikariPlugin(device=0, flags=F.CTX_PLAIN_DIVISION)
+    plain.set_scene(case.scene)
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.3, 0.2))
+    for n in (1, 2, 3):
+        for p in (odd, plain):
+            p.render(hk.cornell_camera(117, 83), s, frame_number=n)
+    assert diff_buffers(snapshot(odd), snapshot(plain)) == {}
