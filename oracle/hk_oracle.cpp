@@ -92,6 +92,8 @@ struct Ctx {
   int W = 0, H = 0;    // full (deferred / albedo / reservoir allocation) size
   int RW = 0, RH = 0;  // scaled render size
   int UW = 0, UH = 0;  // SMAA Tu4x output size, ceil(size * 2 / ratio)
+  uint16_t* step_rec = nullptr;  // orc_debug_record_steps: [RH][RW][slots][3] u16, filled by pass_indirect
+  uint32_t step_slots = 0;
   uint32_t mapped_parity = 0;  // frame parity whose planes the non-PREVIOUS ids of the double-buffered set name
   float ratio = 1.0f;
   std::vector<uint8_t> buf[HK_BUF_COUNT];
@@ -497,6 +499,20 @@ struct Scene {
   const HkView* view;
   const HkLights* lights;
   uint64_t n_tlas = 0, n_blas = 0;  // per-thread ray counters
+  // tools/divergence_model.py: per-ray traversal work (inner-node visits, triangle tests, instance entries)
+  // of the current pixel's rays, in call order; null unless orc_debug_record_steps armed it
+  uint16_t* step_rec = nullptr;
+  uint32_t step_slot = 0, step_slots = 0, step_base = 0;  // slot = 3 * bounce + {0 closest hit, 1 emitter BLAS ray, 2 shadow ray}
+  uint32_t cur_nodes = 0, cur_tris = 0, cur_entries = 0;
+  void step_flush() {
+    if (step_rec && step_slot < step_slots) {
+      step_rec[3 * step_slot] = (uint16_t)std::min(cur_nodes, 65535u);
+      step_rec[3 * step_slot + 1] = (uint16_t)std::min(cur_tris, 65535u);
+      step_rec[3 * step_slot + 2] = (uint16_t)std::min(cur_entries, 65535u);
+    }
+    step_slot++;
+    cur_nodes = cur_tris = cur_entries = 0;
+  }
 };
 static inline v3 P3(const float* p) { return V3(p[0], p[1], p[2]); }
 
@@ -573,6 +589,7 @@ static bool traverse_bottom(Scene& sc, Hit* hit, const Ray& ray, const HkMeshInd
       aabb.min = min3(P3(vertices[0].position), min3(P3(vertices[1].position), P3(vertices[2].position)));
       aabb.max = max3(P3(vertices[0].position), max3(P3(vertices[1].position), P3(vertices[2].position)));
       if (intersects_aabb(ray, aabb) < hit->intersection.distance) {
+        sc.cur_tris++;
         Intersection intersection = intersects_triangle(ray, vertices);
         if (intersection.distance < hit->intersection.distance) {
           hit->intersection = intersection;
@@ -585,6 +602,7 @@ static bool traverse_bottom(Scene& sc, Hit* hit, const Ray& ray, const HkMeshInd
     } else {
       aabb.min = P3(node.min);
       aabb.max = P3(node.max);
+      sc.cur_nodes++;
       index = (intersects_aabb(ray, aabb) < hit->intersection.distance) ? node.entry_index : node.exit_index;
     }
   }
@@ -611,18 +629,21 @@ static Hit traverse_top(Scene& sc, const Ray& ray, float max_distance, float ear
         r.origin = instance_position_world_to_local(instance, ray.origin);
         r.direction = instance_direction_world_to_local(instance, ray.direction);
         r.inv_direction = 1.0f / r.direction;
+        sc.cur_entries++;
         if (traverse_bottom(sc, &hit, r, instance.mesh, early_distance)) {
           hit.instance_index = instance_index;
-          if (hit.intersection.distance < early_distance) return hit;
+          if (hit.intersection.distance < early_distance) { sc.step_flush(); return hit; }
         }
       }
       index = node.exit_index;
     } else {
       aabb.min = P3(node.min);
       aabb.max = P3(node.max);
+      sc.cur_nodes++;
       index = (intersects_aabb(ray, aabb) < hit.intersection.distance) ? node.entry_index : node.exit_index;
     }
   }
+  sc.step_flush();
   return hit;
 }
 static HitInfo empty_hit_info(v3 position, v3 direction) {  // light.wgsl:488-494
@@ -768,7 +789,10 @@ static LightCandidate select_light_candidate(Scene& sc, v4 rand, v3 position, v3
     candidate.direction = ray.direction;
     bool front = dot(candidate.direction, normal) > 0.0f;
     if (front) sc.n_blas++;
-    if (front && traverse_bottom(sc, &hit, r, emissive_instance.mesh, 0.0f)) {
+    sc.step_slot = sc.step_base + 1u;
+    const bool blas_hit = front && traverse_bottom(sc, &hit, r, emissive_instance.mesh, 0.0f);
+    sc.step_flush();
+    if (blas_hit) {
       hit.instance_index = emissive.instance;
       *info = hit_info(sc, ray, hit);
       candidate.max_distance = hit.intersection.distance;
@@ -1331,6 +1355,13 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
     const HkFrame& frame = c->frame;
     for (int x = 0; x < rw; ++x) {
       const int index = x + rw * y;
+      if (c->step_rec) {  // tools/divergence_model.py
+        sc.step_rec = c->step_rec + (size_t)3 * c->step_slots * index;
+        sc.step_slots = c->step_slots;
+        sc.step_slot = 0;
+        sc.cur_nodes = sc.cur_tris = sc.cur_entries = 0;
+        sc.step_base = 0;
+      }
       v2 uv = coords_to_uv(x, y, sz.rw, sz.rh);
       int dcx, dcy;
       jittered_deferred_coords(sc, sz, uv, &dcx, &dcy);
@@ -1373,11 +1404,13 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
         Sample bounce_sample = s;
         v3 color_transport = V3(1.0f, 1.0f, 1.0f);
         for (uint32_t n = 0u; n < frame.indirect_bounces && (color_transport.x > 0.01f || color_transport.y > 0.01f || color_transport.z > 0.01f); n += 1u) {
+          sc.step_base = 3u * n;
           v4 rand_sample = sample_cosine_hemisphere(V2(bounce_sample.random.x, bounce_sample.random.y));
           ray.origin = xyz(bounce_sample.visible_position) + bounce_sample.visible_normal * RAY_BIAS;
           ray.direction = mul(normal_basis(bounce_sample.visible_normal), xyz(rand_sample));
           ray.inv_direction = 1.0f / ray.direction;
 
+          sc.step_slot = sc.step_base;
           hit = traverse_top(sc, ray, F32_MAX, 0.0f, DONT_EXCLUDE);
           info = hit_info(sc, ray, hit);
 
@@ -1405,6 +1438,7 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
               ray.direction = candidate.direction;
               ray.inv_direction = 1.0f / ray.direction;
 
+              sc.step_slot = sc.step_base + 2u;
               hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance);
               occlude_hit_info(ray, hit, &info);
 
@@ -1434,7 +1468,8 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
         ray.direction = mul(normal_basis(s.visible_normal), xyz(rand_sample));
         ray.inv_direction = 1.0f / ray.direction;
 
-        hit = traverse_top(sc, ray, F32_MAX, 0.0f, DONT_EXCLUDE);
+        sc.step_slot = sc.step_base;
+          hit = traverse_top(sc, ray, F32_MAX, 0.0f, DONT_EXCLUDE);
         info = hit_info(sc, ray, hit);
 
         s.sample_position = info.position;
@@ -1452,7 +1487,8 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
             ray.origin = xyz(s.sample_position) + s.sample_normal * RAY_BIAS;
             ray.direction = candidate.direction;
             ray.inv_direction = 1.0f / ray.direction;
-            hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance);
+            sc.step_slot = sc.step_base + 2u;
+              hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance);
             occlude_hit_info(ray, hit, &info);
             v4 in_radiance = input_radiance(sc, ray, info, sample_directional, candidate.emissive_instance, false);
             out_radiance = shading(sc, normalize(xyz(s.visible_position) - xyz(s.sample_position)), s.sample_normal, ray.direction, surface, in_radiance);
@@ -2306,6 +2342,15 @@ int orc_frame_render(orc_ctx* ctx, const HkFrame* f, const HkView* v, const HkPr
   return HK_OK;
 }
 int orc_frame_wait(orc_ctx* ctx) { (void)ctx; return HK_OK; }
+// Measurement hook for tools/divergence_model.py (not part of the mirrored API): while armed, pass_indirect
+// records for every pixel the traversal work of its rays in call order - (inner-node visits, triangle
+// tests, instance entries) per traverse_top call / stand-alone traverse_bottom call.  buf = [RH][RW][slots][3] u16.
+int orc_debug_record_steps(orc_ctx* ctx, uint16_t* buf, uint32_t slots) {
+  ORC_CHECK(ctx, HK_E_INVALID, "null ctx");
+  ctx->c.step_rec = buf;
+  ctx->c.step_slots = buf ? slots : 0;
+  return HK_OK;
+}
 static size_t logical_bytes(const Ctx* c, uint32_t buffer) {
   int w, h;
   buf_dims(c, buffer, &w, &h);
