@@ -155,14 +155,26 @@ def _f32(m):
 
 @dataclass
 class Camera:
-    """Camera3dBundle with bevy's default PerspectiveProjection (fov pi/4, near 0.1, infinite reverse-Z)."""
+    """Camera3dBundle with bevy's default PerspectiveProjection (fov pi/4, near 0.1, infinite reverse-Z), or -
+    with ortho_height - bevy 0.9's OrthographicProjection (ScalingMode::FixedVertical(ortho_height), near 0,
+    far 1000, reverse-Z): the `view.projection[3].w == 1.0` branch of light.wgsl:714-727,1040."""
     transform: list  # column-major 4x4 camera-to-world (16 doubles)
     width: int
     height: int
     fov: float = 0.78539816339744830962
     near: float = 0.1
+    ortho_height: Optional[float] = None
+    ortho_far: float = 1000.0
 
-    def projection(self):  # Mat4::perspective_infinite_reverse_rh
+    def projection(self):  # Mat4::perspective_infinite_reverse_rh / Mat4::orthographic_rh(l, r, b, t, far, near)
+        if self.ortho_height is not None:
+            half_h = 0.5 * self.ortho_height
+            half_w = half_h * float(self.width) / float(self.height)
+            rcp_w, rcp_h, r = 1.0 / (2.0 * half_w), 1.0 / (2.0 * half_h), 1.0 / (self.ortho_far - 0.0)
+            m = [0.0] * 16
+            m[0], m[5], m[10] = 2.0 * rcp_w, 2.0 * rcp_h, r
+            m[12], m[13], m[14], m[15] = 0.0, 0.0, r * self.ortho_far, 1.0
+            return m
         f = 1.0 / math.tan(0.5 * self.fov)
         aspect = float(self.width) / float(self.height)
         m = [0.0] * 16
@@ -171,6 +183,10 @@ class Camera:
 
     def inverse_projection(self):
         p = self.projection()
+        if self.ortho_height is not None:  # diagonal + translation in z
+            m = [0.0] * 16
+            m[0], m[5], m[10], m[14], m[15] = 1.0 / p[0], 1.0 / p[5], 1.0 / p[10], -p[14] / p[10], 1.0
+            return m
         m = [0.0] * 16
         m[0], m[5], m[11], m[14] = 1.0 / p[0], 1.0 / p[5], 1.0 / p[14], -1.0
         return m

@@ -93,6 +93,10 @@ def make_case(name):
         scene, sun = yard_textured_scene()
         return Case(name, scene, synthetic_camera(80, 56), S(indirect_bounces=1, upscale=U.SMAA_TU_1_0), lights=hk.lights_uniform(directional=sun),
                     frames=range(1, 6), antialias=True)
+    if name == "yard_ortho":           # OrthographicProjection: the projection[3].w == 1 branches (light.wgsl:714-727,1040), parallel primary rays
+        scene, sun = yard_scene()
+        cam = hk.Camera(hk.look_at_transform((6.0, 7.0, 8.0), (0.0, 0.5, 0.0)), 88, 64, ortho_height=9.0)
+        return Case(name, scene, cam, S(indirect_bounces=2, upscale=U.SMAA_TU_1_0), lights=hk.lights_uniform(directional=sun), frames=range(1, 5))
     if name == "flight_helmet":        # the reference's textured glTF asset: 94 722 triangles, 10 textures
         if "helmet" not in _CACHE:
             from bevy_hikari_amd.scenes import flight_helmet_scene
@@ -104,7 +108,7 @@ def make_case(name):
     raise KeyError(name)
 
 
-CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5", "cornell_aa_default", "yard_aa_smaa2x", "flight_helmet"]
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5", "cornell_aa_default", "yard_aa_smaa2x", "flight_helmet", "yard_ortho"]
 
 
 def run_case(plugin, case, on_frame=None):
@@ -130,3 +134,27 @@ def diff_buffers(a, b):
             ys, xs = np.nonzero(ne)
             bad[name] = f"{int(ne.sum())} px, first (x={xs[0]}, y={ys[0]}): {x[ys[0], xs[0]]} vs {y[ys[0], xs[0]]}"
     return bad
+
+
+GBUFFER_IDS = (F.BUF_POSITION, F.BUF_NORMAL, F.BUF_DEPTH_GRADIENT, F.BUF_INSTANCE_MATERIAL, F.BUF_VELOCITY_UV)
+
+
+def run_case_with_host_gbuffer(source, plugin, case):
+    """A host that keeps its raster prepass: per frame hk_frame_begin, then the five G-buffer
+    planes written with hk_write_buffer, then hk_frame_render(HK_FRAME_EXTERNAL_GBUFFER).  `source` renders the same
+    frames normally and supplies the planes."""
+    source.set_scene(case.scene)
+    plugin.set_scene(case.scene)
+    s = case.settings
+    for n in case.frames:
+        source.render(case.camera, s, lights=case.lights, frame_number=n, antialias=case.antialias)
+        size = (case.camera.width, case.camera.height, s.upscale.ratio())
+        if plugin._size != size:
+            plugin.engine.resize(*size)
+            plugin._size = size
+        frame, view, pview = hk.frame_uniform(s, n), case.camera.view_uniform(), case.camera.previous_view_uniform()
+        plugin.engine.frame_begin(frame, view, pview, case.lights)        # selects the planes frame n writes
+        for b in GBUFFER_IDS:
+            plugin.engine.write(b, source.engine.read(b))
+        plugin.engine.frame_render(frame, view, pview, case.lights, s.to_c(), F.FRAME_EXTERNAL_GBUFFER | (F.FRAME_ANTIALIAS if case.antialias else 0))
+    plugin.engine.wait()

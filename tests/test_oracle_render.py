@@ -89,3 +89,15 @@ def test_nodes_equal_frame_render():
         for n in case.frames:
             p.render(case.camera, case.settings, lights=case.lights, frame_number=n, by_nodes=by_nodes, antialias=case.antialias)
     assert diff_buffers(snapshot(a), snapshot(b)) == {}
+
+
+@pytest.mark.parametrize("name", ["cornell_upscale2", "cornell_aa_default"])
+def test_host_supplied_gbuffer_gives_the_same_frames(name):
+    """HK_FRAME_EXTERNAL_GBUFFER (a host that keeps its raster prepass): same frames as the internal prepass,
+    including the previous-frame planes the anti-aliasing tail reads."""
+    from cases import run_case_with_host_gbuffer
+
+    case = make_case(name)
+    a, b = oracle_plugin(), oracle_plugin()
+    run_case_with_host_gbuffer(a, b, case)
+    assert diff_buffers(snapshot(a), snapshot(b)) == {}

@@ -465,3 +465,15 @@ def test_certified_division_route_changes_no_bit():
         for p in (odd, plain):
             p.render(hk.cornell_camera(117, 83), s, frame_number=n)
     assert diff_buffers(snapshot(odd), snapshot(plain)) == {}
+
+
+@pytest.mark.parametrize("name", ["cornell_upscale2", "cornell_aa_default"])
+def test_host_supplied_gbuffer_gives_the_same_frames(name):
+    """HK_FRAME_EXTERNAL_GBUFFER on the GPU: G-buffer planes written by the host after hk_frame_begin, the derived
+    planes (depth, packed denoiser taps) rebuilt by k_derive_planes - every buffer as with the internal prepass."""
+    from cases import run_case_with_host_gbuffer
+
+    case = make_case(name)
+    a, b = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0)
+    run_case_with_host_gbuffer(a, b, case)
+    assert diff_buffers(snapshot(a), snapshot(b)) == {}
