@@ -194,10 +194,10 @@ HKD float V_SmithGGXCorrelated(float roughness, float NoV, float NoL) {
   float lambdaL = NoV * sqrtf((NoL - a2 * NoL) * NoL + a2);
   return 0.5f / (lambdaV + lambdaL);
 }
-HKD float F_Schlick(float f0, float f90, float VoH) { return f0 + (f90 - f0) * pow_(1.0f - VoH, 5.0f); }
+HKD float F_Schlick(float f0, float f90, float VoH) { return f0 + (f90 - f0) * pow5_(1.0f - VoH); }
 HKD f3 fresnel(f3 f0, float LoH) {
   float f90 = saturate(dot(f0, F3s(50.0f * 0.33f)));
-  float p = pow_(1.0f - LoH, 5.0f);
+  float p = pow5_(1.0f - LoH);
   return f0 + (F3s(f90) - f0) * p;
 }
 HKD f3 specular(f3 f0, float roughness, float NoV, float NoL, float NoH, float LoH, float specularIntensity) {
@@ -334,7 +334,7 @@ HKD float compute_jacobian(const Sample& q, const Sample& r) {  // light.wgsl:98
   return clamp_(term_1 * term_2, 1.0f, 50.0f);
 }
 HKD float reservoir_variance(const Reservoir& r) {  // light.wgsl:1224-1226,1488-1490,1672-1674
-  float variance = r.w2_sum / r.count - pow_(r.w_sum / r.count, 2.0f);
+  float variance = r.w2_sum / r.count - pow2_(r.w_sum / r.count);
   variance = (r.count < 1.0f) ? variance : variance / r.count;
   return fmin_(variance, HK_MAX_VARIANCE);
 }
@@ -797,7 +797,7 @@ HKD ShadingSite make_site(const DFrame& fr, f3 V, f3 N, const Surface& surface) 
   st.F0 = F3s(0.16f * reflectance * reflectance * (1.0f - metallic)) + base_color * metallic;
   st.diffuse_color = base_color * (1.0f - metallic);
   st.NdotV = fmax_(dot(N, V), 0.0001f);
-  st.view_pow5 = pow_(1.0f - st.NdotV, 5.0f);                    // F_Schlick(1, f90, NoV) of Fd_Burley
+  st.view_pow5 = pow5_(1.0f - st.NdotV);                    // F_Schlick(1, f90, NoV) of Fd_Burley
   st.fresnel_f90 = saturate(dot(st.F0, F3s(50.0f * 0.33f)));     // fresnel()
   st.ambient_radiance = env_brdf_terms(st.diffuse_color, st.roughness, occlusion, st.F0, N, V) * F3(fr.amb_r, fr.amb_g, fr.amb_b);
   return st;
@@ -809,13 +809,13 @@ HKD f3 shade(const ShadingSite& st, f3 L, f4 in_radiance) {
   float LoH = saturate(dot(L, Hh));
   // Fd_Burley
   float f90 = 0.5f + 2.0f * st.roughness * LoH * LoH;
-  float lightScatter = 1.0f + (f90 - 1.0f) * pow_(1.0f - NoL, 5.0f);
+  float lightScatter = 1.0f + (f90 - 1.0f) * pow5_(1.0f - NoL);
   float viewScatter = 1.0f + (f90 - 1.0f) * st.view_pow5;
   f3 diffuse = st.diffuse_color * (lightScatter * viewScatter * (1.0f / HK_PI));
   // specular
   float D = D_GGX(st.roughness, NoH);
   float Vs = V_SmithGGXCorrelated(st.roughness, st.NdotV, NoL);
-  float p = pow_(1.0f - LoH, 5.0f);
+  float p = pow5_(1.0f - LoH);
   f3 F = st.F0 + (F3s(st.fresnel_f90) - st.F0) * p;
   f3 specular_light = (1.0f * D * Vs) * F;
   f3 lit_radiance = (specular_light + diffuse) * xyz(in_radiance) * NoL;

@@ -214,6 +214,12 @@ HKD float pow_(float x, float y) {
   if (x == 0.0f) return y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : __builtin_inff());
   return exp2_(y * log2_(x));
 }
+// pow(x, c) for the constant exponents of the path, x >= 0: the multiplication / square-root chains the
+// numeric contract prescribes (oracle/hk_oracle_math.h header)
+HKD float pow2_(float x) { return x * x; }
+HKD float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }
+HKD float pow16_(float x) { float x2 = x * x; float x4 = x2 * x2; float x8 = x4 * x4; return x8 * x8; }
+HKD float pow_quarter_(float x) { return sqrtf(sqrtf(x)); }
 
 // ---- f16 storage (v_cvt_f16_f32 / v_cvt_f32_f16: round-to-nearest-even, denormals kept)
 // The empty asm keeps the f32 value opaque: without it the backend folds a preceding multiply into

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
       sum_w[ch] = 0.0f;
     }
     lum[ch] = luminance(irradiance);
-    lum_denominator[ch] = 4.0f * pow_(variance, 0.25f) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
+    lum_denominator[ch] = 4.0f * pow_quarter_(variance) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
     ff_moment_1[ch] = 0.0f;
     ff_moment_2[ch] = 0.0f;
     ff_count[ch] = 0.0f;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     const uint4 gs = d.dn_g[gx + fr.dw * gy];
     const f3 sample_normal = normalize(xyz(unpack4x8snorm(gs.y)));
     // channel-independent part of the weight, evaluated once
-    const float w_normal = pow_(fmax_(0.0f, dot(normal, sample_normal)), 16.0f);
+    const float w_normal = pow16_(fmax_(0.0f, dot(normal, sample_normal)));
     const float w_depth = exp_((-fabsf(depth - u2f(gs.x))) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
     const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - u2f(gs.z)));
     const float w_geometry = w_normal * w_depth * w_instance;

@@ -305,10 +305,10 @@ static inline float V_SmithGGXCorrelated(float roughness, float NoV, float NoL) 
   return v;
 }
 static inline v3 F_Schlick_vec(v3 f0, float f90, float VoH) {
-  float p = pow_(1.0f - VoH, 5.0f);
+  float p = pow5_(1.0f - VoH);
   return f0 + (V3s(f90) - f0) * p;
 }
-static inline float F_Schlick(float f0, float f90, float VoH) { return f0 + (f90 - f0) * pow_(1.0f - VoH, 5.0f); }
+static inline float F_Schlick(float f0, float f90, float VoH) { return f0 + (f90 - f0) * pow5_(1.0f - VoH); }
 static inline v3 fresnel(v3 f0, float LoH) {
   float f90 = saturate(dot(f0, V3s(50.0f * 0.33f)));
   return F_Schlick_vec(f0, f90, LoH);
@@ -1310,7 +1310,7 @@ static void pass_direct_lit(Ctx* c, bool emissive_lit, int y0, int y1) {
       r.s.visible_normal = s.visible_normal;
       r.lifetime += 1.0f;
 
-      float variance = r.w2_sum / r.count - pow_(r.w_sum / r.count, 2.0f);
+      float variance = r.w2_sum / r.count - pow2_(r.w_sum / r.count);
       variance = (r.count < 1.0f) ? variance : variance / r.count;
       variance = fmin_(variance, MAX_VARIANCE);
       variance_texture.store_f32(x, y, variance);
@@ -1523,7 +1523,7 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
       r.s.visible_normal = s.visible_normal;
       r.lifetime += 1.0f;
 
-      float variance = r.w2_sum / r.count - pow_(r.w_sum / r.count, 2.0f);
+      float variance = r.w2_sum / r.count - pow2_(r.w_sum / r.count);
       variance = (r.count < 1.0f) ? variance : variance / r.count;
       variance = fmin_(variance, MAX_VARIANCE);
       variance_texture.store_f32(x, y, variance);
@@ -1666,7 +1666,7 @@ static void pass_spatial_reuse(Ctx* c, bool emissive_lit, int y0, int y1) {
       rs.spatial[index] = pack_reservoir(r);
 
       if (use_spatial_variance) {
-        float variance = r.w2_sum / r.count - pow_(r.w_sum / r.count, 2.0f);
+        float variance = r.w2_sum / r.count - pow2_(r.w_sum / r.count);
         variance = (r.count < 1.0f) ? variance : variance / r.count;
         variance = fmin_(variance, MAX_VARIANCE);
         variance_texture.store_f32(x, y, variance);
@@ -1720,14 +1720,14 @@ static void pass_demodulation(Ctx* c, int channel, int y0, int y1) {  // denoise
     }
   }
 }
-static float normal_weight(v3 n0, v3 n1) { return pow_(fmax_(0.0f, dot(n0, n1)), 16.0f); }  // denoise.wgsl:44-47
+static float normal_weight(v3 n0, v3 n1) { return pow16_(fmax_(0.0f, dot(n0, n1))); }  // denoise.wgsl:44-47
 static float depth_weight(float d0, float d1, v2 gradient, v2 offset) {  // denoise.wgsl:50-53
   float eps = 0.01f;
   return exp_((-fabsf(d0 - d1)) / (fabsf(dot(gradient, offset)) + eps));
 }
 static float luminance_weight(float l0, float l1, float variance) {  // denoise.wgsl:56-61
   float strictness = 4.0f, exponent = 0.25f, eps = 0.001f;
-  return exp_((-fabsf(l0 - l1)) / (strictness * pow_(variance, exponent) + eps));
+  return exp_((-fabsf(l0 - l1)) / (strictness * pow_quarter_(variance) + eps));
 }
 static float instance_weight(float i0, float i1) { return fmax_(0.0f, 1.0f - fabsf(i0 - i1)); }  // denoise.wgsl:63-65
 

@@ -24,7 +24,11 @@
 //    v_max_f32 do on gfx950); clamp(x,lo,hi) = min(max(x,lo),hi); saturate = clamp(x,0,1)
 //  * sin, cos, exp, exp2, log2: the polynomial routines below (Cephes single-precision
 //    coefficients, explicit fma Horner); pow(x,y) = exp2(y*log2(x)) with pow(0,y>0) = 0, which is
-//    the accuracy class WGSL itself states for pow.
+//    the accuracy class WGSL itself states for pow.  Every pow on this path has a CONSTANT exponent
+//    (5 in bevy_pbr's F_Schlick, 16 in normal_weight, 2 in the variance, 0.25 in luminance_weight) and
+//    a non-negative base; these are evaluated the way shader compilers strength-reduce them - by
+//    multiplications ((x*x)*(x*x))*x, squarings, sqrt(sqrt(x)) - which is within pow's WGSL accuracy
+//    (a few ulp, tighter than exp2(y*log2 x)) and an order of magnitude cheaper: pow5_, pow16_, pow2_, pow_quarter_.
 //  * f32->f16 round-to-nearest-even with overflow to inf, f16 denormals preserved.
 //  * pack4x8snorm / pack2x16unorm / unpack*: the WGSL formulas (floor(0.5 + s*clamp(x))).
 #pragma once
@@ -239,6 +243,11 @@ static inline float pow_(float x, float y) {
   if (x == 0.0f) return y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : INFINITY);
   return exp2_(y * log2_(x));
 }
+// pow(x, c) for the constant exponents of the path, x >= 0 (see the header comment)
+static inline float pow2_(float x) { return x * x; }
+static inline float pow5_(float x) { float x2 = x * x; return (x2 * x2) * x; }
+static inline float pow16_(float x) { float x2 = x * x; float x4 = x2 * x2; float x8 = x4 * x4; return x8 * x8; }
+static inline float pow_quarter_(float x) { return sqrtf(sqrtf(x)); }
 
 // ---- f16 (IEEE binary16), round-to-nearest-even
 static inline uint16_t f32_to_f16(float f) {
