@@ -607,7 +607,7 @@ GBuffer make_gbuffer(const hk_ctx* c) {
   g.instance_material = (float2*)c->buf[HK_BUF_INSTANCE_MATERIAL];
   g.velocity_uv = (float4*)c->buf[HK_BUF_VELOCITY_UV];
   g.depth = c->depth_plane;
-  g.dn_g = (uint4*)c->dn_g;
+  g.dn_g = (float4*)c->dn_g;
   return g;
 }
 // group 6 ping-pong, light.rs:376,480-481,518-546
@@ -686,7 +686,8 @@ int run_denoise_fused(hk_ctx* c, uint32_t nch, int level, int y0, int y1) {
   ScopedTimer timer(c, HK_PASS_DENOISE_L0 + (uint32_t)level);
   DenoiseTargets d{};
   d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
-  d.dn_g = (const uint4*)c->dn_g;
+  d.dn_g = (const float4*)c->dn_g;
+  d.depth = c->depth_plane;
   d.depth_gradient = (const float2*)c->buf[HK_BUF_DEPTH_GRADIENT];
   for (uint32_t ch = 0; ch < nch; ++ch) {
     d.input[ch] = (const uint2*)dn_internal(c, nch, ch, level);
@@ -737,7 +738,8 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       const int level = (int)(pass - HK_PASS_DENOISE_L0);
       DenoiseTargets d{};
       d.albedo = (const uint2*)c->buf[HK_BUF_ALBEDO];
-      d.dn_g = (const uint4*)c->dn_g;
+      d.dn_g = (const float4*)c->dn_g;
+      d.depth = c->depth_plane;
       d.depth_gradient = (const float2*)c->buf[HK_BUF_DEPTH_GRADIENT];
       d.input[0] = (const uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level];
       d.output[0] = level == 3 ? (uint2*)c->buf[HK_BUF_DENOISE_RENDER0 + arg] : (uint2*)c->buf[HK_BUF_DENOISE_INTERNAL0 + level + 1];

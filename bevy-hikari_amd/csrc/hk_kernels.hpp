@@ -15,7 +15,7 @@ struct GBuffer {
   float4* __restrict__ velocity_uv;       // rgba32f
   // derived planes (not part of the reference's bindings): written by k_prepass / k_derive_planes
   float* __restrict__ depth;              // position.w alone: 4-B taps for the spatial-reuse ray march
-  uint4* __restrict__ dn_g;               // bits of (depth, snorm8 normal, instance id, 0): one 16-B tap for the denoiser
+  float4* __restrict__ dn_g;              // (normalised stored normal xyz, instance id + 0.5): one 16-B tap for the denoiser
 };
 // groups 5 + 6 for one light channel (light.wgsl:26-31,68-75; ping-pong light.rs:518-546)
 struct LightTargets {
@@ -36,12 +36,20 @@ struct DemodTargets {
 };
 struct DenoiseTargets {
   const uint2* __restrict__ albedo;
-  const uint4* __restrict__ dn_g;               // bits of (depth, snorm8 normal, instance id, 0) per full-size pixel
+  const float4* __restrict__ dn_g;              // (normalize(unpack4x8snorm(normal)), instance id + 0.5) per full-size pixel
+  const float* __restrict__ depth;              // position.w per full-size pixel
   const float2* __restrict__ depth_gradient;
   const uint2* input[3];                        // internal_texture_<level> per channel
   uint2* output[3];                             // internal_texture_<level+1> / denoise_render[channel]
   const float* internal_variance[3];
 };
+
+// what an a-trous tap needs of a G-buffer pixel besides its depth: the normal exactly as the filter derives it
+// from the rgba8snorm texel (denoise.wgsl:226,262: normalize(textureLoad(normal_texture).xyz)) and the instance id
+__device__ __forceinline__ float4 denoise_geometry(uint32_t packed_normal, float instance) {
+  const f3 n = normalize(xyz(unpack4x8snorm(packed_normal)));
+  return make_float4(n.x, n.y, n.z, instance);
+}
 
 struct Pixel { int x, y; bool valid; };
 

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
       g.instance_material[idx] = make_float2(0, 0);
       g.velocity_uv[idx] = make_float4(0, 0, 0, 0);
       g.depth[idx] = 0.0f;
-      g.dn_g[idx] = make_uint4(0u, 0u, 0u, 0u);
+      g.dn_g[idx] = denoise_geometry(0u, 0.0f);
     } else {
       const DInstance& in = sc.instances[hit.instance_index];
       const float4 q0 = sc.tri_v0[hit.primitive_index], q1 = sc.tri_v1[hit.primitive_index], q2 = sc.tri_v2[hit.primitive_index];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
       g.instance_material[idx] = make_float2((float)hit.instance_index + 0.5f, (float)in.material + 0.5f);
       g.velocity_uv[idx] = make_float4(velocity.x, velocity.y, uv.x, uv.y);
       g.depth[idx] = depth;
-      g.dn_g[idx] = make_uint4(f2u(depth), packed_normal, f2u((float)hit.instance_index + 0.5f), 0u);
+      g.dn_g[idx] = denoise_geometry(packed_normal, (float)hit.instance_index + 0.5f);
     }
   }
   flush_counters<COUNT>(rc, primary, counters);

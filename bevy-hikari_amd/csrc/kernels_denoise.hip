@@ -3,9 +3,10 @@
 // The reference runs, per render channel, demodulation then denoise L0..L3 (post_process.rs:
 // 1190-1224): 15 dispatches per frame, each re-reading the same G-buffer taps (normal, depth,
 // instance) from three planes.  Here
-//   * the per-tap geometry lives in ONE 16-B record per pixel (`dn_g` = depth, snorm8 normal bits,
-//     instance id), derived once per frame (k_derive_planes / k_prepass), so a tap costs one
-//     dwordx4 instead of a 16-B-strided depth read + two more loads;
+//   * the per-tap geometry lives in one 16-B record per pixel (`dn_g` = the NORMALISED stored normal and
+//     the instance id) plus the 4-B depth plane, derived once per frame (k_derive_planes / k_prepass): a
+//     tap costs a dwordx4 + a dword instead of three strided loads, and the normalisation (IEEE sqrt +
+//     divide, 29 instructions) is done once per pixel instead of once per tap per level per launch;
 //   * all channels of one level run in ONE launch (template NCH): the geometric weights
 //     w_normal * w_depth * w_instance of a tap are channel-independent and computed once, only the
 //     luminance weight and the accumulation are per channel.  5 launches per frame instead of 15.
@@ -19,14 +20,14 @@
 namespace hkd {
 
 // depth plane (f32) for the spatial-reuse ray march + packed denoise geometry, from the G-buffer
-__global__ __launch_bounds__(256) void k_derive_planes(GBuffer g, float* __restrict__ depth_plane, uint4* __restrict__ dn_g, int width, int row_begin,
+__global__ __launch_bounds__(256) void k_derive_planes(GBuffer g, float* __restrict__ depth_plane, float4* __restrict__ dn_g, int width, int row_begin,
                                                        int row_end) {
   const Pixel px = pixel_of_thread(width, row_begin, row_end);
   if (!px.valid) return;
   const int idx = px.x + width * px.y;
   const float depth = g.position[idx].w;
   depth_plane[idx] = depth;
-  dn_g[idx] = make_uint4(f2u(depth), g.normal[idx], f2u(g.instance_material[idx].x), 0u);
+  dn_g[idx] = denoise_geometry(g.normal[idx], g.instance_material[idx].x);
 }
 
 template <int NCH>
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
   int dx, dy;
   nearest_coords(deferred_uv, fr.dw, fr.dh, &dx, &dy);
   const int didx = dx + fr.dw * dy;
-  const uint4 gc = d.dn_g[didx];
-  const float depth = u2f(gc.x);
+  const float4 gc = d.dn_g[didx];
+  const float depth = d.depth[didx];
   if (depth < HK_F32_EPSILON) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) d.output[ch][index] = make_uint2(0u, 0u);
@@ -91,8 +92,8 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
   }
   const float2 dg = d.depth_gradient[didx];
   const f2 depth_gradient = F2(dg.x, dg.y);
-  const f3 normal = normalize(xyz(unpack4x8snorm(gc.y)));
-  const float instance = u2f(gc.z);
+  const f3 normal = F3(gc.x, gc.y, gc.z);
+  const float instance = gc.w;
 
   f3 sum_irradiance[NCH];
   float sum_w[NCH], lum[NCH], lum_denominator[NCH], ff_moment_1[NCH], ff_moment_2[NCH], ff_count[NCH];
@@ -125,12 +126,13 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     const f2 sample_deferred_uv = jittered_deferred_uv(fr, sample_uv, 0.5f);
     int gx, gy;
     nearest_coords(sample_deferred_uv, fr.dw, fr.dh, &gx, &gy);
-    const uint4 gs = d.dn_g[gx + fr.dw * gy];
-    const f3 sample_normal = normalize(xyz(unpack4x8snorm(gs.y)));
+    const float4 gs = d.dn_g[gx + fr.dw * gy];
+    const float sample_depth = d.depth[gx + fr.dw * gy];
+    const f3 sample_normal = F3(gs.x, gs.y, gs.z);
     // channel-independent part of the weight, evaluated once
     const float w_normal = pow16_(fmax_(0.0f, dot(normal, sample_normal)));
-    const float w_depth = exp_((-fabsf(depth - u2f(gs.x))) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
-    const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - u2f(gs.z)));
+    const float w_depth = exp_((-fabsf(depth - sample_depth)) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
+    const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - gs.w));
     const float w_geometry = w_normal * w_depth * w_instance;
     const float kernel_w = fr.kernel[(oy + 1) * 3 + (ox + 1)];
 #pragma unroll
@@ -177,7 +179,7 @@ using namespace hkd;
 
 void launch_derive_planes(hipStream_t st, const GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_derive_planes, grid_for(width, y1 - y0), dim3(256), 0, st, g, depth_plane, (uint4*)dn_g, width, y0, y1);
+  hipLaunchKernelGGL(k_derive_planes, grid_for(width, y1 - y0), dim3(256), 0, st, g, depth_plane, (float4*)dn_g, width, y0, y1);
 }
 
 void launch_demodulation(hipStream_t st, int nch, const DFrame& fr, const DemodTargets& d, int y0, int y1) {
