@@ -608,6 +608,7 @@ GBuffer make_gbuffer(const hk_ctx* c) {
   g.velocity_uv = (float4*)c->buf[HK_BUF_VELOCITY_UV];
   g.depth = c->depth_plane;
   g.dn_g = (float4*)c->dn_g;
+  g.albedo_out = nullptr;
   return g;
 }
 // group 6 ping-pong, light.rs:376,480-481,518-546
@@ -680,7 +681,7 @@ int run_demodulation_fused(hk_ctx* c, uint32_t nch, int y0, int y1) {
   HK_HIP(hipGetLastError());
   return HK_OK;
 }
-int run_denoise_fused(hk_ctx* c, uint32_t nch, int level, int y0, int y1) {
+int run_denoise_fused(hk_ctx* c, uint32_t nch, int level, int y0, int y1, bool with_tone_mapping = false) {
   if (y1 <= y0) return HK_OK;
   const DFrame fr = make_dframe(c);
   ScopedTimer timer(c, HK_PASS_DENOISE_L0 + (uint32_t)level);
@@ -693,6 +694,10 @@ int run_denoise_fused(hk_ctx* c, uint32_t nch, int level, int y0, int y1) {
     d.input[ch] = (const uint2*)dn_internal(c, nch, ch, level);
     d.output[ch] = level == 3 ? (uint2*)c->buf[HK_BUF_DENOISE_RENDER0 + ch] : (uint2*)dn_internal(c, nch, ch, level + 1);
     d.internal_variance[ch] = dn_variance(c, nch, ch);
+  }
+  if (with_tone_mapping && level == 3 && nch == (c->frame.indirect_bounces != 0u ? 3u : 2u)) {  // the channels tone_mapping sums, post_process.rs:941-954
+    d.tone_mapped = (uint2*)c->buf[HK_BUF_TONE_MAPPED];
+    memcpy(d.clear_color, c->frame.clear_color, sizeof(d.clear_color));
   }
   launch_denoise(c->stream, level, (int)nch, 0, fr, d, y0, y1);
   HK_HIP(hipGetLastError());
@@ -1065,15 +1070,26 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     }
     int f0, f1;
     full_rows_for(c, clampr(b0 - den - sp), clampr(b1 + den + sp), &f0, &f1);
+    bool albedo_done = false;
     if (!(flags & HK_FRAME_EXTERNAL_GBUFFER)) {
-      HK_RUN(HK_PASS_PREPASS, 0, f0, f1);
+      if (f1 > f0) {  // the prepass also fills the albedo of every pixel it covers (a superset of the rows albedo needs)
+        const DFrame fr = make_dframe(c);
+        GBuffer g = make_gbuffer(c);
+        g.albedo_out = (uint2*)c->buf[HK_BUF_ALBEDO];
+        unsigned long long* counters = (c->flags & HK_CTX_COUNT_RAYS) ? c->d_counters : nullptr;
+        const Jitter j = prepass_jitter(c);
+        ScopedTimer timer(c, HK_PASS_PREPASS);
+        launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters);
+        HK_HIP(hipGetLastError());
+        albedo_done = true;
+      }
     } else if (f1 > f0) {  // host-rasterised G-buffer: only the derived planes are ours to fill
       launch_derive_planes(c->stream, make_gbuffer(c), c->depth_plane, c->dn_g, c->W, f0, f1);
       c->derived_dirty = false;
     }
     int a0, a1;
     full_rows_for(c, clampr(b0 - den), clampr(b1 + den), &a0, &a1);
-    HK_RUN(HK_PASS_FULL_SCREEN_ALBEDO, 0, a0, a1);  // light.rs:646-653
+    if (!albedo_done) HK_RUN(HK_PASS_FULL_SCREEN_ALBEDO, 0, a0, a1);  // light.rs:646-653
     HK_RUN(HK_PASS_DIRECT_LIT, 0, b0, b1);          // light.rs:656-688
     HK_RUN(HK_PASS_DIRECT_EMISSIVE, 0, b0, b1);
     HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
@@ -1092,9 +1108,10 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       if ((rc = run_denoise_fused(c, nch, 0, clampr(b0 - 7), clampr(b1 + 7)))) return rc;
       if ((rc = run_denoise_fused(c, nch, 1, clampr(b0 - 3), clampr(b1 + 3)))) return rc;
       if ((rc = run_denoise_fused(c, nch, 2, clampr(b0 - 1), clampr(b1 + 1)))) return rc;
-      if ((rc = run_denoise_fused(c, nch, 3, b0, b1))) return rc;
+      if ((rc = run_denoise_fused(c, nch, 3, b0, b1, true))) return rc;  // + tone mapping (post_process.rs:1226-1234) in the same launch
+    } else {
+      HK_RUN(HK_PASS_TONE_MAPPING, 0u, b0, b1);                   // post_process.rs:1226-1234
     }
-    HK_RUN(HK_PASS_TONE_MAPPING, st->denoise ? 1u : 0u, b0, b1);  // post_process.rs:1226-1234
     if (c->timing_mask) {
       (void)hipEventRecord(c->frame_stop, c->stream);
       c->frame_timed = true;

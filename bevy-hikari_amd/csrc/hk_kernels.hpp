@@ -16,6 +16,9 @@ struct GBuffer {
   // derived planes (not part of the reference's bindings): written by k_prepass / k_derive_planes
   float* __restrict__ depth;              // position.w alone: 4-B taps for the spatial-reuse ray march
   float4* __restrict__ dn_g;              // (normalised stored normal xyz, instance id + 0.5): one 16-B tap for the denoiser
+  // optional: k_prepass also evaluates full_screen_albedo (light.wgsl:1019-1042) for the pixels it covers and
+  // writes it here (the frame path); null = the separate k_full_screen_albedo dispatch does it
+  uint2* __restrict__ albedo_out;
 };
 // groups 5 + 6 for one light channel (light.wgsl:26-31,68-75; ping-pong light.rs:518-546)
 struct LightTargets {
@@ -42,6 +45,10 @@ struct DenoiseTargets {
   const uint2* input[3];                        // internal_texture_<level> per channel
   uint2* output[3];                             // internal_texture_<level+1> / denoise_render[channel]
   const float* internal_variance[3];
+  // optional, level 3 with all channels in the launch: also apply tone_mapping.wgsl:21-32 to the sum of the
+  // (f16-rounded) channel outputs and write tone_mapping_output (the frame path); null = separate dispatch
+  uint2* tone_mapped;
+  float clear_color[4];
 };
 
 // what an a-trous tap needs of a G-buffer pixel besides its depth: the normal exactly as the filter derives it

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
       g.velocity_uv[idx] = make_float4(0, 0, 0, 0);
       g.depth[idx] = 0.0f;
       g.dn_g[idx] = denoise_geometry(0u, 0.0f);
+      if (g.albedo_out) g.albedo_out[idx] = make_uint2(0u, 0u);
     } else {
       const DInstance& in = sc.instances[hit.instance_index];
       const float4 q0 = sc.tri_v0[hit.primitive_index], q1 = sc.tri_v1[hit.primitive_index], q2 = sc.tri_v2[hit.primitive_index];
@@ -156,6 +157,14 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
       g.velocity_uv[idx] = make_float4(velocity.x, velocity.y, uv.x, uv.y);
       g.depth[idx] = depth;
       g.dn_g[idx] = denoise_geometry(packed_normal, (float)hit.instance_index + 0.5f);
+      if (g.albedo_out) {  // full_screen_albedo on the values just stored (light.wgsl:1019-1042)
+        uint2 a = make_uint2(0u, 0u);
+        if (!(depth < HK_F32_EPSILON)) {
+          Surface surface = retreive_surface(sc, f32_to_u32((float)in.material + 0.5f), uv);
+          a = pack_f16x4(F4(env_brdf(calculate_view(fr, world_position), xyz(unpack4x8snorm(packed_normal)), surface), 1.0f));
+        }
+        g.albedo_out[idx] = a;
+      }
     }
   }
   flush_counters<COUNT>(rc, primary, counters);

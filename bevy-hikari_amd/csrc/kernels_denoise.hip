@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
   if (depth < HK_F32_EPSILON) {
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) d.output[ch][index] = make_uint2(0u, 0u);
+    if (LEVEL == 3 && d.tone_mapped) d.tone_mapped[index] = pack_f16x4(F4(d.clear_color[0], d.clear_color[1], d.clear_color[2], d.clear_color[3]));  // sum has w = 0
     return;
   }
   const float2 dg = d.depth_gradient[didx];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
       }
     }
   }
-  f4 albedo = F4(0, 0, 0, 0);
+  f4 albedo = F4(0, 0, 0, 0), tone_sum = F4(0, 0, 0, 0);
   if (LEVEL == 3) {
     int ax, ay;
     nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
@@ -168,7 +169,17 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     }
     f4 color = F4(irradiance, 1.0f);
     if (LEVEL == 3) color = color * albedo;
-    d.output[ch][index] = pack_f16x4(color);
+    const uint2 packed = pack_f16x4(color);
+    d.output[ch][index] = packed;
+    if (LEVEL == 3) tone_sum = (ch == 0) ? unpack_f16x4(packed) : tone_sum + unpack_f16x4(packed);  // what tone_mapping loads back
+  }
+  if (LEVEL == 3 && d.tone_mapped) {  // tone_mapping.wgsl:21-32 (k_tone_mapping), channels summed in its order
+    const f3 c = F3(fmax_(tone_sum.x, 0.0039f), fmax_(tone_sum.y, 0.0039f), fmax_(tone_sum.z, 0.0039f));
+    const float l_old = dot(c, F3(0.2126f, 0.7152f, 0.0722f));
+    const float l_new = l_old / (1.0f + l_old);
+    f4 o = F4(c * (l_new / l_old), tone_sum.w);
+    if (!(tone_sum.w > 0.0f)) o = F4(d.clear_color[0], d.clear_color[1], d.clear_color[2], d.clear_color[3]);
+    d.tone_mapped[index] = pack_f16x4(o);
   }
 }
 
