@@ -165,8 +165,10 @@ static void emit(uint32_t buffer, uint32_t width, uint32_t height, uint32_t lo, 
   }
 }
 
-int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count, uint32_t stage,
+int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count, uint32_t stage_arg,
                      uint32_t frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
+  const uint32_t stage = stage_arg & 0xffu, history_rows = stage_arg >> 8;  // HK_STAGE_TEMPORAL_WITH_HISTORY
+  HK_REQUIRE(history_rows == 0 || stage == HK_STAGE_TEMPORAL, HK_E_INVALID, "history rows only apply to the temporal stage");
   HK_REQUIRE(st && n_ops && band_count > 0 && band_index < band_count && stage < HK_STAGE_COUNT, HK_E_INVALID, "bad argument");
   HK_REQUIRE(stage != HK_STAGE_ANTIALIAS || band_count == 1, HK_E_UNSUPPORTED, "the antialias stage runs on the whole image (band_count 1)");
   uint32_t rw, rh;
@@ -181,7 +183,15 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
   auto hi = [&](uint32_t a) { return std::min(rh, b1 + a); };
   // reservoir ping-pong, light.rs:376,480-481: the temporal dispatch writes buf[previous + T]
   const uint32_t previous = 1u - (frame_number % 2u);
-  if (stage == HK_STAGE_SPATIAL) {
+  if (stage == HK_STAGE_TEMPORAL && history_rows > 0 && st->temporal_reuse) {
+    // exchange C: what frame n reads as history = what frame n-1 wrote.  light.rs:518-546: previous = buf[current + T],
+    // previous_spatial = buf[current + S] with (T, S) = (0, 4) sun, (2, 4) emissive, (6, 8) indirect.
+    const uint32_t current = frame_number % 2u;
+    const uint32_t temporal[3] = {0u, 2u, 6u};
+    for (uint32_t t : temporal) emit(HK_BUF_RESERVOIR0 + current + t, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
+    if (st->emissive_spatial_reuse) emit(HK_BUF_RESERVOIR0 + current + 4u, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
+    if (st->indirect_spatial_reuse) emit(HK_BUF_RESERVOIR0 + current + 8u, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
+  } else if (stage == HK_STAGE_SPATIAL) {
     // reservoirs are allocated at full width (light.rs:344) but indexed with the scaled width
     // (light.wgsl:1061): a "row" of the exchange is rw reservoirs
     if (st->emissive_spatial_reuse) {

@@ -11,6 +11,8 @@ per frame:
     stage SPATIAL       spatial_reuse on the band
     exchange B          render (15 rows) + variance (16 rows) per denoised channel   -> denoiser
     stage POST_PROCESS  demodulation + 4 a-trous levels on band + shrinking apron, tone mapping
+and, only when the camera or objects moved (history_rows > 0), before stage TEMPORAL:
+    exchange C          last frame's temporal + spatial reservoirs, history_rows rows -> reprojection across the border
 
 Which rows of which buffer move is decided by the library (`hk_band_plan_for`, pure host logic);
 this module only executes that plan with isend/irecv on zero-copy views of the library's device
@@ -123,12 +125,17 @@ class BandRenderer:
             self.torch.cuda.synchronize()
         return nbytes
 
-    def render(self, frame, view, previous_view, lights, settings, width, height):
-        """One frame: three stages with the two halo exchanges in between."""
+    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0):
+        """One frame: three stages with the two halo exchanges in between.  history_rows > 0 (camera or
+        objects moved since the last frame) first fetches that many rows of last frame's reservoirs from the
+        neighbouring bands (exchange C, HK_STAGE_TEMPORAL_WITH_HISTORY): reprojection may cross the band border."""
         e = self.engine
         sc = settings.to_c()
         ratio = settings.upscale.ratio()
         e.frame_begin(frame, view, previous_view, lights)
+        if history_rows > 0:
+            self._sync_before_exchange()
+            self.exchange(F.STAGE_TEMPORAL | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_TEMPORAL, sc)
         self._sync_before_exchange()
         self.exchange(F.STAGE_SPATIAL, frame.number, sc, width, height, ratio)

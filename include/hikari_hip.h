@@ -444,7 +444,15 @@ int hk_frame_wait(hk_ctx* ctx);
 int hk_set_band(hk_ctx* ctx, uint32_t band_index, uint32_t band_count);
 int hk_band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32_t* row_begin, uint32_t* row_end);
 /* Halo transfers that must complete before `stage` runs on this context.  Pure host logic.
- * ops may be NULL to query the count. */
+ * ops may be NULL to query the count.
+ * Moving cameras / objects: the temporal and spatial dispatches read LAST frame's reservoirs at reprojected
+ * positions (light.wgsl:1091,1144,1404,1525), which can lie up to |velocity| rows inside a neighbouring band.
+ * Passing HK_STAGE_TEMPORAL_WITH_HISTORY(rows) as the stage returns "exchange C": `rows` rows of the
+ * reservoir buffers frame n reads as history (the temporal outputs of all three channels and the spatial
+ * outputs that are enabled), to be received before stage TEMPORAL of frame n.  A reprojection that lands
+ * beyond the halo reads the local, stale rows - the documented deviation; rows = 0 (static camera) is
+ * plain HK_STAGE_TEMPORAL and has no transfers. */
+#define HK_STAGE_TEMPORAL_WITH_HISTORY(rows) ((uint32_t)HK_STAGE_TEMPORAL | ((uint32_t)(rows) << 8))
 int hk_band_plan(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, HkHaloOp* ops, uint32_t* n_ops);
 /* Same plan without a context (used by hosts that only schedule): */
 int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count,

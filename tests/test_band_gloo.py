@@ -82,3 +82,69 @@ def test_bands_equal_single_rank(tmp_path, world, case_name):
                 continue
             assert (d[key].view(np.uint8) == a[b0:b1].view(np.uint8)).all(), f"rank {rank} band [{b0},{b1}) differs in {key}"
     assert rows == full["tone_mapped"].shape[0]
+
+
+def _moving_cameras(n_frames, w, h):
+    import bevy_hikari_amd as hk
+
+    # vertical motion: reprojection crosses rows, i.e. the band border
+    return [hk.Camera(hk.look_at_transform((0.0, 0.4 + 0.16 * n, 4.0), (0.0, 0.4 + 0.16 * n, 0.0)), w, h) for n in range(1, n_frames + 1)]
+
+
+def _motion_worker(rank, world, port, history_rows, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bevy_hikari_amd as hk
+    from bevy_hikari_amd import _ffi as F
+    from bevy_hikari_amd.distributed import BandRenderer
+    from oracle_lib import oracle_engine, set_threads
+
+    set_threads(2)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    w, h, frames = 96, 64, 8
+    e = oracle_engine()
+    e.upload_noise()
+    e.upload_scene(hk.load_cornell())
+    e.resize(w, h, 1.0)
+    r = BandRenderer(e, rank, world, backend_device="cpu")
+    cams = _moving_cameras(frames, w, h)
+    for n in range(1, frames + 1):
+        cam, prev = cams[n - 1], cams[max(n - 2, 0)]
+        r.render(hk.frame_uniform(s, n), cam.view_uniform(), cam.previous_view_uniform(prev), hk.lights_uniform(), s, w, h,
+                 history_rows=history_rows if n > 1 else 0)
+    b0, b1 = r.band(h)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b0=b0, b1=b1, **{f"d{i}": e.read(F.BUF_DENOISE_RENDER0 + i)[b0:b1] for i in range(3)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_history_halo_for_a_moving_camera(tmp_path):
+    """Exchange C (HK_STAGE_TEMPORAL_WITH_HISTORY): with the camera moving, reprojection crosses the band border.
+    Without the history halo a band reads its own stale copy of the neighbour's rows; with it the union of the bands
+    is within the north-star tolerance of the single-rank frame (not bit-equal: the reference's scatter-store into
+    previous_spatial races across pixels, and a band only sees its own pixels' stores)."""
+    import bevy_hikari_amd as hk
+    from oracle_lib import oracle_plugin
+
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    ref = oracle_plugin()
+    ref.set_scene(hk.load_cornell())
+    for n, cam in enumerate(_moving_cameras(8, 96, 64), start=1):
+        ref.render(cam, s, frame_number=n)
+    want = ref.output(s)
+    err = {}
+    for rows in (0, 12):
+        out = tmp_path / f"rows{rows}"
+        out.mkdir()
+        mp.spawn(_motion_worker, args=(2, _free_port(), rows, str(out)), nprocs=2, join=True)
+        got = np.zeros_like(want)
+        for rank in range(2):
+            d = np.load(out / f"rank{rank}.npz")
+            for i in range(3):
+                got[i, int(d["b0"]):int(d["b1"])] = d[f"d{i}"].view(np.float16).astype(np.float32)
+        err[rows] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    assert err[12] <= 1e-3, err
+    assert err[12] < err[0], err
