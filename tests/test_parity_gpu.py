@@ -477,3 +477,34 @@ def test_host_supplied_gbuffer_gives_the_same_frames(name):
     a, b = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0)
     run_case_with_host_gbuffer(a, b, case)
     assert diff_buffers(snapshot(a), snapshot(b)) == {}
+
+
+def test_baseline_config_1_exact():
+    """BASELINE config 1 as SURVEY 8d states it: Cornell 256x256 traced (ratio 1.0), 1 bounce, defaults otherwise,
+    frames 1..8 from zeroed reservoirs - every buffer of every frame bit for bit."""
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)
+    scene, cam = hk.load_cornell(), hk.cornell_camera(256, 256)
+    gpu, cpu = hk.HikariPlugin(device=0), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    for n in range(1, 9):
+        for p in (gpu, cpu):
+            p.render(cam, s, frame_number=n)
+        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        assert bad == {}, (n, bad)
+
+
+def test_sixty_four_frame_sequence_stays_bit_exact():
+    """The bench sequence length (frames 1..64, BASELINE config 2 at a quarter of its size): validation frames of
+    both intervals, reservoir lifetimes past their cap, M-capping - no drift between the two sides at frame 64."""
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    scene, cam = hk.load_cornell(), hk.cornell_camera(480, 272)
+    gpu, cpu = hk.HikariPlugin(device=0), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    for n in range(1, 65):
+        for p in (gpu, cpu):
+            p.render(cam, s, frame_number=n)
+        if n in (16, 32, 48, 64):
+            bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+            assert bad == {}, (n, bad)
