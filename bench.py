@@ -168,11 +168,12 @@ def main():
     band_rows = H if rend is None else (rend.band(H)[1] - rend.band(H)[0])
     algo_bytes = INDIRECT_BYTES_PER_PIXEL * W * band_rows
     achieved = algo_bytes / (ind_ms * 1e-3) / 1e9 if ind_ms > 0 else 0.0
-    traffic = None
+    traffic, limiter = None, None
     tpath = os.path.join(ROOT, "profiles", "r01_indirect_hbm_traffic.json")
     if os.path.exists(tpath) and world == 1 and (W, H) == (1920, 1080):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            prof = json.load(open(tpath))
+            traffic, limiter = prof.get("hbm_bytes_per_launch"), prof.get("limiter")  # PMC passes of the same command, see profiles/
         except Exception:
             traffic = None
 
@@ -210,6 +211,8 @@ def main():
             "launches": int(st.pass_launches[F.PASS_INDIRECT]),
         },
     }
+    if limiter:
+        out["roofline"]["limiter"] = limiter
     if passes:
         out["pass_ms"] = passes
 
