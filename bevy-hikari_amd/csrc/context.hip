@@ -1118,15 +1118,18 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     }
     c->frames += 1;
   } else if (stage == HK_STAGE_ANTIALIAS) {            // post_process.rs:1236-1272
-    HK_REQUIRE(c->band_count == 1, HK_E_UNSUPPORTED, "the antialias stage runs on the whole image (band_count 1)");
-    if (st->upscale_kind == HK_UPSCALE_SMAA_TU4X) {
-      HK_RUN(HK_PASS_SMAA_TU4X, 0, 0, c->RH);
-      HK_RUN(HK_PASS_SMAA_TU4X_EXTRAPOLATE, 0, 0, c->RH);
+    // band: TAA on the band's output rows; its input row beyond the border comes from the extrapolation of the
+    // neighbouring quad row, which needs the SMAA samples one more row out (footprints: hk_band_plan_for, exchange D)
+    const bool smaa = st->upscale_kind == HK_UPSCALE_SMAA_TU4X;
+    if (smaa) {
+      HK_RUN(HK_PASS_SMAA_TU4X, 0, clampr(b0 - 2), clampr(b1 + 2));
+      HK_RUN(HK_PASS_SMAA_TU4X_EXTRAPOLATE, 0, clampr(b0 - 1), clampr(b1 + 1));
     }
     if (st->taa == HK_TAA_JASMINE) {
       int w, h;
       buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &h);
-      HK_RUN(HK_PASS_TAA_JASMINE, 0, 0, h);
+      const int scale = smaa ? 2 : 1;
+      HK_RUN(HK_PASS_TAA_JASMINE, 0, std::min(h, scale * b0), b1 == c->RH ? h : std::min(h, scale * b1));
     }
   } else {
     HK_REQUIRE(false, HK_E_INVALID, "unknown stage %u", stage);

@@ -168,9 +168,8 @@ static void emit(uint32_t buffer, uint32_t width, uint32_t height, uint32_t lo, 
 int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count, uint32_t stage_arg,
                      uint32_t frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
   const uint32_t stage = stage_arg & 0xffu, history_rows = stage_arg >> 8;  // HK_STAGE_TEMPORAL_WITH_HISTORY
-  HK_REQUIRE(history_rows == 0 || stage == HK_STAGE_TEMPORAL, HK_E_INVALID, "history rows only apply to the temporal stage");
+  HK_REQUIRE(history_rows == 0 || stage == HK_STAGE_TEMPORAL || stage == HK_STAGE_ANTIALIAS, HK_E_INVALID, "history rows only apply to the temporal and antialias stages");
   HK_REQUIRE(st && n_ops && band_count > 0 && band_index < band_count && stage < HK_STAGE_COUNT, HK_E_INVALID, "bad argument");
-  HK_REQUIRE(stage != HK_STAGE_ANTIALIAS || band_count == 1, HK_E_UNSUPPORTED, "the antialias stage runs on the whole image (band_count 1)");
   uint32_t rw, rh;
   int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
   if (rc) return rc;
@@ -208,6 +207,42 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
       for (uint32_t ch = 0; ch < nch; ++ch) {
         emit(HK_BUF_RENDER0 + ch, rw, rh, lo(15), hi(15), band_index, band_count, ops, &n, cap);
         emit(HK_BUF_VARIANCE0 + ch, rw, rh, lo(16), hi(16), band_index, band_count, ops, &n, cap);
+      }
+    }
+  }
+  else if (stage == HK_STAGE_ANTIALIAS) {
+    // exchange D.  Footprints (smaa.wgsl, taa.wgsl) in rows of the scaled render image: TAA reads its input 1 row
+    // around the pixel; with SMAA Tu4x that input row comes from the extrapolation of the neighbouring quad row,
+    // which reads the quads 1 row around it, whose SMAA samples read tone_mapping_output 2 rows around them
+    // (2x2 gather at +-2.5 output texels): 4 rows in all.  History is read at the reprojected position:
+    // previous tone-mapped rows are already local for a static camera (last frame's exchange D delivered them into
+    // the plane that is `previous` now); previous TAA rows are not (TAA only runs on the band) - 5-tap Catmull-Rom
+    // over bilinear taps reaches 3 output rows.  history_rows (scaled render rows) extends the history planes.
+    const bool smaa = st->upscale_kind == HK_UPSCALE_SMAA_TU4X, taa = st->taa == HK_TAA_JASMINE;
+    const uint32_t tm = smaa ? 4u : (taa ? 1u : 0u);
+    if (tm) emit(HK_BUF_TONE_MAPPED, rw, rh, lo(tm), hi(tm), band_index, band_count, ops, &n, cap);
+    if (smaa && history_rows) emit(HK_BUF_PREVIOUS_TONE_MAPPED, rw, rh, lo(tm + history_rows), hi(tm + history_rows), band_index, band_count, ops, &n, cap);
+    if (taa) {
+      // taa_output rows are output rows: 2 per render row with SMAA Tu4x (ceil(size * 2 / ratio) of them), 1 otherwise
+      const uint32_t scale = smaa ? 2u : 1u;
+      const float s2 = (1.0f / clamp_ratio(upscale_ratio)) * 2.0f;
+      const uint32_t tw = smaa ? (uint32_t)ceilf((float)width * s2) : rw, th = smaa ? (uint32_t)ceilf((float)height * s2) : rh;
+      const uint32_t reach = 4u + scale * history_rows;
+      const uint32_t need_lo = scale * b0 > reach ? scale * b0 - reach : 0u, need_hi = std::min(th, scale * b1 + reach);
+      for (uint32_t j = 0; j < band_count; ++j) {
+        if (j == band_index) continue;
+        uint32_t o0, o1;
+        band_rows(rh, j, band_count, &o0, &o1);
+        const uint32_t a = std::max(need_lo, scale * o0), b = std::min(need_hi, std::min(th, scale * o1));
+        if (a >= b) continue;
+        if (ops && n < cap) {
+          ops[n].buffer = HK_BUF_PREVIOUS_TAA_OUTPUT;
+          ops[n].peer = j;
+          ops[n].row_begin = a;
+          ops[n].row_end = b;
+          ops[n].row_bytes = (uint64_t)tw * buffer_bpp(HK_BUF_PREVIOUS_TAA_OUTPUT);
+        }
+        n += 1;
       }
     }
   }

@@ -60,16 +60,19 @@ class BandRenderer:
         self._plans = {}
         engine.set_band(rank, world_size)
 
-    def _view(self, buf):
-        if buf not in self._views:
+    def _view(self, buf, parity=0):
+        # the double-buffered ids (HkBuffer: position, velocity, tone-mapped, TAA) name a different plane on odd and
+        # even frames, so views are kept per frame parity; they are taken after hk_frame_begin of such a frame
+        key = (buf, parity)
+        if key not in self._views:
             torch = self.torch
             ptr, nbytes = self.engine.device_ptr(buf)
             if self.device == "cuda":
                 t = torch.as_tensor(_DevView(ptr, nbytes), device="cuda")
             else:
                 t = torch.from_numpy(np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)))
-            self._views[buf] = t
-        return self._views[buf]
+            self._views[key] = t
+        return self._views[key]
 
     def invalidate_views(self):  # after hk_resize
         self._views = {}
@@ -90,9 +93,9 @@ class BandRenderer:
             for op in halo_plan(width, height, upscale_ratio, peer_rank, self.world, stage, frame_number, settings_c):
                 lo, hi = op.row_begin * op.row_bytes, op.row_end * op.row_bytes
                 if peer_rank == self.rank:       # I receive rows owned by op.peer
-                    out.append((True, self._view(op.buffer)[lo:hi], op.peer))
+                    out.append((True, self._view(op.buffer, frame_number & 1)[lo:hi], op.peer))
                 elif op.peer == self.rank:       # peer_rank needs rows I own
-                    out.append((False, self._view(op.buffer)[lo:hi], peer_rank))
+                    out.append((False, self._view(op.buffer, frame_number & 1)[lo:hi], peer_rank))
         self._plans[key] = out
         return out
 
@@ -125,7 +128,7 @@ class BandRenderer:
             self.torch.cuda.synchronize()
         return nbytes
 
-    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0):
+    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0, antialias=False):
         """One frame: three stages with the two halo exchanges in between.  history_rows > 0 (camera or
         objects moved since the last frame) first fetches that many rows of last frame's reservoirs from the
         neighbouring bands (exchange C, HK_STAGE_TEMPORAL_WITH_HISTORY): reprojection may cross the band border."""
@@ -143,6 +146,10 @@ class BandRenderer:
         self._sync_before_exchange()
         self.exchange(F.STAGE_POST_PROCESS, frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_POST_PROCESS, sc)
+        if antialias:  # SMAA Tu4x / TAA on the band: exchange D = tone-mapped rows + last frame's TAA rows
+            self._sync_before_exchange()
+            self.exchange(F.STAGE_ANTIALIAS | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
+            e.frame_stage(F.STAGE_ANTIALIAS, sc)
 
     def _sync_before_exchange(self):
         # When the engine runs on torch's current stream (Engine.set_stream), RCCL orders itself

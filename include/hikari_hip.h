@@ -276,8 +276,9 @@ typedef enum HkStage {
   HK_STAGE_SPATIAL = 1,      /* spatial_reuse dispatches that are enabled */
   HK_STAGE_POST_PROCESS = 2, /* demodulation + a-trous x4 per channel, tone mapping */
   HK_STAGE_ANTIALIAS = 3,    /* the rest of PostProcessNode::run (post_process.rs:1236-1272): SMAA Tu4x (+extrapolate)
-                                when upscale_kind is SMAA_TU4X, then TAA when taa is JASMINE.  Whole image only
-                                (band_count must be 1); not part of hk_frame_render unless HK_FRAME_ANTIALIAS. */
+                                when upscale_kind is SMAA_TU4X, then TAA when taa is JASMINE, on the band (exchange D of
+                                hk_band_plan_for: tone-mapped rows + last frame's TAA rows).  Not part of hk_frame_render
+                                unless HK_FRAME_ANTIALIAS. */
   HK_STAGE_COUNT = 4
 } HkStage;
 

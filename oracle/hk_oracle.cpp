@@ -2299,15 +2299,16 @@ int orc_frame_stage_rows(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uin
     pass_tone_mapping(&c, st->denoise != 0, b0, b1);
     c.stats.frames++;
   } else if (stage == HK_STAGE_ANTIALIAS) {  // post_process.rs:1236-1272
-    ORC_CHECK(c.band_count == 1 && b0 == 0 && b1 == c.RH, HK_E_UNSUPPORTED, "the antialias stage runs on the whole image");
-    if (st->upscale_kind == HK_UPSCALE_SMAA_TU4X) {
-      pass_smaa_tu4x(&c, 0, c.RH);
-      pass_smaa_tu4x_extrapolate(&c, 0, c.RH);
+    const bool smaa = st->upscale_kind == HK_UPSCALE_SMAA_TU4X;
+    if (smaa) {  // aprons: see hk_band_plan_for (exchange D)
+      pass_smaa_tu4x(&c, clampr(b0 - 2), clampr(b1 + 2));
+      pass_smaa_tu4x_extrapolate(&c, clampr(b0 - 1), clampr(b1 + 1));
     }
     if (st->taa == HK_TAA_JASMINE) {
       int w, h;
       buf_dims(&c, HK_BUF_TAA_OUTPUT, &w, &h);
-      pass_taa_jasmine(&c, 0, h);
+      const int scale = smaa ? 2 : 1;
+      pass_taa_jasmine(&c, std::min(h, scale * b0), b1 == c.RH ? h : std::min(h, scale * b1));
     }
   } else {
     ORC_CHECK(false, HK_E_INVALID, "unknown stage");

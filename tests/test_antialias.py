@@ -92,10 +92,17 @@ def test_taa_blend_of_a_static_view_is_exact():
     assert (out[..., 3] == cur[..., 3]).all()
 
 
-def test_antialias_stage_is_whole_image_only():
+def test_antialias_band_plan():
+    """Exchange D: tone-mapped rows (4 with SMAA Tu4x, 1 for TAA alone) and last frame's TAA rows around the band."""
     from bevy_hikari_amd.distributed import halo_plan
 
-    with pytest.raises(hk.HikariError) as e:
-        halo_plan(1920, 1080, 1.0, 0, 2, F.STAGE_ANTIALIAS, 5, S().to_c())
-    assert e.value.code == F.HK_E_UNSUPPORTED
     assert halo_plan(1920, 1080, 1.0, 0, 1, F.STAGE_ANTIALIAS, 5, S().to_c()) == []
+    ops = halo_plan(1920, 1080, 2.0, 1, 4, F.STAGE_ANTIALIAS, 5, S().to_c())          # 960x540 traced, bands of 135 rows
+    got = sorted((o.buffer, o.peer, o.row_begin, o.row_end, o.row_bytes) for o in ops)
+    assert got == [(F.BUF_TONE_MAPPED, 0, 131, 135, 960 * 8), (F.BUF_TONE_MAPPED, 2, 270, 274, 960 * 8),
+                   (F.BUF_PREVIOUS_TAA_OUTPUT, 0, 266, 270, 1920 * 8), (F.BUF_PREVIOUS_TAA_OUTPUT, 2, 540, 544, 1920 * 8)]
+    fsr = halo_plan(1920, 1080, 1.5, 0, 2, F.STAGE_ANTIALIAS, 5, S(upscale=U.Fsr1(1.5, 0.2)).to_c())   # TAA at the scaled size
+    assert sorted((o.buffer, o.row_begin, o.row_end) for o in fsr) == [(F.BUF_TONE_MAPPED, 360, 361), (F.BUF_PREVIOUS_TAA_OUTPUT, 360, 364)]
+    moving = halo_plan(1920, 1080, 2.0, 0, 2, F.STAGE_ANTIALIAS | (3 << 8), 5, S().to_c())              # 3 rows of motion
+    assert sorted((o.buffer, o.row_begin, o.row_end) for o in moving) == [(F.BUF_TONE_MAPPED, 270, 274), (F.BUF_PREVIOUS_TONE_MAPPED, 270, 277),
+                                                                           (F.BUF_PREVIOUS_TAA_OUTPUT, 540, 550)]

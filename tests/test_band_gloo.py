@@ -148,3 +148,63 @@ def test_history_halo_for_a_moving_camera(tmp_path):
         err[rows] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
     assert err[12] <= 1e-3, err
     assert err[12] < err[0], err
+
+
+def _aa_worker(rank, world, port, case_name, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bevy_hikari_amd as hk
+    from bevy_hikari_amd import _ffi as F
+    from bevy_hikari_amd.distributed import BandRenderer
+    from cases import make_case
+    from oracle_lib import oracle_engine, set_threads
+
+    set_threads(2)
+    case = make_case(case_name)
+    s = case.settings
+    e = oracle_engine()
+    e.upload_noise()
+    e.upload_scene(case.scene)
+    w, h = case.camera.width, case.camera.height
+    e.resize(w, h, s.upscale.ratio())
+    r = BandRenderer(e, rank, world, backend_device="cpu")
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    for n in case.frames:
+        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, antialias=True)
+    _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
+    b0, b1 = r.band(rh)
+    out = {"b0": b0, "b1": b1, "rh": rh}
+    for b, name in ((F.BUF_TONE_MAPPED, "tone_mapped"), (F.BUF_UPSCALE_OUTPUT, "upscale_output"), (F.BUF_TAA_OUTPUT, "taa_output")):
+        _, bh, _ = e.buffer_info(b)
+        scale = 2 if bh > rh else 1
+        y0, y1 = min(bh, scale * b0), (bh if b1 == rh else min(bh, scale * b1))
+        out[name] = e.read(b)[y0:y1]
+        out[name + "_rows"] = np.array([y0, y1])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_aa_default"), (3, "yard_aa_smaa2x")])
+def test_antialias_bands_equal_single_rank(tmp_path, world, case_name):
+    """SMAA Tu4x + TAA on bands (exchange D): the union of the bands' output rows equals the single-rank image bit
+    for bit, for a static camera."""
+    from cases import make_case, run_case, snapshot
+    from oracle_lib import oracle_plugin
+
+    mp.spawn(_aa_worker, args=(world, _free_port(), case_name, str(tmp_path)), nprocs=world, join=True)
+    case = make_case(case_name)
+    ref = oracle_plugin()
+    run_case(ref, case)
+    full = snapshot(ref)
+    for name in ("tone_mapped", "upscale_output", "taa_output"):
+        covered = 0
+        for rank in range(world):
+            d = np.load(tmp_path / f"rank{rank}.npz")
+            y0, y1 = (int(v) for v in d[name + "_rows"])
+            covered += y1 - y0
+            assert (d[name].view(np.uint8) == full[name][y0:y1].view(np.uint8)).all(), f"rank {rank} rows [{y0},{y1}) differ in {name}"
+        assert covered == full[name].shape[0], name

@@ -208,19 +208,27 @@ def _gpu_band_worker(rank, world, port, case_name, out_dir):
     r = BandRenderer(e, rank, world)
     view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
     for n in case.frames:
-        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h)
+        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, antialias=case.antialias)
     e.wait()
     _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
     b0, b1 = r.band(rh)
     prev = 1 - case.frames[-1] % 2
     want = [F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2,
             F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8]
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b0=b0, b1=b1, **{ALL_BUFFERS[b]: e.read(b)[b0:b1] for b in want})
+    out = {ALL_BUFFERS[b]: e.read(b)[b0:b1] for b in want if e.buffer_info(b)[1] == rh}   # (reservoirs are indexed with the scaled width inside full-size storage)
+    if case.antialias:  # output rows: two per render row with SMAA Tu4x
+        for b in (F.BUF_UPSCALE_OUTPUT, F.BUF_TAA_OUTPUT):
+            _, bh, _ = e.buffer_info(b)
+            scale = 2 if bh > rh else 1
+            y0, y1 = min(bh, scale * b0), (bh if b1 == rh else min(bh, scale * b1))
+            out[ALL_BUFFERS[b]] = e.read(b)[y0:y1]
+            out[ALL_BUFFERS[b] + "_rows"] = np.array([y0, y1])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b0=b0, b1=b1, **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun")])
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun"), (3, "cornell_aa_default")])
 def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
     """The band-sharded GPU path (hk_set_band + hk_frame_stage + halo exchange) on ONE GPU: every
     rank renders its band on device 0, halos travel over gloo (staged through host memory because
@@ -242,8 +250,10 @@ def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
         d = np.load(tmp_path / f"rank{rank}.npz")
         b0, b1 = int(d["b0"]), int(d["b1"])
         for key in d.files:
-            if key not in ("b0", "b1"):
-                assert (d[key].view(np.uint8) == full[key][b0:b1].view(np.uint8)).all(), f"rank {rank} [{b0},{b1}) differs in {key}"
+            if key in ("b0", "b1") or key.endswith("_rows"):
+                continue
+            y0, y1 = (int(v) for v in d[key + "_rows"]) if key + "_rows" in d.files else (b0, b1)
+            assert (d[key].view(np.uint8) == full[key][y0:y1].view(np.uint8)).all(), f"rank {rank} [{y0},{y1}) differs in {key}"
 
 
 def test_sponza_class_vs_oracle():
