@@ -141,6 +141,16 @@ def main():
     ceng.reset_stats()
     run_frames(ceng, crend, args.warmup + 1, args.warmup + args.steps)
     cst = ceng.stats()
+    # the dominant kernel ALONE on the GPU: same frames on a single-stream context (in the timed run the two
+    # direct-light dispatches share the GPU with it from a second stream, which stretches its own duration)
+    xeng, xrend = make_engine(F.CTX_SINGLE_STREAM)
+    run_frames(xeng, xrend, 1, args.warmup)
+    xeng.wait()
+    xeng.reset_stats()
+    xeng.set_timing_mask(1 << F.PASS_INDIRECT)
+    run_frames(xeng, xrend, args.warmup + 1, args.warmup + min(args.steps, 16))
+    xst = xeng.stats()
+    ind_ms_alone = xst.pass_ms_total[F.PASS_INDIRECT] / max(1, xst.pass_launches[F.PASS_INDIRECT])
     traced = np.array([cst.rays_tlas + cst.rays_blas], dtype=np.float64)
     if dist is not None:
         t = torch.tensor(traced, dtype=torch.float64, device="cuda")
@@ -152,13 +162,13 @@ def main():
     same = bool((ceng.read(F.BUF_TONE_MAPPED) == eng.read(F.BUF_TONE_MAPPED)).all())
 
     passes = None
-    if args.passes and world == 1:
-        eng.reset_stats()
-        eng.set_timing_mask(0xFFFF)
-        run_frames(eng, rend, args.warmup + args.steps + 1, args.warmup + args.steps + 6)
-        ps = eng.stats()
+    if args.passes and world == 1:   # per-pass times with every dispatch alone on the GPU
+        xeng.reset_stats()
+        xeng.set_timing_mask(0xFFFF)
+        run_frames(xeng, xrend, args.warmup + min(args.steps, 16) + 1, args.warmup + min(args.steps, 16) + 6)
+        ps = xeng.stats()
         passes = {F.PASS_NAMES[i]: round(ps.pass_ms_total[i] / 6.0, 4) for i in range(F.PASS_COUNT) if ps.pass_launches[i]}
-        eng.set_timing_mask(0)
+        xeng.set_timing_mask(0)
 
     if rank != 0:
         if dist is not None:
@@ -209,6 +219,9 @@ def main():
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": round(ind_ms, 5),
             "launches": int(st.pass_launches[F.PASS_INDIRECT]),
+            # the same kernel with nothing else on the GPU (HK_CTX_SINGLE_STREAM replay of the same frames)
+            "alone": {"avg_launch_ms": round(ind_ms_alone, 5), "achieved": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9, 3) if ind_ms_alone > 0 else 0.0,
+                      "frac": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ind_ms_alone > 0 else 0.0},
         },
     }
     if limiter:

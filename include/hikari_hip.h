@@ -325,6 +325,12 @@ int hk_device_count(int* count);
 #define HK_CTX_COUNT_RAYS 1u
 #define HK_CTX_TIME_PASSES 2u
 #define HK_CTX_PLAIN_DIVISION 4u
+/* By default hk_frame_stage / hk_frame_render run the two direct-light dispatches (sun, emissive: light.rs:656-688)
+ * on a second HIP stream, concurrently with indirect_lit_ambient and its spatial pass - they touch disjoint
+ * reservoir / render buffers (light.rs:518-546) - and join before anything reads their outputs (demodulation, halo
+ * exchange B, hk_read_buffer, hk_frame_wait ...).  hk_pass_run never forks.  bit3 keeps everything on one stream:
+ * same results, no overlap (used to time a kernel alone). */
+#define HK_CTX_SINGLE_STREAM 8u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);
 

@@ -518,3 +518,33 @@ def test_sixty_four_frame_sequence_stays_bit_exact():
         if n in (16, 32, 48, 64):
             bad = diff_buffers(snapshot(gpu), snapshot(cpu))
             assert bad == {}, (n, bad)
+
+
+def test_second_stream_overlap_changes_no_bit_and_joins_on_reads():
+    """The frame path runs the two direct-light dispatches on a second stream (joined before demodulation);
+    HK_CTX_SINGLE_STREAM keeps one stream.  Same frames; and a host that stops after the temporal stage and
+    reads the sun / emissive outputs must see them complete (hk_read_buffer joins)."""
+    case = make_case("yard_sun")      # both direct channels carry light, emissive spatial reuse on
+    snaps = []
+    for flags in (0, F.CTX_SINGLE_STREAM):
+        p = hk.HikariPlugin(device=0, flags=flags)
+        run_case(p, case)
+        snaps.append(snapshot(p))
+    assert diff_buffers(snaps[0], snaps[1]) == {}
+    s = case.settings
+    outs = []
+    for flags in (0, F.CTX_SINGLE_STREAM):
+        e = hk.Engine(device=0, flags=flags)
+        e.upload_noise()
+        e.upload_scene(case.scene)
+        e.resize(case.camera.width, case.camera.height, s.upscale.ratio())
+        for n in (1, 2, 3):
+            e.frame_begin(hk.frame_uniform(s, n), case.camera.view_uniform(), case.camera.previous_view_uniform(), case.lights)
+            e.frame_stage(F.STAGE_TEMPORAL, s.to_c())
+            got = [e.read(b) for b in (F.BUF_RENDER0, F.BUF_RENDER0 + 1, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 1)]   # straight after the fork
+            e.frame_stage(F.STAGE_SPATIAL, s.to_c())
+            e.frame_stage(F.STAGE_POST_PROCESS, s.to_c())
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert (a.view(np.uint8) == b.view(np.uint8)).all()
+    assert outs[0][1].view(np.float16).astype(np.float32)[..., :3].max() > 0
