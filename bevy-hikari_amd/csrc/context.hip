@@ -99,6 +99,9 @@ struct hk_ctx {
   uint32_t flags = 0;
   hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless hk_set_stream)
   hipStream_t own_stream = nullptr;
+  hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
+  hipEvent_t fork_event = nullptr, join_event = nullptr;
+  bool forked = false;                 // side_stream holds work the main stream has not waited for yet
 
   // host copies of the reference-layout scene (kept for the layout conversion)
   std::vector<HkVertex> vertices;
@@ -704,6 +707,24 @@ int run_denoise_fused(hk_ctx* c, uint32_t nch, int level, int y0, int y1, bool w
   return HK_OK;
 }
 
+// make the main stream wait for what was enqueued on the side stream
+int join_side(hk_ctx* c) {
+  if (!c->forked) return HK_OK;
+  HK_HIP(hipEventRecord(c->join_event, c->side_stream));
+  HK_HIP(hipStreamWaitEvent(c->stream, c->join_event, 0));
+  c->forked = false;
+  return HK_OK;
+}
+// run one dispatch on the side stream (timers record there too)
+int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1);
+int run_pass_on_side(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
+  hipStream_t main_stream = c->stream;
+  c->stream = c->side_stream;
+  const int rc = (y1 > y0) ? run_pass(c, pass, arg, y0, y1) : HK_OK;
+  c->stream = main_stream;
+  return rc;
+}
+
 int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
   const DFrame fr = make_dframe(c);
   const GBuffer g = make_gbuffer(c);
@@ -829,6 +850,14 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
     return HK_E_HIP;
   }
   c->stream = c->own_stream;
+  if (!(flags & HK_CTX_SINGLE_STREAM)) {
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming) != hipSuccess) {
+      set_error("cannot create the side stream");
+      hk_destroy(c);
+      return HK_E_HIP;
+    }
+  }
   *out = c;
   return HK_OK;
 }
@@ -846,6 +875,9 @@ void hk_destroy(hk_ctx* c) {
   c->d_tex_data.release();
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+  if (c->fork_event) (void)hipEventDestroy(c->fork_event);
+  if (c->join_event) (void)hipEventDestroy(c->join_event);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1025,6 +1057,7 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
 int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint32_t row_end) {
   int rc = ready(c);
   if (rc) return rc;
+  if ((rc = join_side(c))) return rc;
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
   int rows = full_grid ? c->H : c->RH;
   if (pass == HK_PASS_TAA_JASMINE) { int w; buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &rows); }
@@ -1065,6 +1098,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     if (b_ > a_ && (rc = run_pass(c, pass, arg, a_, b_))) return rc; \
   } while (0)
   if (stage == HK_STAGE_TEMPORAL) {
+    if ((rc = join_side(c))) return rc;
     if (c->timing_mask) {
       (void)hipEventRecord(c->frame_start, c->stream);
     }
@@ -1090,13 +1124,34 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     int a0, a1;
     full_rows_for(c, clampr(b0 - den), clampr(b1 + den), &a0, &a1);
     if (!albedo_done) HK_RUN(HK_PASS_FULL_SCREEN_ALBEDO, 0, a0, a1);  // light.rs:646-653
-    HK_RUN(HK_PASS_DIRECT_LIT, 0, b0, b1);          // light.rs:656-688
-    HK_RUN(HK_PASS_DIRECT_EMISSIVE, 0, b0, b1);
-    HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
+    if (c->side_stream && b1 > b0) {
+      // sun and emissive share their spatial reservoir buffers (S = 4 for both, light.rs:518-546) and stay in order
+      // on the side stream; indirect (T = 6, S = 8) and everything it feeds is independent of them until demodulation
+      HK_HIP(hipEventRecord(c->fork_event, c->stream));
+      HK_HIP(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));
+      c->forked = true;
+      if ((rc = run_pass_on_side(c, HK_PASS_DIRECT_LIT, 0, b0, b1))) return rc;
+      if ((rc = run_pass_on_side(c, HK_PASS_DIRECT_EMISSIVE, 0, b0, b1))) return rc;
+      HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
+      // a band's exchange A ships the emissive temporal reservoirs when their spatial pass is on
+      if (c->band_count > 1 && st->emissive_spatial_reuse && (rc = join_side(c))) return rc;
+    } else {
+      HK_RUN(HK_PASS_DIRECT_LIT, 0, b0, b1);          // light.rs:656-688
+      HK_RUN(HK_PASS_DIRECT_EMISSIVE, 0, b0, b1);
+      HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
+    }
   } else if (stage == HK_STAGE_SPATIAL) {            // light.rs:689-697
-    if (st->emissive_spatial_reuse) HK_RUN(HK_PASS_EMISSIVE_SPATIAL_REUSE, 0, b0, b1);
+    if (st->emissive_spatial_reuse) {
+      if (c->forked) {
+        if ((rc = run_pass_on_side(c, HK_PASS_EMISSIVE_SPATIAL_REUSE, 0, b0, b1))) return rc;
+      } else {
+        HK_RUN(HK_PASS_EMISSIVE_SPATIAL_REUSE, 0, b0, b1);
+      }
+    }
     if (st->indirect_spatial_reuse) HK_RUN(HK_PASS_INDIRECT_SPATIAL_REUSE, 0, b0, b1);
+    if ((rc = join_side(c))) return rc;              // exchange B / demodulation read all three channels
   } else if (stage == HK_STAGE_POST_PROCESS) {
+    if ((rc = join_side(c))) return rc;
     if (st->denoise) {                               // post_process.rs:1190-1224
       const uint32_t nch = st->indirect_bounces == 0 ? 2u : 3u;  // post_process.rs:949-954
       if (c->derived_dirty) {
@@ -1150,6 +1205,7 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
 int hk_frame_wait(hk_ctx* c) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   HK_HIP(hipSetDevice(c->device));
+  { int rc = join_side(c); if (rc) return rc; }
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   return HK_OK;
@@ -1168,6 +1224,7 @@ int hk_read_buffer(hk_ctx* c, uint32_t buffer, void* dst, size_t bytes) {
   HK_REQUIRE(c && dst && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
   HK_REQUIRE(bytes == buffer_logical_bytes(c, buffer), HK_E_INVALID, "size mismatch: buffer has %zu bytes", buffer_logical_bytes(c, buffer));
   HK_HIP(hipSetDevice(c->device));
+  { int rc_ = join_side(c); if (rc_) return rc_; }
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(dst, c->buf[buffer], bytes, hipMemcpyDeviceToHost));
   return HK_OK;
@@ -1176,6 +1233,7 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
   HK_REQUIRE(c && src && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
   HK_REQUIRE(bytes == buffer_logical_bytes(c, buffer), HK_E_INVALID, "size mismatch: buffer has %zu bytes", buffer_logical_bytes(c, buffer));
   HK_HIP(hipSetDevice(c->device));
+  { int rc_ = join_side(c); if (rc_) return rc_; }
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
   if (buffer == HK_BUF_POSITION || buffer == HK_BUF_NORMAL || buffer == HK_BUF_INSTANCE_MATERIAL) c->derived_dirty = true;
@@ -1190,6 +1248,7 @@ int hk_device_ptr(hk_ctx* c, uint32_t buffer, void** ptr, size_t* bytes) {
 int hk_set_stream(hk_ctx* c, void* s) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   HK_HIP(hipSetDevice(c->device));
+  { int rc = join_side(c); if (rc) return rc; }
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -1208,6 +1267,7 @@ int hk_set_timing_mask(hk_ctx* c, uint32_t mask) {
 int hk_get_stats(hk_ctx* c, HkStats* out) {
   HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
   HK_HIP(hipSetDevice(c->device));
+  { int rc = join_side(c); if (rc) return rc; }
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   memset(out, 0, sizeof(*out));
