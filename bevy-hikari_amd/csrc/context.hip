@@ -255,17 +255,18 @@ struct ScopedTimer {
   hk_ctx* c;
   bool on;
   TimedLaunch t{};
-  ScopedTimer(hk_ctx* ctx, uint32_t slot) : c(ctx), on((ctx->timing_mask >> slot) & 1u) {
+  bool attached;  // the launcher attaches start / stop to the dispatch (hipExtLaunchKernel) instead of recording them around it
+  ScopedTimer(hk_ctx* ctx, uint32_t slot, bool attach = false) : c(ctx), on((ctx->timing_mask >> slot) & 1u), attached(attach) {
     if (on) {
       t.slot = slot;
       t.start = get_event(c);
       t.stop = get_event(c);
-      (void)hipEventRecord(t.start, c->stream);
+      if (!attached) (void)hipEventRecord(t.start, c->stream);
     }
   }
   ~ScopedTimer() {
     if (on) {
-      (void)hipEventRecord(t.stop, c->stream);
+      if (!attached) (void)hipEventRecord(t.stop, c->stream);
       c->pending.push_back(t);
     }
   }
@@ -733,7 +734,7 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     launch_derive_planes(c->stream, g, c->depth_plane, c->dn_g, c->W, 0, c->H);
     c->derived_dirty = false;
   }
-  ScopedTimer timer(c, pass);
+  ScopedTimer timer(c, pass, pass == HK_PASS_INDIRECT);
   switch (pass) {
     case HK_PASS_PREPASS: {
       Jitter j = prepass_jitter(c);
@@ -744,7 +745,8 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     case HK_PASS_DIRECT_LIT: launch_direct(c->stream, false, c->scene, fr, g, make_light_targets(c, 0), y0, y1, counters); break;
     case HK_PASS_DIRECT_EMISSIVE: launch_direct(c->stream, true, c->scene, fr, g, make_light_targets(c, 1), y0, y1, counters); break;
     case HK_PASS_INDIRECT:  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
-      launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, make_light_targets(c, 2), y0, y1, counters);
+      launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, make_light_targets(c, 2), y0, y1, counters,
+                      timer.on ? timer.t.start : nullptr, timer.on ? timer.t.stop : nullptr);
       break;
     case HK_PASS_EMISSIVE_SPATIAL_REUSE: launch_spatial(c->stream, true, c->scene, fr, g, make_light_targets(c, 1), y0, y1); break;
     case HK_PASS_INDIRECT_SPATIAL_REUSE: launch_spatial(c->stream, false, c->scene, fr, g, make_light_targets(c, 2), y0, y1); break;

@@ -91,7 +91,7 @@ void launch_albedo(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr,
 void launch_direct(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                    int y0, int y1, unsigned long long* counters);
 void launch_indirect(hipStream_t st, bool multiple_bounces, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g,
-                     const hkd::LightTargets& t, int y0, int y1, unsigned long long* counters);
+                     const hkd::LightTargets& t, int y0, int y1, unsigned long long* counters, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                     int y0, int y1);
 void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);

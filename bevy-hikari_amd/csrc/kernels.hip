@@ -18,6 +18,7 @@
 // (dispatcher: block b -> XCD b % 8) form a contiguous range of the image and neighbouring tiles
 // share that XCD's L2 for the gather passes.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 
@@ -729,15 +730,17 @@ void launch_direct(hipStream_t st, bool emissive_lit, const DScene& sc, const DF
   if (emissive_lit) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
 #undef HK_LAUNCH
 }
+// start / stop (optional): events attached to the dispatch itself (hipExtLaunchKernel) - they take the kernel's own
+// begin / end timestamps without the two extra barrier packets of hipEventRecord around it
 void launch_indirect(hipStream_t st, bool multiple_bounces, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1,
-                     unsigned long long* counters) {
+                     unsigned long long* counters, hipEvent_t start, hipEvent_t stop) {
   if (y1 <= y0) return;
   dim3 grid = grid_for(fr.rw, y1 - y0);
   const size_t lds = lds_bytes_for(sc);
-#define HK_LAUNCH(M)                                                                                                         \
-  if (counters) hipLaunchKernelGGL((k_indirect<M, true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);      \
-  else if (lds) hipLaunchKernelGGL((k_indirect<M, false, true>), grid, dim3(256), lds, st, sc, fr, g, t, y0, y1, counters);    \
-  else hipLaunchKernelGGL((k_indirect<M, false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+#define HK_LAUNCH(M)                                                                                                                              \
+  if (counters) hipExtLaunchKernelGGL((k_indirect<M, true, false>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);      \
+  else if (lds) hipExtLaunchKernelGGL((k_indirect<M, false, true>), grid, dim3(256), (uint32_t)lds, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);    \
+  else hipExtLaunchKernelGGL((k_indirect<M, false, false>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);
   if (multiple_bounces) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
 #undef HK_LAUNCH
 }
