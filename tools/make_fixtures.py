@@ -251,6 +251,20 @@ def make_flight_helmet(tex_size=256):
     print(f"flight_helmet: {len(j['meshes'])} meshes, {ntri} tris, {len(images)} textures {tex_size}^2, {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def make_cornell_screenshot():
+    """assets/screenshots/cornell.png - the ONE output of the reference itself that ships with it (800x600, taken
+    from examples/cornell.rs with the orbit camera dollied in and the short box's material edited in the inspector) -
+    box-filtered to 200x150 RGB8 for tests/test_reference_screenshot.py.  Not a golden vector (no settings, frame
+    count or camera pose are recorded), but it does pin the conventions no oracle of ours could: projection, scene
+    transform, emitter strength, tone mapping and display encoding."""
+    from PIL import Image
+
+    im = Image.open(os.path.join(REF, "assets", "screenshots", "cornell.png")).convert("RGB").resize((200, 150), Image.BOX)
+    out = os.path.join(ROOT, "tests", "golden", "reference_cornell_screenshot_200x150.npz")
+    np.savez_compressed(out, rgb=np.asarray(im, dtype=np.uint8))
+    print("cornell screenshot:", os.path.getsize(out), "bytes")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference checkout not present; fixtures are already committed")
@@ -259,3 +273,4 @@ if __name__ == "__main__":
     make_cornell()
     make_cornell_bin()
     make_flight_helmet()
+    make_cornell_screenshot()
