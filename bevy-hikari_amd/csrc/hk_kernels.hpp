@@ -60,13 +60,18 @@ __device__ __forceinline__ float4 denoise_geometry(uint32_t packed_normal, float
 
 struct Pixel { int x, y; bool valid; };
 
+// XCD_BANDS = true: linear workgroup ids are remapped so that each XCD (dispatcher: block b -> XCD b % 8) works on one
+// contiguous eighth of the image and gather passes find their neighbours' data in that XCD's L2.  false: tiles go
+// round-robin over the XCDs - for the ray kernels, whose cost per tile varies a lot and which gather nothing from
+// neighbouring pixels, balance across the XCDs is worth more than locality.
+template <bool XCD_BANDS = true>
 __device__ __forceinline__ Pixel pixel_of_thread(int width, int row_begin, int row_end) {
   const int tiles_x = (width + 15) >> 4;
-  // XCD-aware remap of the linear workgroup id
   const uint32_t nb = gridDim.x;
   uint32_t b = blockIdx.x;
   const uint32_t per = nb >> 3;
-  if (per > 0 && b < per * 8u) b = (b & 7u) * per + (b >> 3);
+  // (a launch of a few workgroups per CU - one band of a multi-GPU split - has nothing to balance: keep the bands)
+  if ((XCD_BANDS || nb < 2048u) && per > 0 && b < per * 8u) b = (b & 7u) * per + (b >> 3);
   const int tile_x = (int)(b % (uint32_t)tiles_x), tile_y = (int)(b / (uint32_t)tiles_x);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   Pixel p;

@@ -97,7 +97,7 @@ template <bool COUNT, bool LDS>
 __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
                                                   unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
-  const Pixel px = pixel_of_thread(fr.dw, row_begin, row_end);
+  const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
   RayCounters rc{0, 0};
   uint32_t primary = 0;
   if (px.valid) {
@@ -194,7 +194,7 @@ template <bool EMISSIVE_LIT, bool COUNT, bool LDS>
 __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                      unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
-  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
   RayCounters rc{0, 0};
   if (px.valid) {
     const int x = px.x, y = px.y;
@@ -382,7 +382,7 @@ template <bool MULTIPLE_BOUNCES, bool COUNT, bool LDS>
 __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                    unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
-  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
   RayCounters rc{0, 0};
   if (px.valid) {
     const int x = px.x, y = px.y;
