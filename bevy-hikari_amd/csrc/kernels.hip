@@ -14,9 +14,11 @@
 // Thread mapping: the reference dispatches 8x8 workgroups = one wave64 per tile.  Here a
 // workgroup is 256 threads = four 8x8 wave tiles arranged 2x2 (16x16 pixels), so every wave still
 // owns a compact 8x8 tile (coherent rays, coalesced 8-pixel row segments) while a CU gets four
-// waves per workgroup slot.  Workgroup ids are remapped so that the tiles an XCD receives
-// (dispatcher: block b -> XCD b % 8) form a contiguous range of the image and neighbouring tiles
-// share that XCD's L2 for the gather passes.
+// waves per workgroup slot.  The dispatcher hands block b to XCD b % 8.  The kernels of this file take their
+// tiles in that order (pixel_of_thread<false>): the cost of a tile varies a lot (background vs geometry, trip
+// counts), so spreading neighbouring tiles over all eight XCDs keeps them equally busy - measured against giving
+// each XCD one contiguous eighth of the image (which the a-trous kernels do keep, for their neighbours' data in
+// L2): k_indirect -17 %, k_spatial_reuse -13 %, k_prepass -12 %.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -514,7 +516,7 @@ struct SpatialTaps {
 };
 template <bool EMISSIVE_LIT>
 __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, SpatialTaps taps, int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
   if (!px.valid) return;
   constexpr uint32_t SPATIAL_REUSE_COUNT = EMISSIVE_LIT ? 8u : 16u;
   const int x = px.x, y = px.y;
