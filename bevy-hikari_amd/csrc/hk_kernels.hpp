@@ -60,6 +60,36 @@ __device__ __forceinline__ float4 denoise_geometry(uint32_t packed_normal, float
 
 struct Pixel { int x, y; bool valid; };
 
+// A wave's 64 reservoir records, written as full cache lines.  A lane holds its pixel's 64-B record in four 16-B
+// chunks; storing them directly makes every store instruction touch 64 different lines, 16 B each, and the L2 has to
+// stitch the lines together (nontemporal stores, which skip that, run these kernels 2x slower).  Here the wave
+// transposes through LDS: instruction k writes chunks 64k..64k+63 of the tile in memory order, i.e. two rows of
+// eight pixels = 2 x 512 contiguous bytes.  ALL lanes of the wave must call it (wave-uniform control flow);
+// `write` says whether this lane's record is to be stored.  lds: 4 x 65 uint4 per wave (padded against bank conflicts).
+constexpr int HK_TILE_LDS_UINT4 = 4 * 65;
+__device__ __forceinline__ void store_packed_tile(uint4* lds, PackedReservoir* __restrict__ buf, int width, const Pixel& px, const PackedReservoir& p, bool write) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long wmask = __ballot(write);
+  if (wmask == 0ull) return;
+  lds[0 * 65 + lane] = make_uint4(p.radiance.x, p.radiance.y, p.random.x, p.random.y);
+  lds[1 * 65 + lane] = make_uint4(f2u(p.visible_position.x), f2u(p.visible_position.y), f2u(p.visible_position.z), f2u(p.visible_position.w));
+  lds[2 * 65 + lane] = make_uint4(f2u(p.sample_position.x), f2u(p.sample_position.y), f2u(p.sample_position.z), f2u(p.sample_position.w));
+  lds[3 * 65 + lane] = make_uint4(p.visible_normal, p.sample_normal, p.reservoir.x, p.reservoir.y);
+  __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order; this only pins the compiler's schedule
+  // tile origin: this lane's pixel minus its position in the 8x8 tile (valid or not, the arithmetic is the same)
+  const int tile_x0 = px.x - (lane & 7), tile_y0 = px.y - (lane >> 3);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int m = k * 64 + lane, record = m >> 2, part = m & 3;
+    const uint4 v = lds[part * 65 + record];
+    if ((wmask >> record) & 1ull) {
+      const int x = tile_x0 + (record & 7), y = tile_y0 + (record >> 3);
+      reinterpret_cast<uint4*>(buf + (x + width * y))[part] = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // the next call reuses the buffer
+}
+
 // XCD_BANDS = true: linear workgroup ids are remapped so that each XCD (dispatcher: block b -> XCD b % 8) works on one
 // contiguous eighth of the image and gather passes find their neighbours' data in that XCD's L2.  false: tiles go
 // round-robin over the XCDs - for the ray kernels, whose cost per tile varies a lot and which gather nothing from

@@ -198,6 +198,9 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
   RayCounters rc{0, 0};
+  __shared__ uint4 tile_lds[4][HK_TILE_LDS_UINT4];
+  PackedReservoir out = pack_reservoir(zero_reservoir());  // what goes to t.current at the end (and, for background pixels, to both spatial buffers)
+  bool write_current = false, background = false;
   if (px.valid) {
     const int x = px.x, y = px.y;
     const int index = x + fr.rw * y;
@@ -214,10 +217,9 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
     if (depth < HK_F32_EPSILON) {  // light.wgsl:1058-1069
       Reservoir r = zero_reservoir();
       set_reservoir(r, s, 0.0f);
-      const PackedReservoir pr = pack_reservoir(r);
-      store_packed(t.current, index, pr);
-      store_packed(t.spatial, index, pr);
-      store_packed(t.previous_spatial, index, pr);
+      out = pack_reservoir(r);
+      write_current = true;
+      background = true;
       t.variance[index] = 0.0f;
       t.render[index] = make_uint2(0u, 0u);
     } else {
@@ -304,7 +306,10 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
       r.lifetime += 1.0f;
 
       t.variance[index] = reservoir_variance(r);
-      if (fr.temporal_reuse > 0u) store_packed(t.current, index, pack_reservoir(r));
+      if (fr.temporal_reuse > 0u) {
+        out = pack_reservoir(r);
+        write_current = true;
+      }
 
       Surface surface = retreive_surface(sc, im_y, F2(velocity_uv.z, velocity_uv.w));
       f3 view_direction = calculate_view(fr, position);
@@ -314,6 +319,11 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
       t.render[index] = pack_f16x4(F4(out_color, 1.0f));
     }
   }
+  // the per-pixel records leave as whole cache lines (store_packed_tile); every lane of the wave gets here
+  uint4* lds = tile_lds[threadIdx.x >> 6];
+  store_packed_tile(lds, t.current, fr.rw, px, out, write_current);
+  store_packed_tile(lds, t.spatial, fr.rw, px, out, background);
+  store_packed_tile(lds, t.previous_spatial, fr.rw, px, out, background);
   flush_counters<COUNT>(rc, 0, counters);
 }
 
