@@ -142,7 +142,8 @@ struct hk_ctx {
   // private planes (no HkBuffer id): derived G-buffer planes and the denoiser's per-channel sets used
   // when all channels of a level run in one launch (the exposed internals hold the LAST channel, which
   // is what they hold after the reference's channel-by-channel loop)
-  float* depth_plane = nullptr;
+  float* depth_plane = nullptr;       // position.w of the current frame's G-buffer (4-B taps)
+  float* prev_depth_plane = nullptr;  // ... of the previous frame's (follows the frame parity like HK_BUF_PREVIOUS_POSITION)
   void* dn_g = nullptr;
   void* dn_extra[2][4] = {};
   float* dn_extra_var[2] = {};
@@ -207,6 +208,8 @@ int free_screen(hk_ctx* c) {
     c->buf_bytes[b] = 0;
   }
   if (c->depth_plane) (void)hipFree(c->depth_plane);
+  if (c->prev_depth_plane) (void)hipFree(c->prev_depth_plane);
+  c->prev_depth_plane = nullptr;
   if (c->dn_g) (void)hipFree(c->dn_g);
   c->depth_plane = nullptr;
   c->dn_g = nullptr;
@@ -788,6 +791,7 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       ab.position = c->buf[HK_BUF_POSITION]; ab.velocity_uv = c->buf[HK_BUF_VELOCITY_UV];
       ab.previous_position = c->buf[HK_BUF_PREVIOUS_POSITION]; ab.previous_velocity_uv = c->buf[HK_BUF_PREVIOUS_VELOCITY_UV];
       ab.instance_material = c->buf[HK_BUF_INSTANCE_MATERIAL];
+      ab.depth = c->depth_plane; ab.previous_depth = c->prev_depth_plane;
       ab.full_w = c->W; ab.full_h = c->H;
       if (pass == HK_PASS_SMAA_TU4X) {
         ab.render = c->buf[HK_BUF_TONE_MAPPED]; ab.render_w = c->RW; ab.render_h = c->RH;
@@ -1013,6 +1017,8 @@ int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
   const size_t nf = (size_t)c->W * c->H, nr = (size_t)c->RW * c->RH;
   HK_HIP(hipMalloc((void**)&c->depth_plane, nf * 4));
   HK_HIP(hipMemset(c->depth_plane, 0, nf * 4));
+  HK_HIP(hipMalloc((void**)&c->prev_depth_plane, nf * 4));
+  HK_HIP(hipMemset(c->prev_depth_plane, 0, nf * 4));
   HK_HIP(hipMalloc(&c->dn_g, nf * 16));
   HK_HIP(hipMemset(c->dn_g, 0, nf * 16));
   for (int k = 0; k < 2; ++k) {
@@ -1048,6 +1054,7 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
   // Work already enqueued captured its pointers at launch, so swapping here needs no synchronisation.
   if ((f->number & 1u) != c->mapped_parity) {
     std::swap(c->buf[HK_BUF_POSITION], c->buf[HK_BUF_PREVIOUS_POSITION]);
+    std::swap(c->depth_plane, c->prev_depth_plane);
     std::swap(c->buf[HK_BUF_VELOCITY_UV], c->buf[HK_BUF_PREVIOUS_VELOCITY_UV]);
     std::swap(c->buf[HK_BUF_TONE_MAPPED], c->buf[HK_BUF_PREVIOUS_TONE_MAPPED]);
     std::swap(c->buf[HK_BUF_TAA_OUTPUT], c->buf[HK_BUF_PREVIOUS_TAA_OUTPUT]);

@@ -136,6 +136,7 @@ void launch_tone_mapping(hipStream_t st, const hkd::DFrame& fr, const void* dire
 // anti-aliasing tail (kernels_aa.hip): raw plane pointers + sizes of one dispatch's bindings
 struct AaBuffers {
   const void *position, *velocity_uv, *previous_position, *previous_velocity_uv, *instance_material;  // full size
+  const float *depth, *previous_depth;  // position.w / previous_position.w alone: the depth-only taps read 4 B instead of 16
   int full_w, full_h;
   const void* render;           // rgba16f: tone_mapping_output[current] (SMAA) / TAA input
   int render_w, render_h;

@@ -62,9 +62,18 @@ HKD f4 sample_linear(const Plane16& t, f2 uv) {
   const f4 t00 = texel(t, f.x0, f.y0), t10 = texel(t, f.x1, f.y0), t01 = texel(t, f.x0, f.y1), t11 = texel(t, f.x1, f.y1);
   return mix4(mix4(t00, t10, f.fx), mix4(t01, t11, f.fx), f.fy);
 }
-HKD f4 gather_w(const Plane32& t, f2 uv) {  // textureGather(3, position-like texture, ..)
+struct PlaneW {  // the w component of a position texture (clip depth) as its own f32 plane
+  const float* __restrict__ p;
+  int w, h;
+};
+HKD f4 gather_w(const PlaneW& t, f2 uv) {  // textureGather(3, position-like texture, ..)
   const Footprint f = footprint(t.w, t.h, uv);
-  return F4(t.p[f.x0 + t.w * f.y1].w, t.p[f.x1 + t.w * f.y1].w, t.p[f.x1 + t.w * f.y0].w, t.p[f.x0 + t.w * f.y0].w);
+  return F4(t.p[f.x0 + t.w * f.y1], t.p[f.x1 + t.w * f.y1], t.p[f.x1 + t.w * f.y0], t.p[f.x0 + t.w * f.y0]);
+}
+HKD float sample_nearest_w(const PlaneW& t, f2 uv) {
+  int x, y;
+  nearest_coords(t.w, t.h, uv, &x, &y);
+  return t.p[x + t.w * y];
 }
 HKD void load_loose(const uint2* p, int w, int h, int x, int y, f4* out) {  // textureLoad: zeros out of bounds
   *out = (x >= 0 && y >= 0 && x < w && y < h) ? unpack_f16x4(p[x + w * y]) : F4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -106,14 +115,14 @@ HKD f4 depth_ratio4(float current, f4 previous) {  // select(current / previous,
             previous.z == 0.0f ? 1.0f : current / previous.z, previous.w == 0.0f ? 1.0f : current / previous.w);
 }
 // taa.wgsl:54-73, smaa.wgsl:54-73
-HKD f2 nearest_velocity(const Plane32& position, const Plane32& velocity_uv, f2 uv, f2 texel_size) {
+HKD f2 nearest_velocity(const PlaneW& position, const Plane32& velocity_uv, f2 uv, f2 texel_size) {
   f4 depths;
-  depths.x = sample_nearest(position, uv + F2(texel_size.x, texel_size.y)).w;
-  depths.y = sample_nearest(position, uv + F2(-texel_size.x, texel_size.y)).w;
-  depths.z = sample_nearest(position, uv + F2(texel_size.x, -texel_size.y)).w;
-  depths.w = sample_nearest(position, uv + F2(-texel_size.x, -texel_size.y)).w;
+  depths.x = sample_nearest_w(position, uv + F2(texel_size.x, texel_size.y));
+  depths.y = sample_nearest_w(position, uv + F2(-texel_size.x, texel_size.y));
+  depths.z = sample_nearest_w(position, uv + F2(texel_size.x, -texel_size.y));
+  depths.w = sample_nearest_w(position, uv + F2(-texel_size.x, -texel_size.y));
   const float max_depth = fmax_(fmax_(depths.x, depths.y), fmax_(depths.z, depths.w));
-  const float depth = sample_nearest(position, uv).w;
+  const float depth = sample_nearest_w(position, uv);
   f2 offset = F2(0.0f, 0.0f);
   if (depth < max_depth) {
     const f4 eq = F4(depths.x == max_depth ? 1.0f : 0.0f, depths.y == max_depth ? 1.0f : 0.0f, depths.z == max_depth ? 1.0f : 0.0f,
@@ -128,6 +137,7 @@ HKD f2 nearest_velocity(const Plane32& position, const Plane32& velocity_uv, f2 
 
 struct AaTargets {
   Plane32 position, velocity_uv, previous_position, previous_velocity_uv;
+  PlaneW depth, previous_depth;  // position.w / previous_position.w
   const float2* __restrict__ instance_material;  // full size (position.w x position.h)
   Plane16 render, previous_render;
   uint2* output;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256) void k_taa_jasmine(AaTargets t, float blend, f
   const f2 uv = F2(((float)x + 0.5f) / size.x, ((float)y + 0.5f) / size.y);
   const f4 original_color = sample_nearest(t.render, uv);
   const f3 current_color = rgb(original_color);
-  const f2 velocity = nearest_velocity(t.position, t.velocity_uv, uv, render_texel);
+  const f2 velocity = nearest_velocity(t.depth, t.velocity_uv, uv, render_texel);
   const f2 previous_uv = uv - velocity;
   const bool boundary_miss = fabsf(previous_uv.x - 0.5f) > 0.5f || fabsf(previous_uv.y - 0.5f) > 0.5f;
   const f4 current_position_depth = sample_nearest(t.position, uv);
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(256) void k_taa_jasmine(AaTargets t, float blend, f
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const f2 bias = i == 0 ? F2(0.0f, 0.0f) : F2((i & 1) ? 1.5f : -1.5f, i <= 2 ? 1.5f : -1.5f) * texel_size;
-    const f4 previous_depths = gather_w(t.previous_position, previous_uv + bias);
+    const f4 previous_depths = gather_w(t.previous_depth, previous_uv + bias);
     const f4 depth_ratio = depth_ratio4(current_position_depth.w, previous_depths);
     has_content = has_content || any_gt(previous_depths, 0.0f);
     depth_miss = depth_miss || any_lt(depth_ratio, 0.95f);
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void k_smaa_tu4x(AaTargets t, uint32_t frame_n
   const f3 current_color = rgb(sample_nearest(t.render, uv));
   const int pox = 2 * x + previous_jitter, poy = 2 * y + previous_jitter;
   const f2 previous_output_uv = F2(((float)pox + 0.5f) / output_size.x, ((float)poy + 0.5f) / output_size.y);
-  const f2 velocity = nearest_velocity(t.position, t.velocity_uv, previous_output_uv, deferred_texel);
+  const f2 velocity = nearest_velocity(t.depth, t.velocity_uv, previous_output_uv, deferred_texel);
   const f2 previous_reprojected_uv = previous_output_uv - velocity;
   f3 previous_color = rgb(sample_nearest(t.previous_render, previous_reprojected_uv));
   const bool boundary_miss = fabsf(previous_reprojected_uv.x - 0.5f) > 0.5f || fabsf(previous_reprojected_uv.y - 0.5f) > 0.5f;
@@ -238,12 +248,12 @@ __global__ __launch_bounds__(256) void k_smaa_tu4x(AaTargets t, uint32_t frame_n
   };
   const float current_instance = instance_at(previous_output_uv);
   bool instance_miss = false;
-  const float current_depth = sample_nearest(t.position, previous_output_uv).w;
+  const float current_depth = sample_nearest_w(t.depth, previous_output_uv);
   bool depth_miss = current_depth == 0.0f;
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const f2 bias = i == 0 ? F2(0.0f, 0.0f) : F2((i & 1) ? 2.5f : -2.5f, i <= 2 ? 2.5f : -2.5f) * texel_size;
-    const f4 previous_depths = gather_w(t.previous_position, previous_reprojected_uv + bias);
+    const f4 previous_depths = gather_w(t.previous_depth, previous_reprojected_uv + bias);
     const f4 depth_ratio = depth_ratio4(current_depth, previous_depths);
     const bool any_ratio = any_lt(depth_ratio, 0.95f);
     depth_miss = depth_miss || any_ratio;
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(256) void k_smaa_tu4x(AaTargets t, uint32_t frame_n
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const f2 bias = i == 0 ? F2(0.0f, 0.0f) : F2((i & 1) ? 2.5f : -2.5f, i <= 2 ? 2.5f : -2.5f) * texel_size;
-      const f4 ds = gather_w(t.position, previous_output_uv + bias);
+      const f4 ds = gather_w(t.depth, previous_output_uv + bias);
       const f4 d = F4(current_depth - ds.x, current_depth - ds.y, current_depth - ds.z, current_depth - ds.w);
       const float dds = sqrtf(dot(d, d));
       if (dds < min_ds) uv_bias = bias;
@@ -331,6 +341,8 @@ static AaTargets make_targets(const AaBuffers& b) {
   t.velocity_uv = Plane32{(const float4*)b.velocity_uv, b.full_w, b.full_h};
   t.previous_position = Plane32{(const float4*)b.previous_position, b.full_w, b.full_h};
   t.previous_velocity_uv = Plane32{(const float4*)b.previous_velocity_uv, b.full_w, b.full_h};
+  t.depth = PlaneW{b.depth, b.full_w, b.full_h};
+  t.previous_depth = PlaneW{b.previous_depth, b.full_w, b.full_h};
   t.instance_material = (const float2*)b.instance_material;
   t.render = Plane16{(const uint2*)b.render, b.render_w, b.render_h};
   t.previous_render = Plane16{(const uint2*)b.previous_render, b.previous_w, b.previous_h};
