@@ -158,3 +158,27 @@ def run_case_with_host_gbuffer(source, plugin, case):
             plugin.engine.write(b, source.engine.read(b))
         plugin.engine.frame_render(frame, view, pview, case.lights, s.to_c(), F.FRAME_EXTERNAL_GBUFFER | (F.FRAME_ANTIALIAS if case.antialias else 0))
     plugin.engine.wait()
+
+
+def random_case(seed):
+    """Seeded point of the HikariSettings space (lib.rs:402-433) x scene x odd image size x AA tail, for the sweeps."""
+    rng = np.random.default_rng(1000 + seed)
+    ratio = float(rng.choice([1.0, 1.25, 1.5, 2.0]))
+    upscale = hk.Upscale.SmaaTu4x(ratio) if rng.random() < 0.5 else hk.Upscale.Fsr1(ratio, 0.2)
+    s = hk.HikariSettings(
+        direct_validate_interval=int(rng.integers(1, 5)), emissive_validate_interval=int(rng.integers(1, 7)),
+        max_temporal_reuse_count=int(rng.choice([1, 8, 50])), max_spatial_reuse_count=int(rng.choice([4, 100, 800])),
+        max_reservoir_lifetime=float(rng.choice([0.5, 3.0, 100.0])), solar_angle=float(rng.choice([0.0, 0.046, 0.2])),
+        indirect_bounces=int(rng.integers(0, 4)), max_indirect_luminance=float(rng.choice([0.5, 10.0])),
+        temporal_reuse=bool(rng.random() < 0.8), emissive_spatial_reuse=bool(rng.random() < 0.5),
+        indirect_spatial_reuse=bool(rng.random() < 0.7), denoise=bool(rng.random() < 0.7),
+        taa=hk.Taa.Jasmine if rng.random() < 0.6 else hk.Taa.NONE, upscale=upscale)
+    w, h = int(rng.integers(33, 120)), int(rng.integers(25, 90))
+    if rng.random() < 0.5:
+        scene, cam, lights = cornell_scene(), hk.cornell_camera(w, h), hk.lights_uniform()
+    else:
+        scene, sun = synthetic_scene(n_boxes=8, n_spheres=3, n_emitters=2, sphere_rings=5, sphere_segs=6, textured=bool(rng.random() < 0.5))
+        cam, lights = synthetic_camera(w, h), hk.lights_uniform(directional=sun)
+    antialias = bool(rng.random() < 0.6)
+    first = int(rng.integers(1, 7))
+    return Case(f"random{seed}", scene, cam, s, lights=lights, frames=range(first, first + 3), antialias=antialias)

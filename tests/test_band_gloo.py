@@ -159,11 +159,11 @@ def _aa_worker(rank, world, port, case_name, out_dir):
     import bevy_hikari_amd as hk
     from bevy_hikari_amd import _ffi as F
     from bevy_hikari_amd.distributed import BandRenderer
-    from cases import make_case
+    from cases import make_case, random_case
     from oracle_lib import oracle_engine, set_threads
 
     set_threads(2)
-    case = make_case(case_name)
+    case = random_case(int(case_name[6:])) if case_name.startswith("random") else make_case(case_name)
     s = case.settings
     e = oracle_engine()
     e.upload_noise()
@@ -173,7 +173,7 @@ def _aa_worker(rank, world, port, case_name, out_dir):
     r = BandRenderer(e, rank, world, backend_device="cpu")
     view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
     for n in case.frames:
-        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, antialias=True)
+        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, antialias=case.antialias)
     _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
     b0, b1 = r.band(rh)
     out = {"b0": b0, "b1": b1, "rh": rh}
@@ -188,15 +188,17 @@ def _aa_worker(rank, world, port, case_name, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name", [(2, "cornell_aa_default"), (3, "yard_aa_smaa2x")])
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_aa_default"), (3, "yard_aa_smaa2x"), (2, "random3"), (3, "random7"), (4, "random12"),
+                                              (3, "random21"), (2, "random30"), (4, "random35")])
 def test_antialias_bands_equal_single_rank(tmp_path, world, case_name):
-    """SMAA Tu4x + TAA on bands (exchange D): the union of the bands' output rows equals the single-rank image bit
-    for bit, for a static camera."""
-    from cases import make_case, run_case, snapshot
+    """All four stages on bands - for the named cases SMAA Tu4x + TAA (exchange D), for the random ones whatever the
+    seeded settings say (aprons depend on them: emissive spatial reuse, denoise off, ratio != 1, 0 bounces ...): the
+    union of the bands' rows equals the single-rank image bit for bit, for a static camera."""
+    from cases import make_case, random_case, run_case, snapshot
     from oracle_lib import oracle_plugin
 
     mp.spawn(_aa_worker, args=(world, _free_port(), case_name, str(tmp_path)), nprocs=world, join=True)
-    case = make_case(case_name)
+    case = random_case(int(case_name[6:])) if case_name.startswith("random") else make_case(case_name)
     ref = oracle_plugin()
     run_case(ref, case)
     full = snapshot(ref)

@@ -552,35 +552,17 @@ def test_second_stream_overlap_changes_no_bit_and_joins_on_reads():
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_settings_vs_oracle(seed):
-    """Seeded sweep over the HikariSettings space (lib.rs:402-433): bounce counts, reuse switches, validation
+    """Seeded sweep over the HikariSettings space (cases.random_case): bounce counts, reuse switches, validation
     intervals, reuse caps, lifetimes, denoise, upscale kind / ratio, TAA, odd image sizes, with and without the
     anti-aliasing tail - three frames each, every buffer bit for bit."""
-    rng = np.random.default_rng(1000 + seed)
-    ratio = float(rng.choice([1.0, 1.25, 1.5, 2.0]))
-    upscale = hk.Upscale.SmaaTu4x(ratio) if rng.random() < 0.5 else hk.Upscale.Fsr1(ratio, 0.2)
-    s = hk.HikariSettings(
-        direct_validate_interval=int(rng.integers(1, 5)), emissive_validate_interval=int(rng.integers(1, 7)),
-        max_temporal_reuse_count=int(rng.choice([1, 8, 50])), max_spatial_reuse_count=int(rng.choice([4, 100, 800])),
-        max_reservoir_lifetime=float(rng.choice([0.5, 3.0, 100.0])), solar_angle=float(rng.choice([0.0, 0.046, 0.2])),
-        indirect_bounces=int(rng.integers(0, 4)), max_indirect_luminance=float(rng.choice([0.5, 10.0])),
-        temporal_reuse=bool(rng.random() < 0.8), emissive_spatial_reuse=bool(rng.random() < 0.5),
-        indirect_spatial_reuse=bool(rng.random() < 0.7), denoise=bool(rng.random() < 0.7),
-        taa=hk.Taa.Jasmine if rng.random() < 0.6 else hk.Taa.NONE, upscale=upscale)
-    w, h = int(rng.integers(33, 120)), int(rng.integers(25, 90))
-    if rng.random() < 0.5:
-        scene, cam, lights = hk.load_cornell(), hk.cornell_camera(w, h), hk.lights_uniform()
-    else:
-        from bevy_hikari_amd.scenes import synthetic_camera, synthetic_scene
+    from cases import random_case
 
-        scene, sun = synthetic_scene(n_boxes=8, n_spheres=3, n_emitters=2, sphere_rings=5, sphere_segs=6, textured=bool(rng.random() < 0.5))
-        cam, lights = synthetic_camera(w, h), hk.lights_uniform(directional=sun)
-    antialias = bool(rng.random() < 0.6)
-    first = int(rng.integers(1, 7))
+    case = random_case(seed)
     gpu, cpu = hk.HikariPlugin(device=0), oracle()
     for p in (gpu, cpu):
-        p.set_scene(scene)
-    for n in range(first, first + 3):
+        p.set_scene(case.scene)
+    for n in case.frames:
         for p in (gpu, cpu):
-            p.render(cam, s, lights=lights, frame_number=n, antialias=antialias)
+            p.render(case.camera, case.settings, lights=case.lights, frame_number=n, antialias=case.antialias)
         bad = diff_buffers(snapshot(gpu), snapshot(cpu))
-        assert bad == {}, (seed, n, s, (w, h), antialias, bad)
+        assert bad == {}, (seed, n, case.settings, (case.camera.width, case.camera.height), case.antialias, bad)
