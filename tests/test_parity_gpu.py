@@ -193,9 +193,9 @@ def _gpu_band_worker(rank, world, port, case_name, out_dir):
 
     import bevy_hikari_amd as hk
     from bevy_hikari_amd.distributed import BandRenderer
-    from cases import ALL_BUFFERS, make_case
+    from cases import ALL_BUFFERS, make_case, random_case
 
-    case = make_case(case_name)
+    case = random_case(int(case_name[6:])) if case_name.startswith("random") else make_case(case_name)
     s = case.settings
     e = hk.Engine(device=0)
     e.upload_noise()
@@ -228,7 +228,7 @@ def _gpu_band_worker(rank, world, port, case_name, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun"), (3, "cornell_aa_default")])
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun"), (3, "cornell_aa_default"), (2, "random7"), (4, "random12"), (3, "random21")])
 def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
     """The band-sharded GPU path (hk_set_band + hk_frame_stage + halo exchange) on ONE GPU: every
     rank renders its band on device 0, halos travel over gloo (staged through host memory because
@@ -242,7 +242,9 @@ def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_gpu_band_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
-    case = make_case(case_name)
+    from cases import random_case
+
+    case = random_case(int(case_name[6:])) if case_name.startswith("random") else make_case(case_name)
     ref = hk.HikariPlugin(device=0)
     run_case(ref, case)
     full = snapshot(ref)
