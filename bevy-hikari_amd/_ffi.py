@@ -24,16 +24,16 @@ BUF_POSITION, BUF_NORMAL, BUF_DEPTH_GRADIENT, BUF_INSTANCE_MATERIAL, BUF_VELOCIT
 BUF_VARIANCE0, BUF_RENDER0, BUF_RESERVOIR0 = 6, 9, 12
 BUF_DENOISE_INTERNAL0, BUF_DENOISE_INTERNAL_VARIANCE, BUF_DENOISE_RENDER0, BUF_TONE_MAPPED = 22, 26, 27, 30
 (BUF_PREVIOUS_POSITION, BUF_PREVIOUS_VELOCITY_UV, BUF_PREVIOUS_TONE_MAPPED, BUF_UPSCALE_OUTPUT, BUF_TAA_OUTPUT, BUF_PREVIOUS_TAA_OUTPUT,
- BUF_COUNT) = range(31, 38)
+ BUF_UPSCALE_SHARPENED, BUF_COUNT) = range(31, 39)
 # HkPass
 (PASS_PREPASS, PASS_FULL_SCREEN_ALBEDO, PASS_DIRECT_LIT, PASS_DIRECT_EMISSIVE, PASS_INDIRECT, PASS_EMISSIVE_SPATIAL_REUSE,
  PASS_INDIRECT_SPATIAL_REUSE, PASS_DEMODULATION, PASS_DENOISE_L0, PASS_DENOISE_L1, PASS_DENOISE_L2, PASS_DENOISE_L3,
- PASS_TONE_MAPPING, PASS_SMAA_TU4X, PASS_SMAA_TU4X_EXTRAPOLATE, PASS_TAA_JASMINE, PASS_COUNT) = range(17)
+ PASS_TONE_MAPPING, PASS_SMAA_TU4X, PASS_SMAA_TU4X_EXTRAPOLATE, PASS_TAA_JASMINE, PASS_FSR_EASU, PASS_FSR_RCAS, PASS_COUNT) = range(19)
 PASS_NAMES = ["prepass", "full_screen_albedo", "direct_lit", "direct_emissive", "indirect_lit_ambient", "emissive_spatial_reuse",
               "indirect_spatial_reuse", "demodulation", "denoise_l0", "denoise_l1", "denoise_l2", "denoise_l3", "tone_mapping",
-              "smaa_tu4x", "smaa_tu4x_extrapolate", "taa_jasmine"]
+              "smaa_tu4x", "smaa_tu4x_extrapolate", "taa_jasmine", "fsr_easu", "fsr_rcas"]
 # HkStage
-STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_ANTIALIAS, STAGE_COUNT = range(5)
+STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_ANTIALIAS, STAGE_UPSCALE, STAGE_COUNT = range(6)
 CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM = 1, 2, 4, 8
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS = 1, 2
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
@@ -41,7 +41,7 @@ TAA_JASMINE, TAA_NONE = 0, 1
 UPSCALE_FSR1, UPSCALE_SMAA_TU4X = 0, 1
 NO_TEXTURE = 0xFFFFFFFF
 ADDRESS_CLAMP_TO_EDGE, ADDRESS_REPEAT, ADDRESS_MIRROR_REPEAT = 0, 1, 2
-TIMING_SLOTS = 16
+TIMING_SLOTS = 24
 
 f32, u32, u64 = C.c_float, C.c_uint32, C.c_uint64
 
@@ -156,7 +156,7 @@ _SIGNATURES = {
     "upload_noise": [_vp, _vp, C.c_size_t],
     "upload_textures": [_vp, P(HkImageDesc), u32],
     "resize": [_vp, u32, u32, f32],
-    "set_view_options": [_vp, u32, u32],
+    "set_view_options": [_vp, u32, u32, f32],
     "frame_begin": [_vp, P(HkFrame), P(HkView), P(HkPreviousView), P(HkLights)],
     "pass_run": [_vp, u32, u32, u32, u32],
     "frame_stage": [_vp, u32, P(HkSettings), u32],

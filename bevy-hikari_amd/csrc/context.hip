@@ -156,6 +156,7 @@ struct hk_ctx {
   HkLights lights{};
   bool have_frame = false;
   uint32_t taa = HK_TAA_JASMINE, upscale_kind = HK_UPSCALE_SMAA_TU4X;
+  float upscale_sharpness = 0.0f;
 
   uint32_t band_index = 0, band_count = 1;
 
@@ -178,7 +179,8 @@ namespace {
 // scale in effect after the upscale match (post_process.rs:712-733): 2/ratio for SMAA Tu4x, 1/ratio for FSR1
 void buffer_dims(const hk_ctx* c, uint32_t b, int* w, int* h) {
   if (buffer_is_full_size(b)) { *w = c->W; *h = c->H; return; }
-  if (b == HK_BUF_UPSCALE_OUTPUT || (buffer_is_upscaled(b) && c->upscale_kind == HK_UPSCALE_SMAA_TU4X)) { *w = c->UW; *h = c->UH; return; }
+  if (buffer_is_upscaled(b) && c->upscale_kind == HK_UPSCALE_SMAA_TU4X) { *w = c->UW; *h = c->UH; return; }
+  if (b == HK_BUF_UPSCALE_OUTPUT) { *w = c->W; *h = c->H; return; }  // FSR1: upscale_output is created at scale 1.0 (post_process.rs:723)
   *w = c->RW;
   *h = c->RH;
 }
@@ -812,6 +814,18 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     case HK_PASS_SMAA_TU4X_EXTRAPOLATE:
       launch_smaa_tu4x_extrapolate(c->stream, c->buf[HK_BUF_UPSCALE_OUTPUT], c->UW, c->UH, c->RW, y0, y1);
       break;
+    case HK_PASS_FSR_EASU: {  // post_process.rs:1037-1040,1277-1292: taa_output[current] when TAA is on, else tone-mapped
+      const uint32_t in = c->taa == HK_TAA_JASMINE ? HK_BUF_TAA_OUTPUT : HK_BUF_TONE_MAPPED;
+      int iw, ih;
+      buffer_dims(c, in, &iw, &ih);
+      HK_REQUIRE(c->upscale_kind == HK_UPSCALE_FSR1, HK_E_INVALID, "FSR passes need upscale_kind FSR1");
+      launch_fsr_easu(c->stream, c->buf[in], iw, ih, c->buf[HK_BUF_UPSCALE_OUTPUT], c->W, c->H, y0, y1);
+      break;
+    }
+    case HK_PASS_FSR_RCAS:    // post_process.rs:1294-1308
+      HK_REQUIRE(c->upscale_kind == HK_UPSCALE_FSR1, HK_E_INVALID, "FSR passes need upscale_kind FSR1");
+      launch_fsr_rcas(c->stream, c->buf[HK_BUF_UPSCALE_OUTPUT], c->buf[HK_BUF_UPSCALE_SHARPENED], c->W, c->H, c->upscale_sharpness, y0, y1);
+      break;
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown pass %u", pass);
   }
   HK_HIP(hipGetLastError());
@@ -1035,8 +1049,9 @@ int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
   return HK_OK;
 }
 
-int hk_set_view_options(hk_ctx* c, uint32_t taa, uint32_t upscale_kind) {
+int hk_set_view_options(hk_ctx* c, uint32_t taa, uint32_t upscale_kind, float upscale_sharpness) {
   HK_REQUIRE(c && taa <= HK_TAA_NONE && upscale_kind <= HK_UPSCALE_SMAA_TU4X, HK_E_INVALID, "bad argument");
+  c->upscale_sharpness = upscale_sharpness;
   c->taa = taa;
   c->upscale_kind = upscale_kind;
   return HK_OK;
@@ -1070,6 +1085,7 @@ int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
   int rows = full_grid ? c->H : c->RH;
   if (pass == HK_PASS_TAA_JASMINE) { int w; buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &rows); }
+  if (pass == HK_PASS_FSR_EASU || pass == HK_PASS_FSR_RCAS) rows = c->H;
   const int y0 = (int)row_begin, y1 = row_end == 0 ? rows : (int)row_end;
   HK_REQUIRE(y0 >= 0 && y1 <= rows && y0 <= y1, HK_E_INVALID, "row range [%d,%d) outside 0..%d", y0, y1, rows);
   return run_pass(c, pass, arg, y0, y1);
@@ -1095,6 +1111,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
   HK_REQUIRE(c->band_count <= (uint32_t)c->RH, HK_E_INVALID, "more bands than rows");
   c->taa = st->taa;
   c->upscale_kind = st->upscale_kind;
+  c->upscale_sharpness = st->upscale_sharpness;
   uint32_t ub0, ub1;
   band_rows((uint32_t)c->RH, c->band_index, c->band_count, &ub0, &ub1);
   const int b0 = (int)ub0, b1 = (int)ub1;
@@ -1195,6 +1212,13 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       const int scale = smaa ? 2 : 1;
       HK_RUN(HK_PASS_TAA_JASMINE, 0, std::min(h, scale * b0), b1 == c->RH ? h : std::min(h, scale * b1));
     }
+  } else if (stage == HK_STAGE_UPSCALE) {              // post_process.rs:1277-1308
+    if (st->upscale_kind == HK_UPSCALE_FSR1) {
+      uint32_t w0, w1;
+      band_rows((uint32_t)c->H, c->band_index, c->band_count, &w0, &w1);
+      HK_RUN(HK_PASS_FSR_EASU, 0, std::max((int)w0 - 1, 0), std::min((int)w1 + 1, c->H));
+      HK_RUN(HK_PASS_FSR_RCAS, 0, (int)w0, (int)w1);
+    }
   } else {
     HK_REQUIRE(false, HK_E_INVALID, "unknown stage %u", stage);
   }
@@ -1207,7 +1231,10 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
   if (rc) return rc;
   for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s)
     if ((rc = hk_frame_stage(c, s, st, flags))) return rc;
-  if (flags & HK_FRAME_ANTIALIAS) return hk_frame_stage(c, HK_STAGE_ANTIALIAS, st, flags);
+  if (flags & HK_FRAME_ANTIALIAS) {
+    if ((rc = hk_frame_stage(c, HK_STAGE_ANTIALIAS, st, flags))) return rc;
+    return hk_frame_stage(c, HK_STAGE_UPSCALE, st, flags);
+  }
   return HK_OK;
 }
 

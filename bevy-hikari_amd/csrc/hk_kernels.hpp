@@ -148,5 +148,7 @@ struct AaBuffers {
 void launch_smaa_tu4x(hipStream_t st, const AaBuffers& b, uint32_t frame_number, int y0, int y1);
 void launch_smaa_tu4x_extrapolate(hipStream_t st, void* output, int out_w, int out_h, int render_w, int y0, int y1);
 void launch_taa_jasmine(hipStream_t st, const AaBuffers& b, float blend, const float clear_color[4], int y0, int y1);
+void launch_fsr_easu(hipStream_t st, const void* input, int in_w, int in_h, void* output, int out_w, int out_h, int y0, int y1);
+void launch_fsr_rcas(hipStream_t st, const void* input, void* output, int w, int h, float sharpness, int y0, int y1);
 void launch_debug_math(hipStream_t st, uint32_t op, const float* x, const float* y, float* out, size_t n);
 }  // namespace hk

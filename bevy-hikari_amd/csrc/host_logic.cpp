@@ -36,12 +36,12 @@ uint32_t buffer_bpp(uint32_t b) {
   if (b >= HK_BUF_DENOISE_RENDER0 && b < HK_BUF_DENOISE_RENDER0 + 3) return 8;
   if (b == HK_BUF_TONE_MAPPED || b == HK_BUF_PREVIOUS_TONE_MAPPED) return 8;
   if (b == HK_BUF_PREVIOUS_POSITION || b == HK_BUF_PREVIOUS_VELOCITY_UV) return 16;
-  if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT) return 8;
+  if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT || b == HK_BUF_UPSCALE_SHARPENED) return 8;
   return 0;
 }
 bool buffer_is_full_size(uint32_t b) {
   return b <= HK_BUF_ALBEDO || (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10) || b == HK_BUF_PREVIOUS_POSITION ||
-         b == HK_BUF_PREVIOUS_VELOCITY_UV;
+         b == HK_BUF_PREVIOUS_VELOCITY_UV || b == HK_BUF_UPSCALE_SHARPENED;
 }
 bool buffer_is_upscaled(uint32_t b) { return b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT; }
 
@@ -173,7 +173,7 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
   uint32_t rw, rh;
   int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
   if (rc) return rc;
-  HK_REQUIRE(rh >= band_count, HK_E_INVALID, "more bands than rows");
+  HK_REQUIRE(rh >= band_count, HK_E_INVALID, "more bands than rows");  // then height >= band_count too
   const uint32_t cap = ops ? *n_ops : 0;
   uint32_t n = 0;
   uint32_t b0, b1;
@@ -245,6 +245,18 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
         n += 1;
       }
     }
+  }
+  else if (stage == HK_STAGE_UPSCALE && st->upscale_kind == HK_UPSCALE_FSR1) {
+    // exchange E.  EASU (ffx_fsr1.h:315-441) of window row y reads input rows f-1..f+2 with f = floor(y * con0.y + con0.w),
+    // the same two f32 operations as the kernel; the band's EASU rows are its window rows +-1 for RCAS's cross.
+    uint32_t w0, w1;
+    band_rows(height, band_index, band_count, &w0, &w1);
+    const uint32_t e0 = w0 > 0 ? w0 - 1 : 0, e1 = std::min(height, w1 + 1);
+    const float ivy = (float)rh, osy = (float)height;
+    const float con0y = ivy * (1.0f / osy), con0w = 0.5f * ivy * (1.0f / osy) - 0.5f;
+    const int f_lo = (int)floorf((float)e0 * con0y + con0w) - 1, f_hi = (int)floorf((float)(e1 - 1) * con0y + con0w) + 2;
+    const uint32_t need_lo = (uint32_t)std::max(f_lo, 0), need_hi = (uint32_t)std::min(f_hi, (int)rh - 1) + 1u;
+    emit(st->taa == HK_TAA_JASMINE ? HK_BUF_TAA_OUTPUT : HK_BUF_TONE_MAPPED, rw, rh, need_lo, need_hi, band_index, band_count, ops, &n, cap);
   }
   if (ops && n > cap) {
     *n_ops = n;

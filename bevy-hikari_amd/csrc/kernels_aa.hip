@@ -3,6 +3,7 @@
 //   k_smaa_tu4x              smaa.wgsl:81-188    one thread per render pixel = one 2x2 output quad
 //   k_smaa_tu4x_extrapolate  smaa.wgsl:239-271   the two off-diagonal pixels of every quad, in place
 //   k_taa_jasmine            taa.wgsl:75-170     one thread per output pixel
+//   k_fsr_easu / k_fsr_rcas  fsr/source.zip      FSR1 upscale + sharpen, one thread per window pixel
 //
 // The reference samples textures through a nearest and a linear sampler (post_process.rs:679-690,
 // address mode clamp-to-edge).  Here every plane is a row-major array and the samplers are the
@@ -330,6 +331,163 @@ __global__ __launch_bounds__(256) void k_smaa_tu4x_extrapolate(uint2* output, in
   store_loose(output, ow, oh, bx + 1, by, y_color);
 }
 
+// ------------------------------------------------------------------------------------------
+// FidelityFX Super Resolution 1.0 (Upscale::Fsr1), the f32 path of src/shaders/fsr/source.zip:
+// ffx_fsr1.h FsrEasuF :315-441 (k_fsr_easu, one thread per window pixel, 12 taps of the scaled image) and
+// FsrRcasF :684-768 (k_fsr_rcas, 5-tap cross).  fakeTextureGather (texture_gather.glsl) reads the four texels
+// around a texel corner through four bilinear samples at texel centres; the contract takes the texels.
+// ------------------------------------------------------------------------------------------
+HKD float fsr_prx_lo_rcp(float a) { return u2f(0x7ef07ebbu - f2u(a)); }                                           // ffx_a.h APrxLoRcpF1
+HKD float fsr_prx_med_rcp(float a) { const float b = u2f(0x7ef19fffu - f2u(a)); return b * (-b * a + 2.0f); }    // APrxMedRcpF1
+HKD float fsr_prx_lo_rsq(float a) { return u2f(0x5f347d74u - (f2u(a) >> 1)); }                                    // APrxLoRsqF1
+HKD float fsr_min3(float x, float y, float z) { return fmin_(x, fmin_(y, z)); }
+HKD float fsr_max3(float x, float y, float z) { return fmax_(x, fmax_(y, z)); }
+struct FsrGather { f4 r, g, b; };
+HKD FsrGather fsr_gather(const Plane16& t, f2 p, f2 ps) {
+  const f4 s3 = sample_nearest(t, F2(p.x + ps.x, p.y + ps.y));
+  const f4 s1 = sample_nearest(t, F2(p.x - ps.x, p.y - ps.y));
+  const f4 s2 = sample_nearest(t, F2(p.x + ps.x, p.y + (-ps.y)));
+  const f4 s4 = sample_nearest(t, F2(p.x + (-ps.x), p.y + ps.y));
+  FsrGather o;
+  o.r = F4(s4.x, s3.x, s2.x, s1.x);
+  o.g = F4(s4.y, s3.y, s2.y, s1.y);
+  o.b = F4(s4.z, s3.z, s2.z, s1.z);
+  return o;
+}
+HKD void fsr_easu_tap(f3* aC, float* aW, f2 off, f2 dir, f2 len, float lob, float clp, f3 c) {  // ffx_fsr1.h:239-272
+  f2 v;
+  v.x = (off.x * (dir.x)) + (off.y * dir.y);
+  v.y = (off.x * (-dir.y)) + (off.y * dir.x);
+  v = v * len;
+  float d2 = v.x * v.x + v.y * v.y;
+  d2 = fmin_(d2, clp);
+  float wB = (float)(2.0 / 5.0) * d2 + -1.0f;
+  float wA = lob * d2 + -1.0f;
+  wB *= wB;
+  wA *= wA;
+  wB = (float)(25.0 / 16.0) * wB + (float)(-(25.0 / 16.0 - 1.0));
+  const float w = wB * wA;
+  *aC = *aC + c * w;
+  *aW += w;
+}
+HKD void fsr_easu_set(f2* dir, float* len, f2 pp, int corner, float lA, float lB, float lC, float lD, float lE) {  // ffx_fsr1.h:275-312
+  float w = 0.0f;
+  if (corner == 0) w = (1.0f - pp.x) * (1.0f - pp.y);
+  if (corner == 1) w = pp.x * (1.0f - pp.y);
+  if (corner == 2) w = (1.0f - pp.x) * pp.y;
+  if (corner == 3) w = pp.x * pp.y;
+  const float dc = lD - lC;
+  const float cb = lC - lB;
+  float lenX = fmax_(fabsf(dc), fabsf(cb));
+  lenX = fsr_prx_lo_rcp(lenX);
+  const float dirX = lD - lB;
+  dir->x += dirX * w;
+  lenX = clamp_(fabsf(dirX) * lenX, 0.0f, 1.0f);
+  lenX *= lenX;
+  *len += lenX * w;
+  const float ec = lE - lC;
+  const float ca = lC - lA;
+  float lenY = fmax_(fabsf(ec), fabsf(ca));
+  lenY = fsr_prx_lo_rcp(lenY);
+  const float dirY = lE - lA;
+  dir->y += dirY * w;
+  lenY = clamp_(fabsf(dirY) * lenY, 0.0f, 1.0f);
+  lenY *= lenY;
+  *len += lenY * w;
+}
+HKD f4 fsr_luma(const FsrGather& t) { return t.b * 0.5f + (t.r * 0.5f + t.g); }
+struct FsrEasuArgs {
+  Plane16 input;
+  uint2* output;
+  int ow, oh;
+  float con0[4], con1[4], con2[4], con3[2];  // FsrEasuCon, evaluated on the host in f32
+  f2 half_texel;
+};
+__global__ __launch_bounds__(256) void k_fsr_easu(FsrEasuArgs a, int row_begin, int row_end) {
+  const Pixel px = pixel_of_thread(a.ow, row_begin, row_end);
+  if (!px.valid) return;
+  f2 pp = F2((float)px.x * a.con0[0] + a.con0[2], (float)px.y * a.con0[1] + a.con0[3]);
+  const f2 fp = F2(floorf(pp.x), floorf(pp.y));
+  pp = pp - fp;
+  const f2 p0 = F2(fp.x * a.con1[0] + a.con1[2], fp.y * a.con1[1] + a.con1[3]);
+  const f2 p1 = F2(p0.x + a.con2[0], p0.y + a.con2[1]);
+  const f2 p2 = F2(p0.x + a.con2[2], p0.y + a.con2[3]);
+  const f2 p3 = F2(p0.x + a.con3[0], p0.y + a.con3[1]);
+  const FsrGather bczz = fsr_gather(a.input, p0, a.half_texel), ijfe = fsr_gather(a.input, p1, a.half_texel),
+                  klhg = fsr_gather(a.input, p2, a.half_texel), zzon = fsr_gather(a.input, p3, a.half_texel);
+  const f4 bczzL = fsr_luma(bczz), ijfeL = fsr_luma(ijfe), klhgL = fsr_luma(klhg), zzonL = fsr_luma(zzon);
+  const float bL = bczzL.x, cL = bczzL.y, iL = ijfeL.x, jL = ijfeL.y, fL = ijfeL.z, eL = ijfeL.w, kL = klhgL.x, lL = klhgL.y, hL = klhgL.z,
+              gL = klhgL.w, oL = zzonL.z, nL = zzonL.w;
+  f2 dir = F2(0.0f, 0.0f);
+  float len = 0.0f;
+  fsr_easu_set(&dir, &len, pp, 0, bL, eL, fL, gL, jL);
+  fsr_easu_set(&dir, &len, pp, 1, cL, fL, gL, hL, kL);
+  fsr_easu_set(&dir, &len, pp, 2, fL, iL, jL, kL, nL);
+  fsr_easu_set(&dir, &len, pp, 3, gL, jL, kL, lL, oL);
+  const f2 dir2 = dir * dir;
+  float dirR = dir2.x + dir2.y;
+  const bool zro = dirR < (float)(1.0 / 32768.0);
+  dirR = fsr_prx_lo_rsq(dirR);
+  dirR = zro ? 1.0f : dirR;
+  dir.x = zro ? 1.0f : dir.x;
+  dir = dir * F2(dirR, dirR);
+  len = len * 0.5f;
+  len *= len;
+  const float stretch = (dir.x * dir.x + dir.y * dir.y) * fsr_prx_lo_rcp(fmax_(fabsf(dir.x), fabsf(dir.y)));
+  const f2 len2 = F2(1.0f + (stretch - 1.0f) * len, 1.0f + -0.5f * len);
+  const float lob = 0.5f + (float)((1.0 / 4.0 - 0.04) - 0.5) * len;
+  const float clp = fsr_prx_lo_rcp(lob);
+  const f3 fC = F3(ijfe.r.z, ijfe.g.z, ijfe.b.z), gC = F3(klhg.r.w, klhg.g.w, klhg.b.w), jC = F3(ijfe.r.y, ijfe.g.y, ijfe.b.y),
+           kC = F3(klhg.r.x, klhg.g.x, klhg.b.x);
+  const f3 min4 = min3(F3(fsr_min3(fC.x, gC.x, jC.x), fsr_min3(fC.y, gC.y, jC.y), fsr_min3(fC.z, gC.z, jC.z)), kC);
+  const f3 max4 = max3(F3(fsr_max3(fC.x, gC.x, jC.x), fsr_max3(fC.y, gC.y, jC.y), fsr_max3(fC.z, gC.z, jC.z)), kC);
+  f3 aC = F3(0.0f, 0.0f, 0.0f);
+  float aW = 0.0f;
+#define HK_EASU_TAP(ox, oy, G, ch) fsr_easu_tap(&aC, &aW, F2((ox) - pp.x, (oy) - pp.y), dir, len2, lob, clp, F3(G.r.ch, G.g.ch, G.b.ch))
+  HK_EASU_TAP(0.0f, -1.0f, bczz, x);  // b
+  HK_EASU_TAP(1.0f, -1.0f, bczz, y);  // c
+  HK_EASU_TAP(-1.0f, 1.0f, ijfe, x);  // i
+  HK_EASU_TAP(0.0f, 1.0f, ijfe, y);   // j
+  HK_EASU_TAP(0.0f, 0.0f, ijfe, z);   // f
+  HK_EASU_TAP(-1.0f, 0.0f, ijfe, w);  // e
+  HK_EASU_TAP(1.0f, 1.0f, klhg, x);   // k
+  HK_EASU_TAP(2.0f, 1.0f, klhg, y);   // l
+  HK_EASU_TAP(2.0f, 0.0f, klhg, z);   // h
+  HK_EASU_TAP(1.0f, 0.0f, klhg, w);   // g
+  HK_EASU_TAP(1.0f, 2.0f, zzon, z);   // o
+  HK_EASU_TAP(0.0f, 2.0f, zzon, w);   // n
+#undef HK_EASU_TAP
+  const f3 pix = min3(max4, max3(min4, aC * (1.0f / aW)));
+  a.output[px.x + a.ow * px.y] = pack_f16x4(F4(pix.x, pix.y, pix.z, 1.0f));  // hdr == 0 (post_process.rs:531)
+}
+__global__ __launch_bounds__(256) void k_fsr_rcas(const uint2* __restrict__ input, uint2* __restrict__ output, int w, int h, float sharpness,
+                                                  int row_begin, int row_end) {
+  const Pixel px = pixel_of_thread(w, row_begin, row_end);
+  if (!px.valid) return;
+  const float sharp = exp2_(-sharpness);  // FsrRcasCon, ffx_fsr1.h:662-673
+  f4 b, d, e, f, hh;
+  load_loose(input, w, h, px.x, px.y - 1, &b);
+  load_loose(input, w, h, px.x - 1, px.y, &d);
+  load_loose(input, w, h, px.x, px.y, &e);
+  load_loose(input, w, h, px.x + 1, px.y, &f);
+  load_loose(input, w, h, px.x, px.y + 1, &hh);
+  const float mn4R = fmin_(fsr_min3(b.x, d.x, f.x), hh.x), mn4G = fmin_(fsr_min3(b.y, d.y, f.y), hh.y), mn4B = fmin_(fsr_min3(b.z, d.z, f.z), hh.z);
+  const float mx4R = fmax_(fsr_max3(b.x, d.x, f.x), hh.x), mx4G = fmax_(fsr_max3(b.y, d.y, f.y), hh.y), mx4B = fmax_(fsr_max3(b.z, d.z, f.z), hh.z);
+  const float peakCx = 1.0f, peakCy = -1.0f * 4.0f;
+  const float hitMinR = fmin_(mn4R, e.x) * (1.0f / (4.0f * mx4R)), hitMinG = fmin_(mn4G, e.y) * (1.0f / (4.0f * mx4G)),
+              hitMinB = fmin_(mn4B, e.z) * (1.0f / (4.0f * mx4B));
+  const float hitMaxR = (peakCx - fmax_(mx4R, e.x)) * (1.0f / (4.0f * mn4R + peakCy)),
+              hitMaxG = (peakCx - fmax_(mx4G, e.y)) * (1.0f / (4.0f * mn4G + peakCy)),
+              hitMaxB = (peakCx - fmax_(mx4B, e.z)) * (1.0f / (4.0f * mn4B + peakCy));
+  const float lobeR = fmax_(-hitMinR, hitMaxR), lobeG = fmax_(-hitMinG, hitMaxG), lobeB = fmax_(-hitMinB, hitMaxB);
+  const float lobe = fmax_(-(float)(0.25 - (1.0 / 16.0)), fmin_(fsr_max3(lobeR, lobeG, lobeB), 0.0f)) * sharp;
+  const float rcpL = fsr_prx_med_rcp(4.0f * lobe + 1.0f);
+  const float pixR = (lobe * b.x + lobe * d.x + lobe * hh.x + lobe * f.x + e.x) * rcpL;
+  const float pixG = (lobe * b.y + lobe * d.y + lobe * hh.y + lobe * f.y + e.y) * rcpL;
+  const float pixB = (lobe * b.z + lobe * d.z + lobe * hh.z + lobe * f.z + e.z) * rcpL;
+  output[px.x + w * px.y] = pack_f16x4(F4(pixR, pixG, pixB, 1.0f));
+}
+
 }  // namespace hkd
 
 namespace hk {
@@ -364,6 +522,37 @@ void launch_taa_jasmine(hipStream_t st, const AaBuffers& b, float blend, const f
   if (y1 <= y0) return;
   hipLaunchKernelGGL(k_taa_jasmine, grid_for(b.out_w, y1 - y0), dim3(256), 0, st, make_targets(b), blend,
                      make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]), y0, y1);
+}
+
+void launch_fsr_easu(hipStream_t st, const void* input, int in_w, int in_h, void* output, int out_w, int out_h, int y0, int y1) {
+  if (y1 <= y0) return;
+  FsrEasuArgs a;
+  a.input = Plane16{(const uint2*)input, in_w, in_h};
+  a.output = (uint2*)output;
+  a.ow = out_w;
+  a.oh = out_h;
+  // FsrEasuCon (ffx_fsr1.h:156-203) with inputViewport = inputSize = the scaled size (post_process.rs:522-530)
+  const float ivx = (float)in_w, ivy = (float)in_h, isx = ivx, isy = ivy, osx = (float)out_w, osy = (float)out_h;
+  a.con0[0] = ivx * (1.0f / osx);
+  a.con0[1] = ivy * (1.0f / osy);
+  a.con0[2] = 0.5f * ivx * (1.0f / osx) - 0.5f;
+  a.con0[3] = 0.5f * ivy * (1.0f / osy) - 0.5f;
+  a.con1[0] = 1.0f / isx;
+  a.con1[1] = 1.0f / isy;
+  a.con1[2] = 1.0f * (1.0f / isx);
+  a.con1[3] = -1.0f * (1.0f / isy);
+  a.con2[0] = -1.0f * (1.0f / isx);
+  a.con2[1] = 2.0f * (1.0f / isy);
+  a.con2[2] = 1.0f * (1.0f / isx);
+  a.con2[3] = 2.0f * (1.0f / isy);
+  a.con3[0] = 0.0f * (1.0f / isx);
+  a.con3[1] = 4.0f * (1.0f / isy);
+  a.half_texel = f2{(1.0f / (float)in_w) / 2.0f, (1.0f / (float)in_h) / 2.0f};
+  hipLaunchKernelGGL(k_fsr_easu, grid_for(out_w, y1 - y0), dim3(256), 0, st, a, y0, y1);
+}
+void launch_fsr_rcas(hipStream_t st, const void* input, void* output, int w, int h, float sharpness, int y0, int y1) {
+  if (y1 <= y0) return;
+  hipLaunchKernelGGL(k_fsr_rcas, grid_for(w, y1 - y0), dim3(256), 0, st, (const uint2*)input, (uint2*)output, w, h, sharpness, y0, y1);
 }
 
 }  // namespace hk

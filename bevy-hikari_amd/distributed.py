@@ -150,6 +150,10 @@ class BandRenderer:
             self._sync_before_exchange()
             self.exchange(F.STAGE_ANTIALIAS | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
             e.frame_stage(F.STAGE_ANTIALIAS, sc)
+            if settings.upscale.kind == F.UPSCALE_FSR1:  # FSR1 on the band's window rows: exchange E = the EASU taps' input rows
+                self._sync_before_exchange()
+                self.exchange(F.STAGE_UPSCALE, frame.number, sc, width, height, ratio)
+                e.frame_stage(F.STAGE_UPSCALE, sc)
 
     def _sync_before_exchange(self):
         # When the engine runs on torch's current stream (Engine.set_stream), RCCL orders itself

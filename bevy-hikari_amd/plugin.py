@@ -449,8 +449,8 @@ class Engine:
     def frame_begin(self, frame, view, previous_view, lights):
         self.api.call("frame_begin", self.ctx, C.byref(frame), C.byref(view), C.byref(previous_view), C.byref(lights))
 
-    def set_view_options(self, taa, upscale_kind):
-        self.api.call("set_view_options", self.ctx, taa, upscale_kind)
+    def set_view_options(self, taa, upscale_kind, upscale_sharpness=0.0):
+        self.api.call("set_view_options", self.ctx, taa, upscale_kind, upscale_sharpness)
 
     def pass_run(self, pass_id, arg=0, row_begin=0, row_end=0):
         self.api.call("pass_run", self.ctx, pass_id, arg, row_begin, row_end)
@@ -551,7 +551,7 @@ class _Node:
 
 class PrepassNode(_Node):  # prepass.rs:736-852
     def run(self, settings: HikariSettings):
-        self.engine.set_view_options(settings.taa, settings.upscale.kind)
+        self.engine.set_view_options(settings.taa, settings.upscale.kind, settings.upscale.sharpness_)
         self.engine.pass_run(F.PASS_PREPASS)
 
 
@@ -583,12 +583,15 @@ class PostProcessNode(_Node):  # post_process.rs:1107-1312
 
     def run_antialias(self, settings: HikariSettings):
         e = self.engine
-        e.set_view_options(settings.taa, settings.upscale.kind)
+        e.set_view_options(settings.taa, settings.upscale.kind, settings.upscale.sharpness_)
         if settings.upscale.kind == F.UPSCALE_SMAA_TU4X:           # post_process.rs:1236-1258
             e.pass_run(F.PASS_SMAA_TU4X)
             e.pass_run(F.PASS_SMAA_TU4X_EXTRAPOLATE)
         if settings.taa == Taa.Jasmine:                            # post_process.rs:1260-1275
             e.pass_run(F.PASS_TAA_JASMINE)
+        if settings.upscale.kind == F.UPSCALE_FSR1:                # post_process.rs:1277-1308
+            e.pass_run(F.PASS_FSR_EASU)
+            e.pass_run(F.PASS_FSR_RCAS)
 
 
 class HikariPlugin:
@@ -638,8 +641,8 @@ class HikariPlugin:
         """What OverlayNode samples (overlay.rs:226-231), as f32 [H][W][4]."""
         if settings.upscale.kind == F.UPSCALE_SMAA_TU4X:
             buf = F.BUF_TAA_OUTPUT if settings.taa == Taa.Jasmine else F.BUF_UPSCALE_OUTPUT
-        else:  # FSR1 EASU/RCAS are not part of this library: the image that would enter them
-            buf = F.BUF_TAA_OUTPUT if settings.taa == Taa.Jasmine else F.BUF_TONE_MAPPED
+        else:                                                       # upscale_output[1]: EASU then RCAS
+            buf = F.BUF_UPSCALE_SHARPENED
         return self.engine.read_f16(buf)
 
     def output(self, settings: HikariSettings):

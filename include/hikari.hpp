@@ -286,7 +286,7 @@ class Context {
 struct PrepassNode {  // prepass.rs:736-852
   Context& ctx;
   void run(const HikariSettings& s) {
-    check(hk_set_view_options(ctx.get(), (uint32_t)s.taa, s.upscale.kind), "hk_set_view_options");
+    check(hk_set_view_options(ctx.get(), (uint32_t)s.taa, s.upscale.kind, s.upscale.sharpness()), "hk_set_view_options");
     ctx.pass_run(HK_PASS_PREPASS);
   }
 };
@@ -320,6 +320,10 @@ struct PostProcessNode {  // post_process.rs:1107-1312
       ctx.pass_run(HK_PASS_SMAA_TU4X_EXTRAPOLATE);
     }
     if (s.taa == Taa::Jasmine) ctx.pass_run(HK_PASS_TAA_JASMINE);     // post_process.rs:1260-1275
+    if (s.upscale.kind == HK_UPSCALE_FSR1) {                          // post_process.rs:1277-1308
+      ctx.pass_run(HK_PASS_FSR_EASU);
+      ctx.pass_run(HK_PASS_FSR_RCAS);
+    }
   }
 };
 
@@ -366,12 +370,11 @@ class HikariPlugin {
     return n;
   }
   void wait() { check(hk_frame_wait(ctx_.get()), "hk_frame_wait"); }
-  // the image OverlayNode presents (overlay.rs:226-231); FSR1's EASU/RCAS are outside this library, so for
-  // Upscale::Fsr1 this is the image that would enter them
+  // the image OverlayNode presents (overlay.rs:226-231)
   static uint32_t final_buffer(const HikariSettings& s, bool antialias) {
     if (!antialias) return HK_BUF_TONE_MAPPED;
-    if (s.taa == Taa::Jasmine) return HK_BUF_TAA_OUTPUT;
-    return s.upscale.kind == HK_UPSCALE_SMAA_TU4X ? HK_BUF_UPSCALE_OUTPUT : HK_BUF_TONE_MAPPED;
+    if (s.upscale.kind == HK_UPSCALE_FSR1) return HK_BUF_UPSCALE_SHARPENED;  // upscale_output[1]
+    return s.taa == Taa::Jasmine ? HK_BUF_TAA_OUTPUT : HK_BUF_UPSCALE_OUTPUT;
   }
 
  private:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 2
+#define HK_ABI_VERSION 3
 
 /* ------------------------------------------------------------------ error codes */
 #define HK_OK 0
@@ -244,7 +244,10 @@ typedef enum HkBuffer {
   HK_BUF_UPSCALE_OUTPUT = 34,   /* rgba16f, ceil(size * 2 / ratio): upscale_output[0] of the SMAA Tu4x path */
   HK_BUF_TAA_OUTPUT = 35,       /* rgba16f: taa_output[current]; size of UPSCALE_OUTPUT (SMAA) or scaled (FSR1) */
   HK_BUF_PREVIOUS_TAA_OUTPUT = 36,
-  HK_BUF_COUNT = 37
+  /* FSR1 (Upscale::Fsr1): upscale_output[0] (EASU result) is HK_BUF_UPSCALE_OUTPUT at the window size, upscale_output[1]
+   * (RCAS result, what OverlayNode presents, overlay.rs:228) is this one: rgba16f, window size */
+  HK_BUF_UPSCALE_SHARPENED = 37,
+  HK_BUF_COUNT = 38
 } HkBuffer;
 
 /* One compute dispatch of the reference.  `arg` selects the render channel for
@@ -266,7 +269,10 @@ typedef enum HkPass {
   HK_PASS_SMAA_TU4X = 13,          /* smaa.wgsl:81-188: current + reprojected previous sample of each output quad */
   HK_PASS_SMAA_TU4X_EXTRAPOLATE = 14, /* smaa.wgsl:239-271: the other two pixels of each quad */
   HK_PASS_TAA_JASMINE = 15,        /* taa.wgsl:75-170 */
-  HK_PASS_COUNT = 16
+  HK_PASS_FSR_EASU = 16,           /* FidelityFX FSR 1.0 edge-adaptive spatial upsampling: src/shaders/fsr/source.zip,
+                                      ffx_fsr1.h FsrEasuF through FSR_Pass.glsl (the blob fsr_pass_easu.spv), post_process.rs:1277-1293 */
+  HK_PASS_FSR_RCAS = 17,           /* ... robust contrast-adaptive sharpening, FsrRcasF (fsr_pass_rcas.spv), post_process.rs:1295-1308 */
+  HK_PASS_COUNT = 18
 } HkPass;
 
 /* Frame stages for band-sharded (multi-GPU) rendering: the host exchanges halo rows between
@@ -279,7 +285,12 @@ typedef enum HkStage {
                                 when upscale_kind is SMAA_TU4X, then TAA when taa is JASMINE, on the band (exchange D of
                                 hk_band_plan_for: tone-mapped rows + last frame's TAA rows).  Not part of hk_frame_render
                                 unless HK_FRAME_ANTIALIAS. */
-  HK_STAGE_COUNT = 4
+  HK_STAGE_UPSCALE = 4,      /* upscale_kind FSR1 only (post_process.rs:1277-1308; a no-op for SMAA_TU4X): EASU + RCAS to the
+                                window size.  A band owns the window rows hk_band_rows(height, ..) gives it: EASU runs on those
+                                rows +-1 (RCAS's cross), RCAS on the rows themselves; exchange E of hk_band_plan_for brings the
+                                3-4 rows of the EASU input (taa_output or tone-mapped) the 12 taps reach beyond the render band.
+                                Runs after HK_STAGE_ANTIALIAS under HK_FRAME_ANTIALIAS. */
+  HK_STAGE_COUNT = 5
 } HkStage;
 
 /* One halo transfer the host must perform BEFORE running `stage`: rows [row_begin,row_end) of
@@ -293,7 +304,7 @@ typedef struct HkHaloOp {
   uint64_t row_bytes;
 } HkHaloOp;
 
-#define HK_TIMING_SLOTS 16
+#define HK_TIMING_SLOTS 24
 typedef struct HkStats {
   uint64_t rays_primary;      /* G-buffer rays */
   uint64_t rays_tlas;         /* traverse_top invocations (light.wgsl:442) */
@@ -424,8 +435,9 @@ int hk_resize(hk_ctx* ctx, uint32_t width, uint32_t height, float upscale_ratio)
 /* ------------------------------------------------------------------ per-frame */
 /* the four dynamic uniforms of bind group 0 (prepass.rs:546-553) */
 /* TAA / upscale variant that selects the prepass sub-pixel jitter (prepass.rs:489-490,
- * prepass.wgsl:30-38); hk_frame_stage sets it from HkSettings, hk_pass_run uses the last value. */
-int hk_set_view_options(hk_ctx* ctx, uint32_t taa, uint32_t upscale_kind);
+ * prepass.wgsl:30-38), and Upscale::sharpness() (lib.rs:489-496) that HK_PASS_FSR_RCAS reads;
+ * hk_frame_stage sets all three from HkSettings, hk_pass_run uses the last values. */
+int hk_set_view_options(hk_ctx* ctx, uint32_t taa, uint32_t upscale_kind, float upscale_sharpness);
 int hk_frame_begin(hk_ctx* ctx, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
                    const HkLights* lights);
 /* One dispatch over rows [row_begin,row_end) of its grid (row_end = 0 means "all rows").  The

@@ -104,6 +104,7 @@ struct Ctx {
   HkLights lights{};
   bool have_frame = false;
   uint32_t taa = HK_TAA_JASMINE, upscale_kind = HK_UPSCALE_SMAA_TU4X;  // prepass jitter selection
+  float upscale_sharpness = 0.0f;                                       // Upscale::sharpness(), FSR1 RCAS
 
   uint32_t band_index = 0, band_count = 1;
   Stats stats;
@@ -125,12 +126,12 @@ static int buf_bpp(uint32_t b) {
   if (b >= HK_BUF_DENOISE_RENDER0 && b < HK_BUF_DENOISE_RENDER0 + 3) return 8;
   if (b == HK_BUF_TONE_MAPPED || b == HK_BUF_PREVIOUS_TONE_MAPPED) return 8;
   if (b == HK_BUF_PREVIOUS_POSITION || b == HK_BUF_PREVIOUS_VELOCITY_UV) return 16;
-  if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT) return 8;
+  if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT || b == HK_BUF_UPSCALE_SHARPENED) return 8;
   return 0;
 }
 static bool buf_full_size(uint32_t b) {
   return b <= HK_BUF_ALBEDO || (b >= HK_BUF_RESERVOIR0 && b < HK_BUF_RESERVOIR0 + 10) || b == HK_BUF_PREVIOUS_POSITION ||
-         b == HK_BUF_PREVIOUS_VELOCITY_UV;
+         b == HK_BUF_PREVIOUS_VELOCITY_UV || b == HK_BUF_UPSCALE_SHARPENED;
 }
 static bool buf_upscaled(uint32_t b) { return b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT; }
 
@@ -237,7 +238,8 @@ struct Tex {
 // the scale in effect after the upscale match (post_process.rs:712-733): 2/ratio for SMAA Tu4x, 1/ratio for FSR1.
 static void buf_dims(const Ctx* c, uint32_t b, int* w, int* h) {
   if (buf_full_size(b)) { *w = c->W; *h = c->H; return; }
-  if (b == HK_BUF_UPSCALE_OUTPUT || (buf_upscaled(b) && c->upscale_kind == HK_UPSCALE_SMAA_TU4X)) { *w = c->UW; *h = c->UH; return; }
+  if (buf_upscaled(b) && c->upscale_kind == HK_UPSCALE_SMAA_TU4X) { *w = c->UW; *h = c->UH; return; }
+  if (b == HK_BUF_UPSCALE_OUTPUT) { *w = c->W; *h = c->H; return; }  // FSR1: upscale_output is created at scale 1.0 (post_process.rs:723)
   *w = c->RW;
   *h = c->RH;
 }
@@ -1726,7 +1728,7 @@ static float depth_weight(float d0, float d1, v2 gradient, v2 offset) {  // deno
   return exp_((-fabsf(d0 - d1)) / (fabsf(dot(gradient, offset)) + eps));
 }
 static float luminance_weight(float l0, float l1, float variance) {  // denoise.wgsl:56-61
-  float strictness = 4.0f, exponent = 0.25f, eps = 0.001f;
+  float strictness = 4.0f, eps = 0.001f;  // exponent 0.25: pow_quarter_
   return exp_((-fabsf(l0 - l1)) / (strictness * pow_quarter_(variance) + eps));
 }
 static float instance_weight(float i0, float i1) { return fmax_(0.0f, 1.0f - fabsf(i0 - i1)); }  // denoise.wgsl:63-65
@@ -2057,6 +2059,187 @@ static void pass_smaa_tu4x(Ctx* c, int y0, int y1) {  // smaa.wgsl:81-188; one t
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// FidelityFX Super Resolution 1.0 (Upscale::Fsr1): EASU + RCAS, the 32-bit "slow fallback" path the reference
+// compiles into fsr_pass_easu.spv / fsr_pass_rcas.spv.  Restated from the GLSL that ships inside
+// src/shaders/fsr/source.zip: FSR_Pass.glsl (entry, constants computed per invocation, hdr = 0 from
+// post_process.rs:522-533), ffx_fsr1.h (FsrEasuCon :156-203, FsrEasuTapF :239-272, FsrEasuSetF :275-312,
+// FsrEasuF :315-441, FsrRcasCon :662-673, FsrRcasF :684-768), ffx_a.h (APrxLoRcpF1 / APrxMedRcpF1 / APrxLoRsqF1
+// :1843-1845), texture_gather.glsl (fakeTextureGather: four bilinear samples half an input texel off a texel
+// corner, i.e. exactly the four texels around it - the contract takes the texels).  Dispatch post_process.rs:1277-1308.
+// ------------------------------------------------------------------------------------------
+static inline float fsr_prx_lo_rcp(float a) { return u2f(0x7ef07ebbu - f2u(a)); }
+static inline float fsr_prx_med_rcp(float a) { float b = u2f(0x7ef19fffu - f2u(a)); return b * (-b * a + 2.0f); }
+static inline float fsr_prx_lo_rsq(float a) { return u2f(0x5f347d74u - (f2u(a) >> 1)); }
+static inline float fsr_min3(float x, float y, float z) { return fmin_(x, fmin_(y, z)); }
+static inline float fsr_max3(float x, float y, float z) { return fmax_(x, fmax_(y, z)); }
+struct FsrEasuConst { float con0[4], con1[4], con2[4], con3[4]; };
+static FsrEasuConst fsr_easu_con(float ivx, float ivy, float isx, float isy, float osx, float osy) {  // ffx_fsr1.h:156-203
+  FsrEasuConst k;
+  k.con0[0] = ivx * (1.0f / osx);
+  k.con0[1] = ivy * (1.0f / osy);
+  k.con0[2] = 0.5f * ivx * (1.0f / osx) - 0.5f;
+  k.con0[3] = 0.5f * ivy * (1.0f / osy) - 0.5f;
+  k.con1[0] = 1.0f / isx;
+  k.con1[1] = 1.0f / isy;
+  k.con1[2] = 1.0f * (1.0f / isx);
+  k.con1[3] = -1.0f * (1.0f / isy);
+  k.con2[0] = -1.0f * (1.0f / isx);
+  k.con2[1] = 2.0f * (1.0f / isy);
+  k.con2[2] = 1.0f * (1.0f / isx);
+  k.con2[3] = 2.0f * (1.0f / isy);
+  k.con3[0] = 0.0f * (1.0f / isx);
+  k.con3[1] = 4.0f * (1.0f / isy);
+  k.con3[2] = k.con3[3] = 0.0f;
+  return k;
+}
+// texture_gather.glsl: (x, y, z, w) = texels at (u-,v+), (u+,v+), (u+,v-), (u-,v-) of the corner p, clamp-to-edge
+struct FsrGather { v4 r, g, b; };
+static FsrGather fsr_gather(const Tex& t, v2 p) {
+  v2 ps = V2((1.0f / (float)t.w) / 2.0f, (1.0f / (float)t.h) / 2.0f);
+  v4 s3 = t.sample_nearest(V2(p.x + ps.x, p.y + ps.y));
+  v4 s1 = t.sample_nearest(V2(p.x - ps.x, p.y - ps.y));
+  v4 s2 = t.sample_nearest(V2(p.x + ps.x, p.y + (-ps.y)));
+  v4 s4 = t.sample_nearest(V2(p.x + (-ps.x), p.y + ps.y));
+  FsrGather o;
+  o.r = V4(s4.x, s3.x, s2.x, s1.x);
+  o.g = V4(s4.y, s3.y, s2.y, s1.y);
+  o.b = V4(s4.z, s3.z, s2.z, s1.z);
+  return o;
+}
+static inline void fsr_easu_tap(v3* aC, float* aW, v2 off, v2 dir, v2 len, float lob, float clp, v3 c) {  // ffx_fsr1.h:239-272
+  v2 v;
+  v.x = (off.x * (dir.x)) + (off.y * dir.y);
+  v.y = (off.x * (-dir.y)) + (off.y * dir.x);
+  v = v * len;
+  float d2 = v.x * v.x + v.y * v.y;
+  d2 = fmin_(d2, clp);
+  float wB = (float)(2.0 / 5.0) * d2 + -1.0f;
+  float wA = lob * d2 + -1.0f;
+  wB *= wB;
+  wA *= wA;
+  wB = (float)(25.0 / 16.0) * wB + (float)(-(25.0 / 16.0 - 1.0));
+  float w = wB * wA;
+  *aC = *aC + c * w;
+  *aW += w;
+}
+static inline void fsr_easu_set(v2* dir, float* len, v2 pp, int corner, float lA, float lB, float lC, float lD, float lE) {  // ffx_fsr1.h:275-312
+  float w = 0.0f;
+  if (corner == 0) w = (1.0f - pp.x) * (1.0f - pp.y);
+  if (corner == 1) w = pp.x * (1.0f - pp.y);
+  if (corner == 2) w = (1.0f - pp.x) * pp.y;
+  if (corner == 3) w = pp.x * pp.y;
+  float dc = lD - lC;
+  float cb = lC - lB;
+  float lenX = fmax_(fabsf(dc), fabsf(cb));
+  lenX = fsr_prx_lo_rcp(lenX);
+  float dirX = lD - lB;
+  dir->x += dirX * w;
+  lenX = clamp_(fabsf(dirX) * lenX, 0.0f, 1.0f);
+  lenX *= lenX;
+  *len += lenX * w;
+  float ec = lE - lC;
+  float ca = lC - lA;
+  float lenY = fmax_(fabsf(ec), fabsf(ca));
+  lenY = fsr_prx_lo_rcp(lenY);
+  float dirY = lE - lA;
+  dir->y += dirY * w;
+  lenY = clamp_(fabsf(dirY) * lenY, 0.0f, 1.0f);
+  lenY *= lenY;
+  *len += lenY * w;
+}
+static void pass_fsr_easu(Ctx* c, int y0, int y1) {  // FSR_Pass.glsl CurrFilter (SAMPLE_EASU) + ffx_fsr1.h:315-441
+  Tex input = tex(c, c->taa == HK_TAA_JASMINE ? HK_BUF_TAA_OUTPUT : HK_BUF_TONE_MAPPED);  // post_process.rs:1037-1040
+  Tex output = tex(c, HK_BUF_UPSCALE_OUTPUT);
+  const FsrEasuConst k = fsr_easu_con((float)input.w, (float)input.h, (float)input.w, (float)input.h, (float)output.w, (float)output.h);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y)
+    for (int x = 0; x < output.w; ++x) {
+      v2 pp = V2((float)x * k.con0[0] + k.con0[2], (float)y * k.con0[1] + k.con0[3]);
+      v2 fp = V2(floorf(pp.x), floorf(pp.y));
+      pp = pp - fp;
+      v2 p0 = V2(fp.x * k.con1[0] + k.con1[2], fp.y * k.con1[1] + k.con1[3]);
+      v2 p1 = V2(p0.x + k.con2[0], p0.y + k.con2[1]);
+      v2 p2 = V2(p0.x + k.con2[2], p0.y + k.con2[3]);
+      v2 p3 = V2(p0.x + k.con3[0], p0.y + k.con3[1]);
+      FsrGather bczz = fsr_gather(input, p0), ijfe = fsr_gather(input, p1), klhg = fsr_gather(input, p2), zzon = fsr_gather(input, p3);
+      auto luma = [](const FsrGather& t) { return t.b * 0.5f + (t.r * 0.5f + t.g); };
+      v4 bczzL = luma(bczz), ijfeL = luma(ijfe), klhgL = luma(klhg), zzonL = luma(zzon);
+      float bL = bczzL.x, cL = bczzL.y, iL = ijfeL.x, jL = ijfeL.y, fL = ijfeL.z, eL = ijfeL.w, kL = klhgL.x, lL = klhgL.y, hL = klhgL.z,
+            gL = klhgL.w, oL = zzonL.z, nL = zzonL.w;
+      v2 dir = V2(0.0f, 0.0f);
+      float len = 0.0f;
+      fsr_easu_set(&dir, &len, pp, 0, bL, eL, fL, gL, jL);
+      fsr_easu_set(&dir, &len, pp, 1, cL, fL, gL, hL, kL);
+      fsr_easu_set(&dir, &len, pp, 2, fL, iL, jL, kL, nL);
+      fsr_easu_set(&dir, &len, pp, 3, gL, jL, kL, lL, oL);
+      v2 dir2 = dir * dir;
+      float dirR = dir2.x + dir2.y;
+      bool zro = dirR < (float)(1.0 / 32768.0);
+      dirR = fsr_prx_lo_rsq(dirR);
+      dirR = zro ? 1.0f : dirR;
+      dir.x = zro ? 1.0f : dir.x;
+      dir = dir * V2(dirR, dirR);
+      len = len * 0.5f;
+      len *= len;
+      float stretch = (dir.x * dir.x + dir.y * dir.y) * fsr_prx_lo_rcp(fmax_(fabsf(dir.x), fabsf(dir.y)));
+      v2 len2 = V2(1.0f + (stretch - 1.0f) * len, 1.0f + -0.5f * len);
+      float lob = 0.5f + (float)((1.0 / 4.0 - 0.04) - 0.5) * len;
+      float clp = fsr_prx_lo_rcp(lob);
+      v3 fC = V3(ijfe.r.z, ijfe.g.z, ijfe.b.z), gC = V3(klhg.r.w, klhg.g.w, klhg.b.w), jC = V3(ijfe.r.y, ijfe.g.y, ijfe.b.y),
+         kC = V3(klhg.r.x, klhg.g.x, klhg.b.x);
+      v3 min4 = min3(V3(fsr_min3(fC.x, gC.x, jC.x), fsr_min3(fC.y, gC.y, jC.y), fsr_min3(fC.z, gC.z, jC.z)), kC);
+      v3 max4 = max3(V3(fsr_max3(fC.x, gC.x, jC.x), fsr_max3(fC.y, gC.y, jC.y), fsr_max3(fC.z, gC.z, jC.z)), kC);
+      v3 aC = V3(0.0f, 0.0f, 0.0f);
+      float aW = 0.0f;
+      auto tap = [&](float ox, float oy, float r, float g, float b) { fsr_easu_tap(&aC, &aW, V2(ox - pp.x, oy - pp.y), dir, len2, lob, clp, V3(r, g, b)); };
+      tap(0.0f, -1.0f, bczz.r.x, bczz.g.x, bczz.b.x);  // b
+      tap(1.0f, -1.0f, bczz.r.y, bczz.g.y, bczz.b.y);  // c
+      tap(-1.0f, 1.0f, ijfe.r.x, ijfe.g.x, ijfe.b.x);  // i
+      tap(0.0f, 1.0f, ijfe.r.y, ijfe.g.y, ijfe.b.y);   // j
+      tap(0.0f, 0.0f, ijfe.r.z, ijfe.g.z, ijfe.b.z);   // f
+      tap(-1.0f, 0.0f, ijfe.r.w, ijfe.g.w, ijfe.b.w);  // e
+      tap(1.0f, 1.0f, klhg.r.x, klhg.g.x, klhg.b.x);   // k
+      tap(2.0f, 1.0f, klhg.r.y, klhg.g.y, klhg.b.y);   // l
+      tap(2.0f, 0.0f, klhg.r.z, klhg.g.z, klhg.b.z);   // h
+      tap(1.0f, 0.0f, klhg.r.w, klhg.g.w, klhg.b.w);   // g
+      tap(1.0f, 2.0f, zzon.r.z, zzon.g.z, zzon.b.z);   // o
+      tap(0.0f, 2.0f, zzon.r.w, zzon.g.w, zzon.b.w);   // n
+      v3 pix = min3(max4, max3(min4, aC * (1.0f / aW)));
+      output.store_f16x4(x, y, V4(pix, 1.0f));          // hdr == 0: no c *= c
+    }
+}
+static void pass_fsr_rcas(Ctx* c, int y0, int y1) {  // FSR_Pass.glsl CurrFilter (SAMPLE_RCAS) + ffx_fsr1.h:662-768
+  Tex input = tex(c, HK_BUF_UPSCALE_OUTPUT), output = tex(c, HK_BUF_UPSCALE_SHARPENED);
+  const float sharp = exp2_(-c->upscale_sharpness);  // FsrRcasCon
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int y = y0; y < y1; ++y)
+    for (int x = 0; x < output.w; ++x) {
+      v4 b = input.load_f16x4(x, y - 1), d = input.load_f16x4(x - 1, y), e = input.load_f16x4(x, y), f = input.load_f16x4(x + 1, y),
+         h = input.load_f16x4(x, y + 1);  // texelFetch: zeros outside
+      float bL = b.z * 0.5f + (b.x * 0.5f + b.y), dL = d.z * 0.5f + (d.x * 0.5f + d.y), eL = e.z * 0.5f + (e.x * 0.5f + e.y),
+            fL = f.z * 0.5f + (f.x * 0.5f + f.y), hL = h.z * 0.5f + (h.x * 0.5f + h.y);
+      float nz = 0.25f * bL + 0.25f * dL + 0.25f * fL + 0.25f * hL - eL;
+      nz = clamp_(fabsf(nz) * fsr_prx_med_rcp(fsr_max3(fsr_max3(bL, dL, eL), fL, hL) - fsr_min3(fsr_min3(bL, dL, eL), fL, hL)), 0.0f, 1.0f);
+      nz = -0.5f * nz + 1.0f;  // (computed as in the source; FSR_RCAS_DENOISE is not defined, so it is unused)
+      (void)nz;
+      float mn4R = fmin_(fsr_min3(b.x, d.x, f.x), h.x), mn4G = fmin_(fsr_min3(b.y, d.y, f.y), h.y), mn4B = fmin_(fsr_min3(b.z, d.z, f.z), h.z);
+      float mx4R = fmax_(fsr_max3(b.x, d.x, f.x), h.x), mx4G = fmax_(fsr_max3(b.y, d.y, f.y), h.y), mx4B = fmax_(fsr_max3(b.z, d.z, f.z), h.z);
+      const float peakCx = 1.0f, peakCy = -1.0f * 4.0f;
+      float hitMinR = fmin_(mn4R, e.x) * (1.0f / (4.0f * mx4R)), hitMinG = fmin_(mn4G, e.y) * (1.0f / (4.0f * mx4G)),
+            hitMinB = fmin_(mn4B, e.z) * (1.0f / (4.0f * mx4B));
+      float hitMaxR = (peakCx - fmax_(mx4R, e.x)) * (1.0f / (4.0f * mn4R + peakCy)), hitMaxG = (peakCx - fmax_(mx4G, e.y)) * (1.0f / (4.0f * mn4G + peakCy)),
+            hitMaxB = (peakCx - fmax_(mx4B, e.z)) * (1.0f / (4.0f * mn4B + peakCy));
+      float lobeR = fmax_(-hitMinR, hitMaxR), lobeG = fmax_(-hitMinG, hitMaxG), lobeB = fmax_(-hitMinB, hitMaxB);
+      float lobe = fmax_(-(float)(0.25 - (1.0 / 16.0)), fmin_(fsr_max3(lobeR, lobeG, lobeB), 0.0f)) * sharp;
+      float rcpL = fsr_prx_med_rcp(4.0f * lobe + 1.0f);
+      float pixR = (lobe * b.x + lobe * d.x + lobe * h.x + lobe * f.x + e.x) * rcpL;
+      float pixG = (lobe * b.y + lobe * d.y + lobe * h.y + lobe * f.y + e.y) * rcpL;
+      float pixB = (lobe * b.z + lobe * d.z + lobe * h.z + lobe * f.z + e.z) * rcpL;
+      output.store_f16x4(x, y, V4(pixR, pixG, pixB, 1.0f));
+    }
+}
+
 static inline v3 differential_blend_factor(v4 t, v4 b, v4 n, v4 e, v4 s, v4 w) {  // smaa.wgsl:198-222
   v2 dh = V2(luminance(abs3(rgb(w) - rgb(b))), luminance(abs3(rgb(t) - rgb(e))));
   v2 dv = V2(luminance(abs3(rgb(t) - rgb(s))), luminance(abs3(rgb(n) - rgb(b))));
@@ -2189,8 +2372,9 @@ int orc_resize(orc_ctx* ctx, uint32_t width, uint32_t height, float upscale_rati
   c.mapped_parity = 0;
   return HK_OK;
 }
-int orc_set_view_options(orc_ctx* ctx, uint32_t taa, uint32_t upscale_kind) {
+int orc_set_view_options(orc_ctx* ctx, uint32_t taa, uint32_t upscale_kind, float upscale_sharpness) {
   ORC_CHECK(ctx, HK_E_INVALID, "null ctx");
+  ctx->c.upscale_sharpness = upscale_sharpness;
   ctx->c.taa = taa;
   ctx->c.upscale_kind = upscale_kind;
   return HK_OK;
@@ -2226,6 +2410,10 @@ int orc_pass_run(orc_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, 
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
   int rows = full_grid ? c.H : c.RH;
   if (pass == HK_PASS_TAA_JASMINE) { int w; buf_dims(&c, HK_BUF_TAA_OUTPUT, &w, &rows); }
+  if (pass == HK_PASS_FSR_EASU || pass == HK_PASS_FSR_RCAS) {
+    ORC_CHECK(c.upscale_kind == HK_UPSCALE_FSR1, HK_E_INVALID, "FSR passes need upscale_kind FSR1");
+    rows = c.H;
+  }
   int y0 = (int)row_begin, y1 = row_end == 0 ? rows : (int)row_end;
   ORC_CHECK(y0 >= 0 && y1 <= rows && y0 <= y1, HK_E_INVALID, "row range");
   switch (pass) {
@@ -2233,6 +2421,8 @@ int orc_pass_run(orc_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, 
     case HK_PASS_SMAA_TU4X: pass_smaa_tu4x(&c, y0, y1); break;
     case HK_PASS_SMAA_TU4X_EXTRAPOLATE: pass_smaa_tu4x_extrapolate(&c, y0, y1); break;
     case HK_PASS_TAA_JASMINE: pass_taa_jasmine(&c, y0, y1); break;
+    case HK_PASS_FSR_EASU: pass_fsr_easu(&c, y0, y1); break;
+    case HK_PASS_FSR_RCAS: pass_fsr_rcas(&c, y0, y1); break;
     case HK_PASS_FULL_SCREEN_ALBEDO: pass_full_screen_albedo(&c, y0, y1); break;
     case HK_PASS_DIRECT_LIT: pass_direct_lit(&c, false, y0, y1); break;
     case HK_PASS_DIRECT_EMISSIVE: pass_direct_lit(&c, true, y0, y1); break;
@@ -2267,6 +2457,7 @@ int orc_frame_stage_rows(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uin
   Ctx& c = ctx->c;
   c.taa = st->taa;
   c.upscale_kind = st->upscale_kind;
+  c.upscale_sharpness = st->upscale_sharpness;
   const int b0 = (int)band_begin, b1 = (int)band_end;
   auto clampr = [&](int v) { return std::min(std::max(v, 0), c.RH); };
   const int den = st->denoise ? 16 : 0;
@@ -2310,6 +2501,13 @@ int orc_frame_stage_rows(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uin
       const int scale = smaa ? 2 : 1;
       pass_taa_jasmine(&c, std::min(h, scale * b0), b1 == c.RH ? h : std::min(h, scale * b1));
     }
+  } else if (stage == HK_STAGE_UPSCALE) {  // post_process.rs:1277-1308
+    if (st->upscale_kind == HK_UPSCALE_FSR1) {
+      const int bi = (int)c.band_index, bn = (int)c.band_count, base = c.H / bn, rem = c.H % bn;  // hk_band_rows over the window height
+      const int w0 = bi * base + std::min(bi, rem), w1 = w0 + base + (bi < rem ? 1 : 0);
+      pass_fsr_easu(&c, std::max(w0 - 1, 0), std::min(w1 + 1, c.H));
+      pass_fsr_rcas(&c, w0, w1);
+    }
   } else {
     ORC_CHECK(false, HK_E_INVALID, "unknown stage");
   }
@@ -2339,7 +2537,10 @@ int orc_frame_render(orc_ctx* ctx, const HkFrame* f, const HkView* v, const HkPr
     rc = orc_frame_stage(ctx, s, st, flags);
     if (rc) return rc;
   }
-  if (flags & HK_FRAME_ANTIALIAS) return orc_frame_stage(ctx, HK_STAGE_ANTIALIAS, st, flags);
+  if (flags & HK_FRAME_ANTIALIAS) {
+    int rc = orc_frame_stage(ctx, HK_STAGE_ANTIALIAS, st, flags);
+    return rc ? rc : orc_frame_stage(ctx, HK_STAGE_UPSCALE, st, flags);
+  }
   return HK_OK;
 }
 int orc_frame_wait(orc_ctx* ctx) { (void)ctx; return HK_OK; }

@@ -19,7 +19,8 @@ for _i in range(4):
     ALL_BUFFERS[F.BUF_DENOISE_INTERNAL0 + _i] = f"internal{_i}"
 ALL_BUFFERS.update({F.BUF_PREVIOUS_POSITION: "previous_position", F.BUF_PREVIOUS_VELOCITY_UV: "previous_velocity_uv",
                     F.BUF_PREVIOUS_TONE_MAPPED: "previous_tone_mapped", F.BUF_UPSCALE_OUTPUT: "upscale_output",
-                    F.BUF_TAA_OUTPUT: "taa_output", F.BUF_PREVIOUS_TAA_OUTPUT: "previous_taa_output"})
+                    F.BUF_TAA_OUTPUT: "taa_output", F.BUF_PREVIOUS_TAA_OUTPUT: "previous_taa_output",
+                    F.BUF_UPSCALE_SHARPENED: "upscale_sharpened"})
 
 
 class Case:
@@ -93,6 +94,12 @@ def make_case(name):
         scene, sun = yard_textured_scene()
         return Case(name, scene, synthetic_camera(80, 56), S(indirect_bounces=1, upscale=U.SMAA_TU_1_0), lights=hk.lights_uniform(directional=sun),
                     frames=range(1, 6), antialias=True)
+    if name == "cornell_aa_fsr":       # Upscale::Fsr1 end to end: TAA at the scaled size, EASU to the window, RCAS (post_process.rs:1260-1308)
+        return Case(name, cornell_scene(), hk.cornell_camera(120, 88), S(indirect_bounces=2, upscale=U.Fsr1(1.5, 0.2)), frames=range(1, 6), antialias=True)
+    if name == "yard_aa_fsr_notaa":    # FSR1 straight from the tone-mapped image (Taa::None), ratio 2, full sharpness, odd window size
+        scene, sun = yard_textured_scene()
+        return Case(name, scene, synthetic_camera(83, 57), S(indirect_bounces=1, upscale=U.Fsr1(2.0, 0.0), taa=hk.Taa.NONE),
+                    lights=hk.lights_uniform(directional=sun), frames=range(1, 4), antialias=True)
     if name == "yard_ortho":           # OrthographicProjection: the projection[3].w == 1 branches (light.wgsl:714-727,1040), parallel primary rays
         scene, sun = yard_scene()
         cam = hk.Camera(hk.look_at_transform((6.0, 7.0, 8.0), (0.0, 0.5, 0.0)), 88, 64, ortho_height=9.0)
@@ -108,7 +115,7 @@ def make_case(name):
     raise KeyError(name)
 
 
-CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5", "cornell_aa_default", "yard_aa_smaa2x", "flight_helmet", "yard_ortho"]
+CASE_NAMES = ["cornell_b2", "cornell_b1", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b0_nodenoise", "cornell_notemporal", "cornell_b8", "yard_sun", "yard_textured", "yard_no_emitters", "background_only", "tiny_3x5", "cornell_aa_default", "yard_aa_smaa2x", "flight_helmet", "yard_ortho", "cornell_aa_fsr", "yard_aa_fsr_notaa"]
 
 
 def run_case(plugin, case, on_frame=None):

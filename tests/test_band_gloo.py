@@ -177,10 +177,15 @@ def _aa_worker(rank, world, port, case_name, out_dir):
     _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
     b0, b1 = r.band(rh)
     out = {"b0": b0, "b1": b1, "rh": rh}
-    for b, name in ((F.BUF_TONE_MAPPED, "tone_mapped"), (F.BUF_UPSCALE_OUTPUT, "upscale_output"), (F.BUF_TAA_OUTPUT, "taa_output")):
+    fsr = s.upscale.kind == F.UPSCALE_FSR1
+    for b, name in ((F.BUF_TONE_MAPPED, "tone_mapped"), (F.BUF_UPSCALE_OUTPUT, "upscale_output"), (F.BUF_TAA_OUTPUT, "taa_output"),
+                    (F.BUF_UPSCALE_SHARPENED, "upscale_sharpened")):
         _, bh, _ = e.buffer_info(b)
-        scale = 2 if bh > rh else 1
-        y0, y1 = min(bh, scale * b0), (bh if b1 == rh else min(bh, scale * b1))
+        if fsr and b in (F.BUF_UPSCALE_OUTPUT, F.BUF_UPSCALE_SHARPENED):   # FSR1: a band owns its share of the window rows
+            y0, y1 = r.band(bh)
+        else:
+            scale = 2 if bh > rh else 1
+            y0, y1 = min(bh, scale * b0), (bh if b1 == rh else min(bh, scale * b1))
         out[name] = e.read(b)[y0:y1]
         out[name + "_rows"] = np.array([y0, y1])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
@@ -188,10 +193,10 @@ def _aa_worker(rank, world, port, case_name, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name", [(2, "cornell_aa_default"), (3, "yard_aa_smaa2x"), (2, "random3"), (3, "random7"), (4, "random12"),
-                                              (3, "random21"), (2, "random30"), (4, "random35")])
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_aa_default"), (3, "yard_aa_smaa2x"), (2, "cornell_aa_fsr"), (3, "yard_aa_fsr_notaa"), (2, "random3"), (3, "random7"), (4, "random12"),
+                                              (3, "random21"), (2, "random30"), (4, "random35"), (3, "random22"), (4, "random33"), (2, "random46"), (3, "random5")])
 def test_antialias_bands_equal_single_rank(tmp_path, world, case_name):
-    """All four stages on bands - for the named cases SMAA Tu4x + TAA (exchange D), for the random ones whatever the
+    """All five stages on bands - for the named cases SMAA Tu4x + TAA (exchange D) or TAA + FSR1 (exchange E), for the random ones whatever the
     seeded settings say (aprons depend on them: emissive spatial reuse, denoise off, ratio != 1, 0 bounces ...): the
     union of the bands' rows equals the single-rank image bit for bit, for a static camera."""
     from cases import make_case, random_case, run_case, snapshot
@@ -202,7 +207,8 @@ def test_antialias_bands_equal_single_rank(tmp_path, world, case_name):
     ref = oracle_plugin()
     run_case(ref, case)
     full = snapshot(ref)
-    for name in ("tone_mapped", "upscale_output", "taa_output"):
+    fsr = case.settings.upscale.kind == 0 and case.antialias
+    for name in ("tone_mapped", "upscale_output", "taa_output") + (("upscale_sharpened",) if fsr else ()):
         covered = 0
         for rank in range(world):
             d = np.load(tmp_path / f"rank{rank}.npz")

@@ -67,7 +67,7 @@ def test_pass_rows_are_independent():
         for p, ranges in ((full, [(0, 0)]), (split, [(0, cut), (cut, h)])):
             e = p.engine
             e.frame_begin(frame, view, pview, case.lights)
-            e.set_view_options(s.taa, s.upscale.kind)
+            e.set_view_options(s.taa, s.upscale.kind, s.upscale.sharpness_)
             order = [(F.PASS_PREPASS, 0), (F.PASS_FULL_SCREEN_ALBEDO, 0), (F.PASS_DIRECT_LIT, 0), (F.PASS_DIRECT_EMISSIVE, 0), (F.PASS_INDIRECT, 0),
                      (F.PASS_INDIRECT_SPATIAL_REUSE, 0)]
             for ch in range(3):

@@ -217,10 +217,14 @@ def _gpu_band_worker(rank, world, port, case_name, out_dir):
             F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8]
     out = {ALL_BUFFERS[b]: e.read(b)[b0:b1] for b in want if e.buffer_info(b)[1] == rh}   # (reservoirs are indexed with the scaled width inside full-size storage)
     if case.antialias:  # output rows: two per render row with SMAA Tu4x
-        for b in (F.BUF_UPSCALE_OUTPUT, F.BUF_TAA_OUTPUT):
+        fsr = s.upscale.kind == F.UPSCALE_FSR1
+        for b in (F.BUF_UPSCALE_OUTPUT, F.BUF_TAA_OUTPUT) + ((F.BUF_UPSCALE_SHARPENED,) if fsr else ()):
             _, bh, _ = e.buffer_info(b)
-            scale = 2 if bh > rh else 1
-            y0, y1 = min(bh, scale * b0), (bh if b1 == rh else min(bh, scale * b1))
+            if fsr and b != F.BUF_TAA_OUTPUT:   # FSR1: a band owns its share of the window rows (HK_STAGE_UPSCALE)
+                y0, y1 = r.band(bh)
+            else:
+                scale = 2 if bh > rh else 1
+                y0, y1 = min(bh, scale * b0), (bh if b1 == rh else min(bh, scale * b1))
             out[ALL_BUFFERS[b]] = e.read(b)[y0:y1]
             out[ALL_BUFFERS[b] + "_rows"] = np.array([y0, y1])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), b0=b0, b1=b1, **out)
@@ -228,7 +232,8 @@ def _gpu_band_worker(rank, world, port, case_name, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun"), (3, "cornell_aa_default"), (2, "random7"), (4, "random12"), (3, "random21")])
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun"), (3, "cornell_aa_default"), (2, "random7"), (4, "random12"), (3, "random21"), (2, "cornell_aa_fsr"),
+                                              (3, "random33")])
 def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
     """The band-sharded GPU path (hk_set_band + hk_frame_stage + halo exchange) on ONE GPU: every
     rank renders its band on device 0, halos travel over gloo (staged through host memory because
@@ -398,13 +403,15 @@ AA_CASES = {
     "smaa_ratio2_taa": dict(size=(128, 96), settings=dict(indirect_bounces=2)),                                     # the reference's defaults
     "smaa_ratio1_taa": dict(size=(72, 56), settings=dict(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)),      # 2x the window
     "smaa_odd_no_taa": dict(size=(101, 75), settings=dict(indirect_bounces=1, taa=hk.Taa.NONE)),                    # odd sizes: quads hang over the edge
-    "fsr_ratio15_taa": dict(size=(90, 66), settings=dict(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.5, 0.2))),   # TAA at the scaled size
+    "fsr_ratio15_taa": dict(size=(90, 66), settings=dict(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.5, 0.2))),   # TAA at the scaled size, EASU + RCAS
+    "fsr_ratio2_no_taa": dict(size=(101, 75), settings=dict(indirect_bounces=1, upscale=hk.Upscale.Fsr1(2.0, 0.0), taa=hk.Taa.NONE)),
+    "fsr_ratio1_taa": dict(size=(64, 40), settings=dict(indirect_bounces=0, upscale=hk.Upscale.Fsr1(1.0, 1.5))),      # EASU at 1:1
 }
 
 
 @pytest.mark.parametrize("name", sorted(AA_CASES))
 def test_antialias_bit_exact_vs_oracle(name):
-    """SMAA Tu4x + TAA after the light path, static scene: every buffer bit-exact, frame by frame,
+    """SMAA Tu4x / TAA / FSR1 after the light path, static scene: every buffer bit-exact, frame by frame,
     through hk_frame_render(HK_FRAME_ANTIALIAS) on the GPU and dispatch by dispatch on the oracle."""
     case = AA_CASES[name]
     s = hk.HikariSettings(**case["settings"])
@@ -450,7 +457,7 @@ def test_antialias_kernels_under_motion_on_identical_inputs():
             for b in inputs:      # ... then the oracle's inputs, and only the AA dispatches
                 gpu.engine.write(b, cpu.engine.read(b))
             gpu.post_process.run_antialias(s)
-            for b in (F.BUF_UPSCALE_OUTPUT, F.BUF_TAA_OUTPUT):
+            for b in (F.BUF_UPSCALE_OUTPUT, F.BUF_TAA_OUTPUT, F.BUF_UPSCALE_SHARPENED):
                 a, o = gpu.engine.read(b), cpu.engine.read(b)
                 assert (a == o).all(), (n, b, int((a != o).any(axis=2).sum()))
             vel = cpu.engine.read(F.BUF_VELOCITY_UV)[..., :2]

@@ -30,7 +30,7 @@ for name in CASE_NAMES:
     for k in ("tone_mapped", "denoise_render0", "denoise_render1", "denoise_render2", "render2", "variance2"):
         data[k] = snap[k]
     if case.antialias:
-        for k in ("upscale_output", "taa_output"):
+        for k in ("upscale_output", "taa_output", "upscale_sharpened"):
             data[k] = snap[k]
     st = p.engine.stats()
     data["rays"] = np.array([st.rays_primary, st.rays_tlas, st.rays_blas], dtype=np.uint64)
