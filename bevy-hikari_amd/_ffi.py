@@ -129,7 +129,8 @@ class HkHaloOp(C.Structure):
 class HkStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
-                ("_pad", u32), ("scene_mesh_builds", u64), ("scene_instance_builds", u64)]
+                ("_pad", u32), ("scene_mesh_builds", u64), ("scene_instance_builds", u64),
+                ("scene_async_instance_uploads", u64)]
 
 
 assert C.sizeof(HkVertex) == 32 and C.sizeof(HkPrimitive) == 48 and C.sizeof(HkNode) == 32 and C.sizeof(HkInstance) == 176

@@ -31,6 +31,11 @@ using namespace hkd;
 
 namespace {
 
+__global__ void k_copy_u4(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 template <typename T>
 struct DevArray {
   T* p = nullptr;
@@ -124,6 +129,16 @@ struct hk_ctx {
   // device scene
   uint8_t* scene_mem = nullptr;  // every scene array in one allocation (so small scenes can be staged in LDS by one copy loop)
   size_t dyn_capacity = 0, static_bytes = 0;
+  // Scenes too big for the LDS copy keep TWO slots of the instance-level region, [slot 0][slot 1][mesh region]: an
+  // instance-only update goes through pinned staging into the slot the frames in flight do NOT read, in stream
+  // order, so neither the host nor the GPU waits (animated scenes must not stall on the host).
+  bool two_slots = false;
+  int slot = 0;
+  uint8_t* staging[2] = {nullptr, nullptr};
+  size_t staging_bytes[2] = {0, 0};
+  hipEvent_t staging_done[2] = {nullptr, nullptr};
+  bool staging_pending[2] = {false, false};
+  uint64_t async_instance_uploads = 0;
   size_t st_nodes = 0, st_v0 = 0, st_v1 = 0, st_v2 = 0, st_vn = 0, st_vuv = 0;  // offsets inside the mesh-level region
   uint64_t static_rebuilds = 0, dynamic_rebuilds = 0;
   const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
@@ -529,34 +544,74 @@ int finalize_scene(hk_ctx* c) {
   Blob dyn;
   DynOffsets o{};
   if ((rc = build_dynamic_region(c, dyn, o))) return rc;
-  HK_HIP(hipStreamSynchronize(c->stream));  // frames in flight still read the old arrays
+  const bool in_place = !need_static && dyn.bytes.size() <= c->dyn_capacity;
+  if (!(in_place && c->two_slots)) HK_HIP(hipStreamSynchronize(c->stream));  // frames in flight still read the arrays rewritten below
   if (need_static) {
     Blob st;
     if ((rc = build_static_region(c, st, c->st_nodes, c->st_v0, c->st_v1, c->st_v2, c->st_vn, c->st_vuv))) return rc;
     if (c->scene_mem) { (void)hipFree(c->scene_mem); c->scene_mem = nullptr; }
     c->dyn_capacity = dyn.bytes.size();  // exact: a small scene stays small enough for the LDS copy
     c->static_bytes = st.bytes.size();
-    HK_HIP(hipMalloc((void**)&c->scene_mem, c->dyn_capacity + c->static_bytes));
-    HK_HIP(hipMemcpy(c->scene_mem + c->dyn_capacity, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
-  } else if (dyn.bytes.size() > c->dyn_capacity) {  // instance count grew: move the mesh region behind a larger slot, device to device
+    c->two_slots = c->dyn_capacity + c->static_bytes > HK_LDS_SCENE_BYTES;
+    c->slot = 0;
+    // room for the previous model matrix of every instance, so that the first moving frame already fits its slot
+    if (c->two_slots) c->dyn_capacity = (c->dyn_capacity + 64 * c->instances.size() + 31) & ~(size_t)31;
+    const size_t slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
+    HK_HIP(hipMalloc((void**)&c->scene_mem, slots + c->static_bytes));
+    HK_HIP(hipMemcpy(c->scene_mem + slots, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
+  } else if (!in_place) {  // instance count grew: move the mesh region behind larger slots, device to device
     const size_t cap = ((dyn.bytes.size() + dyn.bytes.size() / 2) + 31) & ~(size_t)31;
+    const size_t old_slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
+    c->two_slots = c->two_slots || cap + c->static_bytes > HK_LDS_SCENE_BYTES;
+    c->slot = 0;
+    const size_t slots = (c->two_slots ? 2 : 1) * cap;
     uint8_t* mem = nullptr;
-    HK_HIP(hipMalloc((void**)&mem, cap + c->static_bytes));
-    HK_HIP(hipMemcpy(mem + cap, c->scene_mem + c->dyn_capacity, c->static_bytes, hipMemcpyDeviceToDevice));
+    HK_HIP(hipMalloc((void**)&mem, slots + c->static_bytes));
+    HK_HIP(hipMemcpy(mem + slots, c->scene_mem + old_slots, c->static_bytes, hipMemcpyDeviceToDevice));
     (void)hipFree(c->scene_mem);
     c->scene_mem = mem;
     c->dyn_capacity = cap;
+  } else if (c->two_slots) {
+    c->slot ^= 1;
   }
-  HK_HIP(hipMemcpy(c->scene_mem, dyn.bytes.data(), dyn.bytes.size(), hipMemcpyHostToDevice));
-  if (dyn.bytes.size() < c->dyn_capacity) HK_HIP(hipMemset(c->scene_mem + dyn.bytes.size(), 0, c->dyn_capacity - dyn.bytes.size()));
+  const size_t slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
+  uint8_t* const slot_mem = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+  if (in_place && c->two_slots) {
+    const int k = c->slot;
+    if (c->staging_pending[k]) {  // the copy that last read this staging buffer (two updates ago)
+      HK_HIP(hipEventSynchronize(c->staging_done[k]));
+      c->staging_pending[k] = false;
+    }
+    if (c->staging_bytes[k] < c->dyn_capacity) {
+      if (c->staging[k]) (void)hipHostFree(c->staging[k]);
+      c->staging[k] = nullptr;
+      c->staging_bytes[k] = 0;
+      HK_HIP(hipHostMalloc((void**)&c->staging[k], c->dyn_capacity, hipHostMallocDefault));
+      c->staging_bytes[k] = c->dyn_capacity;
+    }
+    if (!c->staging_done[k]) HK_HIP(hipEventCreateWithFlags(&c->staging_done[k], hipEventDisableTiming));
+    memcpy(c->staging[k], dyn.bytes.data(), dyn.bytes.size());
+    memset(c->staging[k] + dyn.bytes.size(), 0, c->dyn_capacity - dyn.bytes.size());
+    // a copy KERNEL reading the pinned buffer over PCIe: the update stays on the compute queue of the stream, between
+    // the kernels of two frames, instead of a hand-off to an SDMA engine and back
+    hipLaunchKernelGGL(k_copy_u4, dim3((unsigned)((c->dyn_capacity / 16 + 255) / 256)), dim3(256), 0, c->stream, (uint4*)slot_mem,
+                       (const uint4*)c->staging[k], c->dyn_capacity / 16);
+    HK_HIP(hipGetLastError());
+    HK_HIP(hipEventRecord(c->staging_done[k], c->stream));
+    c->staging_pending[k] = true;
+    c->async_instance_uploads += 1;
+  } else {
+    HK_HIP(hipMemcpy(slot_mem, dyn.bytes.data(), dyn.bytes.size(), hipMemcpyHostToDevice));
+    if (dyn.bytes.size() < c->dyn_capacity) HK_HIP(hipMemset(slot_mem + dyn.bytes.size(), 0, c->dyn_capacity - dyn.bytes.size()));
+  }
 
-  const uint8_t* base = c->scene_mem;
-  const uint8_t* sbase = base + c->dyn_capacity;
+  const uint8_t* base = slot_mem;
+  const uint8_t* sbase = c->scene_mem + slots;
   DScene& s = c->scene;
-  s.blob = (const float4*)base;
-  s.blob_f4 = (uint32_t)((c->dyn_capacity + c->static_bytes) / 16);
+  s.blob = (const float4*)base;  // (two slots: the scene is too big for the LDS copy, blob is not read)
+  s.blob_f4 = (uint32_t)((slots + c->static_bytes) / 16);
   s.nodes = (const float4*)base;
-  s.blas_base = (uint32_t)((c->dyn_capacity + c->st_nodes) / 32);
+  s.blas_base = (uint32_t)(((size_t)(sbase - base) + c->st_nodes) / 32);
   s.instances = (const DInstance*)(base + o.instances);
   c->d_prev_models = (const float4*)(base + o.prev_models);
   s.tri_v0 = (const float4*)(sbase + c->st_v0); s.tri_v1 = (const float4*)(sbase + c->st_v1); s.tri_v2 = (const float4*)(sbase + c->st_v2);
@@ -892,6 +947,10 @@ void hk_destroy(hk_ctx* c) {
   if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
   free_screen(c);
   if (c->scene_mem) (void)hipFree(c->scene_mem);
+  for (int k = 0; k < 2; ++k) {
+    if (c->staging[k]) (void)hipHostFree(c->staging[k]);
+    if (c->staging_done[k]) (void)hipEventDestroy(c->staging_done[k]);
+  }
   c->d_tex_data.release();
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -1316,6 +1375,7 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   out->last_frame_ms = c->last_frame_ms;
   out->scene_mesh_builds = c->static_rebuilds;
   out->scene_instance_builds = c->dynamic_rebuilds;
+  out->scene_async_instance_uploads = c->async_instance_uploads;
   for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
     out->pass_ms_total[i] = c->slot_ms[i];
     out->pass_launches[i] = c->slot_launches[i];

@@ -113,6 +113,8 @@ __device__ __forceinline__ Pixel pixel_of_thread(int width, int row_begin, int r
 
 }  // namespace hkd
 
+#define HK_LDS_SCENE_BYTES 32768u  // scenes up to this size are copied into LDS by the ray kernels (lds_bytes_for)
+
 namespace hk {
 static inline dim3 grid_for(int width, int rows) {
   int tiles_x = (width + 15) / 16, tiles_y = (rows + 15) / 16;

@@ -703,7 +703,7 @@ using namespace hkd;
 
 
 // LDS staging is used when the whole scene blob fits comfortably (4 workgroups per CU stay resident)
-static inline size_t lds_bytes_for(const DScene& sc) { return (size_t)sc.blob_f4 * 16 <= 32768 ? (size_t)sc.blob_f4 * 16 : 0; }
+static inline size_t lds_bytes_for(const DScene& sc) { return (size_t)sc.blob_f4 * 16 <= HK_LDS_SCENE_BYTES ? (size_t)sc.blob_f4 * 16 : 0; }
 
 void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj,
                     const float* prev_view_proj, const float4* prev_models, float jitter_x, float jitter_y, const GBuffer& g, int y0, int y1,

@@ -321,6 +321,9 @@ typedef struct HkStats {
    * instance-only update must leave scene_mesh_builds unchanged. */
   uint64_t scene_mesh_builds;
   uint64_t scene_instance_builds;
+  /* ... of which the instance-level arrays went through pinned staging into the spare slot in stream order, with no
+   * host or device wait (scenes larger than the 32 KB LDS copy keep two slots of the instance-level region) */
+  uint64_t scene_async_instance_uploads;
 } HkStats;
 
 typedef struct hk_ctx hk_ctx;

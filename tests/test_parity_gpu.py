@@ -356,6 +356,42 @@ def test_dynamic_instances_vs_oracle():
     assert (st.scene_mesh_builds, st.scene_instance_builds) == (1, 8)
 
 
+def test_instance_updates_in_flight_use_the_spare_slot():
+    """A scene too big for the LDS copy keeps two slots of the instance-level region: eight animated frames are
+    enqueued back to back - builder re-finish, upload, render, no wait in between - each update going through pinned
+    staging into the slot the frames in flight do not read.  The G-buffer of the last frame (which also holds the
+    previous-model velocity) must be the oracle's, bit for bit, and every update after the first must have taken the
+    asynchronous route."""
+    from bevy_hikari_amd.scenes import animate, synthetic_camera, synthetic_scene
+
+    scene, sun = synthetic_scene(n_boxes=24, n_spheres=6, n_emitters=3, sphere_rings=12, sphere_segs=16)
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam, lights = synthetic_camera(160, 96), hk.lights_uniform(directional=sun)
+    gpu, cpu = hk.HikariPlugin(device=0), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    movers = (2, 5, 11, 17, 23, 26, 29)
+    for p in (gpu, cpu):
+        p.render(cam, s, lights=lights, frame_number=1)
+    cur = scene
+    for n in range(2, 10):                            # GPU: no read, no wait until the end
+        cur = animate(cur, n - 1, movers=movers)
+        gpu.update_instances(cur)
+        gpu.render(cam, s, lights=lights, frame_number=n)
+    cur = animate(cur, 0, movers=movers)              # replay the same poses for the oracle (animate sets absolute poses)
+    for n in range(2, 10):
+        cur = animate(cur, n - 1, movers=movers)
+        cpu.update_instances(cur)
+        cpu.render(cam, s, lights=lights, frame_number=n)
+    bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+    assert not any(k in bad for k in GBUFFER + ("previous_position", "previous_velocity_uv")), bad
+    assert (gpu.engine.read(F.BUF_VELOCITY_UV)[..., :2] != 0).any()
+    a, b = gpu.output(s), cpu.output(s)
+    assert float(np.linalg.norm(a - b) / np.linalg.norm(b)) <= 1e-3
+    st = gpu.engine.stats()
+    assert (st.scene_mesh_builds, st.scene_instance_builds, st.scene_async_instance_uploads) == (1, 9, 8)   # (the slot has room for the previous models from the start)
+
+
 def test_instance_growth_and_late_mesh_use():
     """Instance count grows past the instance-level slot (device-to-device move of the mesh region), then
     an instance of a mesh no earlier instance used appears (its BLAS leaf boxes must be derived).  A static
