@@ -32,6 +32,8 @@ namespace hkd {
 // Small scenes (the whole Cornell box is 9 KB) are copied into LDS once per workgroup and traversed
 // from there: a node step is then a ds_read_b128 pair (~64-cycle latency, 128+ B/clk/CU) instead of
 // an L1-hit global load (~120+ cycles) in the dependent load -> slab test -> next-index chain.
+// (Skipping the copy in workgroups whose pixels are all background - 63 % of the Cornell frame - was measured and
+// rejected: the vote needs the depth first, which puts an HBM round trip in front of the copy; 0.417 vs 0.38 ms.)
 template <bool LDS>
 __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
   if constexpr (!LDS) {
@@ -327,6 +329,39 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   flush_counters<COUNT>(rc, 0, counters);
 }
 
+// HK_PROFILE_SECTIONS (tools/section_profile.py builds a variant with it): wave-level cycle shares of the sections of
+// k_indirect, read with the scalar clock so that a section entered by any lane of the wave is charged once.
+#ifdef HK_PROFILE_SECTIONS
+__device__ unsigned long long g_sections[16];
+struct SecTimer {
+  unsigned long long t0, acc[12];
+  int cur;
+  __device__ void start() {
+    for (int i = 0; i < 12; ++i) acc[i] = 0;
+    cur = 0;
+    t0 = __builtin_amdgcn_s_memtime();
+  }
+  __device__ __forceinline__ void mark(int next) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    acc[cur] += t - t0;
+    t0 = t;
+    cur = next;
+  }
+  __device__ void flush() {
+    mark(0);
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0)  // first active lane
+      for (int i = 0; i < 12; ++i) atomicAdd(&g_sections[i], acc[i]);
+  }
+};
+#define HK_SEC(tm, i) (tm).mark(i)
+#else
+struct SecTimer {
+  __device__ void start() {}
+  __device__ void flush() {}
+};
+#define HK_SEC(tm, i) ((void)0)
+#endif
+
 // One iteration of the MULTIPLE_BOUNCES loop (light.wgsl:1313-1394) on the state a path carries from
 // bounce to bounce.  Returns false when the path ends at this bounce (miss -> ambient, `break`).
 struct PathState {
@@ -338,14 +373,17 @@ struct PathState {
   f3 first_normal;             // s.sample_normal   (bounce 0)
   float pdf;                   // rand_sample.w of bounce 0
 };
-__device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, uint32_t n, PathState& p, RayCounters& rc) {
+__device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, uint32_t n, PathState& p, RayCounters& rc, SecTimer& tm) {
+  HK_SEC(tm, 1);
   f4 rand_sample = sample_cosine_hemisphere(F2(p.random.x, p.random.y));
   Ray ray;
   ray.origin = p.position + p.normal * HK_RAY_BIAS;
   ray.direction = mul(normal_basis(p.normal), xyz(rand_sample));
   ray.inv_direction = 1.0f / ray.direction;
 
+  HK_SEC(tm, 2);
   Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+  HK_SEC(tm, 3);
   HitInfo info = hit_info(sc, ray, hit);
   if (n == 0u) {
     p.first_position = info.position;
@@ -360,7 +398,9 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
     Surface surface = retreive_surface(sc, info.material_index, info.uv);
     surface.roughness = 1.0f;
     const uint32_t info_instance = info.instance_index;
+    HK_SEC(tm, 4);
     LightCandidate candidate = select_light_candidate(sc, fr, p.random, sample_position, sample_normal, info_instance, info, rc);
+    HK_SEC(tm, 5);
     const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
     const f3 bounce_view_direction = normalize(p.position - sample_position);
 
@@ -368,7 +408,9 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
       ray.origin = sample_position + sample_normal * HK_RAY_BIAS;
       ray.direction = candidate.direction;
       ray.inv_direction = 1.0f / ray.direction;
+      HK_SEC(tm, 6);
       hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+      HK_SEC(tm, 7);
       occlude_hit_info(ray, hit, info);
       f4 in_radiance = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
       out_radiance = shading(fr, bounce_view_direction, sample_normal, ray.direction, surface, in_radiance);
@@ -396,6 +438,8 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
   RayCounters rc{0, 0};
+  SecTimer tm;
+  tm.start();
   if (px.valid) {
     const int x = px.x, y = px.y;
     const int index = x + fr.rw * y;
@@ -445,7 +489,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
         p.first_normal = s.sample_normal;
         p.pdf = 0.0f;
         for (uint32_t n = 0u; n < fr.indirect_bounces && (p.transport.x > 0.01f || p.transport.y > 0.01f || p.transport.z > 0.01f); n += 1u) {
-          if (!bounce_step(sc, fr, n, p, rc)) break;
+          if (!bounce_step(sc, fr, n, p, rc, tm)) break;
         }
         s.radiance = p.radiance;
         s.sample_position = p.first_position;
@@ -486,6 +530,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
       }
 
       // ReSTIR: temporal, light.wgsl:1452-1497
+      HK_SEC(tm, 8);
       const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
       r = load_reservoir_uv(t.previous, previous_uv, fr.rw, fr.rh);
       if (!check_previous_reservoir(r, s) && fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f) {
@@ -505,11 +550,13 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
       r.s.visible_normal = s.visible_normal;
       r.lifetime += 1.0f;
 
+      HK_SEC(tm, 9);
       t.variance[index] = reservoir_variance(r);
       if (fr.temporal_reuse > 0u) store_packed(t.current, index, pack_reservoir(r));
       t.render[index] = pack_f16x4(F4(out_radiance * r.w, 1.0f));
     }
   }
+  tm.flush();
   flush_counters<COUNT>(rc, 0, counters);
 }
 
@@ -703,6 +750,18 @@ using namespace hkd;
 
 
 // LDS staging is used when the whole scene blob fits comfortably (4 workgroups per CU stay resident)
+#ifdef HK_PROFILE_SECTIONS
+extern "C" int hk_debug_read_sections(unsigned long long* out16, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hkd::g_sections), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hkd::g_sections), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
 static inline size_t lds_bytes_for(const DScene& sc) { return (size_t)sc.blob_f4 * 16 <= HK_LDS_SCENE_BYTES ? (size_t)sc.blob_f4 * 16 : 0; }
 
 void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj,

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Where does k_indirect spend its wave time?  Builds (``--build``, no GPU needed) a variant of the library with
+-DHK_PROFILE_SECTIONS into build_ab/ and, on the GPU box, renders the bench workload with it and prints the share of
+wave cycles per section (scalar clock, charged once per wave when any lane is inside the section)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = os.path.join(ROOT, "build_ab", "libhikari_hip_sections.so")
+NAMES = ["prologue+idle", "sample+ray setup", "closest-hit traversal", "hit_info+surface", "light candidate", "shadow ray setup",
+         "shadow traversal", "radiance+shading+throughput", "ReSTIR temporal", "stores"]
+
+if "--build" in sys.argv:
+    os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
+    csrc = os.path.join(ROOT, "bevy-hikari_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "context.hip", "host_logic.cpp", "scene_builder.cpp")]
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DHK_PROFILE_SECTIONS",
+                    "-o", VARIANT] + srcs, check=True, cwd=csrc)
+    print("built", VARIANT)
+    sys.exit(0)
+
+os.environ["HIKARI_HIP_LIB"] = VARIANT
+sys.path.insert(0, ROOT)
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+
+w, h, bounces = 1920, 1080, 2
+p = hk.HikariPlugin(device=0, flags=F.CTX_SINGLE_STREAM)
+p.set_scene(hk.load_cornell())
+s = hk.HikariSettings(indirect_bounces=bounces, upscale=hk.Upscale.SMAA_TU_1_0)
+cam = hk.cornell_camera(w, h)
+read = p.engine.api.dll.hk_debug_read_sections
+read.argtypes, read.restype = [C.POINTER(C.c_ulonglong), C.c_int], C.c_int
+out = (C.c_ulonglong * 16)()
+for n in range(1, 9):
+    p.render(cam, s, frame_number=n)
+p.engine.wait()
+assert read(out, 1) == 0
+for n in range(9, 29):
+    p.render(cam, s, frame_number=n)
+p.engine.wait()
+assert read(out, 0) == 0
+tot = float(sum(out[:12]))
+print(json.dumps({"workload": f"cornell {w}x{h} b{bounces}", "frames": 20,
+                  "share": {NAMES[i]: round(out[i] / tot, 4) for i in range(len(NAMES))}}, indent=1))
