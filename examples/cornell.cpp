@@ -3,7 +3,7 @@
 // libhikari_hip.so through the C++ host mirror include/hikari.hpp.  Headless: renders N frames and
 // writes the tone-mapped image as a PPM and/or the raw rgba16f words.
 //
-//   cornell [--size W H] [--frames N] [--bounces B] [--ratio R] [--by-nodes] [--antialias] [--ppm out.ppm] [--raw out.bin] [--describe]
+//   cornell [--size W H] [--frames N] [--bounces B] [--ratio R | --fsr R SHARPNESS] [--by-nodes] [--antialias] [--ppm out.ppm] [--raw out.bin] [--describe]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,8 +83,9 @@ int main(int argc, char** argv) {
     else if (a == "--frames" && i + 1 < argc) frames = (size_t)atoi(argv[++i]);
     else if (a == "--bounces" && i + 1 < argc) settings.indirect_bounces = (size_t)atoi(argv[++i]);
     else if (a == "--ratio" && i + 1 < argc) settings.upscale = Upscale::SmaaTu4x((float)atof(argv[++i]));
+    else if (a == "--fsr" && i + 2 < argc) { const float r = (float)atof(argv[++i]); settings.upscale = Upscale::Fsr1(r, (float)atof(argv[++i])); }  // ratio, sharpness
     else if (a == "--by-nodes") by_nodes = true;
-    else if (a == "--antialias") antialias = true;  // SMAA Tu4x + TAA as the settings say; output = what the overlay presents
+    else if (a == "--antialias") antialias = true;  // SMAA Tu4x / TAA / FSR1 as the settings say; output = what the overlay presents
     else if (a == "--ppm" && i + 1 < argc) ppm = argv[++i];
     else if (a == "--raw" && i + 1 < argc) raw = argv[++i];
     else if (a == "--assets" && i + 1 < argc) assets = argv[++i];

@@ -64,3 +64,21 @@ def test_cpp_host_antialias_matches_the_python_host(tmp_path, by_nodes):
     for n in range(1, 6):
         p.render(hk.cornell_camera(96, 64), s, frame_number=n, antialias=True)
     assert (got == p.engine.read(F.BUF_TAA_OUTPUT)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("by_nodes", [False, True])
+def test_cpp_host_fsr_matches_the_python_host(tmp_path, by_nodes):
+    """--fsr: TAA at the scaled size, then FSR1 EASU + RCAS to the window; the overlay image is upscale_output[1]."""
+    raw = tmp_path / "fsr.bin"
+    args = ["--size", "96", "64", "--frames", "4", "--bounces", "1", "--fsr", "1.5", "0.2", "--antialias", "--raw", str(raw)] + (["--by-nodes"] if by_nodes else [])
+    r = run(*args)
+    assert r.returncode == 0, r.stderr
+    assert "output size 96x64" in r.stdout
+    got = np.fromfile(raw, dtype=np.uint16).reshape(64, 96, 4)
+    p = hk.HikariPlugin(device=0)
+    p.set_scene(hk.load_cornell())
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.5, 0.2))
+    for n in range(1, 5):
+        p.render(hk.cornell_camera(96, 64), s, frame_number=n, antialias=True)
+    assert (got == p.engine.read(F.BUF_UPSCALE_SHARPENED)).all()
