@@ -1,0 +1,96 @@
+"""Property tests of the halo plan (hk_band_plan_for, host logic of the band-sharded frame): for any window size,
+upscale ratio, band count and settings, every op names rows the peer OWNS and this band does not, ops of one buffer
+never overlap, together with the own band they form one contiguous row range, and that range is the band grown by a
+footprint that does not depend on which band asks (except where the image border cuts it)."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+from bevy_hikari_amd.distributed import halo_plan
+
+S, U = hk.HikariSettings, hk.Upscale
+
+sizes = st.tuples(st.integers(64, 4096), st.integers(64, 2400))
+ratios = st.sampled_from([1.0, 1.25, 1.5, 2.0])
+flags = st.tuples(st.booleans(), st.booleans(), st.booleans(), st.booleans(), st.booleans(), st.integers(0, 3))
+
+
+def make_settings(ratio, fl):
+    fsr, taa, emissive, indirect, denoise, bounces = fl
+    return S(upscale=U.Fsr1(ratio, 0.2) if fsr else U.SmaaTu4x(ratio), taa=hk.Taa.Jasmine if taa else hk.Taa.NONE,
+             emissive_spatial_reuse=emissive, indirect_spatial_reuse=indirect, denoise=denoise, indirect_bounces=bounces)
+
+
+def band(rows, i, n):
+    base, rem = divmod(rows, n)
+    b0 = i * base + min(i, rem)
+    return b0, b0 + base + (1 if i < rem else 0)
+
+
+def buffer_rows(width, height, ratio, s, buf):
+    """(rows of the buffer, rows per scaled render row) as the library sizes it for these settings"""
+    rw, rh = F.u32(), F.u32()
+    F.api().call("scaled_size", width, height, ratio, rw, rh)
+    if buf in (F.BUF_TAA_OUTPUT, F.BUF_PREVIOUS_TAA_OUTPUT) and s.upscale.kind == F.UPSCALE_SMAA_TU4X:
+        return int(np.ceil(np.float32(height) * (np.float32(1.0) / np.float32(max(1.0, min(2.0, ratio)))) * np.float32(2.0))), 2
+    return rh.value, 1
+
+
+@settings(max_examples=150, deadline=None)
+@given(sizes, ratios, st.integers(2, 8), flags, st.integers(1, 64), st.integers(0, 6),
+       st.sampled_from([F.STAGE_TEMPORAL, F.STAGE_SPATIAL, F.STAGE_POST_PROCESS, F.STAGE_ANTIALIAS, F.STAGE_UPSCALE]))
+def test_plans_name_foreign_rows_once_and_contiguously(size, ratio, world, fl, frame, history, stage):
+    width, height = size
+    s = make_settings(ratio, fl)
+    sc = s.to_c()
+    stage_arg = stage | ((history << 8) if stage in (F.STAGE_TEMPORAL, F.STAGE_ANTIALIAS) else 0)
+    per_band = []
+    for i in range(world):
+        ops = halo_plan(width, height, ratio, i, world, stage_arg, frame, sc)
+        per_band.append(ops)
+        by_buffer = {}
+        for o in ops:
+            assert o.peer != i and 0 <= o.peer < world and o.row_begin < o.row_end
+            rows, scale = buffer_rows(width, height, ratio, s, o.buffer)
+            rh = buffer_rows(width, height, ratio, s, F.BUF_TONE_MAPPED)[0]
+            p0, p1 = band(rh, o.peer, world)
+            own0, own1 = band(rh, i, world)
+            lo, hi = scale * p0, (rows if p1 == rh else min(rows, scale * p1))
+            assert lo <= o.row_begin and o.row_end <= hi, "rows the peer does not own"
+            assert o.row_end <= scale * own0 or o.row_begin >= min(rows, scale * own1), "rows this band owns itself"
+            assert o.row_bytes > 0 and o.row_bytes % 4 == 0
+            by_buffer.setdefault(o.buffer, []).append((o.row_begin, o.row_end, scale * own0, min(rows, scale * own1)))
+        for buf, spans in by_buffer.items():
+            spans.sort()
+            for (a0, a1, _, _), (b0, b1, _, _) in zip(spans, spans[1:]):
+                assert a1 <= b0, "overlapping ops"
+            own0, own1 = spans[0][2], spans[0][3]
+            if stage != F.STAGE_UPSCALE:          # (exchange E feeds the WINDOW rows of the band, which need not touch its render rows)
+                covered = sorted([(a, b) for a, b, _, _ in spans] + [(own0, own1)])
+                for (a0, a1), (b0, b1) in zip(covered, covered[1:]):
+                    assert a1 == b0, f"gap between the halo and the band in buffer {buf}"
+    # symmetry: what the interior bands fetch below equals what they fetch above (same footprint on both sides)
+    for i in range(1, world - 1):
+        for buf in {o.buffer for o in per_band[i]}:
+            rows, scale = buffer_rows(width, height, ratio, s, buf)
+            rh = buffer_rows(width, height, ratio, s, F.BUF_TONE_MAPPED)[0]
+            own0, own1 = band(rh, i, world)
+            below = sum(o.row_end - o.row_begin for o in per_band[i] if o.buffer == buf and o.row_end <= scale * own0)
+            above = sum(o.row_end - o.row_begin for o in per_band[i] if o.buffer == buf and o.row_begin >= scale * own1)
+            if stage != F.STAGE_UPSCALE and scale * own0 >= below + 8 and rows - scale * own1 >= above + 8 and below and above:
+                assert below == above, (buf, below, above)
+
+
+@settings(max_examples=60, deadline=None)
+@given(sizes, ratios, st.integers(1, 8))
+def test_band_rows_partition_the_image(size, ratio, world):
+    rw, rh = F.u32(), F.u32()
+    F.api().call("scaled_size", size[0], size[1], ratio, rw, rh)
+    prev = 0
+    for i in range(world):
+        b0, b1 = F.u32(), F.u32()
+        F.api().call("band_rows", rh.value, i, world, b0, b1)
+        assert b0.value == prev and b1.value > b0.value and (b0.value, b1.value) == band(rh.value, i, world)
+        prev = b1.value
+    assert prev == rh.value

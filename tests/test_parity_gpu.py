@@ -392,6 +392,42 @@ def test_instance_updates_in_flight_use_the_spare_slot():
     assert (st.scene_mesh_builds, st.scene_instance_builds, st.scene_async_instance_uploads) == (1, 9, 8)   # (the slot has room for the previous models from the start)
 
 
+def test_two_slot_scene_grows_between_frames_in_flight():
+    """The same two-slot scene, with instances ADDED while frames are in flight: the update that outgrows the slots
+    takes the synchronous route (device-to-device move of the mesh region behind two larger slots), the ones after it
+    are asynchronous again.  Static camera, static objects apart from the additions: every buffer is bit-exact."""
+    from bevy_hikari_amd.scenes import _trs, synthetic_camera, synthetic_scene
+
+    scene, sun = synthetic_scene(n_boxes=24, n_spheres=6, n_emitters=3, sphere_rings=12, sphere_segs=16)
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam, lights = synthetic_camera(128, 80), hk.lights_uniform(directional=sun)
+    gpu, cpu = hk.HikariPlugin(device=0), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    b = scene.builder
+    n_frame = [0]
+
+    def frames(k):
+        for _ in range(k):
+            n_frame[0] += 1
+            for p in (gpu, cpu):
+                p.render(cam, s, lights=lights, frame_number=n_frame[0])
+
+    frames(2)
+    for round_ in range(3):       # 40 instances per round: the first round outgrows the slots (room for +50 %), later ones may not
+        for k in range(40):
+            b.add_instance(0, 1 + k % 5, _trs((-4.0 + 0.2 * k, 0.3 + 0.5 * round_, 3.0), (0.1 * k, 0.2, 0.0), (0.15, 0.15, 0.15)))
+        grown = b.finish()
+        for p in (gpu, cpu):
+            p.update_instances(grown)
+        frames(2)
+    bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+    assert bad == {}, bad
+    st = gpu.engine.stats()
+    assert st.scene_mesh_builds == 1 and st.scene_instance_builds == 4
+    assert 1 <= st.scene_async_instance_uploads <= 2      # at least one of the three updates fitted the enlarged slots
+
+
 def test_instance_growth_and_late_mesh_use():
     """Instance count grows past the instance-level slot (device-to-device move of the mesh region), then
     an instance of a mesh no earlier instance used appears (its BLAS leaf boxes must be derived).  A static
