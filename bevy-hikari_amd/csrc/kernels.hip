@@ -362,6 +362,21 @@ struct SecTimer {
 #define HK_SEC(tm, i) ((void)0)
 #endif
 
+// HK_ABLATE_WALK_TWICE (tools/section_profile.py --walk-twice): every BVH walk of k_indirect is executed twice, the
+// first result discarded behind an opaque register; the time the kernel gains is what the walks cost in issue slots.
+#ifdef HK_ABLATE_WALK_TWICE
+#define HK_ABLATE_WALK(sc, ray, maxd, mind, excl, rc)                 \
+  do {                                                                \
+    Ray r2_ = (ray);                                                  \
+    asm volatile("" : "+v"(r2_.origin.x));                            \
+    RayCounters rc2_{0, 0};                                           \
+    const Hit h2_ = traverse_top(sc, r2_, maxd, mind, excl, rc2_);    \
+    asm volatile("" ::"v"(h2_.distance), "v"(h2_.primitive_index));   \
+  } while (0)
+#else
+#define HK_ABLATE_WALK(sc, ray, maxd, mind, excl, rc) ((void)0)
+#endif
+
 // One iteration of the MULTIPLE_BOUNCES loop (light.wgsl:1313-1394) on the state a path carries from
 // bounce to bounce.  Returns false when the path ends at this bounce (miss -> ambient, `break`).
 struct PathState {
@@ -382,6 +397,7 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
   ray.inv_direction = 1.0f / ray.direction;
 
   HK_SEC(tm, 2);
+  HK_ABLATE_WALK(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
   Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
   HK_SEC(tm, 3);
   HitInfo info = hit_info(sc, ray, hit);
@@ -409,6 +425,7 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
       ray.direction = candidate.direction;
       ray.inv_direction = 1.0f / ray.direction;
       HK_SEC(tm, 6);
+      HK_ABLATE_WALK(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
       hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
       HK_SEC(tm, 7);
       occlude_hit_info(ray, hit, info);

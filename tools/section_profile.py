@@ -9,7 +9,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANT = os.path.join(ROOT, "build_ab", "libhikari_hip_sections.so")
+TWICE = "--walk-twice" in sys.argv   # ablation instead of the clock: every BVH walk of k_indirect runs twice
+VARIANT = os.path.join(ROOT, "build_ab", "libhikari_hip_walk_twice.so" if TWICE else "libhikari_hip_sections.so")
 NAMES = ["prologue+idle", "sample+ray setup", "closest-hit traversal", "hit_info+surface", "light candidate", "shadow ray setup",
          "shadow traversal", "radiance+shading+throughput", "ReSTIR temporal", "stores"]
 
@@ -17,9 +18,23 @@ if "--build" in sys.argv:
     os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
     csrc = os.path.join(ROOT, "bevy-hikari_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in ("kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "context.hip", "host_logic.cpp", "scene_builder.cpp")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DHK_PROFILE_SECTIONS",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DHK_ABLATE_WALK_TWICE" if TWICE else "-DHK_PROFILE_SECTIONS",
                     "-o", VARIANT] + srcs, check=True, cwd=csrc)
     print("built", VARIANT)
+    sys.exit(0)
+
+if TWICE:   # time k_indirect alone with the shipped library and with the variant (bench.py --passes does the timing)
+    out = {}
+    for name, lib in (("shipped", None), ("walks_twice", VARIANT)):
+        env = dict(os.environ)
+        if lib:
+            env["HIKARI_HIP_LIB"] = lib
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--passes", "--no-cpu-baseline"], env=env, capture_output=True, text=True, check=True)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out[name] = {"k_indirect_alone_ms": d["pass_ms"]["indirect_lit_ambient"], "frame_ms": d["ms_per_step"]}
+    a, b = out["shipped"]["k_indirect_alone_ms"], out["walks_twice"]["k_indirect_alone_ms"]
+    out["walk_share_of_k_indirect"] = round((b - a) / a, 4)
+    print(json.dumps(out, indent=1))
     sys.exit(0)
 
 os.environ["HIKARI_HIP_LIB"] = VARIANT
