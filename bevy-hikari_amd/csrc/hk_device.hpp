@@ -429,8 +429,26 @@ HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t no
 // same load + slab-test stream instead of serialising nested loops under partial exec masks.  Only
 // the two rare events diverge: entering an instance (ray transform) and a triangle test.  Each
 // lane's own visit order, and therefore every result bit, is that of the reference's nested loops.
+#ifdef HK_PROFILE_SECTIONS
+extern __device__ unsigned long long g_walk_events[8];  // wave-iterations: all, with any triangle test, any instance entry, any BLAS exit; lane-iterations
+// exactly one lane - the lowest active one - counts each wave iteration, so early exits of other lanes lose nothing
+#define HK_WALK_LEADER() ((unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(__builtin_amdgcn_ballot_w64(true) >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)__builtin_amdgcn_ballot_w64(true), 0u)) == 0u)
+#define HK_WALK_EVENT(k, cond) do { const bool any_ = __builtin_amdgcn_ballot_w64(cond) != 0ull; if (any_ && HK_WALK_LEADER()) wev_[k] += 1u; } while (0)
+#else
+#define HK_WALK_EVENT(k, cond) ((void)0)
+#endif
 HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, RayCounters& rc) {
   rc.tlas++;
+#ifdef HK_PROFILE_SECTIONS
+  uint32_t wev_[5] = {0u, 0u, 0u, 0u, 0u};
+  struct WalkFlush {
+    uint32_t* w;
+    __device__ ~WalkFlush() {
+      for (int k = 0; k < 5; ++k)
+        if (w[k]) atomicAdd(&g_walk_events[k], (unsigned long long)w[k]);
+    }
+  } wflush_{wev_};
+#endif
   Hit hit;
   hit.uv = F2(0.0f, 0.0f);
   hit.distance = max_distance;
@@ -444,6 +462,14 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
   f3 co = ray.origin, cinv = ray.inv_direction;  // origin / inverse direction of the level being walked
   f3 ld = ray.direction;                          // local direction while inside a BLAS
   for (;;) {
+    HK_WALK_EVENT(0, true);
+    HK_WALK_EVENT(3, index >= limit && in_blas);
+#ifdef HK_PROFILE_SECTIONS
+    {
+      const uint32_t lanes_ = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
+      if (HK_WALK_LEADER()) wev_[4] += lanes_;
+    }
+#endif
     if (index >= limit) {
       if (!in_blas) break;
       // traverse_bottom returned, light.wgsl:465-470
@@ -477,6 +503,8 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
     const bool leaf = entry >= HK_LEAF;
     // inner node: descend on a hit, skip the subtree otherwise; leaf: always continue at its exit
     index = (leaf || !box_hit) ? exit_ : entry;
+    HK_WALK_EVENT(1, leaf && box_hit && in_blas);
+    HK_WALK_EVENT(2, leaf && box_hit && !in_blas);
     if (leaf && box_hit) {  // the two rare events
       if (in_blas) {
         const uint32_t primitive_index = prim_base + entry - HK_LEAF;

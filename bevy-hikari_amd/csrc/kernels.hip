@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
 // k_indirect, read with the scalar clock so that a section entered by any lane of the wave is charged once.
 #ifdef HK_PROFILE_SECTIONS
 __device__ unsigned long long g_sections[16];
+__device__ unsigned long long g_walk_events[8];
 struct SecTimer {
   unsigned long long t0, acc[12];
   int cur;
@@ -768,12 +769,14 @@ using namespace hkd;
 
 // LDS staging is used when the whole scene blob fits comfortably (4 workgroups per CU stay resident)
 #ifdef HK_PROFILE_SECTIONS
-extern "C" int hk_debug_read_sections(unsigned long long* out16, int reset) {
+extern "C" int hk_debug_read_sections(unsigned long long* out16 /* 24 values */, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hkd::g_sections), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(hkd::g_walk_events), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {
     unsigned long long z[16] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(hkd::g_sections), z, sizeof(z)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(hkd::g_walk_events), z, 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
   }
   return 0;
 }

@@ -49,7 +49,7 @@ s = hk.HikariSettings(indirect_bounces=bounces, upscale=hk.Upscale.SMAA_TU_1_0)
 cam = hk.cornell_camera(w, h)
 read = p.engine.api.dll.hk_debug_read_sections
 read.argtypes, read.restype = [C.POINTER(C.c_ulonglong), C.c_int], C.c_int
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 for n in range(1, 9):
     p.render(cam, s, frame_number=n)
 p.engine.wait()
@@ -60,4 +60,8 @@ p.engine.wait()
 assert read(out, 0) == 0
 tot = float(sum(out[:12]))
 print(json.dumps({"workload": f"cornell {w}x{h} b{bounces}", "frames": 20,
-                  "share": {NAMES[i]: round(out[i] / tot, 4) for i in range(len(NAMES))}}, indent=1))
+                  "share": {NAMES[i]: round(out[i] / tot, 4) for i in range(len(NAMES))},
+                  # every walk of the frame (all ray kernels): what a wave pays per loop iteration
+                  "walk": {"wave_iterations_per_frame": out[16] / 20, "with_a_triangle_test": round(out[17] / out[16], 4),
+                           "with_an_instance_entry": round(out[18] / out[16], 4), "with_a_blas_exit": round(out[19] / out[16], 4),
+                           "active_lanes_per_iteration": round(out[20] / out[16], 2)}}, indent=1))
