@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""One-off wide sweep of tests/test_parity_gpu.py::test_random_settings_vs_oracle: seeds [first, last) of
+cases.random_case, three frames each, every buffer GPU vs oracle bit for bit.  Prints one JSON line."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bevy_hikari_amd as hk
+from cases import diff_buffers, random_case, snapshot
+from oracle_lib import oracle_plugin
+
+first, last = int(sys.argv[1]), int(sys.argv[2])
+fresh = "--fresh" in sys.argv      # a new pair of contexts per seed (what the committed test does) instead of one pair for the sweep
+gpu, cpu = hk.HikariPlugin(device=0), oracle_plugin()
+bad, kinds, t0 = {}, {"fsr": 0, "smaa": 0, "antialias": 0, "frames": 0}, time.time()
+for seed in range(first, last):
+    case = random_case(seed)
+    if fresh:
+        gpu, cpu = hk.HikariPlugin(device=0), oracle_plugin()
+    kinds["fsr" if case.settings.upscale.kind == 0 else "smaa"] += 1
+    kinds["antialias"] += int(case.antialias)
+    for p in (gpu, cpu):
+        p.set_scene(case.scene)
+        p._previous_camera = None   # a camera cut WITH history is camera motion: the reference's scatter-store race, not a parity case
+    for n in case.frames:
+        for p in (gpu, cpu):
+            p.render(case.camera, case.settings, lights=case.lights, frame_number=n, antialias=case.antialias)
+        kinds["frames"] += 1
+        d = diff_buffers(snapshot(gpu), snapshot(cpu))
+        if d:
+            bad[f"{seed}:{n}"] = d
+            break
+short = {k: {b: v[:90] for b, v in d.items()} for k, d in list(bad.items())[:6]}
+print(json.dumps({"seeds": [first, last], "fresh_contexts": fresh, "cases": kinds, "n_mismatching_seeds": len(bad), "which": list(bad)[:40], "first": short,
+                  "seconds": round(time.time() - t0, 1)}))
