@@ -654,7 +654,7 @@ def test_one_context_pair_through_many_scenes_sizes_and_settings():
     (hk_resize: new buffers, zeroed reservoirs, plane parity reset), the upscale kind and the settings under a live
     context.  The camera history is dropped at each cut - a cut WITH history is camera motion, i.e. the reference's
     scatter-store race - and every buffer of every frame stays bit-exact.
-    (tools/fuzz_sweep.py runs the same loop over any seed range; 400 seeds / 1200 frames were clean.)"""
+    (tools/fuzz_sweep.py runs the same loop over any seed range; 3400 seeds / 10 200 frames were clean.)"""
     from cases import random_case
 
     gpu, cpu = hk.HikariPlugin(device=0), oracle()
