@@ -34,7 +34,7 @@ PASS_NAMES = ["prepass", "full_screen_albedo", "direct_lit", "direct_emissive", 
               "smaa_tu4x", "smaa_tu4x_extrapolate", "taa_jasmine", "fsr_easu", "fsr_rcas"]
 # HkStage
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_ANTIALIAS, STAGE_UPSCALE, STAGE_COUNT = range(6)
-CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM = 1, 2, 4, 8
+CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER = 1, 2, 4, 8, 16
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS = 1, 2
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1

@@ -141,6 +141,11 @@ struct hk_ctx {
   uint64_t async_instance_uploads = 0;
   size_t st_nodes = 0, st_v0 = 0, st_v1 = 0, st_v2 = 0, st_vn = 0, st_vuv = 0;  // offsets inside the mesh-level region
   uint64_t static_rebuilds = 0, dynamic_rebuilds = 0;
+  // HK_CTX_DETERMINISTIC_SCATTER: parked previous_spatial stores; set 0 serves the two direct-light dispatches (in order
+  // on one stream), set 1 indirect_lit_ambient, which may run beside them
+  int* det_winner[2] = {nullptr, nullptr};
+  int* det_to[2] = {nullptr, nullptr};
+  void* det_pending[2] = {nullptr, nullptr};
   const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
   DevArray<uint32_t> d_noise;
   DevArray<uint32_t> d_tex_data;
@@ -219,6 +224,13 @@ bool certify_uv_division(int size) {
 }
 
 int free_screen(hk_ctx* c) {
+  for (int k = 0; k < 2; ++k) {
+    if (c->det_winner[k]) (void)hipFree(c->det_winner[k]);
+    if (c->det_to[k]) (void)hipFree(c->det_to[k]);
+    if (c->det_pending[k]) (void)hipFree(c->det_pending[k]);
+    c->det_winner[k] = c->det_to[k] = nullptr;
+    c->det_pending[k] = nullptr;
+  }
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
     if (c->buf[b]) (void)hipFree(c->buf[b]);
     c->buf[b] = nullptr;
@@ -686,6 +698,10 @@ LightTargets make_light_targets(const hk_ctx* c, int channel) {
   t.spatial = (PackedReservoir*)c->buf[HK_BUF_RESERVOIR0 + prev + S[channel]];
   t.variance = (float*)c->buf[HK_BUF_VARIANCE0 + channel];
   t.render = (uint2*)c->buf[HK_BUF_RENDER0 + channel];
+  const int set = channel == 2 ? 1 : 0;
+  t.det_winner = c->det_winner[set];
+  t.det_to = c->det_to[set];
+  t.det_pending = (PackedReservoir*)c->det_pending[set];
   return t;
 }
 
@@ -802,12 +818,23 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       break;
     }
     case HK_PASS_FULL_SCREEN_ALBEDO: launch_albedo(c->stream, c->scene, fr, g, c->buf[HK_BUF_ALBEDO], y0, y1); break;
-    case HK_PASS_DIRECT_LIT: launch_direct(c->stream, false, c->scene, fr, g, make_light_targets(c, 0), y0, y1, counters); break;
-    case HK_PASS_DIRECT_EMISSIVE: launch_direct(c->stream, true, c->scene, fr, g, make_light_targets(c, 1), y0, y1, counters); break;
-    case HK_PASS_INDIRECT:  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
-      launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, make_light_targets(c, 2), y0, y1, counters,
-                      timer.on ? timer.t.start : nullptr, timer.on ? timer.t.stop : nullptr);
+    case HK_PASS_DIRECT_LIT:
+    case HK_PASS_DIRECT_EMISSIVE:
+    case HK_PASS_INDIRECT: {
+      const LightTargets t = make_light_targets(c, pass == HK_PASS_DIRECT_LIT ? 0 : (pass == HK_PASS_DIRECT_EMISSIVE ? 1 : 2));
+      const size_t px = (size_t)c->RW * c->RH;
+      if (t.det_winner) {  // nothing parked, no winner: -1 everywhere
+        HK_HIP(hipMemsetAsync(t.det_winner, 0xFF, px * sizeof(int), c->stream));
+        HK_HIP(hipMemsetAsync(t.det_to, 0xFF, px * sizeof(int), c->stream));
+      }
+      if (pass == HK_PASS_INDIRECT)  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
+        launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, t, y0, y1, counters, timer.on ? timer.t.start : nullptr,
+                        timer.on ? timer.t.stop : nullptr);
+      else
+        launch_direct(c->stream, pass == HK_PASS_DIRECT_EMISSIVE, c->scene, fr, g, t, y0, y1, counters);
+      if (t.det_winner) launch_resolve_scatter(c->stream, t, (int)px);
       break;
+    }
     case HK_PASS_EMISSIVE_SPATIAL_REUSE: launch_spatial(c->stream, true, c->scene, fr, g, make_light_targets(c, 1), y0, y1); break;
     case HK_PASS_INDIRECT_SPATIAL_REUSE: launch_spatial(c->stream, false, c->scene, fr, g, make_light_targets(c, 2), y0, y1); break;
     case HK_PASS_DEMODULATION: {
@@ -1088,6 +1115,12 @@ int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
     c->buf_bytes[b] = bytes;
   }
   const size_t nf = (size_t)c->W * c->H, nr = (size_t)c->RW * c->RH;
+  if (c->flags & HK_CTX_DETERMINISTIC_SCATTER)
+    for (int k = 0; k < 2; ++k) {
+      HK_HIP(hipMalloc((void**)&c->det_winner[k], nr * sizeof(int)));
+      HK_HIP(hipMalloc((void**)&c->det_to[k], nr * sizeof(int)));
+      HK_HIP(hipMalloc(&c->det_pending[k], nr * 64));
+    }
   HK_HIP(hipMalloc((void**)&c->depth_plane, nf * 4));
   HK_HIP(hipMemset(c->depth_plane, 0, nf * 4));
   HK_HIP(hipMalloc((void**)&c->prev_depth_plane, nf * 4));

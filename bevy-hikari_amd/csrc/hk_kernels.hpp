@@ -28,6 +28,12 @@ struct LightTargets {
   PackedReservoir* spatial;                      // binding 3
   float* variance;                               // r32f
   uint2* render;                                 // rgba16f
+  // HK_CTX_DETERMINISTIC_SCATTER (verification mode, nullptr otherwise): stores to previous_spatial are parked here
+  // and applied by k_resolve_scatter - the store of the highest thread index wins, the oracle's resolution of the
+  // reference's write-write race (light.wgsl:1063,1092-1095,1199-1202,1456-1459)
+  int* det_winner;               // per previous_spatial slot: highest pixel index that stores to it (-1: none)
+  int* det_to;                   // per pixel: the slot its parked store goes to (-1: none)
+  PackedReservoir* det_pending;  // per pixel: the parked value
 };
 // groups 3 + 4 of the denoise pipeline (denoise.wgsl:10-28), for up to three channels per launch
 struct DemodTargets {
@@ -152,5 +158,6 @@ void launch_smaa_tu4x_extrapolate(hipStream_t st, void* output, int out_w, int o
 void launch_taa_jasmine(hipStream_t st, const AaBuffers& b, float blend, const float clear_color[4], int y0, int y1);
 void launch_fsr_easu(hipStream_t st, const void* input, int in_w, int in_h, void* output, int out_w, int out_h, int y0, int y1);
 void launch_fsr_rcas(hipStream_t st, const void* input, void* output, int w, int h, float sharpness, int y0, int y1);
+void launch_resolve_scatter(hipStream_t st, const hkd::LightTargets& t, int pixels);
 void launch_debug_math(hipStream_t st, uint32_t op, const float* x, const float* y, float* out, size_t n);
 }  // namespace hk

@@ -54,6 +54,23 @@ __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
   }
 }
 
+// every store to previous_spatial goes through here: the reference lets them race; the verification mode parks them
+__device__ __forceinline__ void store_previous_spatial(const LightTargets& t, int from, int to, const PackedReservoir& v) {
+  if (t.det_winner) {
+    store_packed(t.det_pending, from, v);
+    t.det_to[from] = to;
+    atomicMax(&t.det_winner[to], from);
+  } else {
+    store_packed(t.previous_spatial, to, v);
+  }
+}
+__global__ __launch_bounds__(256) void k_resolve_scatter(LightTargets t, int pixels) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= pixels) return;
+  const int to = t.det_to[i];
+  if (to >= 0 && t.det_winner[to] == i) store_packed(t.previous_spatial, to, load_packed(t.det_pending, i));
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const RayCounters& rc, uint32_t primary, unsigned long long* counters) {
   if (!COUNT) return;
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
       const bool prev_on_screen = fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f;
       const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
 
-      if (!check_previous_reservoir(r, s) && prev_on_screen) store_packed(t.previous_spatial, previous_index, pack_reservoir(r));
+      if (!check_previous_reservoir(r, s) && prev_on_screen) store_previous_spatial(t, index, previous_index, pack_reservoir(r));
 
       const uint32_t validate_interval = EMISSIVE_LIT ? fr.emissive_validate_interval : fr.direct_validate_interval;
       const uint32_t select_light_instance = EMISSIVE_LIT ? im_x : HK_DONT_SAMPLE_EMISSIVE;
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
         }
         float luminance_ratio = luminance(xyz(validate_radiance)) / fmax_(luminance(xyz(r.s.radiance)), 0.0001f);
         if (luminance_ratio > 1.25f || luminance_ratio < 0.8f) {
-          if (prev_on_screen) store_packed(t.previous_spatial, previous_index, pack_reservoir(r));
+          if (prev_on_screen) store_previous_spatial(t, index, previous_index, pack_reservoir(r));
           float w_new = (candidate.p > 0.0f) ? luminance(xyz(s.radiance)) / candidate.p : 0.0f;
           set_reservoir(r, s, w_new);
         }
@@ -325,7 +342,8 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   uint4* lds = tile_lds[threadIdx.x >> 6];
   store_packed_tile(lds, t.current, fr.rw, px, out, write_current);
   store_packed_tile(lds, t.spatial, fr.rw, px, out, background);
-  store_packed_tile(lds, t.previous_spatial, fr.rw, px, out, background);
+  store_packed_tile(lds, t.previous_spatial, fr.rw, px, out, background && !t.det_winner);
+  if (t.det_winner && background) store_previous_spatial(t, px.x + fr.rw * px.y, px.x + fr.rw * px.y, out);
   flush_counters<COUNT>(rc, 0, counters);
 }
 
@@ -477,7 +495,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
       const PackedReservoir pr = pack_reservoir(r);
       store_packed(t.current, index, pr);
       store_packed(t.spatial, index, pr);
-      store_packed(t.previous_spatial, index, pr);
+      store_previous_spatial(t, index, index, pr);
       t.variance[index] = 0.0f;
       t.render[index] = make_uint2(0u, 0u);
     } else {
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
       r = load_reservoir_uv(t.previous, previous_uv, fr.rw, fr.rh);
       if (!check_previous_reservoir(r, s) && fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f) {
         const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
-        store_packed(t.previous_spatial, previous_index, pack_reservoir(r));
+        store_previous_spatial(t, index, previous_index, pack_reservoir(r));
       }
       surface = retreive_surface(sc, im_y, F2(velocity_uv.z, velocity_uv.w));
       const f3 view_direction = calculate_view(fr, position);
@@ -834,6 +852,9 @@ void launch_indirect(hipStream_t st, bool multiple_bounces, const DScene& sc, co
   else hipExtLaunchKernelGGL((k_indirect<M, false, false>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);
   if (multiple_bounces) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
 #undef HK_LAUNCH
+}
+void launch_resolve_scatter(hipStream_t st, const LightTargets& t, int pixels) {
+  hipLaunchKernelGGL(k_resolve_scatter, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, st, t, pixels);
 }
 void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1) {
   if (y1 <= y0) return;

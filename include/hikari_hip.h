@@ -345,6 +345,13 @@ int hk_device_count(int* count);
  * exchange B, hk_read_buffer, hk_frame_wait ...).  hk_pass_run never forks.  bit3 keeps everything on one stream:
  * same results, no overlap (used to time a kernel alone). */
 #define HK_CTX_SINGLE_STREAM 8u
+/* Verification mode.  The reference lets the stores to previous_spatial_reservoir_buffer race under camera / object
+ * motion (light.wgsl:1063,1092-1095,1199-1202,1456-1459: a thread stores at the REPROJECTED pixel, which another thread
+ * owns); by default so does this library - same kernels, whichever store arrives last stays.  bit4 parks those stores and
+ * applies them after the dispatch so that the store of the highest thread index wins, which is how the CPU oracle
+ * resolves the race: with it a moving camera and moving objects are bit-exact against the oracle too.  Costs three
+ * extra launches and 72 B per pixel of scratch per light dispatch; not meant for production frames. */
+#define HK_CTX_DETERMINISTIC_SCATTER 16u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);
 

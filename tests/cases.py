@@ -189,3 +189,41 @@ def random_case(seed):
     antialias = bool(rng.random() < 0.6)
     first = int(rng.integers(1, 7))
     return Case(f"random{seed}", scene, cam, s, lights=lights, frames=range(first, first + 3), antialias=antialias)
+
+
+def motion_case(seed):
+    """Seeded moving-camera + moving-instances sequence on a synthetic yard (40 % of them above the 32 KB LDS limit, i.e.
+    on the two-slot asynchronous instance upload), random settings and anti-aliasing tail.  Returns a dict; run_motion_case
+    drives a plugin through it."""
+    from bevy_hikari_amd.scenes import synthetic_scene
+
+    rng = np.random.default_rng(7000 + seed)
+    big = bool(rng.random() < 0.4)
+    scene, sun = synthetic_scene(n_boxes=int(rng.integers(6, 26)), n_spheres=int(rng.integers(1, 6)), n_emitters=int(rng.integers(1, 4)),
+                                 sphere_rings=12 if big else 5, sphere_segs=16 if big else 6, seed=int(rng.integers(1, 1 << 30)))
+    n_inst = len(scene.instances)
+    movers = tuple(int(i) for i in rng.choice(n_inst, size=min(n_inst, int(rng.integers(1, 8))), replace=False))
+    w, h = int(rng.integers(48, 160)), int(rng.integers(40, 110))
+    ratio = float(rng.choice([1.0, 1.5, 2.0]))
+    s = hk.HikariSettings(indirect_bounces=int(rng.integers(0, 3)), upscale=hk.Upscale.SmaaTu4x(ratio) if rng.random() < 0.5 else hk.Upscale.Fsr1(ratio, 0.3),
+                          taa=hk.Taa.Jasmine if rng.random() < 0.7 else hk.Taa.NONE, emissive_spatial_reuse=bool(rng.random() < 0.5))
+    return dict(scene=scene, lights=hk.lights_uniform(directional=sun), movers=movers, size=(w, h), settings=s, antialias=bool(rng.random() < 0.7),
+                eye=np.array([6.4, 4.4, 8.0]) + rng.normal(0, 0.5, 3), drift=rng.normal(0, 0.08, 3), frames=5)
+
+
+def run_motion_case(plugins, case, on_frame):
+    """Both plugins through the same animated sequence; on_frame(n) after every frame."""
+    from bevy_hikari_amd.scenes import animate
+
+    for p in plugins:
+        p.set_scene(case["scene"])
+    cur = case["scene"]
+    for n in range(1, case["frames"] + 1):
+        if n > 1:
+            cur = animate(cur, n - 1, movers=case["movers"])
+            for p in plugins:
+                p.update_instances(cur)
+        cam = hk.Camera(hk.look_at_transform(tuple(case["eye"] + case["drift"] * n), (0.0, 0.6, 0.0)), *case["size"])
+        for p in plugins:
+            p.render(cam, case["settings"], lights=case["lights"], frame_number=n, antialias=case["antialias"])
+        on_frame(n)

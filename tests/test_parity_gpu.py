@@ -668,3 +668,43 @@ def test_one_context_pair_through_many_scenes_sizes_and_settings():
                 p.render(case.camera, case.settings, lights=case.lights, frame_number=n, antialias=case.antialias)
             bad = diff_buffers(snapshot(gpu), snapshot(cpu))
             assert bad == {}, (seed, n, bad)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_motion_is_bit_exact_once_the_race_is_resolved_like_the_oracle(seed):
+    """Moving camera + moving instances (cases.motion_case), random settings and AA tail.  The reference lets the
+    reprojected stores to previous_spatial race; HK_CTX_DETERMINISTIC_SCATTER parks them and lets the highest thread
+    index win, which is the oracle's rule - and then EVERY buffer of EVERY frame is bit-exact under motion too: the
+    race is the only thing that separates the two under motion.  (tools/fuzz_sweep.py --motion --deterministic:
+    900 sequences clean.)"""
+    from cases import motion_case, run_motion_case
+
+    case = motion_case(seed)
+    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_DETERMINISTIC_SCATTER), oracle()
+
+    def check(n):
+        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        assert bad == {}, (seed, n, bad)
+
+    run_motion_case((gpu, cpu), case, check)
+    assert (gpu.engine.read(F.BUF_VELOCITY_UV)[..., :2] != 0).any()
+
+
+def test_racing_default_stays_close_under_motion():
+    """Without the flag the stores race as in the reference: the G-buffer is still exact and the image stays within a
+    few 1e-3 of the oracle's (the oracle's pick of the race is as arbitrary as the GPU's)."""
+    from cases import motion_case, run_motion_case
+
+    rels = []
+    for seed in range(12):
+        case = motion_case(seed)
+        gpu, cpu = hk.HikariPlugin(device=0), oracle()
+
+        def check(n):
+            bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+            assert not any(k in bad for k in GBUFFER + ("previous_position", "previous_velocity_uv")), (seed, n, bad)
+
+        run_motion_case((gpu, cpu), case, check)
+        a, b = gpu.output(case["settings"]), cpu.output(case["settings"])
+        rels.append(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-20)))
+    assert np.median(rels) <= 1e-3 and max(rels) <= 5e-2, rels
