@@ -1,0 +1,118 @@
+// The parts of bevy 0.9.1 the reference's shaders import but the reference checkout does not vendor
+// (Cargo.toml: bevy = "0.9"): restated from the published sources of bevy_pbr 0.9.1
+// (crates/bevy_pbr/src/render/{mesh_view_types,utils,pbr_lighting}.wgsl) and bevy_core_pipeline 0.9.1
+// (src/tonemapping/tonemapping_shared.wgsl), only what light.wgsl / tone_mapping.wgsl reference.  The SAME text is what
+// oracle/hk_oracle.cpp restates in its "bevy_pbr 0.9.1" section, so the execution of the reference's shaders through
+// tools/wgsl does NOT pin these few functions - it pins everything the reference itself ships.
+
+#define_import_path bevy_pbr::mesh_view_types
+
+struct View {
+    view_proj: mat4x4<f32>,
+    inverse_view_proj: mat4x4<f32>,
+    view: mat4x4<f32>,
+    inverse_view: mat4x4<f32>,
+    projection: mat4x4<f32>,
+    inverse_projection: mat4x4<f32>,
+    world_position: vec3<f32>,
+    // viewport(x_origin, y_origin, width, height)
+    viewport: vec4<f32>,
+};
+
+// (only the members the path reads; the harness binds the object directly, no byte layout is decoded)
+struct DirectionalLight {
+    color: vec4<f32>,
+    direction_to_light: vec3<f32>,
+};
+
+struct Lights {
+    directional_lights: array<DirectionalLight, 1u>,
+    ambient_color: vec4<f32>,
+    n_directional_lights: u32,
+};
+
+#define_import_path bevy_pbr::utils
+
+let PI: f32 = 3.141592653589793;
+
+#define_import_path bevy_pbr::lighting
+
+// Normal distribution function (specular D)
+fn D_GGX(roughness: f32, NoH: f32, h: vec3<f32>) -> f32 {
+    let oneMinusNoHSquared = 1.0 - NoH * NoH;
+    let a = NoH * roughness;
+    let k = roughness / (oneMinusNoHSquared + a * a);
+    let d = k * k * (1.0 / PI);
+    return d;
+}
+
+// Visibility function (Specular G)
+fn V_SmithGGXCorrelated(roughness: f32, NoV: f32, NoL: f32) -> f32 {
+    let a2 = roughness * roughness;
+    let lambdaV = NoL * sqrt((NoV - a2 * NoV) * NoV + a2);
+    let lambdaL = NoV * sqrt((NoL - a2 * NoL) * NoL + a2);
+    let v = 0.5 / (lambdaV + lambdaL);
+    return v;
+}
+
+// Fresnel function
+fn F_Schlick_vec(f0: vec3<f32>, f90: f32, VoH: f32) -> vec3<f32> {
+    // not using mix to keep the vec3 and float versions identical
+    return f0 + (f90 - f0) * pow(1.0 - VoH, 5.0);
+}
+
+fn F_Schlick(f0: f32, f90: f32, VoH: f32) -> f32 {
+    // not using mix to keep the vec3 and float versions identical
+    return f0 + (f90 - f0) * pow(1.0 - VoH, 5.0);
+}
+
+fn fresnel(f0: vec3<f32>, LoH: f32) -> vec3<f32> {
+    // f_90 suitable for ambient occlusion
+    let f90 = saturate(dot(f0, vec3<f32>(50.0 * 0.33)));
+    return F_Schlick_vec(f0, f90, LoH);
+}
+
+// Specular BRDF: Cook-Torrance approximation
+fn specular(f0: vec3<f32>, roughness: f32, h: vec3<f32>, NoV: f32, NoL: f32, NoH: f32, LoH: f32, specularIntensity: f32) -> vec3<f32> {
+    let D = D_GGX(roughness, NoH, h);
+    let V = V_SmithGGXCorrelated(roughness, NoV, NoL);
+    let F = fresnel(f0, LoH);
+
+    return (specularIntensity * D * V) * F;
+}
+
+// Diffuse BRDF: Disney / Burley
+fn Fd_Burley(roughness: f32, NoV: f32, NoL: f32, LoH: f32) -> f32 {
+    let f90 = 0.5 + 2.0 * roughness * LoH * LoH;
+    let lightScatter = F_Schlick(1.0, f90, NoL);
+    let viewScatter = F_Schlick(1.0, f90, NoV);
+    return lightScatter * viewScatter * (1.0 / PI);
+}
+
+// From https://www.unrealengine.com/en-US/blog/physically-based-shading-on-mobile
+fn EnvBRDFApprox(f0: vec3<f32>, perceptual_roughness: f32, NoV: f32) -> vec3<f32> {
+    let c0 = vec4<f32>(-1.0, -0.0275, -0.572, 0.022);
+    let c1 = vec4<f32>(1.0, 0.0425, 1.04, -0.04);
+    let r = perceptual_roughness * c0 + c1;
+    let a004 = min(r.x * r.x, exp2(-9.28 * NoV)) * r.x + r.y;
+    let AB = vec2<f32>(-1.04, 1.04) * a004 + r.zw;
+    return f0 * AB.x + AB.y;
+}
+
+fn perceptualRoughnessToRoughness(perceptualRoughness: f32) -> f32 {
+    // clamp perceptual roughness to prevent precision problems
+    let clampedPerceptualRoughness = clamp(perceptualRoughness, 0.089, 1.0);
+    return clampedPerceptualRoughness * clampedPerceptualRoughness;
+}
+
+#define_import_path bevy_core_pipeline::tonemapping
+
+fn tonemapping_luminance(v: vec3<f32>) -> f32 {
+    return dot(v, vec3<f32>(0.2126, 0.7152, 0.0722));
+}
+
+fn reinhard_luminance(color: vec3<f32>) -> vec3<f32> {
+    let l_old = tonemapping_luminance(color);
+    let l_new = l_old / (1.0 + l_old);
+    return color * (l_new / l_old);
+}

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Pin the CPU oracle against the reference's OWN shader source.
+
+The reference ships no tests or golden vectors and cannot be built here, but its shaders are text:
+src/shaders/{light,denoise,tone_mapping,taa,smaa}.wgsl.  tools/wgsl translates that text mechanically to Python (one
+f32 rounding per operation, implementation-defined choices bound to the oracle's numeric contract - see
+tools/wgsl/runtime.py) and this script runs every compute entry point on the state the oracle has BEFORE the
+corresponding dispatch and compares what the shader writes with what the oracle wrote, byte for byte.  The G-buffer
+comes from the oracle (prepass.wgsl is a raster shader; the ray-cast G-buffer is this project's contract).
+
+  python tools/wgsl_pin.py [--size W H] [--frames N] [--write]      (needs /root/reference; minutes of pure Python)
+
+--write stores the inputs and the shader-produced outputs of every dispatch under tests/golden/wgsl_pin.npz, which
+tests/test_wgsl_pin.py replays against the oracle without the reference."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+from oracle_lib import oracle_plugin
+from wgsl import runtime as R
+from wgsl import types as T
+from wgsl.engine import Module
+
+SHADERS = "/root/reference/src/shaders"
+f32 = np.float32
+
+
+# ---------------------------------------------------------------- buffers <-> textures
+def tex_from(engine, buf, kind):
+    raw = engine.read(buf)
+    h, w = raw.shape[:2]
+    data = np.zeros((h, w, 4), np.float32)
+    data[..., 3] = 1.0
+    if kind == "rgba16f":
+        data[...] = raw.view(np.float16).astype(np.float32)
+    elif kind == "rgba32f":
+        data[...] = raw.view(np.float32)
+    elif kind == "rg32f":
+        data[..., :2] = raw.view(np.float32).reshape(h, w, 2)
+    elif kind == "r32f":
+        data[..., 0] = raw.view(np.float32).reshape(h, w)
+    elif kind == "rgba8snorm":
+        b = raw.view(np.uint8).reshape(h, w, 4).astype(np.int8).astype(np.float32)
+        data[...] = np.maximum(b / f32(127.0), f32(-1.0))
+    else:
+        raise KeyError(kind)
+    return T.Texture(data, store_f16=(kind == "rgba16f"))
+
+
+def tex_bytes(tex, kind):
+    d = tex.data
+    if kind == "rgba16f":
+        return d.astype(np.float16).view(np.uint16)
+    if kind == "r32f":
+        return d[..., 0:1].copy()
+    raise KeyError(kind)
+
+
+def as_bytes(a):
+    return np.frombuffer(bytes(a), dtype=np.uint8).copy()
+
+
+class Lights:     # bevy_pbr Lights, the members the path reads (HkLights)
+    def __init__(self, l):
+        class D: pass
+        d = D()
+        d.color = T.vec4f32(*l.directional_color)
+        d.direction_to_light = T.vec3f32(*l.direction_to_light)
+        self.directional_lights = [d]
+        self.ambient_color = T.vec4f32(*l.ambient_color)
+        self.n_directional_lights = R.u32(l.n_directional_lights)
+
+
+# ---------------------------------------------------------------- the light passes
+T_SLOT, S_SLOT = (0, 2, 6), (4, 4, 8)
+LIGHT = {F.PASS_FULL_SCREEN_ALBEDO: ("full_screen_albedo", (), None), F.PASS_DIRECT_LIT: ("direct_lit", ("RENDER_EMISSIVE",), 0),
+         F.PASS_DIRECT_EMISSIVE: ("direct_lit", ("EMISSIVE_LIT",), 1), F.PASS_EMISSIVE_SPATIAL_REUSE: ("spatial_reuse", ("EMISSIVE_LIT",), 1),
+         F.PASS_INDIRECT: ("indirect_lit_ambient", None, 2), F.PASS_INDIRECT_SPATIAL_REUSE: ("spatial_reuse", (), 2)}
+_modules = {}
+
+
+def module(filename, defs):
+    key = (filename, tuple(sorted(defs)))
+    if key not in _modules:
+        _modules[key] = Module(SHADERS, filename, defs)
+    return _modules[key]
+
+
+class Pinner:
+    def __init__(self, plugin, scene, noise, log):
+        self.p, self.e, self.scene, self.noise, self.log = plugin, plugin.engine, scene, noise, log
+        self.results = []
+        self.real_pass_run = self.e.pass_run
+        self.e.pass_run = self.pass_run            # every dispatch of the node path goes through here
+
+    def uniforms(self, m):
+        e = self.e
+        m.bind(frame=as_bytes(self.frame), view=as_bytes(self.view), previous_view=as_bytes(self.pview), lights=Lights(self.lights))
+
+    def begin(self, frame, view, pview, lights):
+        self.frame, self.view, self.pview, self.lights = frame, view, pview, lights
+
+    def pass_run(self, pass_id, arg=0, row_begin=0, row_end=0):
+        if pass_id in LIGHT:
+            self.light_pass(pass_id)
+        else:
+            self.real_pass_run(pass_id, arg, row_begin, row_end)
+
+    def reservoirs(self, channel):
+        cur = self.frame.number % 2
+        prev = 1 - cur
+        ids = dict(previous_reservoir_buffer=cur + T_SLOT[channel], reservoir_buffer=prev + T_SLOT[channel],
+                   previous_spatial_reservoir_buffer=cur + S_SLOT[channel], spatial_reservoir_buffer=prev + S_SLOT[channel])
+        return {k: F.BUF_RESERVOIR0 + v for k, v in ids.items()}
+
+    def light_pass(self, pass_id):
+        e = self.e
+        entry, defs, channel = LIGHT[pass_id]
+        if defs is None:
+            defs = ("MULTIPLE_BOUNCES",) if self.frame.indirect_bounces >= 2 else ()
+        m = module("light.wgsl", ("NO_TEXTURE",) + tuple(defs))
+        self.uniforms(m)
+        sc = self.scene
+        m.bind(vertex_buffer=as_bytes(sc.vertices), primitive_buffer=as_bytes(sc.primitives), asset_node_buffer=np.concatenate([np.zeros(16, np.uint8), as_bytes(sc.asset_nodes)]),
+               alias_table_buffer=as_bytes(sc.alias_table), instance_buffer=as_bytes(sc.instances),
+               instance_node_buffer=np.concatenate([np.array([len(sc.instance_nodes), 0, 0, 0], np.uint32).view(np.uint8), as_bytes(sc.instance_nodes)]),
+               material_buffer=as_bytes(sc.materials),
+               emissive_node_buffer=np.concatenate([np.array([len(sc.emissive_nodes), 0, 0, 0], np.uint32).view(np.uint8), as_bytes(sc.emissive_nodes)]),
+               emissive_buffer=as_bytes(sc.emissives))
+        m.bind(position_texture=tex_from(e, F.BUF_POSITION, "rgba32f"), normal_texture=tex_from(e, F.BUF_NORMAL, "rgba8snorm"),
+               depth_gradient_texture=tex_from(e, F.BUF_DEPTH_GRADIENT, "rg32f"), instance_material_texture=tex_from(e, F.BUF_INSTANCE_MATERIAL, "rg32f"),
+               velocity_uv_texture=tex_from(e, F.BUF_VELOCITY_UV, "rgba32f"))
+        m.bind(textures=T.Texture(np.ones((1, 1, 4), np.float32)), samplers=T.Sampler(True, "repeat"),
+               noise_texture=[T.Texture(self.noise[i].astype(np.float32) / f32(255.0)) for i in range(16)], noise_sampler=T.Sampler(False, "repeat"))
+        ch = 0 if channel is None else channel
+        albedo = tex_from(e, F.BUF_ALBEDO, "rgba16f")
+        variance = tex_from(e, F.BUF_VARIANCE0 + ch, "r32f")
+        render = tex_from(e, F.BUF_RENDER0 + ch, "rgba16f")
+        m.bind(albedo_texture=albedo, variance_texture=variance, render_texture=render)
+        res = self.reservoirs(ch)
+        res_bytes = {k: e.read(b).view(np.uint8).reshape(-1).copy() for k, b in res.items()}
+        m.bind(**res_bytes)
+        rw, rh = e.buffer_info(F.BUF_RENDER0)[:2]
+        w, h = e.buffer_info(F.BUF_ALBEDO)[:2]
+        gx, gy = ((w + 7) // 8, (h + 7) // 8) if entry == "full_screen_albedo" else ((rw + 7) // 8, (rh + 7) // 8)
+        t0 = time.time()
+        m.dispatch(entry, gx, gy)
+        seconds = time.time() - t0
+        self.real_pass_run(pass_id)                 # now the oracle
+        bad = {}
+        outs = {"albedo": (albedo, F.BUF_ALBEDO, "rgba16f")} if channel is None else {"variance": (variance, F.BUF_VARIANCE0 + ch, "r32f"),
+                                                                                         "render": (render, F.BUF_RENDER0 + ch, "rgba16f")}
+        for name, (tex, buf, kind) in outs.items():
+            got, want = tex_bytes(tex, kind), e.read(buf)
+            ne = (got.reshape(want.shape[0], want.shape[1], -1).view(np.uint8) != want.reshape(want.shape[0], want.shape[1], -1).view(np.uint8)).any(axis=2)
+            if ne.any():
+                ys, xs = np.nonzero(ne)
+                bad[name] = f"{int(ne.sum())} px, first (x={xs[0]}, y={ys[0]}): {got[ys[0], xs[0]]} vs {want[ys[0], xs[0]]}"
+        if channel is not None:
+            for k, b in res.items():
+                if k == "previous_reservoir_buffer":
+                    continue
+                want = e.read(b).view(np.uint8).reshape(-1)
+                got = res_bytes[k]
+                n = rw * rh * 64         # the reservoirs the pass indexes (full-size allocation, scaled-size indexing)
+                ne = (got[:n].reshape(-1, 64) != want[:n].reshape(-1, 64)).any(axis=1)
+                if ne.any():
+                    i = int(np.nonzero(ne)[0][0])
+                    bad[k] = f"{int(ne.sum())} reservoirs, first #{i} (x={i % rw}, y={i // rw}): {got[i * 64:(i + 1) * 64].view(np.uint32)} vs {want[i * 64:(i + 1) * 64].view(np.uint32)}"
+        rec = {"frame": int(self.frame.number), "pass": F.PASS_NAMES[pass_id], "entry": entry, "defs": list(defs), "seconds": round(seconds, 1), "mismatch": bad}
+        self.results.append(rec)
+        self.log(rec)
+
+
+def main():
+    size = (24, 16)
+    if "--size" in sys.argv:
+        i = sys.argv.index("--size")
+        size = (int(sys.argv[i + 1]), int(sys.argv[i + 2]))
+    frames = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 2
+    fn_cache = {}
+
+    def contract(op, x, y):
+        key = (op, float(x), float(y))
+        if key not in fn_cache:
+            xi, yi, out = (C.c_float * 1)(float(x)), (C.c_float * 1)(float(y)), (C.c_float * 1)()
+            assert dll.orc_debug_math(None, op, xi, yi, out, 1) == 0
+            fn_cache[key] = f32(out[0])
+        return fn_cache[key]
+
+    p = oracle_plugin()
+    dll = p.engine.api.dll
+    dll.orc_debug_math.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t]
+    R.bind_contract(contract)
+    scene = hk.load_cornell()
+    p.set_scene(scene)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0, emissive_spatial_reuse=True)
+    cam = hk.cornell_camera(*size)
+    from bevy_hikari_amd.plugin import load_noise
+    noise = load_noise().reshape(16, 64, 64, 4)
+    pin = Pinner(p, scene, noise, lambda rec: print(json.dumps(rec), flush=True))
+    real_frame_begin = p.engine.frame_begin
+
+    def frame_begin(frame, view, pview, lights):
+        pin.begin(frame, view, pview, lights)
+        real_frame_begin(frame, view, pview, lights)
+    p.engine.frame_begin = frame_begin
+    for n in range(1, frames + 1):
+        p.render(cam, s, frame_number=n, by_nodes=True)
+    bad = [r for r in pin.results if r["mismatch"]]
+    print(json.dumps({"dispatches": len(pin.results), "mismatching": len(bad), "seconds": round(sum(r["seconds"] for r in pin.results), 1)}))
+
+
+if __name__ == "__main__":
+    main()
