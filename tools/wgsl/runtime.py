@@ -276,6 +276,15 @@ def neg(a):
     return -a
 
 
+class Box:
+    """the target of a `ptr<function, T>` whose pointee is a scalar / vector / matrix (immutable here): the caller boxes the
+    variable for the call and writes it back afterwards; structs are passed by reference instead"""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v
+
+
 def cp(x):
     """WGSL value semantics: structs and arrays are copied on assignment / argument passing / return"""
     if x.__class__ is V or isinstance(x, (np.generic, bool, int, float, M)):

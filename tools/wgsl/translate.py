@@ -33,6 +33,13 @@ class Translator:
         self.consts = []
         self.lines = []
         self.tmp = 0
+        # pointer parameters: a struct pointee is passed by reference, anything else through a _R.Box
+        self.box_sig = {}
+        for d in decls:
+            if d[0] == "fn":
+                self.box_sig[d[1]] = [p[1][1] == "ptr" and p[1][2][1][1] not in self.structs for p in d[2]]
+        self.box_params = set()
+        self.pre, self.post = [], []
 
     # ------------------------------------------------------------ types
     def type_expr(self, ty):
@@ -115,8 +122,10 @@ class Translator:
             return f"{self.expr(e[1])}[{self.expr(e[2])}]"
         if k == "un":
             op, x = e[1], e[2]
+            if op == "*" and x[0] == "id" and x[1] in self.box_params:
+                return f"{pyname(x[1])}.v"
             if op in ("&", "*"):
-                return self.expr(x)          # pointers are references to mutable objects
+                return self.expr(x)          # pointers to structs are references to the mutable object
             if op == "!":
                 return f"_R.lnot({self.expr(x)})"
             if op == "~":
@@ -149,6 +158,14 @@ class Translator:
                 return "(yield)"
             if name in BUILTINS:
                 return f"{BUILTINS[name]}({', '.join(args)})"
+            for i, boxed in enumerate(self.box_sig.get(name, ())):
+                a = e[2][i]
+                if boxed and a[0] == "un" and a[1] == "&":       # box the variable for the call, write it back after the statement
+                    self.tmp += 1
+                    tmp = f"_b{self.tmp}"
+                    self.pre.append(f"{tmp} = _R.Box({self.expr(a[2])})")
+                    self.post.append((a[2], f"{tmp}.v"))
+                    args[i] = tmp
             return f"{pyname(name)}({', '.join(args)})"
         raise NotImplementedError(k)
 
@@ -167,7 +184,10 @@ class Translator:
         while t[0] == "paren":
             t = t[1]
         if t[0] == "un" and t[1] == "*":      # (*p) = value: overwrite the pointee in place
-            self.emit(depth, f"{self.expr(t[2])}.set_value({value_src})")
+            if t[2][0] == "id" and t[2][1] in self.box_params:
+                self.emit(depth, f"{pyname(t[2][1])}.v = {value_src}")
+            else:
+                self.emit(depth, f"{self.expr(t[2])}.set_value({value_src})")
             return
         if t[0] == "id":
             self.emit(depth, f"{pyname(t[1])} = {value_src}")
@@ -196,6 +216,25 @@ class Translator:
             raise NotImplementedError(f"assignment to {t[0]}")
 
     def stmt(self, depth, s, loops):
+        if s[0] in ("var", "assign", "expr", "return"):
+            self.pre, self.post = [], []
+            mark = len(self.lines)
+            self.stmt_inner(depth, s, loops)
+            body = self.lines[mark:]
+            del self.lines[mark:]
+            for line in self.pre:
+                self.emit(depth, line)
+            post = self.post
+            self.pre, self.post = [], []
+            if post and s[0] == "return":
+                raise NotImplementedError("return of a call that takes a boxed pointer")
+            self.lines.extend(body)
+            for target, src in post:
+                self.assign(depth, target, src)
+            return
+        self.stmt_inner(depth, s, loops)
+
+    def stmt_inner(self, depth, s, loops):
         k = s[0]
         if k == "block":
             if not s[1]:
@@ -276,6 +315,7 @@ class Translator:
                     self.emit(0, f"{pyname(name)} = {self.value(init) if init is not None else self.zero_expr(ty)}")
             elif d[0] == "fn":
                 _, name, params, ret, block, attrs = d
+                self.box_params = {p[0] for p, boxed in zip(params, self.box_sig[name]) if boxed}
                 self.emit(0, f"def {pyname(name)}({', '.join(pyname(p[0]) for p in params)}):")
                 n0 = len(self.lines)
                 used_globals = sorted(self.assigned_globals(block))

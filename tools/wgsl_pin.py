@@ -113,8 +113,75 @@ class Pinner:
     def pass_run(self, pass_id, arg=0, row_begin=0, row_end=0):
         if pass_id in LIGHT:
             self.light_pass(pass_id)
+        elif pass_id == F.PASS_DEMODULATION or F.PASS_DENOISE_L0 <= pass_id <= F.PASS_DENOISE_L3:
+            self.denoise_pass(pass_id, arg)
+        elif pass_id == F.PASS_TONE_MAPPING:
+            self.tone_mapping_pass(arg)
         else:
             self.real_pass_run(pass_id, arg, row_begin, row_end)
+
+    def deferred(self, m):
+        e = self.e
+        m.bind(position_texture=tex_from(e, F.BUF_POSITION, "rgba32f"), normal_texture=tex_from(e, F.BUF_NORMAL, "rgba8snorm"),
+               depth_gradient_texture=tex_from(e, F.BUF_DEPTH_GRADIENT, "rg32f"), instance_material_texture=tex_from(e, F.BUF_INSTANCE_MATERIAL, "rg32f"),
+               velocity_uv_texture=tex_from(e, F.BUF_VELOCITY_UV, "rgba32f"), nearest_sampler=T.Sampler(False, "clamp"), linear_sampler=T.Sampler(True, "clamp"))
+
+    def compare(self, rec, outs):
+        e, bad = self.e, {}
+        for name, (tex, buf, kind) in outs.items():
+            got, want = tex_bytes(tex, kind), e.read(buf)
+            ne = (got.reshape(want.shape[0], want.shape[1], -1).view(np.uint8) != want.reshape(want.shape[0], want.shape[1], -1).view(np.uint8)).any(axis=2)
+            if ne.any():
+                ys, xs = np.nonzero(ne)
+                bad[name] = f"{int(ne.sum())} px, first (x={xs[0]}, y={ys[0]}): {got[ys[0], xs[0]]} vs {want[ys[0], xs[0]]}"
+        rec["mismatch"] = bad
+        self.results.append(rec)
+        self.log(rec)
+
+    def denoise_pass(self, pass_id, ch):
+        # post_process.rs:1190-1224: demodulation, then denoise levels 0..3 per channel; FIREFLY_FILTERING for the emissive and
+        # indirect channels (post_process.rs:773-783); bind groups 3 (denoise_internal) and 4 (denoise_render[ch])
+        e = self.e
+        demod = pass_id == F.PASS_DEMODULATION
+        level = pass_id - F.PASS_DENOISE_L0
+        defs = () if demod else (f"DENOISE_LEVEL_{level}",) + (("FIREFLY_FILTERING",) if ch > 0 else ())
+        m = module("denoise.wgsl", defs)
+        self.uniforms(m)
+        self.deferred(m)
+        internal = [tex_from(e, F.BUF_DENOISE_INTERNAL0 + i, "rgba16f") for i in range(4)]
+        ivar = tex_from(e, F.BUF_DENOISE_INTERNAL_VARIANCE, "r32f")
+        out = tex_from(e, F.BUF_DENOISE_RENDER0 + ch, "rgba16f")
+        m.bind(internal_texture_0=internal[0], internal_texture_1=internal[1], internal_texture_2=internal[2], internal_texture_3=internal[3], internal_variance=ivar,
+               albedo_texture=tex_from(e, F.BUF_ALBEDO, "rgba16f"), variance_texture=tex_from(e, F.BUF_VARIANCE0 + ch, "r32f"),
+               render_texture=tex_from(e, F.BUF_RENDER0 + ch, "rgba16f"), output_texture=out)
+        rw, rh = e.buffer_info(F.BUF_RENDER0)[:2]
+        t0 = time.time()
+        m.dispatch("demodulation" if demod else "denoise", (rw + 7) // 8, (rh + 7) // 8)
+        rec = {"frame": int(self.frame.number), "pass": F.PASS_NAMES[pass_id], "entry": "demodulation" if demod else "denoise", "defs": list(defs), "channel": ch,
+               "seconds": round(time.time() - t0, 1)}
+        self.real_pass_run(pass_id, ch)
+        if demod:
+            outs = {"internal0": (internal[0], F.BUF_DENOISE_INTERNAL0, "rgba16f"), "internal_variance": (ivar, F.BUF_DENOISE_INTERNAL_VARIANCE, "r32f")}
+        elif level < 3:
+            outs = {f"internal{level + 1}": (internal[level + 1], F.BUF_DENOISE_INTERNAL0 + level + 1, "rgba16f")}
+        else:
+            outs = {"denoise_render": (out, F.BUF_DENOISE_RENDER0 + ch, "rgba16f")}
+        self.compare(rec, outs)
+
+    def tone_mapping_pass(self, denoised):
+        e = self.e
+        m = module("tone_mapping.wgsl", ())
+        self.uniforms(m)
+        base = F.BUF_DENOISE_RENDER0 if denoised else F.BUF_RENDER0
+        out = tex_from(e, F.BUF_TONE_MAPPED, "rgba16f")
+        m.bind(direct_render_texture=tex_from(e, base, "rgba16f"), emissive_render_texture=tex_from(e, base + 1, "rgba16f"),
+               indirect_render_texture=tex_from(e, base + 2, "rgba16f"), output_texture=out)
+        rw, rh = e.buffer_info(F.BUF_TONE_MAPPED)[:2]
+        t0 = time.time()
+        m.dispatch("tone_mapping", (rw + 7) // 8, (rh + 7) // 8)
+        rec = {"frame": int(self.frame.number), "pass": "tone_mapping", "entry": "tone_mapping", "defs": [], "seconds": round(time.time() - t0, 1)}
+        self.real_pass_run(F.PASS_TONE_MAPPING, denoised)
+        self.compare(rec, {"tone_mapped": (out, F.BUF_TONE_MAPPED, "rgba16f")})
 
     def reservoirs(self, channel):
         cur = self.frame.number % 2
