@@ -80,11 +80,23 @@ class Module:
     def unbound(self, used_only_by=None):
         return [n for n in self.ns["RESOURCES"] if translate.pyname(n) not in self.ns]
 
-    def dispatch(self, entry, groups_x, groups_y, only=None):
+    def dispatch(self, entry, groups_x, groups_y, only=None, limit=None):
         """run `entry` for every invocation of a groups_x x groups_y grid of workgroups (z = 1).  `only(gx, gy)` filters
         workgroups.  Entry points that contain workgroupBarrier() are generators and run in lockstep per workgroup."""
         fn, wg, builtins = self.ns["ENTRY_POINTS"][entry]
         wx, wy = wg[0], wg[1] if len(wg) > 1 else 1
+        if not self.ns["WORKGROUP_VARS"] or "yield" not in self.python[self.python.index(f"def {translate.pyname(entry)}("):].split("\ndef ", 1)[0]:
+            # no barrier: invocations are independent; run them in LINEAR order (y, then x) so that stores which race in the
+            # reference (a thread writing another thread's slot) resolve as "highest invocation index wins", the oracle's rule
+            for y in range(groups_y * wy):
+                for x in range(groups_x * wx):
+                    if limit is not None and (x >= limit[0] or y >= limit[1]):
+                        continue
+                    vals = {"global_invocation_id": T.vec3u32(x, y, 0), "local_invocation_id": T.vec3u32(x % wx, y % wy, 0),
+                            "workgroup_id": T.vec3u32(x // wx, y // wy, 0), "num_workgroups": T.vec3u32(groups_x, groups_y, 1),
+                            "local_invocation_index": R.u32((y % wy) * wx + x % wx)}
+                    fn(*[vals[b] for b in builtins.values()])
+            return
         for gy in range(groups_y):
             for gx in range(groups_x):
                 if only is not None and not only(gx, gy):
@@ -94,6 +106,8 @@ class Module:
                 pending = []
                 for ly in range(wy):
                     for lx in range(wx):
+                        if limit is not None and (gx * wx + lx >= limit[0] or gy * wy + ly >= limit[1]):
+                            continue
                         vals = {"global_invocation_id": T.vec3u32(gx * wx + lx, gy * wy + ly, 0), "local_invocation_id": T.vec3u32(lx, ly, 0),
                                 "workgroup_id": T.vec3u32(gx, gy, 0), "num_workgroups": T.vec3u32(groups_x, groups_y, 1),
                                 "local_invocation_index": R.u32(ly * wx + lx)}

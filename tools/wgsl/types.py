@@ -179,8 +179,11 @@ mat2x2, mat3x3, mat4x4 = R.make_mat(2, 2), R.make_mat(3, 3), R.make_mat(4, 4)
 
 # ---------------------------------------------------------------- textures and samplers
 class Sampler:
-    def __init__(self, linear=False, address="clamp"):
-        self.linear, self.address = linear, address
+    """address: "clamp" | "repeat" | "mirror" (per axis); noise=True: the blue-noise lookup, which the oracle evaluates as
+    floor(fract(uv) * size) (hk_oracle.cpp noise_fetch)"""
+
+    def __init__(self, linear=False, address="clamp", address_v=None, noise=False):
+        self.linear, self.address, self.address_v, self.noise = linear, address, address_v or address, noise
 
 
 class Texture:
@@ -228,25 +231,29 @@ def texture_store(tex, coords, value):
 def _wrap(i, n, address):
     if address == "repeat":
         return i % n
+    if address == "mirror":
+        p = 2 * n
+        m = i % p
+        return m if m < n else p - 1 - m
     return min(max(i, 0), n - 1)
 
 
 def texture_sample_level(tex, sampler, uv, level):
     w, h = f32(tex.w), f32(tex.h)
     if not sampler.linear:
-        if sampler.address == "repeat":     # the noise lookup: fract first, as the oracle does (hk_oracle.cpp noise_fetch)
-            x = int(np.floor(R.w_fract(uv[0]) * w)) & (tex.w - 1) if tex.w & (tex.w - 1) == 0 else int(np.floor(R.w_fract(uv[0]) * w)) % tex.w
-            y = int(np.floor(R.w_fract(uv[1]) * h)) & (tex.h - 1) if tex.h & (tex.h - 1) == 0 else int(np.floor(R.w_fract(uv[1]) * h)) % tex.h
+        if sampler.noise:
+            x = int(np.floor(R.w_fract(uv[0]) * w)) % tex.w
+            y = int(np.floor(R.w_fract(uv[1]) * h)) % tex.h
         else:
-            x = _wrap(int(np.floor(uv[0] * w)), tex.w, "clamp")
-            y = _wrap(int(np.floor(uv[1] * h)), tex.h, "clamp")
+            x = _wrap(int(np.floor(uv[0] * w)), tex.w, sampler.address)
+            y = _wrap(int(np.floor(uv[1] * h)), tex.h, sampler.address_v)
         return tex.texel(x, y)
     px, py = uv[0] * w - f32(0.5), uv[1] * h - f32(0.5)
     fx0, fy0 = f32(np.floor(px)), f32(np.floor(py))
     fx, fy = px - fx0, py - fy0
     ix, iy = int(fx0), int(fy0)
     x0, x1 = _wrap(ix, tex.w, sampler.address), _wrap(ix + 1, tex.w, sampler.address)
-    y0, y1 = _wrap(iy, tex.h, sampler.address), _wrap(iy + 1, tex.h, sampler.address)
+    y0, y1 = _wrap(iy, tex.h, sampler.address_v), _wrap(iy + 1, tex.h, sampler.address_v)
     top = R.w_mix(tex.texel(x0, y0), tex.texel(x1, y0), fx)
     bot = R.w_mix(tex.texel(x0, y1), tex.texel(x1, y1), fx)
     return R.w_mix(top, bot, fy)

@@ -70,6 +70,20 @@ def as_bytes(a):
     return np.frombuffer(bytes(a), dtype=np.uint8).copy()
 
 
+_SRGB = np.array([(v / 255.0 / 12.92 if v / 255.0 <= 0.04045 else ((v / 255.0 + 0.055) / 1.055) ** 2.4) for v in range(256)], dtype=np.float64).astype(np.float32)
+_ADDRESS = {F.ADDRESS_CLAMP_TO_EDGE: "clamp", F.ADDRESS_REPEAT: "repeat", F.ADDRESS_MIRROR_REPEAT: "mirror"}
+
+
+def material_texture(im):
+    """(Texture, Sampler) of one entry of the `textures` / `samplers` binding arrays (mod.rs:760-782): rgba8, sRGB colour decoded per
+    texel before filtering, as texture units do (the oracle's contract, hk_oracle.cpp texel())"""
+    rgba = np.ascontiguousarray(im["rgba"], dtype=np.uint8)
+    data = rgba.astype(np.float32) / f32(255.0)
+    if im.get("srgb", True):
+        data[..., :3] = _SRGB[rgba[..., :3]]
+    return T.Texture(data), T.Sampler(bool(im.get("linear", True)), _ADDRESS[im.get("address_u", F.ADDRESS_REPEAT)], _ADDRESS[im.get("address_v", F.ADDRESS_REPEAT)])
+
+
 class Lights:     # bevy_pbr Lights, the members the path reads (HkLights)
     def __init__(self, l):
         class D: pass
@@ -100,6 +114,7 @@ class Pinner:
     def __init__(self, plugin, scene, noise, log):
         self.p, self.e, self.scene, self.noise, self.log = plugin, plugin.engine, scene, noise, log
         self.results = []
+        self.textures = [material_texture(im) for im in getattr(scene, "textures", [])]
         self.real_pass_run = self.e.pass_run
         self.e.pass_run = self.pass_run            # every dispatch of the node path goes through here
 
@@ -117,6 +132,8 @@ class Pinner:
             self.denoise_pass(pass_id, arg)
         elif pass_id == F.PASS_TONE_MAPPING:
             self.tone_mapping_pass(arg)
+        elif pass_id in (F.PASS_SMAA_TU4X, F.PASS_SMAA_TU4X_EXTRAPOLATE, F.PASS_TAA_JASMINE):
+            self.antialias_pass(pass_id)
         else:
             self.real_pass_run(pass_id, arg, row_begin, row_end)
 
@@ -168,6 +185,31 @@ class Pinner:
             outs = {"denoise_render": (out, F.BUF_DENOISE_RENDER0 + ch, "rgba16f")}
         self.compare(rec, outs)
 
+    def antialias_pass(self, pass_id):
+        # post_process.rs:983-1035 (bind groups), 1236-1275 (dispatches): SMAA Tu4x reads tone_mapping_output[previous / current] and
+        # writes upscale_output[0]; TAA reads taa_output[previous] and upscale_output[0] (SMAA Tu4x) or tone_mapping_output[current]
+        e = self.e
+        smaa_kind = self.settings.upscale.kind == F.UPSCALE_SMAA_TU4X
+        rw, rh = e.buffer_info(F.BUF_TONE_MAPPED)[:2]
+        if pass_id == F.PASS_TAA_JASMINE:
+            m, entry = module("taa.wgsl", ()), "taa_jasmine"
+            prev_b, cur_b, out_b = F.BUF_PREVIOUS_TAA_OUTPUT, (F.BUF_UPSCALE_OUTPUT if smaa_kind else F.BUF_TONE_MAPPED), F.BUF_TAA_OUTPUT
+            gx, gy = ((2 * rw + 7) // 8, (2 * rh + 7) // 8) if smaa_kind else ((rw + 7) // 8, (rh + 7) // 8)
+        else:
+            m, entry = module("smaa.wgsl", ()), ("smaa_tu4x" if pass_id == F.PASS_SMAA_TU4X else "smaa_tu4x_extrapolate")
+            prev_b, cur_b, out_b = F.BUF_PREVIOUS_TONE_MAPPED, F.BUF_TONE_MAPPED, F.BUF_UPSCALE_OUTPUT
+            gx, gy = (rw + 7) // 8, (rh + 7) // 8
+        self.uniforms(m)
+        self.deferred(m)
+        out = tex_from(e, out_b, "rgba16f")
+        m.bind(previous_position_texture=tex_from(e, F.BUF_PREVIOUS_POSITION, "rgba32f"), previous_velocity_uv_texture=tex_from(e, F.BUF_PREVIOUS_VELOCITY_UV, "rgba32f"),
+               previous_render_texture=tex_from(e, prev_b, "rgba16f"), render_texture=tex_from(e, cur_b, "rgba16f"), output_texture=out)
+        t0 = time.time()
+        m.dispatch(entry, gx, gy)
+        rec = {"frame": int(self.frame.number), "pass": F.PASS_NAMES[pass_id], "entry": entry, "defs": [], "seconds": round(time.time() - t0, 1)}
+        self.real_pass_run(pass_id)
+        self.compare(rec, {F.PASS_NAMES[pass_id] + "_output": (out, out_b, "rgba16f")})
+
     def tone_mapping_pass(self, denoised):
         e = self.e
         m = module("tone_mapping.wgsl", ())
@@ -195,7 +237,7 @@ class Pinner:
         entry, defs, channel = LIGHT[pass_id]
         if defs is None:
             defs = ("MULTIPLE_BOUNCES",) if self.frame.indirect_bounces >= 2 else ()
-        m = module("light.wgsl", ("NO_TEXTURE",) + tuple(defs))
+        m = module("light.wgsl", (() if self.textures else ("NO_TEXTURE",)) + tuple(defs))      # light.rs:141-143
         self.uniforms(m)
         sc = self.scene
         m.bind(vertex_buffer=as_bytes(sc.vertices), primitive_buffer=as_bytes(sc.primitives), asset_node_buffer=np.concatenate([np.zeros(16, np.uint8), as_bytes(sc.asset_nodes)]),
@@ -207,8 +249,11 @@ class Pinner:
         m.bind(position_texture=tex_from(e, F.BUF_POSITION, "rgba32f"), normal_texture=tex_from(e, F.BUF_NORMAL, "rgba8snorm"),
                depth_gradient_texture=tex_from(e, F.BUF_DEPTH_GRADIENT, "rg32f"), instance_material_texture=tex_from(e, F.BUF_INSTANCE_MATERIAL, "rg32f"),
                velocity_uv_texture=tex_from(e, F.BUF_VELOCITY_UV, "rgba32f"))
-        m.bind(textures=T.Texture(np.ones((1, 1, 4), np.float32)), samplers=T.Sampler(True, "repeat"),
-               noise_texture=[T.Texture(self.noise[i].astype(np.float32) / f32(255.0)) for i in range(16)], noise_sampler=T.Sampler(False, "repeat"))
+        if self.textures:
+            m.bind(textures=[t for t, _ in self.textures], samplers=[sm for _, sm in self.textures])
+        else:
+            m.bind(textures=T.Texture(np.ones((1, 1, 4), np.float32)), samplers=T.Sampler(True, "repeat"))
+        m.bind(noise_texture=[T.Texture(self.noise[i].astype(np.float32) / f32(255.0)) for i in range(16)], noise_sampler=T.Sampler(False, "repeat", noise=True))
         ch = 0 if channel is None else channel
         albedo = tex_from(e, F.BUF_ALBEDO, "rgba16f")
         variance = tex_from(e, F.BUF_VARIANCE0 + ch, "r32f")
@@ -221,7 +266,10 @@ class Pinner:
         w, h = e.buffer_info(F.BUF_ALBEDO)[:2]
         gx, gy = ((w + 7) // 8, (h + 7) // 8) if entry == "full_screen_albedo" else ((rw + 7) // 8, (rh + 7) // 8)
         t0 = time.time()
-        m.dispatch(entry, gx, gy)
+        # The reference has no bounds guard (light.rs:651,686 round the grid up to 8): invocations beyond the image run, read a zero
+        # G-buffer texel and store "background" reservoirs at coords.x + width * coords.y, i.e. into the first pixels of the NEXT row,
+        # racing with their owners.  The oracle and the library guard instead; the pin runs the guarded grid.
+        m.dispatch(entry, gx, gy, limit=(w, h) if entry == "full_screen_albedo" else (rw, rh))
         seconds = time.time() - t0
         self.real_pass_run(pass_id)                 # now the oracle
         bad = {}
@@ -269,23 +317,66 @@ def main():
     dll = p.engine.api.dll
     dll.orc_debug_math.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t]
     R.bind_contract(contract)
-    scene = hk.load_cornell()
-    p.set_scene(scene)
-    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0, emissive_spatial_reuse=True)
-    cam = hk.cornell_camera(*size)
     from bevy_hikari_amd.plugin import load_noise
     noise = load_noise().reshape(16, 64, 64, 4)
+    which = sys.argv[sys.argv.index("--case") + 1] if "--case" in sys.argv else "cornell_b2"
+    first = 1
+    if which.startswith("random"):      # tests/cases.py random_case: settings x scene x odd size x AA tail (the GPU fuzz space)
+        from cases import random_case
+        rc = random_case(int(which[6:]))
+        scene, cam_for, s, lights, antialias = rc.scene, (lambda n: rc.camera), rc.settings, rc.lights, rc.antialias
+        size, first, frames = (rc.camera.width, rc.camera.height), rc.frames[0], len(rc.frames)
+    else:
+        scene, cam_for, s, lights, antialias = CASES[which](size)
+    p.set_scene(scene)
     pin = Pinner(p, scene, noise, lambda rec: print(json.dumps(rec), flush=True))
+    pin.settings = s
     real_frame_begin = p.engine.frame_begin
 
-    def frame_begin(frame, view, pview, lights):
-        pin.begin(frame, view, pview, lights)
-        real_frame_begin(frame, view, pview, lights)
+    def frame_begin(frame, view, pview, lgt):
+        pin.begin(frame, view, pview, lgt)
+        real_frame_begin(frame, view, pview, lgt)
     p.engine.frame_begin = frame_begin
-    for n in range(1, frames + 1):
-        p.render(cam, s, frame_number=n, by_nodes=True)
+    for n in range(first, first + frames):
+        p.render(cam_for(n), s, lights=lights, frame_number=n, by_nodes=True, antialias=antialias)
     bad = [r for r in pin.results if r["mismatch"]]
-    print(json.dumps({"dispatches": len(pin.results), "mismatching": len(bad), "seconds": round(sum(r["seconds"] for r in pin.results), 1)}))
+    print(json.dumps({"case": which, "size": list(size), "frames": frames, "dispatches": len(pin.results), "mismatching": len(bad),
+                      "seconds": round(sum(r["seconds"] for r in pin.results), 1)}))
+    return pin.results
+
+
+def _cornell(bounces, **kw):
+    def make(size):
+        s = hk.HikariSettings(indirect_bounces=bounces, **kw)
+        cam = hk.cornell_camera(*size)
+        return hk.load_cornell(), (lambda n: cam), s, hk.lights_uniform(), kw.get("antialias_tail", False)
+    return make
+
+
+def _yard(size, textured, fsr, motion):
+    from bevy_hikari_amd.scenes import animate, synthetic_camera, synthetic_scene
+    scene, sun = synthetic_scene(n_boxes=8, n_spheres=3, n_emitters=2, sphere_rings=5, sphere_segs=6, textured=textured)
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.5, 0.2) if fsr else hk.Upscale.SmaaTu4x(1.5), emissive_spatial_reuse=True,
+                          direct_validate_interval=2, emissive_validate_interval=3)
+    if not motion:
+        cam = synthetic_camera(*size)
+        return scene, (lambda n: cam), s, hk.lights_uniform(directional=sun), True
+    return scene, (lambda n: hk.Camera(hk.look_at_transform((6.4 + 0.15 * n, 4.4, 8.0 - 0.1 * n), (0.0, 0.6, 0.0)), *size)), s, hk.lights_uniform(directional=sun), True
+
+
+CASES = {
+    # sun + two emitters + light BVH / alias tables, the TEXTURED pipelines (base colour, metallic, occlusion, emissive textures),
+    # ratio 1.5, validation frames every 2 / 3 frames, SMAA Tu4x + TAA
+    "yard_textured_aa": lambda size: _yard(size, True, False, False),
+    # the same yard without textures under camera motion, FSR1-kind sizes (TAA at the scaled size): reprojection, velocity, the
+    # scatter stores that race in the reference (resolved here and in the oracle as highest invocation index wins)
+    "yard_moving_camera": lambda size: _yard(size, False, True, True),
+    # Cornell, MULTIPLE_BOUNCES pipeline, both spatial passes, denoise, ratio 1
+    "cornell_b2": lambda size: (hk.load_cornell(), (lambda n, c=hk.cornell_camera(*size): c),
+                                hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0, emissive_spatial_reuse=True), hk.lights_uniform(), False),
+    # the reference's default settings end to end: 1 bounce (single-bounce pipeline), ratio 2, SMAA Tu4x + TAA
+    "cornell_default_aa": lambda size: (hk.load_cornell(), (lambda n, c=hk.cornell_camera(*size): c), hk.HikariSettings(), hk.lights_uniform(), True),
+}
 
 
 if __name__ == "__main__":
