@@ -1,0 +1,169 @@
+"""The oracle pinned against the reference's OWN shader source.
+
+tools/wgsl translates src/shaders/{light,denoise,tone_mapping,taa,smaa}.wgsl of the reference mechanically to Python and
+tools/wgsl_pin.py executes every compute entry point on the state the oracle has before the corresponding dispatch; what the
+shader writes must equal what the oracle writes, byte for byte (reservoir buffers, render / variance / denoise / tone-mapped /
+SMAA / TAA textures).  These tests run where the reference checkout is mounted (this container); on the GPU box they skip.
+The translator itself is also tested on small WGSL programs that need no reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import wgsl_pin
+from wgsl import runtime as R
+from wgsl import translate
+from wgsl import types as T
+
+needs_reference = pytest.mark.skipif(not wgsl_pin.reference_available(), reason="/root/reference is not mounted here")
+
+
+def run(src, fn, *args):
+    ns = {"_R": R, "_T": T, "RESOURCES": {}, "WORKGROUP_VARS": {}, "ENTRY_POINTS": {}, "_ONCE": (0,)}
+    exec(translate.translate(src), ns)
+    return ns[fn](*args)
+
+
+def test_translator_value_semantics_pointers_loops_and_integers():
+    src = """
+    struct Inner { v: vec3<f32>, n: u32, };
+    struct Outer { a: Inner, w: f32, };
+    fn bump(p: ptr<function, Outer>, acc: ptr<function, f32>, k: f32) {
+        (*p).a.v.y = (*p).a.v.y + k;      // component of a vector inside nested structs, through a pointer
+        (*p).w += k;                      // a FIELD called w, not a swizzle
+        *acc += k * 2.0;                  // pointer to a scalar
+    }
+    fn f(n: u32) -> vec4<f32> {
+        var o: Outer;                     // zero-initialised
+        let copy = o;                     // value semantics: `copy` must not see the writes below
+        var acc = 0.5;
+        var sum = 0u;
+        for (var i = 0u; i < n; i += 1u) {
+            if i == 2u { continue; }
+            if i == 5u { break; }
+            bump(&o, &acc, f32(i));
+            sum += i * i;
+        }
+        var q: Outer;
+        q = o;
+        q.a.n = 7u;
+        return vec4<f32>(o.a.v.y + copy.a.v.y, o.w, acc, f32(sum + q.a.n + o.a.n));
+    }
+    fn ints(a: i32, b: i32) -> vec4<i32> { return vec4<i32>(a / b, a % b, a >> 1u, (a * 65536) * 65536); }
+    fn hash(value: u32) -> u32 {
+        var state = value;
+        state = state ^ 2747636419u;
+        state = state * 2654435769u;
+        state = state ^ state >> 16u;
+        return state * 2654435769u;
+    }
+    """
+    out = run(src, "f", R.u32(10))
+    assert [float(x) for x in out] == [0 + 1 + 3 + 4, 8.0, 0.5 + 16.0, float(0 + 1 + 9 + 16 + 7)]      # i = 0, 1, 3, 4
+    assert [int(x) for x in run(src, "ints", R.i32(-7), R.i32(2))] == [-3, -1, -4, 0]                  # truncating division, wrapping multiply
+    state = (12345 ^ 2747636419) * 2654435769 & 0xFFFFFFFF
+    state ^= state >> 16
+    assert int(run(src, "hash_", R.u32(12345))) == state * 2654435769 & 0xFFFFFFFF
+
+
+def test_translator_rounds_every_f32_operation_once():
+    src = "fn g(a: f32, b: f32, c: f32) -> f32 { return a * b + c; }\nfn d(a: vec3<f32>, b: vec3<f32>) -> f32 { return dot(a, b); }"
+    a, b, c = np.float32(1.0000001), np.float32(1.0000001), np.float32(-1.0)
+    assert run(src, "g", a, b, c) == np.float32(np.float32(a * b) + c)                     # no contraction
+    va, vb = T.vec3f32(0.1, 0.2, 0.3), T.vec3f32(0.7, -0.4, 0.9)
+    want = R.fma(va[2], vb[2], R.fma(va[1], vb[1], va[0] * vb[0]))                         # the contract's fma chain
+    assert run(src, "d", va, vb) == want
+
+
+def test_wgsl_memory_layout_matches_the_c_abi():
+    """The struct layouts the translator derives from the reference's WGSL are the ones the C ABI declares (hikari_hip.h)."""
+    if not wgsl_pin.reference_available():
+        pytest.skip("/root/reference is not mounted here")
+    m = wgsl_pin.module("light.wgsl", ("NO_TEXTURE",))
+    size = lambda name: m.ns["S_" + name].TYPE.size
+    assert (size("Frame"), size("View"), size("PreviousView"), size("Instance"), size("Material"), size("Emissive"), size("Node"), size("Vertex"),
+            size("Primitive"), size("PackedReservoir")) == (256, 416, 128, 176, 80, 64, 32, 32, 48, 64)
+
+
+@needs_reference
+@pytest.mark.parametrize("case,size,frames,dispatches", [("cornell_b2", (16, 12), 2, 44), ("cornell_default_aa", (24, 16), 2, 48)])
+def test_reference_shaders_reproduce_the_oracle(case, size, frames, dispatches):
+    """cornell_b2: MULTIPLE_BOUNCES pipeline, both spatial passes, denoise x3 channels x4 levels, tone mapping.
+    cornell_default_aa: HikariSettings::default() - single-bounce pipeline, ratio 2, SMAA Tu4x + extrapolation + TAA."""
+    results = wgsl_pin.run_case(case, size, frames)
+    assert len(results) == dispatches
+    assert [r for r in results if r["mismatch"]] == []
+
+
+@needs_reference
+def test_the_pin_notices_a_changed_constant():
+    """Negative control: RAY_BIAS 0.02 -> 0.03 in the translated light.wgsl must break every dispatch that traces."""
+    saved = dict(wgsl_pin._modules)
+    wgsl_pin._modules.clear()
+    try:
+        def patch(m):
+            m.ns["RAY_BIAS"] = np.float32(0.03)
+        results = wgsl_pin.run_case("cornell_b2", (16, 12), 1, patch=patch)
+    finally:
+        wgsl_pin._modules.clear()
+        wgsl_pin._modules.update(saved)
+    bad = {r["pass"] for r in results if r["mismatch"]}
+    assert {"direct_emissive", "indirect_lit_ambient"} <= bad
+
+
+# ---------------------------------------------------------------- replay of committed shader-produced fixtures (no reference needed)
+FIXTURES = {"cornell_b2": ((16, 12), 2), "cornell_default_aa": ((24, 16), 3), "yard_textured_aa": ((30, 22), 3), "yard_moving_camera": ((30, 22), 3)}
+
+
+def replay(plugin, case):
+    """tests/golden/wgsl_<case>_*.npz holds what the REFERENCE'S SHADERS wrote in every dispatch of the sequence
+    (tools/wgsl_pin.py --write, run where the reference is mounted).  Drive `plugin` through the same dispatches and return the
+    list of (dispatch, buffer) whose bytes differ from what the shader wrote."""
+    import bevy_hikari_amd as hk
+
+    size, frames = FIXTURES[case]
+    data = np.load(os.path.join(ROOT, "tests", "golden", f"wgsl_{case}_{size[0]}x{size[1]}_f{frames}.npz"))
+    by_dispatch = {}
+    for key in data.files:
+        by_dispatch.setdefault(int(key[1:4]), []).append(key)
+    scene, cam_for, s, lights, antialias = wgsl_pin.CASES[case](size)
+    plugin.set_scene(scene)
+    e, index, bad = plugin.engine, [0], []
+    real = e.pass_run
+
+    def hooked(pass_id, arg=0, row_begin=0, row_end=0):
+        index[0] += 1
+        real(pass_id, arg, row_begin, row_end)
+        for key in by_dispatch.get(index[0], ()):
+            want = data[key]
+            got = e.read(int(key.split("buf")[1])).view(np.uint8).reshape(-1)[:len(want)]
+            if not (got == want).all():
+                bad.append((index[0], key, int((got != want).sum())))
+
+    e.pass_run = hooked
+    for n in range(1, frames + 1):
+        plugin.render(cam_for(n), s, lights=lights, frame_number=n, by_nodes=True, antialias=antialias)
+    assert index[0] >= max(by_dispatch)     # (dispatches the reference ships only as SPIR-V - FSR1 - have no record)
+    return bad
+
+
+@pytest.mark.parametrize("case", sorted(FIXTURES))
+def test_oracle_equals_what_the_reference_shaders_wrote(case):
+    from oracle_lib import oracle_plugin
+
+    assert replay(oracle_plugin(), case) == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(FIXTURES))
+def test_gpu_equals_what_the_reference_shaders_wrote(case):
+    """The HIP path against the outputs of the reference's own WGSL, dispatch by dispatch - no oracle in between.  The moving-camera
+    fixture resolves the reference's store race by highest invocation index (HK_CTX_DETERMINISTIC_SCATTER does the same)."""
+    import bevy_hikari_amd as hk
+    from bevy_hikari_amd import _ffi as F
+
+    assert replay(hk.HikariPlugin(device=0, flags=F.CTX_DETERMINISTIC_SCATTER), case) == []

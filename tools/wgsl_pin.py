@@ -110,13 +110,21 @@ def module(filename, defs):
     return _modules[key]
 
 
+def reference_available():
+    return os.path.isdir(SHADERS)
+
+
 class Pinner:
     def __init__(self, plugin, scene, noise, log):
         self.p, self.e, self.scene, self.noise, self.log = plugin, plugin.engine, scene, noise, log
-        self.results = []
+        self.results, self.recorded, self.dispatch_index = [], {}, 0
         self.textures = [material_texture(im) for im in getattr(scene, "textures", [])]
         self.real_pass_run = self.e.pass_run
         self.e.pass_run = self.pass_run            # every dispatch of the node path goes through here
+
+    def record(self, buf, data):
+        """what the SHADER wrote to `buf` in the dispatch being compared (fixture for replays without the reference)"""
+        self.recorded[f"d{self.dispatch_index:03d}_buf{buf}"] = np.ascontiguousarray(data).view(np.uint8).reshape(-1).copy()
 
     def uniforms(self, m):
         e = self.e
@@ -126,6 +134,7 @@ class Pinner:
         self.frame, self.view, self.pview, self.lights = frame, view, pview, lights
 
     def pass_run(self, pass_id, arg=0, row_begin=0, row_end=0):
+        self.dispatch_index += 1
         if pass_id in LIGHT:
             self.light_pass(pass_id)
         elif pass_id == F.PASS_DEMODULATION or F.PASS_DENOISE_L0 <= pass_id <= F.PASS_DENOISE_L3:
@@ -147,6 +156,7 @@ class Pinner:
         e, bad = self.e, {}
         for name, (tex, buf, kind) in outs.items():
             got, want = tex_bytes(tex, kind), e.read(buf)
+            self.record(buf, got)
             ne = (got.reshape(want.shape[0], want.shape[1], -1).view(np.uint8) != want.reshape(want.shape[0], want.shape[1], -1).view(np.uint8)).any(axis=2)
             if ne.any():
                 ys, xs = np.nonzero(ne)
@@ -238,6 +248,8 @@ class Pinner:
         if defs is None:
             defs = ("MULTIPLE_BOUNCES",) if self.frame.indirect_bounces >= 2 else ()
         m = module("light.wgsl", (() if self.textures else ("NO_TEXTURE",)) + tuple(defs))      # light.rs:141-143
+        if self.patch:
+            self.patch(m)
         self.uniforms(m)
         sc = self.scene
         m.bind(vertex_buffer=as_bytes(sc.vertices), primitive_buffer=as_bytes(sc.primitives), asset_node_buffer=np.concatenate([np.zeros(16, np.uint8), as_bytes(sc.asset_nodes)]),
@@ -277,6 +289,7 @@ class Pinner:
                                                                                          "render": (render, F.BUF_RENDER0 + ch, "rgba16f")}
         for name, (tex, buf, kind) in outs.items():
             got, want = tex_bytes(tex, kind), e.read(buf)
+            self.record(buf, got)
             ne = (got.reshape(want.shape[0], want.shape[1], -1).view(np.uint8) != want.reshape(want.shape[0], want.shape[1], -1).view(np.uint8)).any(axis=2)
             if ne.any():
                 ys, xs = np.nonzero(ne)
@@ -287,6 +300,7 @@ class Pinner:
                     continue
                 want = e.read(b).view(np.uint8).reshape(-1)
                 got = res_bytes[k]
+                self.record(b, got[:rw * rh * 64])
                 n = rw * rh * 64         # the reservoirs the pass indexes (full-size allocation, scaled-size indexing)
                 ne = (got[:n].reshape(-1, 64) != want[:n].reshape(-1, 64)).any(axis=1)
                 if ne.any():
@@ -297,29 +311,28 @@ class Pinner:
         self.log(rec)
 
 
-def main():
-    size = (24, 16)
-    if "--size" in sys.argv:
-        i = sys.argv.index("--size")
-        size = (int(sys.argv[i + 1]), int(sys.argv[i + 2]))
-    frames = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 2
-    fn_cache = {}
+_contract_cache = {}
 
-    def contract(op, x, y):
-        key = (op, float(x), float(y))
-        if key not in fn_cache:
-            xi, yi, out = (C.c_float * 1)(float(x)), (C.c_float * 1)(float(y)), (C.c_float * 1)()
-            assert dll.orc_debug_math(None, op, xi, yi, out, 1) == 0
-            fn_cache[key] = f32(out[0])
-        return fn_cache[key]
 
+def run_case(which, size=(24, 16), frames=2, log=None, patch=None):
+    """Drive the oracle through `which` dispatch by dispatch, executing the reference's WGSL for each one on the state the oracle
+    has before it.  Returns the list of per-dispatch records ({"pass", "entry", "defs", "mismatch": {buffer: description}, ...}).
+    `patch(module)` may tamper with a translated module (negative controls)."""
     p = oracle_plugin()
     dll = p.engine.api.dll
     dll.orc_debug_math.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t]
+
+    def contract(op, x, y):
+        key = (op, float(x), float(y))
+        if key not in _contract_cache:
+            xi, yi, out = (C.c_float * 1)(float(x)), (C.c_float * 1)(float(y)), (C.c_float * 1)()
+            assert dll.orc_debug_math(None, op, xi, yi, out, 1) == 0
+            _contract_cache[key] = f32(out[0])
+        return _contract_cache[key]
+
     R.bind_contract(contract)
     from bevy_hikari_amd.plugin import load_noise
     noise = load_noise().reshape(16, 64, 64, 4)
-    which = sys.argv[sys.argv.index("--case") + 1] if "--case" in sys.argv else "cornell_b2"
     first = 1
     if which.startswith("random"):      # tests/cases.py random_case: settings x scene x odd size x AA tail (the GPU fuzz space)
         from cases import random_case
@@ -329,8 +342,8 @@ def main():
     else:
         scene, cam_for, s, lights, antialias = CASES[which](size)
     p.set_scene(scene)
-    pin = Pinner(p, scene, noise, lambda rec: print(json.dumps(rec), flush=True))
-    pin.settings = s
+    pin = Pinner(p, scene, noise, log or (lambda rec: None))
+    pin.settings, pin.patch = s, patch
     real_frame_begin = p.engine.frame_begin
 
     def frame_begin(frame, view, pview, lgt):
@@ -339,18 +352,26 @@ def main():
     p.engine.frame_begin = frame_begin
     for n in range(first, first + frames):
         p.render(cam_for(n), s, lights=lights, frame_number=n, by_nodes=True, antialias=antialias)
-    bad = [r for r in pin.results if r["mismatch"]]
-    print(json.dumps({"case": which, "size": list(size), "frames": frames, "dispatches": len(pin.results), "mismatching": len(bad),
-                      "seconds": round(sum(r["seconds"] for r in pin.results), 1)}))
+    run_case.recorded = pin.recorded
     return pin.results
 
 
-def _cornell(bounces, **kw):
-    def make(size):
-        s = hk.HikariSettings(indirect_bounces=bounces, **kw)
-        cam = hk.cornell_camera(*size)
-        return hk.load_cornell(), (lambda n: cam), s, hk.lights_uniform(), kw.get("antialias_tail", False)
-    return make
+def main():
+    size = (24, 16)
+    if "--size" in sys.argv:
+        i = sys.argv.index("--size")
+        size = (int(sys.argv[i + 1]), int(sys.argv[i + 2]))
+    frames = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 2
+    which = sys.argv[sys.argv.index("--case") + 1] if "--case" in sys.argv else "cornell_b2"
+    results = run_case(which, size, frames, log=lambda rec: print(json.dumps(rec), flush=True))
+    bad = [r for r in results if r["mismatch"]]
+    if "--write" in sys.argv:
+        assert not bad and not which.startswith("random")
+        path = os.path.join(ROOT, "tests", "golden", f"wgsl_{which}_{size[0]}x{size[1]}_f{frames}.npz")
+        np.savez_compressed(path, **run_case.recorded)
+        print("wrote", path, os.path.getsize(path), "bytes,", len(run_case.recorded), "buffers")
+    print(json.dumps({"case": which, "frames": len({r["frame"] for r in results}), "dispatches": len(results), "mismatching": len(bad),
+                      "seconds": round(sum(r["seconds"] for r in results), 1)}))
 
 
 def _yard(size, textured, fsr, motion):
