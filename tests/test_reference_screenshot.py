@@ -1,7 +1,7 @@
 """The one output of the reference itself that ships with it: assets/screenshots/cornell.png (fixture made by
 tools/make_fixtures.py).  It records no settings, frame count or camera pose - examples/cornell.rs puts the camera on
 an orbit controller and an egui inspector in the window, and the short box in the picture has visibly been given
-another material - so it cannot serve as a golden vector and parity stays "unpinned".  But it does test what the
+another material - so it cannot serve as a golden vector (the pin of the oracle is tests/test_wgsl_pin.py).  But it does test what the
 oracle cannot test against itself: with ONE free parameter (the dolly distance of the orbit camera) the whole path
 - glTF scene transform, pi/4 infinite reverse-Z projection, G-buffer, emitter strength 255*a*rgb, ReSTIR, denoiser,
 Reinhard tone mapping, SMAA Tu4x + TAA, sRGB display encoding - must land on the reference's picture."""

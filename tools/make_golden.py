@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the CPU oracle.
 
-PARITY UNPINNED: the reference has no golden vectors and cannot run here, so these fixtures pin
-the ORACLE (a line-by-line restatement of the reference WGSL) against regressions and let the GPU
-tests compare against committed data; they are not outputs of the reference itself."""
+These fixtures are the ORACLE's outputs: they pin the oracle against regressions and let the GPU tests compare against committed
+data; they are not outputs of the reference.  The fixtures that ARE produced from the reference - by executing its WGSL - are
+tests/golden/wgsl_*.npz (tools/wgsl_pin.py --write)."""
 import hashlib
 import os
 import sys
