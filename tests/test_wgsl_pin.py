@@ -167,3 +167,23 @@ def test_gpu_equals_what_the_reference_shaders_wrote(case):
     from bevy_hikari_amd import _ffi as F
 
     assert replay(hk.HikariPlugin(device=0, flags=F.CTX_DETERMINISTIC_SCATTER), case) == []
+
+
+def test_translator_block_scoping():
+    src = """
+    fn f(c: bool) -> vec3<f32> {
+        let a = 1.0;
+        var out = 0.0;
+        if c {
+            let a = 2.0;            // shadows, must not leak
+            out = a;
+        }
+        for (var i = 0u; i < 2u; i += 1u) {
+            let a = 5.0;
+            out += a;
+        }
+        return vec3<f32>(a, out, 0.0);
+    }
+    """
+    assert [float(x) for x in run(src, "f", True)] == [1.0, 12.0, 0.0]
+    assert [float(x) for x in run(src, "f", False)] == [1.0, 10.0, 0.0]

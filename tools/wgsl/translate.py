@@ -40,6 +40,31 @@ class Translator:
                 self.box_sig[d[1]] = [p[1][1] == "ptr" and p[1][2][1][1] not in self.structs for p in d[2]]
         self.box_params = set()
         self.pre, self.post = [], []
+        self.scopes = []            # WGSL block scoping: name -> Python name, innermost last (shadowing declarations are renamed)
+        self.used_names = set()
+
+    def push_scope(self):
+        self.scopes.append({})
+
+    def pop_scope(self):
+        self.scopes.pop()
+
+    def declare(self, name):
+        py = pyname(name)
+        if any(name in sc for sc in self.scopes[:-1]) or (py in self.used_names and name not in self.scopes[-1]):
+            k = 1
+            while f"{py}__{k}" in self.used_names:
+                k += 1
+            py = f"{py}__{k}"
+        self.scopes[-1][name] = py
+        self.used_names.add(py)
+        return py
+
+    def lookup(self, name):
+        for sc in reversed(self.scopes):
+            if name in sc:
+                return sc[name]
+        return pyname(name)         # module scope
 
     # ------------------------------------------------------------ types
     def type_expr(self, ty):
@@ -113,7 +138,7 @@ class Translator:
         if k == "bool":
             return "True" if e[1] else "False"
         if k == "id":
-            return pyname(e[1])
+            return self.lookup(e[1])
         if k == "paren":
             return f"({self.expr(e[1])})"
         if k == "member":
@@ -123,7 +148,7 @@ class Translator:
         if k == "un":
             op, x = e[1], e[2]
             if op == "*" and x[0] == "id" and x[1] in self.box_params:
-                return f"{pyname(x[1])}.v"
+                return f"{self.lookup(x[1])}.v"
             if op in ("&", "*"):
                 return self.expr(x)          # pointers to structs are references to the mutable object
             if op == "!":
@@ -185,12 +210,12 @@ class Translator:
             t = t[1]
         if t[0] == "un" and t[1] == "*":      # (*p) = value: overwrite the pointee in place
             if t[2][0] == "id" and t[2][1] in self.box_params:
-                self.emit(depth, f"{pyname(t[2][1])}.v = {value_src}")
+                self.emit(depth, f"{self.lookup(t[2][1])}.v = {value_src}")
             else:
                 self.emit(depth, f"{self.expr(t[2])}.set_value({value_src})")
             return
         if t[0] == "id":
-            self.emit(depth, f"{pyname(t[1])} = {value_src}")
+            self.emit(depth, f"{self.lookup(t[1])} = {value_src}")
         elif t[0] == "member":
             base, name = t[1], t[2]
             if re.fullmatch(r"[xyzw]{1,4}|[rgba]{1,4}", name):
@@ -239,8 +264,10 @@ class Translator:
         if k == "block":
             if not s[1]:
                 self.emit(depth, "pass")
+            self.push_scope()
             for x in s[1]:
                 self.stmt(depth, x, loops)
+            self.pop_scope()
         elif k == "var":
             _, kind, name, ty, init = s
             if init is not None:
@@ -249,7 +276,7 @@ class Translator:
                     src = f"_R.vconvert({ty[1]!r}, {src})"
             else:
                 src = self.zero_expr(ty)
-            self.emit(depth, f"{pyname(name)} = {src}")
+            self.emit(depth, f"{self.declare(name)} = {src}")      # (the initialiser was translated before the name became visible)
         elif k == "assign":
             _, op, target, value = s
             if op == "=":
@@ -266,6 +293,7 @@ class Translator:
                 self.stmt(depth + 1, s[3], loops)
         elif k == "for":
             _, init, cond, update, body = s
+            self.push_scope()
             if init is not None:
                 self.stmt(depth, init, loops)
             flag = f"_brk{len(loops)}"
@@ -276,6 +304,7 @@ class Translator:
             self.emit(depth + 1, f"if {flag}: break")
             if update is not None:
                 self.stmt(depth + 1, update, loops)
+            self.pop_scope()
         elif k == "break":
             self.emit(depth, f"{loops[-1]} = True")
             self.emit(depth, "break")
@@ -316,7 +345,10 @@ class Translator:
             elif d[0] == "fn":
                 _, name, params, ret, block, attrs = d
                 self.box_params = {p[0] for p, boxed in zip(params, self.box_sig[name]) if boxed}
-                self.emit(0, f"def {pyname(name)}({', '.join(pyname(p[0]) for p in params)}):")
+                self.scopes, self.used_names = [{}], set()
+                for prm in params:
+                    self.declare(prm[0])
+                self.emit(0, f"def {pyname(name)}({', '.join(self.lookup(p[0]) for p in params)}):")
                 n0 = len(self.lines)
                 used_globals = sorted(self.assigned_globals(block))
                 if used_globals:
