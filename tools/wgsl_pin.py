@@ -187,12 +187,8 @@ class Pinner:
         rec = {"frame": int(self.frame.number), "pass": F.PASS_NAMES[pass_id], "entry": "demodulation" if demod else "denoise", "defs": list(defs), "channel": ch,
                "seconds": round(time.time() - t0, 1)}
         self.real_pass_run(pass_id, ch)
-        if demod:
-            outs = {"internal0": (internal[0], F.BUF_DENOISE_INTERNAL0, "rgba16f"), "internal_variance": (ivar, F.BUF_DENOISE_INTERNAL_VARIANCE, "r32f")}
-        elif level < 3:
-            outs = {f"internal{level + 1}": (internal[level + 1], F.BUF_DENOISE_INTERNAL0 + level + 1, "rgba16f")}
-        else:
-            outs = {"denoise_render": (out, F.BUF_DENOISE_RENDER0 + ch, "rgba16f")}
+        outs = {f"internal{i}": (internal[i], F.BUF_DENOISE_INTERNAL0 + i, "rgba16f") for i in range(4)}      # all writable resources of groups 3 and 4
+        outs.update({"internal_variance": (ivar, F.BUF_DENOISE_INTERNAL_VARIANCE, "r32f"), "denoise_render": (out, F.BUF_DENOISE_RENDER0 + ch, "rgba16f")})
         self.compare(rec, outs)
 
     def antialias_pass(self, pass_id):
@@ -285,8 +281,8 @@ class Pinner:
         seconds = time.time() - t0
         self.real_pass_run(pass_id)                 # now the oracle
         bad = {}
-        outs = {"albedo": (albedo, F.BUF_ALBEDO, "rgba16f")} if channel is None else {"variance": (variance, F.BUF_VARIANCE0 + ch, "r32f"),
-                                                                                         "render": (render, F.BUF_RENDER0 + ch, "rgba16f")}
+        # every writable resource of the bind groups is compared, also the ones this entry point is not expected to touch
+        outs = {"albedo": (albedo, F.BUF_ALBEDO, "rgba16f"), "variance": (variance, F.BUF_VARIANCE0 + ch, "r32f"), "render": (render, F.BUF_RENDER0 + ch, "rgba16f")}
         for name, (tex, buf, kind) in outs.items():
             got, want = tex_bytes(tex, kind), e.read(buf)
             self.record(buf, got)
@@ -339,6 +335,11 @@ def run_case(which, size=(24, 16), frames=2, log=None, patch=None):
         rc = random_case(int(which[6:]))
         scene, cam_for, s, lights, antialias = rc.scene, (lambda n: rc.camera), rc.settings, rc.lights, rc.antialias
         size, first, frames = (rc.camera.width, rc.camera.height), rc.frames[0], len(rc.frames)
+    elif which.startswith("case:"):     # a named case of tests/cases.py at its own size and frame range
+        from cases import make_case
+        mc = make_case(which[5:])
+        scene, cam_for, s, lights, antialias = mc.scene, (lambda n: mc.camera), mc.settings, mc.lights, mc.antialias
+        size, first, frames = (mc.camera.width, mc.camera.height), mc.frames[0], len(mc.frames)
     else:
         scene, cam_for, s, lights, antialias = CASES[which](size)
     p.set_scene(scene)
