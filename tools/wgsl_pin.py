@@ -222,8 +222,11 @@ class Pinner:
         self.uniforms(m)
         base = F.BUF_DENOISE_RENDER0 if denoised else F.BUF_RENDER0
         out = tex_from(e, F.BUF_TONE_MAPPED, "rgba16f")
+        indirect = tex_from(e, base + 2, "rgba16f")
+        if self.frame.indirect_bounces == 0:      # post_process.rs:949-954: "Use fallback texture when there is no indirect denoise pass"
+            indirect = T.Texture(np.zeros((1, 1, 4), np.float32))
         m.bind(direct_render_texture=tex_from(e, base, "rgba16f"), emissive_render_texture=tex_from(e, base + 1, "rgba16f"),
-               indirect_render_texture=tex_from(e, base + 2, "rgba16f"), output_texture=out)
+               indirect_render_texture=indirect, output_texture=out)
         rw, rh = e.buffer_info(F.BUF_TONE_MAPPED)[:2]
         t0 = time.time()
         m.dispatch("tone_mapping", (rw + 7) // 8, (rh + 7) // 8)
