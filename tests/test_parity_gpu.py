@@ -654,7 +654,7 @@ def test_one_context_pair_through_many_scenes_sizes_and_settings():
     (hk_resize: new buffers, zeroed reservoirs, plane parity reset), the upscale kind and the settings under a live
     context.  The camera history is dropped at each cut - a cut WITH history is camera motion, i.e. the reference's
     scatter-store race - and every buffer of every frame stays bit-exact.
-    (tools/fuzz_sweep.py runs the same loop over any seed range; 3400 seeds / 10 200 frames were clean.)"""
+    (tools/fuzz_sweep.py runs the same loop over any seed range; 13 400 seeds / 40 200 frames were clean.)"""
     from cases import random_case
 
     gpu, cpu = hk.HikariPlugin(device=0), oracle()
@@ -676,7 +676,7 @@ def test_motion_is_bit_exact_once_the_race_is_resolved_like_the_oracle(seed):
     reprojected stores to previous_spatial race; HK_CTX_DETERMINISTIC_SCATTER parks them and lets the highest thread
     index win, which is the oracle's rule - and then EVERY buffer of EVERY frame is bit-exact under motion too: the
     race is the only thing that separates the two under motion.  (tools/fuzz_sweep.py --motion --deterministic:
-    900 sequences clean.)"""
+    2 900 sequences clean.)"""
     from cases import motion_case, run_motion_case
 
     case = motion_case(seed)
