@@ -7,7 +7,7 @@
 // PARITY: PINNED TO THE REFERENCE'S SHADER SOURCE, NOT TO A RUN OF THE REFERENCE.  The reference has no tests, golden
 // vectors or fixtures for this path and cannot be built or run in this environment (no Rust toolchain, wgpu or Vulkan
 // ICD).  The oracle is a line-by-line restatement of the reference WGSL; every function cites the reference file:line it
-// follows (paths relative to /root/reference).  tools/wgsl_pin.py executes that WGSL itself (tools/wgsl: a WGSL -> Python
+// follows (paths relative to /root/reference).  tests/tools/wgsl_pin.py executes that WGSL itself (tests/tools/wgsl: a WGSL -> Python
 // translation, one f32 rounding per operation) dispatch by dispatch next to this file and finds no differing byte
 // (tests/test_wgsl_pin.py).  NOT covered by that pin and still "unpinned" in the strict sense: the
 // bevy_pbr functions below, the ray-cast G-buffer, the FSR1 passes.  Third-party arithmetic the
@@ -504,7 +504,7 @@ struct Scene {
   const HkView* view;
   const HkLights* lights;
   uint64_t n_tlas = 0, n_blas = 0;  // per-thread ray counters
-  // tools/divergence_model.py: per-ray traversal work (inner-node visits, triangle tests, instance entries)
+  // tests/tools/divergence_model.py: per-ray traversal work (inner-node visits, triangle tests, instance entries)
   // of the current pixel's rays, in call order; null unless orc_debug_record_steps armed it
   uint16_t* step_rec = nullptr;
   uint32_t step_slot = 0, step_slots = 0, step_base = 0;  // slot = 3 * bounce + {0 closest hit, 1 emitter BLAS ray, 2 shadow ray}
@@ -1360,7 +1360,7 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
     const HkFrame& frame = c->frame;
     for (int x = 0; x < rw; ++x) {
       const int index = x + rw * y;
-      if (c->step_rec) {  // tools/divergence_model.py
+      if (c->step_rec) {  // tests/tools/divergence_model.py
         sc.step_rec = c->step_rec + (size_t)3 * c->step_slots * index;
         sc.step_slots = c->step_slots;
         sc.step_slot = 0;
@@ -2547,7 +2547,7 @@ int orc_frame_render(orc_ctx* ctx, const HkFrame* f, const HkView* v, const HkPr
   return HK_OK;
 }
 int orc_frame_wait(orc_ctx* ctx) { (void)ctx; return HK_OK; }
-// Measurement hook for tools/divergence_model.py (not part of the mirrored API): while armed, pass_indirect
+// Measurement hook for tests/tools/divergence_model.py (not part of the mirrored API): while armed, pass_indirect
 // records for every pixel the traversal work of its rays in call order - (inner-node visits, triangle
 // tests, instance entries) per traverse_top call / stand-alone traverse_bottom call.  buf = [RH][RW][slots][3] u16.
 int orc_debug_record_steps(orc_ctx* ctx, uint16_t* buf, uint32_t slots) {

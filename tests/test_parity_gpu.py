@@ -41,7 +41,7 @@ def test_bit_exact_vs_oracle_every_frame(name):
 
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_matches_golden_fixture(name):
-    """Same check without the oracle in the loop: committed fixtures (tools/make_golden.py)."""
+    """Same check without the oracle in the loop: committed fixtures (tests/tools/make_golden.py)."""
     case = make_case(name)
     gpu = hk.HikariPlugin(device=0)
     run_case(gpu, case)
@@ -654,7 +654,7 @@ def test_one_context_pair_through_many_scenes_sizes_and_settings():
     (hk_resize: new buffers, zeroed reservoirs, plane parity reset), the upscale kind and the settings under a live
     context.  The camera history is dropped at each cut - a cut WITH history is camera motion, i.e. the reference's
     scatter-store race - and every buffer of every frame stays bit-exact.
-    (tools/fuzz_sweep.py runs the same loop over any seed range; 13 400 seeds / 40 200 frames were clean.)"""
+    (tests/tools/fuzz_sweep.py runs the same loop over any seed range; 13 400 seeds / 40 200 frames were clean.)"""
     from cases import random_case
 
     gpu, cpu = hk.HikariPlugin(device=0), oracle()
@@ -675,7 +675,7 @@ def test_motion_is_bit_exact_once_the_race_is_resolved_like_the_oracle(seed):
     """Moving camera + moving instances (cases.motion_case), random settings and AA tail.  The reference lets the
     reprojected stores to previous_spatial race; HK_CTX_DETERMINISTIC_SCATTER parks them and lets the highest thread
     index win, which is the oracle's rule - and then EVERY buffer of EVERY frame is bit-exact under motion too: the
-    race is the only thing that separates the two under motion.  (tools/fuzz_sweep.py --motion --deterministic:
+    race is the only thing that separates the two under motion.  (tests/tools/fuzz_sweep.py --motion --deterministic:
     2 900 sequences clean.)"""
     from cases import motion_case, run_motion_case
 

@@ -1,7 +1,7 @@
 """The oracle pinned against the reference's OWN shader source.
 
-tools/wgsl translates src/shaders/{light,denoise,tone_mapping,taa,smaa}.wgsl of the reference mechanically to Python and
-tools/wgsl_pin.py executes every compute entry point on the state the oracle has before the corresponding dispatch; what the
+tests/tests/tools/wgsl translates src/shaders/{light,denoise,tone_mapping,taa,smaa}.wgsl of the reference mechanically to Python and
+tests/tools/wgsl_pin.py executes every compute entry point on the state the oracle has before the corresponding dispatch; what the
 shader writes must equal what the oracle writes, byte for byte (reservoir buffers, render / variance / denoise / tone-mapped /
 SMAA / TAA textures).  These tests run where the reference checkout is mounted (this container); on the GPU box they skip.
 The translator itself is also tested on small WGSL programs that need no reference."""
@@ -13,7 +13,7 @@ import pytest
 
 from conftest import ROOT
 
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import wgsl_pin
 from wgsl import runtime as R
 from wgsl import translate
@@ -121,7 +121,7 @@ FIXTURES = {"cornell_b2": ((16, 12), 2), "cornell_default_aa": ((24, 16), 3), "y
 
 def replay(plugin, case):
     """tests/golden/wgsl_<case>_*.npz holds what the REFERENCE'S SHADERS wrote in every dispatch of the sequence
-    (tools/wgsl_pin.py --write, run where the reference is mounted).  Drive `plugin` through the same dispatches and return the
+    (tests/tools/wgsl_pin.py --write, run where the reference is mounted).  Drive `plugin` through the same dispatches and return the
     list of (dispatch, buffer) whose bytes differ from what the shader wrote."""
     import bevy_hikari_amd as hk
 

@@ -9,7 +9,7 @@ max-over-lanes of the per-lane work and compares it with
   * two pixels per lane, traced back to back in one loop (tile 8x16): max over lanes of the SUM,
   * four pixels per lane (tile 16x16),
   * the bound of perfect re-grouping: total work / 64.
-Usage: python tools/divergence_model.py [width height bounces frames]"""
+Usage: python tests/tools/divergence_model.py [width height bounces frames]"""
 import ctypes as C
 import json
 import os
@@ -17,7 +17,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import bevy_hikari_amd as hk

@@ -3,12 +3,12 @@
 
 These fixtures are the ORACLE's outputs: they pin the oracle against regressions and let the GPU tests compare against committed
 data; they are not outputs of the reference.  The fixtures that ARE produced from the reference - by executing its WGSL - are
-tests/golden/wgsl_*.npz (tools/wgsl_pin.py --write)."""
+tests/golden/wgsl_*.npz (tests/tools/wgsl_pin.py --write)."""
 import hashlib
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

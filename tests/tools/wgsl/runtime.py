@@ -1,4 +1,4 @@
-"""Runtime of the WGSL -> Python translation (tools/wgsl): value types and builtins.
+"""Runtime of the WGSL -> Python translation (tests/tests/tools/wgsl): value types and builtins.
 
 TEST INFRASTRUCTURE ONLY.  Executes the reference's OWN shader source (src/shaders/*.wgsl) one invocation at a time,
 every f32 operation rounded once (numpy.float32 scalars), so that the CPU oracle - a hand restatement of the same

@@ -360,7 +360,7 @@ class Translator:
                     builtins = {p[0]: p[2].get("builtin", [None])[0] for p in params}
                     self.emit(0, f"ENTRY_POINTS[{name!r}] = ({pyname(name)}, {tuple(int(re.sub('[iu]$', '', a)) for a in attrs.get('workgroup_size', ['1']))!r}, {builtins!r})")
             body.extend(self.lines)
-        out.append("# generated by tools/wgsl/translate.py - do not edit")
+        out.append("# generated by tests/tools/wgsl/translate.py - do not edit")
         for i, c in enumerate(self.consts):
             out.append(f"_k{i} = {c}")
         out.extend(body)

@@ -2,13 +2,13 @@
 """Pin the CPU oracle against the reference's OWN shader source.
 
 The reference ships no tests or golden vectors and cannot be built here, but its shaders are text:
-src/shaders/{light,denoise,tone_mapping,taa,smaa}.wgsl.  tools/wgsl translates that text mechanically to Python (one
+src/shaders/{light,denoise,tone_mapping,taa,smaa}.wgsl.  tests/tests/tools/wgsl translates that text mechanically to Python (one
 f32 rounding per operation, implementation-defined choices bound to the oracle's numeric contract - see
-tools/wgsl/runtime.py) and this script runs every compute entry point on the state the oracle has BEFORE the
+tests/tools/wgsl/runtime.py) and this script runs every compute entry point on the state the oracle has BEFORE the
 corresponding dispatch and compares what the shader writes with what the oracle wrote, byte for byte.  The G-buffer
 comes from the oracle (prepass.wgsl is a raster shader; the ray-cast G-buffer is this project's contract).
 
-  python tools/wgsl_pin.py [--size W H] [--frames N] [--write]      (needs /root/reference; minutes of pure Python)
+  python tests/tools/wgsl_pin.py [--size W H] [--frames N] [--write]      (needs /root/reference; minutes of pure Python)
 
 --write stores the inputs and the shader-produced outputs of every dispatch under tests/golden/wgsl_pin.npz, which
 tests/test_wgsl_pin.py replays against the oracle without the reference."""
@@ -20,10 +20,10 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import bevy_hikari_amd as hk
 from bevy_hikari_amd import _ffi as F
 from oracle_lib import oracle_plugin
