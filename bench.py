@@ -66,6 +66,12 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # Test hooks (tests/test_bench_ranks.py): HIKARI_BENCH_BACKEND=gloo + HIKARI_BENCH_DEVICE=0 run every rank on ONE GPU with
+    # halos staged through host memory, to exercise the multi-rank code path where a node has a single GPU (RCCL refuses
+    # two ranks on one device).  The driver never sets them: N ranks = N GPUs over RCCL.
+    backend = os.environ.get("HIKARI_BENCH_BACKEND", "nccl")
+    if "HIKARI_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["HIKARI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         torch.cuda.set_stream(torch.cuda.Stream())  # a real stream handle (the default stream's is 0)
@@ -73,7 +79,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import bevy_hikari_amd as hk
     from bevy_hikari_amd import _ffi as F
@@ -127,7 +136,7 @@ def main():
     barrier()
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = eng.stats()
@@ -153,7 +162,7 @@ def main():
     ind_ms_alone = xst.pass_ms_total[F.PASS_INDIRECT] / max(1, xst.pass_launches[F.PASS_INDIRECT])
     traced = np.array([cst.rays_tlas + cst.rays_blas], dtype=np.float64)
     if dist is not None:
-        t = torch.tensor(traced, dtype=torch.float64, device="cuda")
+        t = torch.tensor(traced, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         traced = t.cpu().numpy()
     # primary rays: one per pixel per frame (apron rows ray-cast redundantly by neighbouring bands are not counted)
