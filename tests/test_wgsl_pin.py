@@ -187,3 +187,21 @@ def test_translator_block_scoping():
     """
     assert [float(x) for x in run(src, "f", True)] == [1.0, 12.0, 0.0]
     assert [float(x) for x in run(src, "f", False)] == [1.0, 10.0, 0.0]
+
+
+@needs_reference
+def test_the_reference_has_no_bounds_guard():
+    """Documents the deviation of DESIGN section 6: the reference rounds its dispatch up to multiples of 8 and no entry point checks
+    invocation_id.  At a render width of 27 (40 / 1.5) the invocations x = 27..31 of row y read a zero G-buffer texel, take the
+    "background" branch and store reservoirs at x + 27 * y - the first five pixels of row y + 1.  Executing the reference's
+    shaders with their full grid shows exactly that and nothing else; the oracle and the kernels run the guarded grid."""
+    results = wgsl_pin.run_case("yard_textured_aa", (40, 28), 1, unguarded=True)
+    light = [r for r in results if r["entry"] in ("direct_lit", "indirect_lit_ambient", "spatial_reuse")]
+    assert light and all(r["mismatch"] for r in light[:2])                 # the sun and emissive dispatches clobber
+    import re
+    for r in light:
+        for desc in r["mismatch"].values():
+            m = re.search(r"first #\d+ \(x=(\d+), y=(\d+)\)", desc)
+            assert m and int(m.group(1)) < 32 - 27, desc                   # only slots the out-of-range invocations alias into
+    other = [r for r in results if r["entry"] not in ("direct_lit", "indirect_lit_ambient", "spatial_reuse")]
+    assert all(not r["mismatch"] for r in other)                           # texture-only passes: out-of-range stores are discarded

@@ -118,6 +118,7 @@ class Pinner:
     def __init__(self, plugin, scene, noise, log):
         self.p, self.e, self.scene, self.noise, self.log = plugin, plugin.engine, scene, noise, log
         self.results, self.recorded, self.dispatch_index = [], {}, 0
+        self.unguarded = False      # True: run the reference's full grid, invocations beyond the image included (it has no bounds guard)
         self.textures = [material_texture(im) for im in getattr(scene, "textures", [])]
         self.real_pass_run = self.e.pass_run
         self.e.pass_run = self.pass_run            # every dispatch of the node path goes through here
@@ -280,7 +281,7 @@ class Pinner:
         # The reference has no bounds guard (light.rs:651,686 round the grid up to 8): invocations beyond the image run, read a zero
         # G-buffer texel and store "background" reservoirs at coords.x + width * coords.y, i.e. into the first pixels of the NEXT row,
         # racing with their owners.  The oracle and the library guard instead; the pin runs the guarded grid.
-        m.dispatch(entry, gx, gy, limit=(w, h) if entry == "full_screen_albedo" else (rw, rh))
+        m.dispatch(entry, gx, gy, limit=None if self.unguarded else ((w, h) if entry == "full_screen_albedo" else (rw, rh)))
         seconds = time.time() - t0
         self.real_pass_run(pass_id)                 # now the oracle
         bad = {}
@@ -313,7 +314,7 @@ class Pinner:
 _contract_cache = {}
 
 
-def run_case(which, size=(24, 16), frames=2, log=None, patch=None):
+def run_case(which, size=(24, 16), frames=2, log=None, patch=None, unguarded=False):
     """Drive the oracle through `which` dispatch by dispatch, executing the reference's WGSL for each one on the state the oracle
     has before it.  Returns the list of per-dispatch records ({"pass", "entry", "defs", "mismatch": {buffer: description}, ...}).
     `patch(module)` may tamper with a translated module (negative controls)."""
@@ -347,7 +348,7 @@ def run_case(which, size=(24, 16), frames=2, log=None, patch=None):
         scene, cam_for, s, lights, antialias = CASES[which](size)
     p.set_scene(scene)
     pin = Pinner(p, scene, noise, log or (lambda rec: None))
-    pin.settings, pin.patch = s, patch
+    pin.settings, pin.patch, pin.unguarded = s, patch, unguarded
     real_frame_begin = p.engine.frame_begin
 
     def frame_begin(frame, view, pview, lgt):
