@@ -9,8 +9,8 @@
 // ICD).  The oracle is a line-by-line restatement of the reference WGSL; every function cites the reference file:line it
 // follows (paths relative to /root/reference).  tests/tools/wgsl_pin.py executes that WGSL itself (tests/tools/wgsl: a WGSL -> Python
 // translation, one f32 rounding per operation) dispatch by dispatch next to this file and finds no differing byte
-// (tests/test_wgsl_pin.py).  NOT covered by that pin and still "unpinned" in the strict sense: the
-// bevy_pbr functions below, the ray-cast G-buffer, the FSR1 passes.  Third-party arithmetic the
+// (tests/test_wgsl_pin.py); the FSR1 passes likewise from the GLSL in src/shaders/fsr/source.zip.  NOT
+// covered by that pin and still "unpinned" in the strict sense: the bevy_pbr functions below and the ray-cast G-buffer.  Third-party arithmetic the
 // path imports but the checkout does not vendor (bevy_pbr 0.9.1 `lighting`/`utils` WGSL modules,
 // bevy_core_pipeline 0.9.1 `tonemapping`) is restated from the published bevy 0.9.1 sources in
 // the section "bevy_pbr 0.9.1" below and kept in one place so it can be corrected.

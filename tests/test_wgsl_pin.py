@@ -90,10 +90,12 @@ def test_wgsl_memory_layout_matches_the_c_abi():
 
 
 @needs_reference
-@pytest.mark.parametrize("case,size,frames,dispatches", [("cornell_b2", (16, 12), 2, 44), ("cornell_default_aa", (24, 16), 2, 48)])
+@pytest.mark.parametrize("case,size,frames,dispatches", [("cornell_b2", (16, 12), 2, 44), ("cornell_default_aa", (24, 16), 2, 48), ("cornell_fsr", (30, 20), 1, 24)])
 def test_reference_shaders_reproduce_the_oracle(case, size, frames, dispatches):
     """cornell_b2: MULTIPLE_BOUNCES pipeline, both spatial passes, denoise x3 channels x4 levels, tone mapping.
-    cornell_default_aa: HikariSettings::default() - single-bounce pipeline, ratio 2, SMAA Tu4x + extrapolation + TAA."""
+    cornell_default_aa: HikariSettings::default() - single-bounce pipeline, ratio 2, SMAA Tu4x + extrapolation + TAA.
+    cornell_fsr: Upscale::Fsr1 - TAA at the scaled size, then FSR 1.0 EASU + RCAS executed from the GLSL the reference ships in
+    src/shaders/fsr/source.zip (tests/tools/glsl.py: cpp + a GLSL -> Python translation)."""
     results = wgsl_pin.run_case(case, size, frames)
     assert len(results) == dispatches
     assert [r for r in results if r["mismatch"]] == []
@@ -116,7 +118,8 @@ def test_the_pin_notices_a_changed_constant():
 
 
 # ---------------------------------------------------------------- replay of committed shader-produced fixtures (no reference needed)
-FIXTURES = {"cornell_b2": ((16, 12), 2), "cornell_default_aa": ((24, 16), 3), "yard_textured_aa": ((30, 22), 3), "yard_moving_camera": ((30, 22), 3)}
+FIXTURES = {"cornell_b2": ((16, 12), 2), "cornell_default_aa": ((24, 16), 3), "yard_textured_aa": ((30, 22), 3), "yard_moving_camera": ((30, 22), 3),
+            "cornell_fsr": ((36, 24), 2)}
 
 
 def replay(plugin, case):
@@ -147,7 +150,7 @@ def replay(plugin, case):
     e.pass_run = hooked
     for n in range(1, frames + 1):
         plugin.render(cam_for(n), s, lights=lights, frame_number=n, by_nodes=True, antialias=antialias)
-    assert index[0] >= max(by_dispatch)     # (dispatches the reference ships only as SPIR-V - FSR1 - have no record)
+    assert index[0] >= max(by_dispatch)
     return bad
 
 
@@ -205,3 +208,25 @@ def test_the_reference_has_no_bounds_guard():
             assert m and int(m.group(1)) < 32 - 27, desc                   # only slots the out-of-range invocations alias into
     other = [r for r in results if r["entry"] not in ("direct_lit", "indirect_lit_ambient", "spatial_reuse")]
     assert all(not r["mismatch"] for r in other)                           # texture-only passes: out-of-range stores are discarded
+
+
+def test_glsl_translator_out_parameters_ternary_and_chained_assignment():
+    import glsl
+
+    src = """
+    void split(float x, out float lo, inout float acc){ lo = x < 0.5 ? x : 0.5; acc += x; }
+    float f(float a){
+        float lo, acc = 1.0;
+        uvec4 c;
+        c[2] = c[3] = 7u;
+        split(a, lo, acc);
+        split(a * 2.0, lo, acc);
+        for(int i = 0; i < 3; i++){ if(i == 1) continue; acc += 1.0; }
+        return lo + acc + float(c.z + c.w) + uintBitsToFloat(floatBitsToUint(0.25));
+    }
+    """
+    tr = glsl.Translator(src)
+    ns = {"_R": R, "_T": T, "_G": glsl.G, "_ONCE": (0,)}
+    exec(tr.module(), ns)
+    assert tr.skipped == []
+    assert float(ns["f"](np.float32(0.2))) == pytest.approx(0.4 + (1.0 + 0.2 + 0.4 + 2.0) + 14.0 + 0.25)

@@ -110,6 +110,20 @@ def module(filename, defs):
     return _modules[key]
 
 
+_fsr_dir = None
+
+
+def fsr_source_dir():
+    """the GLSL of FSR 1.0 as shipped inside the reference (a zip next to the SPIR-V blobs), unpacked to a temporary directory"""
+    global _fsr_dir
+    if _fsr_dir is None:
+        import tempfile
+        import zipfile
+        _fsr_dir = tempfile.mkdtemp(prefix="hk_fsr_src_")
+        zipfile.ZipFile(os.path.join(SHADERS, "fsr", "source.zip")).extractall(_fsr_dir)
+    return _fsr_dir
+
+
 def reference_available():
     return os.path.isdir(SHADERS)
 
@@ -144,6 +158,8 @@ class Pinner:
             self.tone_mapping_pass(arg)
         elif pass_id in (F.PASS_SMAA_TU4X, F.PASS_SMAA_TU4X_EXTRAPOLATE, F.PASS_TAA_JASMINE):
             self.antialias_pass(pass_id)
+        elif pass_id in (F.PASS_FSR_EASU, F.PASS_FSR_RCAS):
+            self.fsr_pass(pass_id)
         else:
             self.real_pass_run(pass_id, arg, row_begin, row_end)
 
@@ -214,6 +230,37 @@ class Pinner:
         t0 = time.time()
         m.dispatch(entry, gx, gy)
         rec = {"frame": int(self.frame.number), "pass": F.PASS_NAMES[pass_id], "entry": entry, "defs": [], "seconds": round(time.time() - t0, 1)}
+        self.real_pass_run(pass_id)
+        self.compare(rec, {F.PASS_NAMES[pass_id] + "_output": (out, out_b, "rgba16f")})
+
+    def fsr_pass(self, pass_id):
+        # FidelityFX FSR 1.0 as the reference ships it: src/shaders/fsr/source.zip (FSR_Pass.glsl + ffx_a.h + ffx_fsr1.h, the source
+        # of fsr_pass_{easu,rcas}.spv), preprocessed with cpp and executed through tests/tools/glsl.py.  Bindings and constants:
+        # post_process.rs:503-534 (input viewport = input size = scaled size, output = window, hdr 0), 1037-1071, 1277-1308.
+        import glsl
+        e = self.e
+        easu = pass_id == F.PASS_FSR_EASU
+        key = ("fsr", easu)
+        if key not in _modules:
+            _modules[key] = glsl.Module(fsr_source_dir(), "FSR_Pass.glsl", {"SAMPLE_EASU": int(easu), "SAMPLE_RCAS": int(not easu), "SAMPLE_BILINEAR": 0})
+        m = _modules[key]
+        in_b = (F.BUF_TAA_OUTPUT if self.settings.taa == hk.Taa.Jasmine else F.BUF_TONE_MAPPED) if easu else F.BUF_UPSCALE_OUTPUT
+        out_b = F.BUF_UPSCALE_OUTPUT if easu else F.BUF_UPSCALE_SHARPENED
+        src, out = tex_from(e, in_b, "rgba16f"), tex_from(e, out_b, "rgba16f")
+        iw, ih = e.buffer_info(F.BUF_TONE_MAPPED)[:2]
+        ow, oh = e.buffer_info(out_b)[:2]
+        m.ns.update(InputTexture=src, InputSampler=T.Sampler(True, "clamp"), OutputTexture=out, input_viewport_in_pixels=T.vec2f32(iw, ih),
+                    input_size_in_pixels=T.vec2f32(iw, ih), output_size_in_pixels=T.vec2f32(ow, oh), sharpness=f32(self.settings.upscale.sharpness()),
+                    hdr=R.u32(0))
+        t0 = time.time()
+        for gy in range((oh + 15) // 16):          # one workgroup of 64 invocations covers 16x16 output pixels (FSR_Pass.glsl main)
+            for gx in range((ow + 15) // 16):
+                m.ns["gl_WorkGroupID"] = T.vec3u32(gx, gy, 0)
+                for lid in range(64):
+                    m.ns["gl_LocalInvocationID"] = T.vec3u32(lid, 0, 0)
+                    m.ns["main"]()
+        rec = {"frame": int(self.frame.number), "pass": F.PASS_NAMES[pass_id], "entry": "FSR_Pass.glsl main (%s)" % ("EASU" if easu else "RCAS"), "defs": [],
+               "seconds": round(time.time() - t0, 1)}
         self.real_pass_run(pass_id)
         self.compare(rec, {F.PASS_NAMES[pass_id] + "_output": (out, out_b, "rgba16f")})
 
@@ -391,6 +438,9 @@ def _yard(size, textured, fsr, motion):
 
 
 CASES = {
+    # Upscale::Fsr1 end to end on Cornell: TAA at the scaled size, then the reference's GLSL EASU + RCAS to the window
+    "cornell_fsr": lambda size: (hk.load_cornell(), (lambda n, c=hk.cornell_camera(*size): c), hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.5, 0.2)),
+                                 hk.lights_uniform(), True),
     # sun + two emitters + light BVH / alias tables, the TEXTURED pipelines (base colour, metallic, occlusion, emissive textures),
     # ratio 1.5, validation frames every 2 / 3 frames, SMAA Tu4x + TAA
     "yard_textured_aa": lambda size: _yard(size, True, False, False),
