@@ -230,3 +230,84 @@ def test_glsl_translator_out_parameters_ternary_and_chained_assignment():
     exec(tr.module(), ns)
     assert tr.skipped == []
     assert float(ns["f"](np.float32(0.2))) == pytest.approx(0.4 + (1.0 + 0.2 + 0.4 + 2.0) + 14.0 + 0.25)
+
+
+@needs_reference
+def test_prepass_fragment_formulas_match_the_ray_cast_gbuffer():
+    """prepass.wgsl is a raster pipeline and the library ray-casts its G-buffer, so the two cannot be compared invocation by
+    invocation - but the FORMULAS of the reference's fragment() can: fed with the world position the oracle stored for a pixel, the
+    reference's own code must produce the oracle's velocity (un-jittered reprojection with view / previous_view), its id encoding
+    (index + 0.5) and pass position / uv through.  Moving camera, so the velocity is not trivially zero."""
+    import bevy_hikari_amd as hk
+    from bevy_hikari_amd import _ffi as F
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_scene
+    from oracle_lib import oracle_plugin
+    from wgsl.engine import Module
+
+    scene, sun = synthetic_scene(n_boxes=8, n_spheres=3, n_emitters=2, sphere_rings=5, sphere_segs=6)
+    p = oracle_plugin()
+    p.set_scene(scene)
+    s = hk.HikariSettings(indirect_bounces=0, denoise=False, upscale=hk.Upscale.SMAA_TU_1_0)
+    cams = [hk.Camera(hk.look_at_transform((6.4 + 0.3 * n, 4.4, 8.0 - 0.2 * n), (0.0, 0.6, 0.0)), 40, 28) for n in (1, 2)]
+    for n, cam in enumerate(cams, start=1):
+        p.render(cam, s, lights=hk.lights_uniform(directional=sun), frame_number=n)
+    e = p.engine
+    position, velocity_uv, ids = e.read(F.BUF_POSITION), e.read(F.BUF_VELOCITY_UV), e.read(F.BUF_INSTANCE_MATERIAL)
+    m = Module(wgsl_pin.SHADERS, "prepass.wgsl", ("TEMPORAL_ANTI_ALIASING", "SMAA_TU4X"))
+    view, pview = cams[1].view_uniform(), cams[1].previous_view_uniform(cams[0])
+    m.bind(view=wgsl_pin.as_bytes(view), previous_view=wgsl_pin.as_bytes(pview))
+    fragment, VertexOutput, InstanceIndex = m.ns["fragment"], m.ns["S_VertexOutput"].TYPE, m.ns["S_InstanceIndex"].TYPE
+    checked = 0
+    for y in range(28):
+        for x in range(40):
+            if position[y, x, 3] < 1.19e-7:
+                continue
+            inp = VertexOutput.zero()
+            inp.world_position = T.vec4f32(*position[y, x, :3], 1.0)
+            inp.previous_world_position = inp.world_position          # static objects (prepass.wgsl:50 with previous_mesh.model == mesh.model)
+            inp.uv = T.vec2f32(*velocity_uv[y, x, 2:])
+            inp.clip_position = T.vec4f32(x + 0.5, y + 0.5, position[y, x, 3], 1.0)      # fragment-stage @builtin(position): (window xy, depth, 1/w)
+            idx = InstanceIndex.zero()
+            idx.instance, idx.material = R.u32(int(ids[y, x, 0])), R.u32(int(ids[y, x, 1]))
+            m.ns["instance_index"] = idx
+            out = fragment(inp)
+            assert [np.float32(v) for v in out.velocity_uv] == list(velocity_uv[y, x]), (x, y)
+            assert [np.float32(v) for v in out.position] == list(position[y, x]), (x, y)
+            assert [np.float32(v) for v in out.instance_material] == list(ids[y, x]), (x, y)
+            checked += 1
+    assert checked > 300 and np.abs(velocity_uv[..., :2]).max() > 1e-3
+
+
+@needs_reference
+@pytest.mark.parametrize("smaa", [True, False])
+def test_prepass_jitter_sequence_and_sign_match_the_reference(smaa):
+    """The vertex stage shifts clip positions by 2 * frame_jitter() * texel_size * (1, -1) (prepass.wgsl:30-38,53-71).  The oracle
+    shifts its primary rays instead; so the world point it stores for pixel (x, y), projected with the un-jittered view_proj and
+    shifted by the REFERENCE's frame_jitter() for that frame, must land on the pixel centre - for the Halton index rule of both
+    upscale kinds (frame >> 1 with SMAA Tu4x, frame otherwise)."""
+    import bevy_hikari_amd as hk
+    from bevy_hikari_amd import _ffi as F
+    from oracle_lib import oracle_plugin
+    from wgsl.engine import Module
+
+    W, H = 48, 32
+    p = oracle_plugin()
+    p.set_scene(hk.load_cornell())
+    s = hk.HikariSettings(indirect_bounces=0, denoise=False, upscale=hk.Upscale.SmaaTu4x(1.0) if smaa else hk.Upscale.Fsr1(1.0, 0.0))
+    cam = hk.cornell_camera(W, H)
+    m = Module(wgsl_pin.SHADERS, "prepass.wgsl", ("TEMPORAL_ANTI_ALIASING",) + (("SMAA_TU4X",) if smaa else ()))
+    vp = np.ctypeslib.as_array(cam.view_uniform().view_proj).reshape(4, 4).T.astype(np.float64)      # column-major -> math layout
+    seen = set()
+    for n in (1, 2, 3, 4, 7, 18, 33):
+        p.render(cam, s, frame_number=n)
+        m.bind(frame=wgsl_pin.as_bytes(hk.frame_uniform(s, n)))
+        jitter = np.array([float(v) for v in m.ns["frame_jitter"]()], dtype=np.float64)
+        seen.add(tuple(jitter))
+        pos = p.engine.read(F.BUF_POSITION).astype(np.float64)
+        ys, xs = np.nonzero(pos[..., 3] > 1.19e-7)
+        clip = np.concatenate([pos[ys, xs, :3], np.ones((len(ys), 1))], axis=1) @ vp.T
+        ndc = clip[:, :2] / clip[:, 3:4] + 2.0 * jitter * np.array([1.0 / W, 1.0 / H]) * np.array([1.0, -1.0])
+        centre = np.stack([(xs + 0.5) / W * 2.0 - 1.0, 1.0 - (ys + 0.5) / H * 2.0], axis=1)
+        err_px = np.abs(ndc - centre) * np.array([W, H]) / 2.0
+        assert err_px.max() < 2e-3, (n, err_px.max())          # f32 ray / projection arithmetic, far below the jitter itself
+    assert len(seen) >= 4

@@ -14,7 +14,7 @@ BUILTINS = {
     "pack4x8snorm": "_R.pack4x8snorm", "unpack4x8snorm": "_R.unpack4x8snorm", "pack4x8unorm": "_R.pack4x8unorm", "unpack4x8unorm": "_R.unpack4x8unorm",
     "textureLoad": "_T.texture_load", "textureStore": "_T.texture_store", "textureDimensions": "_T.texture_dimensions",
     "textureSampleLevel": "_T.texture_sample_level", "textureGather": "_T.texture_gather", "textureNumLevels": "_T.texture_num_levels",
-    "arrayLength": "_T.array_length",
+    "arrayLength": "_T.array_length", "dpdx": "_T.dpdx", "dpdy": "_T.dpdy",
 }
 SCALARS = {"f32", "i32", "u32", "bool"}
 PYKEYWORDS = {"lambda", "from", "in", "is", "not", "and", "or", "def", "class", "pass", "global", "del", "with", "as", "import", "yield", "None", "True", "False",

@@ -271,3 +271,15 @@ def texture_gather(component, tex, sampler, uv):
 
 def array_length(a):
     return u32(len(a))
+
+
+# derivative builtins of fragment shaders: the harness that runs a fragment function sets these (default: flat)
+DERIVATIVES = {"dpdx": lambda v: R.F0 * v, "dpdy": lambda v: R.F0 * v}
+
+
+def dpdx(v):
+    return DERIVATIVES["dpdx"](v)
+
+
+def dpdy(v):
+    return DERIVATIVES["dpdy"](v)
