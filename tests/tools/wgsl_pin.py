@@ -437,7 +437,15 @@ def _yard(size, textured, fsr, motion):
     return scene, (lambda n: hk.Camera(hk.look_at_transform((6.4 + 0.15 * n, 4.4, 8.0 - 0.1 * n), (0.0, 0.6, 0.0)), *size)), s, hk.lights_uniform(directional=sun), True
 
 
+def _helmet(size):
+    from bevy_hikari_amd.scenes import flight_helmet_scene
+    scene, sun, camera = flight_helmet_scene()
+    return scene, (lambda n, c=camera(*size): c), hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0), hk.lights_uniform(directional=sun), False
+
+
 CASES = {
+    # the reference's textured glTF asset (assets/models/FlightHelmet): 94 722 triangles, 10 real textures, deep BLASes
+    "flight_helmet": _helmet,
     # Upscale::Fsr1 end to end on Cornell: TAA at the scaled size, then the reference's GLSL EASU + RCAS to the window
     "cornell_fsr": lambda size: (hk.load_cornell(), (lambda n, c=hk.cornell_camera(*size): c), hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.5, 0.2)),
                                  hk.lights_uniform(), True),
