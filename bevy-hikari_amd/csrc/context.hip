@@ -1091,8 +1091,20 @@ int hk_upload_noise(hk_ctx* c, const uint8_t* rgba, size_t bytes) {
   return HK_OK;
 }
 
+static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio);
+
 int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
-  HK_REQUIRE(c && width && height, HK_E_INVALID, "bad size");
+  // pixel indices are 32-bit signed in the kernels (x + width * y); 16384^2 leaves room for the 2x SMAA Tu4x output as well
+  HK_REQUIRE(c && width && height && width <= 16384u && height <= 16384u, HK_E_INVALID, "bad size %u x %u (1..16384)", width, height);
+  const int rc = resize_resources(c, width, height, upscale_ratio);
+  if (rc) {  // e.g. out of device memory half way: leave the context without screen resources rather than with some of them
+    free_screen(c);
+    c->W = c->H = c->RW = c->RH = c->UW = c->UH = 0;
+  }
+  return rc;
+}
+
+static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
   HK_HIP(hipSetDevice(c->device));
   HK_HIP(hipStreamSynchronize(c->stream));
   free_screen(c);

@@ -161,6 +161,13 @@ def test_error_paths():
         ctx = C.c_void_p()
         eng.api.call("create", 99, 0, C.byref(ctx))
     assert e.value.code == F.HK_E_NO_DEVICE
+    # sizes beyond the 32-bit pixel index are refused, and a refused resize leaves no half-allocated screen behind
+    with pytest.raises(hk.HikariError) as e:
+        eng.resize(20000, 16, 1.0)
+    assert e.value.code == F.HK_E_INVALID
+    assert eng.buffer_info(F.BUF_TONE_MAPPED)[:2] == (64, 64)          # the earlier resources are untouched by a rejected call
+    eng.resize(48, 32, 1.5)
+    assert eng.buffer_info(F.BUF_TONE_MAPPED)[:2] == (32, 22)
 
 
 def test_band_renderer_single_gpu_views():
