@@ -532,6 +532,16 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o) {
   return HK_OK;
 }
 
+int join_side(hk_ctx* c);
+// wait for everything the context has enqueued, on BOTH streams (the direct-light dispatches of a frame may still be
+// running on the side stream when a host uploads, resizes or reads statistics between two stages)
+int sync_all(hk_ctx* c) {
+  const int rc = join_side(c);
+  if (rc) return rc;
+  HK_HIP(hipStreamSynchronize(c->stream));
+  return HK_OK;
+}
+
 int finalize_scene(hk_ctx* c) {
   if (!c->mesh_dirty && !c->dynamic_dirty && !c->textures_dirty) return HK_OK;
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
@@ -549,7 +559,7 @@ int finalize_scene(hk_ctx* c) {
   if (c->textures_dirty) {
     std::vector<uint32_t> tex_data;
     for (const hk_ctx::HostTexture& t : c->textures) tex_data.insert(tex_data.end(), t.texels.begin(), t.texels.end());
-    HK_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = sync_all(c))) return rc;
     if ((rc = c->d_tex_data.upload(tex_data))) return rc;
     c->textures_dirty = false;
   }
@@ -557,7 +567,7 @@ int finalize_scene(hk_ctx* c) {
   DynOffsets o{};
   if ((rc = build_dynamic_region(c, dyn, o))) return rc;
   const bool in_place = !need_static && dyn.bytes.size() <= c->dyn_capacity;
-  if (!(in_place && c->two_slots)) HK_HIP(hipStreamSynchronize(c->stream));  // frames in flight still read the arrays rewritten below
+  if (!(in_place && c->two_slots) && (rc = sync_all(c))) return rc;  // frames in flight still read the arrays rewritten below
   if (need_static) {
     Blob st;
     if ((rc = build_static_region(c, st, c->st_nodes, c->st_v0, c->st_v1, c->st_v2, c->st_vn, c->st_vuv))) return rc;
@@ -1106,7 +1116,7 @@ int hk_resize(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
 
 static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float upscale_ratio) {
   HK_HIP(hipSetDevice(c->device));
-  HK_HIP(hipStreamSynchronize(c->stream));
+  { const int rc_ = sync_all(c); if (rc_) return rc_; }
   free_screen(c);
   uint32_t rw, rh;
   int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
@@ -1213,6 +1223,12 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
   if (rc) return rc;
   HK_REQUIRE(st, HK_E_INVALID, "settings is NULL");
   HK_REQUIRE(c->band_count <= (uint32_t)c->RH, HK_E_INVALID, "more bands than rows");
+  HK_REQUIRE(st->taa <= HK_TAA_NONE && st->upscale_kind <= HK_UPSCALE_SMAA_TU4X, HK_E_INVALID, "bad taa / upscale_kind in settings");
+  // HkSettings and the HkFrame of hk_frame_begin describe the same HikariSettings (view.rs:141-193): the fields both carry must agree
+  HK_REQUIRE(st->indirect_bounces == c->frame.indirect_bounces && (st->temporal_reuse != 0u) == (c->frame.temporal_reuse != 0u) &&
+                 (st->emissive_spatial_reuse != 0u) == (c->frame.emissive_spatial_reuse != 0u) &&
+                 (st->indirect_spatial_reuse != 0u) == (c->frame.indirect_spatial_reuse != 0u),
+             HK_E_INVALID, "HkSettings disagrees with the HkFrame given to hk_frame_begin (indirect_bounces / reuse flags)");
   c->taa = st->taa;
   c->upscale_kind = st->upscale_kind;
   c->upscale_sharpness = st->upscale_sharpness;
@@ -1430,7 +1446,7 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
 int hk_reset_stats(hk_ctx* c) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   HK_HIP(hipSetDevice(c->device));
-  HK_HIP(hipStreamSynchronize(c->stream));
+  { const int rc_ = sync_all(c); if (rc_) return rc_; }
   drain_timers(c);
   HK_HIP(hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)));
   c->frames = 0;

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "hk_internal.hpp"
 
@@ -132,9 +133,11 @@ int hk_frame_from_settings(const HkSettings* s, uint32_t frame_number, HkFrame* 
 
 int hk_scaled_size(uint32_t width, uint32_t height, float upscale_ratio, uint32_t* sw, uint32_t* sh) {  // light.rs:318-319
   HK_REQUIRE(sw && sh && width && height, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(std::isfinite(upscale_ratio), HK_E_INVALID, "upscale ratio is not finite");  // clamp_ratio(NaN) is NaN
   float scale = 1.0f / clamp_ratio(upscale_ratio);
   *sw = (uint32_t)ceilf(scale * (float)width);
   *sh = (uint32_t)ceilf(scale * (float)height);
+  HK_REQUIRE(*sw >= 1u && *sh >= 1u, HK_E_INVALID, "scaled size is empty");
   return HK_OK;
 }
 
