@@ -294,6 +294,68 @@ def test_sponza_class_vs_oracle():
     assert np.isfinite(out).all() and out[..., :3].max() > 0.05
 
 
+def test_config3_full_1080p_vs_oracle():
+    """BASELINE config 3 stand-in at the FULL 1920x1080 (3 bounces, denoise, sun + 8 emitters): every buffer of two frames bit for
+    bit against the oracle - the global-memory (non-LDS) traversal path at the size the config is quoted on."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large()
+    s = hk.HikariSettings(indirect_bounces=3, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = synthetic_camera(1920, 1080, extent=9.0)
+    lights = hk.lights_uniform(directional=sun)
+    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    for n in (1, 2):
+        for p in (gpu, cpu):
+            p.render(cam, s, lights=lights, frame_number=n)
+        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        assert bad == {}, (n, bad)
+    sg, sc = gpu.engine.stats(), cpu.engine.stats()
+    assert (sg.rays_tlas, sg.rays_blas) == (sc.rays_tlas, sc.rays_blas) and sg.rays_tlas > 1920 * 1080 * 2
+
+
+def test_config4_city_class_vs_oracle():
+    """BASELINE config 4 stand-in (1.5 M unique triangles, 2002 instances, sun 10 000 lux, 2 bounces) compared with the ORACLE:
+    640x360, every buffer of two frames bit for bit (the 4K run of the same scene below checks size-independent properties)."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+    sun = dict(sun, illuminance=10000.0)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = synthetic_camera(640, 360, extent=30.0)
+    lights = hk.lights_uniform(directional=sun)
+    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    for n in (1, 2):
+        for p in (gpu, cpu):
+            p.render(cam, s, lights=lights, frame_number=n)
+        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        assert bad == {}, (n, bad)
+    sg, sc = gpu.engine.stats(), cpu.engine.stats()
+    assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)
+    out = gpu.output(s)
+    assert np.isfinite(out).all() and out[..., :3].max() > 0.05
+
+
+def test_config5_full_4k_8_bounces_vs_oracle():
+    """BASELINE config 5 at its FULL size (Cornell 3840x2160, 8 bounces, emissive + indirect spatial reuse, denoise off): two
+    frames, every buffer bit for bit against the oracle."""
+    s = hk.HikariSettings(indirect_bounces=8, emissive_spatial_reuse=True, denoise=False, upscale=hk.Upscale.SMAA_TU_1_0)
+    scene, cam = hk.load_cornell(), hk.cornell_camera(3840, 2160)
+    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    for n in (1, 2):
+        for p in (gpu, cpu):
+            p.render(cam, s, frame_number=n)
+    bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+    assert bad == {}, bad
+    sg, sc = gpu.engine.stats(), cpu.engine.stats()
+    assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)
+
+
 def test_city_class_4k_properties():
     """BASELINE config 4 stand-in at its full size on one GPU (seeded synthetic, ~1.5 M unique
     triangles, 2002 instances, 3840x2160, 2 bounces): determinism, dispatch row-range independence
@@ -698,12 +760,16 @@ def test_motion_is_bit_exact_once_the_race_is_resolved_like_the_oracle(seed):
 
 
 def test_racing_default_stays_close_under_motion():
-    """Without the flag the stores race as in the reference: the G-buffer is still exact and the image stays within a
-    few 1e-3 of the oracle's (the oracle's pick of the race is as arbitrary as the GPU's)."""
+    """Without the flag the stores race as in the reference: the G-buffer is still exact, and the image is held to the north
+    star's 1e-3 relative L2 - as a FRACTION of sequences, because the oracle's pick of each race (highest thread index) is as
+    arbitrary as the GPU's (arrival order) and an unlucky pick moves a 48..160-pixel image by more than that.  Measured over 300
+    sequences in round 1: 7 % above 1e-3, none above 1.5e-2; with HK_CTX_DETERMINISTIC_SCATTER (test above) every byte agrees.
+    The measured fraction is printed and written to gpurun_out/racing_report.json when that directory exists."""
     from cases import motion_case, run_motion_case
 
     rels = []
-    for seed in range(12):
+    n_seeds = 40
+    for seed in range(n_seeds):
         case = motion_case(seed)
         gpu, cpu = hk.HikariPlugin(device=0), oracle()
 
@@ -714,4 +780,14 @@ def test_racing_default_stays_close_under_motion():
         run_motion_case((gpu, cpu), case, check)
         a, b = gpu.output(case["settings"]), cpu.output(case["settings"])
         rels.append(float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-20)))
-    assert np.median(rels) <= 1e-3 and max(rels) <= 5e-2, rels
+    above = [r for r in rels if r > 1e-3]
+    report = {"sequences": n_seeds, "fraction_above_1e-3": len(above) / n_seeds, "median": float(np.median(rels)), "max": max(rels),
+              "above": sorted(above)}
+    print("racing default vs oracle:", report)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        with open(os.path.join(out_dir, "racing_report.json"), "w") as f:
+            json.dump(report, f, indent=1)
+    assert np.median(rels) <= 1e-3 and len(above) <= 0.2 * n_seeds and max(rels) <= 5e-2, report
