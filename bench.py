@@ -2,17 +2,25 @@
 """Headline benchmark: Mray/s + frame ms on Cornell 1920x1080, 2 indirect bounces, ReSTIR
 (temporal + indirect spatial) on, denoise on, upscale ratio 1.0 (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}] [--blocks B]
 
 One "step" is one frame of the hot path (prepass rays -> light passes -> ReSTIR -> denoise) over
 synthetic input that is resident in HBM before the timed region.  N > 1 is launched by
-torch.distributed.run, one rank per GPU; the frame is sharded into N horizontal bands with two
-RCCL halo exchanges per frame (bevy-hikari_amd/distributed.py).  Rank 0 prints ONE JSON line.
+torch.distributed.run, one rank per GPU; the frame is sharded into N horizontal bands with the halo
+exchanges running INSIDE the library over RCCL (hk_comm_*; include/hikari_hip.h).  Rank 0 prints ONE JSON line.
+
+Timing: W warm-up frames, then B (default 5) timed blocks of EXACTLY K frames each, every block bracketed by
+barrier + device synchronisation on both sides, MAX over ranks per block.  `value` / `ms_per_step` are the
+MEDIAN block; `blocks_ms_per_step` lists all of them, `min_ms_per_step` the fastest.
 
 Ray accounting: rays = primary rays (one per pixel) + traverse_top invocations + stand-alone
 traverse_bottom invocations.  They are counted by replaying the same frames on a second
 context created with HK_CTX_COUNT_RAYS (the path is deterministic, so the replay traces exactly the
 rays of the timed run) - the timed region itself carries no counters.
+
+--config selects the other BASELINE.json configs on ONE GPU (3: Sponza-class stand-in 1080p 3 bounces;
+4: city-class stand-in 4K 2 bounces; 5: Cornell 4K 8 bounces, both spatial passes, denoise off).  The
+default (2) is the configuration the metric is quoted on.
 """
 import argparse
 import json
@@ -41,18 +49,54 @@ def cgroup_cpus():
     return n
 
 
+def workload(hk, config, width, height, bounces):
+    """(scene, camera, settings, lights, description, default steps) of a BASELINE.json config."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    U = hk.Upscale.SMAA_TU_1_0
+    if config == 2:
+        W, H = width or 1920, height or 1080
+        b = 2 if bounces is None else bounces
+        return (hk.load_cornell(), hk.cornell_camera(W, H), hk.HikariSettings(indirect_bounces=b, upscale=U), hk.lights_uniform(),
+                f"Cornell box {W}x{H}, {b} indirect bounces, ReSTIR temporal + indirect spatial reuse on, denoise on, upscale ratio 1.0, static camera")
+    if config == 3:
+        W, H = width or 1920, height or 1080
+        b = 3 if bounces is None else bounces
+        scene, sun = synthetic_large()
+        return (scene, synthetic_camera(W, H, extent=9.0), hk.HikariSettings(indirect_bounces=b, upscale=U), hk.lights_uniform(directional=sun),
+                f"config 3 stand-in: seeded Sponza-class scene (256 k unique triangles, 409 instances, 50 materials, 8 emitters, sun 100 000 lux) {W}x{H}, {b} bounces, denoise on")
+    if config == 4:
+        W, H = width or 3840, height or 2160
+        b = 2 if bounces is None else bounces
+        scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+        return (scene, synthetic_camera(W, H, extent=30.0), hk.HikariSettings(indirect_bounces=b, upscale=U),
+                hk.lights_uniform(directional=dict(sun, illuminance=10000.0)),
+                f"config 4 stand-in: seeded city-class scene (1.5 M unique triangles, 2002 instances, 1 emitter, sun 10 000 lux) {W}x{H}, {b} bounces, denoise on")
+    if config == 5:
+        W, H = width or 3840, height or 2160
+        b = 8 if bounces is None else bounces
+        return (hk.load_cornell(), hk.cornell_camera(W, H), hk.HikariSettings(indirect_bounces=b, emissive_spatial_reuse=True, denoise=False, upscale=U),
+                hk.lights_uniform(), f"config 5: Cornell box {W}x{H}, {b} bounces, emissive + indirect spatial reuse on, denoise off")
+    raise SystemExit(f"unknown --config {config}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=None, help="frames per timed block (default 48; 12 for --config 3/4/5)")
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--bounces", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps frames each; the median is reported")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--passes", action="store_true", help="also report a per-pass time breakdown (extra untimed frames)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 48 if args.config == 2 else 12
 
     import numpy as np
     import torch
@@ -66,34 +110,30 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    # Test hooks (tests/test_bench_ranks.py): HIKARI_BENCH_BACKEND=gloo + HIKARI_BENCH_DEVICE=0 run every rank on ONE GPU with
-    # halos staged through host memory, to exercise the multi-rank code path where a node has a single GPU (RCCL refuses
-    # two ranks on one device).  The driver never sets them: N ranks = N GPUs over RCCL.
-    backend = os.environ.get("HIKARI_BENCH_BACKEND", "nccl")
+    # Test hooks (tests/test_bench_ranks.py): HIKARI_BENCH_TRANSPORT=host + HIKARI_BENCH_DEVICE=0 run every rank on ONE GPU with
+    # halos staged through host memory over gloo, to exercise the multi-rank code path where a node has a single GPU (RCCL
+    # refuses two ranks on one device).  The driver never sets them: N ranks = N GPUs, halos over RCCL inside the library.
+    transport = os.environ.get("HIKARI_BENCH_TRANSPORT", "rccl")
     if "HIKARI_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["HIKARI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        torch.cuda.set_stream(torch.cuda.Stream())  # a real stream handle (the default stream's is 0)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # the process group only carries the rendezvous (RCCL unique id), the barriers and the max-over-ranks of the timing;
+        # the data path - the halo rows - moves inside libhikari_hip.so over its own RCCL communicator
+        dist.init_process_group("gloo")
 
     import bevy_hikari_amd as hk
     from bevy_hikari_amd import _ffi as F
     from bevy_hikari_amd.distributed import BandRenderer
 
-    W, H = args.width, args.height
-    settings = hk.HikariSettings(indirect_bounces=args.bounces, upscale=hk.Upscale.SMAA_TU_1_0)  # others = defaults
+    scene, camera, settings, lights, description = workload(hk, args.config, args.width, args.height, args.bounces)
+    W, H = camera.width, camera.height
     sc = settings.to_c()
-    scene = hk.load_cornell()
-    camera = hk.cornell_camera(W, H)
-    view, pview, lights = camera.view_uniform(), camera.previous_view_uniform(), hk.lights_uniform()
+    view, pview = camera.view_uniform(), camera.previous_view_uniform()
+    transport_used = [None]
 
     def make_engine(flags):
         e = hk.Engine(device=local_rank, flags=flags)
@@ -102,10 +142,8 @@ def main():
         e.resize(W, H, 1.0)
         r = None
         if world > 1:
-            # run the library on the (non-default) torch stream RCCL orders itself against
-            e.set_stream(torch.cuda.current_stream().cuda_stream)
-            e.on_host_stream = torch.cuda.current_stream().cuda_stream != 0
-            r = BandRenderer(e, rank, world)
+            r = BandRenderer(e, rank, world, transport=transport)
+            transport_used[0] = r.transport
         return e, r
 
     def run_frames(e, r, first, last):
@@ -121,34 +159,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # ------------------------------------------------------------------ timed run
     eng, rend = make_engine(0)
     run_frames(eng, rend, 1, args.warmup)
     eng.wait()
     eng.reset_stats()
     eng.set_timing_mask(1 << F.PASS_INDIRECT)  # HIP events around the dominant kernel only
-    barrier()
-    t0 = time.perf_counter()
-    run_frames(eng, rend, args.warmup + 1, args.warmup + args.steps)
-    eng.wait()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    barrier()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    blocks = []
+    n0 = args.warmup
+    for _ in range(max(1, args.blocks)):
+        barrier()
+        t0 = time.perf_counter()
+        run_frames(eng, rend, n0 + 1, n0 + args.steps)
+        eng.wait()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        barrier()
+        blocks.append(max_over_ranks(t1 - t0))
+        n0 += args.steps
+    last_frame = n0
+    elapsed = float(np.median(blocks))
     st = eng.stats()
     ind_ms = st.pass_ms_total[F.PASS_INDIRECT] / max(1, st.pass_launches[F.PASS_INDIRECT])
     eng.set_timing_mask(0)
 
-    # ------------------------------------------------------------------ ray count by deterministic replay
+    # ------------------------------------------------------------------ ray count by deterministic replay (one block's worth of frames:
+    # the camera is static and the rays per frame are counted over the LAST timed block)
     ceng, crend = make_engine(F.CTX_COUNT_RAYS)
-    run_frames(ceng, crend, 1, args.warmup)
+    run_frames(ceng, crend, 1, last_frame - args.steps)
     ceng.wait()
     ceng.reset_stats()
-    run_frames(ceng, crend, args.warmup + 1, args.warmup + args.steps)
+    run_frames(ceng, crend, last_frame - args.steps + 1, last_frame)
     cst = ceng.stats()
     # the dominant kernel ALONE on the GPU: same frames on a single-stream context (in the timed run the two
     # direct-light dispatches share the GPU with it from a second stream, which stretches its own duration)
@@ -160,13 +208,13 @@ def main():
     run_frames(xeng, xrend, args.warmup + 1, args.warmup + min(args.steps, 16))
     xst = xeng.stats()
     ind_ms_alone = xst.pass_ms_total[F.PASS_INDIRECT] / max(1, xst.pass_launches[F.PASS_INDIRECT])
-    traced = np.array([cst.rays_tlas + cst.rays_blas], dtype=np.float64)
+    traced = float(cst.rays_tlas + cst.rays_blas)
     if dist is not None:
-        t = torch.tensor(traced, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([traced], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        traced = t.cpu().numpy()
+        traced = float(t.item())
     # primary rays: one per pixel per frame (apron rows ray-cast redundantly by neighbouring bands are not counted)
-    total_rays = float(traced[0]) + float(W) * H * args.steps
+    total_rays = traced + float(W) * H * args.steps
     # the replay must reproduce the timed frames bit for bit
     same = bool((ceng.read(F.BUF_TONE_MAPPED) == eng.read(F.BUF_TONE_MAPPED)).all())
 
@@ -179,22 +227,24 @@ def main():
         passes = {F.PASS_NAMES[i]: round(ps.pass_ms_total[i] / 6.0, 4) for i in range(F.PASS_COUNT) if ps.pass_launches[i]}
         xeng.set_timing_mask(0)
 
+    # ------------------------------------------------------------------ empirical HBM ceiling, same run
+    hbm = None
+    if rank == 0 and not args.no_hbm_probe:
+        del ceng, crend
+        copy_gbs, triad_gbs = xeng.measure_hbm(1 << 30, 8)
+        hbm = {"copy_gbs": round(copy_gbs, 1), "triad_gbs": round(triad_gbs, 1), "bytes_per_array": 1 << 30,
+               "note": "grid-stride float4 copy (2 x 1 GiB per pass) / triad (3 x 1 GiB per pass), 8 passes each, HIP events"}
+
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
     band_rows = H if rend is None else (rend.band(H)[1] - rend.band(H)[0])
     algo_bytes = INDIRECT_BYTES_PER_PIXEL * W * band_rows
     achieved = algo_bytes / (ind_ms * 1e-3) / 1e9 if ind_ms > 0 else 0.0
-    traffic, limiter = None, None
-    tpath = os.path.join(ROOT, "profiles", "r01_indirect_hbm_traffic.json")
-    if os.path.exists(tpath) and world == 1 and (W, H) == (1920, 1080):
-        try:
-            prof = json.load(open(tpath))
-            traffic, limiter = prof.get("hbm_bytes_per_launch"), prof.get("limiter")  # PMC passes of the same command, see profiles/
-        except Exception:
-            traffic = None
+    ms_blocks = [round(b / args.steps * 1e3, 4) for b in blocks]
 
     out = {
         "metric": "Mray/s (Cornell 1080p 2-bounce, whole job) + frame ms",
@@ -208,23 +258,28 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (assets/models/cornell.glb geometry, reference blue-noise tiles, zeroed reservoirs)",
+        "data": "synthetic (assets/models/cornell.glb geometry or seeded generator, reference blue-noise tiles, zeroed reservoirs)",
         "config": {
-            "workload": f"Cornell box {W}x{H}, {args.bounces} indirect bounces, ReSTIR temporal + indirect spatial reuse on, denoise on, upscale ratio 1.0, static camera",
-            "frames": f"warmup 1..{args.warmup}, timed {args.warmup + 1}..{args.warmup + args.steps}",
+            "workload": description,
+            "baseline_config": args.config,
+            "frames": f"warmup 1..{args.warmup}, then {len(blocks)} timed blocks of {args.steps} frames ({args.warmup + 1}..{last_frame}); value = median block",
             "parallelism": f"band{world}" if world > 1 else "single",
         },
+        "blocks_ms_per_step": ms_blocks,
+        "min_ms_per_step": min(ms_blocks),
         "mray_per_s_per_gpu": round(total_rays / elapsed / 1e6 / world, 3),
         "rays_per_frame": round(total_rays / args.steps, 1),
         "replay_bit_identical": same,
         "roofline": {
-            "kernel": "k_indirect<MULTIPLE_BOUNCES> (indirect_lit_ambient, light.wgsl:1263-1498)",
+            "kernel": "k_indirect (indirect_lit_ambient, light.wgsl:1263-1498)",
             "bound": "hbm",
             "achieved": round(achieved, 3),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6),
-            "traffic": traffic,
+            # HBM bytes per launch from PMC counters cannot be collected inside this process; the rocprofv3 --pmc passes of
+            # this very command are committed under profiles/ (see "traffic_profile" below)
+            "traffic": None,
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": round(ind_ms, 5),
             "launches": int(st.pass_launches[F.PASS_INDIRECT]),
@@ -233,8 +288,19 @@ def main():
                       "frac": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ind_ms_alone > 0 else 0.0},
         },
     }
-    if limiter:
-        out["roofline"]["limiter"] = limiter
+    if hbm:
+        out["roofline"]["hbm_ceiling_measured"] = hbm
+        out["roofline"]["frac_of_measured_copy"] = round(achieved / hbm["copy_gbs"], 6) if hbm["copy_gbs"] > 0 else None
+        # the whole frame against the same ceiling: SURVEY 8d's 1.70 KB/px of compulsory traffic (config 2's pass list)
+        if args.config == 2:
+            frame_bytes = 1700.0 * W * H
+            out["frame_roofline"] = {"algorithmic_bytes_per_frame": frame_bytes, "achieved_gbs": round(frame_bytes / (elapsed / args.steps) / 1e9, 1),
+                                     "frac_of_peak": round(frame_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    tpath = os.path.join(ROOT, "profiles", "r02_indirect_hbm_traffic.json")
+    if os.path.exists(tpath) and world == 1 and args.config == 2:
+        out["traffic_profile"] = {"source": "profiles/r02_indirect_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"}
+    if transport_used[0]:
+        out["config"]["halo_transport"] = transport_used[0]
     if passes:
         out["pass_ms"] = passes
 
@@ -268,6 +334,7 @@ def main():
         }
     print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -126,6 +126,10 @@ class HkHaloOp(C.Structure):
     _fields_ = [("buffer", u32), ("peer", u32), ("row_begin", u32), ("row_end", u32), ("row_bytes", u64)]
 
 
+class HkTransfer(C.Structure):
+    _fields_ = [("buffer", u32), ("peer", u32), ("is_recv", u32), ("_pad", u32), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
+
+
 class HkStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
@@ -202,8 +206,26 @@ _PRODUCT_ONLY = {
     "stream": [_vp, P(_vp)],
     "set_stream": [_vp, _vp],
     "set_timing_mask": [_vp, u32],
+    "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
+    "band_schedule": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkTransfer), P(u32)],
+    "comm_unique_id": [P(C.c_uint8)],
+    "comm_init": [_vp, u32, u32, P(C.c_uint8)],
+    "comm_destroy": [_vp],
+    "comm_set_history_rows": [_vp, u32],
+    "comm_exchange": [_vp, u32, P(HkSettings)],
+    "multi_create": [u32, P(C.c_int), u32, P(_vp)],
+    "multi_context": [_vp, u32, P(_vp)],
+    "multi_upload_scene": [_vp, _vp],
+    "multi_upload_scene_instances": [_vp, _vp],
+    "multi_upload_textures": [_vp, P(HkImageDesc), u32],
+    "multi_upload_noise": [_vp, _vp, C.c_size_t],
+    "multi_resize": [_vp, u32, u32, f32],
+    "multi_set_history_rows": [_vp, u32],
+    "multi_frame_render": [_vp, P(HkFrame), P(HkView), P(HkPreviousView), P(HkLights), P(HkSettings), u32],
+    "multi_wait": [_vp],
+    "multi_read_buffer": [_vp, u32, _vp, C.c_size_t],
 }
-_VOID = {"destroy": [_vp], "scene_builder_destroy": [_vp]}
+_VOID = {"destroy": [_vp], "scene_builder_destroy": [_vp], "multi_destroy": [_vp]}
 
 #: every symbol include/hikari_hip.h declares (checked by tests/test_abi.py)
 DECLARED_SYMBOLS = sorted(["hk_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY) + list(_VOID)] + ["hk_abi_version", "hk_last_error"])
@@ -228,7 +250,7 @@ class Api:
             fn.argtypes, fn.restype = argtypes, C.c_int
             self._fns[name] = fn
         for name, argtypes in _VOID.items():
-            if prefix != "hk_" and name.startswith("scene_builder"):
+            if prefix != "hk_" and (name.startswith("scene_builder") or name.startswith("multi_")):
                 continue
             fn = getattr(self.dll, prefix + name)
             fn.argtypes, fn.restype = argtypes, None

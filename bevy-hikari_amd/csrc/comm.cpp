@@ -1,0 +1,468 @@
+// comm.cpp - the halo exchanges of a band-sharded frame, inside the boundary.
+//
+// The reference renders a frame from one process into one command encoder (src/light.rs:590-702,
+// src/post_process.rs:1131-1311).  Sharded over the GPUs of a node the same dispatch order needs
+// neighbour exchanges between the temporal and spatial dispatches (light.rs:689-697) and before the denoiser; which
+// rows of which buffer is hk_band_plan_for / hk_band_schedule (host_logic.cpp).  This file executes that schedule:
+//
+//   hk_comm_*   one process per GPU: ncclSend / ncclRecv pairs inside one group per exchange, on the context's stream
+//               (RCCL over xGMI; point-to-point, neighbouring bands only).  librccl is dlopen'ed on first use.
+//   hk_multi_*  one process, several GPUs (what a Bevy render thread would drive): hipMemcpyPeerAsync on the receiver's
+//               stream, ordered against the owner's stream with events.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is resolved at run time
+#include <string.h>
+
+#include <deque>
+#include <new>
+#include <vector>
+
+#include "hk_internal.hpp"
+
+using namespace hk;
+
+#define HK_HIP(expr)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      ::hk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);        \
+      return HK_E_HIP;                                                                                   \
+    }                                                                                                    \
+  } while (0)
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    // a copy some other component of the process already mapped (PyTorch ships its own) is as good as the system one
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names)
+      if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (r.lib) {
+#define HK_SYM(name) r.name = reinterpret_cast<decltype(r.name)>(dlsym(r.lib, "nccl" #name))
+      HK_SYM(GetUniqueId); HK_SYM(CommInitRank); HK_SYM(CommDestroy); HK_SYM(GroupStart); HK_SYM(GroupEnd); HK_SYM(Send); HK_SYM(Recv); HK_SYM(GetErrorString);
+#undef HK_SYM
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString) {
+        dlclose(r.lib);
+        r.lib = nullptr;
+      }
+    }
+  }
+  return r.lib ? &r : nullptr;
+}
+
+#define HK_NCCL(R, expr)                                                                     \
+  do {                                                                                       \
+    ncclResult_t e_ = (expr);                                                                \
+    if (e_ != ncclSuccess) {                                                                 \
+      ::hk::set_error("%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(e_), __FILE__, __LINE__); \
+      return HK_E_HIP;                                                                       \
+    }                                                                                        \
+  } while (0)
+
+struct Comm {
+  ncclComm_t comm = nullptr;
+  uint32_t rank = 0, n_ranks = 1;
+  // schedules are cached per (stage argument, frame parity, settings): a band's frame is a few hundred microseconds at
+  // 8 GPUs, so nothing is re-planned per frame
+  struct Cached {
+    uint32_t stage_arg, rank, parity, width, height;
+    float ratio;
+    HkSettings st;
+    std::vector<HkTransfer> tr;
+  };
+  std::deque<Cached> cache;  // (deque: references stay valid while entries are appended)
+  uint64_t exchanges = 0, bytes_received = 0;
+};
+
+int schedule_for(std::deque<Comm::Cached>& cache, const CtxInfo& ci, uint32_t rank, uint32_t n_ranks, uint32_t stage_arg, const HkSettings* st,
+                 const std::vector<HkTransfer>** out) {
+  for (const Comm::Cached& e : cache)
+    if (e.stage_arg == stage_arg && e.rank == rank && e.parity == (ci.frame_number & 1u) && e.width == ci.width && e.height == ci.height &&
+        e.ratio == ci.ratio && memcmp(&e.st, st, sizeof(HkSettings)) == 0) {
+      *out = &e.tr;
+      return HK_OK;
+    }
+  Comm::Cached e;
+  e.stage_arg = stage_arg;
+  e.rank = rank;
+  e.parity = ci.frame_number & 1u;
+  e.width = ci.width;
+  e.height = ci.height;
+  e.ratio = ci.ratio;
+  e.st = *st;
+  uint32_t n = 0;
+  int rc = hk_band_schedule(ci.width, ci.height, ci.ratio, rank, n_ranks, stage_arg, ci.frame_number, st, nullptr, &n);
+  if (rc) return rc;
+  e.tr.resize(n);
+  if (n && (rc = hk_band_schedule(ci.width, ci.height, ci.ratio, rank, n_ranks, stage_arg, ci.frame_number, st, e.tr.data(), &n))) return rc;
+  cache.push_back(std::move(e));  // (bounded by the callers: they clear the cache when it grows past a few hundred entries)
+  *out = &cache.back().tr;
+  return HK_OK;
+}
+
+}  // namespace
+
+namespace hk {
+
+int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
+  Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
+  HK_REQUIRE(cm && cm->comm, HK_E_NOT_READY, "no communicator attached (hk_comm_init)");
+  HK_REQUIRE(st, HK_E_INVALID, "settings is NULL");
+  Rccl* R = rccl();
+  HK_REQUIRE(R, HK_E_UNSUPPORTED, "librccl could not be loaded");
+  CtxInfo ci;
+  int rc = ctx_info(c, &ci);
+  if (rc) return rc;
+  HK_REQUIRE(ci.width > 0, HK_E_NOT_READY, "hk_resize has not been called");
+  const std::vector<HkTransfer>* tr = nullptr;
+  if (cm->cache.size() > 256) cm->cache.clear();  // settings changed many times: start over
+  if ((rc = schedule_for(cm->cache, ci, cm->rank, cm->n_ranks, stage_arg, st, &tr))) return rc;
+  if (tr->empty()) return HK_OK;
+  HK_HIP(hipSetDevice(ci.device));
+  // No join with the side stream here: hk_frame_stage joins it exactly where an exchange reads what the direct-light
+  // dispatches wrote (end of TEMPORAL when the emissive channel has a spatial pass, end of SPATIAL before exchange B), so
+  // exchange A (indirect reservoirs, main stream) overlaps the direct-light kernels still running on the side stream.
+  hipStream_t stream = (hipStream_t)ci.stream;
+  HK_NCCL(R, R->GroupStart());
+  for (const HkTransfer& t : *tr) {
+    size_t logical = 0;
+    char* base = static_cast<char*>(ctx_buffer(c, t.buffer, &logical));
+    if (!base || t.offset + t.bytes > logical) {
+      (void)R->GroupEnd();
+      HK_REQUIRE(false, HK_E_INVALID, "halo transfer outside buffer %u", t.buffer);
+    }
+    ncclResult_t e = t.is_recv ? R->Recv(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream)
+                               : R->Send(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream);
+    if (e != ncclSuccess) {
+      (void)R->GroupEnd();
+      set_error("ncclSend/ncclRecv failed: %s", R->GetErrorString(e));
+      return HK_E_HIP;
+    }
+    if (t.is_recv) cm->bytes_received += t.bytes;
+  }
+  HK_NCCL(R, R->GroupEnd());
+  cm->exchanges += 1;
+  return HK_OK;
+}
+
+void comm_release(hk_ctx* c) {
+  void** slot = ctx_comm_slot(c);
+  Comm* cm = static_cast<Comm*>(*slot);
+  if (!cm) return;
+  Rccl* R = rccl();
+  if (R && cm->comm) (void)R->CommDestroy(cm->comm);
+  delete cm;
+  *slot = nullptr;
+}
+
+}  // namespace hk
+
+// ------------------------------------------------------------------ hk_multi
+struct hk_multi {
+  std::vector<hk_ctx*> ctx;
+  std::vector<int> device;
+  std::vector<hipEvent_t> produced, copied;  // per context: "my stage is enqueued up to here" / "my incoming copies are enqueued up to here"
+  std::deque<Comm::Cached> cache;
+  uint32_t history_rows = 0;
+  uint64_t exchanges = 0, bytes_copied = 0;
+};
+
+namespace {
+
+// everything band i receives before `stage_arg`, as peer copies on i's stream; events order them against the owners' streams
+int multi_exchange(hk_multi* m, uint32_t stage_arg, const HkSettings* st) {
+  const uint32_t n = (uint32_t)m->ctx.size();
+  if (n < 2) return HK_OK;
+  std::vector<const std::vector<HkTransfer>*> plans(n, nullptr);
+  std::vector<CtxInfo> ci(n);
+  bool any = false;
+  if (m->cache.size() > 1024) m->cache.clear();
+  for (uint32_t i = 0; i < n; ++i) {
+    int rc = ctx_info(m->ctx[i], &ci[i]);
+    if (rc) return rc;
+    HK_REQUIRE(ci[i].width > 0, HK_E_NOT_READY, "hk_multi_resize has not been called");
+    if ((rc = schedule_for(m->cache, ci[i], i, n, stage_arg, st, &plans[i]))) return rc;
+    any = any || !plans[i]->empty();
+  }
+  if (!any) return HK_OK;
+  // 1. every band: "produced" recorded on its stream (hk_frame_stage has joined the side stream wherever an exchange reads
+  //    what the direct-light dispatches wrote; exchange A therefore overlaps them)
+  for (uint32_t i = 0; i < n; ++i) {
+    HK_HIP(hipSetDevice(m->device[i]));
+    HK_HIP(hipEventRecord(m->produced[i], (hipStream_t)ci[i].stream));
+  }
+  // 2. every band: wait for the owners of the rows it receives, then copy them in
+  std::vector<uint8_t> read_by(n * n, 0);  // read_by[p * n + i]: band i copies rows out of band p
+  for (uint32_t i = 0; i < n; ++i) {
+    HK_HIP(hipSetDevice(m->device[i]));
+    hipStream_t stream = (hipStream_t)ci[i].stream;
+    std::vector<uint8_t> waited(n, 0);
+    bool copies = false;
+    for (const HkTransfer& t : *plans[i]) {
+      if (!t.is_recv) continue;
+      HK_REQUIRE(t.peer < n, HK_E_INVALID, "bad peer in schedule");
+      if (!waited[t.peer]) {
+        HK_HIP(hipStreamWaitEvent(stream, m->produced[t.peer], 0));
+        waited[t.peer] = 1;
+      }
+      size_t ldst = 0, lsrc = 0;
+      char* dst = static_cast<char*>(ctx_buffer(m->ctx[i], t.buffer, &ldst));
+      const char* src = static_cast<const char*>(ctx_buffer(m->ctx[t.peer], t.buffer, &lsrc));
+      HK_REQUIRE(dst && src && t.offset + t.bytes <= ldst && t.offset + t.bytes <= lsrc, HK_E_INVALID, "halo transfer outside buffer %u", t.buffer);
+      if (m->device[i] == m->device[t.peer])
+        HK_HIP(hipMemcpyAsync(dst + t.offset, src + t.offset, t.bytes, hipMemcpyDeviceToDevice, stream));
+      else
+        HK_HIP(hipMemcpyPeerAsync(dst + t.offset, m->device[i], src + t.offset, m->device[t.peer], t.bytes, stream));
+      read_by[t.peer * n + i] = 1;
+      m->bytes_copied += t.bytes;
+      copies = true;
+    }
+    if (copies) HK_HIP(hipEventRecord(m->copied[i], stream));
+  }
+  // 3. an owner does not run ahead of the copies that read its rows (its next dispatches may overwrite them)
+  for (uint32_t p = 0; p < n; ++p) {
+    HK_HIP(hipSetDevice(m->device[p]));
+    for (uint32_t i = 0; i < n; ++i)
+      if (read_by[p * n + i]) HK_HIP(hipStreamWaitEvent((hipStream_t)ci[p].stream, m->copied[i], 0));
+  }
+  m->exchanges += 1;
+  return HK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hk_comm_unique_id(uint8_t id[HK_COMM_ID_BYTES]) {
+  HK_REQUIRE(id, HK_E_INVALID, "id is NULL");
+  static_assert(sizeof(ncclUniqueId) == HK_COMM_ID_BYTES, "ncclUniqueId size");
+  Rccl* R = rccl();
+  HK_REQUIRE(R, HK_E_UNSUPPORTED, "librccl could not be loaded (%s)", dlerror() ? "dlopen failed" : "symbols missing");
+  ncclUniqueId u;
+  HK_NCCL(R, R->GetUniqueId(&u));
+  memcpy(id, &u, HK_COMM_ID_BYTES);
+  return HK_OK;
+}
+
+int hk_comm_init(hk_ctx* c, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK_COMM_ID_BYTES]) {
+  HK_REQUIRE(c && id && n_ranks > 0 && rank < n_ranks, HK_E_INVALID, "bad argument");
+  Rccl* R = rccl();
+  HK_REQUIRE(R, HK_E_UNSUPPORTED, "librccl could not be loaded");
+  CtxInfo ci;
+  int rc = ctx_info(c, &ci);
+  if (rc) return rc;
+  comm_release(c);
+  HK_HIP(hipSetDevice(ci.device));
+  Comm* cm = new (std::nothrow) Comm();
+  HK_REQUIRE(cm, HK_E_NOMEM, "allocation failed");
+  ncclUniqueId u;
+  memcpy(&u, id, HK_COMM_ID_BYTES);
+  ncclResult_t e = R->CommInitRank(&cm->comm, (int)n_ranks, u, (int)rank);
+  if (e != ncclSuccess) {
+    set_error("ncclCommInitRank(rank %u of %u, device %d) failed: %s", rank, n_ranks, ci.device, R->GetErrorString(e));
+    delete cm;
+    return HK_E_HIP;
+  }
+  cm->rank = rank;
+  cm->n_ranks = n_ranks;
+  *ctx_comm_slot(c) = cm;
+  return hk_set_band(c, rank, n_ranks);
+}
+
+int hk_comm_destroy(hk_ctx* c) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  const int rc = hk_frame_wait(c);
+  comm_release(c);
+  return rc;
+}
+
+int hk_comm_set_history_rows(hk_ctx* c, uint32_t rows) {
+  HK_REQUIRE(c && rows < (1u << 16), HK_E_INVALID, "bad argument");
+  *ctx_history_rows(c) = rows;
+  return HK_OK;
+}
+
+int hk_comm_exchange(hk_ctx* c, uint32_t stage, const HkSettings* st) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  return comm_exchange(c, stage, st);
+}
+
+int hk_multi_create(uint32_t n, const int* device_ids, uint32_t flags, hk_multi** out) {
+  HK_REQUIRE(out && device_ids && n > 0 && n <= 64, HK_E_INVALID, "bad argument");
+  *out = nullptr;
+  hk_multi* m = new (std::nothrow) hk_multi();
+  HK_REQUIRE(m, HK_E_NOMEM, "allocation failed");
+  for (uint32_t i = 0; i < n; ++i) {
+    hk_ctx* c = nullptr;
+    int rc = hk_create(device_ids[i], flags, &c);
+    if (!rc) rc = hk_set_band(c, i, n);
+    if (rc) {
+      if (c) hk_destroy(c);
+      hk_multi_destroy(m);
+      return rc;
+    }
+    m->ctx.push_back(c);
+    m->device.push_back(device_ids[i]);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipSetDevice(device_ids[i]) != hipSuccess || hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+      set_error("event creation failed on device %d", device_ids[i]);
+      if (a) (void)hipEventDestroy(a);
+      hk_multi_destroy(m);
+      return HK_E_HIP;
+    }
+    m->produced.push_back(a);
+    m->copied.push_back(b);
+  }
+  // neighbouring bands copy from each other: direct xGMI access where the devices differ
+  for (uint32_t i = 0; i + 1 < n; ++i) {
+    const int a = device_ids[i], b = device_ids[i + 1];
+    if (a == b) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+      (void)hipSetDevice(a);
+      (void)hipDeviceEnablePeerAccess(b, 0);  // hipErrorPeerAccessAlreadyEnabled is fine
+      (void)hipSetDevice(b);
+      (void)hipDeviceEnablePeerAccess(a, 0);
+      (void)hipGetLastError();
+    }
+  }
+  *out = m;
+  return HK_OK;
+}
+
+void hk_multi_destroy(hk_multi* m) {
+  if (!m) return;
+  for (size_t i = 0; i < m->ctx.size(); ++i) {
+    hk_destroy(m->ctx[i]);
+    if (i < m->produced.size()) {
+      (void)hipSetDevice(m->device[i]);
+      (void)hipEventDestroy(m->produced[i]);
+      (void)hipEventDestroy(m->copied[i]);
+    }
+  }
+  delete m;
+}
+
+int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out) {
+  HK_REQUIRE(m && out && i < m->ctx.size(), HK_E_INVALID, "bad argument");
+  *out = m->ctx[i];
+  return HK_OK;
+}
+
+#define HK_EACH(call)                   \
+  HK_REQUIRE(m, HK_E_INVALID, "multi is NULL"); \
+  for (hk_ctx * c : m->ctx) {           \
+    const int rc_ = (call);             \
+    if (rc_) return rc_;                \
+  }                                     \
+  return HK_OK
+
+int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene(c, b)); }
+int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene_instances(c, b)); }
+int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n) { HK_EACH(hk_upload_textures(c, images, n)); }
+int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes) { HK_EACH(hk_upload_noise(c, rgba, bytes)); }
+int hk_multi_resize(hk_multi* m, uint32_t w, uint32_t h, float ratio) {
+  HK_REQUIRE(m, HK_E_INVALID, "multi is NULL");
+  m->cache.clear();
+  HK_EACH(hk_resize(c, w, h, ratio));
+}
+int hk_multi_wait(hk_multi* m) { HK_EACH(hk_frame_wait(c)); }
+#undef HK_EACH
+
+int hk_multi_set_history_rows(hk_multi* m, uint32_t rows) {
+  HK_REQUIRE(m && rows < (1u << 16), HK_E_INVALID, "bad argument");
+  m->history_rows = rows;
+  return HK_OK;
+}
+
+int hk_multi_frame_render(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
+  HK_REQUIRE(m && st, HK_E_INVALID, "bad argument");
+  int rc;
+  for (hk_ctx* c : m->ctx)
+    if ((rc = hk_frame_begin(c, f, v, pv, l))) return rc;
+  const uint32_t hist = m->history_rows << 8;
+  auto stage = [&](uint32_t s) {
+    for (hk_ctx* c : m->ctx) {
+      const int r = hk_frame_stage(c, s, st, flags);
+      if (r) return r;
+    }
+    return (int)HK_OK;
+  };
+  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) {
+    if ((s != HK_STAGE_TEMPORAL || hist) && (rc = multi_exchange(m, s == HK_STAGE_TEMPORAL ? (s | hist) : s, st))) return rc;
+    if ((rc = stage(s))) return rc;
+  }
+  if (flags & HK_FRAME_ANTIALIAS) {
+    if ((rc = multi_exchange(m, HK_STAGE_ANTIALIAS | hist, st))) return rc;
+    if ((rc = stage(HK_STAGE_ANTIALIAS))) return rc;
+    if (st->upscale_kind == HK_UPSCALE_FSR1 && (rc = multi_exchange(m, HK_STAGE_UPSCALE, st))) return rc;
+    if ((rc = stage(HK_STAGE_UPSCALE))) return rc;
+  }
+  return HK_OK;
+}
+
+int hk_multi_read_buffer(hk_multi* m, uint32_t buffer, void* dst, size_t bytes) {
+  HK_REQUIRE(m && dst && !m->ctx.empty(), HK_E_INVALID, "bad argument");
+  const uint32_t n = (uint32_t)m->ctx.size();
+  uint32_t bw = 0, bh = 0, bpp = 0;
+  int rc = hk_buffer_info(m->ctx[0], buffer, &bw, &bh, &bpp);
+  if (rc) return rc;
+  CtxInfo ci;
+  if ((rc = ctx_info(m->ctx[0], &ci))) return rc;
+  uint32_t rw, rh;
+  if ((rc = hk_scaled_size(ci.width, ci.height, ci.ratio, &rw, &rh))) return rc;
+  // reservoir buffers are allocated window-size but indexed as rw x rh records (light.rs:344, light.wgsl:1061)
+  const bool reservoir = buffer >= HK_BUF_RESERVOIR0 && buffer < HK_BUF_RESERVOIR0 + 10;
+  const uint32_t rows = reservoir ? rh : bh;
+  const size_t row_bytes = (size_t)(reservoir ? rw : bw) * bpp;
+  HK_REQUIRE(bytes == (size_t)bw * bh * bpp, HK_E_INVALID, "size mismatch: buffer has %zu bytes", (size_t)bw * bh * bpp);
+  // Which rows of `buffer` does band i own?  Bands partition the RENDER rows [b0, b1):
+  //   render-size buffers (and the rw x rh records of a reservoir buffer)   [b0, b1)
+  //   SMAA Tu4x outputs (upscale_output / taa_output, two rows per render row) [2 b0, 2 b1) clamped, the last band to the end
+  //   FSR1 window-size outputs                                               hk_band_rows(height) (HK_STAGE_UPSCALE)
+  //   full-size planes (G-buffer, albedo) at ratio > 1                        the window rows under [b0, b1) (every band ray-casts
+  //                                                                           a superset of them, full_rows_for in context.hip)
+  const bool upscaled = buffer == HK_BUF_UPSCALE_OUTPUT || buffer == HK_BUF_TAA_OUTPUT || buffer == HK_BUF_PREVIOUS_TAA_OUTPUT;
+  const bool fsr_window = ci.upscale_kind == HK_UPSCALE_FSR1 && (buffer == HK_BUF_UPSCALE_OUTPUT || buffer == HK_BUF_UPSCALE_SHARPENED);
+  std::vector<uint8_t> tmp(bytes);
+  memset(dst, 0, bytes);
+  for (uint32_t i = 0; i < n; ++i) {
+    uint32_t b0, b1, y0, y1;
+    if ((rc = hk_band_rows(rh, i, n, &b0, &b1))) return rc;
+    if (fsr_window) {
+      if ((rc = hk_band_rows(ci.height, i, n, &y0, &y1))) return rc;
+    } else if (rows == rh) {
+      y0 = b0; y1 = b1;
+    } else if (upscaled && ci.upscale_kind == HK_UPSCALE_SMAA_TU4X) {
+      y0 = 2 * b0 < rows ? 2 * b0 : rows;
+      y1 = (b1 == rh) ? rows : (2 * b1 < rows ? 2 * b1 : rows);
+    } else {
+      y0 = (uint32_t)((uint64_t)b0 * rows / rh);
+      y1 = (b1 == rh) ? rows : (uint32_t)((uint64_t)b1 * rows / rh);
+    }
+    if (y1 <= y0) continue;
+    if ((rc = hk_read_buffer(m->ctx[i], buffer, tmp.data(), bytes))) return rc;
+    memcpy(static_cast<uint8_t*>(dst) + (size_t)y0 * row_bytes, tmp.data() + (size_t)y0 * row_bytes, (size_t)(y1 - y0) * row_bytes);
+  }
+  return HK_OK;
+}
+
+}  // extern "C"

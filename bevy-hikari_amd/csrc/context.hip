@@ -36,6 +36,17 @@ __global__ void k_copy_u4(uint4* __restrict__ dst, const uint4* __restrict__ src
   if (i < n) dst[i] = src[i];
 }
 
+// HBM ceiling probes (hk_measure_hbm): grid-stride float4 streams, 16 B per lane per access
+__global__ __launch_bounds__(256) void k_stream_copy(float4* __restrict__ a, const float4* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] = b[i];
+}
+__global__ __launch_bounds__(256) void k_stream_triad(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, float s, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float4 x = b[i], y = c[i];
+    a[i] = make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
+  }
+}
+
 template <typename T>
 struct DevArray {
   T* p = nullptr;
@@ -179,6 +190,8 @@ struct hk_ctx {
   float upscale_sharpness = 0.0f;
 
   uint32_t band_index = 0, band_count = 1;
+  void* comm = nullptr;        // RCCL communicator state, owned by comm.cpp (hk_comm_init)
+  uint32_t history_rows = 0;   // exchange C rows (hk_comm_set_history_rows)
 
   // statistics
   unsigned long long* d_counters = nullptr;  // primary, tlas, blas
@@ -926,6 +939,31 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
 
 }  // namespace
 
+namespace hk {
+int ctx_info(hk_ctx* c, CtxInfo* o) {
+  HK_REQUIRE(c && o, HK_E_INVALID, "bad argument");
+  o->device = c->device;
+  o->stream = (void*)c->stream;
+  o->width = (uint32_t)c->W;
+  o->height = (uint32_t)c->H;
+  o->ratio = c->ratio;
+  o->frame_number = c->frame.number;
+  o->band_index = c->band_index;
+  o->band_count = c->band_count;
+  o->upscale_kind = c->upscale_kind;
+  o->taa = c->taa;
+  return HK_OK;
+}
+void* ctx_buffer(hk_ctx* c, uint32_t b, size_t* logical_bytes) {
+  if (!c || b >= HK_BUF_COUNT) return nullptr;
+  if (logical_bytes) *logical_bytes = buffer_logical_bytes(c, b);
+  return c->buf[b];
+}
+void** ctx_comm_slot(hk_ctx* c) { return &c->comm; }
+uint32_t* ctx_history_rows(hk_ctx* c) { return &c->history_rows; }
+int ctx_join_side(hk_ctx* c) { return join_side(c); }
+}  // namespace hk
+
 extern "C" {
 
 int hk_device_count(int* count) {
@@ -977,7 +1015,9 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
 void hk_destroy(hk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  (void)join_side(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  comm_release(c);
   drain_timers(c);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->frame_start) (void)hipEventDestroy(c->frame_start);
@@ -1349,10 +1389,18 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
 int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   int rc = hk_frame_begin(c, f, v, pv, l);
   if (rc) return rc;
-  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s)
+  HK_REQUIRE(st, HK_E_INVALID, "settings is NULL");
+  // with a communicator attached (hk_comm_init) the halo exchanges of the band plan run here, on the context's stream
+  const bool ex = c->comm != nullptr && c->band_count > 1;
+  const uint32_t hist = c->history_rows << 8;
+  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) {
+    if (ex && (s != HK_STAGE_TEMPORAL || hist) && (rc = comm_exchange(c, s == HK_STAGE_TEMPORAL ? (s | hist) : s, st))) return rc;
     if ((rc = hk_frame_stage(c, s, st, flags))) return rc;
+  }
   if (flags & HK_FRAME_ANTIALIAS) {
+    if (ex && (rc = comm_exchange(c, HK_STAGE_ANTIALIAS | hist, st))) return rc;
     if ((rc = hk_frame_stage(c, HK_STAGE_ANTIALIAS, st, flags))) return rc;
+    if (ex && st->upscale_kind == HK_UPSCALE_FSR1 && (rc = comm_exchange(c, HK_STAGE_UPSCALE, st))) return rc;
     return hk_frame_stage(c, HK_STAGE_UPSCALE, st, flags);
   }
   return HK_OK;
@@ -1398,7 +1446,7 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
 int hk_device_ptr(hk_ctx* c, uint32_t buffer, void** ptr, size_t* bytes) {
   HK_REQUIRE(c && ptr && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
   *ptr = c->buf[buffer];
-  if (bytes) *bytes = buffer_logical_bytes(c, buffer);
+  if (bytes) *bytes = c->buf_bytes[buffer];  // the ALLOCATION (independent of the upscale kind in effect), so a host may keep a view across settings changes
   return HK_OK;
 }
 int hk_set_stream(hk_ctx* c, void* s) {
@@ -1455,6 +1503,42 @@ int hk_reset_stats(hk_ctx* c) {
     c->slot_launches[i] = 0;
   }
   return HK_OK;
+}
+
+int hk_measure_hbm(hk_ctx* c, size_t bytes, uint32_t reps, double* copy_gbs, double* triad_gbs) {
+  HK_REQUIRE(c && copy_gbs && triad_gbs && bytes >= 4096 && reps > 0, HK_E_INVALID, "bad argument");
+  HK_HIP(hipSetDevice(c->device));
+  { const int rc_ = sync_all(c); if (rc_) return rc_; }
+  const size_t n = bytes / 16;
+  float4 *a = nullptr, *b = nullptr, *d = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = HK_OK;
+  auto fail = [&](const char* what, hipError_t e) { set_error("%s failed: %s", what, hipGetErrorString(e)); rc = HK_E_HIP; };
+  hipError_t e;
+  if ((e = hipMalloc((void**)&a, n * 16)) != hipSuccess || (e = hipMalloc((void**)&b, n * 16)) != hipSuccess || (e = hipMalloc((void**)&d, n * 16)) != hipSuccess) fail("hipMalloc", e);
+  if (!rc && ((e = hipMemsetAsync(a, 0, n * 16, c->stream)) != hipSuccess || (e = hipMemsetAsync(b, 0, n * 16, c->stream)) != hipSuccess ||
+              (e = hipMemsetAsync(d, 0, n * 16, c->stream)) != hipSuccess)) fail("hipMemsetAsync", e);
+  if (!rc && ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess)) fail("hipEventCreate", e);
+  const dim3 grid(256 * 32);  // 32 workgroups per CU of grid-stride work
+  for (int pass = 0; pass < 2 && !rc; ++pass) {
+    for (uint32_t k = 0; k <= reps && !rc; ++k) {  // k = 0 warms up
+      if (k == 1) (void)hipEventRecord(e0, c->stream);
+      if (pass == 0) hipLaunchKernelGGL(k_stream_copy, grid, dim3(256), 0, c->stream, a, (const float4*)b, n);
+      else hipLaunchKernelGGL(k_stream_triad, grid, dim3(256), 0, c->stream, a, (const float4*)b, (const float4*)d, 0.5f, n);
+    }
+    (void)hipEventRecord(e1, c->stream);
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { fail("hipStreamSynchronize", e); break; }
+    float ms = 0.0f;
+    if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) { fail("hipEventElapsedTime", e); break; }
+    const double gbs = (double)(pass == 0 ? 2 : 3) * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    if (pass == 0) *copy_gbs = gbs; else *triad_gbs = gbs;
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (a) (void)hipFree(a);
+  if (b) (void)hipFree(b);
+  if (d) (void)hipFree(d);
+  return rc;
 }
 
 int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float* out, size_t n) {

@@ -37,4 +37,22 @@ struct Aprons {
 };
 Aprons band_aprons(const HkSettings* settings);
 
+
+// ---- what comm.cpp needs from a context (hk_ctx is private to context.hip)
+struct CtxInfo {
+  int device;
+  void* stream;            // hipStream_t the context enqueues on
+  uint32_t width, height;  // window size
+  float ratio;
+  uint32_t frame_number, band_index, band_count, upscale_kind, taa;
+};
+int ctx_info(hk_ctx* c, CtxInfo* out);
+void* ctx_buffer(hk_ctx* c, uint32_t buffer, size_t* logical_bytes);
+void** ctx_comm_slot(hk_ctx* c);       // owned by comm.cpp (NULL = no communicator)
+uint32_t* ctx_history_rows(hk_ctx* c);
+int ctx_join_side(hk_ctx* c);          // main stream waits for the side stream
+// run before `stage` by hk_frame_render when a communicator is attached
+int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st);
+void comm_release(hk_ctx* c);          // hk_destroy
+
 }  // namespace hk

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "hk_internal.hpp"
 
@@ -266,6 +267,41 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
     HK_REQUIRE(false, HK_E_INVALID, "ops array too small: need %u", n);
   }
   *n_ops = n;
+  return HK_OK;
+}
+
+int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint32_t rank, uint32_t n_ranks, uint32_t stage,
+                     uint32_t frame_number, const HkSettings* st, HkTransfer* out, uint32_t* n_out) {
+  HK_REQUIRE(st && n_out && n_ranks > 0 && rank < n_ranks, HK_E_INVALID, "bad argument");
+  const uint32_t cap = out ? *n_out : 0;
+  uint32_t n = 0;
+  std::vector<HkHaloOp> ops;
+  for (uint32_t r = 0; r < n_ranks; ++r) {  // the fixed global order: receive plan of rank 0, 1, ...
+    uint32_t k = 0;
+    int rc = hk_band_plan_for(width, height, upscale_ratio, r, n_ranks, stage, frame_number, st, nullptr, &k);
+    if (rc) return rc;
+    ops.resize(k);
+    if (k && (rc = hk_band_plan_for(width, height, upscale_ratio, r, n_ranks, stage, frame_number, st, ops.data(), &k))) return rc;
+    for (uint32_t i = 0; i < k; ++i) {
+      const HkHaloOp& op = ops[i];
+      const bool recv = r == rank, send = op.peer == rank;
+      if (!recv && !send) continue;
+      if (out && n < cap) {
+        out[n].buffer = op.buffer;
+        out[n].peer = recv ? op.peer : r;
+        out[n].is_recv = recv ? 1u : 0u;
+        out[n]._pad = 0;
+        out[n].offset = (uint64_t)op.row_begin * op.row_bytes;
+        out[n].bytes = (uint64_t)(op.row_end - op.row_begin) * op.row_bytes;
+      }
+      n += 1;
+    }
+  }
+  if (out && n > cap) {
+    *n_out = n;
+    HK_REQUIRE(false, HK_E_INVALID, "transfer array too small: need %u", n);
+  }
+  *n_out = n;
   return HK_OK;
 }
 

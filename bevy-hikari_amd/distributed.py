@@ -1,10 +1,6 @@
-"""Band-sharded rendering across GPUs: one process per GPU (torch.distributed; backend "nccl" is
-RCCL over xGMI on ROCm, "gloo" on CPU for tests).
-
-The frame is cut into horizontal bands of the render image, one per rank, with the scene
-replicated.  Every pass is per-pixel with a bounded screen-space footprint, so the only
-data that crosses ranks are halo rows, exchanged point-to-point between neighbouring bands twice
-per frame:
+"""Band-sharded rendering across GPUs: the frame is cut into horizontal bands of the render image, one per
+GPU, with the scene replicated.  Every pass is per-pixel with a bounded screen-space footprint, so the only data that
+crosses GPUs are halo rows between neighbouring bands:
 
     stage TEMPORAL      prepass (+apron), albedo, direct_lit x2, indirect on the band
     exchange A          temporal reservoirs, 20 rows (10 for the emissive channel)   -> spatial_reuse
@@ -14,11 +10,18 @@ per frame:
 and, only when the camera or objects moved (history_rows > 0), before stage TEMPORAL:
     exchange C          last frame's temporal + spatial reservoirs, history_rows rows -> reprojection across the border
 
-Which rows of which buffer move is decided by the library (`hk_band_plan_for`, pure host logic);
-this module only executes that plan with isend/irecv on zero-copy views of the library's device
-buffers.  Buffers are allocated full-frame on every rank (288 GB HBM makes the 1.6 GB @1080p /
-6.6 GB @4K irrelevant), so a halo row lands at the same address it has on its owner and no
-coordinate translation exists anywhere.
+Which rows of which buffer move, in which order, is decided by the library (`hk_band_plan_for`, `hk_band_schedule`: pure
+host logic) and - on GPUs - the transfers themselves run INSIDE the library:
+
+  * one process per GPU: `hk_comm_init` attaches an RCCL communicator to the context and `hk_frame_render` performs the
+    exchanges itself on the context's stream (ncclSend / ncclRecv over xGMI).  `BandRenderer(transport="rccl")` only does the
+    rendezvous: rank 0's `hk_comm_unique_id` bytes travel through torch.distributed's (gloo) object broadcast.
+  * one process, several GPUs: `MultiEngine` = `hk_multi_*` (peer copies ordered by events; what a Bevy render thread drives).
+
+`BandRenderer(transport="host")` is the TEST transport: it executes the same `hk_band_schedule` with torch.distributed
+isend / irecv through host memory - over gloo on CPU (the oracle as the compute) and for several ranks sharing ONE GPU (RCCL
+refuses two ranks on one device).  Buffers are allocated full-frame on every rank (288 GB HBM makes the 1.6 GB @1080p /
+6.6 GB @4K irrelevant), so a halo row lands at the address it has on its owner and no coordinate translation exists anywhere.
 """
 import ctypes as C
 
@@ -46,27 +49,56 @@ def halo_plan(width, height, upscale_ratio, band_index, band_count, stage, frame
     return [ops[i] for i in range(n2.value)]
 
 
-class BandRenderer:
-    """Drives one rank's band of the frame; `engine` is a bevy_hikari_amd.Engine (or, in the CPU
-    tests, the oracle behind the same class)."""
+def band_schedule(width, height, upscale_ratio, rank, n_ranks, stage, frame_number, settings_c):
+    """hk_band_schedule: every transfer `rank` takes part in before `stage`, sends and receives, in the global order all
+    ranks agree on (list of HkTransfer)."""
+    api = F.api()
+    n = F.u32(0)
+    api.call("band_schedule", width, height, upscale_ratio, rank, n_ranks, stage, frame_number, C.byref(settings_c), None, C.byref(n))
+    tr = (F.HkTransfer * max(n.value, 1))()
+    n2 = F.u32(n.value)
+    if n.value:
+        api.call("band_schedule", width, height, upscale_ratio, rank, n_ranks, stage, frame_number, C.byref(settings_c), tr, C.byref(n2))
+    return [tr[i] for i in range(n2.value)]
 
-    def __init__(self, engine, rank, world_size, backend_device="cuda"):
+
+class BandRenderer:
+    """Drives one rank's band of the frame; `engine` is a bevy_hikari_amd.Engine (or, in the CPU tests, the oracle behind
+    the same class).  transport: "rccl" (the product: exchanges inside the library) or "host" (tests, see the module text)."""
+
+    def __init__(self, engine, rank, world_size, backend_device="cuda", transport=None):
         import torch
 
         self.torch = torch
         self.engine, self.rank, self.world = engine, rank, world_size
         self.device = backend_device
+        self.transport = transport or ("host" if backend_device == "cpu" else "rccl")
         self._views = {}
         self._plans = {}
+        self._generation = getattr(engine, "generation", 0)
         engine.set_band(rank, world_size)
+        if self.transport == "rccl" and world_size > 1:
+            import torch.distributed as dist
 
+            # rendezvous: rank 0 creates the RCCL id, the (gloo) process group carries its 128 bytes to the other ranks
+            box = [engine.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            engine.comm_init(rank, world_size, box[0])
+
+    # ------------------------------------------------------------------ host transport (tests)
     def _view(self, buf, parity=0):
         # the double-buffered ids (HkBuffer: position, velocity, tone-mapped, TAA) name a different plane on odd and
-        # even frames, so views are kept per frame parity; they are taken after hk_frame_begin of such a frame
+        # even frames, so views are kept per frame parity; they are taken after hk_frame_begin of such a frame.
+        # Engine.resize frees every buffer and bumps engine.generation: views and plans of an older generation are dropped.
+        gen = getattr(self.engine, "generation", 0)
+        if gen != self._generation:
+            self._views, self._plans, self._generation = {}, {}, gen
         key = (buf, parity)
         if key not in self._views:
             torch = self.torch
-            ptr, nbytes = self.engine.device_ptr(buf)
+            ptr, _logical = self.engine.device_ptr(buf)
+            _w, _h, _bpp = self.engine.buffer_info(buf)
+            nbytes = self.engine.allocated_bytes(buf)   # the allocation, not the logical size of the current upscale kind
             if self.device == "cuda":
                 t = torch.as_tensor(_DevView(ptr, nbytes), device="cuda")
             else:
@@ -74,40 +106,33 @@ class BandRenderer:
             self._views[key] = t
         return self._views[key]
 
-    def invalidate_views(self):  # after hk_resize
+    def invalidate_views(self):  # kept for callers of the round-1 interface; resize is tracked through engine.generation
         self._views = {}
         self._plans = {}
 
     def _transfers(self, stage, frame_number, settings_c, width, height, upscale_ratio):
-        """(is_recv, view slice, peer) for every transfer of `stage` this rank takes part in, in a
-        global order all ranks agree on.  The plan depends on the frame number only through its
-        parity (reservoir ping-pong), so it is built once per (stage, parity, settings) and reused:
-        at 8 GPUs a band's frame is a few hundred microseconds and per-frame host work would
-        otherwise dominate."""
+        """(is_recv, view slice, peer) of hk_band_schedule.  The schedule depends on the frame number only through its
+        parity (reservoir ping-pong), so it is built once per (stage, parity, settings) and reused."""
+        gen = getattr(self.engine, "generation", 0)
+        if gen != self._generation:
+            self._views, self._plans, self._generation = {}, {}, gen
         key = (stage, frame_number & 1, width, height, upscale_ratio, bytes(settings_c))
         hit = self._plans.get(key)
         if hit is not None:
             return hit
         out = []
-        for peer_rank in range(self.world):  # fixed global order: plans of rank 0, 1, ...
-            for op in halo_plan(width, height, upscale_ratio, peer_rank, self.world, stage, frame_number, settings_c):
-                lo, hi = op.row_begin * op.row_bytes, op.row_end * op.row_bytes
-                if peer_rank == self.rank:       # I receive rows owned by op.peer
-                    out.append((True, self._view(op.buffer, frame_number & 1)[lo:hi], op.peer))
-                elif op.peer == self.rank:       # peer_rank needs rows I own
-                    out.append((False, self._view(op.buffer, frame_number & 1)[lo:hi], peer_rank))
+        for t in band_schedule(width, height, upscale_ratio, self.rank, self.world, stage, frame_number, settings_c):
+            out.append((bool(t.is_recv), self._view(t.buffer, frame_number & 1)[t.offset:t.offset + t.bytes], t.peer))
         self._plans[key] = out
         return out
 
     def exchange(self, stage, frame_number, settings_c, width, height, upscale_ratio):
-        """Execute the halo plan of `stage` for every rank pair this rank takes part in."""
+        """Execute the schedule of `stage` through host memory (the engine has been waited for)."""
         if self.world == 1:
             return 0
         import torch.distributed as dist
 
-        # RCCL moves device memory directly; gloo (CPU tests, and the one-GPU multi-rank test) cannot
-        # address device memory, so device views are staged through host tensors there.
-        staged = self.device == "cuda" and dist.get_backend() != "nccl"
+        staged = self.device == "cuda"
         ops, nbytes, landing = [], 0, []
         for is_recv, view, peer in self._transfers(stage, frame_number, settings_c, width, height, upscale_ratio):
             if is_recv:
@@ -125,44 +150,98 @@ class BandRenderer:
         for view, tmp in landing:
             view.copy_(tmp)
         if landing:
-            self.torch.cuda.synchronize()
+            self.torch.cuda.synchronize()  # the halo rows are in place before the next stage is enqueued on the engine's stream
         return nbytes
 
     def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0, antialias=False):
-        """One frame: three stages with the two halo exchanges in between.  history_rows > 0 (camera or
-        objects moved since the last frame) first fetches that many rows of last frame's reservoirs from the
-        neighbouring bands (exchange C, HK_STAGE_TEMPORAL_WITH_HISTORY): reprojection may cross the band border."""
+        """One frame of this rank's band.  history_rows > 0 (camera or objects moved since the last frame) first fetches
+        that many rows of last frame's reservoirs from the neighbouring bands (exchange C)."""
         e = self.engine
         sc = settings.to_c()
+        if self.transport == "rccl":
+            if self.world > 1:
+                e.comm_set_history_rows(int(history_rows))
+            e.frame_render(frame, view, previous_view, lights, sc, F.FRAME_ANTIALIAS if antialias else 0)
+            return
         ratio = settings.upscale.ratio()
         e.frame_begin(frame, view, previous_view, lights)
         if history_rows > 0:
-            self._sync_before_exchange()
+            e.wait()
             self.exchange(F.STAGE_TEMPORAL | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_TEMPORAL, sc)
-        self._sync_before_exchange()
+        e.wait()
         self.exchange(F.STAGE_SPATIAL, frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_SPATIAL, sc)
-        self._sync_before_exchange()
+        e.wait()
         self.exchange(F.STAGE_POST_PROCESS, frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_POST_PROCESS, sc)
         if antialias:  # SMAA Tu4x / TAA on the band: exchange D = tone-mapped rows + last frame's TAA rows
-            self._sync_before_exchange()
+            e.wait()
             self.exchange(F.STAGE_ANTIALIAS | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
             e.frame_stage(F.STAGE_ANTIALIAS, sc)
             if settings.upscale.kind == F.UPSCALE_FSR1:  # FSR1 on the band's window rows: exchange E = the EASU taps' input rows
-                self._sync_before_exchange()
+                e.wait()
                 self.exchange(F.STAGE_UPSCALE, frame.number, sc, width, height, ratio)
                 e.frame_stage(F.STAGE_UPSCALE, sc)
-
-    def _sync_before_exchange(self):
-        # When the engine runs on torch's current stream (Engine.set_stream), RCCL orders itself
-        # against that stream and nothing is needed.  On the engine's own stream (or the CPU
-        # oracle) wait for the stage to finish first.
-        if not getattr(self.engine, "on_host_stream", False):
-            self.engine.wait()
 
     def band(self, rows):
         base, rem = divmod(rows, self.world)
         b0 = self.rank * base + min(self.rank, rem)
         return b0, b0 + base + (1 if self.rank < rem else 0)
+
+
+class MultiEngine:
+    """hk_multi_*: one process, n GPUs, one band per context; the library moves the halo rows itself (peer copies ordered by
+    events).  device_ids may repeat - several bands on one GPU - which is how the path is tested on a one-GPU box."""
+
+    def __init__(self, device_ids, flags=0):
+        from .plugin import Engine
+
+        self.api = F.api()
+        self.h = C.c_void_p()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self.api.call("multi_create", len(device_ids), ids, flags, C.byref(self.h))
+        self.n = len(device_ids)
+        self.contexts = []
+        for i in range(self.n):
+            c = C.c_void_p()
+            self.api.call("multi_context", self.h, i, C.byref(c))
+            self.contexts.append(Engine.borrowed(self.api, c))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.api.raw("multi_destroy")(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload_scene(self, scene):
+        for e in self.contexts:
+            e.upload_scene(scene)   # (textures included)
+
+    def upload_noise(self, noise=None):
+        for e in self.contexts:
+            e.upload_noise(noise)
+
+    def resize(self, width, height, upscale_ratio=1.0):
+        self.api.call("multi_resize", self.h, width, height, upscale_ratio)
+        for e in self.contexts:
+            e.generation += 1
+
+    def set_history_rows(self, rows):
+        self.api.call("multi_set_history_rows", self.h, rows)
+
+    def frame_render(self, frame, view, previous_view, lights, settings_c, flags=0):
+        self.api.call("multi_frame_render", self.h, C.byref(frame), C.byref(view), C.byref(previous_view), C.byref(lights), C.byref(settings_c), flags)
+
+    def wait(self):
+        self.api.call("multi_wait", self.h)
+
+    def read(self, buf):
+        """The union of the bands' own rows of `buf` (same array shape as Engine.read)."""
+        e = self.contexts[0]
+        w, h, bpp = e.buffer_info(buf)
+        raw = np.empty(w * h * bpp, dtype=np.uint8)
+        self.api.call("multi_read_buffer", self.h, buf, raw.ctypes.data_as(C.c_void_p), raw.size)
+        return e.shape_buffer(buf, raw)

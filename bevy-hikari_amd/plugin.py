@@ -402,11 +402,20 @@ class Engine:
         self.ctx = C.c_void_p()
         self.api.call("create", device, flags, C.byref(self.ctx))
         self.width = self.height = 0
+        self.owned = True
+        self.generation = 0  # bumped by resize(): holders of device pointers / views compare it (distributed.BandRenderer)
+
+    @classmethod
+    def borrowed(cls, api, ctx):
+        """An Engine over a context somebody else owns (hk_multi_context): never destroyed from here."""
+        e = cls.__new__(cls)
+        e.api, e.ctx, e.owned, e.generation, e.width, e.height = api, ctx, False, 0, 0, 0
+        return e
 
     def close(self):
-        if self.ctx:
+        if self.ctx and getattr(self, "owned", True):
             self.api.raw("destroy")(self.ctx)
-            self.ctx = C.c_void_p()
+        self.ctx = C.c_void_p()
 
     def __del__(self):
         try:
@@ -444,6 +453,7 @@ class Engine:
     def resize(self, width, height, upscale_ratio=1.0):
         self.api.call("resize", self.ctx, width, height, upscale_ratio)
         self.width, self.height = width, height
+        self.generation += 1  # every buffer was freed and reallocated: device pointers / views of an older generation are dead
 
     # -- per frame
     def frame_begin(self, frame, view, previous_view, lights):
@@ -473,8 +483,7 @@ class Engine:
         self.api.call("buffer_info", self.ctx, buf, C.byref(w), C.byref(h), C.byref(bpp))
         return w.value, h.value, bpp.value
 
-    def read(self, buf):
-        """Raw contents as a numpy array [h, w, k] (f32 for 16/8-byte float formats, u16 for rgba16f, u32 otherwise)."""
+    def _buffer_layout(self, buf):
         w, h, bpp = self.buffer_info(buf)
         if buf in (F.BUF_DEPTH_GRADIENT, F.BUF_INSTANCE_MATERIAL):
             dt, k = np.float32, 2
@@ -482,9 +491,19 @@ class Engine:
             dt, k = np.float32, 1
         else:
             dt, k = _BUF_DTYPES[bpp]
+        return h, w, k, dt
+
+    def read(self, buf):
+        """Raw contents as a numpy array [h, w, k] (f32 for 16/8-byte float formats, u16 for rgba16f, u32 otherwise)."""
+        h, w, k, dt = self._buffer_layout(buf)
         out = np.empty((h, w, k), dtype=dt)
         self.api.call("read_buffer", self.ctx, buf, out.ctypes.data, out.nbytes)
         return out
+
+    def shape_buffer(self, buf, raw_bytes):
+        """Raw bytes of `buf` (e.g. from hk_multi_read_buffer) as the array Engine.read would return."""
+        h, w, k, dt = self._buffer_layout(buf)
+        return np.frombuffer(raw_bytes, dtype=dt).reshape(h, w, k).copy()
 
     def read_f16(self, buf):
         return self.read(buf).view(np.float16).astype(np.float32)
@@ -497,6 +516,25 @@ class Engine:
         p, n = C.c_void_p(), C.c_size_t()
         self.api.call("device_ptr", self.ctx, buf, C.byref(p), C.byref(n))
         return p.value, n.value
+
+    def allocated_bytes(self, buf):
+        return self.device_ptr(buf)[1]
+
+    # -- halo exchange inside the library (one process per GPU; bevy-hikari_amd/distributed.py does the rendezvous)
+    def comm_unique_id(self):
+        ident = (C.c_uint8 * 128)()
+        self.api.call("comm_unique_id", ident)
+        return bytes(ident)
+
+    def comm_init(self, rank, n_ranks, ident):
+        buf = (C.c_uint8 * 128).from_buffer_copy(ident)
+        self.api.call("comm_init", self.ctx, rank, n_ranks, buf)
+
+    def comm_set_history_rows(self, rows):
+        self.api.call("comm_set_history_rows", self.ctx, rows)
+
+    def comm_destroy(self):
+        self.api.call("comm_destroy", self.ctx)
 
     def stats(self):
         s = F.HkStats()
@@ -512,6 +550,12 @@ class Engine:
 
     def set_timing_mask(self, mask):
         self.api.call("set_timing_mask", self.ctx, mask)
+
+    def measure_hbm(self, bytes_per_array=1 << 30, reps=8):
+        """Empirical HBM ceiling: (copy GB/s, triad GB/s) of grid-stride float4 streams over arrays too big for the Infinity Cache."""
+        cp, tr = C.c_double(), C.c_double()
+        self.api.call("measure_hbm", self.ctx, bytes_per_array, reps, C.byref(cp), C.byref(tr))
+        return cp.value, tr.value
 
     def debug_math(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -4,6 +4,7 @@
 // writes the tone-mapped image as a PPM and/or the raw rgba16f words.
 //
 //   cornell [--size W H] [--frames N] [--bounces B] [--ratio R | --fsr R SHARPNESS] [--by-nodes] [--antialias] [--ppm out.ppm] [--raw out.bin] [--describe]
+//           [--gpus N [--devices a,b,..]]   band-sharded over N GPUs from this one process (hk_multi_*); --devices may repeat an id
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -76,6 +77,8 @@ int main(int argc, char** argv) {
   size_t frames = 8;
   HikariSettings settings;  // HikariSettings::default(), examples/cornell.rs:53
   bool by_nodes = false, describe = false, antialias = false;
+  int gpus = 1;
+  std::vector<int> devices;
   std::string ppm, raw, assets = "bevy-hikari_amd/assets";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -90,6 +93,16 @@ int main(int argc, char** argv) {
     else if (a == "--raw" && i + 1 < argc) raw = argv[++i];
     else if (a == "--assets" && i + 1 < argc) assets = argv[++i];
     else if (a == "--describe") describe = true;
+    else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
+    else if (a == "--devices" && i + 1 < argc) {
+      std::string list = argv[++i];
+      for (size_t p = 0; p < list.size();) {
+        size_t q = list.find(',', p);
+        if (q == std::string::npos) q = list.size();
+        devices.push_back(atoi(list.substr(p, q - p).c_str()));
+        p = q + 1;
+      }
+    }
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
   if (describe) {  // no GPU needed: host-side mirrors only
@@ -105,6 +118,24 @@ int main(int argc, char** argv) {
     check(hk_scene_builder_emissives(b.handle(), &em, &n_em), "emissives");
     std::printf("tlas_nodes=%u emissives=%u\n", n_nodes, n_em);
     return 0;
+  }
+  if (gpus > 1 || !devices.empty()) try {  // one process, several GPUs: the frame cut into one band per device
+    if (devices.empty()) for (int d = 0; d < gpus; ++d) devices.push_back(d);
+    HikariMultiGpuPlugin plugin(read_file(assets + "/noise_rgba8_16x64x64.bin"), devices);
+    SceneBuilder scene;
+    load_cornell(assets + "/cornell.hkscene", scene);
+    plugin.set_scene(scene);
+    Camera camera = Camera::looking_at({0.0, 1.0, 4.0}, {0.0, 1.0, 0.0}, {0.0, 1.0, 0.0}, w, h);
+    for (size_t n = 1; n <= frames; ++n) plugin.render(camera, settings, n, nullptr, antialias);
+    plugin.wait();
+    uint32_t rw = 0, rh = 0;
+    std::vector<uint8_t> tm = plugin.read(HikariPlugin::final_buffer(settings, antialias), &rw, &rh);
+    if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)tm.data(), (std::streamsize)tm.size());
+    std::printf("rendered %zu frames at %ux%u on %zu bands (output size %ux%u)\n", frames, w, h, devices.size(), rw, rh);
+    return 0;
+  } catch (const Error& e) {
+    std::fprintf(stderr, "hikari error %d: %s\n", e.code, e.what());
+    return e.code == HK_E_NO_DEVICE ? 3 : 1;
   }
   try {
     HikariPlugin plugin(read_file(assets + "/noise_rgba8_16x64x64.bin"));  // App::new().add_plugin(HikariPlugin)

@@ -388,4 +388,62 @@ class HikariPlugin {
   std::optional<Camera> previous_;
 };
 
+// The same plugin over several GPUs of one node, still ONE process and one render thread (Bevy's model): hk_multi_* cuts the
+// frame into one band per device, replicates the scene and moves the halo rows between neighbouring bands itself
+// (light.rs:689-697 is where the spatial dispatches need their neighbours' temporal reservoirs).
+class HikariMultiGpuPlugin {
+ public:
+  HikariMultiGpuPlugin(const std::vector<uint8_t>& noise_rgba8_16x64x64, const std::vector<int>& devices, uint32_t flags = 0) {
+    check(hk_multi_create((uint32_t)devices.size(), devices.data(), flags, &m_), "hk_multi_create");
+    const int rc = hk_multi_upload_noise(m_, noise_rgba8_16x64x64.data(), noise_rgba8_16x64x64.size());
+    if (rc) { hk_multi_destroy(m_); m_ = nullptr; check(rc, "hk_multi_upload_noise"); }
+  }
+  ~HikariMultiGpuPlugin() { hk_multi_destroy(m_); }
+  HikariMultiGpuPlugin(const HikariMultiGpuPlugin&) = delete;
+  HikariMultiGpuPlugin& operator=(const HikariMultiGpuPlugin&) = delete;
+  void set_scene(const SceneBuilder& b) { check(hk_multi_upload_scene(m_, b.handle()), "hk_multi_upload_scene"); }
+  void update_instances(const SceneBuilder& b) { check(hk_multi_upload_scene_instances(m_, b.handle()), "hk_multi_upload_scene_instances"); }
+  // rows of last frame's reservoirs fetched across the band borders before reprojection (0 for a static camera)
+  void set_history_rows(uint32_t rows) { check(hk_multi_set_history_rows(m_, rows), "hk_multi_set_history_rows"); }
+  size_t render(const Camera& camera, const HikariSettings& settings, std::optional<size_t> frame_number = std::nullopt, const HkLights* lights = nullptr,
+                bool antialias = false) {
+    if (camera.width != width_ || camera.height != height_ || settings.upscale.ratio() != ratio_) {
+      check(hk_multi_resize(m_, camera.width, camera.height, settings.upscale.ratio()), "hk_multi_resize");
+      width_ = camera.width;
+      height_ = camera.height;
+      ratio_ = settings.upscale.ratio();
+    }
+    const size_t n = frame_number ? *frame_number : counter_.tick();
+    const HkSettings sc = settings.to_c();
+    HkFrame frame;
+    check(hk_frame_from_settings(&sc, (uint32_t)n, &frame), "hk_frame_from_settings");
+    const HkView view = camera.view_uniform();
+    const HkPreviousView pview = previous_ ? previous_->previous_view_uniform() : camera.previous_view_uniform();
+    const HkLights l = lights ? *lights : lights_uniform();
+    check(hk_multi_frame_render(m_, &frame, &view, &pview, &l, &sc, antialias ? HK_FRAME_ANTIALIAS : 0u), "hk_multi_frame_render");
+    previous_ = camera;
+    return n;
+  }
+  void wait() { check(hk_multi_wait(m_), "hk_multi_wait"); }
+  // the union of the bands (every band's own rows)
+  std::vector<uint8_t> read(uint32_t buffer, uint32_t* w = nullptr, uint32_t* h = nullptr) const {
+    hk_ctx* c0 = nullptr;
+    check(hk_multi_context(m_, 0, &c0), "hk_multi_context");
+    uint32_t bw, bh, bpp;
+    check(hk_buffer_info(c0, buffer, &bw, &bh, &bpp), "hk_buffer_info");
+    std::vector<uint8_t> out((size_t)bw * bh * bpp);
+    check(hk_multi_read_buffer(m_, buffer, out.data(), out.size()), "hk_multi_read_buffer");
+    if (w) *w = bw;
+    if (h) *h = bh;
+    return out;
+  }
+
+ private:
+  hk_multi* m_ = nullptr;
+  FrameCounter counter_;
+  uint32_t width_ = 0, height_ = 0;
+  float ratio_ = 0.0f;
+  std::optional<Camera> previous_;
+};
+
 }  // namespace hikari

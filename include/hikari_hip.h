@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 3
+#define HK_ABI_VERSION 4
 
 /* ------------------------------------------------------------------ error codes */
 #define HK_OK 0
@@ -487,12 +487,73 @@ int hk_band_plan(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, HkHalo
 int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count,
                      uint32_t stage, uint32_t frame_number, const HkSettings* settings, HkHaloOp* ops, uint32_t* n_ops);
 
+/* One side of a halo transfer, as the executor needs it: a byte range of a buffer (the same range on both sides - buffers are
+ * allocated full-frame on every rank, so a halo row lands at the address it has on its owner) moving between this rank and
+ * `peer`. */
+typedef struct HkTransfer {
+  uint32_t buffer;   /* HkBuffer */
+  uint32_t peer;     /* rank (= band index) on the other side */
+  uint32_t is_recv;  /* 1: this rank receives rows `peer` owns; 0: this rank sends rows it owns */
+  uint32_t _pad;
+  uint64_t offset;   /* bytes from the start of the buffer */
+  uint64_t bytes;
+} HkTransfer;
+/* Every transfer rank `rank` of `n_ranks` takes part in before `stage` (hk_band_plan_for's stage argument, including
+ * HK_STAGE_TEMPORAL_WITH_HISTORY), sends AND receives, in ONE global order all ranks derive identically (the receive plans of
+ * rank 0, 1, ... in turn) - the order a transport that pairs sends with receives by issue order (RCCL) needs.  Pure host
+ * logic; out may be NULL to query the count. */
+int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint32_t rank, uint32_t n_ranks, uint32_t stage,
+                     uint32_t frame_number, const HkSettings* settings, HkTransfer* out, uint32_t* n_out);
+
+/* ------------------------------------------------------------------ halo exchange inside the boundary: one process per GPU, RCCL over xGMI */
+/* The reference's LightNode / PostProcessNode record every dispatch of a frame into one command encoder (light.rs:590-702);
+ * a sharded frame needs a neighbour exchange between the temporal and the spatial dispatches (light.rs:689-697) and before
+ * the denoiser.  With a communicator attached, hk_frame_render performs those exchanges itself, on the context's stream:
+ *   [exchange C, history rows]  TEMPORAL  exchange A  SPATIAL  exchange B  POST_PROCESS  [exchange D  ANTIALIAS  exchange E  UPSCALE]
+ * as ncclSend / ncclRecv pairs inside one ncclGroupStart / ncclGroupEnd per exchange (librccl is loaded on first use; a
+ * single-GPU host never touches it).  Rank 0 obtains the id, ships its HK_COMM_ID_BYTES bytes to the other ranks by any host
+ * channel (a Bevy app: its own launcher; bench.py: the torch.distributed store), every rank calls hk_comm_init - which also
+ * does hk_set_band(rank, n_ranks) - and then simply renders frames. */
+#define HK_COMM_ID_BYTES 128
+int hk_comm_unique_id(uint8_t id[HK_COMM_ID_BYTES]);
+int hk_comm_init(hk_ctx* ctx, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK_COMM_ID_BYTES]);
+int hk_comm_destroy(hk_ctx* ctx);
+/* rows of last frame's reservoirs / AA history fetched from the neighbours before TEMPORAL / ANTIALIAS (exchange C): the
+ * host sets what its camera / object motion needs, 0 (default) for a static view */
+int hk_comm_set_history_rows(hk_ctx* ctx, uint32_t rows);
+/* one exchange by hand (hosts that drive hk_frame_stage themselves): everything hk_band_schedule lists for `stage` */
+int hk_comm_exchange(hk_ctx* ctx, uint32_t stage, const HkSettings* settings);
+
+/* ------------------------------------------------------------------ one process, several GPUs (hk_create(n_gpus, device_ids)) */
+/* Bevy renders from ONE process and one render thread: hk_multi is the same band-sharded frame driven by a single host
+ * thread - n contexts, one per device, scene replicated, each rendering its band; halo rows move with hipMemcpyPeerAsync on
+ * the receiver's stream, ordered against the owner's stream with events (no host synchronisation inside a frame).
+ * device_ids may repeat (several bands on one GPU: how the path is tested where only one GPU exists). */
+typedef struct hk_multi hk_multi;
+int hk_multi_create(uint32_t n, const int* device_ids, uint32_t flags, hk_multi** out);
+void hk_multi_destroy(hk_multi* m);
+int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out); /* the i-th band's context (borrowed) */
+int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b);
+int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b);
+int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n_images);
+int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes);
+int hk_multi_resize(hk_multi* m, uint32_t width, uint32_t height, float upscale_ratio);
+int hk_multi_set_history_rows(hk_multi* m, uint32_t rows);
+int hk_multi_frame_render(hk_multi* m, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
+                          const HkLights* lights, const HkSettings* settings, uint32_t flags);
+int hk_multi_wait(hk_multi* m);
+/* the union of the bands: every band's own rows of `buffer` (a buffer whose rows are render rows, or full-size rows at
+ * upscale ratio 1) gathered into one host image of the buffer's full size */
+int hk_multi_read_buffer(hk_multi* m, uint32_t buffer, void* dst, size_t bytes);
+
 /* ------------------------------------------------------------------ buffer access */
 int hk_buffer_info(hk_ctx* ctx, uint32_t buffer, uint32_t* width, uint32_t* height, uint32_t* bytes_per_pixel);
 /* synchronous copies (wait for the stream first) */
 int hk_read_buffer(hk_ctx* ctx, uint32_t buffer, void* dst, size_t bytes);
 int hk_write_buffer(hk_ctx* ctx, uint32_t buffer, const void* src, size_t bytes);
-/* raw device pointer for zero-copy views (halo exchange through RCCL / torch.distributed) */
+/* raw device pointer for zero-copy views (a host that composites or exchanges the buffers itself).  *bytes = the size of the
+ * ALLOCATION, which does not depend on the upscale kind in effect (hk_buffer_info gives the logical size); the pointer is
+ * valid until the next hk_resize (and, for the double-buffered ids, names another plane after the next hk_frame_begin). */
 int hk_device_ptr(hk_ctx* ctx, uint32_t buffer, void** ptr, size_t* bytes);
 int hk_stream(hk_ctx* ctx, void** hip_stream);
 /* Enqueue all subsequent work on a HIP stream owned by the host (e.g. the stream its RCCL calls
@@ -502,6 +563,12 @@ int hk_set_stream(hk_ctx* ctx, void* hip_stream);
 int hk_set_timing_mask(hk_ctx* ctx, uint32_t pass_mask);
 int hk_get_stats(hk_ctx* ctx, HkStats* out);
 int hk_reset_stats(hk_ctx* ctx);
+
+/* Measurement hook ("measure the empirical HBM ceiling with a device copy/triad kernel in the same run"): streams
+ * three private arrays of `bytes_per_array` bytes (use >= 1 GiB: the 256 MB Infinity Cache must not hold them) `reps` times
+ * on the context's stream and returns the sustained rates in GB/s (1e9), HIP events around the launches: copy a = b moves
+ * 2 x bytes per pass, triad a = b + s * c moves 3 x bytes. */
+int hk_measure_hbm(hk_ctx* ctx, size_t bytes_per_array, uint32_t reps, double* copy_gbs, double* triad_gbs);
 
 /* Test hook: evaluate one of the library's device math routines elementwise (op: 0 sin, 1 cos,
  * 2 exp, 3 exp2, 4 log2, 5 pow(x, y), 6 min(x,y), 7 max(x,y), 8 f32->f16->f32, 9 x/y, 10 sqrt).

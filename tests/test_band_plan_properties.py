@@ -94,3 +94,30 @@ def test_band_rows_partition_the_image(size, ratio, world):
         assert b0.value == prev and b1.value > b0.value and (b0.value, b1.value) == band(rh.value, i, world)
         prev = b1.value
     assert prev == rh.value
+
+
+@settings(max_examples=80, deadline=None)
+@given(sizes, ratios, st.integers(2, 8), flags, st.integers(1, 64), st.integers(0, 6),
+       st.sampled_from([F.STAGE_TEMPORAL, F.STAGE_SPATIAL, F.STAGE_POST_PROCESS, F.STAGE_ANTIALIAS, F.STAGE_UPSCALE]))
+def test_schedules_pair_up_in_issue_order(size, ratio, world, fl, frame, history, stage):
+    """hk_band_schedule is what the transports execute (RCCL inside the library, peer copies in hk_multi, gloo in the tests).
+    RCCL pairs the sends and receives of two ranks BY ISSUE ORDER, so for every ordered pair (a -> b) the sequence of sends a
+    issues to b must be, element for element (buffer, offset, bytes), the sequence of receives b issues from a; and the
+    receives of a rank are exactly its halo plan."""
+    from bevy_hikari_amd.distributed import band_schedule
+
+    width, height = size
+    sc = make_settings(ratio, fl).to_c()
+    stage_arg = stage | ((history << 8) if stage in (F.STAGE_TEMPORAL, F.STAGE_ANTIALIAS) else 0)
+    sched = [band_schedule(width, height, ratio, r, world, stage_arg, frame, sc) for r in range(world)]
+    for a in range(world):
+        for b in range(world):
+            if a == b:
+                continue
+            sends = [(t.buffer, t.offset, t.bytes) for t in sched[a] if not t.is_recv and t.peer == b]
+            recvs = [(t.buffer, t.offset, t.bytes) for t in sched[b] if t.is_recv and t.peer == a]
+            assert sends == recvs, (a, b)
+    for r in range(world):
+        plan = sorted((o.buffer, o.peer, o.row_begin * o.row_bytes, (o.row_end - o.row_begin) * o.row_bytes) for o in halo_plan(width, height, ratio, r, world, stage_arg, frame, sc))
+        assert plan == sorted((t.buffer, t.peer, t.offset, t.bytes) for t in sched[r] if t.is_recv)
+        assert all(t.peer != r and t.bytes > 0 for t in sched[r])

@@ -21,7 +21,7 @@ def test_describe_matches_reference_constants():
     r = run("--describe")
     assert r.returncode == 0, r.stderr
     assert "graph=hikari nodes=hikari_prepass,hikari_light,hikari_post_process,hikari_overlay workgroup=8 noise=16" in r.stdout
-    assert "defaults_match_library=1 ratio=2.0 abi=3" in r.stdout      # C++ HikariSettings{} == hk_settings_default (lib.rs:435-455)
+    assert "defaults_match_library=1 ratio=2.0 abi=4" in r.stdout      # C++ HikariSettings{} == hk_settings_default (lib.rs:435-455)
     assert "tlas_nodes=22 emissives=1" in r.stdout                      # same builder result as the Python path
 
 
@@ -82,3 +82,22 @@ def test_cpp_host_fsr_matches_the_python_host(tmp_path, by_nodes):
     for n in range(1, 5):
         p.render(hk.cornell_camera(96, 64), s, frame_number=n, antialias=True)
     assert (got == p.engine.read(F.BUF_UPSCALE_SHARPENED)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bands,antialias", [(2, False), (3, True)])
+def test_cpp_host_multi_gpu_bands_equal_the_single_context_frame(tmp_path, bands, antialias):
+    """--devices 0,0[,0]: the one-process multi-GPU path (hk_multi_*: bands + peer-copy halo exchanges ordered by events) with
+    every band on device 0; the gathered image equals the single-context frame bit for bit."""
+    raw = tmp_path / "multi.bin"
+    args = ["--size", "96", "64", "--frames", "5", "--bounces", "2", "--ratio", "2.0" if antialias else "1.0", "--devices", ",".join(["0"] * bands), "--raw", str(raw)]
+    r = run(*(args + (["--antialias"] if antialias else [])))
+    assert r.returncode == 0, r.stderr
+    assert f"on {bands} bands" in r.stdout
+    got = np.fromfile(raw, dtype=np.uint16).reshape(64, 96, 4)
+    p = hk.HikariPlugin(device=0)
+    p.set_scene(hk.load_cornell())
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_2_0 if antialias else hk.Upscale.SMAA_TU_1_0)
+    for n in range(1, 6):
+        p.render(hk.cornell_camera(96, 64), s, frame_number=n, antialias=antialias)
+    assert (got == p.engine.read(F.BUF_TAA_OUTPUT if antialias else F.BUF_TONE_MAPPED)).all()

@@ -1,0 +1,106 @@
+"""The halo exchange INSIDE the boundary (include/hikari_hip.h: hk_multi_*, hk_comm_*), on the one GPU a test box has.
+
+hk_multi_*: one process drives several bands; here every band's context sits on device 0 (device ids may repeat), so the
+whole code path - per-band stages, hk_band_schedule, peer copies on the receiver's stream, the event ordering between the
+bands' streams, the gather - runs exactly as on n GPUs, and the union of the bands must equal the single-context frame bit
+for bit.  hk_comm_*: RCCL refuses two ranks on one device, so what can run here is the one-rank communicator (dlopen of
+librccl, ncclGetUniqueId, ncclCommInitRank, hk_frame_render's exchange hooks with an empty schedule)."""
+import numpy as np
+import pytest
+
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+from bevy_hikari_amd.distributed import MultiEngine
+from cases import make_case, random_case, run_case, snapshot
+
+pytestmark = pytest.mark.gpu
+
+
+def case_of(name):
+    return random_case(int(name[6:])) if name.startswith("random") else make_case(name)
+
+
+@pytest.mark.parametrize("bands,case_name", [(2, "cornell_b2"), (3, "yard_sun"), (3, "cornell_aa_default"), (4, "random12"), (2, "cornell_aa_fsr"), (8, "cornell_b2"),
+                                             (3, "random33"), (2, "yard_textured")])
+def test_multi_engine_union_equals_single_context(bands, case_name):
+    case = case_of(case_name)
+    s = case.settings
+    m = MultiEngine([0] * bands)
+    m.upload_noise()
+    m.upload_scene(case.scene)
+    w, h = case.camera.width, case.camera.height
+    m.resize(w, h, s.upscale.ratio())
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    for n in case.frames:
+        m.frame_render(hk.frame_uniform(s, n), view, pview, case.lights, s.to_c(), F.FRAME_ANTIALIAS if case.antialias else 0)
+    m.wait()
+    ref = hk.HikariPlugin(device=0)
+    run_case(ref, case)
+    e = ref.engine
+    prev = 1 - case.frames[-1] % 2
+    want = [F.BUF_TONE_MAPPED, F.BUF_RENDER0, F.BUF_RENDER0 + 1, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2, F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8,
+            F.BUF_POSITION, F.BUF_ALBEDO]
+    if s.denoise:
+        want += [F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1] + ([F.BUF_DENOISE_RENDER0 + 2] if s.indirect_bounces else [])
+    if case.antialias:
+        want += [F.BUF_TAA_OUTPUT] if s.taa == hk.Taa.Jasmine else []
+        want += [F.BUF_UPSCALE_OUTPUT] + ([F.BUF_UPSCALE_SHARPENED] if s.upscale.kind == F.UPSCALE_FSR1 else [])
+    for b in want:
+        a, r = m.read(b), e.read(b)
+        if F.BUF_RESERVOIR0 <= b < F.BUF_RESERVOIR0 + 10:   # rw x rh records inside window-size storage: compare the records
+            rw, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
+            a, r = a.reshape(-1, 16)[:rw * rh], r.reshape(-1, 16)[:rw * rh]
+        assert a.shape == r.shape and (a.view(np.uint8) == r.view(np.uint8)).all(), f"{case_name} x{bands}: buffer {b} differs"
+
+
+def test_multi_engine_history_rows_under_camera_motion():
+    """Exchange C inside the library: with the camera moving vertically, reprojection crosses the band borders; with the
+    history halo the union stays within the north star's 1e-3 of the single-context frame, without it it does not."""
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    w, h, frames = 96, 64, 8
+    cams = [hk.Camera(hk.look_at_transform((0.0, 0.4 + 0.16 * n, 4.0), (0.0, 0.4 + 0.16 * n, 0.0)), w, h) for n in range(1, frames + 1)]
+    scene = hk.load_cornell()
+
+    def run(target, history):
+        for n in range(1, frames + 1):
+            cam, prev = cams[n - 1], cams[max(n - 2, 0)]
+            if isinstance(target, MultiEngine):
+                target.set_history_rows(history if n > 1 else 0)
+            target.frame_render(hk.frame_uniform(s, n), cam.view_uniform(), cam.previous_view_uniform(prev), hk.lights_uniform(), s.to_c())
+        target.wait()
+
+    ref = hk.Engine(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)
+    ref.upload_noise(); ref.upload_scene(scene); ref.resize(w, h, 1.0)
+    run(ref, 0)
+    want = np.stack([ref.read_f16(F.BUF_DENOISE_RENDER0 + i) for i in range(3)])
+    errs = {}
+    for history in (0, 12):
+        m = MultiEngine([0, 0], flags=F.CTX_DETERMINISTIC_SCATTER)
+        m.upload_noise(); m.upload_scene(scene); m.resize(w, h, 1.0)
+        run(m, history)
+        got = np.stack([m.read(F.BUF_DENOISE_RENDER0 + i).view(np.float16).astype(np.float32) for i in range(3)])
+        errs[history] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    assert errs[12] <= 1e-3 and errs[12] < errs[0], errs
+
+
+def test_rccl_single_rank_communicator():
+    e = hk.Engine(device=0)
+    ident = e.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
+    e.comm_init(0, 1, ident)
+    case = make_case("cornell_b2")
+    e.upload_noise(); e.upload_scene(case.scene)
+    e.resize(case.camera.width, case.camera.height, 1.0)
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    for n in case.frames:
+        e.frame_render(hk.frame_uniform(case.settings, n), view, pview, case.lights, case.settings.to_c())
+    ref = hk.HikariPlugin(device=0)
+    run_case(ref, case)
+    assert (e.read(F.BUF_TONE_MAPPED) == ref.engine.read(F.BUF_TONE_MAPPED)).all()
+    e.comm_destroy()
+
+
+def test_multi_create_rejects_bad_devices():
+    with pytest.raises(hk.HikariError) as err:
+        MultiEngine([0, 99])
+    assert err.value.code == F.HK_E_NO_DEVICE

@@ -209,10 +209,7 @@ def _gpu_band_worker(rank, world, port, case_name, out_dir):
     e.upload_scene(case.scene)
     w, h = case.camera.width, case.camera.height
     e.resize(w, h, s.upscale.ratio())
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    e.set_stream(stream.cuda_stream)  # same stream discipline as bench.py
-    r = BandRenderer(e, rank, world)
+    r = BandRenderer(e, rank, world, transport="host")  # several ranks on ONE device: halos through host memory over gloo
     view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
     for n in case.frames:
         r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, antialias=case.antialias)
