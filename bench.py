@@ -233,7 +233,7 @@ def main():
         del ceng, crend
         copy_gbs, triad_gbs = xeng.measure_hbm(1 << 30, 8)
         hbm = {"copy_gbs": round(copy_gbs, 1), "triad_gbs": round(triad_gbs, 1), "bytes_per_array": 1 << 30,
-               "note": "grid-stride float4 copy (2 x 1 GiB per pass) / triad (3 x 1 GiB per pass), 8 passes each, HIP events"}
+               "note": "float4 copy (2 x 1 GiB per pass) / triad (3 x 1 GiB per pass), best of a grid-stride loop and a one-shot 4-accesses-per-lane launch, 8 passes each, HIP events"}
 
     if rank != 0:
         if dist is not None:

@@ -34,7 +34,11 @@ PASS_NAMES = ["prepass", "full_screen_albedo", "direct_lit", "direct_emissive", 
               "smaa_tu4x", "smaa_tu4x_extrapolate", "taa_jasmine", "fsr_easu", "fsr_rcas"]
 # HkStage
 STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_ANTIALIAS, STAGE_UPSCALE, STAGE_COUNT = range(6)
-CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER = 1, 2, 4, 8, 16
+#: OR-ed into the flags of every Engine / MultiEngine this process creates.  0 in the product.  The GPU test suite sets it to
+#: CTX_EXACT_TRAVERSAL (tests/conftest.py, through the environment so that spawned rank processes inherit it) because its bar is
+#: bit equality with the oracle, which walks in the reference's order.
+DEFAULT_CTX_FLAGS = int(os.environ.get("HIKARI_HIP_DEFAULT_CTX_FLAGS", "0"))
+CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER, CTX_EXACT_TRAVERSAL = 1, 2, 4, 8, 16, 32
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS = 1, 2
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1
@@ -207,6 +211,7 @@ _PRODUCT_ONLY = {
     "set_stream": [_vp, _vp],
     "set_timing_mask": [_vp, u32],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
+    "bvh_rethread": [P(HkNode), u32, u32, P(HkNode)],
     "band_schedule": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkTransfer), P(u32)],
     "comm_unique_id": [P(C.c_uint8)],
     "comm_init": [_vp, u32, u32, P(C.c_uint8)],

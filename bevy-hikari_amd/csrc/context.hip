@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <new>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "hk_internal.hpp"
@@ -44,6 +46,24 @@ __global__ __launch_bounds__(256) void k_stream_triad(float4* __restrict__ a, co
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float4 x = b[i], y = c[i];
     a[i] = make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
+  }
+}
+
+// one-shot variants: every thread moves four float4 that are a whole grid apart (four independent 16-B loads in flight per lane,
+// every wave-instruction one contiguous 1 KiB), no loop
+__global__ __launch_bounds__(256) void k_stream_copy4(float4* __restrict__ a, const float4* __restrict__ b, size_t quarter) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= quarter) return;
+  const float4 x0 = b[i], x1 = b[i + quarter], x2 = b[i + 2 * quarter], x3 = b[i + 3 * quarter];
+  a[i] = x0; a[i + quarter] = x1; a[i + 2 * quarter] = x2; a[i + 3 * quarter] = x3;
+}
+__global__ __launch_bounds__(256) void k_stream_triad4(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, float s, size_t quarter) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= quarter) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 x = b[i + k * quarter], y = c[i + k * quarter];
+    a[i + k * quarter] = make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
   }
 }
 
@@ -145,6 +165,7 @@ struct hk_ctx {
   // order, so neither the host nor the GPU waits (animated scenes must not stall on the host).
   bool two_slots = false;
   int slot = 0;
+  bool threaded = false;  // eight direction-ordered flattenings of every TLAS / BLAS are stored (hikari_hip.h HK_CTX_EXACT_TRAVERSAL)
   uint8_t* staging[2] = {nullptr, nullptr};
   size_t staging_bytes[2] = {0, 0};
   hipEvent_t staging_done[2] = {nullptr, nullptr};
@@ -354,6 +375,24 @@ size_t fold_leaf_navigators(std::vector<float4>& lo, std::vector<float4>& hi, si
 // Node indices are in 32-B units from the start of the allocation: TLAS node i is node i, BLAS node k
 // of a mesh is node blas_base + node_offset + k with blas_base = dyn_capacity / 32.
 
+// `orderings` flattenings of the reference-layout array `src` (ordering 0 = the reference's own order), each range
+// [offset, offset + count) of `ranges` re-threaded on its own (hk_bvh_rethread); a malformed range keeps the reference order
+void thread_orderings(const std::vector<HkNode>& src, const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int orderings, std::vector<std::vector<HkNode>>& out) {
+  out.assign((size_t)orderings, std::vector<HkNode>());
+  out[0] = src;
+  if (orderings <= 1) return;
+  std::vector<std::thread> workers;
+  for (int o = 1; o < orderings; ++o) {
+    out[o] = src;
+    workers.emplace_back([&, o]() {
+      for (const auto& r : ranges)
+        if (r.second && !rethread_flat_bvh(src.data() + r.first, r.second, (uint32_t)o, out[o].data() + r.first))
+          std::copy(src.begin() + r.first, src.begin() + r.first + r.second, out[o].begin() + r.first);
+    });
+  }
+  for (std::thread& w : workers) w.join();
+}
+
 // mesh-level region; fills c->node_prim_offset.  Needs the instances' mesh records to know which
 // primitive range a BLAS leaf indexes (GpuMeshIndex travels with the instance, mod.rs:147-156).
 int build_static_region(hk_ctx* c, Blob& blob, size_t& off_nodes, size_t& off_v0, size_t& off_v1, size_t& off_v2, size_t& off_vn, size_t& off_vuv) {
@@ -362,33 +401,41 @@ int build_static_region(hk_ctx* c, Blob& blob, size_t& off_nodes, size_t& off_v0
   node_prim_offset.assign(n_nodes, -1);
   for (const HkInstance& in : c->instances)
     for (uint32_t k = 0; k < in.mesh.node_count; ++k) node_prim_offset[in.mesh.node_offset + k] = in.mesh.primitive;
-  std::vector<float4> lo(n_nodes), hi(n_nodes);
-  for (size_t i = 0; i < n_nodes; ++i) {
-    const HkNode& n = c->asset_nodes[i];
-    float mn[3] = {n.min[0], n.min[1], n.min[2]}, mx[3] = {n.max[0], n.max[1], n.max[2]};
-    if (n.entry_index >= HK_BVH_LEAF_FLAG && node_prim_offset[i] >= 0) {  // light.wgsl:408-412
-      size_t prim = (size_t)node_prim_offset[i] + (n.entry_index - HK_BVH_LEAF_FLAG);
-      HK_REQUIRE(prim < n_prims, HK_E_INVALID, "BLAS leaf primitive out of bounds");
-      const HkPrimitiveVertex* v = c->primitives[prim].vertices;
-      for (int k = 0; k < 3; ++k) {
-        mn[k] = hmin(v[0].position[k], hmin(v[1].position[k], v[2].position[k]));
-        mx[k] = hmax(v[0].position[k], hmax(v[1].position[k], v[2].position[k]));
-      }
-    }
-    lo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
-    hi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
-  }
-  {  // fold single-leaf navigators, once per distinct mesh range
+  std::vector<std::pair<uint32_t, uint32_t>> ranges;  // distinct mesh ranges
+  {
     std::vector<uint8_t> done(n_nodes + 1, 0);
     for (const HkInstance& in : c->instances) {
       if (in.mesh.node_count == 0 || done[in.mesh.node_offset]) continue;
       done[in.mesh.node_offset] = 1;
-      fold_leaf_navigators(lo, hi, in.mesh.node_offset, in.mesh.node_count);
+      ranges.emplace_back(in.mesh.node_offset, in.mesh.node_count);
     }
   }
+  const int orderings = c->threaded ? 8 : 1;
+  std::vector<std::vector<HkNode>> ordered;
+  thread_orderings(c->asset_nodes, ranges, orderings, ordered);
   std::vector<float4> nodes;
-  nodes.reserve(2 * n_nodes);
-  for (size_t i = 0; i < n_nodes; ++i) { nodes.push_back(lo[i]); nodes.push_back(hi[i]); }
+  nodes.reserve(2 * n_nodes * (size_t)orderings);
+  std::vector<float4> lo(n_nodes), hi(n_nodes);
+  for (int o = 0; o < orderings; ++o) {
+    const std::vector<HkNode>& src = ordered[o];
+    for (size_t i = 0; i < n_nodes; ++i) {
+      const HkNode& n = src[i];
+      float mn[3] = {n.min[0], n.min[1], n.min[2]}, mx[3] = {n.max[0], n.max[1], n.max[2]};
+      if (n.entry_index >= HK_BVH_LEAF_FLAG && node_prim_offset[i] >= 0) {  // light.wgsl:408-412
+        size_t prim = (size_t)node_prim_offset[i] + (n.entry_index - HK_BVH_LEAF_FLAG);
+        HK_REQUIRE(prim < n_prims, HK_E_INVALID, "BLAS leaf primitive out of bounds");
+        const HkPrimitiveVertex* v = c->primitives[prim].vertices;
+        for (int k = 0; k < 3; ++k) {
+          mn[k] = hmin(v[0].position[k], hmin(v[1].position[k], v[2].position[k]));
+          mx[k] = hmax(v[0].position[k], hmax(v[1].position[k], v[2].position[k]));
+        }
+      }
+      lo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
+      hi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
+    }
+    for (const auto& r : ranges) fold_leaf_navigators(lo, hi, r.first, r.second);  // fold single-leaf navigators, once per distinct mesh range
+    for (size_t i = 0; i < n_nodes; ++i) { nodes.push_back(lo[i]); nodes.push_back(hi[i]); }
+  }
   off_nodes = blob.add(nodes);  // offset 0: the region itself starts on a 32-B boundary
 
   std::vector<float4> v0(n_prims), v1(n_prims), v2(n_prims);
@@ -417,25 +464,30 @@ struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emi
 
 int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o) {
   const size_t n_tlas = c->instance_nodes.size();
+  const int orderings = c->threaded ? 8 : 1;
+  std::vector<std::vector<HkNode>> ordered;
+  thread_orderings(c->instance_nodes, {{0u, (uint32_t)n_tlas}}, orderings, ordered);
   std::vector<float4> tlo(n_tlas), thi(n_tlas);
-  for (size_t i = 0; i < n_tlas; ++i) {
-    const HkNode& n = c->instance_nodes[i];
-    const float* mn = n.min;
-    const float* mx = n.max;
-    if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:454-457: the leaf box is the instance's world AABB
-      uint32_t inst = n.entry_index - HK_BVH_LEAF_FLAG;
-      HK_REQUIRE(inst < c->instances.size(), HK_E_INVALID, "TLAS leaf instance out of bounds");
-      mn = c->instances[inst].min;
-      mx = c->instances[inst].max;
-    }
-    tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
-    thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
-  }
-  fold_leaf_navigators(tlo, thi, 0, n_tlas);
   std::vector<float4> tlas;
-  tlas.reserve(2 * n_tlas);
-  for (size_t i = 0; i < n_tlas; ++i) { tlas.push_back(tlo[i]); tlas.push_back(thi[i]); }
-  o.tlas = blob.add(tlas);  // offset 0
+  tlas.reserve(2 * n_tlas * (size_t)orderings);
+  for (int ord = 0; ord < orderings; ++ord) {
+    for (size_t i = 0; i < n_tlas; ++i) {
+      const HkNode& n = ordered[ord][i];
+      const float* mn = n.min;
+      const float* mx = n.max;
+      if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:454-457: the leaf box is the instance's world AABB
+        uint32_t inst = n.entry_index - HK_BVH_LEAF_FLAG;
+        HK_REQUIRE(inst < c->instances.size(), HK_E_INVALID, "TLAS leaf instance out of bounds");
+        mn = c->instances[inst].min;
+        mx = c->instances[inst].max;
+      }
+      tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
+      thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
+    }
+    fold_leaf_navigators(tlo, thi, 0, n_tlas);
+    for (size_t i = 0; i < n_tlas; ++i) { tlas.push_back(tlo[i]); tlas.push_back(thi[i]); }
+  }
+  o.tlas = blob.add(tlas);  // offset 0: ordering `ord` starts at node ord * n_tlas
 
   const bool have_prev = c->prev_models.size() == 16 * c->instances.size();
   std::vector<DInstance> di(c->instances.size());
@@ -560,6 +612,16 @@ int finalize_scene(hk_ctx* c) {
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
   const size_t n_nodes = c->asset_nodes.size();
   bool need_static = c->mesh_dirty || !c->scene_mem || c->node_prim_offset.size() != n_nodes;
+  {  // direction-threaded flattenings for everything that will not be traversed from the LDS copy (an estimate of the blob size decides;
+     // a scene near the limit that ends up outside LDS without them merely walks in the reference's order)
+    const size_t est = n_nodes * 32 + c->primitives.size() * 48 + c->vertices.size() * 24 + c->instance_nodes.size() * 32 + c->instances.size() * 208 +
+                       c->materials.size() * 64 + c->emissive_nodes.size() * 32 + c->alias_table.size() * 8;
+    const bool want = !(c->flags & HK_CTX_EXACT_TRAVERSAL) && est > HK_LDS_SCENE_BYTES;
+    if (want != c->threaded) {
+      c->threaded = want;
+      need_static = true;
+    }
+  }
   for (const HkInstance& in : c->instances) {
     HK_REQUIRE((size_t)in.mesh.node_offset + in.mesh.node_count <= n_nodes, HK_E_INVALID, "instance mesh node range out of bounds");
     HK_REQUIRE(in.material < c->materials.size(), HK_E_INVALID, "instance material out of bounds");
@@ -660,6 +722,8 @@ int finalize_scene(hk_ctx* c) {
   s.emissives = (const DEmissive*)(base + o.emissives); s.alias = (const float2*)(base + o.alias);
   s.noise = c->d_noise.p;
   s.tlas_count = (uint32_t)c->instance_nodes.size();
+  s.tlas_stride = c->threaded ? (uint32_t)c->instance_nodes.size() : 0u;
+  s.blas_stride = c->threaded ? (uint32_t)c->asset_nodes.size() : 0u;
   s.light_count = (uint32_t)c->emissive_nodes.size();
   c->mesh_dirty = c->dynamic_dirty = false;
   c->static_rebuilds += need_static ? 1 : 0;
@@ -1520,18 +1584,27 @@ int hk_measure_hbm(hk_ctx* c, size_t bytes, uint32_t reps, double* copy_gbs, dou
               (e = hipMemsetAsync(d, 0, n * 16, c->stream)) != hipSuccess)) fail("hipMemsetAsync", e);
   if (!rc && ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess)) fail("hipEventCreate", e);
   const dim3 grid(256 * 32);  // 32 workgroups per CU of grid-stride work
-  for (int pass = 0; pass < 2 && !rc; ++pass) {
+  const size_t quarter = n / 4;
+  const dim3 grid4((unsigned)((quarter + 255) / 256));
+  *copy_gbs = *triad_gbs = 0.0;
+  // two access shapes per probe (a grid-stride loop; a one-shot launch with four independent 16-B accesses per lane): the
+  // ceiling is the better of the two
+  for (int pass = 0; pass < 4 && !rc; ++pass) {
+    const bool triad = pass & 1, oneshot = pass >= 2;
     for (uint32_t k = 0; k <= reps && !rc; ++k) {  // k = 0 warms up
       if (k == 1) (void)hipEventRecord(e0, c->stream);
-      if (pass == 0) hipLaunchKernelGGL(k_stream_copy, grid, dim3(256), 0, c->stream, a, (const float4*)b, n);
-      else hipLaunchKernelGGL(k_stream_triad, grid, dim3(256), 0, c->stream, a, (const float4*)b, (const float4*)d, 0.5f, n);
+      if (!triad && !oneshot) hipLaunchKernelGGL(k_stream_copy, grid, dim3(256), 0, c->stream, a, (const float4*)b, n);
+      else if (triad && !oneshot) hipLaunchKernelGGL(k_stream_triad, grid, dim3(256), 0, c->stream, a, (const float4*)b, (const float4*)d, 0.5f, n);
+      else if (!triad) hipLaunchKernelGGL(k_stream_copy4, grid4, dim3(256), 0, c->stream, a, (const float4*)b, quarter);
+      else hipLaunchKernelGGL(k_stream_triad4, grid4, dim3(256), 0, c->stream, a, (const float4*)b, (const float4*)d, 0.5f, quarter);
     }
     (void)hipEventRecord(e1, c->stream);
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { fail("hipStreamSynchronize", e); break; }
     float ms = 0.0f;
     if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) { fail("hipEventElapsedTime", e); break; }
-    const double gbs = (double)(pass == 0 ? 2 : 3) * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;
-    if (pass == 0) *copy_gbs = gbs; else *triad_gbs = gbs;
+    const double moved = (double)((oneshot ? 4 * quarter : n) * 16);
+    const double gbs = (double)(triad ? 3 : 2) * moved * reps / ((double)ms * 1e-3) / 1e9;
+    if (!triad) *copy_gbs = std::max(*copy_gbs, gbs); else *triad_gbs = std::max(*triad_gbs, gbs);
   }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);

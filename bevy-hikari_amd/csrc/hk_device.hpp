@@ -75,6 +75,9 @@ struct DScene {
   const float* __restrict__ srgb_lut;    // 256-entry sRGB -> linear table
   uint32_t n_textures;
   uint32_t tlas_count, blas_base, light_count;
+  // direction-threaded BVHs (hikari_hip.h HK_CTX_EXACT_TRAVERSAL): ordering `oct` of the TLAS starts at node oct * tlas_stride,
+  // of BLAS node k at blas_base + oct * blas_stride + k.  Both strides are 0 when only the reference's order is stored.
+  uint32_t tlas_stride, blas_stride;
   const float4* __restrict__ blob;       // all arrays above (except noise) live in [blob, blob + blob_f4)
   uint32_t blob_f4;
 };
@@ -392,13 +395,17 @@ HKD f3 local_to_world_normal(const DInstance& in, f3 n) {  // light.wgsl:324-338
   return normalize(mul(m, n));
 }
 
+// sign pattern of a ray direction: selects the flattening whose child order is the one this ray meets (strides 0: always 0)
+HKD uint32_t ray_octant(f3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
+
 // stackless skip-link walk of one BLAS, light.wgsl:400-440
 HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t node_offset, uint32_t node_count, uint32_t primitive_offset,
                          float early_distance) {
   bool intersected = false;
   uint32_t index = 0u;
+  const uint32_t nbase = sc.blas_base + ray_octant(ray.direction) * sc.blas_stride + node_offset;
   while (index < node_count) {
-    const float4* __restrict__ nd = sc.nodes + 2u * (sc.blas_base + node_offset + index);
+    const float4* __restrict__ nd = sc.nodes + 2u * (nbase + index);
     const float4 lo = nd[0];
     const float4 hi = nd[1];
     const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
@@ -455,7 +462,8 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
   hit.instance_index = HK_U32_MAX;
   hit.primitive_index = HK_U32_MAX;
   // cursor of the level being walked: node = nodes[base + index], index < limit
-  uint32_t index = 0u, limit = sc.tlas_count, base = 0u;
+  const uint32_t tlas_base = ray_octant(ray.direction) * sc.tlas_stride;
+  uint32_t index = 0u, limit = sc.tlas_count, base = tlas_base;
   uint32_t t_resume = 0u;  // TLAS index to continue with when the current BLAS is exhausted
   uint32_t prim_base = 0u, cur_instance = 0u;
   bool in_blas = false, intersected = false;
@@ -480,7 +488,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
       in_blas = false;
       index = t_resume;
       limit = sc.tlas_count;
-      base = 0u;
+      base = tlas_base;
       co = ray.origin;
       cinv = ray.inv_direction;
       continue;
@@ -532,7 +540,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
           ld = world_to_local_direction(in, ray.direction);
           cinv = 1.0f / ld;
           t_resume = index;
-          base = sc.blas_base + in.node_offset;
+          base = sc.blas_base + ray_octant(ld) * sc.blas_stride + in.node_offset;
           index = 0u;
           limit = in.node_count;
           prim_base = in.primitive;

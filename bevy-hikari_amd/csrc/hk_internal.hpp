@@ -22,6 +22,10 @@ void set_error(const char* fmt, ...);
 // flat skip-link BVH over n boxes (min xyz, max xyz) in the `bvh` 0.7.1 flatten_custom format
 std::vector<HkNode> build_flat_bvh(const std::vector<float>& boxes_min_max);
 
+// the same tree flattened for ray-direction octant `oct` (bit k set: direction component k negative); false if `nodes` is not a
+// well-formed flatten_custom array.  Indices are local to the array.
+bool rethread_flat_bvh(const HkNode* nodes, uint32_t count, uint32_t oct, HkNode* out);
+
 // bytes per pixel / full-size flag of an HkBuffer id (0 = invalid id)
 uint32_t buffer_bpp(uint32_t buffer);
 bool buffer_is_full_size(uint32_t buffer);

@@ -66,6 +66,75 @@ Aprons band_aprons(const HkSettings* st) {
   return a;
 }
 
+// ---- direction-threaded skip-link BVHs ------------------------------------------------------------------------------
+// The reference's flat BVH (`bvh` 0.7.1 flatten_custom, mod.rs:458-459) fixes ONE depth-first order: left child first,
+// whatever the ray's direction, so a closest-hit walk (light.wgsl:400-486) prunes with `t_box < hit.distance` only once it
+// has stumbled on a near hit.  The same stackless walk becomes front-to-back-ish if the array is flattened with the
+// children of every inner node in the order the ray meets them; that order depends only on the SIGNS of the ray
+// direction, so eight flattenings of the same tree - one per direction octant - cover every ray ("multiple-threaded
+// BVH"; 8 x 32 B per node is nothing next to 288 GB).  Same nodes, same boxes, same leaves: only entry / exit indices and
+// the position of a node in the array change, so a walk visits the same candidates and returns the same closest hit up
+// to exact ties between two triangles (which the visiting order breaks differently).
+bool rethread_flat_bvh(const HkNode* nodes, uint32_t count, uint32_t oct, HkNode* out) {
+  if (count == 0) return true;
+  struct Frame { uint32_t begin, end, first, second, nav_out; int stage; };
+  std::vector<Frame> stack;
+  stack.push_back({0u, count, 0u, 0u, 0u, 0});
+  uint32_t out_pos = 0;
+  auto is_leaf = [&](uint32_t i) { return nodes[i].entry_index >= HK_BVH_LEAF_FLAG; };
+  auto put_nav = [&](uint32_t at, uint32_t child, uint32_t exit_) {
+    out[at] = nodes[child];
+    out[at].entry_index = at + 1u;
+    out[at].exit_index = exit_;
+  };
+  while (!stack.empty()) {
+    Frame& f = stack.back();
+    if (f.stage == 0) {
+      if (f.end - f.begin == 1u) {  // a single leaf
+        if (!is_leaf(f.begin) || out_pos >= count) return false;
+        out[out_pos] = nodes[f.begin];
+        out[out_pos].exit_index = out_pos + 1u;
+        out_pos += 1u;
+        stack.pop_back();
+        continue;
+      }
+      const uint32_t a = f.begin;
+      if (is_leaf(a)) return false;
+      const uint32_t b = nodes[a].exit_index;
+      if (!(b > a + 1u && b < f.end) || is_leaf(b) || nodes[b].exit_index != f.end || nodes[a].entry_index != a + 1u || nodes[b].entry_index != b + 1u) return false;
+      // the axis along which the two child boxes are furthest apart; `lower` = the child met first by a ray travelling in + direction
+      int axis = 0;
+      float best = -1.0f, ca_axis = 0.0f, cb_axis = 0.0f;
+      for (int k = 0; k < 3; ++k) {
+        const float ca = nodes[a].min[k] + nodes[a].max[k], cb = nodes[b].min[k] + nodes[b].max[k];
+        const float d = fabsf(ca - cb);
+        if (d > best) { best = d; axis = k; ca_axis = ca; cb_axis = cb; }
+      }
+      const bool a_lower = ca_axis <= cb_axis;
+      const bool negative = (oct >> axis) & 1u;
+      const bool a_first = a_lower != negative;
+      f.first = a_first ? a : b;
+      f.second = a_first ? b : a;
+      f.stage = 1;
+      if (out_pos >= count) return false;
+      f.nav_out = out_pos++;
+      const Frame child{f.first + 1u, nodes[f.first].exit_index, 0u, 0u, 0u, 0};
+      stack.push_back(child);  // (invalidates f)
+    } else if (f.stage == 1) {
+      put_nav(f.nav_out, f.first, out_pos);
+      f.stage = 2;
+      if (out_pos >= count) return false;
+      f.nav_out = out_pos++;
+      const Frame child{f.second + 1u, nodes[f.second].exit_index, 0u, 0u, 0u, 0};
+      stack.push_back(child);
+    } else {
+      put_nav(f.nav_out, f.second, out_pos);
+      stack.pop_back();
+    }
+  }
+  return out_pos == count;
+}
+
 }  // namespace hk
 
 using namespace hk;
@@ -267,6 +336,12 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
     HK_REQUIRE(false, HK_E_INVALID, "ops array too small: need %u", n);
   }
   *n_ops = n;
+  return HK_OK;
+}
+
+int hk_bvh_rethread(const HkNode* nodes, uint32_t count, uint32_t octant, HkNode* out) {
+  HK_REQUIRE(nodes && out && octant < 8u && nodes != out, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(rethread_flat_bvh(nodes, count, octant, out), HK_E_INVALID, "not a flat BVH in the bvh 0.7.1 flatten_custom layout");
   return HK_OK;
 }
 

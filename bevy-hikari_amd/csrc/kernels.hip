@@ -43,6 +43,8 @@ __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
     for (uint32_t i = threadIdx.x; i < sc.blob_f4; i += 256u) hk_smem[i] = sc.blob[i];
     __syncthreads();
     DScene l = sc;
+    l.tlas_stride = 0u;  // (a scene that fits the LDS copy keeps the reference's single order: compile-time zeros, the octant arithmetic folds away)
+    l.blas_stride = 0u;
     const char* gb = reinterpret_cast<const char*>(sc.blob);
     const char* lb = reinterpret_cast<const char*>(hk_smem);
 #define HK_REBASE(field) l.field = reinterpret_cast<decltype(l.field)>(lb + (reinterpret_cast<const char*>(sc.field) - gb))

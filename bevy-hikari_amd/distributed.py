@@ -200,7 +200,7 @@ class MultiEngine:
         self.api = F.api()
         self.h = C.c_void_p()
         ids = (C.c_int * len(device_ids))(*device_ids)
-        self.api.call("multi_create", len(device_ids), ids, flags, C.byref(self.h))
+        self.api.call("multi_create", len(device_ids), ids, flags | F.DEFAULT_CTX_FLAGS, C.byref(self.h))
         self.n = len(device_ids)
         self.contexts = []
         for i in range(self.n):

@@ -400,7 +400,7 @@ class Engine:
     def __init__(self, api=None, device=0, flags=0):
         self.api = api or F.api()
         self.ctx = C.c_void_p()
-        self.api.call("create", device, flags, C.byref(self.ctx))
+        self.api.call("create", device, flags | (F.DEFAULT_CTX_FLAGS if self.api.prefix == "hk_" else 0), C.byref(self.ctx))
         self.width = self.height = 0
         self.owned = True
         self.generation = 0  # bumped by resize(): holders of device pointers / views compare it (distributed.BandRenderer)

@@ -352,6 +352,16 @@ int hk_device_count(int* count);
  * resolves the race: with it a moving camera and moving objects are bit-exact against the oracle too.  Costs three
  * extra launches and 72 B per pixel of scratch per light dispatch; not meant for production frames. */
 #define HK_CTX_DETERMINISTIC_SCATTER 16u
+/* Traversal order.  The reference walks its flat BVHs in ONE fixed depth-first order (`bvh` 0.7.1 flatten_custom: left child
+ * first, light.wgsl:400-486), which for a closest-hit ray coming "from the right" means visiting most of the tree before the
+ * near hit that would have pruned it.  For scenes too large for the LDS copy the library therefore keeps EIGHT flattenings of
+ * every TLAS / BLAS - one per sign pattern of the ray direction, children ordered the way such a ray meets them
+ * (hk_bvh_rethread) - and each ray walks the one of its octant with the same stackless loop: same nodes, boxes, leaves and
+ * per-candidate arithmetic, so the closest hit is the reference's except where two candidates tie exactly (which the order
+ * breaks differently) - parity is then the north star's 1e-3 relative L2, not bit equality.  Occlusion (any-hit) results do
+ * not depend on the order at all.  bit5 forces the reference's single order everywhere: the verification mode in which large
+ * scenes are bit-exact against the oracle too.  Scenes that fit the LDS copy (Cornell) always use the reference order. */
+#define HK_CTX_EXACT_TRAVERSAL 32u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);
 
@@ -399,6 +409,12 @@ int hk_scene_builder_instance_nodes(const hk_scene_builder* b, const HkNode** p,
 int hk_scene_builder_emissives(const hk_scene_builder* b, const HkEmissive** p, uint32_t* n);
 int hk_scene_builder_emissive_nodes(const hk_scene_builder* b, const HkNode** p, uint32_t* n);
 int hk_scene_builder_alias_table(const hk_scene_builder* b, const HkAliasEntry** p, uint32_t* n);
+
+/* The layout conversion behind HK_CTX_EXACT_TRAVERSAL's opposite (see there): `nodes[0..count)` is ONE flat BVH in the `bvh`
+ * 0.7.1 flatten_custom layout the reference produces (mod.rs:185-201,458-459; entry / exit indices local to the array);
+ * `out` receives the same tree flattened for ray-direction octant `octant` (bit k set = direction component k negative).
+ * Pure host logic. */
+int hk_bvh_rethread(const HkNode* nodes, uint32_t count, uint32_t octant, HkNode* out);
 
 /* ------------------------------------------------------------------ uploads (Prepare stage) */
 /* MeshRenderAssets::set + write_buffer, mesh.rs:43-64 (3 global buffers) */

@@ -23,6 +23,21 @@ ALL_BUFFERS.update({F.BUF_PREVIOUS_POSITION: "previous_position", F.BUF_PREVIOUS
                     F.BUF_UPSCALE_SHARPENED: "upscale_sharpened"})
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def product_default_traversal():
+    """Engines created inside use the product's default flags (direction-threaded BVHs for scenes beyond the LDS copy) instead
+    of the suite-wide HK_CTX_EXACT_TRAVERSAL (tests/conftest.py)."""
+    old = F.DEFAULT_CTX_FLAGS
+    F.DEFAULT_CTX_FLAGS = 0
+    try:
+        yield
+    finally:
+        F.DEFAULT_CTX_FLAGS = old
+
+
 class Case:
     def __init__(self, name, scene, camera, settings, lights=None, frames=(1, 2, 3, 4), antialias=False):
         self.name, self.scene, self.camera, self.settings, self.frames = name, scene, camera, settings, list(frames)

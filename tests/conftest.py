@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+# The suite's bar is BIT equality with the oracle, which walks every BVH in the reference's order: contexts are created with
+# HK_CTX_EXACT_TRAVERSAL (32) unless a test asks for the product default (cases.product_default_traversal()).  Through the
+# environment, so that the rank processes the band tests spawn inherit it.
+os.environ.setdefault("HIKARI_HIP_DEFAULT_CTX_FLAGS", "32")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

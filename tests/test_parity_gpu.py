@@ -353,6 +353,72 @@ def test_config5_full_4k_8_bounces_vs_oracle():
     assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)
 
 
+def _threaded_vs_exact(name, scene, cam, s, lights, frames, tol_pixels):
+    """The product default for scenes beyond the LDS copy - eight direction-ordered flattenings of every TLAS / BLAS, each ray
+    walking the one of its octant - against HK_CTX_EXACT_TRAVERSAL (the reference's single order, bit-exact vs the oracle in the
+    tests above) on the same frames: the north star's 1e-3 relative L2 on the output, and the fraction of pixels whose primary
+    hit (instance id) or any G-buffer byte differs - exact ties between two candidates are the only thing the order can change."""
+    from cases import product_default_traversal
+
+    exact = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS)
+    with product_default_traversal():
+        fast = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS)
+    for p in (exact, fast):
+        p.set_scene(scene)
+    for n in frames:
+        for p in (exact, fast):
+            p.render(cam, s, lights=lights, frame_number=n)
+    a, b = fast.output(s), exact.output(s)
+    rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    ia, ib = fast.engine.read(F.BUF_INSTANCE_MATERIAL), exact.engine.read(F.BUF_INSTANCE_MATERIAL)
+    pa, pb = fast.engine.read(F.BUF_POSITION), exact.engine.read(F.BUF_POSITION)
+    hit_diff = float((ia[..., 0] != ib[..., 0]).mean())
+    pos_diff = float((pa.view(np.uint32) != pb.view(np.uint32)).any(axis=2).mean())
+    sf, se = fast.engine.stats(), exact.engine.stats()
+    report = {"case": name, "rel_l2": rel, "primary_hit_instance_differs": hit_diff, "gbuffer_position_differs": pos_diff,
+              "rays": [int(sf.rays_tlas + sf.rays_blas), int(se.rays_tlas + se.rays_blas)]}
+    print("threaded vs exact traversal:", report)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        with open(os.path.join(out_dir, f"threaded_traversal_{name}.json"), "w") as f:
+            json.dump(report, f, indent=1)
+    assert rel <= 1e-3 and hit_diff <= tol_pixels and pos_diff <= 10 * tol_pixels, report
+    return report
+
+
+def test_threaded_traversal_config3_within_tolerance():
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large()
+    _threaded_vs_exact("config3_1080p", scene, synthetic_camera(1920, 1080, extent=9.0), hk.HikariSettings(indirect_bounces=3, upscale=hk.Upscale.SMAA_TU_1_0),
+                       hk.lights_uniform(directional=sun), (1, 2, 3, 4), 1e-5)
+
+
+def test_threaded_traversal_config4_within_tolerance():
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+    _threaded_vs_exact("config4_1080p", scene, synthetic_camera(1920, 1080, extent=30.0), hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0),
+                       hk.lights_uniform(directional=dict(sun, illuminance=10000.0)), (1, 2, 3), 1e-5)
+
+
+def test_threaded_traversal_flight_helmet_vs_oracle():
+    """... and against the ORACLE itself on the reference's textured asset (deep BLASes): default flags, 1e-3."""
+    from cases import product_default_traversal
+
+    case = make_case("flight_helmet")
+    with product_default_traversal():
+        gpu = hk.HikariPlugin(device=0)
+    cpu = oracle()
+    for p in (gpu, cpu):
+        run_case(p, case)
+    a, b = gpu.output(case.settings), cpu.output(case.settings)
+    rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert rel <= 1e-3, rel
+
+
 def test_city_class_4k_properties():
     """BASELINE config 4 stand-in at its full size on one GPU (seeded synthetic, ~1.5 M unique
     triangles, 2002 instances, 3840x2160, 2 bounces): determinism, dispatch row-range independence

@@ -166,3 +166,65 @@ def test_traversal_equals_brute_force():
         hits += 1
         assert inst.value != 0xFFFFFFFF and abs(t.value - bt) < 1e-3 * max(1.0, bt)
     assert hits > 150
+
+
+def _walk_always(nodes):
+    """skip-link walk that descends everywhere: the leaf visiting order of a flat BVH"""
+    i, out = 0, []
+    while i < len(nodes):
+        if nodes[i].entry_index >= LEAF:
+            out.append(nodes[i].entry_index - LEAF)
+            i = nodes[i].exit_index
+        else:
+            i = nodes[i].entry_index
+    return out
+
+
+def test_direction_threaded_flattenings(cornell):
+    """hk_bvh_rethread (the eight per-octant flattenings kept for large scenes): every flattening is a well-formed flat BVH over
+    the SAME leaves and boxes; octant 7 visits the leaves in exactly the reverse order of octant 0; and along the axis that
+    separates two siblings, the sibling visited first is the one a ray of that direction sign meets first."""
+    scene, _ = synthetic_scene(n_boxes=30, n_spheres=6, n_emitters=3)
+    api = F.api()
+    for nodes in (list(scene.instance_nodes), list(cornell.instance_nodes), list(scene.asset_nodes)[scene.instances[1].mesh.node_offset:][:scene.instances[1].mesh.node_count]):
+        n = len(nodes)
+        src = (F.HkNode * n)(*nodes)
+        n_shapes = (n + 2) // 3
+        orders = []
+        for oct in range(8):
+            out = (F.HkNode * n)()
+            api.call("bvh_rethread", src, n, oct, out)
+            got = list(out)
+            for i, nd in enumerate(got):  # structure
+                assert i < nd.exit_index <= n and (nd.entry_index >= LEAF or nd.entry_index == i + 1)
+            assert sorted(_walk_always(got)) == list(range(n_shapes))
+            # the multiset of (box, leaf id / navigator) is unchanged: same nodes, only re-linked
+            key = lambda nd: (tuple(nd.min), tuple(nd.max), nd.entry_index if nd.entry_index >= LEAF else -1)
+            assert sorted(map(key, got)) == sorted(map(key, nodes))
+            # sibling order: navigator a at i and its sibling b at exit(a) (when b is a navigator ending where the parent ends)
+            for i, a in enumerate(got):
+                j = a.exit_index
+                if a.entry_index >= LEAF or j >= n or got[j].entry_index >= LEAF:
+                    continue
+                parent_end = got[j].exit_index
+                if i > 0 and not (got[i - 1].entry_index == i and got[i - 1].exit_index == parent_end) and i != 0:
+                    continue  # (a, b) are siblings only if a is the first child of the node in front of it (or of the root)
+                ca = np.array(list(a.min)) + np.array(list(a.max))
+                cb = np.array(list(got[j].min)) + np.array(list(got[j].max))
+                axis = int(np.argmax(np.abs(ca - cb)))
+                if ca[axis] != cb[axis]:
+                    first_is_lower = ca[axis] < cb[axis]
+                    assert first_is_lower == (not (oct >> axis) & 1), (oct, i, j, axis)
+            orders.append(_walk_always(got))
+        assert orders[7] == orders[0][::-1]
+        # ordering 0 of a tree whose left children are all "lower" is not required to equal the reference order, but re-threading
+        # octant 0 twice is idempotent
+        out0 = (F.HkNode * n)()
+        api.call("bvh_rethread", src, n, 0, out0)
+        out00 = (F.HkNode * n)()
+        api.call("bvh_rethread", out0, n, 0, out00)
+        assert bytes(out0) == bytes(out00)
+    bad = (F.HkNode * 3)(*list(cornell.instance_nodes)[:3])
+    import pytest
+    with pytest.raises(F.HikariError):
+        api.call("bvh_rethread", bad, 3, 0, (F.HkNode * 3)())
