@@ -178,6 +178,12 @@ struct hk_ctx {
   int* det_winner[2] = {nullptr, nullptr};
   int* det_to[2] = {nullptr, nullptr};
   void* det_pending[2] = {nullptr, nullptr};
+  // uniform-tile store elision (hk_kernels.hpp TileMeta): one record per 8x8 tile per reservoir buffer; tile_meta_zero[k] = the
+  // device array of buffer k is known to be all zero ("contents unknown" everywhere)
+  TileMeta* tile_meta[10] = {};
+  bool tile_meta_zero[10] = {};
+  int tiles_x = 0, tiles_y = 0;
+  uint32_t elide_serial = 0;
   const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
   DevArray<uint32_t> d_noise;
   DevArray<uint32_t> d_tex_data;
@@ -269,6 +275,11 @@ int free_screen(hk_ctx* c) {
     if (c->buf[b]) (void)hipFree(c->buf[b]);
     c->buf[b] = nullptr;
     c->buf_bytes[b] = 0;
+  }
+  for (int k = 0; k < 10; ++k) {
+    if (c->tile_meta[k]) (void)hipFree(c->tile_meta[k]);
+    c->tile_meta[k] = nullptr;
+    c->tile_meta_zero[k] = false;
   }
   if (c->depth_plane) (void)hipFree(c->depth_plane);
   if (c->prev_depth_plane) (void)hipFree(c->prev_depth_plane);
@@ -789,7 +800,38 @@ LightTargets make_light_targets(const hk_ctx* c, int channel) {
   t.det_winner = c->det_winner[set];
   t.det_to = c->det_to[set];
   t.det_pending = (PackedReservoir*)c->det_pending[set];
+  t.m_current = t.m_spatial = t.m_previous_spatial = nullptr;
+  t.serial = 0;
+  t.tiles_x = c->tiles_x;
+  t.rw = c->RW;
   return t;
+}
+// Attach the tile records of the dispatch's reservoir targets (uniform-tile store elision), or - when this dispatch cannot
+// maintain them (a band of a sharded frame, a row range that does not start on a tile row) - declare the tiles of the buffers
+// it writes unknown.  `spatial_pass`: spatial_reuse reads `current` and writes `spatial` only.
+int attach_tile_meta(hk_ctx* c, LightTargets& t, int channel, bool spatial_pass, int y0, int y1) {
+  if (!c->tile_meta[0]) return HK_OK;
+  static const int T[3] = {0, 2, 6}, S[3] = {4, 4, 8};
+  const int cur = (int)(c->frame.number % 2u), prev = 1 - cur;
+  const int k_current = prev + T[channel], k_spatial = prev + S[channel], k_previous_spatial = cur + S[channel];
+  const bool maintain = c->band_count == 1 && (y0 % 8) == 0 && ((y1 % 8) == 0 || y1 == c->RH);  // whole tiles only
+  const size_t mb = (size_t)c->tiles_x * c->tiles_y * sizeof(TileMeta);
+  const int written[3] = {spatial_pass ? -1 : k_current, k_spatial, spatial_pass ? -1 : k_previous_spatial};
+  for (int k : written) {
+    if (k < 0) continue;
+    if (maintain) {
+      c->tile_meta_zero[k] = false;
+    } else if (!c->tile_meta_zero[k]) {
+      HK_HIP(hipMemsetAsync(c->tile_meta[k], 0, mb, c->stream));
+      c->tile_meta_zero[k] = true;
+    }
+  }
+  if (!maintain) return HK_OK;
+  t.m_current = c->tile_meta[k_current];
+  t.m_spatial = c->tile_meta[k_spatial];
+  t.m_previous_spatial = c->tile_meta[k_previous_spatial];
+  t.serial = ++c->elide_serial;
+  return HK_OK;
 }
 
 int ready(hk_ctx* c) {
@@ -908,7 +950,9 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     case HK_PASS_DIRECT_LIT:
     case HK_PASS_DIRECT_EMISSIVE:
     case HK_PASS_INDIRECT: {
-      const LightTargets t = make_light_targets(c, pass == HK_PASS_DIRECT_LIT ? 0 : (pass == HK_PASS_DIRECT_EMISSIVE ? 1 : 2));
+      const int channel = pass == HK_PASS_DIRECT_LIT ? 0 : (pass == HK_PASS_DIRECT_EMISSIVE ? 1 : 2);
+      LightTargets t = make_light_targets(c, channel);
+      { const int rc_ = attach_tile_meta(c, t, channel, false, y0, y1); if (rc_) return rc_; }
       const size_t px = (size_t)c->RW * c->RH;
       if (t.det_winner) {  // nothing parked, no winner: -1 everywhere
         HK_HIP(hipMemsetAsync(t.det_winner, 0xFF, px * sizeof(int), c->stream));
@@ -922,8 +966,14 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       if (t.det_winner) launch_resolve_scatter(c->stream, t, (int)px);
       break;
     }
-    case HK_PASS_EMISSIVE_SPATIAL_REUSE: launch_spatial(c->stream, true, c->scene, fr, g, make_light_targets(c, 1), y0, y1); break;
-    case HK_PASS_INDIRECT_SPATIAL_REUSE: launch_spatial(c->stream, false, c->scene, fr, g, make_light_targets(c, 2), y0, y1); break;
+    case HK_PASS_EMISSIVE_SPATIAL_REUSE:
+    case HK_PASS_INDIRECT_SPATIAL_REUSE: {
+      const int channel = pass == HK_PASS_EMISSIVE_SPATIAL_REUSE ? 1 : 2;
+      LightTargets t = make_light_targets(c, channel);
+      { const int rc_ = attach_tile_meta(c, t, channel, true, y0, y1); if (rc_) return rc_; }
+      launch_spatial(c->stream, channel == 1, c->scene, fr, g, t, y0, y1);
+      break;
+    }
     case HK_PASS_DEMODULATION: {
       HK_REQUIRE(arg < 3, HK_E_INVALID, "channel out of range");
       DemodTargets d{};
@@ -1247,6 +1297,16 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
       HK_HIP(hipMalloc((void**)&c->det_to[k], nr * sizeof(int)));
       HK_HIP(hipMalloc(&c->det_pending[k], nr * 64));
     }
+  if (!(c->flags & HK_CTX_DETERMINISTIC_SCATTER)) {  // (the verification mode parks its scatter stores: no elision there)
+    c->tiles_x = (c->RW + 7) / 8;
+    c->tiles_y = (c->RH + 7) / 8;
+    const size_t mb = (size_t)c->tiles_x * c->tiles_y * sizeof(TileMeta);
+    for (int k = 0; k < 10; ++k) {
+      HK_HIP(hipMalloc((void**)&c->tile_meta[k], mb));
+      HK_HIP(hipMemset(c->tile_meta[k], 0, mb));
+      c->tile_meta_zero[k] = true;
+    }
+  }
   HK_HIP(hipMalloc((void**)&c->depth_plane, nf * 4));
   HK_HIP(hipMemset(c->depth_plane, 0, nf * 4));
   HK_HIP(hipMalloc((void**)&c->prev_depth_plane, nf * 4));
@@ -1504,6 +1564,11 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
   { int rc_ = join_side(c); if (rc_) return rc_; }
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
+  if (buffer >= HK_BUF_RESERVOIR0 && buffer < HK_BUF_RESERVOIR0 + 10 && c->tile_meta[buffer - HK_BUF_RESERVOIR0]) {  // host-written reservoirs: tiles unknown
+    const uint32_t k = buffer - HK_BUF_RESERVOIR0;
+    HK_HIP(hipMemset(c->tile_meta[k], 0, (size_t)c->tiles_x * c->tiles_y * sizeof(TileMeta)));
+    c->tile_meta_zero[k] = true;
+  }
   if (buffer == HK_BUF_POSITION || buffer == HK_BUF_NORMAL || buffer == HK_BUF_INSTANCE_MATERIAL) c->derived_dirty = true;
   return HK_OK;
 }

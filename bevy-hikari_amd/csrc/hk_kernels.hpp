@@ -20,6 +20,19 @@ struct GBuffer {
   // writes it here (the frame path); null = the separate k_full_screen_albedo dispatch does it
   uint2* __restrict__ albedo_out;
 };
+// Uniform-tile store elision.  The reference stores a packed reservoir to up to three buffers for EVERY pixel of EVERY light
+// dispatch, background included (light.wgsl:1058-1069,1279-1287,1527-1532) - on a frame that is 64 % sky that is ~1 GB of HBM
+// writes per frame that rewrite the same constant record over itself.  Per reservoir buffer and 8x8 tile the library keeps a
+// small record: `id` = hash of the record ALL 64 slots of the tile hold, `src` = the id of the input tile that record was derived
+// from (spatial_reuse's background branch re-packs its input), `valid` = serial number of the dispatch that wrote the tile
+// uniformly (0: contents unknown / not uniform), `poison` = highest serial of a dispatch that stored into the tile from OUTSIDE
+// (the reprojected scatter stores to previous_spatial).  A wave whose 64 pixels are all background may skip its tile store iff
+// the tile already holds exactly that record: valid > poison && id == the record's id.  Contents of every buffer are therefore
+// bit for bit what they are without the elision; only redundant traffic disappears.
+struct TileMeta {
+  unsigned long long id, src;
+  uint32_t valid, poison, pad0, pad1;
+};
 // groups 5 + 6 for one light channel (light.wgsl:26-31,68-75; ping-pong light.rs:518-546)
 struct LightTargets {
   const PackedReservoir* __restrict__ previous;  // binding 0
@@ -34,6 +47,13 @@ struct LightTargets {
   int* det_winner;               // per previous_spatial slot: highest pixel index that stores to it (-1: none)
   int* det_to;                   // per pixel: the slot its parked store goes to (-1: none)
   PackedReservoir* det_pending;  // per pixel: the parked value
+  // uniform-tile store elision (TileMeta above); all null when it is off (verification mode, band-sharded or row-unaligned dispatches)
+  TileMeta* m_current;
+  TileMeta* m_spatial;
+  TileMeta* m_previous_spatial;
+  uint32_t serial;  // of this dispatch, > 0, increasing
+  int tiles_x;      // 8x8 tiles per row of the render image
+  int rw;           // render width (reservoir index = x + rw * y)
 };
 // groups 3 + 4 of the denoise pipeline (denoise.wgsl:10-28), for up to three channels per launch
 struct DemodTargets {
@@ -65,6 +85,41 @@ __device__ __forceinline__ float4 denoise_geometry(uint32_t packed_normal, float
 }
 
 struct Pixel { int x, y; bool valid; };
+
+// ---- uniform-tile store elision helpers: every call is made by ALL live lanes of a wave with wave-uniform arguments
+__device__ __forceinline__ unsigned long long record_id(const PackedReservoir& p) {
+  const uint32_t w[16] = {p.radiance.x, p.radiance.y, p.random.x, p.random.y, f2u(p.visible_position.x), f2u(p.visible_position.y), f2u(p.visible_position.z),
+                          f2u(p.visible_position.w), f2u(p.sample_position.x), f2u(p.sample_position.y), f2u(p.sample_position.z), f2u(p.sample_position.w),
+                          p.visible_normal, p.sample_normal, p.reservoir.x, p.reservoir.y};
+  unsigned long long h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    h ^= (unsigned long long)w[k] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 29;
+  }
+  return h | 1ull;
+}
+__device__ __forceinline__ bool wave_leader() { return (int)__lane_id() == __ffsll((long long)__ballot(1)) - 1; }
+// the 8x8 tile this wave covers (wave-uniform by construction of pixel_of_thread, valid lane or not)
+__device__ __forceinline__ int wave_tile(const Pixel& px, int tiles_x) {
+  const int lane = threadIdx.x & 63;
+  return ((px.y - (lane >> 3)) >> 3) * tiles_x + ((px.x - (lane & 7)) >> 3);
+}
+__device__ __forceinline__ bool tile_holds(const TileMeta* m, int tile, unsigned long long id) {
+  const TileMeta v = m[tile];
+  return v.valid > v.poison && v.id == id;
+}
+__device__ __forceinline__ void tile_mark(TileMeta* m, int tile, unsigned long long id, unsigned long long src, uint32_t serial) {
+  if (wave_leader()) {
+    m[tile].id = id;
+    m[tile].src = src;
+    m[tile].valid = serial;
+  }
+}
+__device__ __forceinline__ void tile_unknown(TileMeta* m, int tile) {
+  if (wave_leader()) m[tile].valid = 0u;
+}
 
 // A wave's 64 reservoir records, written as full cache lines.  A lane holds its pixel's 64-B record in four 16-B
 // chunks; storing them directly makes every store instruction touch 64 different lines, 16 B each, and the L2 has to

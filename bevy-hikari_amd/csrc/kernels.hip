@@ -64,6 +64,11 @@ __device__ __forceinline__ void store_previous_spatial(const LightTargets& t, in
     atomicMax(&t.det_winner[to], from);
   } else {
     store_packed(t.previous_spatial, to, v);
+    // a store into a slot some other wave's tile owns: whatever that tile's record says, it no longer holds (TileMeta::poison)
+    if (t.m_previous_spatial && to != from) {
+      const int ty = to / t.rw, tx = to - ty * t.rw;
+      atomicMax(&t.m_previous_spatial[(ty >> 3) * t.tiles_x + (tx >> 3)].poison, t.serial);
+    }
   }
 }
 __global__ __launch_bounds__(256) void k_resolve_scatter(LightTargets t, int pixels) {
@@ -342,9 +347,29 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   }
   // the per-pixel records leave as whole cache lines (store_packed_tile); every lane of the wave gets here
   uint4* lds = tile_lds[threadIdx.x >> 6];
-  store_packed_tile(lds, t.current, fr.rw, px, out, write_current);
-  store_packed_tile(lds, t.spatial, fr.rw, px, out, background);
-  store_packed_tile(lds, t.previous_spatial, fr.rw, px, out, background && !t.det_winner);
+  bool skip_current = false, skip_spatial = false, skip_previous_spatial = false;
+  if (t.m_current) {  // uniform-tile store elision (hk_kernels.hpp TileMeta)
+    const int tile = wave_tile(px, t.tiles_x);
+    const bool all_background = __ballot(px.valid && !background) == 0ull;
+    if (all_background) {  // `out` is the same record in every lane
+      const unsigned long long id = record_id(out);
+      skip_current = tile_holds(t.m_current, tile, id);
+      skip_spatial = tile_holds(t.m_spatial, tile, id);
+      skip_previous_spatial = tile_holds(t.m_previous_spatial, tile, id);
+      if (!skip_current) tile_mark(t.m_current, tile, id, 0ull, t.serial);
+      if (!skip_spatial) tile_mark(t.m_spatial, tile, id, 0ull, t.serial);
+      if (!skip_previous_spatial) tile_mark(t.m_previous_spatial, tile, id, 0ull, t.serial);
+    } else {
+      tile_unknown(t.m_current, tile);
+      if (__ballot(background) != 0ull) {  // a mixed tile: its background slots are rewritten below, the others keep older records
+        tile_unknown(t.m_spatial, tile);
+        tile_unknown(t.m_previous_spatial, tile);
+      }
+    }
+  }
+  if (!skip_current) store_packed_tile(lds, t.current, fr.rw, px, out, write_current);
+  if (!skip_spatial) store_packed_tile(lds, t.spatial, fr.rw, px, out, background);
+  if (!skip_previous_spatial) store_packed_tile(lds, t.previous_spatial, fr.rw, px, out, background && !t.det_winner);
   if (t.det_winner && background) store_previous_spatial(t, px.x + fr.rw * px.y, px.x + fr.rw * px.y, out);
   flush_counters<COUNT>(rc, 0, counters);
 }
@@ -496,11 +521,24 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
     Sample s = zero_sample();
     Reservoir r = zero_reservoir();
 
-    if (fr.indirect_bounces == 0u || depth < HK_F32_EPSILON) {  // light.wgsl:1279-1287
+    const bool background = fr.indirect_bounces == 0u || depth < HK_F32_EPSILON;
+    const bool all_background = __ballot(!background) == 0ull;  // among the wave's valid pixels
+    const int tile = wave_tile(px, t.tiles_x);
+    if (background) {  // light.wgsl:1279-1287
       const PackedReservoir pr = pack_reservoir(r);
-      store_packed(t.current, index, pr);
-      store_packed(t.spatial, index, pr);
-      store_previous_spatial(t, index, index, pr);
+      bool skip_current = false, skip_spatial = false, skip_previous_spatial = false;
+      if (t.m_current && all_background) {  // uniform-tile store elision (hk_kernels.hpp TileMeta): every lane stores the same record
+        const unsigned long long id = record_id(pr);
+        skip_current = tile_holds(t.m_current, tile, id);
+        skip_spatial = tile_holds(t.m_spatial, tile, id);
+        skip_previous_spatial = tile_holds(t.m_previous_spatial, tile, id);
+        if (!skip_current) tile_mark(t.m_current, tile, id, 0ull, t.serial);
+        if (!skip_spatial) tile_mark(t.m_spatial, tile, id, 0ull, t.serial);
+        if (!skip_previous_spatial) tile_mark(t.m_previous_spatial, tile, id, 0ull, t.serial);
+      }
+      if (!skip_current) store_packed(t.current, index, pr);
+      if (!skip_spatial) store_packed(t.spatial, index, pr);
+      if (!skip_previous_spatial) store_previous_spatial(t, index, index, pr);
       t.variance[index] = 0.0f;
       t.render[index] = make_uint2(0u, 0u);
     } else {
@@ -596,6 +634,13 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
       if (fr.temporal_reuse > 0u) store_packed(t.current, index, pack_reservoir(r));
       t.render[index] = pack_f16x4(F4(out_radiance * r.w, 1.0f));
     }
+    if (t.m_current && !all_background) {  // a tile with real pixels: no longer one record everywhere
+      tile_unknown(t.m_current, tile);
+      if (__ballot(background) != 0ull) {
+        tile_unknown(t.m_spatial, tile);
+        tile_unknown(t.m_previous_spatial, tile);
+      }
+    }
   }
   tm.flush();
   flush_counters<COUNT>(rc, 0, counters);
@@ -628,9 +673,32 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
   const f3 position = xyz(position_depth);
   const float depth = position_depth.w;
 
+  // background pixels re-pack their temporal reservoir into the spatial buffer (light.wgsl:1527-1532).  Uniform-tile store
+  // elision (hk_kernels.hpp TileMeta): a wave of background pixels whose input tile holds ONE record everywhere, and whose
+  // output tile already holds the re-pack of exactly that record, has nothing to load or store.
+  const bool background = depth < HK_F32_EPSILON;
+  const bool all_background = __ballot(!background) == 0ull;  // among the wave's valid pixels
+  const int tile = wave_tile(px, t.tiles_x);
+  unsigned long long input_id = 0ull;
+  if (t.m_current && all_background) {
+    const TileMeta in = t.m_current[tile];
+    if (in.valid > in.poison) {
+      input_id = in.id;
+      const TileMeta have = t.m_spatial[tile];
+      if (have.valid > have.poison && have.src == input_id) {
+        t.render[index] = make_uint2(0u, 0u);
+        return;
+      }
+    }
+  }
   Reservoir r = unpack_reservoir(load_packed(t.current, index));
-  if (depth < HK_F32_EPSILON) {
-    store_packed(t.spatial, index, pack_reservoir(r));
+  if (background) {
+    const PackedReservoir pr = pack_reservoir(r);
+    store_packed(t.spatial, index, pr);
+    if (t.m_spatial) {
+      if (all_background && input_id != 0ull) tile_mark(t.m_spatial, tile, record_id(pr), input_id, t.serial);
+      else tile_unknown(t.m_spatial, tile);
+    }
     t.render[index] = make_uint2(0u, 0u);
     return;
   }
@@ -749,6 +817,7 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
   r.w = (total_lum > 0.0f) ? r.w_sum / total_lum : 0.0f;
   r.lifetime += 1.0f;
   store_packed(t.spatial, index, pack_reservoir(r));
+  if (t.m_spatial) tile_unknown(t.m_spatial, tile);
   if (use_spatial_variance) t.variance[index] = reservoir_variance(r);
   t.render[index] = pack_f16x4(F4(r.w * out_radiance, 1.0f));
 }
