@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   // the per-pixel records leave as whole cache lines (store_packed_tile); every lane of the wave gets here
   uint4* lds = tile_lds[threadIdx.x >> 6];
   bool skip_current = false, skip_spatial = false, skip_previous_spatial = false;
-  if (t.m_current) {  // uniform-tile store elision (hk_kernels.hpp TileMeta)
+  if (t.m_current && __ballot(px.valid) != 0ull) {  // uniform-tile store elision (hk_kernels.hpp TileMeta); a wave entirely beyond the image edge owns no tile
     const int tile = wave_tile(px, t.tiles_x);
     const bool all_background = __ballot(px.valid && !background) == 0ull;
     if (all_background) {  // `out` is the same record in every lane
