@@ -878,8 +878,9 @@ def test_uniform_tile_store_elision_changes_no_bit():
         for p in (gpu, cpu):
             p.render(cam, s, frame_number=n)
         prev_cam, prev_eye = cam, eye
-        if static or n == 1:  # (a jump frame reprojects: the reference's scatter race is visible there, covered by the motion tests)
-            bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        if static or n == 1:  # (a jump frame reprojects: the reference's scatter race is visible there, covered by the motion tests;
+            # the previous_* planes of the frame after a jump ARE that jump frame)
+            bad = {k: v for k, v in diff_buffers(snapshot(gpu), snapshot(cpu)).items() if not k.startswith("previous_")}
             assert bad == {}, (n, bad)
     # a host write into a reservoir buffer (what the fixture replays do) must drop the tile records of that buffer
     for p in (gpu, cpu):
@@ -888,11 +889,11 @@ def test_uniform_tile_store_elision_changes_no_bit():
         r[:8, :16] = 0x3C003C00
         e.write(F.BUF_RESERVOIR0 + 8, r)
         e.write(F.BUF_RESERVOIR0 + 9, r)
-    for k in range(3):
+    for it in range(3):
         n += 1
         for p in (gpu, cpu):
             p.render(prev_cam, s, frame_number=n)
-        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        bad = {name: v for name, v in diff_buffers(snapshot(gpu), snapshot(cpu)).items() if not name.startswith("previous_") or it > 0}
         assert bad == {}, (n, bad)
     # partial-row dispatches that do not end on a tile row, then whole-frame dispatches again
     e = gpu.engine
