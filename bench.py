@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--ctx-flags", type=int, default=0, help="OR-ed into the flags of the timed contexts (64 = HK_CTX_WAVEFRONT, 128 = HK_CTX_FUSED_INDIRECT, 32 = HK_CTX_EXACT_TRAVERSAL)")
     ap.add_argument("--passes", action="store_true", help="also report a per-pass time breakdown (extra untimed frames)")
     args = ap.parse_args()
     if args.steps is None:
@@ -167,7 +168,7 @@ def main():
         return float(t.item())
 
     # ------------------------------------------------------------------ timed run
-    eng, rend = make_engine(0)
+    eng, rend = make_engine(args.ctx_flags)
     run_frames(eng, rend, 1, args.warmup)
     eng.wait()
     eng.reset_stats()
@@ -187,12 +188,13 @@ def main():
     last_frame = n0
     elapsed = float(np.median(blocks))
     st = eng.stats()
+    schedule = eng.indirect_schedule()
     ind_ms = st.pass_ms_total[F.PASS_INDIRECT] / max(1, st.pass_launches[F.PASS_INDIRECT])
     eng.set_timing_mask(0)
 
     # ------------------------------------------------------------------ ray count by deterministic replay (one block's worth of frames:
     # the camera is static and the rays per frame are counted over the LAST timed block)
-    ceng, crend = make_engine(F.CTX_COUNT_RAYS)
+    ceng, crend = make_engine(F.CTX_COUNT_RAYS | (args.ctx_flags & F.CTX_EXACT_TRAVERSAL))
     run_frames(ceng, crend, 1, last_frame - args.steps)
     ceng.wait()
     ceng.reset_stats()
@@ -200,7 +202,7 @@ def main():
     cst = ceng.stats()
     # the dominant kernel ALONE on the GPU: same frames on a single-stream context (in the timed run the two
     # direct-light dispatches share the GPU with it from a second stream, which stretches its own duration)
-    xeng, xrend = make_engine(F.CTX_SINGLE_STREAM)
+    xeng, xrend = make_engine(F.CTX_SINGLE_STREAM | args.ctx_flags)
     run_frames(xeng, xrend, 1, args.warmup)
     xeng.wait()
     xeng.reset_stats()
@@ -271,7 +273,9 @@ def main():
         "rays_per_frame": round(total_rays / args.steps, 1),
         "replay_bit_identical": same,
         "roofline": {
-            "kernel": "k_indirect (indirect_lit_ambient, light.wgsl:1263-1498)",
+            "kernel": "k_indirect (indirect_lit_ambient, light.wgsl:1263-1498)" if schedule == "fused" else
+                      "indirect_lit_ambient (light.wgsl:1263-1498) as k_wf_setup + k_wf_trace / k_wf_shade per bounce + k_wf_final: first dispatch start to last dispatch end",
+            "schedule": schedule,
             "bound": "hbm",
             "achieved": round(achieved, 3),
             "peak": HBM_PEAK_GBS,

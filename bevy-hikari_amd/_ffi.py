@@ -39,6 +39,7 @@ STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_ANTIALIAS, STAGE_UPSCAL
 #: bit equality with the oracle, which walks in the reference's order.
 DEFAULT_CTX_FLAGS = int(os.environ.get("HIKARI_HIP_DEFAULT_CTX_FLAGS", "0"))
 CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER, CTX_EXACT_TRAVERSAL = 1, 2, 4, 8, 16, 32
+CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient with >= 2 bounces (hikari_hip.h)
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS = 1, 2
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1
@@ -210,6 +211,7 @@ _PRODUCT_ONLY = {
     "stream": [_vp, P(_vp)],
     "set_stream": [_vp, _vp],
     "set_timing_mask": [_vp, u32],
+    "indirect_schedule": [_vp, P(u32)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "bvh_rethread": [P(HkNode), u32, u32, P(HkNode)],
     "band_schedule": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkTransfer), P(u32)],

@@ -206,6 +206,11 @@ struct hk_ctx {
   void* dn_extra[2][4] = {};
   float* dn_extra_var[2] = {};
   bool derived_dirty = false;
+  // scratch of the queue-based schedule of indirect_lit_ambient (hikari_hip.h HK_CTX_WAVEFRONT): ONE allocation, carved into
+  // the planes of hkd::WfBuffers on first use and again after hk_resize
+  void* wf_mem = nullptr;
+  hkd::WfBuffers wf{};
+  int compute_units = 0;
 
   // uniforms
   HkFrame frame{};
@@ -281,6 +286,9 @@ int free_screen(hk_ctx* c) {
     c->tile_meta[k] = nullptr;
     c->tile_meta_zero[k] = false;
   }
+  if (c->wf_mem) (void)hipFree(c->wf_mem);
+  c->wf_mem = nullptr;
+  c->wf = hkd::WfBuffers{};
   if (c->depth_plane) (void)hipFree(c->depth_plane);
   if (c->prev_depth_plane) (void)hipFree(c->prev_depth_plane);
   c->prev_depth_plane = nullptr;
@@ -913,6 +921,46 @@ int run_denoise_fused(hk_ctx* c, uint32_t nch, int level, int y0, int y1, bool w
   return HK_OK;
 }
 
+// Which schedule indirect_lit_ambient takes (hikari_hip.h HK_CTX_WAVEFRONT).  The counting kernels exist in the fused form only.
+bool use_wavefront(const hk_ctx* c) {
+  if (c->frame.indirect_bounces < 2u || c->frame.indirect_bounces > 60u || (c->flags & HK_CTX_COUNT_RAYS)) return false;
+  if (c->flags & HK_CTX_FUSED_INDIRECT) return false;
+  if (c->flags & HK_CTX_WAVEFRONT) return true;
+  return (size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES;
+}
+// the scratch of the queue-based schedule: allocated on first use for the current render size
+int ensure_wavefront(hk_ctx* c) {
+  const size_t cap = (size_t)c->RW * c->RH;
+  if (c->wf_mem && c->wf.cap == ((cap + 3) & ~(size_t)3)) return HK_OK;
+  if (c->wf_mem) {
+    HK_HIP(hipStreamSynchronize(c->stream));
+    HK_HIP(hipFree(c->wf_mem));
+    c->wf_mem = nullptr;
+  }
+  if (!c->compute_units) {
+    hipDeviceProp_t prop;
+    HK_HIP(hipGetDeviceProperties(&prop, c->device));
+    c->compute_units = prop.multiProcessorCount;
+  }
+  // 16-B planes first, then the 4-B arrays; every sub-array stays 16-B aligned (cap rounded up to 4)
+  const size_t n = (cap + 3) & ~(size_t)3;
+  const size_t f4_planes = 9 + 2 + 2 + 1, u32_arrays = 1 + 1 + 1 + 1 + 2 + 2;  // state, cr, sr, ch0 | pixel, sr2, ch1, sh, alive[2], shadow[2]
+  const size_t bytes = 1024 + n * (f4_planes * 16 + u32_arrays * 4);
+  HK_HIP(hipMalloc(&c->wf_mem, bytes));
+  uint8_t* p = (uint8_t*)c->wf_mem;
+  hkd::WfBuffers& w = c->wf;
+  w.ctr = (uint32_t*)p; p += 1024;
+  auto f4 = [&](size_t planes) { float4* q = (float4*)p; p += planes * n * 16; return q; };
+  auto u32 = [&](size_t arrays) { uint32_t* q = (uint32_t*)p; p += arrays * n * 4; return q; };
+  w.state = f4(9);
+  w.cr0 = f4(1); w.cr1 = f4(1); w.sr0 = f4(1); w.sr1 = f4(1); w.ch0 = f4(1);
+  w.pixel = u32(1); w.sr2 = u32(1); w.ch1 = u32(1); w.sh = u32(1);
+  w.alive[0] = u32(1); w.alive[1] = u32(1);
+  w.shadow[0] = u32(1); w.shadow[1] = u32(1);
+  w.cap = (uint32_t)n;
+  return HK_OK;
+}
+
 // make the main stream wait for what was enqueued on the side stream
 int join_side(hk_ctx* c) {
   if (!c->forked) return HK_OK;
@@ -958,7 +1006,11 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
         HK_HIP(hipMemsetAsync(t.det_winner, 0xFF, px * sizeof(int), c->stream));
         HK_HIP(hipMemsetAsync(t.det_to, 0xFF, px * sizeof(int), c->stream));
       }
-      if (pass == HK_PASS_INDIRECT)  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
+      if (pass == HK_PASS_INDIRECT && use_wavefront(c)) {
+        { const int rc_ = ensure_wavefront(c); if (rc_) return rc_; }
+        launch_indirect_wavefront(c->stream, c->scene, fr, g, t, c->wf, y0, y1, c->compute_units, timer.on ? timer.t.start : nullptr,
+                                  timer.on ? timer.t.stop : nullptr);
+      } else if (pass == HK_PASS_INDIRECT)  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
         launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, t, y0, y1, counters, timer.on ? timer.t.start : nullptr,
                         timer.on ? timer.t.stop : nullptr);
       else
@@ -1620,6 +1672,15 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   }
   return HK_OK;
 }
+int hk_indirect_schedule(hk_ctx* c, uint32_t* out) {
+  HK_REQUIRE(c && out, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(c->have_frame, HK_E_NOT_READY, "hk_frame_begin has not been called");
+  HK_HIP(hipSetDevice(c->device));
+  { const int rc = finalize_scene(c); if (rc) return rc; }
+  *out = use_wavefront(c) ? 1u : 0u;
+  return HK_OK;
+}
+
 int hk_reset_stats(hk_ctx* c) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   HK_HIP(hipSetDevice(c->device));

@@ -55,6 +55,42 @@ struct LightTargets {
   int tiles_x;      // 8x8 tiles per row of the render image
   int rw;           // render width (reservoir index = x + rw * y)
 };
+// The queue-based schedule of indirect_lit_ambient (kernels_wavefront.hip): what a path carries from stage to stage, in
+// planes indexed by path slot, plus the ray queues and their counters.  `cap` = the most paths one dispatch can have
+// (the pixels of the render image).
+struct WfBuffers {
+  uint32_t* ctr;       // 192 counters, zeroed per dispatch: [s] paths alive at bounce s, [64 + s] shadow rays / [128 + s] claimed rays of trace stage s
+  uint32_t* pixel;     // [slot] x + rw * y
+  float4* state;       // 9 planes of `cap`: random | position, pdf | normal, pending | transport | radiance | first hit position | first hit normal | radiance to add if the shadow ray is clear | if it is occluded
+  float4 *cr0, *cr1;   // closest-hit ray of the bounce: (origin, -), (direction, pdf of the direction)
+  float4 *sr0, *sr1;   // shadow ray of the bounce: (origin, max_distance), (direction, early-out distance)
+  uint32_t* sr2;       // ... and the instance its walk excludes (the sampled emitter)
+  float4* ch0;         // closest hit: (distance, u, v, primitive index bits)
+  uint32_t* ch1;       // ... its instance index (U32_MAX: miss)
+  uint32_t* sh;        // instance the shadow ray hit (U32_MAX: clear)
+  uint32_t* alive[2];  // slots alive at a bounce (= the closest-hit rays of that bounce's trace stage), ping-pong
+  uint32_t* shadow[2]; // slots whose shadow ray the trace stage walks, ping-pong
+  uint32_t cap;
+};
+// Instance motion on the device (kernels_scene.hip): the arrays of the instance-level region the refit kernels rewrite, plus
+// the refit's own side arrays.
+struct RefitUpdate {       // one record per instance whose transform changed (read from pinned host memory)
+  uint32_t instance;
+  uint32_t moved;          // 0: the instance moved in the previous update but not in this one (its `moved` flag is cleared)
+  float model[16];         // new model matrix, column-major
+  float aabb_center[3], aabb_half[3];  // the mesh's local box (bevy Aabb), instance.rs:286-296
+};
+struct RefitScene {
+  DInstance* instances;
+  float4* prev_models;                   // 4 columns per instance
+  float4 *inst_lo, *inst_hi;             // world AABB per instance
+  const uint32_t* emissive_of_instance;  // emitter index or U32_MAX
+  DEmissive* emissives;
+  float2* alias;
+  float* alias_scratch;                  // 5 floats per alias entry
+  const float4* materials;
+  const float4 *tri_v0, *tri_v1, *tri_v2;
+};
 // groups 3 + 4 of the denoise pipeline (denoise.wgsl:10-28), for up to three channels per launch
 struct DemodTargets {
   const uint2* __restrict__ albedo;     // rgba16f, full size
@@ -190,6 +226,13 @@ void launch_direct(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, con
                    int y0, int y1, unsigned long long* counters);
 void launch_indirect(hipStream_t st, bool multiple_bounces, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g,
                      const hkd::LightTargets& t, int y0, int y1, unsigned long long* counters, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+// the same dispatch as launch_indirect(multiple_bounces = true), scheduled through ray queues (kernels_wavefront.hip)
+void launch_indirect_wavefront(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
+                               const hkd::WfBuffers& w, int y0, int y1, int compute_units, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+void launch_copy_region(hipStream_t st, void* dst, const void* src, size_t bytes);
+void launch_gather_instance_boxes(hipStream_t st, const hkd::RefitScene& s, const float4* tlas, uint32_t tlas_count);
+void launch_refit(hipStream_t st, const hkd::RefitScene& s, const hkd::RefitUpdate* updates, uint32_t n_updates, uint32_t* failed, float4* tlas,
+                  uint32_t tlas_count, uint32_t orderings, float4* light_lo, float4* light_hi, uint32_t light_count);
 void launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                     int y0, int y1);
 void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);

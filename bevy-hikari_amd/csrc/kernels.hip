@@ -26,72 +26,15 @@
 
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
+#include "hk_light.hpp"
 
 namespace hkd {
 
-// Small scenes (the whole Cornell box is 9 KB) are copied into LDS once per workgroup and traversed
-// from there: a node step is then a ds_read_b128 pair (~64-cycle latency, 128+ B/clk/CU) instead of
-// an L1-hit global load (~120+ cycles) in the dependent load -> slab test -> next-index chain.
-// (Skipping the copy in workgroups whose pixels are all background - 63 % of the Cornell frame - was measured and
-// rejected: the vote needs the depth first, which puts an HBM round trip in front of the copy; 0.417 vs 0.38 ms.)
-template <bool LDS>
-__device__ __forceinline__ DScene stage_scene(const DScene& sc) {
-  if constexpr (!LDS) {
-    return sc;
-  } else {
-    extern __shared__ __attribute__((aligned(16))) float4 hk_smem[];
-    for (uint32_t i = threadIdx.x; i < sc.blob_f4; i += 256u) hk_smem[i] = sc.blob[i];
-    __syncthreads();
-    DScene l = sc;
-    l.tlas_stride = 0u;  // (a scene that fits the LDS copy keeps the reference's single order: compile-time zeros, the octant arithmetic folds away)
-    l.blas_stride = 0u;
-    const char* gb = reinterpret_cast<const char*>(sc.blob);
-    const char* lb = reinterpret_cast<const char*>(hk_smem);
-#define HK_REBASE(field) l.field = reinterpret_cast<decltype(l.field)>(lb + (reinterpret_cast<const char*>(sc.field) - gb))
-    HK_REBASE(nodes); HK_REBASE(instances);
-    HK_REBASE(tri_v0); HK_REBASE(tri_v1); HK_REBASE(tri_v2); HK_REBASE(vtx_normal); HK_REBASE(vtx_uv);
-    HK_REBASE(materials); HK_REBASE(tex_info); HK_REBASE(srgb_lut); HK_REBASE(light_lo); HK_REBASE(light_hi); HK_REBASE(emissives); HK_REBASE(alias);
-#undef HK_REBASE
-    return l;
-  }
-}
-
-// every store to previous_spatial goes through here: the reference lets them race; the verification mode parks them
-__device__ __forceinline__ void store_previous_spatial(const LightTargets& t, int from, int to, const PackedReservoir& v) {
-  if (t.det_winner) {
-    store_packed(t.det_pending, from, v);
-    t.det_to[from] = to;
-    atomicMax(&t.det_winner[to], from);
-  } else {
-    store_packed(t.previous_spatial, to, v);
-    // a store into a slot some other wave's tile owns: whatever that tile's record says, it no longer holds (TileMeta::poison)
-    if (t.m_previous_spatial && to != from) {
-      const int ty = to / t.rw, tx = to - ty * t.rw;
-      atomicMax(&t.m_previous_spatial[(ty >> 3) * t.tiles_x + (tx >> 3)].poison, t.serial);
-    }
-  }
-}
 __global__ __launch_bounds__(256) void k_resolve_scatter(LightTargets t, int pixels) {
   const int i = (int)(blockIdx.x * 256u + threadIdx.x);
   if (i >= pixels) return;
   const int to = t.det_to[i];
   if (to >= 0 && t.det_winner[to] == i) store_packed(t.previous_spatial, to, load_packed(t.det_pending, i));
-}
-
-template <bool COUNT>
-__device__ __forceinline__ void flush_counters(const RayCounters& rc, uint32_t primary, unsigned long long* counters) {
-  if (!COUNT) return;
-  uint32_t a = rc.tlas, b = rc.blas, c = primary;
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_down(a, off);
-    b += __shfl_down(b, off);
-    c += __shfl_down(c, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (c) atomicAdd(&counters[0], (unsigned long long)c);
-    if (a) atomicAdd(&counters[1], (unsigned long long)a);
-    if (b) atomicAdd(&counters[2], (unsigned long long)b);
-  }
 }
 
 // ------------------------------------------------------------------ prepass by primary rays
@@ -469,6 +412,35 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
     const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
     const f3 bounce_view_direction = normalize(p.position - sample_position);
 
+#ifdef HK_BOTH_OUTCOMES
+    // A shadow ray only selects between two radiance values (kernels_wavefront.hip, header): both are evaluated BEFORE the
+    // walk, and so is the throughput update, so the walk runs with the path state and six floats live instead of the
+    // surface, the candidate and the hit info.  Same operations on the same operands, same order of the additions.
+    const f3 next_transport = p.transport * env_brdf(bounce_view_direction, sample_normal, surface);
+    if (dot(candidate.direction, sample_normal) > 0.0f && candidate.p > 0.0f) {
+      ray.origin = sample_position + sample_normal * HK_RAY_BIAS;
+      ray.direction = candidate.direction;
+      ray.inv_direction = 1.0f / ray.direction;
+      const f4 in_clear = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
+      f3 add[2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const f4 in_radiance = o == 0 ? in_clear : F4(0.0f, 0.0f, 0.0f, 1.0f);
+        out_radiance = shading(fr, bounce_view_direction, sample_normal, ray.direction, surface, in_radiance);
+        out_radiance = out_radiance / candidate.p;
+        if (n > 0u) out_radiance = (rand_sample.w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample.w;
+        float out_luminance = luminance(out_radiance);
+        if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
+        add[o] = p.transport * out_radiance;
+      }
+      HK_SEC(tm, 6);
+      HK_ABLATE_WALK(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+      hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+      HK_SEC(tm, 7);
+      p.radiance = p.radiance + F4(hit.instance_index != HK_U32_MAX ? add[1] : add[0], 1.0f);
+    }
+    p.transport = next_transport;
+#else
     if (dot(candidate.direction, sample_normal) > 0.0f && candidate.p > 0.0f) {
       ray.origin = sample_position + sample_normal * HK_RAY_BIAS;
       ray.direction = candidate.direction;
@@ -487,6 +459,7 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
       p.radiance = p.radiance + F4(p.transport * out_radiance, 1.0f);
     }
     p.transport = p.transport * env_brdf(bounce_view_direction, sample_normal, surface);
+#endif
     p.random = fract(p.random + fr.number_golden);
     p.position = sample_position;
     p.normal = sample_normal;
@@ -574,6 +547,29 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
         s.sample_position = p.first_position;
         s.sample_normal = p.first_normal;
         pdf = p.pdf;
+#ifdef HK_TAIL_RELOAD
+        // The pixel's G-buffer record and noise sample are read AGAIN for the temporal tail instead of being carried through
+        // the bounce loop (~20 registers a lane does not have: the kernel sits at the 128-VGPR ceiling with spills): the same
+        // loads and operations as in the prologue give the same values.  The opaque copy of the index keeps the compiler from
+        // merging the two reads.
+        {
+          int didx2 = didx, x2 = x, y2 = y;
+          asm volatile("" : "+v"(didx2), "+v"(x2), "+v"(y2));
+          const float4 pd2 = g.position[didx2];
+          const float2 imf2 = g.instance_material[didx2];
+          Sample s2 = zero_sample();
+          s2.random = noise_fetch(sc, x2, y2, fr.number);
+          s2.random = fract(s2.random + fr.number_golden);
+          s2.visible_position = F4(pd2);
+          s2.visible_normal = normalize(xyz(unpack4x8snorm(g.normal[didx2])));
+          s2.visible_instance = f32_to_u32(imf2.x);
+          s2.radiance = s.radiance;
+          s2.sample_position = s.sample_position;
+          s2.sample_normal = s.sample_normal;
+          HK_SEC(tm, 8);
+          indirect_temporal_tail(sc, fr, t, x2 + fr.rw * y2, coords_to_uv(fr, x2, y2), xyz(F4(pd2)), g.velocity_uv[didx2], f32_to_u32(imf2.y), s2, pdf);
+        }
+#endif
       } else {  // light.wgsl:1395-1450
         f4 rand_sample = sample_cosine_hemisphere(F2(s.random.x, s.random.y));
         ray.origin = xyz(s.visible_position) + s.visible_normal * HK_RAY_BIAS;
@@ -609,30 +605,13 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
       }
 
       // ReSTIR: temporal, light.wgsl:1452-1497
-      HK_SEC(tm, 8);
-      const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
-      r = load_reservoir_uv(t.previous, previous_uv, fr.rw, fr.rh);
-      if (!check_previous_reservoir(r, s) && fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f) {
-        const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
-        store_previous_spatial(t, index, previous_index, pack_reservoir(r));
+#ifdef HK_TAIL_RELOAD
+      if (!MULTIPLE_BOUNCES)
+#endif
+      {
+        HK_SEC(tm, 8);
+        indirect_temporal_tail(sc, fr, t, index, uv, position, velocity_uv, im_y, s, pdf);
       }
-      surface = retreive_surface(sc, im_y, F2(velocity_uv.z, velocity_uv.w));
-      const f3 view_direction = calculate_view(fr, position);
-      f3 sample_radiance = shading(fr, view_direction, s.visible_normal, normalize(xyz(s.sample_position) - xyz(s.visible_position)), surface, s.radiance);
-      float w_new = (pdf > 0.0f) ? luminance(sample_radiance) / pdf : 0.0f;
-      temporal_restir(r, s, w_new, fr.max_temporal_reuse_count);
-
-      f3 out_radiance = shading(fr, view_direction, r.s.visible_normal, normalize(xyz(r.s.sample_position) - xyz(r.s.visible_position)), surface, r.s.radiance);
-      float total_lum = r.count * luminance(out_radiance);
-      r.w = (total_lum > 0.0f) ? r.w_sum / total_lum : 0.0f;
-      r.s.visible_position = s.visible_position;
-      r.s.visible_normal = s.visible_normal;
-      r.lifetime += 1.0f;
-
-      HK_SEC(tm, 9);
-      t.variance[index] = reservoir_variance(r);
-      if (fr.temporal_reuse > 0u) store_packed(t.current, index, pack_reservoir(r));
-      t.render[index] = pack_f16x4(F4(out_radiance * r.w, 1.0f));
     }
     if (t.m_current && !all_background) {  // a tile with real pixels: no longer one record everywhere
       tile_unknown(t.m_current, tile);

@@ -1,0 +1,268 @@
+// kernels_scene.hip - instance motion on the device (reference: prepare_instances, instance.rs:286-437).
+//
+// When an instance moves the reference recomputes, on the CPU, its world AABB and inverse-transpose matrix
+// (instance.rs:286-325), the emitter record that follows from them (position, radius, surface area, alias table:
+// instance.rs:380-420) and then REBUILDS both acceleration structures - `BVH::build` over all instances and over all
+// emitters (instance.rs:365-371,422-428) - before re-uploading every buffer.  Here the per-instance work runs in one
+// kernel over the moved instances, reading their new model matrices straight from pinned host memory, and the two
+// trees are REFIT in place: same topology (in all eight direction-threaded orderings), every inner box recomputed as the
+// union of the leaf boxes below it.  No tree is built and no scene buffer crosses PCIe; the host keeps re-building the
+// reference's SAH tree at its leisure (hk_upload_scene_instances, asynchronous) when motion has degraded the refit one.
+//
+// Exactness: everything per instance is the host builder's arithmetic (scene_builder.cpp) operation for operation -
+// the double-precision cofactor inverse rounded once, the 8-corner AABB seeded at zero, 0.5 * |cross| triangle areas
+// summed in order, the alias-table construction of mod.rs:320-376 - so a refit scene equals what the host path would
+// upload for the same tree shape, bit for bit (tests/test_device_refit.py feeds the oracle exactly that).
+#include <hip/hip_runtime.h>
+
+#include "hk_device.hpp"
+#include "hk_kernels.hpp"
+
+namespace hkd {
+
+namespace {
+__device__ __forceinline__ void mat_point(const float* m, const float* p, float* out) {  // glam Mat4::transform_point3
+  for (int k = 0; k < 3; ++k) out[k] = m[k] * p[0] + m[4 + k] * p[1] + m[8 + k] * p[2] + m[12 + k];
+}
+__device__ __forceinline__ void mat_vector(const float* m, const float* p, float* out) {  // glam Mat4::transform_vector3
+  for (int k = 0; k < 3; ++k) out[k] = m[k] * p[0] + m[4 + k] * p[1] + m[8 + k] * p[2];
+}
+// inverse().transpose() in double, rounded once: scene_builder.cpp inverse_transpose, term for term
+__device__ bool inverse_transpose(const float* m, float* out) {
+  double a[16], inv[16];
+  for (int i = 0; i < 16; ++i) a[i] = m[i];
+  inv[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+  inv[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+  inv[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+  inv[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+  inv[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+  inv[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+  inv[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+  inv[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+  inv[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+  inv[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+  inv[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+  inv[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+  inv[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+  inv[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+  inv[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+  inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+  const double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
+  if (det == 0.0) return false;
+  const double id = 1.0 / det;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) out[c * 4 + r] = (float)(inv[r * 4 + c] * id);
+  return true;
+}
+__device__ __forceinline__ float hmin(float a, float b) { return b < a ? b : a; }  // std::min / std::max of the host builder
+__device__ __forceinline__ float hmax(float a, float b) { return a < b ? b : a; }
+}  // namespace
+
+// ------------------------------------------------------------------ per moved instance (instance.rs:286-325,380-420)
+// One thread per update record.  `failed` receives 1 + instance id of a singular transform (the record is skipped).
+__global__ __launch_bounds__(64) void k_refit_instances(RefitScene s, const RefitUpdate* __restrict__ updates, uint32_t n_updates, uint32_t* failed) {
+  const uint32_t u = blockIdx.x * 64u + threadIdx.x;
+  if (u >= n_updates) return;
+  const RefitUpdate up = updates[u];
+  const uint32_t id = up.instance;
+  DInstance& d = s.instances[id];
+  if (up.moved == 0u) {  // moved last time, at rest now: its previous model is its model (PreviousMeshUniform)
+    d.moved = 0u;
+    return;
+  }
+  float itm[16];
+  if (!inverse_transpose(up.model, itm)) {
+    atomicMax(failed, id + 1u);
+    return;
+  }
+  // previous model = the model this instance was rendered with so far (prepass.wgsl:50,96)
+  s.prev_models[4u * id + 0u] = d.m0;
+  s.prev_models[4u * id + 1u] = d.m1;
+  s.prev_models[4u * id + 2u] = d.m2;
+  s.prev_models[4u * id + 3u] = d.m3;
+  const float* m = up.model;
+  d.im0 = make_float4(itm[0], itm[4], itm[8], itm[12]);  // context.hip build_dynamic_region
+  d.im1 = make_float4(itm[1], itm[5], itm[9], itm[13]);
+  d.im2 = make_float4(itm[2], itm[6], itm[10], itm[14]);
+  d.im3 = make_float4(itm[3], itm[7], itm[11], itm[15]);
+  d.m0 = make_float4(m[0], m[1], m[2], m[3]);
+  d.m1 = make_float4(m[4], m[5], m[6], m[7]);
+  d.m2 = make_float4(m[8], m[9], m[10], m[11]);
+  d.m3 = make_float4(m[12], m[13], m[14], m[15]);
+  d.n0 = make_float4(itm[0], itm[1], itm[2], 0.0f);
+  d.n1 = make_float4(itm[4], itm[5], itm[6], 0.0f);
+  d.n2 = make_float4(itm[8], itm[9], itm[10], 0.0f);
+  d.moved = 1u;
+  // world AABB: the mesh box's 8 corners as vectors, min / max seeded at zero, then the centre added (instance.rs:286-305)
+  float center[3];
+  mat_point(m, up.aabb_center, center);
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  for (int corner = 0; corner < 8; ++corner) {
+    const float e[3] = {up.aabb_half[0] * (float)(2 * (corner & 1) - 1), up.aabb_half[1] * (float)(2 * ((corner >> 1) & 1) - 1),
+                        up.aabb_half[2] * (float)(2 * ((corner >> 2) & 1) - 1)};
+    float t[3];
+    mat_vector(m, e, t);
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = hmin(mn[k], t[k]);
+      mx[k] = hmax(mx[k], t[k]);
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    mn[k] = mn[k] + center[k];
+    mx[k] = mx[k] + center[k];
+  }
+  s.inst_lo[id] = make_float4(mn[0], mn[1], mn[2], 0.0f);
+  s.inst_hi[id] = make_float4(mx[0], mx[1], mx[2], 0.0f);
+  const uint32_t e = s.emissive_of_instance[id];
+  if (e == HK_U32_MAX) return;
+  // the emitter record, instance.rs:380-420
+  DEmissive& em = s.emissives[e];
+  const float4 col = s.materials[4u * d.material + 1u];
+  const float intensity = 255.0f * col.w * sqrtf(col.x * col.x + col.y * col.y + col.z * col.z);
+  float pos[3], d2 = 0.0f;
+  for (int k = 0; k < 3; ++k) {
+    pos[k] = 0.5f * (mx[k] + mn[k]);
+    const float dd = mx[k] - mn[k];
+    d2 += dd * dd;
+  }
+  const float radius = 0.5f * sqrtf(d2) + sqrtf(intensity);
+  em.position_radius = make_float4(pos[0], pos[1], pos[2], radius);
+  // GpuMesh::transformed_primitive_areas (mod.rs:307-318) and build_alias_table (mod.rs:320-376) on this emitter's triangles
+  const uint32_t n = em.alias_count;  // = the mesh's triangle count
+  float* areas = s.alias_scratch + 5u * (size_t)em.alias_offset;  // [n] areas, then the two stacks (id, prob) x 2
+  uint32_t* over_id = reinterpret_cast<uint32_t*>(areas + n);
+  float* over_p = areas + 2u * n;
+  uint32_t* under_id = reinterpret_cast<uint32_t*>(areas + 3u * n);
+  float* under_p = areas + 4u * n;
+  float surface_area = 0.0f;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t prim = d.primitive + i;
+    const float4 q0 = s.tri_v0[prim], q1 = s.tri_v1[prim], q2 = s.tri_v2[prim];
+    const float l0[3] = {q0.x, q0.y, q0.z}, l1[3] = {q1.x, q1.y, q1.z}, l2[3] = {q2.x, q2.y, q2.z};
+    float v0[3], v1[3], v2[3];
+    mat_point(m, l0, v0);
+    mat_point(m, l1, v1);
+    mat_point(m, l2, v2);
+    const float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const float b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    const float c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const float area = 0.5f * fabsf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]));
+    areas[i] = area;
+    surface_area += area;
+  }
+  em.surface_area = surface_area;
+  const float mean_area = surface_area / (float)n;
+  uint32_t n_over = 0u, n_under = 0u;
+  for (uint32_t i = 0; i < n; ++i) {
+    const float p = areas[i] / mean_area;
+    if (p > 1.0f) { over_id[n_over] = i; over_p[n_over] = p; ++n_over; }
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    const float p = areas[i] / mean_area;
+    if (p < 1.0f) { under_id[n_under] = i; under_p[n_under] = p; ++n_under; }
+  }
+  float2* table = s.alias + em.alias_offset;
+  for (uint32_t i = 0; i < n; ++i) table[i] = make_float2(0.0f, u2f(i));
+  while (n_under != 0u && n_over != 0u) {
+    --n_over;
+    const uint32_t oid = over_id[n_over];
+    float op = over_p[n_over];
+    --n_under;
+    const uint32_t uid = under_id[n_under];
+    const float upb = under_p[n_under];
+    const float delta = 1.0f - upb;
+    op -= delta;
+    if (op > 1.0f) { over_id[n_over] = oid; over_p[n_over] = op; ++n_over; }
+    else if (op < 1.0f) { under_id[n_under] = oid; under_p[n_under] = op; ++n_under; }
+    table[uid] = make_float2(delta, u2f(oid));
+  }
+}
+
+// ------------------------------------------------------------------ refit of a flat skip-link BVH
+// One WAVE per node.  A node whose entry carries the leaf flag (a leaf, or a navigator that took over its single leaf's role:
+// context.hip fold_leaf_navigators) gets its shape's box; every other node is the navigator of the subtree stored in
+// (i, exit): the union of the leaf boxes in that range - min / max are exact, so the order of the union does not matter.
+// LIGHT = the light BVH (leaf box = emitter position -/+ radius, light.wgsl:633-636), else the TLAS (leaf box = the
+// instance's world AABB, light.wgsl:454-457).  `count` nodes per ordering, `orderings` orderings back to back.
+template <bool LIGHT>
+__global__ __launch_bounds__(256) void k_refit_flat_bvh(RefitScene s, float4* lo, float4* hi, uint32_t stride /* float4 between lo of consecutive nodes */,
+                                                        uint32_t count, uint32_t orderings) {
+  const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (wave >= count * orderings) return;
+  const uint32_t ord = wave / count, i = wave - ord * count;
+  float4* nlo = lo + (size_t)ord * count * stride;
+  float4* nhi = hi + (size_t)ord * count * stride;
+  auto shape_box = [&](uint32_t shape, f3& mn, f3& mx) {
+    if (LIGHT) {
+      const float4 pr = s.emissives[shape].position_radius;
+      mn = F3(pr.x - pr.w, pr.y - pr.w, pr.z - pr.w);
+      mx = F3(pr.x + pr.w, pr.y + pr.w, pr.z + pr.w);
+    } else {
+      mn = xyz(F4(s.inst_lo[shape]));
+      mx = xyz(F4(s.inst_hi[shape]));
+    }
+  };
+  const uint32_t entry = f2u(nlo[(size_t)i * stride].w), exit_ = f2u(nhi[(size_t)i * stride].w);
+  f3 mn = F3(INFINITY, INFINITY, INFINITY), mx = F3(-INFINITY, -INFINITY, -INFINITY);
+  if (entry >= HK_LEAF) {
+    shape_box(entry - HK_LEAF, mn, mx);
+  } else {
+    for (uint32_t k = i + 1u + lane; k < exit_ && k < count; k += 64u) {
+      const uint32_t e = f2u(nlo[(size_t)k * stride].w);
+      if (e < HK_LEAF) continue;
+      f3 a, b;
+      shape_box(e - HK_LEAF, a, b);
+      mn = F3(hmin(mn.x, a.x), hmin(mn.y, a.y), hmin(mn.z, a.z));
+      mx = F3(hmax(mx.x, b.x), hmax(mx.y, b.y), hmax(mx.z, b.z));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = F3(hmin(mn.x, __shfl_xor(mn.x, off)), hmin(mn.y, __shfl_xor(mn.y, off)), hmin(mn.z, __shfl_xor(mn.z, off)));
+      mx = F3(hmax(mx.x, __shfl_xor(mx.x, off)), hmax(mx.y, __shfl_xor(mx.y, off)), hmax(mx.z, __shfl_xor(mx.z, off)));
+    }
+  }
+  if (lane == 0u) {
+    nlo[(size_t)i * stride] = make_float4(mn.x, mn.y, mn.z, u2f(entry));
+    nhi[(size_t)i * stride] = make_float4(mx.x, mx.y, mx.z, u2f(exit_));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_copy_region_u4(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
+// world AABB of every instance, from the TLAS leaves of ordering 0 (after a host upload: the refit reads them from here)
+__global__ __launch_bounds__(256) void k_gather_instance_boxes(RefitScene s, const float4* __restrict__ tlas, uint32_t count) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  const float4 lo = tlas[2u * i], hi = tlas[2u * i + 1u];
+  const uint32_t entry = f2u(lo.w);
+  if (entry < HK_LEAF) return;
+  s.inst_lo[entry - HK_LEAF] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+  s.inst_hi[entry - HK_LEAF] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+}
+
+}  // namespace hkd
+
+namespace hk {
+using namespace hkd;
+
+void launch_copy_region(hipStream_t st, void* dst, const void* src, size_t bytes) {
+  const size_t n = bytes / 16;
+  if (!n) return;
+  hipLaunchKernelGGL(k_copy_region_u4, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, (uint4*)dst, (const uint4*)src, n);
+}
+void launch_gather_instance_boxes(hipStream_t st, const RefitScene& s, const float4* tlas, uint32_t tlas_count) {
+  if (!tlas_count) return;
+  hipLaunchKernelGGL(k_gather_instance_boxes, dim3((tlas_count + 255u) / 256u), dim3(256), 0, st, s, tlas, tlas_count);
+}
+void launch_refit(hipStream_t st, const RefitScene& s, const RefitUpdate* updates, uint32_t n_updates, uint32_t* failed, float4* tlas, uint32_t tlas_count,
+                  uint32_t orderings, float4* light_lo, float4* light_hi, uint32_t light_count) {
+  if (n_updates) hipLaunchKernelGGL(k_refit_instances, dim3((n_updates + 63u) / 64u), dim3(64), 0, st, s, updates, n_updates, failed);
+  // TLAS nodes are interleaved (lo, hi) pairs, the light BVH two planes
+  if (tlas_count) {
+    const uint32_t waves = tlas_count * orderings;
+    hipLaunchKernelGGL((k_refit_flat_bvh<false>), dim3((waves + 3u) / 4u), dim3(256), 0, st, s, tlas, tlas + 1, 2u, tlas_count, orderings);
+  }
+  if (light_count) hipLaunchKernelGGL((k_refit_flat_bvh<true>), dim3((light_count + 3u) / 4u), dim3(256), 0, st, s, light_lo, light_hi, 1u, light_count, 1u);
+}
+
+}  // namespace hk

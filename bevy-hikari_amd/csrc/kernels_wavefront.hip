@@ -1,0 +1,509 @@
+// kernels_wavefront.hip - indirect_lit_ambient (light.wgsl:1263-1498, MULTIPLE_BOUNCES) as a queue-based schedule.
+//
+// The fused kernel (kernels.hip k_indirect) keeps one pixel in one lane from the G-buffer read to the reservoir store;
+// its BVH walks then run until the slowest lane of the wave is done (Cornell: 28 of 64 lanes live per step; a scene
+// of 256 k triangles: walks of hundreds of steps whose lengths differ by 10x inside one 8x8 tile).  Here the same
+// arithmetic per pixel, per ray and per bounce is cut at the walks:
+//
+//   k_wf_setup   pixel-mapped like k_indirect: background pixels are finished on the spot (zero reservoirs, the
+//                uniform-tile store elision); every other pixel gets a path SLOT (wave ballot + prefix count, one atomic
+//                per wave), its path state and its first bounce ray
+//   k_wf_trace   persistent waves; a lane whose ray has ended takes the next ray of the stage's queue (wave ballot of
+//                the idle lanes + mbcnt prefix into a 64-entry block the wave reserved with ONE atomic), so a wave
+//                keeps walking with full lanes until the queue is dry - the active-ray compaction across bounces
+//                that BASELINE.json's north star names, applied to the whole frame instead of one tile
+//   k_wf_shade   bounce n of every live path (hit attributes, light candidate, both outcomes of the shadow ray,
+//                throughput, next bounce ray); emits the shadow ray of bounce n and the closest-hit ray of bounce n+1
+//                - they are independent, so ONE trace launch walks both lists - and compacts the surviving paths
+//   k_wf_final   adds the last shadow result and runs the temporal-reuse tail (hk_light.hpp indirect_temporal_tail)
+//
+// Launches for N bounces: setup, N x (trace, shade), trace, final.  What a path carries from stage to stage lives in
+// 16-B planes indexed by slot (coalesced dwordx4 accesses): 9 planes of path state, 2 + 3 of rays, 2 + 1 of hits.
+//
+// Bit-exactness.  A shadow ray's outcome only selects between two radiance values: `occlude_hit_info` followed by
+// `input_radiance` (light.wgsl:526-533,835-867) gives (0,0,0,1) for EVERY occluder (the sampled emitter is excluded from
+// the walk, so the occluder never is the emitter) and leaves the candidate's own hit info untouched otherwise.  The
+// shade stage therefore evaluates the reference's expression for both outcomes before the ray is traced and the next
+// stage adds the one the walk selected - in bounce order, so every float addition happens in the reference's order.
+// Everything else is the fused kernel's code on the same operands.  tests/test_parity_gpu.py compares the two schedules
+// buffer by buffer, and each against the oracle.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "hk_device.hpp"
+#include "hk_kernels.hpp"
+#include "hk_light.hpp"
+
+namespace hkd {
+
+namespace {
+constexpr uint32_t WF_SHADOW = 0x80000000u;
+// counters (WfBuffers::ctr): per stage s
+constexpr uint32_t WF_ALIVE = 0u;    // [s] paths alive at bounce s (s = 0: all slots)
+constexpr uint32_t WF_SHADOWS = 64u;  // [s] shadow rays trace stage s walks (emitted by the shade stage of bounce s - 1)
+constexpr uint32_t WF_QHEAD = 128u;   // [s] rays of trace stage s claimed so far (its queue = the alive list, then the shadow list)
+
+#ifndef HK_WF_REFILL_MIN
+#define HK_WF_REFILL_MIN 4u   // a wave fetches new rays once this many lanes are idle (or all of them)
+#endif
+#ifndef HK_WF_TRACE_WAVES
+#define HK_WF_TRACE_WAVES 7   // waves per SIMD the trace kernel is compiled for (69 VGPRs, no spills; 8 would spill 44 B per lane)
+#endif
+#ifndef HK_WF_STEPS
+#define HK_WF_STEPS 6         // node steps between two looks at the idle lanes
+#endif
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {  // set bits of `mask` below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// One atomic per WORKGROUP and list (a single hot counter takes ~10 ns per atomic on this chip: one per wave - 32 k per
+// dispatch at 1080p - was a third of the shade stage).  Called by all 256 threads; lds: 6 words.
+__device__ __forceinline__ uint32_t block_push(uint32_t* counter, bool want, uint32_t* lds) {
+  const unsigned long long m = __ballot(want);
+  const uint32_t wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0u) lds[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    const uint32_t total = lds[0] + lds[1] + lds[2] + lds[3];
+    lds[4] = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = lds[4];
+  for (uint32_t k = 0; k < wave; ++k) base += lds[k];
+  __syncthreads();  // lds is reused by the next call
+  return base + lane_rank(m);
+}
+
+// path state planes (WfBuffers::state + k * cap)
+enum : uint32_t { PL_RANDOM = 0, PL_POSITION_PDF, PL_NORMAL_PENDING, PL_TRANSPORT, PL_RADIANCE, PL_FIRST_POSITION, PL_FIRST_NORMAL, PL_ADD_CLEAR, PL_ADD_OCCLUDED };
+__device__ __forceinline__ float4* plane(const WfBuffers& w, uint32_t k) { return w.state + (size_t)k * w.cap; }
+
+// the next bounce ray of a path: light.wgsl:1316-1321 (sample_cosine_hemisphere through the normal's basis, biased origin)
+__device__ __forceinline__ void emit_bounce_ray(const WfBuffers& w, uint32_t slot, f4 random, f3 position, f3 normal) {
+  const f4 rand_sample = sample_cosine_hemisphere(F2(random.x, random.y));
+  const f3 origin = position + normal * HK_RAY_BIAS;
+  const f3 direction = mul(normal_basis(normal), xyz(rand_sample));
+  w.cr0[slot] = make_float4(origin.x, origin.y, origin.z, 0.0f);
+  w.cr1[slot] = make_float4(direction.x, direction.y, direction.z, rand_sample.w);
+}
+}  // namespace
+
+// ------------------------------------------------------------------ setup: background pixels, slots, first rays
+__global__ __launch_bounds__(256) void k_wf_setup(DScene sc, DFrame fr, GBuffer g, LightTargets t, WfBuffers w, int row_begin, int row_end) {
+  const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
+  bool path = false;
+  int index = 0;
+  f4 random = F4(0, 0, 0, 0);
+  f3 position = F3(0, 0, 0), normal = F3(0, 0, 0);
+  if (px.valid) {  // the prologue of k_indirect, light.wgsl:1263-1308
+    const int x = px.x, y = px.y;
+    index = x + fr.rw * y;
+    const f2 uv = coords_to_uv(fr, x, y);
+    int dcx, dcy;
+    jittered_deferred_coords(fr, uv, &dcx, &dcy);
+    const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh);
+    const int didx = dcx + fr.dw * dcy;
+    const float4 position_depth = din ? g.position[didx] : make_float4(0, 0, 0, 0);
+    const float depth = position_depth.w;
+    const bool background = fr.indirect_bounces == 0u || depth < HK_F32_EPSILON;
+    const bool all_background = __ballot(!background) == 0ull;  // among the wave's valid pixels
+    const int tile = wave_tile(px, t.tiles_x);
+    if (background) {  // light.wgsl:1279-1287
+      const PackedReservoir pr = pack_reservoir(zero_reservoir());
+      bool skip_current = false, skip_spatial = false, skip_previous_spatial = false;
+      if (t.m_current && all_background) {  // uniform-tile store elision (hk_kernels.hpp TileMeta)
+        const unsigned long long id = record_id(pr);
+        skip_current = tile_holds(t.m_current, tile, id);
+        skip_spatial = tile_holds(t.m_spatial, tile, id);
+        skip_previous_spatial = tile_holds(t.m_previous_spatial, tile, id);
+        if (!skip_current) tile_mark(t.m_current, tile, id, 0ull, t.serial);
+        if (!skip_spatial) tile_mark(t.m_spatial, tile, id, 0ull, t.serial);
+        if (!skip_previous_spatial) tile_mark(t.m_previous_spatial, tile, id, 0ull, t.serial);
+      }
+      if (!skip_current) store_packed(t.current, index, pr);
+      if (!skip_spatial) store_packed(t.spatial, index, pr);
+      if (!skip_previous_spatial) store_previous_spatial(t, index, index, pr);
+      t.variance[index] = 0.0f;
+      t.render[index] = make_uint2(0u, 0u);
+    } else {
+      normal = normalize(xyz(unpack4x8snorm(g.normal[didx])));
+      random = noise_fetch(sc, x, y, fr.number);
+      random = fract(random + fr.number_golden);
+      position = xyz(position_depth);
+      path = true;
+    }
+    if (t.m_current && !all_background) {  // a tile with real pixels: no longer one record everywhere
+      tile_unknown(t.m_current, tile);
+      if (__ballot(background) != 0ull) {
+        tile_unknown(t.m_spatial, tile);
+        tile_unknown(t.m_previous_spatial, tile);
+      }
+    }
+  }
+  __shared__ uint32_t push_lds[6];
+  const uint32_t slot = block_push(&w.ctr[WF_ALIVE], path, push_lds);
+  if (path) {
+    w.pixel[slot] = (uint32_t)index;
+    w.alive[0][slot] = slot;  // bounce 0: every slot is alive
+    plane(w, PL_RANDOM)[slot] = to_float4(random);
+    plane(w, PL_POSITION_PDF)[slot] = make_float4(position.x, position.y, position.z, 0.0f);
+    plane(w, PL_NORMAL_PENDING)[slot] = make_float4(normal.x, normal.y, normal.z, 0.0f);
+    // (transport = 1, radiance = 0: the shade stage of bounce 0 starts from these values without reading their planes)
+    emit_bounce_ray(w, slot, random, position, normal);
+  }
+}
+
+// ------------------------------------------------------------------ trace: persistent waves, lanes refill from the queue
+// traverse_top (hk_device.hpp, light.wgsl:400-486) as a resumable state: begin() = its prologue, step() = one iteration
+// of its loop; a lane's sequence of steps, and with it every result bit, is that of the fused kernels.
+namespace {
+struct Walk {
+  f3 origin, direction, inv_direction;  // the world-space ray
+  float early_distance;
+  uint32_t exclude_instance;
+  Hit hit;
+  uint32_t tlas_base, index, limit, base, t_resume, prim_base, cur_instance;
+  bool in_blas, intersected;
+  f3 co, cinv, ld;  // origin / inverse direction of the level being walked, local direction inside a BLAS
+};
+__device__ __forceinline__ void walk_begin(Walk& k, const DScene& sc, f3 origin, f3 direction, float max_distance, float early_distance, uint32_t exclude) {
+  k.origin = origin;
+  k.direction = direction;
+  k.inv_direction = 1.0f / direction;
+  k.early_distance = early_distance;
+  k.exclude_instance = exclude;
+  k.hit.uv = F2(0.0f, 0.0f);
+  k.hit.distance = max_distance;
+  k.hit.instance_index = HK_U32_MAX;
+  k.hit.primitive_index = HK_U32_MAX;
+  k.tlas_base = ray_octant(direction) * sc.tlas_stride;
+  k.index = 0u;
+  k.limit = sc.tlas_count;
+  k.base = k.tlas_base;
+  k.t_resume = 0u;
+  k.prim_base = 0u;
+  k.cur_instance = 0u;
+  k.in_blas = false;
+  k.intersected = false;
+  k.co = k.origin;
+  k.cinv = k.inv_direction;
+  k.ld = direction;
+}
+// returns true when the walk has ended (k.hit is the result)
+__device__ __forceinline__ bool walk_step(Walk& k, const DScene& sc) {
+  if (k.index >= k.limit) {
+    if (!k.in_blas) return true;
+    if (k.intersected) {  // traverse_bottom returned, light.wgsl:465-470
+      k.hit.instance_index = k.cur_instance;
+      if (k.hit.distance < k.early_distance) return true;
+    }
+    k.in_blas = false;
+    k.index = k.t_resume;
+    k.limit = sc.tlas_count;
+    k.base = k.tlas_base;
+    k.co = k.origin;
+    k.cinv = k.inv_direction;
+    return false;
+  }
+  const float4* __restrict__ nd = sc.nodes + 2u * (k.base + k.index);
+  const float4 lo = nd[0];
+  const float4 hi = nd[1];
+  const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
+  const f3 t1 = (xyz(lo) - k.co) * k.cinv;  // intersects_aabb, light.wgsl:344-362
+  const f3 t2 = (xyz(hi) - k.co) * k.cinv;
+  float t_min = fmin_(t1.x, t2.x);
+  float t_max = fmax_(t1.x, t2.x);
+  t_min = fmax_(t_min, fmin_(t1.y, t2.y));
+  t_max = fmin_(t_max, fmax_(t1.y, t2.y));
+  t_min = fmax_(t_min, fmin_(t1.z, t2.z));
+  t_max = fmin_(t_max, fmax_(t1.z, t2.z));
+  const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
+  const bool box_hit = t_box < k.hit.distance;
+  const bool leaf = entry >= HK_LEAF;
+  k.index = (leaf || !box_hit) ? exit_ : entry;
+  if (leaf && box_hit) {
+    if (k.in_blas) {
+      const uint32_t primitive_index = k.prim_base + entry - HK_LEAF;
+      Ray lr;
+      lr.origin = k.co;
+      lr.direction = k.ld;
+      lr.inv_direction = k.cinv;
+      f2 uv;
+      const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+      if (d < k.hit.distance) {
+        k.hit.uv = uv;
+        k.hit.distance = d;
+        k.hit.primitive_index = primitive_index;
+        k.intersected = true;
+        if (d < k.early_distance) {  // light.wgsl:421-423 then 466-469
+          k.hit.instance_index = k.cur_instance;
+          return true;
+        }
+      }
+    } else {
+      const uint32_t instance_index = entry - HK_LEAF;
+      if (instance_index != k.exclude_instance) {
+        const DInstance& in = sc.instances[instance_index];
+        k.co = world_to_local_position(in, k.origin);
+        k.ld = world_to_local_direction(in, k.direction);
+        k.cinv = 1.0f / k.ld;
+        k.t_resume = k.index;
+        k.base = sc.blas_base + ray_octant(k.ld) * sc.blas_stride + in.node_offset;
+        k.index = 0u;
+        k.limit = in.node_count;
+        k.prim_base = in.primitive;
+        k.cur_instance = instance_index;
+        k.in_blas = true;
+        k.intersected = false;
+      }
+    }
+  }
+  return false;
+}
+}  // namespace
+
+// Stage `stage` walks the closest-hit rays of the paths alive at bounce `stage` and the shadow rays the shade stage of bounce
+// `stage - 1` emitted: queue entry i is alive[i] for i < n_alive, else shadow[i - n_alive].
+template <bool LDS>
+__global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc, WfBuffers w, uint32_t stage) {
+  const DScene sc = stage_scene<LDS>(gsc);
+  const uint32_t n_alive = w.ctr[WF_ALIVE + stage], tail = n_alive + w.ctr[WF_SHADOWS + stage];
+  const uint32_t* __restrict__ alive = w.alive[stage & 1u];
+  const uint32_t* __restrict__ shadow = w.shadow[stage & 1u];
+  uint32_t* head_ptr = &w.ctr[WF_QHEAD + stage];
+  const uint32_t all_lanes = gridDim.x * 256u;
+  // the wave's reserve: entries [res_base, res_base + res_count) of the queue are this wave's to hand to its lanes
+  uint32_t res_base = 0u, res_count = 0u;
+  bool exhausted = tail == 0u;  // nothing left to reserve from the queue
+  bool active = false;
+  uint32_t entry_id = 0u;
+  Walk k;
+  walk_begin(k, sc, F3(0, 0, 0), F3(1, 1, 1), 0.0f, 0.0f, HK_DONT_EXCLUDE);
+  for (;;) {
+    const unsigned long long idle_mask = __ballot(!active);
+    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+    const bool dry = exhausted && res_count == 0u;
+    if (dry && n_idle == 64u) break;
+    if (!dry && (n_idle >= HK_WF_REFILL_MIN || n_idle == 64u)) {
+      const uint32_t rank = lane_rank(idle_mask);
+      uint32_t mine = HK_U32_MAX;
+      uint32_t given = 0u;
+      if (res_count < n_idle && !exhausted) {  // hand out what is left, then reserve the next block
+        given = res_count;
+        if (!active && rank < given) mine = res_base + rank;
+        // one atomic per 256 rays while every lane of the launch can still be fed four more times from what is left, per 64
+        // near the end of the queue (short blocks there keep the last waves from walking a long reserve alone)
+        const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : 64u;
+        uint32_t b = 0u;
+        if ((threadIdx.x & 63u) == 0u) b = atomicAdd(head_ptr, block);
+        b = __builtin_amdgcn_readfirstlane(b);
+        res_base = b;
+        res_count = b < tail ? min(block, tail - b) : 0u;
+        if (b + block >= tail) exhausted = true;
+      }
+      if (!active && rank >= given && rank - given < res_count) mine = res_base + (rank - given);
+      const uint32_t used = min(n_idle - given, res_count);
+      res_base += used;
+      res_count -= used;
+      if (mine != HK_U32_MAX) {
+        entry_id = mine < n_alive ? alive[mine] : (shadow[mine - n_alive] | WF_SHADOW);
+        const uint32_t slot = entry_id & ~WF_SHADOW;
+        if (entry_id & WF_SHADOW) {
+          const float4 a = w.sr0[slot], b4 = w.sr1[slot];
+          walk_begin(k, sc, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), a.w, b4.w, w.sr2[slot]);
+        } else {
+          const float4 a = w.cr0[slot], b4 = w.cr1[slot];
+          walk_begin(k, sc, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE);
+        }
+        active = true;
+      }
+    }
+#pragma unroll 1
+    for (int s = 0; s < HK_WF_STEPS; ++s) {
+      if (active && walk_step(k, sc)) {
+        const uint32_t slot = entry_id & ~WF_SHADOW;
+        if (entry_id & WF_SHADOW) {
+          w.sh[slot] = k.hit.instance_index;
+        } else {
+          w.ch0[slot] = make_float4(k.hit.distance, k.hit.uv.x, k.hit.uv.y, u2f(k.hit.primitive_index));
+          w.ch1[slot] = k.hit.instance_index;
+        }
+        active = false;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ shade: bounce n of every live path
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_wf_shade(DScene gsc, DFrame fr, WfBuffers w, uint32_t n) {
+  const DScene sc = stage_scene<LDS>(gsc);
+  const uint32_t count = w.ctr[WF_ALIVE + n];
+  const uint32_t* __restrict__ alive_in = w.alive[n & 1u];
+  uint32_t* alive_out = w.alive[(n + 1u) & 1u];
+  uint32_t* shadow_out = w.shadow[(n + 1u) & 1u];
+  __shared__ uint32_t push_lds[6];
+  RayCounters rc{0, 0};
+  for (uint32_t first = blockIdx.x * 256u; first < count; first += gridDim.x * 256u) {  // workgroup-uniform trip count
+    const uint32_t i = first + threadIdx.x;
+    const bool valid = i < count;
+    bool want_shadow = false, want_next = false;
+    uint32_t slot = 0u;
+    if (valid) {
+      slot = alive_in[i];
+      f4 random = F4(plane(w, PL_RANDOM)[slot]);
+      const float4 pp = plane(w, PL_POSITION_PDF)[slot];
+      const float4 np = plane(w, PL_NORMAL_PENDING)[slot];
+      f3 position = F3(pp.x, pp.y, pp.z), normal = F3(np.x, np.y, np.z);
+      float pdf = pp.w;
+      f3 transport = F3(1.0f, 1.0f, 1.0f);  // light.wgsl:1310-1311
+      f4 radiance = F4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (n != 0u) {
+        transport = xyz(F4(plane(w, PL_TRANSPORT)[slot]));
+        radiance = F4(plane(w, PL_RADIANCE)[slot]);
+      }
+      if (np.w != 0.0f) {  // the shadow ray of bounce n - 1 has been traced by now: add the outcome it selected
+        const float4 add = (w.sh[slot] != HK_U32_MAX) ? plane(w, PL_ADD_OCCLUDED)[slot] : plane(w, PL_ADD_CLEAR)[slot];
+        radiance = radiance + F4(add.x, add.y, add.z, 1.0f);
+      }
+      // light.wgsl:1313-1394, one iteration (bounce_step of kernels.hip) from the hit on
+      const float4 ro = w.cr0[slot], rd = w.cr1[slot], h0 = w.ch0[slot];
+      Ray ray;
+      ray.origin = F3(ro.x, ro.y, ro.z);
+      ray.direction = F3(rd.x, rd.y, rd.z);
+      ray.inv_direction = F3(0, 0, 0);  // not read below
+      const float rand_sample_w = rd.w;
+      Hit hit;
+      hit.distance = h0.x;
+      hit.uv = F2(h0.y, h0.z);
+      hit.primitive_index = f2u(h0.w);
+      hit.instance_index = w.ch1[slot];
+      HitInfo info = hit_info(sc, ray, hit);
+      if (n == 0u) {
+        plane(w, PL_FIRST_POSITION)[slot] = to_float4(info.position);
+        plane(w, PL_FIRST_NORMAL)[slot] = make_float4(info.normal.x, info.normal.y, info.normal.z, 0.0f);
+        pdf = rand_sample_w;
+      }
+      const f3 sample_position = xyz(info.position);
+      const f3 sample_normal = info.normal;
+      float pending = 0.0f;
+      if (hit.instance_index != HK_U32_MAX) {
+        Surface surface = retreive_surface(sc, info.material_index, info.uv);
+        surface.roughness = 1.0f;
+        const uint32_t info_instance = info.instance_index;
+        LightCandidate candidate = select_light_candidate(sc, fr, random, sample_position, sample_normal, info_instance, info, rc);
+        const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
+        const f3 bounce_view_direction = normalize(position - sample_position);
+        if (dot(candidate.direction, sample_normal) > 0.0f && candidate.p > 0.0f) {
+          Ray sray;
+          sray.origin = sample_position + sample_normal * HK_RAY_BIAS;
+          sray.direction = candidate.direction;
+          sray.inv_direction = F3(0, 0, 0);
+          w.sr0[slot] = make_float4(sray.origin.x, sray.origin.y, sray.origin.z, candidate.max_distance);
+          w.sr1[slot] = make_float4(sray.direction.x, sray.direction.y, sray.direction.z, candidate.min_distance);
+          w.sr2[slot] = candidate.emissive_instance;
+          // both outcomes of the walk (see the header): unoccluded = the candidate's own hit info, occluded = (0,0,0,1)
+          const f4 in_clear = input_radiance(sc, fr, sray, info, sample_directional, candidate.emissive_instance, false);
+          f3 add[2];
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {
+            const f4 in_radiance = o == 0 ? in_clear : F4(0.0f, 0.0f, 0.0f, 1.0f);
+            f3 out_radiance = shading(fr, bounce_view_direction, sample_normal, sray.direction, surface, in_radiance);
+            out_radiance = out_radiance / candidate.p;
+            if (n > 0u) out_radiance = (rand_sample_w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample_w;
+            const float out_luminance = luminance(out_radiance);
+            if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
+            add[o] = transport * out_radiance;
+          }
+          plane(w, PL_ADD_CLEAR)[slot] = make_float4(add[0].x, add[0].y, add[0].z, 0.0f);
+          plane(w, PL_ADD_OCCLUDED)[slot] = make_float4(add[1].x, add[1].y, add[1].z, 0.0f);
+          pending = 1.0f;
+          want_shadow = true;
+        }
+        transport = transport * env_brdf(bounce_view_direction, sample_normal, surface);
+        random = fract(random + fr.number_golden);
+        position = sample_position;
+        normal = sample_normal;
+        // the loop condition of light.wgsl:1313 for bounce n + 1
+        want_next = n + 1u < fr.indirect_bounces && (transport.x > 0.01f || transport.y > 0.01f || transport.z > 0.01f);
+        if (want_next) emit_bounce_ray(w, slot, random, position, normal);
+      } else {
+        const f3 out_radiance = xyz(input_radiance(sc, fr, ray, info, false, HK_DONT_SAMPLE_EMISSIVE, true));
+        radiance = radiance + F4(transport * out_radiance, 0.0f);
+      }
+      plane(w, PL_RANDOM)[slot] = to_float4(random);
+      plane(w, PL_POSITION_PDF)[slot] = make_float4(position.x, position.y, position.z, pdf);
+      plane(w, PL_NORMAL_PENDING)[slot] = make_float4(normal.x, normal.y, normal.z, pending);
+      plane(w, PL_TRANSPORT)[slot] = make_float4(transport.x, transport.y, transport.z, 0.0f);
+      plane(w, PL_RADIANCE)[slot] = to_float4(radiance);
+    }
+    // survivors and shadow rays of the next trace stage: one atomic per workgroup and list
+    const uint32_t a = block_push(&w.ctr[WF_ALIVE + n + 1u], want_next, push_lds);
+    if (want_next) alive_out[a] = slot;
+    const uint32_t q = block_push(&w.ctr[WF_SHADOWS + n + 1u], want_shadow, push_lds);
+    if (want_shadow) shadow_out[q] = slot;
+  }
+}
+
+// ------------------------------------------------------------------ final: last shadow result + the temporal-reuse tail
+__global__ __launch_bounds__(256, 4) void k_wf_final(DScene sc, DFrame fr, GBuffer g, LightTargets t, WfBuffers w) {
+  const uint32_t count = w.ctr[WF_ALIVE];
+  for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < count; slot += gridDim.x * 256u) {
+    const int index = (int)w.pixel[slot];
+    const int y = index / fr.rw, x = index - y * fr.rw;
+    // the G-buffer prologue of k_indirect again (light.wgsl:1263-1308): the same loads and operations, the same values
+    const f2 uv = coords_to_uv(fr, x, y);
+    int dcx, dcy;
+    jittered_deferred_coords(fr, uv, &dcx, &dcy);
+    const int didx = dcx + fr.dw * dcy;  // in bounds: the pixel was not background
+    const float4 position_depth = g.position[didx];
+    const f3 position = xyz(position_depth);
+    const float2 imf = g.instance_material[didx];
+    const uint32_t im_x = f32_to_u32(imf.x), im_y = f32_to_u32(imf.y);
+    const float4 velocity_uv = g.velocity_uv[didx];
+    Sample s = zero_sample();
+    s.random = noise_fetch(sc, x, y, fr.number);
+    s.random = fract(s.random + fr.number_golden);
+    s.visible_position = F4(position, position_depth.w);
+    s.visible_normal = normalize(xyz(unpack4x8snorm(g.normal[didx])));
+    s.visible_instance = im_x;
+    f4 radiance = F4(plane(w, PL_RADIANCE)[slot]);
+    if (plane(w, PL_NORMAL_PENDING)[slot].w != 0.0f) {
+      const float4 add = (w.sh[slot] != HK_U32_MAX) ? plane(w, PL_ADD_OCCLUDED)[slot] : plane(w, PL_ADD_CLEAR)[slot];
+      radiance = radiance + F4(add.x, add.y, add.z, 1.0f);
+    }
+    s.radiance = radiance;
+    s.sample_position = F4(plane(w, PL_FIRST_POSITION)[slot]);
+    s.sample_normal = xyz(F4(plane(w, PL_FIRST_NORMAL)[slot]));
+    const float pdf = plane(w, PL_POSITION_PDF)[slot].w;
+    indirect_temporal_tail(sc, fr, t, index, uv, position, velocity_uv, im_y, s, pdf);
+  }
+}
+
+}  // namespace hkd
+
+// ------------------------------------------------------------------ host launcher
+namespace hk {
+using namespace hkd;
+
+size_t wavefront_bytes_per_path() { return 4 + 9 * 16 + 2 * 16 + 2 * 16 + 4 + 16 + 4 + 4 + 2 * 8 + 2 * 4; }
+
+void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,
+                               int y1, int compute_units, hipEvent_t start, hipEvent_t stop) {
+  if (y1 <= y0) return;
+  (void)hipMemsetAsync(w.ctr, 0, 192 * sizeof(uint32_t), st);
+  hipExtLaunchKernelGGL(k_wf_setup, grid_for(fr.rw, y1 - y0), dim3(256), 0, st, start, nullptr, 0, sc, fr, g, t, w, y0, y1);
+  const size_t lds = (size_t)sc.blob_f4 * 16 <= HK_LDS_SCENE_BYTES ? (size_t)sc.blob_f4 * 16 : 0;
+  const dim3 persistent((unsigned)(compute_units * 8));  // 8 workgroups of 4 waves per CU: what 64 VGPRs leave resident
+  const uint32_t bounces = fr.indirect_bounces;
+  for (uint32_t n = 0; n <= bounces; ++n) {
+    if (lds) hipLaunchKernelGGL((k_wf_trace<true>), persistent, dim3(256), lds, st, sc, w, n);
+    else hipLaunchKernelGGL((k_wf_trace<false>), persistent, dim3(256), 0, st, sc, w, n);
+    if (n == bounces) break;
+    if (lds) hipLaunchKernelGGL((k_wf_shade<true>), persistent, dim3(256), lds, st, sc, fr, w, n);
+    else hipLaunchKernelGGL((k_wf_shade<false>), persistent, dim3(256), 0, st, sc, fr, w, n);
+  }
+  hipExtLaunchKernelGGL(k_wf_final, persistent, dim3(256), 0, st, nullptr, stop, 0, sc, fr, g, t, w);
+}
+
+}  // namespace hk

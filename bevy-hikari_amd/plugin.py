@@ -551,6 +551,12 @@ class Engine:
     def set_timing_mask(self, mask):
         self.api.call("set_timing_mask", self.ctx, mask)
 
+    def indirect_schedule(self):
+        """'fused' or 'wavefront': the schedule indirect_lit_ambient takes for the frame most recently begun (HK_CTX_WAVEFRONT)."""
+        v = C.c_uint32()
+        self.api.call("indirect_schedule", self.ctx, C.byref(v))
+        return "wavefront" if v.value else "fused"
+
     def measure_hbm(self, bytes_per_array=1 << 30, reps=8):
         """Empirical HBM ceiling: (copy GB/s, triad GB/s) of grid-stride float4 streams over arrays too big for the Infinity Cache."""
         cp, tr = C.c_double(), C.c_double()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 4
+#define HK_ABI_VERSION 5
 
 /* ------------------------------------------------------------------ error codes */
 #define HK_OK 0
@@ -362,6 +362,17 @@ int hk_device_count(int* count);
  * not depend on the order at all.  bit5 forces the reference's single order everywhere: the verification mode in which large
  * scenes are bit-exact against the oracle too.  Scenes that fit the LDS copy (Cornell) always use the reference order. */
 #define HK_CTX_EXACT_TRAVERSAL 32u
+/* Schedule of indirect_lit_ambient with two or more bounces (light.wgsl:1263-1498, the MULTIPLE_BOUNCES pipeline of
+ * light.rs:663-666).  FUSED: one kernel, one pixel per lane from the G-buffer read to the reservoir store - the walks of a
+ * wave last as long as its slowest ray.  WAVEFRONT: the same per-pixel arithmetic cut at the walks - a set-up dispatch gives
+ * every non-background pixel a path slot, persistent trace waves pull rays from a queue (a lane whose ray has ended takes the
+ * next one: wave ballot + prefix count, one atomic per 64 rays), a shade dispatch per bounce emits that bounce's shadow ray and
+ * the next closest-hit ray into one queue and compacts the surviving paths; path state travels in 16-B planes indexed by slot
+ * (~290 B per pixel of scratch, allocated on first use).  Both schedules produce the same bytes in every buffer.  Default:
+ * wavefront for scenes beyond the LDS copy (long walks, where lane refill pays), fused for scenes that fit it (short walks,
+ * where the ~0.4 KB per path and bounce of queue traffic costs more than the idle lanes).  bit6 / bit7 force one or the other. */
+#define HK_CTX_WAVEFRONT 64u
+#define HK_CTX_FUSED_INDIRECT 128u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);
 
@@ -579,6 +590,9 @@ int hk_set_stream(hk_ctx* ctx, void* hip_stream);
 int hk_set_timing_mask(hk_ctx* ctx, uint32_t pass_mask);
 int hk_get_stats(hk_ctx* ctx, HkStats* out);
 int hk_reset_stats(hk_ctx* ctx);
+/* Which schedule the indirect_lit_ambient dispatch of the frame most recently begun takes (see HK_CTX_WAVEFRONT): 0 = fused
+ * kernel, 1 = wavefront (ray queues).  Depends on the flags, the frame's indirect_bounces and the size of the uploaded scene. */
+int hk_indirect_schedule(hk_ctx* ctx, uint32_t* out);
 
 /* Measurement hook ("measure the empirical HBM ceiling with a device copy/triad kernel in the same run"): streams
  * three private arrays of `bytes_per_array` bytes (use >= 1 GiB: the 256 MB Infinity Cache must not hold them) `reps` times
