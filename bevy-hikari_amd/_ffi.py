@@ -139,7 +139,7 @@ class HkStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
                 ("_pad", u32), ("scene_mesh_builds", u64), ("scene_instance_builds", u64),
-                ("scene_async_instance_uploads", u64)]
+                ("scene_async_instance_uploads", u64), ("scene_device_refits", u64)]
 
 
 assert C.sizeof(HkVertex) == 32 and C.sizeof(HkPrimitive) == 48 and C.sizeof(HkNode) == 32 and C.sizeof(HkInstance) == 176
@@ -205,6 +205,7 @@ _PRODUCT_ONLY = {
     "scene_builder_alias_table": [_vp, P(P(HkAliasEntry)), P(u32)],
     "upload_scene": [_vp, _vp],
     "upload_scene_instances": [_vp, _vp],
+    "refit_scene_instances": [_vp, _vp, P(u32)],
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
     "band_plan_for": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],

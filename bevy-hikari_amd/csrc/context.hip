@@ -130,6 +130,9 @@ inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 }  // namespace
 
+// byte offsets of the arrays inside the instance-level region of the scene allocation
+struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emissives, alias, materials, tex_info, srgb_lut; };
+
 struct hk_ctx {
   int device = 0;
   uint32_t flags = 0;
@@ -184,6 +187,21 @@ struct hk_ctx {
   bool tile_meta_zero[10] = {};
   int tiles_x = 0, tiles_y = 0;
   uint32_t elide_serial = 0;
+  // ---- instance motion on the device (hk_refit_scene_instances, kernels_scene.hip)
+  DynOffsets dyn_off{};                   // where the arrays of the instance-level region are (the slot in use)
+  float4 *rf_inst_lo = nullptr, *rf_inst_hi = nullptr, *rf_prev_models = nullptr;  // world AABB / previous model per instance
+  uint32_t* rf_emissive_of_instance = nullptr;
+  float* rf_alias_scratch = nullptr;
+  size_t rf_instances = 0, rf_alias = 0;  // sizes the side arrays were allocated for
+  bool rf_ready = false;                  // side arrays describe the scene as uploaded (cleared by every host-side rebuild)
+  hkd::RefitUpdate* rf_updates[2] = {nullptr, nullptr};  // pinned, read by the kernel over PCIe
+  size_t rf_updates_cap[2] = {0, 0};
+  hipEvent_t rf_done[2] = {nullptr, nullptr};
+  bool rf_pending[2] = {false, false};
+  int rf_k = 0;
+  std::vector<uint32_t> rf_last_moved;    // instances whose `moved` flag is set on the device
+  bool mirrors_stale = false;             // the host copies of emissives / tree boxes no longer describe the device scene
+  uint64_t device_refits = 0;
   const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
   DevArray<uint32_t> d_noise;
   DevArray<uint32_t> d_tex_data;
@@ -479,8 +497,6 @@ int build_static_region(hk_ctx* c, Blob& blob, size_t& off_nodes, size_t& off_v0
   return HK_OK;
 }
 
-struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emissives, alias, materials, tex_info, srgb_lut; };
-
 int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o) {
   const size_t n_tlas = c->instance_nodes.size();
   const int orderings = c->threaded ? 8 : 1;
@@ -626,6 +642,35 @@ int sync_all(hk_ctx* c) {
   return HK_OK;
 }
 
+// point c->scene at the arrays of the slot in use
+void point_scene_at_slot(hk_ctx* c) {
+  const size_t slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
+  const DynOffsets& o = c->dyn_off;
+  const uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+  const uint8_t* sbase = c->scene_mem + slots;
+  DScene& s = c->scene;
+  s.blob = (const float4*)base;  // (two slots: the scene is too big for the LDS copy, blob is not read)
+  s.blob_f4 = (uint32_t)((slots + c->static_bytes) / 16);
+  s.nodes = (const float4*)base;
+  s.blas_base = (uint32_t)(((size_t)(sbase - base) + c->st_nodes) / 32);
+  s.instances = (const DInstance*)(base + o.instances);
+  c->d_prev_models = (const float4*)(base + o.prev_models);
+  s.tri_v0 = (const float4*)(sbase + c->st_v0); s.tri_v1 = (const float4*)(sbase + c->st_v1); s.tri_v2 = (const float4*)(sbase + c->st_v2);
+  s.vtx_normal = (const float4*)(sbase + c->st_vn); s.vtx_uv = (const float2*)(sbase + c->st_vuv);
+  s.materials = (const float4*)(base + o.materials);
+  s.tex_info = (const uint4*)(base + o.tex_info);
+  s.srgb_lut = (const float*)(base + o.srgb_lut);
+  s.tex_data = c->d_tex_data.p;
+  s.n_textures = (uint32_t)c->textures.size();
+  s.light_lo = (const float4*)(base + o.light_lo); s.light_hi = (const float4*)(base + o.light_hi);
+  s.emissives = (const DEmissive*)(base + o.emissives); s.alias = (const float2*)(base + o.alias);
+  s.noise = c->d_noise.p;
+  s.tlas_count = (uint32_t)c->instance_nodes.size();
+  s.tlas_stride = c->threaded ? (uint32_t)c->instance_nodes.size() : 0u;
+  s.blas_stride = c->threaded ? (uint32_t)c->asset_nodes.size() : 0u;
+  s.light_count = (uint32_t)c->emissive_nodes.size();
+}
+
 int finalize_scene(hk_ctx* c) {
   if (!c->mesh_dirty && !c->dynamic_dirty && !c->textures_dirty) return HK_OK;
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
@@ -657,9 +702,15 @@ int finalize_scene(hk_ctx* c) {
     if ((rc = c->d_tex_data.upload(tex_data))) return rc;
     c->textures_dirty = false;
   }
+  HK_REQUIRE(!(c->mirrors_stale && c->dynamic_dirty), HK_E_NOT_READY,
+             "the instance-level arrays were last changed on the device (hk_refit_scene_instances): upload the instances again (hk_upload_scene_instances) "
+             "before a change that rebuilds them on the host");
   Blob dyn;
   DynOffsets o{};
   if ((rc = build_dynamic_region(c, dyn, o))) return rc;
+  c->dyn_off = o;
+  c->rf_ready = false;
+  c->rf_last_moved.clear();
   const bool in_place = !need_static && dyn.bytes.size() <= c->dyn_capacity;
   if (!(in_place && c->two_slots) && (rc = sync_all(c))) return rc;  // frames in flight still read the arrays rewritten below
   if (need_static) {
@@ -690,7 +741,6 @@ int finalize_scene(hk_ctx* c) {
   } else if (c->two_slots) {
     c->slot ^= 1;
   }
-  const size_t slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
   uint8_t* const slot_mem = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
   if (in_place && c->two_slots) {
     const int k = c->slot;
@@ -721,29 +771,7 @@ int finalize_scene(hk_ctx* c) {
     if (dyn.bytes.size() < c->dyn_capacity) HK_HIP(hipMemset(slot_mem + dyn.bytes.size(), 0, c->dyn_capacity - dyn.bytes.size()));
   }
 
-  const uint8_t* base = slot_mem;
-  const uint8_t* sbase = c->scene_mem + slots;
-  DScene& s = c->scene;
-  s.blob = (const float4*)base;  // (two slots: the scene is too big for the LDS copy, blob is not read)
-  s.blob_f4 = (uint32_t)((slots + c->static_bytes) / 16);
-  s.nodes = (const float4*)base;
-  s.blas_base = (uint32_t)(((size_t)(sbase - base) + c->st_nodes) / 32);
-  s.instances = (const DInstance*)(base + o.instances);
-  c->d_prev_models = (const float4*)(base + o.prev_models);
-  s.tri_v0 = (const float4*)(sbase + c->st_v0); s.tri_v1 = (const float4*)(sbase + c->st_v1); s.tri_v2 = (const float4*)(sbase + c->st_v2);
-  s.vtx_normal = (const float4*)(sbase + c->st_vn); s.vtx_uv = (const float2*)(sbase + c->st_vuv);
-  s.materials = (const float4*)(base + o.materials);
-  s.tex_info = (const uint4*)(base + o.tex_info);
-  s.srgb_lut = (const float*)(base + o.srgb_lut);
-  s.tex_data = c->d_tex_data.p;
-  s.n_textures = (uint32_t)c->textures.size();
-  s.light_lo = (const float4*)(base + o.light_lo); s.light_hi = (const float4*)(base + o.light_hi);
-  s.emissives = (const DEmissive*)(base + o.emissives); s.alias = (const float2*)(base + o.alias);
-  s.noise = c->d_noise.p;
-  s.tlas_count = (uint32_t)c->instance_nodes.size();
-  s.tlas_stride = c->threaded ? (uint32_t)c->instance_nodes.size() : 0u;
-  s.blas_stride = c->threaded ? (uint32_t)c->asset_nodes.size() : 0u;
-  s.light_count = (uint32_t)c->emissive_nodes.size();
+  point_scene_at_slot(c);
   c->mesh_dirty = c->dynamic_dirty = false;
   c->static_rebuilds += need_static ? 1 : 0;
   c->dynamic_rebuilds += 1;
@@ -1178,6 +1206,7 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   return HK_OK;
 }
 
+namespace { void free_refit(hk_ctx* c); }
 void hk_destroy(hk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -1194,6 +1223,7 @@ void hk_destroy(hk_ctx* c) {
     if (c->staging[k]) (void)hipHostFree(c->staging[k]);
     if (c->staging_done[k]) (void)hipEventDestroy(c->staging_done[k]);
   }
+  free_refit(c);
   c->d_tex_data.release();
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
@@ -1232,6 +1262,7 @@ int hk_upload_instances(hk_ctx* c, const HkInstance* inst, uint32_t ni, const Hk
   c->prev_models.clear();
   c->have_instances = true;
   c->dynamic_dirty = true;
+  c->mirrors_stale = false;
   return HK_OK;
 }
 int hk_upload_previous_transforms(hk_ctx* c, const float* models, uint32_t n) {
@@ -1276,6 +1307,189 @@ int hk_upload_scene_instances(hk_ctx* c, const hk_scene_builder* b) {
   if ((rc = hk_scene_builder_previous_transforms(b, &pm, &npm))) return rc;
   if ((rc = hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal))) return rc;
   return hk_upload_previous_transforms(c, pm, npm);
+}
+
+// ---- instance motion on the device (kernels_scene.hip) --------------------------------------------------
+namespace {
+void free_refit(hk_ctx* c) {
+  for (void* q : {(void*)c->rf_inst_lo, (void*)c->rf_inst_hi, (void*)c->rf_prev_models, (void*)c->rf_emissive_of_instance, (void*)c->rf_alias_scratch})
+    if (q) (void)hipFree(q);
+  c->rf_inst_lo = c->rf_inst_hi = c->rf_prev_models = nullptr;
+  c->rf_emissive_of_instance = nullptr;
+  c->rf_alias_scratch = nullptr;
+  c->rf_instances = c->rf_alias = 0;
+  c->rf_ready = false;
+  for (int k = 0; k < 2; ++k) {
+    if (c->rf_updates[k]) (void)hipHostFree(c->rf_updates[k]);
+    if (c->rf_done[k]) (void)hipEventDestroy(c->rf_done[k]);
+    c->rf_updates[k] = nullptr;
+    c->rf_done[k] = nullptr;
+    c->rf_updates_cap[k] = 0;
+    c->rf_pending[k] = false;
+  }
+}
+hkd::RefitScene refit_scene(hk_ctx* c) {
+  uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+  hkd::RefitScene r;
+  r.instances = (DInstance*)(base + c->dyn_off.instances);
+  r.prev_models = c->rf_prev_models;
+  r.inst_lo = c->rf_inst_lo;
+  r.inst_hi = c->rf_inst_hi;
+  r.emissive_of_instance = c->rf_emissive_of_instance;
+  r.emissives = (DEmissive*)(base + c->dyn_off.emissives);
+  r.alias = (float2*)(base + c->dyn_off.alias);
+  r.alias_scratch = c->rf_alias_scratch;
+  r.materials = (const float4*)(base + c->dyn_off.materials);
+  r.tri_v0 = c->scene.tri_v0;
+  r.tri_v1 = c->scene.tri_v1;
+  r.tri_v2 = c->scene.tri_v2;
+  return r;
+}
+// side arrays of the refit, (re)filled from the scene as the host last laid it out: world AABB per instance from the TLAS
+// leaves, emitter of an instance, previous models
+int prepare_refit(hk_ctx* c) {
+  if (c->rf_ready) return HK_OK;
+  const size_t ni = c->instances.size(), na = c->alias_table.size();
+  if (ni > c->rf_instances || na > c->rf_alias) {
+    int rc = sync_all(c);
+    if (rc) return rc;
+    const bool keep_updates = true;
+    (void)keep_updates;
+    for (void* q : {(void*)c->rf_inst_lo, (void*)c->rf_inst_hi, (void*)c->rf_prev_models, (void*)c->rf_emissive_of_instance, (void*)c->rf_alias_scratch})
+      if (q) (void)hipFree(q);
+    c->rf_inst_lo = c->rf_inst_hi = c->rf_prev_models = nullptr;
+    c->rf_emissive_of_instance = nullptr;
+    c->rf_alias_scratch = nullptr;
+    c->rf_instances = ni + ni / 4;
+    c->rf_alias = na + na / 4 + 4;
+    HK_HIP(hipMalloc((void**)&c->rf_inst_lo, c->rf_instances * 16));
+    HK_HIP(hipMalloc((void**)&c->rf_inst_hi, c->rf_instances * 16));
+    HK_HIP(hipMalloc((void**)&c->rf_prev_models, c->rf_instances * 64));
+    HK_HIP(hipMalloc((void**)&c->rf_emissive_of_instance, c->rf_instances * 4));
+    HK_HIP(hipMalloc((void**)&c->rf_alias_scratch, c->rf_alias * 5 * 4));
+  }
+  std::vector<uint32_t> eoi(ni, 0xFFFFFFFFu);
+  for (size_t e = 0; e < c->emissives.size(); ++e) eoi[c->emissives[e].instance] = (uint32_t)e;
+  HK_HIP(hipMemcpyAsync(c->rf_emissive_of_instance, eoi.data(), ni * 4, hipMemcpyHostToDevice, c->stream));
+  HK_HIP(hipStreamSynchronize(c->stream));  // (eoi is a local; once per host-side rebuild)
+  const hkd::RefitScene r = refit_scene(c);
+  const uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+  launch_gather_instance_boxes(c->stream, r, (const float4*)(base + c->dyn_off.tlas), (uint32_t)c->instance_nodes.size());
+  // previous models of the instances the host marked as moved (the plane exists only then)
+  if (c->prev_models.size() == 16 * ni && c->dyn_off.prev_models + ni * 64 <= c->dyn_capacity && c->d_prev_models && c->d_prev_models != c->rf_prev_models) {
+    bool any = false;
+    for (size_t i = 0; i < ni && !any; ++i) any = memcmp(&c->prev_models[16 * i], c->instances[i].model, 64) != 0;
+    if (any) launch_copy_region(c->stream, c->rf_prev_models, base + c->dyn_off.prev_models, ni * 64);
+  }
+  HK_HIP(hipGetLastError());
+  c->rf_last_moved.clear();
+  for (size_t i = 0; i < ni; ++i)
+    if (c->prev_models.size() == 16 * ni && memcmp(&c->prev_models[16 * i], c->instances[i].model, 64) != 0) c->rf_last_moved.push_back((uint32_t)i);
+  c->rf_ready = true;
+  return HK_OK;
+}
+}  // namespace
+
+int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out) {
+  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
+  HK_HIP(hipSetDevice(c->device));
+  int rc;
+  if ((rc = finalize_scene(c))) return rc;
+  const uint32_t ni = (uint32_t)c->instances.size();
+  HK_REQUIRE(builder_instance_count(b) == ni, HK_E_INVALID, "the builder has %u instances, the uploaded scene %u: instances were added or removed (use hk_upload_scene_instances)",
+             builder_instance_count(b), ni);
+  // which instances moved since the pose the device holds; their new host-side records (the reference's per-instance work,
+  // instance.rs:286-325, kept in step so that a later host-side rebuild starts from the right poses)
+  std::vector<uint32_t> moved;
+  std::vector<hkd::RefitUpdate> records;
+  for (uint32_t i = 0; i < ni; ++i) {
+    InstanceDecl d;
+    HK_REQUIRE(builder_instance_decl(b, i, &d), HK_E_NOT_READY, "the builder has unfinished mesh changes (hk_scene_builder_finish + hk_upload_scene first)");
+    HkInstance& in = c->instances[i];
+    HK_REQUIRE(d.material == in.material && memcmp(&d.mesh, &in.mesh, sizeof(HkMeshIndex)) == 0, HK_E_INVALID,
+               "instance %u changed its mesh or material (use hk_upload_scene_instances)", i);
+    if (memcmp(d.transform, in.model, 64) == 0) continue;
+    float mn[3], mx[3], itm[16];
+    HK_REQUIRE(instance_world_record(d.transform, d.aabb_center, d.aabb_half, mn, mx, itm), HK_E_INVALID, "singular transform of instance %u", i);
+    hkd::RefitUpdate u;
+    u.instance = i;
+    u.moved = 1u;
+    memcpy(u.model, d.transform, 64);
+    memcpy(u.aabb_center, d.aabb_center, 12);
+    memcpy(u.aabb_half, d.aabb_half, 12);
+    records.push_back(u);
+    moved.push_back(i);
+  }
+  if (moved_out) *moved_out = (uint32_t)moved.size();
+  if ((rc = prepare_refit(c))) return rc;
+  {  // instances that moved in the previous update and rest now: their `moved` flag goes (previous model = model)
+    std::vector<uint8_t> now(ni, 0);
+    for (uint32_t i : moved) now[i] = 1;
+    for (uint32_t i : c->rf_last_moved)
+      if (!now[i]) {
+        hkd::RefitUpdate u{};
+        u.instance = i;
+        u.moved = 0u;
+        records.push_back(u);
+      }
+  }
+  if (records.empty()) {
+    builder_commit_transforms(b);
+    return HK_OK;
+  }
+  // host mirrors of the moved instances
+  for (const hkd::RefitUpdate& u : records) {
+    if (!u.moved) continue;
+    HkInstance& in = c->instances[u.instance];
+    if (c->prev_models.size() != 16 * (size_t)ni) {
+      c->prev_models.resize(16 * (size_t)ni);
+      for (uint32_t j = 0; j < ni; ++j) memcpy(&c->prev_models[16 * (size_t)j], c->instances[j].model, 64);
+    }
+    memcpy(&c->prev_models[16 * (size_t)u.instance], in.model, 64);
+    memcpy(in.model, u.model, 64);
+    (void)instance_world_record(u.model, u.aabb_center, u.aabb_half, in.min, in.max, in.inverse_transpose_model);
+  }
+  for (const hkd::RefitUpdate& u : records)
+    if (!u.moved && c->prev_models.size() == 16 * (size_t)ni) memcpy(&c->prev_models[16 * (size_t)u.instance], c->instances[u.instance].model, 64);
+  // pinned update records, double-buffered against the kernel that reads them
+  const int k = c->rf_k;
+  c->rf_k ^= 1;
+  if (c->rf_pending[k]) {
+    HK_HIP(hipEventSynchronize(c->rf_done[k]));
+    c->rf_pending[k] = false;
+  }
+  if (c->rf_updates_cap[k] < records.size()) {
+    if (c->rf_updates[k]) (void)hipHostFree(c->rf_updates[k]);
+    c->rf_updates[k] = nullptr;
+    c->rf_updates_cap[k] = records.size() + records.size() / 2 + 16;
+    HK_HIP(hipHostMalloc((void**)&c->rf_updates[k], c->rf_updates_cap[k] * sizeof(hkd::RefitUpdate), hipHostMallocDefault));
+  }
+  if (!c->rf_done[k]) HK_HIP(hipEventCreateWithFlags(&c->rf_done[k], hipEventDisableTiming));
+  memcpy(c->rf_updates[k], records.data(), records.size() * sizeof(hkd::RefitUpdate));
+  // frames in flight keep reading the slot they were enqueued with: refit a copy in the spare slot (two-slot scenes), or in
+  // place behind everything enqueued so far (scenes small enough for the LDS copy have one slot)
+  if ((rc = join_side(c))) return rc;
+  if (c->two_slots) {
+    uint8_t* from = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+    c->slot ^= 1;
+    uint8_t* to = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+    launch_copy_region(c->stream, to, from, c->dyn_capacity);
+    point_scene_at_slot(c);
+  }
+  const hkd::RefitScene r = refit_scene(c);
+  uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+  launch_refit(c->stream, r, c->rf_updates[k], (uint32_t)records.size(), nullptr, (float4*)(base + c->dyn_off.tlas), (uint32_t)c->instance_nodes.size(),
+               c->threaded ? 8u : 1u, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi), (uint32_t)c->emissive_nodes.size());
+  HK_HIP(hipGetLastError());
+  HK_HIP(hipEventRecord(c->rf_done[k], c->stream));
+  c->rf_pending[k] = true;
+  c->d_prev_models = c->rf_prev_models;
+  c->rf_last_moved = moved;
+  c->mirrors_stale = true;
+  c->device_refits += 1;
+  builder_commit_transforms(b);
+  return HK_OK;
 }
 int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
   HK_REQUIRE(c && (images || !n), HK_E_INVALID, "NULL argument");
@@ -1666,6 +1880,7 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   out->scene_mesh_builds = c->static_rebuilds;
   out->scene_instance_builds = c->dynamic_rebuilds;
   out->scene_async_instance_uploads = c->async_instance_uploads;
+  out->scene_device_refits = c->device_refits;
   for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
     out->pass_ms_total[i] = c->slot_ms[i];
     out->pass_launches[i] = c->slot_launches[i];

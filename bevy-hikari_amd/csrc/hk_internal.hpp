@@ -26,6 +26,22 @@ std::vector<HkNode> build_flat_bvh(const std::vector<float>& boxes_min_max);
 // well-formed flatten_custom array.  Indices are local to the array.
 bool rethread_flat_bvh(const HkNode* nodes, uint32_t count, uint32_t oct, HkNode* out);
 
+// ---- what the device refit (context.hip hk_refit_scene_instances) needs from a scene builder (private to scene_builder.cpp)
+struct InstanceDecl {
+  HkMeshIndex mesh;
+  uint32_t material;
+  const float* transform;    // 16 floats, column-major: the pose set by add_instance / set_instance_transform
+  const float* aabb_center;  // the mesh's local box (bevy Aabb): 3 + 3 floats
+  const float* aabb_half;
+};
+uint32_t builder_instance_count(const hk_scene_builder* b);
+bool builder_instance_decl(const hk_scene_builder* b, uint32_t i, InstanceDecl* out);
+// what hk_scene_builder_finish does to the PreviousMeshUniform bookkeeping, without building anything
+void builder_commit_transforms(hk_scene_builder* b);
+// instance.rs:286-325 for one instance: world AABB (8 corners of the local box, seeded at zero) and inverse().transpose();
+// false for a singular transform
+bool instance_world_record(const float transform[16], const float aabb_center[3], const float aabb_half[3], float mn[3], float mx[3], float inverse_transpose_model[16]);
+
 // bytes per pixel / full-size flag of an HkBuffer id (0 = invalid id)
 uint32_t buffer_bpp(uint32_t buffer);
 bool buffer_is_full_size(uint32_t buffer);

@@ -44,13 +44,16 @@ constexpr uint32_t WF_SHADOWS = 64u;  // [s] shadow rays trace stage s walks (em
 constexpr uint32_t WF_QHEAD = 128u;   // [s] rays of trace stage s claimed so far (its queue = the alive list, then the shadow list)
 
 #ifndef HK_WF_REFILL_MIN
-#define HK_WF_REFILL_MIN 4u   // a wave fetches new rays once this many lanes are idle (or all of them)
+#define HK_WF_REFILL_MIN 8u   // a wave fetches new rays once this many lanes are idle (or all of them)
 #endif
 #ifndef HK_WF_TRACE_WAVES
 #define HK_WF_TRACE_WAVES 7   // waves per SIMD the trace kernel is compiled for (69 VGPRs, no spills; 8 would spill 44 B per lane)
 #endif
 #ifndef HK_WF_STEPS
-#define HK_WF_STEPS 6         // node steps between two looks at the idle lanes
+#define HK_WF_STEPS 4         // node steps per turn of the node phase
+#endif
+#ifndef HK_WF_NODE_WEIGHT
+#define HK_WF_NODE_WEIGHT 1u  // the node phase runs while (lanes at nodes) x weight >= lanes parked at triangles / instance entries
 #endif
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {  // set bits of `mask` below this lane
@@ -189,13 +192,20 @@ __device__ __forceinline__ void walk_begin(Walk& k, const DScene& sc, f3 origin,
   k.cinv = k.inv_direction;
   k.ld = direction;
 }
-// returns true when the walk has ended (k.hit is the result)
-__device__ __forceinline__ bool walk_step(Walk& k, const DScene& sc) {
+// One step of the walk is one of three things: a NODE step (two 16-B loads, slab test, skip-link select: ~35 instructions, every
+// live lane takes one per iteration in the fused kernels), a TRIANGLE test (~60) or an instance ENTRY (ray transform, ~100).
+// In lock step the last two run whenever ANY lane needs them - with 64 live lanes that is every iteration, at 2-5 live lanes -
+// so refilled lanes alone leave the wave at ~16 % lane utilisation (measured, config 3).  Here a lane that reaches a hit leaf
+// PARKS with the leaf in `pending`; the wave runs whichever of the three phases has the most lanes waiting, so triangle tests
+// and entries execute with many lanes at once.  A lane's own sequence of steps - and with it every result bit - is unchanged.
+enum : uint32_t { PH_IDLE = 0u, PH_NODE = 1u, PH_TRI = 2u, PH_ENTRY = 3u };
+// NODE step; returns the lane's next phase (PH_IDLE: the walk has ended, k.hit is the result)
+__device__ __forceinline__ uint32_t walk_node(Walk& k, const DScene& sc, uint32_t& pending) {
   if (k.index >= k.limit) {
-    if (!k.in_blas) return true;
+    if (!k.in_blas) return PH_IDLE;
     if (k.intersected) {  // traverse_bottom returned, light.wgsl:465-470
       k.hit.instance_index = k.cur_instance;
-      if (k.hit.distance < k.early_distance) return true;
+      if (k.hit.distance < k.early_distance) return PH_IDLE;
     }
     k.in_blas = false;
     k.index = k.t_resume;
@@ -203,7 +213,7 @@ __device__ __forceinline__ bool walk_step(Walk& k, const DScene& sc) {
     k.base = k.tlas_base;
     k.co = k.origin;
     k.cinv = k.inv_direction;
-    return false;
+    return PH_NODE;
   }
   const float4* __restrict__ nd = sc.nodes + 2u * (k.base + k.index);
   const float4 lo = nd[0];
@@ -222,43 +232,47 @@ __device__ __forceinline__ bool walk_step(Walk& k, const DScene& sc) {
   const bool leaf = entry >= HK_LEAF;
   k.index = (leaf || !box_hit) ? exit_ : entry;
   if (leaf && box_hit) {
-    if (k.in_blas) {
-      const uint32_t primitive_index = k.prim_base + entry - HK_LEAF;
-      Ray lr;
-      lr.origin = k.co;
-      lr.direction = k.ld;
-      lr.inv_direction = k.cinv;
-      f2 uv;
-      const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
-      if (d < k.hit.distance) {
-        k.hit.uv = uv;
-        k.hit.distance = d;
-        k.hit.primitive_index = primitive_index;
-        k.intersected = true;
-        if (d < k.early_distance) {  // light.wgsl:421-423 then 466-469
-          k.hit.instance_index = k.cur_instance;
-          return true;
-        }
-      }
-    } else {
-      const uint32_t instance_index = entry - HK_LEAF;
-      if (instance_index != k.exclude_instance) {
-        const DInstance& in = sc.instances[instance_index];
-        k.co = world_to_local_position(in, k.origin);
-        k.ld = world_to_local_direction(in, k.direction);
-        k.cinv = 1.0f / k.ld;
-        k.t_resume = k.index;
-        k.base = sc.blas_base + ray_octant(k.ld) * sc.blas_stride + in.node_offset;
-        k.index = 0u;
-        k.limit = in.node_count;
-        k.prim_base = in.primitive;
-        k.cur_instance = instance_index;
-        k.in_blas = true;
-        k.intersected = false;
-      }
+    pending = entry - HK_LEAF;
+    if (k.in_blas) return PH_TRI;
+    if (pending != k.exclude_instance) return PH_ENTRY;
+  }
+  return PH_NODE;
+}
+// TRIANGLE test of the parked leaf; PH_IDLE when the hit ends the walk (any-hit early out)
+__device__ __forceinline__ uint32_t walk_triangle(Walk& k, const DScene& sc, uint32_t pending) {
+  const uint32_t primitive_index = k.prim_base + pending;
+  Ray lr;
+  lr.origin = k.co;
+  lr.direction = k.ld;
+  lr.inv_direction = k.cinv;
+  f2 uv;
+  const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+  if (d < k.hit.distance) {
+    k.hit.uv = uv;
+    k.hit.distance = d;
+    k.hit.primitive_index = primitive_index;
+    k.intersected = true;
+    if (d < k.early_distance) {  // light.wgsl:421-423 then 466-469
+      k.hit.instance_index = k.cur_instance;
+      return PH_IDLE;
     }
   }
-  return false;
+  return PH_NODE;
+}
+// ENTRY into the parked instance (light.wgsl:458-464)
+__device__ __forceinline__ void walk_enter(Walk& k, const DScene& sc, uint32_t instance_index) {
+  const DInstance& in = sc.instances[instance_index];
+  k.co = world_to_local_position(in, k.origin);
+  k.ld = world_to_local_direction(in, k.direction);
+  k.cinv = 1.0f / k.ld;
+  k.t_resume = k.index;
+  k.base = sc.blas_base + ray_octant(k.ld) * sc.blas_stride + in.node_offset;
+  k.index = 0u;
+  k.limit = in.node_count;
+  k.prim_base = in.primitive;
+  k.cur_instance = instance_index;
+  k.in_blas = true;
+  k.intersected = false;
 }
 }  // namespace
 
@@ -275,22 +289,32 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
   // the wave's reserve: entries [res_base, res_base + res_count) of the queue are this wave's to hand to its lanes
   uint32_t res_base = 0u, res_count = 0u;
   bool exhausted = tail == 0u;  // nothing left to reserve from the queue
-  bool active = false;
+  uint32_t phase = PH_IDLE, pending = 0u;
   uint32_t entry_id = 0u;
   Walk k;
   walk_begin(k, sc, F3(0, 0, 0), F3(1, 1, 1), 0.0f, 0.0f, HK_DONT_EXCLUDE);
+  auto finish = [&]() {  // the lane's walk has ended: its result goes to the slot, the lane is free
+    const uint32_t slot = entry_id & ~WF_SHADOW;
+    if (entry_id & WF_SHADOW) {
+      w.sh[slot] = k.hit.instance_index;
+    } else {
+      w.ch0[slot] = make_float4(k.hit.distance, k.hit.uv.x, k.hit.uv.y, u2f(k.hit.primitive_index));
+      w.ch1[slot] = k.hit.instance_index;
+    }
+  };
   for (;;) {
-    const unsigned long long idle_mask = __ballot(!active);
+    const unsigned long long idle_mask = __ballot(phase == PH_IDLE);
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     const bool dry = exhausted && res_count == 0u;
     if (dry && n_idle == 64u) break;
     if (!dry && (n_idle >= HK_WF_REFILL_MIN || n_idle == 64u)) {
+      const bool idle = phase == PH_IDLE;
       const uint32_t rank = lane_rank(idle_mask);
       uint32_t mine = HK_U32_MAX;
       uint32_t given = 0u;
       if (res_count < n_idle && !exhausted) {  // hand out what is left, then reserve the next block
         given = res_count;
-        if (!active && rank < given) mine = res_base + rank;
+        if (idle && rank < given) mine = res_base + rank;
         // one atomic per 256 rays while every lane of the launch can still be fed four more times from what is left, per 64
         // near the end of the queue (short blocks there keep the last waves from walking a long reserve alone)
         const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : 64u;
@@ -301,7 +325,7 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
         res_count = b < tail ? min(block, tail - b) : 0u;
         if (b + block >= tail) exhausted = true;
       }
-      if (!active && rank >= given && rank - given < res_count) mine = res_base + (rank - given);
+      if (idle && rank >= given && rank - given < res_count) mine = res_base + (rank - given);
       const uint32_t used = min(n_idle - given, res_count);
       res_base += used;
       res_count -= used;
@@ -315,20 +339,30 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
           const float4 a = w.cr0[slot], b4 = w.cr1[slot];
           walk_begin(k, sc, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE);
         }
-        active = true;
+        phase = PH_NODE;
       }
     }
+    // the phase with the most lanes waiting runs (ties: nodes, then triangles)
+    const uint32_t n_node = (uint32_t)__popcll(__ballot(phase == PH_NODE));
+    const uint32_t n_tri = (uint32_t)__popcll(__ballot(phase == PH_TRI));
+    const uint32_t n_entry = (uint32_t)__popcll(__ballot(phase == PH_ENTRY));
+    if (n_node * HK_WF_NODE_WEIGHT >= n_tri && n_node * HK_WF_NODE_WEIGHT >= n_entry && n_node != 0u) {
 #pragma unroll 1
-    for (int s = 0; s < HK_WF_STEPS; ++s) {
-      if (active && walk_step(k, sc)) {
-        const uint32_t slot = entry_id & ~WF_SHADOW;
-        if (entry_id & WF_SHADOW) {
-          w.sh[slot] = k.hit.instance_index;
-        } else {
-          w.ch0[slot] = make_float4(k.hit.distance, k.hit.uv.x, k.hit.uv.y, u2f(k.hit.primitive_index));
-          w.ch1[slot] = k.hit.instance_index;
+      for (int s = 0; s < HK_WF_STEPS; ++s) {
+        if (phase == PH_NODE) {
+          phase = walk_node(k, sc, pending);
+          if (phase == PH_IDLE) finish();
         }
-        active = false;
+      }
+    } else if (n_tri >= n_entry) {
+      if (phase == PH_TRI) {
+        phase = walk_triangle(k, sc, pending);
+        if (phase == PH_IDLE) finish();
+      }
+    } else {
+      if (phase == PH_ENTRY) {
+        walk_enter(k, sc, pending);
+        phase = PH_NODE;
       }
     }
   }

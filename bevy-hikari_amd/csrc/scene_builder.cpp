@@ -326,6 +326,47 @@ std::vector<HkAliasEntry> build_alias_table(const std::vector<float>& areas) {
 }  // namespace
 }  // namespace hk
 
+namespace hk {
+bool instance_world_record(const float transform[16], const float aabb_center[3], const float aabb_half[3], float mn_out[3], float mx_out[3], float itm[16]) {
+  float center[3];
+  mat_point(transform, aabb_center, center);
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};  // seeded at zero, instance.rs:298-299
+  for (int corner = 0; corner < 8; ++corner) {
+    float e[3] = {aabb_half[0] * (float)(2 * (corner & 1) - 1), aabb_half[1] * (float)(2 * ((corner >> 1) & 1) - 1), aabb_half[2] * (float)(2 * ((corner >> 2) & 1) - 1)};
+    float t[3];
+    mat_vector(transform, e, t);
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = std::min(mn[k], t[k]);
+      mx[k] = std::max(mx[k], t[k]);
+    }
+  }
+  for (int k = 0; k < 3; ++k) {
+    mn_out[k] = mn[k] + center[k];
+    mx_out[k] = mx[k] + center[k];
+  }
+  return inverse_transpose(transform, itm);
+}
+uint32_t builder_instance_count(const hk_scene_builder* b) { return b ? (uint32_t)b->instance_decl.size() : 0u; }
+bool builder_instance_decl(const hk_scene_builder* b, uint32_t i, InstanceDecl* out) {
+  if (!b || !b->finished || b->meshes_dirty || i >= b->instance_decl.size()) return false;
+  const BuilderInstance& d = b->instance_decl[i];
+  out->mesh = b->mesh_index[d.mesh];
+  out->material = d.material;
+  out->transform = d.transform;
+  out->aabb_center = b->meshes[d.mesh].aabb_center;
+  out->aabb_half = b->meshes[d.mesh].aabb_half;
+  return true;
+}
+void builder_commit_transforms(hk_scene_builder* b) {
+  std::vector<float> now(b->instance_decl.size() * 16);
+  for (size_t i = 0; i < b->instance_decl.size(); ++i) memcpy(&now[16 * i], b->instance_decl[i].transform, 64);
+  b->previous_transforms = now;
+  const size_t common = std::min(now.size(), b->finished_transforms.size());
+  if (common) memcpy(b->previous_transforms.data(), b->finished_transforms.data(), common * sizeof(float));
+  b->finished_transforms.swap(now);
+}
+}  // namespace hk
+
 using namespace hk;
 
 extern "C" {
@@ -454,40 +495,17 @@ int hk_scene_builder_finish(hk_scene_builder* b) {
     b->meshes_dirty = false;
   }
   b->instances.clear(); b->instance_nodes.clear(); b->emissives.clear(); b->emissive_nodes.clear(); b->alias_table.clear();
-  {  // PreviousMeshUniform: what the transforms were at the last finish (new instances: their own)
-    std::vector<float> now(b->instance_decl.size() * 16);
-    for (size_t i = 0; i < b->instance_decl.size(); ++i) memcpy(&now[16 * i], b->instance_decl[i].transform, 64);
-    b->previous_transforms = now;
-    const size_t common = std::min(now.size(), b->finished_transforms.size());
-    if (common) memcpy(b->previous_transforms.data(), b->finished_transforms.data(), common * sizeof(float));
-    b->finished_transforms.swap(now);
-  }
+  builder_commit_transforms(b);  // PreviousMeshUniform: what the transforms were at the last finish (new instances: their own)
   // instance.rs:286-325
   std::vector<float> boxes;
   for (const BuilderInstance& d : b->instance_decl) {
     const BuilderMesh& mesh = b->meshes[d.mesh];
     HkInstance inst;
     memset(&inst, 0, sizeof(inst));
-    float center[3];
-    mat_point(d.transform, mesh.aabb_center, center);
-    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};  // seeded at zero, instance.rs:298-299
-    for (int corner = 0; corner < 8; ++corner) {
-      float e[3] = {mesh.aabb_half[0] * (float)(2 * (corner & 1) - 1), mesh.aabb_half[1] * (float)(2 * ((corner >> 1) & 1) - 1),
-                    mesh.aabb_half[2] * (float)(2 * ((corner >> 2) & 1) - 1)};
-      float t[3];
-      mat_vector(d.transform, e, t);
-      for (int k = 0; k < 3; ++k) {
-        mn[k] = std::min(mn[k], t[k]);
-        mx[k] = std::max(mx[k], t[k]);
-      }
-    }
-    for (int k = 0; k < 3; ++k) {
-      inst.min[k] = mn[k] + center[k];
-      inst.max[k] = mx[k] + center[k];
-    }
+    HK_REQUIRE(instance_world_record(d.transform, mesh.aabb_center, mesh.aabb_half, inst.min, inst.max, inst.inverse_transpose_model), HK_E_INVALID,
+               "singular instance transform");
     inst.material = d.material;
     memcpy(inst.model, d.transform, 64);
-    HK_REQUIRE(inverse_transpose(d.transform, inst.inverse_transpose_model), HK_E_INVALID, "singular instance transform");
     inst.mesh = b->mesh_index[d.mesh];
     b->instances.push_back(inst);
     boxes.insert(boxes.end(), inst.min, inst.min + 3);

@@ -432,6 +432,13 @@ class Engine:
         """Instance-level update of a scene whose meshes and materials are already uploaded."""
         scene.upload_instances(self.api, self.ctx)
 
+    def refit_instances(self, builder):
+        """Instance motion on the device (hk_refit_scene_instances): the poses set on `builder` since the last upload / refit go to
+        the GPU, which redoes the per-instance work and refits both trees.  Returns the number of instances that moved."""
+        moved = C.c_uint32()
+        self.api.call("refit_scene_instances", self.ctx, builder.h, C.byref(moved))
+        return moved.value
+
     def upload_textures(self, images):
         """images: list of dict(rgba=uint8[h][w][4], srgb=bool, address_u/address_v=F.ADDRESS_*, linear=bool) -
         the `textures` / `samplers` binding arrays (mod.rs:760-782).  Material *_texture ids index this list."""

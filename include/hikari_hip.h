@@ -324,6 +324,8 @@ typedef struct HkStats {
   /* ... of which the instance-level arrays went through pinned staging into the spare slot in stream order, with no
    * host or device wait (scenes larger than the 32 KB LDS copy keep two slots of the instance-level region) */
   uint64_t scene_async_instance_uploads;
+  /* instance updates that ran on the device (hk_refit_scene_instances): no host tree build, no scene buffer over PCIe */
+  uint64_t scene_device_refits;
 } HkStats;
 
 typedef struct hk_ctx hk_ctx;
@@ -446,6 +448,20 @@ typedef struct HkImageDesc {
   uint32_t address_u, address_v; /* HkAddressMode */
   uint32_t filter_linear;        /* 0 = nearest, 1 = bilinear (mag/min filter of the image's sampler) */
 } HkImageDesc;
+/* Instance motion on the DEVICE.  The reference re-runs prepare_instances on the CPU whenever an instance
+ * moves (instance.rs:286-437): per-instance world AABB and inverse-transpose matrix, the emitter records that follow from them
+ * (position, radius, surface area, alias table), a fresh `BVH::build` of the instance tree and of the light tree, and a re-upload
+ * of all five buffers.  hk_upload_scene_instances is that path (host rebuild, asynchronous upload into the spare slot).  This
+ * entry point instead diffs the builder's poses (hk_scene_builder_set_instance_transform) against the poses the device holds and
+ * hands the moved instances - 96 B each, read by the kernel from pinned memory - to the GPU: one kernel redoes the per-instance and
+ * per-emitter work with the host builder's exact arithmetic, two more REFIT the instance tree (in all of its direction-threaded
+ * orderings) and the light tree: same topology, every inner box the union of the leaf boxes below it.  Stream-ordered, no host or
+ * device wait; frames in flight keep the slot they were enqueued with.  What it does NOT do is change the shape of the trees: after
+ * large displacements a host calls hk_upload_scene_instances now and then to get the reference's SAH tree back (any-hit identity
+ * and tie-breaks follow the tree, so a refit frame equals the reference frame for THAT tree, not for the rebuilt one).
+ * Instances must be the ones uploaded (same count, meshes, materials); *moved (optional) = how many poses changed.  The builder's
+ * previous-transform bookkeeping advances as it would in hk_scene_builder_finish. */
+int hk_refit_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t* moved);
 int hk_upload_textures(hk_ctx* ctx, const HkImageDesc* images, uint32_t n_images);
 /* InstanceRenderAssets::set + write_buffer, instance.rs:82-108 */
 int hk_upload_instances(hk_ctx* ctx, const HkInstance* instances, uint32_t n_instances, const HkNode* instance_nodes,

@@ -1,0 +1,148 @@
+"""Instance motion on the device (hk_refit_scene_instances): the GPU redoes the per-instance / per-emitter work
+of prepare_instances (instance.rs:286-420) and REFITS both trees.  The oracle is fed exactly what that must produce - the host
+builder's per-instance records for the new poses, on the OLD tree shapes with every inner box re-derived as the union of the
+leaves below it (numpy, here) - and every buffer of every frame must agree bit for bit."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+from bevy_hikari_amd.plugin import SceneData
+from bevy_hikari_amd.scenes import synthetic_camera, synthetic_scene
+from cases import diff_buffers, product_default_traversal, snapshot
+
+pytestmark = pytest.mark.gpu
+LEAF = 0x80000000
+
+
+def oracle():
+    from oracle_lib import oracle_plugin
+
+    return oracle_plugin()
+
+
+def refit_nodes(nodes, boxes):
+    """`nodes` (HkNode ctypes array, bvh 0.7.1 flatten_custom layout) with every navigator's box = union of the shape boxes in its
+    subtree (i, exit); leaves keep the empty box the reference stores.  boxes: float32[n_shapes][2][3]."""
+    out = (F.HkNode * len(nodes))()
+    C.memmove(out, nodes, C.sizeof(out))
+    entry = np.array([n.entry_index for n in nodes], dtype=np.uint32)
+    for i, n in enumerate(nodes):
+        if entry[i] >= LEAF:
+            continue
+        leaves = [int(entry[j] - LEAF) for j in range(i + 1, min(n.exit_index, len(nodes))) if entry[j] >= LEAF]
+        mn, mx = boxes[leaves, 0].min(axis=0), boxes[leaves, 1].max(axis=0)
+        for k in range(3):
+            out[i].min[k], out[i].max[k] = float(mn[k]), float(mx[k])
+    return out
+
+
+def pose(rest, frame, k):
+    m = rest.reshape(4, 4).T.astype(np.float64)
+    ang = 0.07 * frame * (1 + k)
+    c, s = math.cos(ang), math.sin(ang)
+    rot = np.array([[c, 0, s, 0], [0, 1, 0, 0], [-s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float64)
+    shift = np.eye(4)
+    shift[0, 3] = 0.05 * frame * (1 if k % 2 == 0 else -1)
+    shift[1, 3] = 0.02 * frame * (k % 3 == 0)
+    return (shift @ m @ rot).T.astype(np.float32).reshape(-1)
+
+
+def run_refit_sequence(kw, size, movers_of_frame, flags=0, frames=5, settings=None):
+    """GPU: one upload, then hk_refit_scene_instances per frame.  Oracle: the expected arrays per frame (see the module docstring)."""
+    dev_scene, sun = synthetic_scene(**kw)     # its builder feeds the device refit
+    ref_scene, _ = synthetic_scene(**kw)       # a twin builder produces the host records for the same poses
+    s = settings or hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam, lights = synthetic_camera(*size), hk.lights_uniform(directional=sun)
+    gpu, cpu = hk.HikariPlugin(device=0, flags=flags), oracle()
+    gpu.set_scene(dev_scene)
+    cpu.set_scene(ref_scene)
+    rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in ref_scene.instances], dtype=np.float32)
+    current = rest.copy()
+    builds = gpu.engine.stats().scene_instance_builds
+    for n in range(1, frames + 1):
+        if n > 1:
+            movers = movers_of_frame(n)
+            previous = current.copy()
+            for k, i in enumerate(movers):
+                current[i] = pose(rest[i], n - 1, k)
+                dev_scene.builder.set_instance_transform(i, current[i])
+                ref_scene.builder.set_instance_transform(i, current[i])
+            assert gpu.engine.refit_instances(dev_scene.builder) == len(movers)
+            new = ref_scene.builder.finish()
+            boxes = np.array([[list(i.min), list(i.max)] for i in new.instances], dtype=np.float32)
+            eboxes = np.array([[[e.position[k] - e.radius for k in range(3)], [e.position[k] + e.radius for k in range(3)]] for e in new.emissives], dtype=np.float32)
+            expected = SceneData(previous_transforms=previous, vertices=ref_scene.vertices, primitives=ref_scene.primitives, asset_nodes=ref_scene.asset_nodes,
+                                 materials=ref_scene.materials, instances=new.instances, instance_nodes=refit_nodes(ref_scene.instance_nodes, boxes),
+                                 emissives=new.emissives, emissive_nodes=refit_nodes(ref_scene.emissive_nodes, eboxes) if len(new.emissives) else new.emissive_nodes,
+                                 alias_table=new.alias_table)
+            cpu.update_instances(expected)
+        for p in (gpu, cpu):
+            p.render(cam, s, lights=lights, frame_number=n)
+        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        assert bad == {}, f"frame {n}: {bad}"
+    st = gpu.engine.stats()
+    assert st.scene_device_refits == frames - 1 and st.scene_instance_builds == builds, "the instance-level arrays must not have been rebuilt on the host"
+    return gpu
+
+
+SMALL = dict(n_boxes=3, n_spheres=1, n_emitters=1, sphere_rings=4, sphere_segs=5)    # fits the LDS copy: one slot, refit in place
+LARGE = dict(n_boxes=20, n_spheres=5, n_emitters=3, sphere_rings=12, sphere_segs=16)  # two slots: refit in the spare one
+
+
+def test_refit_small_scene_vs_oracle():
+    n = 1 + 3 + 1 + 1
+    run_refit_sequence(SMALL, (88, 60), lambda f: [1, 4, n - 1])  # a box, the sphere and the emitter move every frame
+
+
+def test_refit_large_scene_vs_oracle():
+    n = 1 + 20 + 5 + 3
+    movers = [2, 7, 11, 22, n - 1, n - 3]  # boxes, a sphere, two of the three emitters
+    run_refit_sequence(LARGE, (120, 72), lambda f: movers if f % 2 == 0 else movers[:3] + [14])  # some rest every other frame: their `moved` flag goes
+
+
+def test_refit_with_three_bounces_and_aa_tail():
+    s = hk.HikariSettings(indirect_bounces=3, emissive_spatial_reuse=True, upscale=hk.Upscale.SmaaTu4x(1.5))
+    run_refit_sequence(LARGE, (96, 64), lambda f: [3, 9, 26], settings=s, frames=4)
+
+
+def test_refit_with_direction_threaded_orderings_stays_within_tolerance():
+    """Product defaults (eight orderings of the instance tree, all refit): against the reference-order refit of the same sequence."""
+    kw, size = LARGE, (160, 96)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    outs = []
+    for exact in (True, False):
+        scene, sun = synthetic_scene(**kw)
+        cam, lights = synthetic_camera(*size), hk.lights_uniform(directional=sun)
+        if exact:
+            p = hk.HikariPlugin(device=0, flags=F.CTX_EXACT_TRAVERSAL)
+        else:
+            with product_default_traversal():
+                p = hk.HikariPlugin(device=0)
+        p.set_scene(scene)
+        rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in scene.instances], dtype=np.float32)
+        for n in range(1, 6):
+            if n > 1:
+                for k, i in enumerate((2, 7, 22, 28)):
+                    scene.builder.set_instance_transform(i, pose(rest[i], n - 1, k))
+                assert p.engine.refit_instances(scene.builder) == 4
+            p.render(cam, s, lights=lights, frame_number=n)
+        outs.append((p.output(s), snapshot(p)))
+    (a, sa), (b, sb) = outs
+    assert float(np.linalg.norm(a - b) / np.linalg.norm(a)) <= 1e-3
+    assert (sa["position"] == sb["position"]).mean() > 0.999  # the G-buffer: equal up to exact ties between two triangles
+
+
+def test_refit_refuses_what_it_cannot_do():
+    scene, _ = synthetic_scene(**SMALL)
+    gpu = hk.HikariPlugin(device=0)
+    gpu.set_scene(scene)
+    other, _ = synthetic_scene(n_boxes=5, n_spheres=1, n_emitters=1, sphere_rings=4, sphere_segs=5)
+    with pytest.raises(hk.HikariError):   # another instance count
+        gpu.engine.refit_instances(other.builder)
+    scene.builder.set_instance_transform(1, np.zeros(16, np.float32))
+    with pytest.raises(hk.HikariError):   # singular transform
+        gpu.engine.refit_instances(scene.builder)
