@@ -348,7 +348,8 @@ bool instance_world_record(const float transform[16], const float aabb_center[3]
 }
 uint32_t builder_instance_count(const hk_scene_builder* b) { return b ? (uint32_t)b->instance_decl.size() : 0u; }
 bool builder_instance_decl(const hk_scene_builder* b, uint32_t i, InstanceDecl* out) {
-  if (!b || !b->finished || b->meshes_dirty || i >= b->instance_decl.size()) return false;
+  // (poses set since the last finish are exactly what the caller is after; the MESH buffers must be the finished ones)
+  if (!b || b->meshes_dirty || b->mesh_index.size() != b->meshes.size() || i >= b->instance_decl.size()) return false;
   const BuilderInstance& d = b->instance_decl[i];
   out->mesh = b->mesh_index[d.mesh];
   out->material = d.material;

@@ -551,6 +551,12 @@ class Engine:
     def reset_stats(self):
         self.api.call("reset_stats", self.ctx)
 
+    def stream(self):
+        """The HIP stream the context enqueues on (hk_stream), as an integer handle."""
+        h = C.c_void_p()
+        self.api.call("stream", self.ctx, C.byref(h))
+        return h.value or 0
+
     def set_stream(self, hip_stream_ptr):
         """Run all subsequent work on a host-owned HIP stream (e.g. torch.cuda.current_stream().cuda_stream)."""
         self.api.call("set_stream", self.ctx, C.c_void_p(hip_stream_ptr))

@@ -51,8 +51,9 @@ def pose(rest, frame, k):
     return (shift @ m @ rot).T.astype(np.float32).reshape(-1)
 
 
-def run_refit_sequence(kw, size, movers_of_frame, flags=0, frames=5, settings=None):
-    """GPU: one upload, then hk_refit_scene_instances per frame.  Oracle: the expected arrays per frame (see the module docstring)."""
+def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCATTER, frames=5, settings=None):
+    """GPU: one upload, then hk_refit_scene_instances per frame.  Oracle: the expected arrays per frame (see the module docstring).
+    Moving objects make the reference's scatter-store race observable: it is resolved the oracle's way here."""
     dev_scene, sun = synthetic_scene(**kw)     # its builder feeds the device refit
     ref_scene, _ = synthetic_scene(**kw)       # a twin builder produces the host records for the same poses
     s = settings or hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
@@ -62,7 +63,7 @@ def run_refit_sequence(kw, size, movers_of_frame, flags=0, frames=5, settings=No
     cpu.set_scene(ref_scene)
     rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in ref_scene.instances], dtype=np.float32)
     current = rest.copy()
-    builds = gpu.engine.stats().scene_instance_builds
+    builds = None
     for n in range(1, frames + 1):
         if n > 1:
             movers = movers_of_frame(n)
@@ -84,6 +85,8 @@ def run_refit_sequence(kw, size, movers_of_frame, flags=0, frames=5, settings=No
             p.render(cam, s, lights=lights, frame_number=n)
         bad = diff_buffers(snapshot(gpu), snapshot(cpu))
         assert bad == {}, f"frame {n}: {bad}"
+        if n == 1:
+            builds = gpu.engine.stats().scene_instance_builds  # the upload
     st = gpu.engine.stats()
     assert st.scene_device_refits == frames - 1 and st.scene_instance_builds == builds, "the instance-level arrays must not have been rebuilt on the host"
     return gpu
