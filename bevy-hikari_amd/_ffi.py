@@ -139,7 +139,7 @@ class HkStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
                 ("_pad", u32), ("scene_mesh_builds", u64), ("scene_instance_builds", u64),
-                ("scene_async_instance_uploads", u64), ("scene_device_refits", u64)]
+                ("scene_async_instance_uploads", u64), ("scene_device_refits", u64), ("scene_device_tree_builds", u64)]
 
 
 assert C.sizeof(HkVertex) == 32 and C.sizeof(HkPrimitive) == 48 and C.sizeof(HkNode) == 32 and C.sizeof(HkInstance) == 176
@@ -206,6 +206,8 @@ _PRODUCT_ONLY = {
     "upload_scene": [_vp, _vp],
     "upload_scene_instances": [_vp, _vp],
     "refit_scene_instances": [_vp, _vp, P(u32)],
+    "rebuild_scene_trees": [_vp],
+    "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
     "band_plan_for": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],

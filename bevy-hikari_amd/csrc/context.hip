@@ -201,7 +201,9 @@ struct hk_ctx {
   int rf_k = 0;
   std::vector<uint32_t> rf_last_moved;    // instances whose `moved` flag is set on the device
   bool mirrors_stale = false;             // the host copies of emissives / tree boxes no longer describe the device scene
-  uint64_t device_refits = 0;
+  uint64_t device_refits = 0, device_tree_builds = 0;
+  void* lbvh_scratch = nullptr;           // hk_rebuild_scene_trees
+  size_t lbvh_scratch_cap = 0;
   const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
   DevArray<uint32_t> d_noise;
   DevArray<uint32_t> d_tex_data;
@@ -1319,6 +1321,9 @@ void free_refit(hk_ctx* c) {
   c->rf_alias_scratch = nullptr;
   c->rf_instances = c->rf_alias = 0;
   c->rf_ready = false;
+  if (c->lbvh_scratch) (void)hipFree(c->lbvh_scratch);
+  c->lbvh_scratch = nullptr;
+  c->lbvh_scratch_cap = 0;
   for (int k = 0; k < 2; ++k) {
     if (c->rf_updates[k]) (void)hipHostFree(c->rf_updates[k]);
     if (c->rf_done[k]) (void)hipEventDestroy(c->rf_done[k]);
@@ -1389,6 +1394,95 @@ int prepare_refit(hk_ctx* c) {
   return HK_OK;
 }
 }  // namespace
+
+namespace {
+// frames in flight keep reading the slot they were enqueued with: a device-side update works on a copy in the spare slot
+// (two-slot scenes), or in place behind everything enqueued so far (scenes small enough for the LDS copy have one slot)
+int begin_device_update(hk_ctx* c) {
+  const int rc = join_side(c);
+  if (rc) return rc;
+  if (c->two_slots) {
+    uint8_t* from = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+    c->slot ^= 1;
+    uint8_t* to = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+    launch_copy_region(c->stream, to, from, c->dyn_capacity);
+    const float4* prev = c->d_prev_models;
+    point_scene_at_slot(c);
+    if (prev == c->rf_prev_models) c->d_prev_models = prev;  // (the refit's own plane is not part of the slot)
+  }
+  return HK_OK;
+}
+}  // namespace
+
+int hk_rebuild_scene_trees(hk_ctx* c) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
+  HK_HIP(hipSetDevice(c->device));
+  int rc;
+  if ((rc = finalize_scene(c))) return rc;
+  const uint32_t ni = (uint32_t)c->instances.size(), ne = (uint32_t)c->emissives.size();
+  HK_REQUIRE(c->instance_nodes.size() == 3 * (size_t)ni - 2 && (ne == 0 || c->emissive_nodes.size() == 3 * (size_t)ne - 2), HK_E_UNSUPPORTED,
+             "the uploaded trees are not in the flatten_custom layout of a binary tree (3n - 2 nodes): nothing to rebuild in place");
+  if ((rc = prepare_refit(c))) return rc;
+  const size_t need = std::max(lbvh_scratch_bytes(ni, nullptr), lbvh_scratch_bytes(std::max(ne, 1u), nullptr));
+  if (need > c->lbvh_scratch_cap) {
+    if ((rc = sync_all(c))) return rc;
+    if (c->lbvh_scratch) (void)hipFree(c->lbvh_scratch);
+    c->lbvh_scratch = nullptr;
+    c->lbvh_scratch_cap = need + need / 4;
+    HK_HIP(hipMalloc(&c->lbvh_scratch, c->lbvh_scratch_cap));
+  }
+  if ((rc = begin_device_update(c))) return rc;
+  const hkd::RefitScene r = refit_scene(c);
+  uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+  float4* tlas = (float4*)(base + c->dyn_off.tlas);
+  HK_REQUIRE(launch_lbvh_build(c->stream, false, r, ni, c->rf_inst_lo, c->rf_inst_hi, c->lbvh_scratch, tlas, tlas + 1, 2u, c->threaded ? 8u : 1u) == 0, HK_E_HIP,
+             "LBVH build of the instance tree failed: %s", hipGetErrorString(hipGetLastError()));
+  if (ne)
+    HK_REQUIRE(launch_lbvh_build(c->stream, true, r, ne, nullptr, nullptr, c->lbvh_scratch, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi),
+                                 1u, 1u) == 0, HK_E_HIP, "LBVH build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
+  c->mirrors_stale = true;
+  c->device_tree_builds += 1;
+  return HK_OK;
+}
+
+// Test hook: the instance tree (ordering 0) and the light tree as the device holds them, converted back to the reference layout
+// (navigators that took over their single leaf's role - fold_leaf_navigators - point at the leaf again)
+int hk_debug_read_trees(hk_ctx* c, HkNode* tlas, uint32_t tlas_cap, HkNode* light, uint32_t light_cap) {
+  HK_REQUIRE(c && (tlas || !tlas_cap) && (light || !light_cap), HK_E_INVALID, "NULL argument");
+  HK_HIP(hipSetDevice(c->device));
+  int rc;
+  if ((rc = finalize_scene(c))) return rc;
+  if ((rc = sync_all(c))) return rc;
+  const uint32_t nt = (uint32_t)c->instance_nodes.size(), nl = (uint32_t)c->emissive_nodes.size();
+  HK_REQUIRE(tlas_cap >= nt && light_cap >= nl, HK_E_INVALID, "need room for %u + %u nodes", nt, nl);
+  const uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
+  auto convert = [](const std::vector<float4>& lo, const std::vector<float4>& hi, HkNode* out) {
+    const uint32_t n = (uint32_t)lo.size();
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    for (uint32_t k = 0; k < n; ++k) {
+      out[k].min[0] = lo[k].x; out[k].min[1] = lo[k].y; out[k].min[2] = lo[k].z;
+      out[k].max[0] = hi[k].x; out[k].max[1] = hi[k].y; out[k].max[2] = hi[k].z;
+      out[k].entry_index = bits(lo[k].w);
+      out[k].exit_index = bits(hi[k].w);
+    }
+    for (uint32_t k = 0; k + 1 < n; ++k)
+      if (out[k].entry_index >= HK_BVH_LEAF_FLAG && out[k + 1].entry_index == out[k].entry_index && out[k + 1].exit_index == out[k].exit_index) out[k].entry_index = k + 1;
+  };
+  if (nt) {
+    std::vector<float4> both(2 * (size_t)nt), lo(nt), hi(nt);
+    HK_HIP(hipMemcpy(both.data(), base + c->dyn_off.tlas, both.size() * 16, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < nt; ++k) { lo[k] = both[2 * k]; hi[k] = both[2 * k + 1]; }
+    convert(lo, hi, tlas);
+  }
+  if (nl) {
+    std::vector<float4> lo(nl), hi(nl);
+    HK_HIP(hipMemcpy(lo.data(), base + c->dyn_off.light_lo, (size_t)nl * 16, hipMemcpyDeviceToHost));
+    HK_HIP(hipMemcpy(hi.data(), base + c->dyn_off.light_hi, (size_t)nl * 16, hipMemcpyDeviceToHost));
+    convert(lo, hi, light);
+  }
+  return HK_OK;
+}
 
 int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out) {
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
@@ -1469,14 +1563,7 @@ int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out
   memcpy(c->rf_updates[k], records.data(), records.size() * sizeof(hkd::RefitUpdate));
   // frames in flight keep reading the slot they were enqueued with: refit a copy in the spare slot (two-slot scenes), or in
   // place behind everything enqueued so far (scenes small enough for the LDS copy have one slot)
-  if ((rc = join_side(c))) return rc;
-  if (c->two_slots) {
-    uint8_t* from = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-    c->slot ^= 1;
-    uint8_t* to = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-    launch_copy_region(c->stream, to, from, c->dyn_capacity);
-    point_scene_at_slot(c);
-  }
+  if ((rc = begin_device_update(c))) return rc;
   const hkd::RefitScene r = refit_scene(c);
   uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
   launch_refit(c->stream, r, c->rf_updates[k], (uint32_t)records.size(), nullptr, (float4*)(base + c->dyn_off.tlas), (uint32_t)c->instance_nodes.size(),
@@ -1881,6 +1968,7 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   out->scene_instance_builds = c->dynamic_rebuilds;
   out->scene_async_instance_uploads = c->async_instance_uploads;
   out->scene_device_refits = c->device_refits;
+  out->scene_device_tree_builds = c->device_tree_builds;
   for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
     out->pass_ms_total[i] = c->slot_ms[i];
     out->pass_launches[i] = c->slot_launches[i];

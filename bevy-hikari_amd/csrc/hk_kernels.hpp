@@ -233,6 +233,11 @@ void launch_copy_region(hipStream_t st, void* dst, const void* src, size_t bytes
 void launch_gather_instance_boxes(hipStream_t st, const hkd::RefitScene& s, const float4* tlas, uint32_t tlas_count);
 void launch_refit(hipStream_t st, const hkd::RefitScene& s, const hkd::RefitUpdate* updates, uint32_t n_updates, uint32_t* failed, float4* tlas,
                   uint32_t tlas_count, uint32_t orderings, float4* light_lo, float4* light_hi, uint32_t light_count);
+// LBVH rebuild of a flat skip-link BVH over n shapes (kernels_scene.hip): scratch size, and the build into `lo` / `hi` (`stride`
+// float4 between consecutive nodes: 2 for the interleaved TLAS, 1 for the two planes of the light BVH)
+size_t lbvh_scratch_bytes(uint32_t n, size_t* sort_temp_bytes);
+int launch_lbvh_build(hipStream_t st, bool light, const hkd::RefitScene& s, uint32_t n, const float4* box_lo, const float4* box_hi, void* scratch, float4* lo,
+                      float4* hi, uint32_t stride, uint32_t orderings);
 void launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                     int y0, int y1);
 void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);

@@ -15,6 +15,11 @@
 // upload for the same tree shape, bit for bit (tests/test_device_refit.py feeds the oracle exactly that).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 
@@ -240,6 +245,211 @@ __global__ __launch_bounds__(256) void k_gather_instance_boxes(RefitScene s, con
   s.inst_hi[entry - HK_LEAF] = make_float4(hi.x, hi.y, hi.z, 0.0f);
 }
 
+
+// ------------------------------------------------------------------ LBVH rebuild of a flat skip-link BVH (Lauterbach 2009 / Karras 2012)
+// hk_rebuild_scene_trees: when motion has degraded a refit tree, a NEW tree over the current leaf boxes is built on the
+// device - Morton codes of the box centres, one radix sort (rocPRIM), Karras' parallel hierarchy, boxes bottom-up - and
+// written straight into the `bvh` 0.7.1 flatten_custom layout the walk expects: a subtree with L leaves occupies 3L - 2
+// consecutive nodes, [navigator of the first child][its subtree][navigator of the second child][its subtree], so the position
+// of every node follows from leaf counts alone (no traversal, no stack).  Any binary tree over n shapes has 3n - 2 nodes:
+// the new tree fills the old one's storage exactly.  Child order per direction octant = the host's hk_bvh_rethread rule.
+struct LbvhBuffers {
+  uint32_t n;                   // shapes
+  const float4 *box_lo, *box_hi;  // LIGHT: derived from emissives instead
+  float* bounds;                // 6 floats: min / max of the box centres (x2)
+  uint32_t *codes, *codes_sorted, *ids, *ids_sorted;
+  // tree nodes: internal i in [0, n - 1), leaf j as n - 1 + j (j = position in the sorted order)
+  uint32_t *parent, *left, *right, *first, *last;  // per internal node (first / last: sorted leaf range it covers)
+  uint32_t* leaf_parent;        // per sorted leaf
+  float4 *node_lo, *node_hi;    // per tree node (2n - 1)
+  uint32_t* arrived;            // per internal node: bottom-up visit counter
+  uint8_t* swap;                // per internal node: bit o set = the RIGHT child comes first in ordering o
+};
+namespace {
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {  // 10 bits -> every third bit
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+template <bool LIGHT>
+__device__ __forceinline__ void lbvh_shape_box(const RefitScene& s, const LbvhBuffers& b, uint32_t shape, f3& mn, f3& mx) {
+  if (LIGHT) {
+    const float4 pr = s.emissives[shape].position_radius;
+    mn = F3(pr.x - pr.w, pr.y - pr.w, pr.z - pr.w);
+    mx = F3(pr.x + pr.w, pr.y + pr.w, pr.z + pr.w);
+  } else {
+    mn = xyz(F4(b.box_lo[shape]));
+    mx = xyz(F4(b.box_hi[shape]));
+  }
+}
+// common prefix length of the (code, position) keys of sorted leaves i and j; -1 outside the array
+__device__ __forceinline__ int lbvh_delta(const uint32_t* __restrict__ codes, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint32_t a = codes[i], c = codes[j];
+  if (a != c) return __clz((int)(a ^ c));
+  return 32 + __clz(i ^ j);
+}
+}  // namespace
+
+template <bool LIGHT>
+__global__ __launch_bounds__(1024) void k_lbvh_bounds(RefitScene s, LbvhBuffers b) {  // one workgroup
+  __shared__ float red[6][16];
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (uint32_t i = threadIdx.x; i < b.n; i += 1024u) {
+    f3 lo, hi;
+    lbvh_shape_box<LIGHT>(s, b, i, lo, hi);
+    const float c[3] = {lo.x + hi.x, lo.y + hi.y, lo.z + hi.z};
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = fminf(mn[k], c[k]);
+      mx[k] = fmaxf(mx[k], c[k]);
+    }
+  }
+  for (int k = 0; k < 3; ++k)
+    for (int off = 32; off > 0; off >>= 1) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], off));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
+    }
+  if ((threadIdx.x & 63u) == 0u)
+    for (int k = 0; k < 3; ++k) {
+      red[k][threadIdx.x >> 6] = mn[k];
+      red[3 + k][threadIdx.x >> 6] = mx[k];
+    }
+  __syncthreads();
+  if (threadIdx.x < 6u) {
+    float v = red[threadIdx.x][0];
+    for (int w = 1; w < 16; ++w) v = threadIdx.x < 3u ? fminf(v, red[threadIdx.x][w]) : fmaxf(v, red[threadIdx.x][w]);
+    b.bounds[threadIdx.x] = v;
+  }
+}
+template <bool LIGHT>
+__global__ __launch_bounds__(256) void k_lbvh_codes(RefitScene s, LbvhBuffers b) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= b.n) return;
+  f3 lo, hi;
+  lbvh_shape_box<LIGHT>(s, b, i, lo, hi);
+  const float c[3] = {lo.x + hi.x, lo.y + hi.y, lo.z + hi.z};
+  uint32_t q[3];
+  for (int k = 0; k < 3; ++k) {
+    const float ext = b.bounds[3 + k] - b.bounds[k];
+    const float t = ext > 0.0f ? (c[k] - b.bounds[k]) / ext : 0.0f;
+    q[k] = (uint32_t)fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+  }
+  b.codes[i] = (expand_bits(q[0]) << 2) | (expand_bits(q[1]) << 1) | expand_bits(q[2]);
+  b.ids[i] = i;
+}
+// Karras 2012, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", section 4: one thread per internal node
+__global__ __launch_bounds__(256) void k_lbvh_hierarchy(LbvhBuffers b) {
+  const int n = (int)b.n, i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= n - 1) return;
+  const uint32_t* codes = b.codes_sorted;
+  const int d = (lbvh_delta(codes, n, i, i + 1) - lbvh_delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = lbvh_delta(codes, n, i, i - d);
+  int lmax = 2;
+  while (lbvh_delta(codes, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (lbvh_delta(codes, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = lbvh_delta(codes, n, i, j);
+  int sft = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (lbvh_delta(codes, n, i, i + (sft + t) * d) > dnode) sft += t;
+    if (t <= 1) break;
+  }
+  const int gamma = i + sft * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  const uint32_t lc = (lo == gamma) ? (uint32_t)(n - 1 + gamma) : (uint32_t)gamma;              // leaf gamma or internal gamma
+  const uint32_t rc = (hi == gamma + 1) ? (uint32_t)(n - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+  b.left[i] = lc;
+  b.right[i] = rc;
+  b.first[i] = (uint32_t)lo;
+  b.last[i] = (uint32_t)hi;
+  if (lc >= (uint32_t)(n - 1)) b.leaf_parent[lc - (uint32_t)(n - 1)] = (uint32_t)i; else b.parent[lc] = (uint32_t)i;
+  if (rc >= (uint32_t)(n - 1)) b.leaf_parent[rc - (uint32_t)(n - 1)] = (uint32_t)i; else b.parent[rc] = (uint32_t)i;
+  if (i == 0) b.parent[0] = HK_U32_MAX;
+}
+// leaf boxes, then every internal node by the second of its children to arrive (min / max are exact: any order gives the same box)
+template <bool LIGHT>
+__global__ __launch_bounds__(256) void k_lbvh_boxes(RefitScene s, LbvhBuffers b) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= b.n) return;
+  f3 mn, mx;
+  lbvh_shape_box<LIGHT>(s, b, b.ids_sorted[j], mn, mx);
+  b.node_lo[b.n - 1u + j] = make_float4(mn.x, mn.y, mn.z, 0.0f);
+  b.node_hi[b.n - 1u + j] = make_float4(mx.x, mx.y, mx.z, 0.0f);
+  if (b.n == 1u) return;
+  uint32_t p = b.leaf_parent[j];
+  for (;;) {
+    __threadfence();
+    if (atomicAdd(&b.arrived[p], 1u) == 0u) return;  // the sibling subtree is not finished: its thread continues from here
+    __threadfence();
+    const uint32_t l = b.left[p], r = b.right[p];
+    const volatile float4* vlo = b.node_lo;
+    const volatile float4* vhi = b.node_hi;
+    const f3 al = F3(vlo[l].x, vlo[l].y, vlo[l].z), ah = F3(vhi[l].x, vhi[l].y, vhi[l].z);
+    const f3 bl = F3(vlo[r].x, vlo[r].y, vlo[r].z), bh = F3(vhi[r].x, vhi[r].y, vhi[r].z);
+    b.node_lo[p] = make_float4(hmin(al.x, bl.x), hmin(al.y, bl.y), hmin(al.z, bl.z), 0.0f);
+    b.node_hi[p] = make_float4(hmax(ah.x, bh.x), hmax(ah.y, bh.y), hmax(ah.z, bh.z), 0.0f);
+    // child order per direction octant: host_logic.cpp rethread_flat_bvh (the axis along which the two boxes are furthest apart)
+    int axis = 0;
+    float best = -1.0f, ca_axis = 0.0f, cb_axis = 0.0f;
+    const float ca[3] = {al.x + ah.x, al.y + ah.y, al.z + ah.z}, cb[3] = {bl.x + bh.x, bl.y + bh.y, bl.z + bh.z};
+    for (int k = 0; k < 3; ++k) {
+      const float dd = fabsf(ca[k] - cb[k]);
+      if (dd > best) { best = dd; axis = k; ca_axis = ca[k]; cb_axis = cb[k]; }
+    }
+    const bool a_lower = ca_axis <= cb_axis;
+    uint32_t sw = 0u;
+    for (uint32_t o = 0; o < 8u; ++o) {
+      const bool negative = (o >> axis) & 1u;
+      if (!(a_lower != negative)) sw |= 1u << o;
+    }
+    b.swap[p] = (uint8_t)sw;
+    p = b.parent[p];
+    if (p == HK_U32_MAX) return;
+  }
+}
+// every tree node except the root writes the navigator in front of its subtree; leaves also write their own slot
+__global__ __launch_bounds__(256) void k_lbvh_emit(LbvhBuffers b, float4* lo, float4* hi, uint32_t stride, uint32_t orderings) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x, n = b.n, total = 2u * n - 1u;
+  if (t >= total * orderings) return;
+  const uint32_t o = t / total, v = t - o * total, count = 3u * n - 2u;
+  float4* nlo = lo + (size_t)o * count * stride;
+  float4* nhi = hi + (size_t)o * count * stride;
+  const bool leaf = v >= n - 1u;
+  const uint32_t shape = leaf ? b.ids_sorted[v - (n - 1u)] : 0u;
+  const float4 blo = b.node_lo[v], bhi = b.node_hi[v];
+  if (n == 1u) {  // flatten_custom of a single leaf: the leaf alone
+    nlo[0] = make_float4(blo.x, blo.y, blo.z, u2f(HK_LEAF | shape));
+    nhi[0] = make_float4(bhi.x, bhi.y, bhi.z, u2f(1u));
+    return;
+  }
+  if (!leaf && v == 0u) return;  // the root has no navigator
+  // start of this node's subtree: walk to the root; a first child starts one node after its parent's start (its navigator),
+  // a second child after the whole first branch
+  auto leaves_of = [&](uint32_t node) { return node >= n - 1u ? 1u : b.last[node] - b.first[node] + 1u; };
+  uint32_t start = 0u, c = v, p = leaf ? b.leaf_parent[v - (n - 1u)] : b.parent[v];
+  while (p != HK_U32_MAX) {
+    const bool right_first = (b.swap[p] >> o) & 1u;
+    const uint32_t first_child = right_first ? b.right[p] : b.left[p];
+    start += (c == first_child) ? 1u : 2u + (3u * leaves_of(first_child) - 2u);
+    c = p;
+    p = b.parent[p];
+  }
+  const uint32_t size = 3u * leaves_of(v) - 2u;
+  if (leaf) {  // folded navigator (context.hip fold_leaf_navigators) + the leaf slot
+    nlo[(size_t)(start - 1u) * stride] = make_float4(blo.x, blo.y, blo.z, u2f(HK_LEAF | shape));
+    nhi[(size_t)(start - 1u) * stride] = make_float4(bhi.x, bhi.y, bhi.z, u2f(start + 1u));
+    nlo[(size_t)start * stride] = make_float4(blo.x, blo.y, blo.z, u2f(HK_LEAF | shape));
+    nhi[(size_t)start * stride] = make_float4(bhi.x, bhi.y, bhi.z, u2f(start + 1u));
+  } else {
+    nlo[(size_t)(start - 1u) * stride] = make_float4(blo.x, blo.y, blo.z, u2f(start));
+    nhi[(size_t)(start - 1u) * stride] = make_float4(bhi.x, bhi.y, bhi.z, u2f(start + size));
+  }
+}
+
 }  // namespace hkd
 
 namespace hk {
@@ -263,6 +473,56 @@ void launch_refit(hipStream_t st, const RefitScene& s, const RefitUpdate* update
     hipLaunchKernelGGL((k_refit_flat_bvh<false>), dim3((waves + 3u) / 4u), dim3(256), 0, st, s, tlas, tlas + 1, 2u, tlas_count, orderings);
   }
   if (light_count) hipLaunchKernelGGL((k_refit_flat_bvh<true>), dim3((light_count + 3u) / 4u), dim3(256), 0, st, s, light_lo, light_hi, 1u, light_count, 1u);
+}
+
+
+// scratch of one LBVH build over n shapes: bytes, and the carving of a single allocation
+size_t lbvh_scratch_bytes(uint32_t n, size_t* sort_temp_bytes) {
+  size_t temp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 30);
+  temp = (temp + 255) & ~(size_t)255;
+  if (sort_temp_bytes) *sort_temp_bytes = temp;
+  const size_t nn = ((size_t)n + 63) & ~(size_t)63;
+  return 256 + temp + nn * (4 * 4 /* codes, ids x2 */ + 5 * 4 /* parent, left, right, first, last */ + 4 /* leaf_parent */ + 4 /* arrived */ + 4 /* swap (padded) */) +
+         2 * nn * 2 * 16 /* node boxes, 2n - 1 */;
+}
+// `tree` = the node array to overwrite: LIGHT ? two planes (lo, hi) : interleaved pairs
+int launch_lbvh_build(hipStream_t st, bool light, const RefitScene& s, uint32_t n, const float4* box_lo, const float4* box_hi, void* scratch, float4* lo, float4* hi,
+                      uint32_t stride, uint32_t orderings) {
+  if (n == 0) return 0;
+  size_t temp = 0;
+  (void)lbvh_scratch_bytes(n, &temp);
+  const size_t nn = ((size_t)n + 63) & ~(size_t)63;
+  uint8_t* p = (uint8_t*)scratch;
+  LbvhBuffers b;
+  b.n = n;
+  b.box_lo = box_lo;
+  b.box_hi = box_hi;
+  b.bounds = (float*)p; p += 256;
+  void* sort_temp = p; p += temp;
+  auto u32 = [&]() { uint32_t* q = (uint32_t*)p; p += nn * 4; return q; };
+  b.codes = u32(); b.codes_sorted = u32(); b.ids = u32(); b.ids_sorted = u32();
+  b.parent = u32(); b.left = u32(); b.right = u32(); b.first = u32(); b.last = u32(); b.leaf_parent = u32(); b.arrived = u32();
+  b.swap = (uint8_t*)u32();
+  b.node_lo = (float4*)p; p += 2 * nn * 16;
+  b.node_hi = (float4*)p; p += 2 * nn * 16;
+  (void)hipMemsetAsync(b.arrived, 0, nn * 4, st);
+  (void)hipMemsetAsync(b.swap, 0, nn * 4, st);
+  const dim3 per_shape((n + 255u) / 256u);
+  if (light) {
+    hipLaunchKernelGGL((k_lbvh_bounds<true>), dim3(1), dim3(1024), 0, st, s, b);
+    hipLaunchKernelGGL((k_lbvh_codes<true>), per_shape, dim3(256), 0, st, s, b);
+  } else {
+    hipLaunchKernelGGL((k_lbvh_bounds<false>), dim3(1), dim3(1024), 0, st, s, b);
+    hipLaunchKernelGGL((k_lbvh_codes<false>), per_shape, dim3(256), 0, st, s, b);
+  }
+  if (rocprim::radix_sort_pairs(sort_temp, temp, (const uint32_t*)b.codes, b.codes_sorted, (const uint32_t*)b.ids, b.ids_sorted, (size_t)n, 0, 30, st) != hipSuccess) return 1;
+  if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, b);
+  if (light) hipLaunchKernelGGL((k_lbvh_boxes<true>), per_shape, dim3(256), 0, st, s, b);
+  else hipLaunchKernelGGL((k_lbvh_boxes<false>), per_shape, dim3(256), 0, st, s, b);
+  const uint32_t threads = (2u * n - 1u) * orderings;
+  hipLaunchKernelGGL(k_lbvh_emit, dim3((threads + 255u) / 256u), dim3(256), 0, st, b, lo, hi, stride, orderings);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
 }  // namespace hk

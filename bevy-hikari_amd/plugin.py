@@ -439,6 +439,17 @@ class Engine:
         self.api.call("refit_scene_instances", self.ctx, builder.h, C.byref(moved))
         return moved.value
 
+    def rebuild_trees(self):
+        """New instance tree and light tree over the current boxes, built on the device (hk_rebuild_scene_trees, LBVH)."""
+        self.api.call("rebuild_scene_trees", self.ctx)
+
+    def read_trees(self, n_instance_nodes, n_emissive_nodes):
+        """(instance_nodes, emissive_nodes) as the device holds them, in the reference layout (test hook)."""
+        a, b = (F.HkNode * max(1, n_instance_nodes))(), (F.HkNode * max(1, n_emissive_nodes))()
+        self.api.call("debug_read_trees", self.ctx, a, n_instance_nodes, b, n_emissive_nodes)
+        return (F.HkNode * n_instance_nodes).from_buffer_copy(bytes(a)[:n_instance_nodes * C.sizeof(F.HkNode)]), \
+               (F.HkNode * n_emissive_nodes).from_buffer_copy(bytes(b)[:n_emissive_nodes * C.sizeof(F.HkNode)])
+
     def upload_textures(self, images):
         """images: list of dict(rgba=uint8[h][w][4], srgb=bool, address_u/address_v=F.ADDRESS_*, linear=bool) -
         the `textures` / `samplers` binding arrays (mod.rs:760-782).  Material *_texture ids index this list."""

@@ -326,6 +326,7 @@ typedef struct HkStats {
   uint64_t scene_async_instance_uploads;
   /* instance updates that ran on the device (hk_refit_scene_instances): no host tree build, no scene buffer over PCIe */
   uint64_t scene_device_refits;
+  uint64_t scene_device_tree_builds;  /* hk_rebuild_scene_trees */
 } HkStats;
 
 typedef struct hk_ctx hk_ctx;
@@ -462,6 +463,15 @@ typedef struct HkImageDesc {
  * Instances must be the ones uploaded (same count, meshes, materials); *moved (optional) = how many poses changed.  The builder's
  * previous-transform bookkeeping advances as it would in hk_scene_builder_finish. */
 int hk_refit_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t* moved);
+/* ... and the REBUILD on the device: new trees over the instances' and the emitters' current boxes - Morton codes of the box
+ * centres, one radix sort, Karras' parallel hierarchy (LBVH), boxes bottom-up - written in place in the flatten_custom layout
+ * (all direction-threaded orderings of the instance tree, child order by the rule of hk_bvh_rethread).  For when refits have
+ * degraded a tree and the host's SAH rebuild (hk_upload_scene_instances) is not wanted on the frame's critical path: 0.1-0.2 ms on
+ * the stream at 2 000-20 000 instances.  The tree is a different one (spatial-median splits instead of the `bvh` crate's binned
+ * SAH): frames equal the reference's up to exact ties between candidates, like any other valid tree over the same instances. */
+int hk_rebuild_scene_trees(hk_ctx* ctx);
+/* Test hook: the instance tree (ordering 0) and the light tree as the device holds them, in the reference's HkNode layout. */
+int hk_debug_read_trees(hk_ctx* ctx, HkNode* instance_nodes, uint32_t instance_cap, HkNode* emissive_nodes, uint32_t emissive_cap);
 int hk_upload_textures(hk_ctx* ctx, const HkImageDesc* images, uint32_t n_images);
 /* InstanceRenderAssets::set + write_buffer, instance.rs:82-108 */
 int hk_upload_instances(hk_ctx* ctx, const HkInstance* instances, uint32_t n_instances, const HkNode* instance_nodes,

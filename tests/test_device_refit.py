@@ -51,7 +51,28 @@ def pose(rest, frame, k):
     return (shift @ m @ rot).T.astype(np.float32).reshape(-1)
 
 
-def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCATTER, frames=5, settings=None):
+def check_tree(nodes, n_shapes, boxes):
+    """A well-formed flatten_custom array over n_shapes: every shape in exactly one leaf, 3n - 2 nodes, every navigator's box the
+    union of the leaves in its subtree, subtree sizes consistent with the exit links."""
+    assert len(nodes) == 3 * n_shapes - 2
+    entry = np.array([n.entry_index for n in nodes], dtype=np.int64)
+    exit_ = np.array([n.exit_index for n in nodes], dtype=np.int64)
+    leaves = entry[entry >= LEAF] - LEAF
+    assert sorted(leaves.tolist()) == list(range(n_shapes))
+    for i in range(len(nodes)):
+        if entry[i] >= LEAF:
+            assert exit_[i] == i + 1
+        else:
+            assert entry[i] == i + 1 and i + 1 < exit_[i] <= len(nodes)
+            k = int(((entry[i + 1:exit_[i]] >= LEAF)).sum())
+            assert exit_[i] - (i + 1) == 3 * k - 2, "a navigator spans exactly one subtree"
+    again = refit_nodes(nodes, boxes)
+    for a, b in zip(again, nodes):
+        if b.entry_index < LEAF:
+            assert list(a.min) == list(b.min) and list(a.max) == list(b.max)
+
+
+def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCATTER, frames=5, settings=None, rebuild_on=()):
     """GPU: one upload, then hk_refit_scene_instances per frame.  Oracle: the expected arrays per frame (see the module docstring).
     Moving objects make the reference's scatter-store race observable: it is resolved the oracle's way here."""
     dev_scene, sun = synthetic_scene(**kw)     # its builder feeds the device refit
@@ -64,6 +85,7 @@ def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCAT
     rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in ref_scene.instances], dtype=np.float32)
     current = rest.copy()
     builds = None
+    topo_tlas, topo_light = ref_scene.instance_nodes, ref_scene.emissive_nodes  # the tree shapes the device holds
     for n in range(1, frames + 1):
         if n > 1:
             movers = movers_of_frame(n)
@@ -76,9 +98,15 @@ def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCAT
             new = ref_scene.builder.finish()
             boxes = np.array([[list(i.min), list(i.max)] for i in new.instances], dtype=np.float32)
             eboxes = np.array([[[e.position[k] - e.radius for k in range(3)], [e.position[k] + e.radius for k in range(3)]] for e in new.emissives], dtype=np.float32)
+            if n in rebuild_on:  # hk_rebuild_scene_trees: new tree shapes, built on the device; the oracle gets exactly those
+                gpu.engine.rebuild_trees()
+                topo_tlas, topo_light = gpu.engine.read_trees(len(topo_tlas), len(topo_light))
+                check_tree(topo_tlas, len(new.instances), boxes)
+                if len(new.emissives):
+                    check_tree(topo_light, len(new.emissives), eboxes)
             expected = SceneData(previous_transforms=previous, vertices=ref_scene.vertices, primitives=ref_scene.primitives, asset_nodes=ref_scene.asset_nodes,
-                                 materials=ref_scene.materials, instances=new.instances, instance_nodes=refit_nodes(ref_scene.instance_nodes, boxes),
-                                 emissives=new.emissives, emissive_nodes=refit_nodes(ref_scene.emissive_nodes, eboxes) if len(new.emissives) else new.emissive_nodes,
+                                 materials=ref_scene.materials, instances=new.instances, instance_nodes=refit_nodes(topo_tlas, boxes),
+                                 emissives=new.emissives, emissive_nodes=refit_nodes(topo_light, eboxes) if len(new.emissives) else new.emissive_nodes,
                                  alias_table=new.alias_table)
             cpu.update_instances(expected)
         for p in (gpu, cpu):
@@ -89,6 +117,7 @@ def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCAT
             builds = gpu.engine.stats().scene_instance_builds  # the upload
     st = gpu.engine.stats()
     assert st.scene_device_refits == frames - 1 and st.scene_instance_builds == builds, "the instance-level arrays must not have been rebuilt on the host"
+    assert st.scene_device_tree_builds == len([n for n in rebuild_on if 1 < n <= frames])
     return gpu
 
 
@@ -110,6 +139,44 @@ def test_refit_large_scene_vs_oracle():
 def test_refit_with_three_bounces_and_aa_tail():
     s = hk.HikariSettings(indirect_bounces=3, emissive_spatial_reuse=True, upscale=hk.Upscale.SmaaTu4x(1.5))
     run_refit_sequence(LARGE, (96, 64), lambda f: [3, 9, 26], settings=s, frames=4)
+
+
+def test_device_rebuilt_trees_vs_oracle():
+    """hk_rebuild_scene_trees (LBVH on the device) in the middle of a refit sequence: the trees are read back, checked for
+    well-formedness and handed to the oracle - every buffer of every frame bit for bit, before and after the rebuilds."""
+    n = 1 + 20 + 5 + 3
+    run_refit_sequence(LARGE, (120, 72), lambda f: [2, 7, 11, 22, n - 1, n - 3], frames=6, rebuild_on=(3, 5))
+    m = 1 + 3 + 1 + 1
+    run_refit_sequence(SMALL, (88, 60), lambda f: [1, 4, m - 1], frames=4, rebuild_on=(2, 3))
+
+
+def test_device_rebuild_of_all_orderings_stays_within_tolerance():
+    """Product defaults: the rebuild writes all eight direction-threaded orderings; against the reference-order context."""
+    kw, size = LARGE, (160, 96)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    outs = []
+    for exact in (True, False):
+        scene, sun = synthetic_scene(**kw)
+        cam, lights = synthetic_camera(*size), hk.lights_uniform(directional=sun)
+        if exact:
+            p = hk.HikariPlugin(device=0, flags=F.CTX_EXACT_TRAVERSAL)
+        else:
+            with product_default_traversal():
+                p = hk.HikariPlugin(device=0)
+        p.set_scene(scene)
+        rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in scene.instances], dtype=np.float32)
+        for n in range(1, 6):
+            if n > 1:
+                for k, i in enumerate((2, 7, 22, 28)):
+                    scene.builder.set_instance_transform(i, pose(rest[i], n - 1, k))
+                assert p.engine.refit_instances(scene.builder) == 4
+                if n == 3:
+                    p.engine.rebuild_trees()
+            p.render(cam, s, lights=lights, frame_number=n)
+        outs.append((p.output(s), snapshot(p)))
+    (a, sa), (b, sb) = outs
+    assert float(np.linalg.norm(a - b) / np.linalg.norm(a)) <= 1e-3
+    assert (sa["position"] == sb["position"]).mean() > 0.999
 
 
 def test_refit_with_direction_threaded_orderings_stays_within_tolerance():
