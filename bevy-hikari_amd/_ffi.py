@@ -227,6 +227,8 @@ _PRODUCT_ONLY = {
     "multi_context": [_vp, u32, P(_vp)],
     "multi_upload_scene": [_vp, _vp],
     "multi_upload_scene_instances": [_vp, _vp],
+    "multi_refit_scene_instances": [_vp, _vp, P(u32)],
+    "multi_rebuild_scene_trees": [_vp],
     "multi_upload_textures": [_vp, P(HkImageDesc), u32],
     "multi_upload_noise": [_vp, _vp, C.c_size_t],
     "multi_resize": [_vp, u32, u32, f32],

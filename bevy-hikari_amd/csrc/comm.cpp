@@ -377,6 +377,7 @@ int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out) {
 
 int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene(c, b)); }
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene_instances(c, b)); }
+int hk_multi_rebuild_scene_trees(hk_multi* m) { HK_EACH(hk_rebuild_scene_trees(c)); }
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n) { HK_EACH(hk_upload_textures(c, images, n)); }
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes) { HK_EACH(hk_upload_noise(c, rgba, bytes)); }
 int hk_multi_resize(hk_multi* m, uint32_t w, uint32_t h, float ratio) {
@@ -386,6 +387,15 @@ int hk_multi_resize(hk_multi* m, uint32_t w, uint32_t h, float ratio) {
 }
 int hk_multi_wait(hk_multi* m) { HK_EACH(hk_frame_wait(c)); }
 #undef HK_EACH
+// every band's context refits its own replica of the scene; the builder's bookkeeping advances once
+int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* moved) {
+  HK_REQUIRE(m && b, HK_E_INVALID, "NULL argument");
+  for (size_t i = 0; i < m->ctx.size(); ++i) {
+    const int rc = hk::refit_instances_impl(m->ctx[i], b, moved, i + 1 == m->ctx.size());
+    if (rc) return rc;
+  }
+  return HK_OK;
+}
 
 int hk_multi_set_history_rows(hk_multi* m, uint32_t rows) {
   HK_REQUIRE(m && rows < (1u << 16), HK_E_INVALID, "bad argument");

@@ -1484,7 +1484,8 @@ int hk_debug_read_trees(hk_ctx* c, HkNode* tlas, uint32_t tlas_cap, HkNode* ligh
   return HK_OK;
 }
 
-int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out) {
+// `commit`: advance the builder's previous-transform bookkeeping (once per update, whichever context sees it last)
+static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool commit) {
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
   HK_HIP(hipSetDevice(c->device));
@@ -1529,7 +1530,7 @@ int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out
       }
   }
   if (records.empty()) {
-    builder_commit_transforms(b);
+    if (commit) builder_commit_transforms(b);
     return HK_OK;
   }
   // host mirrors of the moved instances
@@ -1575,9 +1576,10 @@ int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out
   c->rf_last_moved = moved;
   c->mirrors_stale = true;
   c->device_refits += 1;
-  builder_commit_transforms(b);
+  if (commit) builder_commit_transforms(b);
   return HK_OK;
 }
+int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out) { return refit_impl(c, b, moved_out, true); }
 int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
   HK_REQUIRE(c && (images || !n), HK_E_INVALID, "NULL argument");
   std::vector<hk_ctx::HostTexture> tex(n);
@@ -2066,3 +2068,5 @@ int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float*
 }
 
 }  // extern "C"
+
+int hk::refit_instances_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved, bool commit) { return refit_impl(c, b, moved, commit); }

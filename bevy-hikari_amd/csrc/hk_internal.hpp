@@ -42,6 +42,8 @@ void builder_commit_transforms(hk_scene_builder* b);
 // false for a singular transform
 bool instance_world_record(const float transform[16], const float aabb_center[3], const float aabb_half[3], float mn[3], float mx[3], float inverse_transpose_model[16]);
 
+int refit_instances_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved, bool commit);  // hk_refit_scene_instances
+
 // bytes per pixel / full-size flag of an HkBuffer id (0 = invalid id)
 uint32_t buffer_bpp(uint32_t buffer);
 bool buffer_is_full_size(uint32_t buffer);

@@ -257,6 +257,7 @@ class SceneBuilder {  // the Prepare-stage host work: mesh -> BLAS, TLAS, emissi
   }
   void finish() { check(hk_scene_builder_finish(h_), "hk_scene_builder_finish"); }
   const hk_scene_builder* handle() const { return h_; }
+  hk_scene_builder* handle() { return h_; }
 
  private:
   hk_scene_builder* h_ = nullptr;
@@ -340,6 +341,13 @@ class HikariPlugin {
   void set_scene(const SceneBuilder& b) { check(hk_upload_scene(ctx_.get(), b.handle()), "hk_upload_scene"); }
   // after SceneBuilder::set_instance_transform + finish: rewrite the instance-level device arrays only
   void update_instances(const SceneBuilder& b) { check(hk_upload_scene_instances(ctx_.get(), b.handle()), "hk_upload_scene_instances"); }
+  // instance motion on the device: the poses set on `b` since the last upload / refit; returns how many moved
+  uint32_t refit_instances(SceneBuilder& b) {
+    uint32_t moved = 0;
+    check(hk_refit_scene_instances(ctx_.get(), b.handle(), &moved), "hk_refit_scene_instances");
+    return moved;
+  }
+  void rebuild_trees() { check(hk_rebuild_scene_trees(ctx_.get()), "hk_rebuild_scene_trees"); }
 
   // one frame of the camera's render graph; by_nodes = dispatch by dispatch through the three nodes,
   // otherwise one hk_frame_render call.  Returns the frame number used.
@@ -403,6 +411,12 @@ class HikariMultiGpuPlugin {
   HikariMultiGpuPlugin& operator=(const HikariMultiGpuPlugin&) = delete;
   void set_scene(const SceneBuilder& b) { check(hk_multi_upload_scene(m_, b.handle()), "hk_multi_upload_scene"); }
   void update_instances(const SceneBuilder& b) { check(hk_multi_upload_scene_instances(m_, b.handle()), "hk_multi_upload_scene_instances"); }
+  uint32_t refit_instances(SceneBuilder& b) {
+    uint32_t moved = 0;
+    check(hk_multi_refit_scene_instances(m_, b.handle(), &moved), "hk_multi_refit_scene_instances");
+    return moved;
+  }
+  void rebuild_trees() { check(hk_multi_rebuild_scene_trees(m_), "hk_multi_rebuild_scene_trees"); }
   // rows of last frame's reservoirs fetched across the band borders before reprojection (0 for a static camera)
   void set_history_rows(uint32_t rows) { check(hk_multi_set_history_rows(m_, rows), "hk_multi_set_history_rows"); }
   size_t render(const Camera& camera, const HikariSettings& settings, std::optional<size_t> frame_number = std::nullopt, const HkLights* lights = nullptr,

@@ -588,6 +588,8 @@ void hk_multi_destroy(hk_multi* m);
 int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out); /* the i-th band's context (borrowed) */
 int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b);
+int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* moved); /* hk_refit_scene_instances on every band's replica */
+int hk_multi_rebuild_scene_trees(hk_multi* m);
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n_images);
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes);
 int hk_multi_resize(hk_multi* m, uint32_t width, uint32_t height, float upscale_ratio);

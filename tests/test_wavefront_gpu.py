@@ -125,3 +125,33 @@ def test_wavefront_survives_resize_and_scene_change():
             for n in case.frames:
                 p.render(case.camera, case.settings, lights=case.lights, frame_number=n, antialias=case.antialias)
         assert diff_buffers(snapshot(a), snapshot(b)) == {}, name
+
+
+@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun")])
+def test_wavefront_bands_equal_single_context(tmp_path, world, case_name, monkeypatch):
+    """Band-sharded frames (one rank per band, all on device 0, halos over gloo) with the wavefront schedule forced in every rank:
+    each band's dispatch runs set-up / trace / shade / final over its own rows; the union equals the fused single-context frame."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from cases import run_case
+    from test_parity_gpu import _gpu_band_worker
+
+    monkeypatch.setenv("HIKARI_HIP_DEFAULT_CTX_FLAGS", str(F.CTX_EXACT_TRAVERSAL | F.CTX_WAVEFRONT))  # inherited by the spawned ranks
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gpu_band_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
+    case = make_case(case_name)
+    ref = hk.HikariPlugin(device=0, flags=F.CTX_FUSED_INDIRECT)
+    run_case(ref, case)
+    full = snapshot(ref)
+    for rank in range(world):
+        d = np.load(tmp_path / f"rank{rank}.npz")
+        b0, b1 = int(d["b0"]), int(d["b1"])
+        for key in d.files:
+            if key in ("b0", "b1") or key.endswith("_rows"):
+                continue
+            assert (d[key].view(np.uint8) == full[key][b0:b1].view(np.uint8)).all(), f"rank {rank} [{b0},{b1}) differs in {key}"
