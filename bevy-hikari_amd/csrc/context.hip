@@ -671,6 +671,9 @@ void point_scene_at_slot(hk_ctx* c) {
   s.tlas_stride = c->threaded ? (uint32_t)c->instance_nodes.size() : 0u;
   s.blas_stride = c->threaded ? (uint32_t)c->asset_nodes.size() : 0u;
   s.light_count = (uint32_t)c->emissive_nodes.size();
+  s.shared_xform = 1u;
+  for (const HkInstance& in : c->instances)
+    if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) s.shared_xform = 0u;
 }
 
 int finalize_scene(hk_ctx* c) {

@@ -80,6 +80,9 @@ struct DScene {
   uint32_t tlas_stride, blas_stride;
   const float4* __restrict__ blob;       // all arrays above (except noise) live in [blob, blob + blob_f4)
   uint32_t blob_f4;
+  // 1 when every instance has the same (bitwise) inverse model matrix - a single-asset scene under one root transform, like the
+  // Cornell box: the world -> local ray is then the same for every instance a ray enters (traverse_top)
+  uint32_t shared_xform;
 };
 // per-frame constants, passed by value (lands in SGPRs / scalar cache)
 struct DFrame {
@@ -469,6 +472,16 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
   bool in_blas = false, intersected = false;
   f3 co = ray.origin, cinv = ray.inv_direction;  // origin / inverse direction of the level being walked
   f3 ld = ray.direction;                          // local direction while inside a BLAS
+  // One inverse model for all instances: the local ray is formed ONCE, with every lane of the wave, instead of at each instance
+  // entry with the one or two lanes that happen to enter in that iteration (an entry is ~100 instructions and some lane needs
+  // one in a fifth of the iterations).  Same operands, same operations: same bits.
+  f3 hco = ray.origin, hld = ray.direction, hcinv = ray.inv_direction;
+  if (sc.shared_xform) {
+    const DInstance& in0 = sc.instances[0];
+    hco = world_to_local_position(in0, ray.origin);
+    hld = world_to_local_direction(in0, ray.direction);
+    hcinv = 1.0f / hld;
+  }
   for (;;) {
     HK_WALK_EVENT(0, true);
     HK_WALK_EVENT(3, index >= limit && in_blas);
@@ -536,9 +549,15 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
         const uint32_t instance_index = entry - HK_LEAF;
         if (instance_index != exclude_instance) {
           const DInstance& in = sc.instances[instance_index];
-          co = world_to_local_position(in, ray.origin);
-          ld = world_to_local_direction(in, ray.direction);
-          cinv = 1.0f / ld;
+          if (sc.shared_xform) {
+            co = hco;
+            ld = hld;
+            cinv = hcinv;
+          } else {
+            co = world_to_local_position(in, ray.origin);
+            ld = world_to_local_direction(in, ray.direction);
+            cinv = 1.0f / ld;
+          }
           t_resume = index;
           base = sc.blas_base + ray_octant(ld) * sc.blas_stride + in.node_offset;
           index = 0u;

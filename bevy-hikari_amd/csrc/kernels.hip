@@ -412,24 +412,33 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
     const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
     const f3 bounce_view_direction = normalize(p.position - sample_position);
 
+    // A shadow ray only selects between two radiance values (kernels_wavefront.hip, header): both are evaluated BEFORE the
+    // walk, and so is the throughput update, so the walk runs with the path state and six floats live instead of the
+    // surface, the candidate and the hit info.  Same operations on the same operands, same order of the additions.
+    const f3 next_transport = p.transport * env_brdf(bounce_view_direction, sample_normal, surface);
     if (dot(candidate.direction, sample_normal) > 0.0f && candidate.p > 0.0f) {
       ray.origin = sample_position + sample_normal * HK_RAY_BIAS;
       ray.direction = candidate.direction;
       ray.inv_direction = 1.0f / ray.direction;
+      const f4 in_clear = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
+      f3 add[2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const f4 in_radiance = o == 0 ? in_clear : F4(0.0f, 0.0f, 0.0f, 1.0f);
+        out_radiance = shading(fr, bounce_view_direction, sample_normal, ray.direction, surface, in_radiance);
+        out_radiance = out_radiance / candidate.p;
+        if (n > 0u) out_radiance = (rand_sample.w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample.w;
+        float out_luminance = luminance(out_radiance);
+        if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
+        add[o] = p.transport * out_radiance;
+      }
       HK_SEC(tm, 6);
       HK_ABLATE_WALK(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
       hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
       HK_SEC(tm, 7);
-      occlude_hit_info(ray, hit, info);
-      f4 in_radiance = input_radiance(sc, fr, ray, info, sample_directional, candidate.emissive_instance, false);
-      out_radiance = shading(fr, bounce_view_direction, sample_normal, ray.direction, surface, in_radiance);
-      out_radiance = out_radiance / candidate.p;
-      if (n > 0u) out_radiance = (rand_sample.w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample.w;
-      float out_luminance = luminance(out_radiance);
-      if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
-      p.radiance = p.radiance + F4(p.transport * out_radiance, 1.0f);
+      p.radiance = p.radiance + F4(hit.instance_index != HK_U32_MAX ? add[1] : add[0], 1.0f);
     }
-    p.transport = p.transport * env_brdf(bounce_view_direction, sample_normal, surface);
+    p.transport = next_transport;
     p.random = fract(p.random + fr.number_golden);
     p.position = sample_position;
     p.normal = sample_normal;
@@ -517,6 +526,27 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
         s.sample_position = p.first_position;
         s.sample_normal = p.first_normal;
         pdf = p.pdf;
+        // The pixel's G-buffer record and noise sample are read AGAIN for the temporal tail instead of being carried through
+        // the bounce loop (~20 registers a lane does not have: the kernel sits at the 128-VGPR ceiling with spills): the same
+        // loads and operations as in the prologue give the same values.  The opaque copy of the index keeps the compiler from
+        // merging the two reads.
+        {
+          int didx2 = didx, x2 = x, y2 = y;
+          asm volatile("" : "+v"(didx2), "+v"(x2), "+v"(y2));
+          const float4 pd2 = g.position[didx2];
+          const float2 imf2 = g.instance_material[didx2];
+          Sample s2 = zero_sample();
+          s2.random = noise_fetch(sc, x2, y2, fr.number);
+          s2.random = fract(s2.random + fr.number_golden);
+          s2.visible_position = F4(pd2);
+          s2.visible_normal = normalize(xyz(unpack4x8snorm(g.normal[didx2])));
+          s2.visible_instance = f32_to_u32(imf2.x);
+          s2.radiance = s.radiance;
+          s2.sample_position = s.sample_position;
+          s2.sample_normal = s.sample_normal;
+          HK_SEC(tm, 8);
+          indirect_temporal_tail(sc, fr, t, x2 + fr.rw * y2, coords_to_uv(fr, x2, y2), xyz(F4(pd2)), g.velocity_uv[didx2], f32_to_u32(imf2.y), s2, pdf);
+        }
       } else {  // light.wgsl:1395-1450
         f4 rand_sample = sample_cosine_hemisphere(F2(s.random.x, s.random.y));
         ray.origin = xyz(s.visible_position) + s.visible_normal * HK_RAY_BIAS;
@@ -551,8 +581,8 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
         }
       }
 
-      // ReSTIR: temporal, light.wgsl:1452-1497
-      {
+      // ReSTIR: temporal, light.wgsl:1452-1497 (the MULTIPLE_BOUNCES pipeline ran it above, on the re-read pixel record)
+      if (!MULTIPLE_BOUNCES) {
         HK_SEC(tm, 8);
         indirect_temporal_tail(sc, fr, t, index, uv, position, velocity_uv, im_y, s, pdf);
       }
