@@ -179,6 +179,22 @@ def test_device_rebuild_of_all_orderings_stays_within_tolerance():
     assert (sa["position"] == sb["position"]).mean() > 0.999
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_refit_and_rebuild_random_sequences_vs_oracle(seed):
+    """Seeded scenes (one-slot and two-slot), movers (always including emitters when there are any), settings and rebuild frames."""
+    rng = np.random.default_rng(4200 + seed)
+    big = bool(rng.random() < 0.5)
+    kw = dict(n_boxes=int(rng.integers(2, 24)), n_spheres=int(rng.integers(0, 5)), n_emitters=int(rng.integers(0, 4)), sphere_rings=12 if big else 4,
+              sphere_segs=16 if big else 5, seed=int(rng.integers(1, 1 << 30)))
+    n = 1 + kw["n_boxes"] + kw["n_spheres"] + kw["n_emitters"]
+    movers = sorted(set(int(i) for i in rng.choice(n, size=min(n, int(rng.integers(1, 7))), replace=False)) | ({n - 1} if kw["n_emitters"] else set()))
+    s = hk.HikariSettings(indirect_bounces=int(rng.integers(0, 4)), emissive_spatial_reuse=bool(rng.random() < 0.5), denoise=bool(rng.random() < 0.7),
+                          upscale=hk.Upscale.SmaaTu4x(float(rng.choice([1.0, 1.5, 2.0]))))
+    rebuild_on = tuple(int(f) for f in range(2, 6) if rng.random() < 0.4)
+    run_refit_sequence(kw, (int(rng.integers(48, 130)), int(rng.integers(40, 90))), lambda f: movers if f % 3 else movers[:max(1, len(movers) // 2)], settings=s,
+                       rebuild_on=rebuild_on)
+
+
 def test_refit_with_direction_threaded_orderings_stays_within_tolerance():
     """Product defaults (eight orderings of the instance tree, all refit): against the reference-order refit of the same sequence."""
     kw, size = LARGE, (160, 96)
