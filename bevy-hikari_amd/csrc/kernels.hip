@@ -294,8 +294,13 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
   if (t.m_current && __ballot(px.valid) != 0ull) {  // uniform-tile store elision (hk_kernels.hpp TileMeta); a wave entirely beyond the image edge owns no tile
     const int tile = wave_tile(px, t.tiles_x);
     const bool all_background = __ballot(px.valid && !background) == 0ull;
-    if (all_background) {  // `out` is the same record in every lane
-      const unsigned long long id = record_id(out);
+    if (all_background) {
+      // every VALID lane holds the same record: the reservoir of a background pixel (light.wgsl:1058-1069).  Lanes beyond the image
+      // edge hold something else (their initial `out`), so the id comes from the record itself, not from each lane's copy: the
+      // skip decisions below must be wave-uniform - store_packed_tile is a whole-wave operation.
+      Reservoir bg = zero_reservoir();
+      set_reservoir(bg, zero_sample(), 0.0f);
+      const unsigned long long id = record_id(pack_reservoir(bg));
       skip_current = tile_holds(t.m_current, tile, id);
       skip_spatial = tile_holds(t.m_spatial, tile, id);
       skip_previous_spatial = tile_holds(t.m_previous_spatial, tile, id);
@@ -304,10 +309,11 @@ __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuff
       if (!skip_previous_spatial) tile_mark(t.m_previous_spatial, tile, id, 0ull, t.serial);
     } else {
       tile_unknown(t.m_current, tile);
-      if (__ballot(background) != 0ull) {  // a mixed tile: its background slots are rewritten below, the others keep older records
-        tile_unknown(t.m_spatial, tile);
-        tile_unknown(t.m_previous_spatial, tile);
-      }
+      // its geometry pixels may store a rejected history reservoir into their OWN slot of previous_spatial (store_previous_spatial with
+      // to == from poisons nothing): the tile holds no single record there any more, background pixels or not.  (A tile can
+      // alternate between all-background and all-geometry with the frame parity of the deferred-texel jitter: random case 5001.)
+      tile_unknown(t.m_previous_spatial, tile);
+      if (__ballot(background) != 0ull) tile_unknown(t.m_spatial, tile);  // a mixed tile: its background slots are rewritten below, the others keep older records
     }
   }
   if (!skip_current) store_packed_tile(lds, t.current, fr.rw, px, out, write_current);
@@ -589,10 +595,8 @@ __global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuf
     }
     if (t.m_current && !all_background) {  // a tile with real pixels: no longer one record everywhere
       tile_unknown(t.m_current, tile);
-      if (__ballot(background) != 0ull) {
-        tile_unknown(t.m_spatial, tile);
-        tile_unknown(t.m_previous_spatial, tile);
-      }
+      tile_unknown(t.m_previous_spatial, tile);  // (geometry pixels may store into their own slot of it: k_direct_lit has the long version)
+      if (__ballot(background) != 0ull) tile_unknown(t.m_spatial, tile);
     }
   }
   tm.flush();

@@ -137,10 +137,8 @@ __global__ __launch_bounds__(256) void k_wf_setup(DScene sc, DFrame fr, GBuffer 
     }
     if (t.m_current && !all_background) {  // a tile with real pixels: no longer one record everywhere
       tile_unknown(t.m_current, tile);
-      if (__ballot(background) != 0ull) {
-        tile_unknown(t.m_spatial, tile);
-        tile_unknown(t.m_previous_spatial, tile);
-      }
+      tile_unknown(t.m_previous_spatial, tile);  // (geometry pixels may store into their own slot of it: k_direct_lit has the long version)
+      if (__ballot(background) != 0ull) tile_unknown(t.m_spatial, tile);
     }
   }
   __shared__ uint32_t push_lds[6];

@@ -763,7 +763,9 @@ def test_second_stream_overlap_changes_no_bit_and_joins_on_reads():
     assert outs[0][1].view(np.float16).astype(np.float32)[..., :3].max() > 0
 
 
-@pytest.mark.parametrize("seed", range(40))
+# 5001: a 25-pixel-wide render image whose right-most 8x8 tiles have one valid column, all background - the store elision once took
+# the tile's record id from lanes beyond the image edge (found by the round-2 sweep of 13 200 seeds)
+@pytest.mark.parametrize("seed", list(range(40)) + [5001])
 def test_random_settings_vs_oracle(seed):
     """Seeded sweep over the HikariSettings space (cases.random_case): bounce counts, reuse switches, validation
     intervals, reuse caps, lifetimes, denoise, upscale kind / ratio, TAA, odd image sizes, with and without the
