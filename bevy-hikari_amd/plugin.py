@@ -374,7 +374,9 @@ def load_cornell(nonlinear_colors=False):
     meshes = [b.add_mesh(m["positions"], m["normals"], m["uvs"], m["indices"]) for m in j["meshes"]]
     for inst in j["instances"]:
         b.add_instance(meshes[inst["mesh"]], mats[j["meshes"][inst["mesh"]]["material"]], inst["transform"])
-    return b.finish()
+    scene = b.finish()
+    scene.builder = b  # kept for moving instances: builder.set_instance_transform(i, ..) + Engine.refit_instances(builder) / builder.finish()
+    return scene
 
 
 def cornell_camera(width, height):  # examples/cornell.rs:49-50

@@ -101,3 +101,34 @@ def test_cpp_host_multi_gpu_bands_equal_the_single_context_frame(tmp_path, bands
     for n in range(1, 6):
         p.render(hk.cornell_camera(96, 64), s, frame_number=n, antialias=antialias)
     assert (got == p.engine.read(F.BUF_TAA_OUTPUT if antialias else F.BUF_TONE_MAPPED)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rebuild_at", [0, 3])
+def test_cpp_host_animates_through_the_device_refit(tmp_path, rebuild_at):
+    """--animate: the compiled host moves two boxes per frame through SceneBuilder::set_instance_transform + HikariPlugin::refit_instances
+    (hk_refit_scene_instances; --rebuild-at: hk_rebuild_scene_trees at that frame) - frame for frame what the Python host renders with
+    the same calls."""
+    raw = tmp_path / "anim.bin"
+    args = ["--size", "96", "64", "--frames", "5", "--bounces", "2", "--ratio", "1.0", "--animate", "--deterministic", "--raw", str(raw)] + (["--rebuild-at", str(rebuild_at)] if rebuild_at else [])
+    r = run(*args)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(raw, dtype=np.uint16).reshape(64, 96, 4)
+    scene = hk.load_cornell()
+    rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in scene.instances], dtype=np.float32)
+    p = hk.HikariPlugin(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)  # moving objects: the scatter-store race is resolved the same way on both sides
+    p.set_scene(scene)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    for n in range(1, 6):
+        if n > 1:
+            for i, sign in ((6, 1.0), (7, -1.0)):
+                m = rest[i].copy()
+                m[12] = rest[i][12] + np.float32(0.01) * np.float32(n - 1) * np.float32(sign)
+                scene.builder.set_instance_transform(i, m)
+            assert p.engine.refit_instances(scene.builder) == 2
+            if n == rebuild_at:
+                p.engine.rebuild_trees()
+        p.render(hk.cornell_camera(96, 64), s, frame_number=n)
+    want = p.engine.read(F.BUF_TONE_MAPPED)
+    assert (got == want).all()
+    assert p.engine.stats().scene_device_refits == 4
