@@ -39,6 +39,7 @@ STAGE_TEMPORAL, STAGE_SPATIAL, STAGE_POST_PROCESS, STAGE_ANTIALIAS, STAGE_UPSCAL
 #: bit equality with the oracle, which walks in the reference's order.
 DEFAULT_CTX_FLAGS = int(os.environ.get("HIKARI_HIP_DEFAULT_CTX_FLAGS", "0"))
 CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER, CTX_EXACT_TRAVERSAL = 1, 2, 4, 8, 16, 32
+TREE_SAH, TREE_LBVH = 0, 1  # hk_rebuild_scene_trees
 CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient with >= 2 bounces (hikari_hip.h)
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS = 1, 2
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
@@ -206,7 +207,7 @@ _PRODUCT_ONLY = {
     "upload_scene": [_vp, _vp],
     "upload_scene_instances": [_vp, _vp],
     "refit_scene_instances": [_vp, _vp, P(u32)],
-    "rebuild_scene_trees": [_vp],
+    "rebuild_scene_trees": [_vp, u32],
     "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
@@ -228,7 +229,7 @@ _PRODUCT_ONLY = {
     "multi_upload_scene": [_vp, _vp],
     "multi_upload_scene_instances": [_vp, _vp],
     "multi_refit_scene_instances": [_vp, _vp, P(u32)],
-    "multi_rebuild_scene_trees": [_vp],
+    "multi_rebuild_scene_trees": [_vp, u32],
     "multi_upload_textures": [_vp, P(HkImageDesc), u32],
     "multi_upload_noise": [_vp, _vp, C.c_size_t],
     "multi_resize": [_vp, u32, u32, f32],

@@ -377,7 +377,7 @@ int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out) {
 
 int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene(c, b)); }
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene_instances(c, b)); }
-int hk_multi_rebuild_scene_trees(hk_multi* m) { HK_EACH(hk_rebuild_scene_trees(c)); }
+int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode) { HK_EACH(hk_rebuild_scene_trees(c, mode)); }
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n) { HK_EACH(hk_upload_textures(c, images, n)); }
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes) { HK_EACH(hk_upload_noise(c, rgba, bytes)); }
 int hk_multi_resize(hk_multi* m, uint32_t w, uint32_t h, float ratio) {

@@ -1417,8 +1417,9 @@ int begin_device_update(hk_ctx* c) {
 }
 }  // namespace
 
-int hk_rebuild_scene_trees(hk_ctx* c) {
+int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_REQUIRE(mode == HK_TREE_SAH || mode == HK_TREE_LBVH, HK_E_INVALID, "unknown tree build mode %u", mode);
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
   HK_HIP(hipSetDevice(c->device));
   int rc;
@@ -1439,11 +1440,12 @@ int hk_rebuild_scene_trees(hk_ctx* c) {
   const hkd::RefitScene r = refit_scene(c);
   uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
   float4* tlas = (float4*)(base + c->dyn_off.tlas);
-  HK_REQUIRE(launch_lbvh_build(c->stream, false, r, ni, c->rf_inst_lo, c->rf_inst_hi, c->lbvh_scratch, tlas, tlas + 1, 2u, c->threaded ? 8u : 1u) == 0, HK_E_HIP,
-             "LBVH build of the instance tree failed: %s", hipGetErrorString(hipGetLastError()));
+  const int build = mode == HK_TREE_SAH ? 1 : 0;
+  HK_REQUIRE(launch_tree_build(c->stream, build, false, r, ni, c->rf_inst_lo, c->rf_inst_hi, c->lbvh_scratch, tlas, tlas + 1, 2u, c->threaded ? 8u : 1u) == 0, HK_E_HIP,
+             "device build of the instance tree failed: %s", hipGetErrorString(hipGetLastError()));
   if (ne)
-    HK_REQUIRE(launch_lbvh_build(c->stream, true, r, ne, nullptr, nullptr, c->lbvh_scratch, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi),
-                                 1u, 1u) == 0, HK_E_HIP, "LBVH build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
+    HK_REQUIRE(launch_tree_build(c->stream, build, true, r, ne, nullptr, nullptr, c->lbvh_scratch, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi),
+                                 1u, 1u) == 0, HK_E_HIP, "device build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
   c->mirrors_stale = true;
   c->device_tree_builds += 1;
   return HK_OK;

@@ -236,8 +236,8 @@ void launch_refit(hipStream_t st, const hkd::RefitScene& s, const hkd::RefitUpda
 // LBVH rebuild of a flat skip-link BVH over n shapes (kernels_scene.hip): scratch size, and the build into `lo` / `hi` (`stride`
 // float4 between consecutive nodes: 2 for the interleaved TLAS, 1 for the two planes of the light BVH)
 size_t lbvh_scratch_bytes(uint32_t n, size_t* sort_temp_bytes);
-int launch_lbvh_build(hipStream_t st, bool light, const hkd::RefitScene& s, uint32_t n, const float4* box_lo, const float4* box_hi, void* scratch, float4* lo,
-                      float4* hi, uint32_t stride, uint32_t orderings);
+int launch_tree_build(hipStream_t st, int mode /* 0 LBVH, 1 the reference's binned SAH */, bool light, const hkd::RefitScene& s, uint32_t n, const float4* box_lo,
+                      const float4* box_hi, void* scratch, float4* lo, float4* hi, uint32_t stride, uint32_t orderings);
 void launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                     int y0, int y1);
 void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);

@@ -264,6 +264,7 @@ struct LbvhBuffers {
   float4 *node_lo, *node_hi;    // per tree node (2n - 1)
   uint32_t* arrived;            // per internal node: bottom-up visit counter
   uint8_t* swap;                // per internal node: bit o set = the RIGHT child comes first in ordering o
+  uint32_t keep_order0;         // 1: ordering 0 keeps left-before-right (the reference's own flattening of an SAH-built tree)
 };
 namespace {
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {  // 10 bits -> every third bit
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(256) void k_lbvh_boxes(RefitScene s, LbvhBuffers b)
       const bool negative = (o >> axis) & 1u;
       if (!(a_lower != negative)) sw |= 1u << o;
     }
+    if (b.keep_order0) sw &= ~1u;
     b.swap[p] = (uint8_t)sw;
     p = b.parent[p];
     if (p == HK_U32_MAX) return;
@@ -450,6 +452,395 @@ __global__ __launch_bounds__(256) void k_lbvh_emit(LbvhBuffers b, float4* lo, fl
   }
 }
 
+
+// ------------------------------------------------------------------ the reference's own tree, built on the device
+// `bvh` 0.7.1 BVHNode::build (scene_builder.cpp build_recursive; the crate the reference calls at instance.rs:365-371,422-428) is a
+// top-down binned SAH: per node the bounds of the shapes and of their centres, the longest axis of the centre bounds, six buckets
+// along it, the cheapest of the five splits, the shapes re-ordered bucket by bucket.  Every reduction in it is a min, a max or a
+// count, and the re-ordering is a STABLE sort by bucket: nothing depends on the order in which a parallel machine visits the
+// shapes.  So the same tree can be built level by level: one workgroup, all nodes of a level at once, the shapes in one array
+// that is stably re-sorted per level (block scans of the six bucket flags, segmented at node boundaries, with running counters
+// per node and bucket across the 1024-item chunks).  The costs are the host's float expressions term for term, so the splits -
+// and with them the shape of the tree - are the host's: tests compare the entry / exit links with the host builder's arrays.
+// (Zeros may come out with the other sign than std::min / std::max chains give - a box bound of -0 vs +0 changes no decision.)
+struct SahBuffers {
+  uint32_t* order[2];      // shape ids, segment by segment
+  uint32_t* item_node[2];  // per position: the internal node whose segment it is in, or SAH_DONE once it is a leaf
+  uint8_t* item_bucket;
+  uint32_t* active[2];     // internal nodes split at this level / created for the next
+  uint32_t* acc;           // per internal node: 54 words - bounds (6), centre bounds (6), 6 bucket boxes (36), 6 bucket counts
+  float* split;            // per internal node: 4 words - centre-bounds min on the axis, axis size, (bits) axis, (bits) half-split flag
+  uint32_t* offsets;       // per internal node: 14 words - first target position of each bucket (6), running counts (6), left count, split bucket
+  uint32_t* node_level;    // per internal node: the level of the loop that splits it
+  uint32_t* roots;         // nodes handed to k_sah_subtrees
+  uint32_t* counters;      // [0] internal nodes allocated, [1] subtree roots, [2] the ping-pong side the top of the tree ended on
+};
+namespace {
+constexpr uint32_t SAH_DONE = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t fkey(float f) {  // monotone map f32 -> u32 (for atomicMin / atomicMax)
+  const uint32_t u = f2u(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float funkey(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+__device__ __forceinline__ float box_center(float mn, float mx) { return mn + (mx - mn) / 2.0f; }  // Box::center
+__device__ __forceinline__ float box_area(const float* mn, const float* mx) {                      // Box::surface_area
+  const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+  return 2.0f * (x * y + x * z + y * z);
+}
+// min / max of a box into the accumulator words acc[0..5] (keys): when every lane of the wave that takes part adds to the SAME
+// accumulator (the top levels of the tree: thousands of shapes per node) the wave reduces first - one hot address takes ~10 ns per
+// atomic - otherwise every lane adds on its own.  Called by all lanes of the wave; `take` = this lane has a box for `acc`.
+__device__ __forceinline__ void wave_box_accumulate(uint32_t* acc, bool take, const float* mn, const float* mx, uint32_t* count) {
+  const unsigned long long m = __ballot(take);
+  if (m == 0ull) return;
+  const unsigned long long a = (unsigned long long)(size_t)acc;
+  const int leader = __ffsll((long long)m) - 1;
+  const unsigned long long a0 = __shfl(a, leader);
+  const bool uniform = __ballot(take && a != a0) == 0ull;
+  if (uniform) {
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = take ? mn[k] : INFINITY;
+      hi[k] = take ? mx[k] : -INFINITY;
+      for (int off = 32; off > 0; off >>= 1) {
+        lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+        hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+      }
+    }
+    if ((int)(threadIdx.x & 63u) == leader) {
+      for (int k = 0; k < 3; ++k) {
+        atomicMin(&acc[k], fkey(lo[k]));
+        atomicMax(&acc[3 + k], fkey(hi[k]));
+      }
+      if (count) atomicAdd(count, (uint32_t)__popcll(m));
+    }
+  } else if (take) {
+    for (int k = 0; k < 3; ++k) {
+      atomicMin(&acc[k], fkey(mn[k]));
+      atomicMax(&acc[3 + k], fkey(mx[k]));
+    }
+    if (count) atomicAdd(count, 1u);
+  }
+}
+// exclusive prefix sum of `v` over the 1024 threads of the block (wave scan + one LDS hop); lds: 17 words
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if ((int)lane >= off) inc += t;
+  }
+  __syncthreads();
+  if (lane == 63u) lds[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t run = 0u;
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t t = lds[w];
+      lds[w] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  return lds[wave] + inc - v;
+}
+__device__ __forceinline__ uint32_t block_inclusive_max_scan(uint32_t v, uint32_t* lds) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off);
+    if ((int)lane >= off) inc = max(inc, t);
+  }
+  __syncthreads();
+  if (lane == 63u) lds[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0u) {
+    uint32_t run = 0u;
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t t = lds[w];
+      lds[w] = run;
+      run = max(run, t);
+    }
+  }
+  __syncthreads();
+  return max(lds[wave], inc);
+}
+}  // namespace
+
+// The level loop over one range [r0, r1) of item positions, run by ONE workgroup of 1024 threads: every node of a level at once.
+// `first_level`: node_level value of the range's root (the nodes created below get first_level + 1, ...).  Nodes with at most
+// `defer` shapes are not split here but appended to q.roots (their subtrees are built by k_sah_subtrees, one workgroup each, all
+// at once).  Returns the ping-pong side that holds the range's final order.
+template <bool LIGHT>
+__device__ uint32_t sah_levels(const RefitScene& s, const LbvhBuffers& b, const SahBuffers& q, uint32_t r0, uint32_t r1, uint32_t root, uint32_t cur, uint32_t first_level,
+                               uint32_t defer) {
+  __shared__ uint32_t scan_lds[17];
+  __shared__ uint16_t pre[6][1024];  // per chunk: exclusive prefix of each bucket's flags
+  __shared__ uint32_t head_of[1024];
+  __shared__ uint32_t n_active_lds[2];
+  const uint32_t n = b.n, tid = threadIdx.x;
+  if (tid == 0u) {
+    q.active[cur][r0] = root;
+    q.node_level[root] = first_level;
+    n_active_lds[cur] = 1u;
+    n_active_lds[cur ^ 1u] = 0u;
+  }
+  __syncthreads();
+  for (uint32_t level = first_level;; ++level) {  // (a level with nothing to split ends the loop)
+    const uint32_t n_active = n_active_lds[cur];
+    if (n_active == 0u) break;
+    const uint32_t* order = q.order[cur];
+    const uint32_t* item_node = q.item_node[cur];
+    uint32_t* order_out = q.order[cur ^ 1u];
+    uint32_t* item_node_out = q.item_node[cur ^ 1u];
+    const uint32_t* active = q.active[cur] + r0;
+    uint32_t* active_out = q.active[cur ^ 1u] + r0;
+    auto splitting = [&](uint32_t node) { return node != SAH_DONE && q.node_level[node] == level; };
+    // A: accumulators
+    for (uint32_t a = tid; a < n_active * 54u; a += 1024u) {
+      const uint32_t node = active[a / 54u], w = a % 54u;
+      uint32_t init = 0u;                                             // counts
+      if (w < 48u) init = (w % 6u) < 3u ? fkey(INFINITY) : fkey(-INFINITY);  // a box: min xyz, max xyz
+      q.acc[(size_t)node * 54u + w] = init;
+    }
+    __syncthreads();
+    if (tid == 0u) n_active_lds[cur ^ 1u] = 0u;
+    // B: bounds of the shapes and of their centres
+    for (uint32_t p0 = r0; p0 < r1; p0 += 1024u) {  // (block-uniform trip count: the wave reductions want whole waves)
+      const uint32_t p = p0 + tid;
+      const uint32_t node = p < r1 ? item_node[p] : SAH_DONE;
+      const bool take = splitting(node);
+      float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0}, cc[3] = {0, 0, 0};
+      if (take) {
+        f3 lo, hi;
+        lbvh_shape_box<LIGHT>(s, b, order[p], lo, hi);
+        mn[0] = lo.x; mn[1] = lo.y; mn[2] = lo.z;
+        mx[0] = hi.x; mx[1] = hi.y; mx[2] = hi.z;
+        for (int k = 0; k < 3; ++k) cc[k] = box_center(mn[k], mx[k]);
+      }
+      uint32_t* acc = q.acc + (size_t)(take ? node : 0u) * 54u;
+      wave_box_accumulate(acc, take, mn, mx, nullptr);
+      wave_box_accumulate(acc + 6, take, cc, cc, nullptr);
+    }
+    __syncthreads();
+    // C: split axis
+    for (uint32_t a = tid; a < n_active; a += 1024u) {
+      const uint32_t node = active[a];
+      const uint32_t* acc = q.acc + (size_t)node * 54u;
+      float cmn[3], cmx[3];
+      for (int k = 0; k < 3; ++k) {
+        cmn[k] = funkey(acc[6 + k]);
+        cmx[k] = funkey(acc[9 + k]);
+      }
+      const float x = cmx[0] - cmn[0], y = cmx[1] - cmn[1], z = cmx[2] - cmn[2];
+      const int axis = (x > y && x > z) ? 0 : (y > z ? 1 : 2);  // Box::largest_axis
+      const float axis_size = cmx[axis] - cmn[axis];
+      float* sp = q.split + (size_t)node * 4u;
+      sp[0] = cmn[axis];
+      sp[1] = axis_size;
+      sp[2] = u2f((uint32_t)axis);
+      sp[3] = u2f(axis_size < 0.00001f ? 1u : 0u);  // shapes too close together: the index list is cut in half
+    }
+    __syncthreads();
+    // D: buckets
+    for (uint32_t p0 = r0; p0 < r1; p0 += 1024u) {
+      const uint32_t p = p0 + tid;
+      const uint32_t node = p < r1 ? item_node[p] : SAH_DONE;
+      bool take = splitting(node);
+      float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+      int bk = 0;
+      if (take) {
+        const float* sp = q.split + (size_t)node * 4u;
+        take = f2u(sp[3]) == 0u;
+        if (take) {
+          f3 lo, hi;
+          lbvh_shape_box<LIGHT>(s, b, order[p], lo, hi);
+          mn[0] = lo.x; mn[1] = lo.y; mn[2] = lo.z;
+          mx[0] = hi.x; mx[1] = hi.y; mx[2] = hi.z;
+          const int axis = (int)f2u(sp[2]);
+          const float rel = (box_center(mn[axis], mx[axis]) - sp[0]) / sp[1];
+          bk = (int)(rel * (6.0f - 0.01f));
+          bk = min(max(bk, 0), 5);
+          q.item_bucket[p] = (uint8_t)bk;
+        }
+      }
+      for (int k6 = 0; k6 < 6; ++k6) {  // bucket by bucket: lanes of one node and one bucket share an accumulator
+        const bool mine = take && bk == k6;
+        uint32_t* acc = q.acc + (size_t)(mine ? node : 0u) * 54u;
+        wave_box_accumulate(acc + 12 + 6 * k6, mine, mn, mx, acc + 48 + k6);
+      }
+    }
+    __syncthreads();
+    // E: the cheapest split, the children
+    for (uint32_t a = tid; a < n_active; a += 1024u) {
+      const uint32_t node = active[a];
+      const uint32_t* acc = q.acc + (size_t)node * 54u;
+      const float* sp = q.split + (size_t)node * 4u;
+      uint32_t* off = q.offsets + (size_t)node * 14u;
+      const uint32_t begin = b.first[node], count = b.last[node] - begin + 1u;
+      uint32_t n_left = count / 2u, split_bucket = 6u;  // 6: cut the list in half
+      if (f2u(sp[3]) == 0u) {
+        float bounds_mn[3], bounds_mx[3];
+        for (int k = 0; k < 3; ++k) {
+          bounds_mn[k] = funkey(acc[k]);
+          bounds_mx[k] = funkey(acc[3 + k]);
+        }
+        const float total_area = box_area(bounds_mn, bounds_mx);
+        float min_cost = INFINITY;
+        uint32_t min_bucket = 0u;
+        for (uint32_t i = 0; i < 5u; ++i) {
+          float lmn[3] = {INFINITY, INFINITY, INFINITY}, lmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+          float rmn[3] = {INFINITY, INFINITY, INFINITY}, rmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+          uint32_t ln = 0u, rn = 0u;
+          for (uint32_t k6 = 0; k6 < 6u; ++k6) {
+            const uint32_t* bb = acc + 12u + 6u * k6;
+            float* tmn = k6 <= i ? lmn : rmn;
+            float* tmx = k6 <= i ? lmx : rmx;
+            for (int k = 0; k < 3; ++k) {
+              tmn[k] = hmin(tmn[k], funkey(bb[k]));
+              tmx[k] = hmax(tmx[k], funkey(bb[3 + k]));
+            }
+            if (k6 <= i) ln += acc[48u + k6]; else rn += acc[48u + k6];
+          }
+          const float cost = ((float)ln * box_area(lmn, lmx) + (float)rn * box_area(rmn, rmx)) / total_area;
+          if (cost < min_cost) {
+            min_bucket = i;
+            min_cost = cost;
+          }
+        }
+        uint32_t best_left = 0u;  // (all costs NaN: the host keeps bucket 0 as the split)
+        for (uint32_t k6 = 0; k6 <= min_bucket; ++k6) best_left += acc[48u + k6];
+        if (best_left != 0u && best_left != count) {
+          n_left = best_left;
+          split_bucket = min_bucket;
+        }  // (an empty side - NaN costs - falls back to the half cut, like the host)
+      }
+      uint32_t run = begin;
+      for (uint32_t k6 = 0; k6 < 6u; ++k6) {
+        off[k6] = run;
+        run += acc[48u + k6];
+        off[6u + k6] = 0u;
+      }
+      off[12] = n_left;
+      off[13] = split_bucket;
+      // children: a side with one shape is a leaf at its position, a larger one an internal node - split at the next level, or
+      // handed to a workgroup of its own when it is small enough
+      const uint32_t n_right = count - n_left;
+      uint32_t child[2];
+      for (int side = 0; side < 2; ++side) {
+        const uint32_t c_begin = side == 0 ? begin : begin + n_left, c_count = side == 0 ? n_left : n_right;
+        if (c_count == 1u) {
+          child[side] = (n - 1u) + c_begin;
+          b.leaf_parent[c_begin] = node;
+        } else {
+          const uint32_t id = atomicAdd(&q.counters[0], 1u);
+          child[side] = id;
+          b.first[id] = c_begin;
+          b.last[id] = c_begin + c_count - 1u;
+          b.parent[id] = node;
+          if (c_count <= defer) {
+            q.node_level[id] = SAH_DONE;  // (not a level of this loop)
+            q.roots[atomicAdd(&q.counters[1], 1u)] = id;
+          } else {
+            q.node_level[id] = level + 1u;
+            active_out[atomicAdd(&n_active_lds[cur ^ 1u], 1u)] = id;
+          }
+        }
+      }
+      b.left[node] = child[0];
+      b.right[node] = child[1];
+    }
+    __syncthreads();
+    // F: stable re-order, bucket by bucket inside every segment; chunk after chunk so that the running counts stay in order
+    for (uint32_t c0 = r0; c0 < r1; c0 += 1024u) {
+      const uint32_t p = c0 + tid;
+      const bool in = p < r1;
+      const uint32_t node = in ? item_node[p] : SAH_DONE;
+      const bool split_now = in && splitting(node);
+      const bool moving = split_now && q.offsets[(size_t)node * 14u + 13u] != 6u;
+      const uint32_t bk = moving ? q.item_bucket[p] : 7u;
+      for (uint32_t k6 = 0; k6 < 6u; ++k6) {
+        const uint32_t e = block_exclusive_scan(bk == k6 ? 1u : 0u, scan_lds);
+        pre[k6][tid] = (uint16_t)e;
+      }
+      const bool head = tid == 0u || !in || item_node[p - 1u] != node;
+      const uint32_t h = block_inclusive_max_scan(head ? tid : 0u, scan_lds);
+      head_of[tid] = h;
+      __syncthreads();
+      if (split_now) {
+        const uint32_t* off = q.offsets + (size_t)node * 14u;
+        const uint32_t begin = b.first[node], n_left = off[12];
+        uint32_t target = p;
+        if (moving) target = off[bk] + off[6u + bk] + ((uint32_t)pre[bk][tid] - (uint32_t)pre[bk][h]);
+        const bool goes_left = target < begin + n_left;
+        const uint32_t child = goes_left ? b.left[node] : b.right[node];
+        order_out[target] = order[p];
+        item_node_out[target] = child >= n - 1u ? SAH_DONE : child;
+      } else if (in) {  // a leaf already, or a node that waits for a workgroup of its own
+        order_out[p] = order[p];
+        item_node_out[p] = node;
+      }
+      __syncthreads();
+      // the last item of a node's run in this chunk adds the chunk's counts to the node's running counts
+      if (moving) {
+        const bool last_of_run = tid == 1023u || p + 1u >= r1 || item_node[p + 1u] != node;
+        if (last_of_run) {
+          uint32_t* off = q.offsets + (size_t)node * 14u;
+          for (uint32_t k6 = 0; k6 < 6u; ++k6) off[6u + k6] += ((uint32_t)pre[k6][tid] + (bk == k6 ? 1u : 0u)) - (uint32_t)pre[k6][h];
+        }
+      }
+      __syncthreads();
+    }
+    cur ^= 1u;
+  }
+  __syncthreads();
+  return cur;
+}
+
+// SAH_SUBTREE: nodes with at most this many shapes are built by a workgroup of their own (k_sah_subtrees), all of them at once
+constexpr uint32_t SAH_SUBTREE = 1024u;
+// the top of the tree: one workgroup over the whole array, down to nodes of at most SAH_SUBTREE shapes.  Outputs the LbvhBuffers
+// topology (ids_sorted = leaf order, parent / left / right / first / last / leaf_parent) for k_lbvh_boxes + k_lbvh_emit
+template <bool LIGHT>
+__global__ __launch_bounds__(1024) void k_sah_build(RefitScene s, LbvhBuffers b, SahBuffers q) {
+  const uint32_t n = b.n, tid = threadIdx.x;
+  if (n == 1u) {
+    if (tid == 0u) {
+      b.ids_sorted[0] = 0u;
+      q.counters[1] = 0u;
+    }
+    return;
+  }
+  for (uint32_t i = tid; i < n; i += 1024u) {
+    q.order[0][i] = i;
+    q.item_node[0][i] = 0u;
+  }
+  if (tid == 0u) {
+    b.first[0] = 0u;
+    b.last[0] = n - 1u;
+    b.parent[0] = HK_U32_MAX;
+    q.counters[0] = 1u;  // internal nodes allocated
+    q.counters[1] = 0u;  // subtree roots
+  }
+  __syncthreads();
+  const uint32_t cur = sah_levels<LIGHT>(s, b, q, 0u, n, 0u, 0u, 0u, n > SAH_SUBTREE ? SAH_SUBTREE : 0u);
+  if (tid == 0u) q.counters[2] = cur;  // the side the subtree workgroups start from
+  // leaves fixed at this stage are final; the ranges of the deferred nodes are copied by their own workgroups
+  for (uint32_t i = tid; i < n; i += 1024u)
+    if (q.item_node[cur][i] == SAH_DONE) b.ids_sorted[i] = q.order[cur][i];
+}
+// the subtrees below: one workgroup per deferred node, all at once
+template <bool LIGHT>
+__global__ __launch_bounds__(1024) void k_sah_subtrees(RefitScene s, LbvhBuffers b, SahBuffers q) {
+  const uint32_t n_roots = q.counters[1], start = q.counters[2];
+  for (uint32_t r = blockIdx.x; r < n_roots; r += gridDim.x) {
+    const uint32_t root = q.roots[r], r0 = b.first[root], r1 = b.last[root] + 1u;
+    const uint32_t cur = sah_levels<LIGHT>(s, b, q, r0, r1, root, start, 0x40000000u, 0u);
+    for (uint32_t i = r0 + threadIdx.x; i < r1; i += 1024u) b.ids_sorted[i] = q.order[cur][i];
+    __syncthreads();
+  }
+}
+
 }  // namespace hkd
 
 namespace hk {
@@ -476,7 +867,7 @@ void launch_refit(hipStream_t st, const RefitScene& s, const RefitUpdate* update
 }
 
 
-// scratch of one LBVH build over n shapes: bytes, and the carving of a single allocation
+// scratch of one tree build over n shapes: bytes, and the carving of a single allocation
 size_t lbvh_scratch_bytes(uint32_t n, size_t* sort_temp_bytes) {
   size_t temp = 0;
   (void)rocprim::radix_sort_pairs(nullptr, temp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 30);
@@ -484,11 +875,12 @@ size_t lbvh_scratch_bytes(uint32_t n, size_t* sort_temp_bytes) {
   if (sort_temp_bytes) *sort_temp_bytes = temp;
   const size_t nn = ((size_t)n + 63) & ~(size_t)63;
   return 256 + temp + nn * (4 * 4 /* codes, ids x2 */ + 5 * 4 /* parent, left, right, first, last */ + 4 /* leaf_parent */ + 4 /* arrived */ + 4 /* swap (padded) */) +
-         2 * nn * 2 * 16 /* node boxes, 2n - 1 */;
+         2 * nn * 2 * 16 /* node boxes, 2n - 1 */ + nn * (4 /* item_node[1] */ + 4 /* item_bucket, padded */ + 2 * 4 /* active lists */ + 54 * 4 + 4 * 4 + 14 * 4 + 2 * 4) /* SAH build */;
 }
-// `tree` = the node array to overwrite: LIGHT ? two planes (lo, hi) : interleaved pairs
-int launch_lbvh_build(hipStream_t st, bool light, const RefitScene& s, uint32_t n, const float4* box_lo, const float4* box_hi, void* scratch, float4* lo, float4* hi,
-                      uint32_t stride, uint32_t orderings) {
+// mode 0: LBVH (Morton order), mode 1: the reference's binned SAH (`bvh` 0.7.1).  `lo` / `hi` = the node array to overwrite,
+// `stride` float4 between consecutive nodes (2: interleaved pairs, 1: two planes)
+int launch_tree_build(hipStream_t st, int mode, bool light, const RefitScene& s, uint32_t n, const float4* box_lo, const float4* box_hi, void* scratch, float4* lo,
+                      float4* hi, uint32_t stride, uint32_t orderings) {
   if (n == 0) return 0;
   size_t temp = 0;
   (void)lbvh_scratch_bytes(n, &temp);
@@ -498,6 +890,7 @@ int launch_lbvh_build(hipStream_t st, bool light, const RefitScene& s, uint32_t 
   b.n = n;
   b.box_lo = box_lo;
   b.box_hi = box_hi;
+  b.keep_order0 = mode == 1 ? 1u : 0u;
   b.bounds = (float*)p; p += 256;
   void* sort_temp = p; p += temp;
   auto u32 = [&]() { uint32_t* q = (uint32_t*)p; p += nn * 4; return q; };
@@ -509,15 +902,38 @@ int launch_lbvh_build(hipStream_t st, bool light, const RefitScene& s, uint32_t 
   (void)hipMemsetAsync(b.arrived, 0, nn * 4, st);
   (void)hipMemsetAsync(b.swap, 0, nn * 4, st);
   const dim3 per_shape((n + 255u) / 256u);
-  if (light) {
-    hipLaunchKernelGGL((k_lbvh_bounds<true>), dim3(1), dim3(1024), 0, st, s, b);
-    hipLaunchKernelGGL((k_lbvh_codes<true>), per_shape, dim3(256), 0, st, s, b);
+  if (mode == 1) {
+    SahBuffers q;
+    q.order[0] = b.codes; q.order[1] = b.codes_sorted;       // (the Morton arrays are free in this mode)
+    q.item_node[0] = b.ids; q.item_node[1] = (uint32_t*)p; p += nn * 4;
+    q.item_bucket = (uint8_t*)p; p += nn * 4;
+    q.active[0] = (uint32_t*)p; p += nn * 4;
+    q.active[1] = (uint32_t*)p; p += nn * 4;
+    q.acc = (uint32_t*)p; p += nn * 54 * 4;
+    q.split = (float*)p; p += nn * 4 * 4;
+    q.offsets = (uint32_t*)p; p += nn * 14 * 4;
+    q.node_level = (uint32_t*)p; p += nn * 4;
+    q.roots = (uint32_t*)p; p += nn * 4;
+    q.counters = (uint32_t*)b.bounds;                        // (256 B, unused by this mode)
+    const dim3 subtrees((unsigned)std::min<size_t>(std::max<size_t>(n / 2, 1), 4096));
+    if (light) {
+      hipLaunchKernelGGL((k_sah_build<true>), dim3(1), dim3(1024), 0, st, s, b, q);
+      if (n > SAH_SUBTREE) hipLaunchKernelGGL((k_sah_subtrees<true>), subtrees, dim3(1024), 0, st, s, b, q);
+    } else {
+      hipLaunchKernelGGL((k_sah_build<false>), dim3(1), dim3(1024), 0, st, s, b, q);
+      if (n > SAH_SUBTREE) hipLaunchKernelGGL((k_sah_subtrees<false>), subtrees, dim3(1024), 0, st, s, b, q);
+    }
   } else {
-    hipLaunchKernelGGL((k_lbvh_bounds<false>), dim3(1), dim3(1024), 0, st, s, b);
-    hipLaunchKernelGGL((k_lbvh_codes<false>), per_shape, dim3(256), 0, st, s, b);
+    if (light) {
+      hipLaunchKernelGGL((k_lbvh_bounds<true>), dim3(1), dim3(1024), 0, st, s, b);
+      hipLaunchKernelGGL((k_lbvh_codes<true>), per_shape, dim3(256), 0, st, s, b);
+    } else {
+      hipLaunchKernelGGL((k_lbvh_bounds<false>), dim3(1), dim3(1024), 0, st, s, b);
+      hipLaunchKernelGGL((k_lbvh_codes<false>), per_shape, dim3(256), 0, st, s, b);
+    }
+    if (rocprim::radix_sort_pairs(sort_temp, temp, (const uint32_t*)b.codes, b.codes_sorted, (const uint32_t*)b.ids, b.ids_sorted, (size_t)n, 0, 30, st) != hipSuccess) return 1;
+    if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, b);
   }
-  if (rocprim::radix_sort_pairs(sort_temp, temp, (const uint32_t*)b.codes, b.codes_sorted, (const uint32_t*)b.ids, b.ids_sorted, (size_t)n, 0, 30, st) != hipSuccess) return 1;
-  if (n > 1) hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((n + 254u) / 256u), dim3(256), 0, st, b);
   if (light) hipLaunchKernelGGL((k_lbvh_boxes<true>), per_shape, dim3(256), 0, st, s, b);
   else hipLaunchKernelGGL((k_lbvh_boxes<false>), per_shape, dim3(256), 0, st, s, b);
   const uint32_t threads = (2u * n - 1u) * orderings;

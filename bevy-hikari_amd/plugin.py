@@ -441,9 +441,10 @@ class Engine:
         self.api.call("refit_scene_instances", self.ctx, builder.h, C.byref(moved))
         return moved.value
 
-    def rebuild_trees(self):
-        """New instance tree and light tree over the current boxes, built on the device (hk_rebuild_scene_trees, LBVH)."""
-        self.api.call("rebuild_scene_trees", self.ctx)
+    def rebuild_trees(self, mode=F.TREE_SAH):
+        """New instance tree and light tree over the current boxes, built on the device (hk_rebuild_scene_trees): F.TREE_SAH = the
+        reference's own binned-SAH tree, F.TREE_LBVH = the quick Morton-order tree."""
+        self.api.call("rebuild_scene_trees", self.ctx, mode)
 
     def read_trees(self, n_instance_nodes, n_emissive_nodes):
         """(instance_nodes, emissive_nodes) as the device holds them, in the reference layout (test hook)."""

@@ -347,7 +347,7 @@ class HikariPlugin {
     check(hk_refit_scene_instances(ctx_.get(), b.handle(), &moved), "hk_refit_scene_instances");
     return moved;
   }
-  void rebuild_trees() { check(hk_rebuild_scene_trees(ctx_.get()), "hk_rebuild_scene_trees"); }
+  void rebuild_trees(uint32_t mode = HK_TREE_SAH) { check(hk_rebuild_scene_trees(ctx_.get(), mode), "hk_rebuild_scene_trees"); }
 
   // one frame of the camera's render graph; by_nodes = dispatch by dispatch through the three nodes,
   // otherwise one hk_frame_render call.  Returns the frame number used.
@@ -416,7 +416,7 @@ class HikariMultiGpuPlugin {
     check(hk_multi_refit_scene_instances(m_, b.handle(), &moved), "hk_multi_refit_scene_instances");
     return moved;
   }
-  void rebuild_trees() { check(hk_multi_rebuild_scene_trees(m_), "hk_multi_rebuild_scene_trees"); }
+  void rebuild_trees(uint32_t mode = HK_TREE_SAH) { check(hk_multi_rebuild_scene_trees(m_, mode), "hk_multi_rebuild_scene_trees"); }
   // rows of last frame's reservoirs fetched across the band borders before reprojection (0 for a static camera)
   void set_history_rows(uint32_t rows) { check(hk_multi_set_history_rows(m_, rows), "hk_multi_set_history_rows"); }
   size_t render(const Camera& camera, const HikariSettings& settings, std::optional<size_t> frame_number = std::nullopt, const HkLights* lights = nullptr,

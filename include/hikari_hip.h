@@ -463,13 +463,19 @@ typedef struct HkImageDesc {
  * Instances must be the ones uploaded (same count, meshes, materials); *moved (optional) = how many poses changed.  The builder's
  * previous-transform bookkeeping advances as it would in hk_scene_builder_finish. */
 int hk_refit_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t* moved);
-/* ... and the REBUILD on the device: new trees over the instances' and the emitters' current boxes - Morton codes of the box
- * centres, one radix sort, Karras' parallel hierarchy (LBVH), boxes bottom-up - written in place in the flatten_custom layout
- * (all direction-threaded orderings of the instance tree, child order by the rule of hk_bvh_rethread).  For when refits have
- * degraded a tree and the host's SAH rebuild (hk_upload_scene_instances) is not wanted on the frame's critical path: 0.1-0.2 ms on
- * the stream at 2 000-20 000 instances.  The tree is a different one (spatial-median splits instead of the `bvh` crate's binned
- * SAH): frames equal the reference's up to exact ties between candidates, like any other valid tree over the same instances. */
-int hk_rebuild_scene_trees(hk_ctx* ctx);
+/* ... and the REBUILD on the device, for when refits have degraded a tree: new trees over the instances' and the emitters' current
+ * boxes, written in place in the flatten_custom layout (all direction-threaded orderings of the instance tree; child order of
+ * orderings 1-7 by the rule of hk_bvh_rethread).
+ *   HK_TREE_SAH   the reference's OWN tree: `bvh` 0.7.1's binned-SAH build (BVH::build, instance.rs:365-371,422-428) level by level in
+ *                 one workgroup - every reduction in it is a min, a max or a count and its re-ordering a stable sort by bucket, so
+ *                 the parallel build makes the host's decisions and returns the host's tree shape (the tests compare the links).
+ *                 A frame after it equals the frame after hk_upload_scene_instances.
+ *   HK_TREE_LBVH  Morton codes of the box centres, one radix sort, Karras' parallel hierarchy: a few kernels whatever the depth of
+ *                 the tree, but spatial-median splits - a worse tree (frames 17-23 % slower in the probe scenes); frames equal the
+ *                 reference's up to exact ties between candidates, like any other valid tree over the same instances. */
+#define HK_TREE_SAH 0u
+#define HK_TREE_LBVH 1u
+int hk_rebuild_scene_trees(hk_ctx* ctx, uint32_t mode);
 /* Test hook: the instance tree (ordering 0) and the light tree as the device holds them, in the reference's HkNode layout. */
 int hk_debug_read_trees(hk_ctx* ctx, HkNode* instance_nodes, uint32_t instance_cap, HkNode* emissive_nodes, uint32_t emissive_cap);
 int hk_upload_textures(hk_ctx* ctx, const HkImageDesc* images, uint32_t n_images);
@@ -589,7 +595,7 @@ int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out); /* the i-th band's 
 int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* moved); /* hk_refit_scene_instances on every band's replica */
-int hk_multi_rebuild_scene_trees(hk_multi* m);
+int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode);
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n_images);
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes);
 int hk_multi_resize(hk_multi* m, uint32_t width, uint32_t height, float upscale_ratio);

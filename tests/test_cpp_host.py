@@ -127,7 +127,7 @@ def test_cpp_host_animates_through_the_device_refit(tmp_path, rebuild_at):
                 scene.builder.set_instance_transform(i, m)
             assert p.engine.refit_instances(scene.builder) == 2
             if n == rebuild_at:
-                p.engine.rebuild_trees()
+                p.engine.rebuild_trees()  # HK_TREE_SAH, the C++ mirror's default too
         p.render(hk.cornell_camera(96, 64), s, frame_number=n)
     want = p.engine.read(F.BUF_TONE_MAPPED)
     assert (got == want).all()

@@ -72,7 +72,11 @@ def check_tree(nodes, n_shapes, boxes):
             assert list(a.min) == list(b.min) and list(a.max) == list(b.max)
 
 
-def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCATTER, frames=5, settings=None, rebuild_on=()):
+def same_links(a, b):
+    return len(a) == len(b) and all(x.entry_index == y.entry_index and x.exit_index == y.exit_index for x, y in zip(a, b))
+
+
+def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCATTER, frames=5, settings=None, rebuild_on=(), rebuild_mode=F.TREE_LBVH):
     """GPU: one upload, then hk_refit_scene_instances per frame.  Oracle: the expected arrays per frame (see the module docstring).
     Moving objects make the reference's scatter-store race observable: it is resolved the oracle's way here."""
     dev_scene, sun = synthetic_scene(**kw)     # its builder feeds the device refit
@@ -99,11 +103,15 @@ def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCAT
             boxes = np.array([[list(i.min), list(i.max)] for i in new.instances], dtype=np.float32)
             eboxes = np.array([[[e.position[k] - e.radius for k in range(3)], [e.position[k] + e.radius for k in range(3)]] for e in new.emissives], dtype=np.float32)
             if n in rebuild_on:  # hk_rebuild_scene_trees: new tree shapes, built on the device; the oracle gets exactly those
-                gpu.engine.rebuild_trees()
+                mode = rebuild_mode(n) if callable(rebuild_mode) else rebuild_mode
+                gpu.engine.rebuild_trees(mode)
                 topo_tlas, topo_light = gpu.engine.read_trees(len(topo_tlas), len(topo_light))
                 check_tree(topo_tlas, len(new.instances), boxes)
                 if len(new.emissives):
                     check_tree(topo_light, len(new.emissives), eboxes)
+                if mode == F.TREE_SAH:  # the device ran the reference's own build: the host builder's tree for these poses, link for link
+                    assert same_links(topo_tlas, new.instance_nodes), "instance tree differs from the host's bvh 0.7.1 build"
+                    assert same_links(topo_light, new.emissive_nodes), "light tree differs from the host's bvh 0.7.1 build"
             expected = SceneData(previous_transforms=previous, vertices=ref_scene.vertices, primitives=ref_scene.primitives, asset_nodes=ref_scene.asset_nodes,
                                  materials=ref_scene.materials, instances=new.instances, instance_nodes=refit_nodes(topo_tlas, boxes),
                                  emissives=new.emissives, emissive_nodes=refit_nodes(topo_light, eboxes) if len(new.emissives) else new.emissive_nodes,
@@ -150,6 +158,40 @@ def test_device_rebuilt_trees_vs_oracle():
     run_refit_sequence(SMALL, (88, 60), lambda f: [1, 4, m - 1], frames=4, rebuild_on=(2, 3))
 
 
+def test_device_built_sah_trees_are_the_host_builders_trees():
+    """HK_TREE_SAH: `bvh` 0.7.1's binned-SAH build run on the device must return the tree the host builder returns for the same poses
+    (entry / exit links equal, node for node), and the frames must equal the oracle's on those trees."""
+    n = 1 + 20 + 5 + 3
+    run_refit_sequence(LARGE, (120, 72), lambda f: [2, 7, 11, 22, n - 1, n - 3], frames=6, rebuild_on=(2, 4, 5), rebuild_mode=lambda f: F.TREE_SAH if f != 4 else F.TREE_LBVH)
+    m = 1 + 3 + 1 + 1
+    run_refit_sequence(SMALL, (88, 60), lambda f: [1, 4, m - 1], frames=4, rebuild_on=(2, 3), rebuild_mode=F.TREE_SAH)
+
+
+def test_device_sah_build_at_scale_matches_the_host_builder():
+    """2 009 instances (few small meshes): one refit, then the SAH rebuild on the device against the host's finish() for the same poses."""
+    from bevy_hikari_amd.scenes import synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0004, 20, 16, 32, 2000, 50, 8, 40.0)
+    twin, _ = synthetic_large(0x5EED0004, 20, 16, 32, 2000, 50, 8, 40.0)
+    p = hk.HikariPlugin(device=0, flags=F.CTX_EXACT_TRAVERSAL)
+    p.set_scene(scene)
+    cam, s = synthetic_camera(96, 64, extent=30.0), hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)
+    p.render(cam, s, lights=hk.lights_uniform(directional=sun), frame_number=1)
+    rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in scene.instances], dtype=np.float32)
+    movers = np.random.default_rng(3).choice(len(rest), size=300, replace=False)
+    for k, i in enumerate(movers):
+        t = pose(rest[i], 5, k)
+        scene.builder.set_instance_transform(int(i), t)
+        twin.builder.set_instance_transform(int(i), t)
+    assert p.engine.refit_instances(scene.builder) == len(movers)
+    p.engine.rebuild_trees(F.TREE_SAH)
+    new = twin.builder.finish()
+    tlas, light = p.engine.read_trees(len(new.instance_nodes), len(new.emissive_nodes))
+    assert same_links(tlas, new.instance_nodes) and same_links(light, new.emissive_nodes)
+    boxes = np.array([[list(i.min), list(i.max)] for i in new.instances], dtype=np.float32)
+    check_tree(tlas, len(new.instances), boxes)
+
+
 def test_device_rebuild_of_all_orderings_stays_within_tolerance():
     """Product defaults: the rebuild writes all eight direction-threaded orderings; against the reference-order context."""
     kw, size = LARGE, (160, 96)
@@ -171,7 +213,9 @@ def test_device_rebuild_of_all_orderings_stays_within_tolerance():
                     scene.builder.set_instance_transform(i, pose(rest[i], n - 1, k))
                 assert p.engine.refit_instances(scene.builder) == 4
                 if n == 3:
-                    p.engine.rebuild_trees()
+                    p.engine.rebuild_trees(F.TREE_LBVH)
+                if n == 4:
+                    p.engine.rebuild_trees(F.TREE_SAH)
             p.render(cam, s, lights=lights, frame_number=n)
         outs.append((p.output(s), snapshot(p)))
     (a, sa), (b, sb) = outs
@@ -191,8 +235,9 @@ def test_refit_and_rebuild_random_sequences_vs_oracle(seed):
     s = hk.HikariSettings(indirect_bounces=int(rng.integers(0, 4)), emissive_spatial_reuse=bool(rng.random() < 0.5), denoise=bool(rng.random() < 0.7),
                           upscale=hk.Upscale.SmaaTu4x(float(rng.choice([1.0, 1.5, 2.0]))))
     rebuild_on = tuple(int(f) for f in range(2, 6) if rng.random() < 0.4)
+    modes = {f: (F.TREE_SAH if rng.random() < 0.6 else F.TREE_LBVH) for f in range(2, 6)}
     run_refit_sequence(kw, (int(rng.integers(48, 130)), int(rng.integers(40, 90))), lambda f: movers if f % 3 else movers[:max(1, len(movers) // 2)], settings=s,
-                       rebuild_on=rebuild_on)
+                       rebuild_on=rebuild_on, rebuild_mode=lambda f: modes[f])
 
 
 def test_refit_with_direction_threaded_orderings_stays_within_tolerance():

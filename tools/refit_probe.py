@@ -83,17 +83,18 @@ def probe(n_instances):
         st = p.engine.stats()
         out[mode]["stats"] = {"instance_builds": int(st.scene_instance_builds), "async_uploads": int(st.scene_async_instance_uploads), "device_refits": int(st.scene_device_refits)}
         if mode == "device":   # the LBVH rebuild of both trees on the device, alone on the stream
-            t_gpu = []
-            for _ in range(8):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                p.engine.wait()
-                e0.record(stream)
-                p.engine.rebuild_trees()
-                e1.record(stream)
-                p.engine.wait()
-                t_gpu.append(e0.elapsed_time(e1))
-            out[mode]["rebuild_trees_stream_ms"] = round(float(np.median(t_gpu)), 3)
-            out[mode]["frame_ms_static_after_rebuild"] = round(animated(20, 400, False), 3)
+            for name, tree in (("lbvh", F.TREE_LBVH), ("sah", F.TREE_SAH)):
+                t_gpu = []
+                for _ in range(8):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    p.engine.wait()
+                    e0.record(stream)
+                    p.engine.rebuild_trees(tree)
+                    e1.record(stream)
+                    p.engine.wait()
+                    t_gpu.append(e0.elapsed_time(e1))
+                out[mode][f"rebuild_trees_{name}_stream_ms"] = round(float(np.median(t_gpu)), 3)
+                out[mode][f"frame_ms_static_after_{name}_rebuild"] = round(animated(20, 400 if name == "lbvh" else 500, False), 3)
         if mode == "device":   # leave the builder finished for the next scene
             b.api.call("scene_builder_finish", b.h)
         del p
