@@ -518,8 +518,6 @@ __global__ __launch_bounds__(256, 4) void k_wf_final(DScene sc, DFrame fr, GBuff
 namespace hk {
 using namespace hkd;
 
-size_t wavefront_bytes_per_path() { return 4 + 9 * 16 + 2 * 16 + 2 * 16 + 4 + 16 + 4 + 4 + 2 * 8 + 2 * 4; }
-
 void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,
                                int y1, int compute_units, hipEvent_t start, hipEvent_t stop) {
   if (y1 <= y0) return;
