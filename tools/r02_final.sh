@@ -18,3 +18,12 @@ done
 grep -A9 "k_wf_trace\|k_wf_shade" $OUT/${TAG}_config3_pmc_sq3.txt | head -24
 grep -A2 "k_wf_" $OUT/${TAG}_config3_pmc_fetch3.txt $OUT/${TAG}_config3_pmc_write3.txt | head -40
 rm -rf $OUT/prof_sq3 $OUT/prof_fetch3 $OUT/prof_write3
+# instance motion on the device: probe + kernel durations of the refit / rebuild kernels
+timeout 600 python tools/refit_probe.py 2000 20000 > $OUT/${TAG}_device_refit_probe.json 2>/dev/null
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_refit -- python $OLDPWD/tools/refit_probe.py 20000 > /dev/null 2>&1
+cd $OLDPWD
+DB=$(find $OUT/prof_refit -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/rocpd_summary.py $DB | grep -E "^kernel|k_refit|k_sah|k_lbvh|k_copy_region|k_gather|radix|onesweep|histogram" | head -20 > $OUT/${TAG}_refit_kernel_stats.txt
+cat $OUT/${TAG}_refit_kernel_stats.txt | cut -c1-170
+rm -rf $OUT/prof_refit
