@@ -81,9 +81,28 @@ class BandRenderer:
             import torch.distributed as dist
 
             # rendezvous: rank 0 creates the RCCL id, the (gloo) process group carries its 128 bytes to the other ranks
-            box = [engine.comm_unique_id() if rank == 0 else None]
+            # A rank whose RCCL will not come up (no librccl, no peer access ...) must not leave the others waiting inside
+            # ncclCommInitRank's rendezvous or the first exchange: the ranks agree on the outcome, and if any of them failed
+            # ALL fall back to the host-staged transport (slower, same bytes) and say so in `transport`.
+            self.rccl_error = None
+            try:
+                box = [engine.comm_unique_id() if rank == 0 else None]
+            except Exception as err:  # (HikariError from the library, OSError from the loader)
+                box, self.rccl_error = [None], repr(err)
             dist.broadcast_object_list(box, src=0)
-            engine.comm_init(rank, world_size, box[0])
+            if box[0] is not None:
+                try:
+                    engine.comm_init(rank, world_size, box[0])
+                except Exception as err:
+                    self.rccl_error = repr(err)
+            else:
+                self.rccl_error = self.rccl_error or "rank 0 could not create an RCCL id"
+            ok = torch.tensor([0 if self.rccl_error else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if not self.rccl_error:
+                    engine.comm_destroy()
+                self.transport = "host (rccl unavailable on some rank" + (": " + self.rccl_error if self.rccl_error else "") + ")"
 
     # ------------------------------------------------------------------ host transport (tests)
     def _view(self, buf, parity=0):
@@ -223,6 +242,15 @@ class MultiEngine:
     def upload_noise(self, noise=None):
         for e in self.contexts:
             e.upload_noise(noise)
+
+    def refit_instances(self, builder):
+        """hk_multi_refit_scene_instances: the poses set on `builder` go to every band's device copy of the scene."""
+        moved = C.c_uint32()
+        self.api.call("multi_refit_scene_instances", self.h, builder.h, C.byref(moved))
+        return moved.value
+
+    def rebuild_trees(self, mode=F.TREE_SAH):
+        self.api.call("multi_rebuild_scene_trees", self.h, mode)
 
     def resize(self, width, height, upscale_ratio=1.0):
         self.api.call("multi_resize", self.h, width, height, upscale_ratio)

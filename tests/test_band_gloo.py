@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case_name, out_dir):
+def _worker(rank, world, port, case_name, out_dir, transport=None):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -44,7 +44,9 @@ def _worker(rank, world, port, case_name, out_dir):
     e.upload_scene(case.scene)
     w, h = case.camera.width, case.camera.height
     e.resize(w, h, s.upscale.ratio())
-    r = BandRenderer(e, rank, world, backend_device="cpu")
+    r = BandRenderer(e, rank, world, backend_device="cpu", transport=transport)
+    if transport == "rccl":  # (no RCCL behind the oracle: every rank must have agreed on the host-staged exchange)
+        assert r.transport.startswith("host (rccl unavailable"), r.transport
     view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
     for n in case.frames:
         r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h)
@@ -58,13 +60,15 @@ def _worker(rank, world, port, case_name, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name", [(2, "cornell_b2"), (3, "yard_sun")])
-def test_bands_equal_single_rank(tmp_path, world, case_name):
+@pytest.mark.parametrize("world,case_name,transport", [(2, "cornell_b2", None), (3, "yard_sun", None), (2, "cornell_b2", "rccl")])
+def test_bands_equal_single_rank(tmp_path, world, case_name, transport):
+    """transport "rccl" where RCCL cannot come up (here: the oracle has no communicator): the ranks agree to stage the halos
+    through host memory instead of hanging in the rendezvous, and the frame is the same."""
     from cases import make_case, run_case, snapshot
     from oracle_lib import oracle_plugin
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path), transport), nprocs=world, join=True)
     case = make_case(case_name)
     ref = oracle_plugin()
     run_case(ref, case)

@@ -167,18 +167,21 @@ def test_device_built_sah_trees_are_the_host_builders_trees():
     run_refit_sequence(SMALL, (88, 60), lambda f: [1, 4, m - 1], frames=4, rebuild_on=(2, 3), rebuild_mode=F.TREE_SAH)
 
 
-def test_device_sah_build_at_scale_matches_the_host_builder():
-    """2 009 instances (few small meshes): one refit, then the SAH rebuild on the device against the host's finish() for the same poses."""
+@pytest.mark.parametrize("n_instances,n_emitters,n_movers", [(2000, 8, 300), (20000, 1500, 3000)])
+def test_device_sah_build_at_scale_matches_the_host_builder(n_instances, n_emitters, n_movers):
+    """2 009 / 21 501 instances (few small meshes; the larger one with a 1 500-leaf light tree, so both trees go through the
+    one-workgroup top AND the per-subtree kernel): one refit, then the SAH rebuild on the device against the host's finish()
+    for the same poses."""
     from bevy_hikari_amd.scenes import synthetic_large
 
-    scene, sun = synthetic_large(0x5EED0004, 20, 16, 32, 2000, 50, 8, 40.0)
-    twin, _ = synthetic_large(0x5EED0004, 20, 16, 32, 2000, 50, 8, 40.0)
+    scene, sun = synthetic_large(0x5EED0004, 20, 16, 32, n_instances, 50, n_emitters, 40.0)
+    twin, _ = synthetic_large(0x5EED0004, 20, 16, 32, n_instances, 50, n_emitters, 40.0)
     p = hk.HikariPlugin(device=0, flags=F.CTX_EXACT_TRAVERSAL)
     p.set_scene(scene)
     cam, s = synthetic_camera(96, 64, extent=30.0), hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)
     p.render(cam, s, lights=hk.lights_uniform(directional=sun), frame_number=1)
     rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in scene.instances], dtype=np.float32)
-    movers = np.random.default_rng(3).choice(len(rest), size=300, replace=False)
+    movers = np.random.default_rng(3).choice(len(rest), size=n_movers, replace=False)
     for k, i in enumerate(movers):
         t = pose(rest[i], 5, k)
         scene.builder.set_instance_transform(int(i), t)

@@ -104,3 +104,53 @@ def test_multi_create_rejects_bad_devices():
     with pytest.raises(hk.HikariError) as err:
         MultiEngine([0, 99])
     assert err.value.code == F.HK_E_NO_DEVICE
+
+
+def test_multi_engine_device_motion_reaches_every_band():
+    """hk_multi_refit_scene_instances / hk_multi_rebuild_scene_trees: every band's device copy of the scene gets the same
+    per-instance records and the same trees as a single context fed the same poses (the builder's transforms are committed
+    once, after the last band: were they committed after the first, the others would see no motion), and the union of the bands follows the single-context frame (moving objects reproject across
+    the band borders: exchange C's history rows, the north star's 1e-3)."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_scene
+    from test_device_refit import LARGE, pose, same_links
+
+    multi_scene, sun = synthetic_scene(**LARGE)
+    single_scene, _ = synthetic_scene(**LARGE)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    w, h = 112, 72
+    cam, lights = synthetic_camera(w, h), hk.lights_uniform(directional=sun)
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    m = MultiEngine([0, 0, 0], flags=F.CTX_DETERMINISTIC_SCATTER)
+    ref = hk.Engine(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)
+    for t, scene in ((m, multi_scene), (ref, single_scene)):
+        t.upload_noise(); t.upload_scene(scene); t.resize(w, h, 1.0)
+    m.set_history_rows(16)
+    rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in single_scene.instances], dtype=np.float32)
+    movers = [2, 7, 11, 22, len(rest) - 1]
+    n_tlas, n_light = len(single_scene.instance_nodes), len(single_scene.emissive_nodes)
+    for n in range(1, 7):
+        if n > 1:
+            for k, i in enumerate(movers):
+                for scene in (multi_scene, single_scene):
+                    scene.builder.set_instance_transform(i, pose(rest[i], n - 1, k))
+            assert m.refit_instances(multi_scene.builder) == len(movers)
+            assert ref.refit_instances(single_scene.builder) == len(movers)
+            if n == 4:
+                m.rebuild_trees(F.TREE_SAH); ref.rebuild_trees(F.TREE_SAH)
+            want = ref.read_trees(n_tlas, n_light)
+            for e in m.contexts:
+                got = e.read_trees(n_tlas, n_light)
+                for a, b in zip(got, want):
+                    assert same_links(a, b) and bytes(a) == bytes(b), f"frame {n}: a band's trees differ from the single context's"
+        f = hk.frame_uniform(s, n)
+        m.frame_render(f, view, pview, lights, s.to_c())
+        ref.frame_render(f, view, pview, lights, s.to_c())
+    m.wait()
+    for e in m.contexts:
+        st = e.stats()
+        assert st.scene_device_refits == 5 and st.scene_device_tree_builds == 1
+    assert (m.read(F.BUF_POSITION).view(np.uint8) == ref.read(F.BUF_POSITION).view(np.uint8)).all(), "the G-buffer has no history: bit for bit"
+    got = np.stack([m.read(F.BUF_DENOISE_RENDER0 + i).view(np.float16).astype(np.float32) for i in range(3)])
+    want = np.stack([ref.read_f16(F.BUF_DENOISE_RENDER0 + i) for i in range(3)])
+    err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+    assert err <= 1e-3, err
