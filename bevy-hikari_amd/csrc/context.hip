@@ -811,6 +811,7 @@ DFrame make_dframe(const hk_ctx* c) {
   f.clear_r = h.clear_color[0]; f.clear_g = h.clear_color[1]; f.clear_b = h.clear_color[2]; f.clear_a = h.clear_color[3];
   f.dw = c->W; f.dh = c->H; f.rw = c->RW; f.rh = c->RH;
   f.inv_dw = 1.0f / (float)c->W; f.inv_dh = 1.0f / (float)c->H; f.inv_rw = 1.0f / (float)c->RW; f.inv_rh = 1.0f / (float)c->RH;
+  f.rcp_rw = 1.0 / (double)c->RW; f.rcp_rh = 1.0 / (double)c->RH;
   f.uv_fast = c->uv_fast ? 1u : 0u;
   return f;
 }

@@ -105,6 +105,7 @@ struct DFrame {
   // IEEE quotient (context.hip certify_uv_division), so the flag only selects a cheaper route to the same bits
   float inv_dw, inv_dh, inv_rw, inv_rh;
   uint32_t uv_fast;
+  double rcp_rw, rcp_rh;      // 1.0 / (double)rw, 1.0 / (double)rh (IEEE f64): hk_device_math.hpp quotient_by_reciprocal
 };
 struct PackedReservoir {  // light.wgsl:35-43
   uint2 radiance;

@@ -140,10 +140,19 @@ HKD void sincos_(float x, float* sn, float* cs) {  // same values as sin_ / cos_
   *sn = (q & 2) ? -vs : vs;
   *cs = ((q + 1) & 2) ? -vc : vc;
 }
+// y * 2^k rounded once.  The contract writes it as (y * 2^(k/2)) * 2^(k - k/2): for the k that exp_ / exp2_ produce (-150..128) and
+// their y in [0.7, 1.42] the first product is exact and normal, so the second is the only rounding (to a subnormal, or an overflow
+// to infinity, included) - which is v_ldexp_f32, one instruction instead of eight (tests/test_math_contract.py sweeps the edges).
 HKD float scale2(float y, int k) {
+#ifdef HK_SCALE2_MUL
   int k1 = k / 2, k2 = k - k1;
   return (y * pow2i(k1)) * pow2i(k2);
+#else
+  return __builtin_ldexpf(y, k);
+#endif
 }
+// (exp2_ / exp_ keep their early returns: turning them into selects after the polynomial removes ~250 scalar instructions from
+// k_denoise but made k_spatial_reuse 4 % slower - measured, round 2)
 HKD float exp2_(float x) {
   if (x != x) return x;
   if (x >= 128.0f) return __builtin_inff();
@@ -210,6 +219,15 @@ HKD float log2_(float x) {
   r = r + m;
   return r + (float)e;
 }
+// x / d for many x and one d: rd = 1.0 / (double)d once (IEEE f64 division), then RN32((double)x * rd) per quotient - three full-rate
+// instructions instead of the ~13-slot v_div_scale / v_rcp / fma / v_div_fmas / v_div_fixup sequence.  The f64 product is within
+// 2^-52 (relative) of x / d, and a quotient of two f32 numbers that is not a rounding boundary of the f32 grid is at least 2^-49
+// away from one (x = X 2^a, d = D 2^b, a boundary m = M 2^c with M odd and < 2^25: |x/d - m| / m = |X 2^s - M D| / (M D) with a
+// non-zero integer numerator), so the f32 rounding is the IEEE quotient's - EXCEPT where the quotient is subnormal, where a
+// boundary can be hit exactly and tie the other way.  Use it only where such a quotient cannot matter: the filter weights feed it
+// to exp_, which returns 1.0f for every |argument| < 2^-25.  Zero, infinite and NaN operands behave like the division
+// (0 * inf = NaN = 0 / 0 ...).  Compared against the oracle's plain divisions by every denoise parity test.
+HKD float quotient_by_reciprocal(float x, double rd) { return (float)((double)x * rd); }
 HKD float pow_(float x, float y) {
   if (x == 0.0f) return y > 0.0f ? 0.0f : (y == 0.0f ? 1.0f : __builtin_inff());
   return exp2_(y * log2_(x));

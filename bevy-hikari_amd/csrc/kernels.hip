@@ -359,9 +359,6 @@ struct SecTimer {
 
 // HK_ABLATE_WALK_TWICE (tools/section_profile.py --walk-twice): every BVH walk of k_indirect is executed twice, the
 // first result discarded behind an opaque register; the time the kernel gains is what the walks cost in issue slots.
-#ifndef HK_ABLATE_SPATIAL
-#define HK_ABLATE_SPATIAL 0   // tools: 1 depth march, 2 reservoir unpack, 3 jacobian + shade, 4 sincos executed twice in k_spatial_reuse
-#endif
 #ifdef HK_ABLATE_WALK_TWICE
 #define HK_ABLATE_WALK(sc, ray, maxd, mind, excl, rc)                 \
   do {                                                                \
@@ -687,9 +684,6 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     const float radius = taps.radius[i - 1u];
     float sn, cs;
     sincos_(angle, &sn, &cs);
-#if HK_ABLATE_SPATIAL == 4
-    { float a2 = angle; asm volatile("" : "+v"(a2)); float s2, c2; sincos_(a2, &s2, &c2); asm volatile("" ::"v"(s2), "v"(c2)); }
-#endif
     const f2 offset = radius * F2(cs, sn);
 
     const int scx = f32_to_i32(offset.x + (float)x), scy = f32_to_i32(offset.y + (float)y);
@@ -703,10 +697,6 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     if (depth_ratio < 0.9f || depth_ratio > 1.1f) continue;
 
     q = unpack_reservoir(load_packed(t.current, scx + fr.rw * scy));
-#if HK_ABLATE_SPATIAL == 2
-    { int i2 = scx + fr.rw * scy; asm volatile("" : "+v"(i2)); const Reservoir q2 = unpack_reservoir(load_packed(t.current, i2));
-      asm volatile("" ::"v"(q2.count), "v"(q2.w), "v"(q2.s.radiance.x), "v"(q2.s.random.w), "v"(q2.s.visible_normal.y), "v"(q2.s.sample_normal.z), "v"(q2.lifetime), "v"(q2.s.sample_position.w)); }
-#endif
     const bool normal_miss = dot(s.visible_normal, q.s.visible_normal) < 0.866f;
     if (q.count < HK_F32_EPSILON || normal_miss) continue;
 
@@ -717,27 +707,17 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     const uint32_t tap_count = taps.tap_count[i - 1u];
     bool occluded = false;
     const f2 dir = normalize(offset);
-#if HK_ABLATE_SPATIAL == 1
-    {
-      f2 d2 = dir; asm volatile("" : "+v"(d2.x));
-      bool occ2 = false;
-      for (uint32_t j = 1u; j <= tap_count; j += 1u) {
-        const float tap_dist = (float)j * tap_interval;
-        const f2 tap_offset = tap_dist * d2;
-        const f2 tap_uv = uv + tap_offset / F2((float)fr.rw, (float)fr.rh);
-        int tdx, tdy;
-        jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
-        const float tap_depth = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.depth[tdx + fr.dw * tdy] : 0.0f;
-        const float ref_depth = mix(depth, sample_depth, taps.march_frac[i - 1u][j - 1u]);
-        if (tap_depth > ref_depth + 0.00001f) { occ2 = true; break; }
-      }
-      asm volatile("" ::"v"((int)occ2));
-    }
-#endif
     for (uint32_t j = 1u; j <= tap_count; j += 1u) {
       const float tap_dist = (float)j * tap_interval;
       const f2 tap_offset = tap_dist * dir;
+      // tap_offset / (width, height) through the frame's f64 reciprocals (quotient_by_reciprocal: the IEEE quotient unless that
+      // is subnormal, which it cannot be here - a non-zero component of `dir` is >= 1e-9: the polynomial of an angle that is at
+      // least 2^-25 away from the multiples of pi/2, over a tap radius of a few hundred pixels at most)
+#ifdef HK_MARCH_F32_DIV
       const f2 tap_uv = uv + tap_offset / F2((float)fr.rw, (float)fr.rh);
+#else
+      const f2 tap_uv = uv + F2(quotient_by_reciprocal(tap_offset.x, fr.rcp_rw), quotient_by_reciprocal(tap_offset.y, fr.rcp_rh));
+#endif
       int tdx, tdy;
       jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
       const float tap_depth = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.depth[tdx + fr.dw * tdy] : 0.0f;
@@ -750,11 +730,6 @@ __global__ __launch_bounds__(256, 4) void k_spatial_reuse(DScene sc, DFrame fr, 
     if (occluded) continue;
 
     const float jacobian = (q.s.sample_position.w > 0.5f) ? compute_jacobian(q.s, s) : 1.0f;
-#if HK_ABLATE_SPATIAL == 3
-    { f3 d2 = sample_direction; asm volatile("" : "+v"(d2.x)); const f3 o2 = shade(site, d2, q.s.radiance);
-      Sample qs2 = q.s; asm volatile("" : "+v"(qs2.sample_position.x)); const float j2 = (qs2.sample_position.w > 0.5f) ? compute_jacobian(qs2, s) : 1.0f;
-      asm volatile("" ::"v"(o2.x), "v"(o2.y), "v"(o2.z), "v"(j2)); }
-#endif
     if (EMISSIVE_LIT) {
       merge_reservoir(r, q, luminance(xyz(q.s.radiance)) / jacobian);
     } else {

@@ -97,6 +97,9 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
   const float instance = gc.w;
 
   f3 sum_irradiance[NCH];
+#ifndef HK_DN_F32_DIV
+  double inv_lum_denominator[NCH];  // the eight taps of a channel divide by the same number: see quotient_by_reciprocal
+#endif
   float sum_w[NCH], lum[NCH], lum_denominator[NCH], ff_moment_1[NCH], ff_moment_2[NCH], ff_count[NCH];
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -111,6 +114,9 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     }
     lum[ch] = luminance(irradiance);
     lum_denominator[ch] = 4.0f * pow_quarter_(variance) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
+#ifndef HK_DN_F32_DIV
+    inv_lum_denominator[ch] = 1.0 / (double)lum_denominator[ch];
+#endif
     ff_moment_1[ch] = 0.0f;
     ff_moment_2[ch] = 0.0f;
     ff_count[ch] = 0.0f;
@@ -141,7 +147,11 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
       const f3 irr = xyz(unpack_f16x4(d.input[ch][sx + fr.rw * sy]));
       if (any_is_nan(irr) || irr.x > HK_F32_MAX || irr.y > HK_F32_MAX || irr.z > HK_F32_MAX) continue;
       const float sample_luminance = luminance(irr);
+#ifdef HK_DN_F32_DIV
       const float w_luminance = exp_((-fabsf(lum[ch] - sample_luminance)) / lum_denominator[ch]);
+#else
+      const float w_luminance = exp_(quotient_by_reciprocal(-fabsf(lum[ch] - sample_luminance), inv_lum_denominator[ch]));
+#endif
       const float w = clamp_(w_geometry * w_luminance, 0.0f, 1.0f) * kernel_w;
       sum_irradiance[ch] = sum_irradiance[ch] + irr * w;
       sum_w[ch] += w;

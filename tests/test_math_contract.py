@@ -108,6 +108,50 @@ def test_device_math_bit_exact_vs_oracle(op):
         raise AssertionError(f"{op}: {(~same).sum()} of {same.size} differ, e.g. x={[a[i] for a in args]} gpu={got[i]} cpu={want[i]}")
 
 
+def edge_inputs(op, rng, n=400_000):
+    """Where exp_ / exp2_ leave the normal range: results that are subnormal (one rounding in the final scaling - the device does it
+    with v_ldexp_f32, the contract writes it as two multiplications by powers of two), the flush-to-zero and overflow thresholds
+    and their float neighbours, and the specials."""
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e30, -1e30, 3e38, -3e38, 1e-45, -1e-45, 1e-38, -1e-38], dtype=np.float32)
+
+    def around(v, k=64):
+        out = [np.float32(v)]
+        for _ in range(k):
+            out.append(np.nextafter(out[-1], np.float32(np.inf)))
+        lo = np.float32(v)
+        for _ in range(k):
+            lo = np.nextafter(lo, np.float32(-np.inf))
+            out.append(lo)
+        return np.array(out, dtype=np.float32)
+
+    if op == "exp":
+        return (np.concatenate([rng.uniform(-106.0, -85.0, n), rng.uniform(86.0, 90.0, n // 4), around(-103.972084045410), around(88.72283905206835),
+                                around(-87.33654), special]).astype(np.float32),)
+    if op == "exp2":
+        return (np.concatenate([rng.uniform(-152.0, -124.0, n), rng.uniform(125.0, 129.0, n // 4), around(-150.0), around(128.0), around(-126.0), around(-149.5),
+                                np.arange(-152, 130).astype(np.float32), np.arange(-152, 130).astype(np.float32) + 0.5, special]).astype(np.float32),)
+    # pow = exp2(y * log2(x)): tiny and huge results
+    x = np.concatenate([np.exp(rng.uniform(-80.0, 80.0, n)), special[:4]]).astype(np.float32)
+    y = np.concatenate([rng.uniform(-2.0, 2.0, n), np.array([0.0, 1.0, -1.0, 2.0])]).astype(np.float32)
+    return x, y
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op", ["exp", "exp2", "pow"])
+def test_device_exp_family_at_the_edges_of_the_range(op):
+    import bevy_hikari_amd as hk
+
+    args = edge_inputs(op, np.random.default_rng(11))
+    got = hk.Engine(device=0).debug_math(OPS[op], *args)
+    want = oracle_math(op, *args)
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    if not same.all():
+        i = np.nonzero(~same)[0][:5]
+        raise AssertionError(f"{op}: {(~same).sum()} of {same.size} differ, e.g. x={[a[i] for a in args]} gpu={got[i]} cpu={want[i]}")
+    if op != "pow":
+        assert ((np.abs(want) < 1.17e-38) & (want != 0)).sum() > 10_000, "the sweep must reach subnormal results"
+
+
 NORM_OPS = {"unorm16": (14, 65536), "snorm8": (15, 256), "unorm8": (20, 256)}
 
 
