@@ -208,11 +208,36 @@ __device__ __forceinline__ Pixel pixel_of_thread(int width, int row_begin, int r
   return p;
 }
 
+// The streaming / stencil kernels' mapping (demodulation, a-trous): a wave covers W x (64 / W) pixels and a workgroup four such
+// strips stacked, so that a wave's load of a 4-byte plane is whole 128-B lines instead of eight 32-B pieces of eight lines (the
+// 8 x 8 tiles above suit gathers and rays).  XCD_BANDS as above.  Measured (Cornell 1080p, round 2): demodulation 0.071 ms with
+// 8 x 8 tiles -> 0.047 (32 x 2) -> 0.040 (64 x 1, bands); the a-trous levels 0.072 -> 0.064 by going round-robin, any shape.
+template <int W, bool XCD_BANDS>
+__device__ __forceinline__ Pixel pixel_of_thread_rows(int width, int row_begin, int row_end) {
+  constexpr int H = 64 / W;  // of a wave
+  const int tiles_x = (width + W - 1) / W;
+  uint32_t b = blockIdx.x;
+  const uint32_t nb = gridDim.x, per = nb >> 3;
+  if (XCD_BANDS && per > 0 && b < per * 8u) b = (b & 7u) * per + (b >> 3);
+  const int tile_x = (int)(b % (uint32_t)tiles_x), tile_y = (int)(b / (uint32_t)tiles_x);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  Pixel p;
+  p.x = tile_x * W + (lane & (W - 1));
+  p.y = row_begin + tile_y * (4 * H) + wave * H + (lane / W);
+  p.valid = p.x < width && p.y < row_end;
+  return p;
+}
+
 }  // namespace hkd
 
 #define HK_LDS_SCENE_BYTES 32768u  // scenes up to this size are copied into LDS by the ray kernels (lds_bytes_for)
 
 namespace hk {
+static inline dim3 grid_for_rows(int wave_width, int width, int rows) {  // pixel_of_thread_rows<wave_width, *>
+  int wg_rows = 4 * (64 / wave_width);
+  int tiles_x = (width + wave_width - 1) / wave_width, tiles_y = (rows + wg_rows - 1) / wg_rows;
+  return dim3((unsigned)(tiles_x * tiles_y), 1, 1);
+}
 static inline dim3 grid_for(int width, int rows) {
   int tiles_x = (width + 15) / 16, tiles_y = (rows + 15) / 16;
   return dim3((unsigned)(tiles_x * tiles_y), 1, 1);

@@ -17,6 +17,10 @@
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 
+#ifndef HK_DENOISE_W
+#define HK_DENOISE_W 64  // wave shape of the a-trous levels: 64 x 1 pixels (pixel_of_thread_rows)
+#endif
+
 namespace hkd {
 
 // depth plane (f32) for the spatial-reuse ray march + packed denoise geometry, from the G-buffer
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256) void k_derive_planes(GBuffer g, float* __restr
 
 template <int NCH>
 __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d, int row_begin, int row_end) {  // denoise.wgsl:135-162
-  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+  const Pixel px = pixel_of_thread_rows<64, true>(fr.rw, row_begin, row_end);
   if (!px.valid) return;
   const int x = px.x, y = px.y, index = x + fr.rw * y;
   const f2 uv = coords_to_uv(fr, x, y);
@@ -41,9 +45,31 @@ __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d,
   nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
   const f3 albedo = xyz(unpack_f16x4(d.albedo[ax + fr.dw * ay]));
   nearest_coords(uv, fr.rw, fr.rh, &rx, &ry);
+  uint2 render_in[NCH];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) render_in[ch] = d.render[ch][rx + fr.rw * ry];
+  // The 3 x 3 variance taps (denoise.wgsl:152-160).  All of a pixel's loads are issued before the first is used - a tap outside the
+  // image reads the pixel's own (valid) address and is dropped afterwards - so that a wave waits for memory once, not once per tap;
+  // the sum itself runs in the reference's order (x outer, y inner) with the reference's conditions.
+  float tap_variance[9][NCH];
+  bool tap_inside[9];
+#pragma unroll
+  for (int ox = -1; ox <= 1; ++ox) {
+#pragma unroll
+    for (int oy = -1; oy <= 1; ++oy) {
+      const int k = (ox + 1) * 3 + (oy + 1);
+      const f2 sample_uv = uv + F2((float)ox * fr.inv_rw, (float)oy * fr.inv_rh);  // ox, oy in {-1, 0, 1}: +-RN(1/size) or 0, exactly the quotient
+      tap_inside[k] = !(sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f);
+      int sx, sy;
+      nearest_coords(sample_uv, fr.rw, fr.rh, &sx, &sy);
+      const int at = tap_inside[k] ? sx + fr.rw * sy : index;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) tap_variance[k][ch] = d.variance[ch][at];
+    }
+  }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    f3 irradiance = xyz(unpack_f16x4(d.render[ch][rx + fr.rw * ry]));
+    f3 irradiance = xyz(unpack_f16x4(render_in[ch]));
     const f3 qd = irradiance / albedo;
     irradiance = F3(albedo.x < 0.01f ? 0.0f : qd.x, albedo.y < 0.01f ? 0.0f : qd.y, albedo.z < 0.01f ? 0.0f : qd.z);
     d.output[ch][index] = pack_f16x4(F4(irradiance, 1.0f));  // internal_texture_0
@@ -54,16 +80,13 @@ __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d,
 #pragma unroll
   for (int ox = -1; ox <= 1; ++ox) {
 #pragma unroll
-    for (int oy = -1; oy <= 1; ++oy) {  // call order of denoise.wgsl:152-160: x outer, y inner
-      const f2 sample_uv = uv + F2((float)ox * fr.inv_rw, (float)oy * fr.inv_rh);  // ox, oy in {-1, 0, 1}: +-RN(1/size) or 0, exactly the quotient
-      if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
-      int sx, sy;
-      nearest_coords(sample_uv, fr.rw, fr.rh, &sx, &sy);
+    for (int oy = -1; oy <= 1; ++oy) {
+      const int k = (ox + 1) * 3 + (oy + 1);
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
-        const float variance = d.variance[ch][sx + fr.rw * sy];
-        if (variance > HK_F32_MAX) continue;
-        sum_variance[ch] += fr.kernel[(oy + 1) * 3 + (ox + 1)] * fmax_(variance, 0.0f);
+        const float variance = tap_variance[k][ch];
+        const float with_tap = sum_variance[ch] + fr.kernel[(oy + 1) * 3 + (ox + 1)] * fmax_(variance, 0.0f);
+        sum_variance[ch] = (tap_inside[k] && !(variance > HK_F32_MAX)) ? with_tap : sum_variance[ch];
       }
     }
   }
@@ -74,7 +97,11 @@ __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d,
 // FFMASK bit ch = FIREFLY_FILTERING for channel ch (post_process.rs:773-783,1193-1197)
 template <int LEVEL, int NCH, int FFMASK>
 __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:164-319
-  const Pixel px = pixel_of_thread(fr.rw, row_begin, row_end);
+#if defined(HK_DENOISE_TILES_RR)
+  const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
+#else
+  const Pixel px = pixel_of_thread_rows<HK_DENOISE_W, false>(fr.rw, row_begin, row_end);
+#endif
   if (!px.valid) return;
   constexpr int STEP = 8 >> LEVEL;
   const int x = px.x, y = px.y, index = x + fr.rw * y;
@@ -205,7 +232,7 @@ void launch_derive_planes(hipStream_t st, const GBuffer& g, float* depth_plane, 
 
 void launch_demodulation(hipStream_t st, int nch, const DFrame& fr, const DemodTargets& d, int y0, int y1) {
   if (y1 <= y0) return;
-  dim3 grid = grid_for(fr.rw, y1 - y0);
+  dim3 grid = grid_for_rows(64, fr.rw, y1 - y0);
   switch (nch) {
     case 1: hipLaunchKernelGGL(k_demodulation<1>, grid, dim3(256), 0, st, fr, d, y0, y1); break;
     case 2: hipLaunchKernelGGL(k_demodulation<2>, grid, dim3(256), 0, st, fr, d, y0, y1); break;
@@ -215,7 +242,11 @@ void launch_demodulation(hipStream_t st, int nch, const DFrame& fr, const DemodT
 
 template <int LEVEL>
 static void launch_denoise_level(hipStream_t st, int nch, int ffmask, const DFrame& fr, const DenoiseTargets& d, int y0, int y1) {
+#if defined(HK_DENOISE_TILES_RR)
   dim3 grid = grid_for(fr.rw, y1 - y0);
+#else
+  dim3 grid = grid_for_rows(HK_DENOISE_W, fr.rw, y1 - y0);
+#endif
   if (nch == 1 && ffmask == 0) hipLaunchKernelGGL((k_denoise<LEVEL, 1, 0>), grid, dim3(256), 0, st, fr, d, y0, y1);
   else if (nch == 1) hipLaunchKernelGGL((k_denoise<LEVEL, 1, 1>), grid, dim3(256), 0, st, fr, d, y0, y1);
   else if (nch == 2) hipLaunchKernelGGL((k_denoise<LEVEL, 2, 2>), grid, dim3(256), 0, st, fr, d, y0, y1);  // sun, emissive
