@@ -182,6 +182,21 @@ HKD float exp_(float x) {
   float y = fmaf(p, r * r, r) + 1.0f;
   return scale2(y, (int)z);
 }
+// exp_ for arguments that are never positive (filter weights exp(-|a| / b), b > 0): the overflow test cannot fire and is left out
+HKD float exp_nonpositive_(float x) {
+  if (x != x) return x;
+  if (x < -103.972084045410f) return 0.0f;
+  float z = floorf(fmaf(1.44269504088896341f, x, 0.5f));
+  float r = fmaf(z, -0.693359375f, x);
+  r = fmaf(z, 2.12194440e-4f, r);
+  float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+  p = fmaf(p, r, 8.3334519073e-3f);
+  p = fmaf(p, r, 4.1665795894e-2f);
+  p = fmaf(p, r, 1.6666665459e-1f);
+  p = fmaf(p, r, 5.0000001201e-1f);
+  float y = fmaf(p, r * r, r) + 1.0f;
+  return scale2(y, (int)z);
+}
 HKD float log2_(float x) {
   if (x != x) return x;
   if (x < 0.0f) return __builtin_nanf("");

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d,
 }
 
 // FFMASK bit ch = FIREFLY_FILTERING for channel ch (post_process.rs:773-783,1193-1197)
+// is_nan(c) || c > F32_MAX for some component c - "not (c <= F32_MAX)": one compare per component
+__device__ __forceinline__ bool nan_or_above_max(f3 v) { return !(v.x <= HK_F32_MAX) || !(v.y <= HK_F32_MAX) || !(v.z <= HK_F32_MAX); }
+
 template <int LEVEL, int NCH, int FFMASK>
 __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:164-319
 #if defined(HK_DENOISE_TILES_RR)
@@ -105,10 +108,19 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
   if (!px.valid) return;
   constexpr int STEP = 8 >> LEVEL;
   const int x = px.x, y = px.y, index = x + fr.rw * y;
-  const f2 uv = coords_to_uv(fr, x, y);
-  const f2 deferred_uv = jittered_deferred_uv(fr, uv, 0.5f);
-  int dx, dy;
-  nearest_coords(deferred_uv, fr.dw, fr.dh, &dx, &dy);
+  // The stencil's three columns and three rows: the uv of a tap, whether it lies in the image and the G-buffer texel under it are
+  // separable in x and y, so the chain coords -> uv -> jittered uv -> nearest texel is evaluated once per column and once per row
+  // (on the diagonal (x + a, y + a): column a's x and row a's y in one call) instead of once per tap; the same expressions.
+  int col_texel[3], row_texel[3];
+  bool col_inside[3], row_inside[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const f2 tap_uv = coords_to_uv(fr, x + (a - 1) * STEP, y + (a - 1) * STEP);
+    col_inside[a] = !(tap_uv.x < 0.0f || tap_uv.x > 1.0f);
+    row_inside[a] = !(tap_uv.y < 0.0f || tap_uv.y > 1.0f);
+    nearest_coords(jittered_deferred_uv(fr, tap_uv, 0.5f), fr.dw, fr.dh, &col_texel[a], &row_texel[a]);
+  }
+  const int dx = col_texel[1], dy = row_texel[1];
   const int didx = dx + fr.dw * dy;
   const float4 gc = d.dn_g[didx];
   const float depth = d.depth[didx];
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     f3 irradiance = xyz(unpack_f16x4(d.input[ch][index]));
     sum_irradiance[ch] = irradiance * fr.kernel[4];
     sum_w[ch] = fr.kernel[4];
-    if (any_is_nan(irradiance) || irradiance.x > HK_F32_MAX || irradiance.y > HK_F32_MAX || irradiance.z > HK_F32_MAX) {
+    if (nan_or_above_max(irradiance)) {  // any_is_nan(irradiance) || any(irradiance > F32_MAX), denoise.wgsl:201-205
       irradiance = F3(0, 0, 0);
       sum_irradiance[ch] = F3(0, 0, 0);
       sum_w[ch] = 0.0f;
@@ -155,29 +167,26 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     constexpr int OY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
     const int ox = OX[k], oy = OY[k];
     const int sx = x + ox * STEP, sy = y + oy * STEP;
-    const f2 sample_uv = coords_to_uv(fr, sx, sy);
-    if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) continue;
-    const f2 sample_deferred_uv = jittered_deferred_uv(fr, sample_uv, 0.5f);
-    int gx, gy;
-    nearest_coords(sample_deferred_uv, fr.dw, fr.dh, &gx, &gy);
+    if (!(col_inside[ox + 1] && row_inside[oy + 1])) continue;  // sample_uv outside [0, 1]^2 (denoise.wgsl:232-234)
+    const int gx = col_texel[ox + 1], gy = row_texel[oy + 1];
     const float4 gs = d.dn_g[gx + fr.dw * gy];
     const float sample_depth = d.depth[gx + fr.dw * gy];
     const f3 sample_normal = F3(gs.x, gs.y, gs.z);
     // channel-independent part of the weight, evaluated once
     const float w_normal = pow16_(fmax_(0.0f, dot(normal, sample_normal)));
-    const float w_depth = exp_((-fabsf(depth - sample_depth)) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
+    const float w_depth = exp_nonpositive_((-fabsf(depth - sample_depth)) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
     const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - gs.w));
     const float w_geometry = w_normal * w_depth * w_instance;
     const float kernel_w = fr.kernel[(oy + 1) * 3 + (ox + 1)];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const f3 irr = xyz(unpack_f16x4(d.input[ch][sx + fr.rw * sy]));
-      if (any_is_nan(irr) || irr.x > HK_F32_MAX || irr.y > HK_F32_MAX || irr.z > HK_F32_MAX) continue;
+      if (nan_or_above_max(irr)) continue;  // any_is_nan(irr) || any(irr > F32_MAX)
       const float sample_luminance = luminance(irr);
 #ifdef HK_DN_F32_DIV
-      const float w_luminance = exp_((-fabsf(lum[ch] - sample_luminance)) / lum_denominator[ch]);
+      const float w_luminance = exp_nonpositive_((-fabsf(lum[ch] - sample_luminance)) / lum_denominator[ch]);
 #else
-      const float w_luminance = exp_(quotient_by_reciprocal(-fabsf(lum[ch] - sample_luminance), inv_lum_denominator[ch]));
+      const float w_luminance = exp_nonpositive_(quotient_by_reciprocal(-fabsf(lum[ch] - sample_luminance), inv_lum_denominator[ch]));
 #endif
       const float w = clamp_(w_geometry * w_luminance, 0.0f, 1.0f) * kernel_w;
       sum_irradiance[ch] = sum_irradiance[ch] + irr * w;
@@ -190,11 +199,7 @@ __global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, in
     }
   }
   f4 albedo = F4(0, 0, 0, 0), tone_sum = F4(0, 0, 0, 0);
-  if (LEVEL == 3) {
-    int ax, ay;
-    nearest_coords(deferred_uv, fr.dw, fr.dh, &ax, &ay);
-    albedo = unpack_f16x4(d.albedo[ax + fr.dw * ay]);
-  }
+  if (LEVEL == 3) albedo = unpack_f16x4(d.albedo[didx]);  // nearest texel under jittered_deferred_uv(uv, 0.5): the centre's
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const f3 qd = sum_irradiance[ch] / sum_w[ch];
