@@ -1,0 +1,69 @@
+"""Register budgets of the gfx950 kernels, read from the code objects inside the built library (tools/kernel_resources.py: no GPU,
+no recompile).  A kernel that silently crosses an occupancy step or starts spilling costs tens of per cent (round 2 measured
+k_spatial_reuse at five waves per SIMD: 73 spilled VGPRs, 0.32 -> 0.50 ms), and nothing else on a CPU box would notice."""
+import os
+import re
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_resources import resources  # noqa: E402
+
+LIB = os.path.join(ROOT, "bevy-hikari_amd", "libhikari_hip.so")
+
+# kernel (regex on the demangled name) -> most VGPRs it may use (512 / waves per SIMD, in the allocation granule of 8)
+BUDGETS = {
+    r"k_indirect<true, false, true>": 128,     # the dominant ray kernel, LDS scene: 4 waves per SIMD
+    r"k_spatial_reuse<false>": 128,
+    r"k_spatial_reuse<true>": 128,
+    r"k_prepass<false, true>": 128,
+    r"k_wf_trace<(true|false)>": 72,           # HK_WF_TRACE_WAVES = 7
+    r"k_wf_shade<(true|false)>": 128,
+    r"k_wf_setup": 64,
+    r"k_denoise<\d, 3, 6>": 72,                # 7 waves per SIMD
+    r"k_demodulation<3>": 64,
+    r"k_refit_flat_bvh<(true|false)>": 32,
+    r"k_refit_instances": 128,
+}
+# kernels that are allowed scratch (bytes per lane): verification / counting variants and one tail kernel, none of them on the
+# default path of an LDS-resident scene
+SCRATCH_ALLOWED = {
+    r"k_indirect<true, false, false>": 32,     # fused schedule on a scene in global memory (the default there is the wavefront)
+    r"k_indirect<true, true, false>": 64,      # ray-counting replay
+    r"k_wf_final": 16,
+}
+
+
+@pytest.fixture(scope="module")
+def table():
+    t = resources(LIB)
+    assert len(t) > 60, "the library's code objects were not found"
+    return t
+
+
+def test_hot_kernels_stay_inside_their_occupancy_budget(table):
+    for pattern, budget in BUDGETS.items():
+        hits = {n: r for n, r in table.items() if re.search(pattern, n)}
+        assert hits, f"no kernel matches {pattern}"
+        for name, r in hits.items():
+            assert r["vgpr_count"] <= budget, f"{name}: {r['vgpr_count']} VGPRs > {budget}"
+            assert r["vgpr_spill_count"] == 0, f"{name}: spills {r['vgpr_spill_count']} VGPRs"
+
+
+def test_no_unexpected_scratch(table):
+    for name, r in table.items():
+        if "rocprim::" in name:  # the library's radix sort (LBVH rebuild) is not ours to budget
+            continue
+        allowed = max([b for p, b in SCRATCH_ALLOWED.items() if re.search(p, name)], default=0)
+        assert r["private_segment_fixed_size"] <= allowed, f"{name}: {r['private_segment_fixed_size']} B of scratch per lane (allowed {allowed})"
+
+
+def test_lds_leaves_room_for_the_scene_copy(table):
+    """The ray kernels copy scenes of up to 32 KB into dynamic LDS on top of their static LDS; with four workgroups per CU that
+    has to fit the CU's 160 KB."""
+    for name, r in table.items():
+        if re.search(r"k_(direct_lit|indirect|prepass|wf_trace|wf_shade)", name):
+            assert 4 * (r["group_segment_fixed_size"] + 32768) <= 160 * 1024 + 4 * 16640, name  # (k_direct_lit: its 16.6 KB store tile)
