@@ -17,6 +17,21 @@
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 
+// Pixel -> wave mapping of the post-process kernels.  Default: 8 x 8 tiles in XCD bands (pixel_of_thread<true>).  The row-shaped
+// mapping that took demodulation from 0.071 to 0.040 ms (pixel_of_thread_rows) has NOT been measured on these kernels yet: build
+// with -DHK_AA_ROWS_W=64 (or 32) [-DHK_AA_ROWS_XCD=0] to try it (tools/build_variant.sh); results cannot change, only who computes
+// which pixel.
+#ifdef HK_AA_ROWS_W
+#ifndef HK_AA_ROWS_XCD
+#define HK_AA_ROWS_XCD 1
+#endif
+#define HK_AA_PIXEL(width, row_begin, row_end) pixel_of_thread_rows<HK_AA_ROWS_W, HK_AA_ROWS_XCD != 0>(width, row_begin, row_end)
+#define HK_AA_GRID(width, rows) grid_for_rows(HK_AA_ROWS_W, width, rows)
+#else
+#define HK_AA_PIXEL(width, row_begin, row_end) pixel_of_thread(width, row_begin, row_end)
+#define HK_AA_GRID(width, rows) grid_for(width, rows)
+#endif
+
 namespace hkd {
 
 struct Plane16 {  // rgba16f
@@ -146,7 +161,7 @@ struct AaTargets {
 };
 
 __global__ __launch_bounds__(256) void k_taa_jasmine(AaTargets t, float blend, float4 clear_color, int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread(t.ow, row_begin, row_end);
+  const Pixel px = HK_AA_PIXEL(t.ow, row_begin, row_end);
   if (!px.valid) return;
   const int x = px.x, y = px.y;
   const f2 size = F2((float)t.ow, (float)t.oh);
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(256) void k_taa_jasmine(AaTargets t, float blend, f
 }
 
 __global__ __launch_bounds__(256) void k_smaa_tu4x(AaTargets t, uint32_t frame_number, int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread(t.render.w, row_begin, row_end);
+  const Pixel px = HK_AA_PIXEL(t.render.w, row_begin, row_end);
   if (!px.valid) return;
   const int x = px.x, y = px.y;
   const f2 input_size = F2((float)t.render.w, (float)t.render.h), output_size = F2((float)t.ow, (float)t.oh);
@@ -314,7 +329,7 @@ HKD f4 differential_blend(f4 t, f4 b, f4 l, f4 r, f3 factor) {  // smaa.wgsl:224
 }
 // Reads only the diagonal pixels k_smaa_tu4x wrote, writes only the off-diagonal ones: in place, no hazard.
 __global__ __launch_bounds__(256) void k_smaa_tu4x_extrapolate(uint2* output, int ow, int oh, int render_w, int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread(render_w, row_begin, row_end);
+  const Pixel px = HK_AA_PIXEL(render_w, row_begin, row_end);
   if (!px.valid) return;
   const int bx = 2 * px.x, by = 2 * px.y;
   f4 t_color, b_color, n_color, e_color, s_color, w_color;
@@ -404,7 +419,7 @@ struct FsrEasuArgs {
   f2 half_texel;
 };
 __global__ __launch_bounds__(256) void k_fsr_easu(FsrEasuArgs a, int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread(a.ow, row_begin, row_end);
+  const Pixel px = HK_AA_PIXEL(a.ow, row_begin, row_end);
   if (!px.valid) return;
   f2 pp = F2((float)px.x * a.con0[0] + a.con0[2], (float)px.y * a.con0[1] + a.con0[3]);
   const f2 fp = F2(floorf(pp.x), floorf(pp.y));
@@ -462,7 +477,7 @@ __global__ __launch_bounds__(256) void k_fsr_easu(FsrEasuArgs a, int row_begin, 
 }
 __global__ __launch_bounds__(256) void k_fsr_rcas(const uint2* __restrict__ input, uint2* __restrict__ output, int w, int h, float sharpness,
                                                   int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread(w, row_begin, row_end);
+  const Pixel px = HK_AA_PIXEL(w, row_begin, row_end);
   if (!px.valid) return;
   const float sharp = exp2_(-sharpness);  // FsrRcasCon, ffx_fsr1.h:662-673
   f4 b, d, e, f, hh;
@@ -512,15 +527,15 @@ static AaTargets make_targets(const AaBuffers& b) {
 
 void launch_smaa_tu4x(hipStream_t st, const AaBuffers& b, uint32_t frame_number, int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_smaa_tu4x, grid_for(b.render_w, y1 - y0), dim3(256), 0, st, make_targets(b), frame_number, y0, y1);
+  hipLaunchKernelGGL(k_smaa_tu4x, HK_AA_GRID(b.render_w, y1 - y0), dim3(256), 0, st, make_targets(b), frame_number, y0, y1);
 }
 void launch_smaa_tu4x_extrapolate(hipStream_t st, void* output, int out_w, int out_h, int render_w, int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_smaa_tu4x_extrapolate, grid_for(render_w, y1 - y0), dim3(256), 0, st, (uint2*)output, out_w, out_h, render_w, y0, y1);
+  hipLaunchKernelGGL(k_smaa_tu4x_extrapolate, HK_AA_GRID(render_w, y1 - y0), dim3(256), 0, st, (uint2*)output, out_w, out_h, render_w, y0, y1);
 }
 void launch_taa_jasmine(hipStream_t st, const AaBuffers& b, float blend, const float clear_color[4], int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_taa_jasmine, grid_for(b.out_w, y1 - y0), dim3(256), 0, st, make_targets(b), blend,
+  hipLaunchKernelGGL(k_taa_jasmine, HK_AA_GRID(b.out_w, y1 - y0), dim3(256), 0, st, make_targets(b), blend,
                      make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]), y0, y1);
 }
 
@@ -548,11 +563,11 @@ void launch_fsr_easu(hipStream_t st, const void* input, int in_w, int in_h, void
   a.con3[0] = 0.0f * (1.0f / isx);
   a.con3[1] = 4.0f * (1.0f / isy);
   a.half_texel = f2{(1.0f / (float)in_w) / 2.0f, (1.0f / (float)in_h) / 2.0f};
-  hipLaunchKernelGGL(k_fsr_easu, grid_for(out_w, y1 - y0), dim3(256), 0, st, a, y0, y1);
+  hipLaunchKernelGGL(k_fsr_easu, HK_AA_GRID(out_w, y1 - y0), dim3(256), 0, st, a, y0, y1);
 }
 void launch_fsr_rcas(hipStream_t st, const void* input, void* output, int w, int h, float sharpness, int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_fsr_rcas, grid_for(w, y1 - y0), dim3(256), 0, st, (const uint2*)input, (uint2*)output, w, h, sharpness, y0, y1);
+  hipLaunchKernelGGL(k_fsr_rcas, HK_AA_GRID(w, y1 - y0), dim3(256), 0, st, (const uint2*)input, (uint2*)output, w, h, sharpness, y0, y1);
 }
 
 }  // namespace hk
