@@ -17,19 +17,20 @@
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 
-// Pixel -> wave mapping of the post-process kernels.  Default: 8 x 8 tiles in XCD bands (pixel_of_thread<true>).  The row-shaped
-// mapping that took demodulation from 0.071 to 0.040 ms (pixel_of_thread_rows) has NOT been measured on these kernels yet: build
-// with -DHK_AA_ROWS_W=64 (or 32) [-DHK_AA_ROWS_XCD=0] to try it (tools/build_variant.sh); results cannot change, only who computes
-// which pixel.
-#ifdef HK_AA_ROWS_W
-#ifndef HK_AA_ROWS_XCD
-#define HK_AA_ROWS_XCD 1
+// Pixel -> wave mapping of the post-process kernels (hk_kernels.hpp pixel_of_thread_rows; results cannot depend on it, only who
+// computes which pixel).  Measured on Cornell 1080p traced -> 3840x2160 SMAA Tu4x + TAA (tools/config_probe.py aa), 8 x 8 tiles
+// in XCD bands -> 64 x 1 rows in bands -> 64 x 1 rows round-robin:  k_smaa_tu4x 0.079 -> 0.063 -> 0.061 ms,
+// k_taa_jasmine 0.206 -> 0.201 -> 0.180 ms, k_smaa_tu4x_extrapolate 0.031 -> 0.030 -> 0.033 ms.  The two FSR kernels have not
+// been measured and keep the tiles unless built with -DHK_FSR_ROWS_W=64 [-DHK_FSR_ROWS_XCD=0].
+#ifdef HK_FSR_ROWS_W
+#ifndef HK_FSR_ROWS_XCD
+#define HK_FSR_ROWS_XCD 1
 #endif
-#define HK_AA_PIXEL(width, row_begin, row_end) pixel_of_thread_rows<HK_AA_ROWS_W, HK_AA_ROWS_XCD != 0>(width, row_begin, row_end)
-#define HK_AA_GRID(width, rows) grid_for_rows(HK_AA_ROWS_W, width, rows)
+#define HK_FSR_PIXEL(width, row_begin, row_end) pixel_of_thread_rows<HK_FSR_ROWS_W, HK_FSR_ROWS_XCD != 0>(width, row_begin, row_end)
+#define HK_FSR_GRID(width, rows) grid_for_rows(HK_FSR_ROWS_W, width, rows)
 #else
-#define HK_AA_PIXEL(width, row_begin, row_end) pixel_of_thread(width, row_begin, row_end)
-#define HK_AA_GRID(width, rows) grid_for(width, rows)
+#define HK_FSR_PIXEL(width, row_begin, row_end) pixel_of_thread(width, row_begin, row_end)
+#define HK_FSR_GRID(width, rows) grid_for(width, rows)
 #endif
 
 namespace hkd {
@@ -161,7 +162,7 @@ struct AaTargets {
 };
 
 __global__ __launch_bounds__(256) void k_taa_jasmine(AaTargets t, float blend, float4 clear_color, int row_begin, int row_end) {
-  const Pixel px = HK_AA_PIXEL(t.ow, row_begin, row_end);
+  const Pixel px = pixel_of_thread_rows<64, false>(t.ow, row_begin, row_end);
   if (!px.valid) return;
   const int x = px.x, y = px.y;
   const f2 size = F2((float)t.ow, (float)t.oh);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void k_taa_jasmine(AaTargets t, float blend, f
 }
 
 __global__ __launch_bounds__(256) void k_smaa_tu4x(AaTargets t, uint32_t frame_number, int row_begin, int row_end) {
-  const Pixel px = HK_AA_PIXEL(t.render.w, row_begin, row_end);
+  const Pixel px = pixel_of_thread_rows<64, false>(t.render.w, row_begin, row_end);
   if (!px.valid) return;
   const int x = px.x, y = px.y;
   const f2 input_size = F2((float)t.render.w, (float)t.render.h), output_size = F2((float)t.ow, (float)t.oh);
@@ -329,7 +330,7 @@ HKD f4 differential_blend(f4 t, f4 b, f4 l, f4 r, f3 factor) {  // smaa.wgsl:224
 }
 // Reads only the diagonal pixels k_smaa_tu4x wrote, writes only the off-diagonal ones: in place, no hazard.
 __global__ __launch_bounds__(256) void k_smaa_tu4x_extrapolate(uint2* output, int ow, int oh, int render_w, int row_begin, int row_end) {
-  const Pixel px = HK_AA_PIXEL(render_w, row_begin, row_end);
+  const Pixel px = pixel_of_thread_rows<64, true>(render_w, row_begin, row_end);
   if (!px.valid) return;
   const int bx = 2 * px.x, by = 2 * px.y;
   f4 t_color, b_color, n_color, e_color, s_color, w_color;
@@ -419,7 +420,7 @@ struct FsrEasuArgs {
   f2 half_texel;
 };
 __global__ __launch_bounds__(256) void k_fsr_easu(FsrEasuArgs a, int row_begin, int row_end) {
-  const Pixel px = HK_AA_PIXEL(a.ow, row_begin, row_end);
+  const Pixel px = HK_FSR_PIXEL(a.ow, row_begin, row_end);
   if (!px.valid) return;
   f2 pp = F2((float)px.x * a.con0[0] + a.con0[2], (float)px.y * a.con0[1] + a.con0[3]);
   const f2 fp = F2(floorf(pp.x), floorf(pp.y));
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void k_fsr_easu(FsrEasuArgs a, int row_begin, 
 }
 __global__ __launch_bounds__(256) void k_fsr_rcas(const uint2* __restrict__ input, uint2* __restrict__ output, int w, int h, float sharpness,
                                                   int row_begin, int row_end) {
-  const Pixel px = HK_AA_PIXEL(w, row_begin, row_end);
+  const Pixel px = HK_FSR_PIXEL(w, row_begin, row_end);
   if (!px.valid) return;
   const float sharp = exp2_(-sharpness);  // FsrRcasCon, ffx_fsr1.h:662-673
   f4 b, d, e, f, hh;
@@ -527,15 +528,15 @@ static AaTargets make_targets(const AaBuffers& b) {
 
 void launch_smaa_tu4x(hipStream_t st, const AaBuffers& b, uint32_t frame_number, int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_smaa_tu4x, HK_AA_GRID(b.render_w, y1 - y0), dim3(256), 0, st, make_targets(b), frame_number, y0, y1);
+  hipLaunchKernelGGL(k_smaa_tu4x, grid_for_rows(64, b.render_w, y1 - y0), dim3(256), 0, st, make_targets(b), frame_number, y0, y1);
 }
 void launch_smaa_tu4x_extrapolate(hipStream_t st, void* output, int out_w, int out_h, int render_w, int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_smaa_tu4x_extrapolate, HK_AA_GRID(render_w, y1 - y0), dim3(256), 0, st, (uint2*)output, out_w, out_h, render_w, y0, y1);
+  hipLaunchKernelGGL(k_smaa_tu4x_extrapolate, grid_for_rows(64, render_w, y1 - y0), dim3(256), 0, st, (uint2*)output, out_w, out_h, render_w, y0, y1);
 }
 void launch_taa_jasmine(hipStream_t st, const AaBuffers& b, float blend, const float clear_color[4], int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_taa_jasmine, HK_AA_GRID(b.out_w, y1 - y0), dim3(256), 0, st, make_targets(b), blend,
+  hipLaunchKernelGGL(k_taa_jasmine, grid_for_rows(64, b.out_w, y1 - y0), dim3(256), 0, st, make_targets(b), blend,
                      make_float4(clear_color[0], clear_color[1], clear_color[2], clear_color[3]), y0, y1);
 }
 
@@ -563,11 +564,11 @@ void launch_fsr_easu(hipStream_t st, const void* input, int in_w, int in_h, void
   a.con3[0] = 0.0f * (1.0f / isx);
   a.con3[1] = 4.0f * (1.0f / isy);
   a.half_texel = f2{(1.0f / (float)in_w) / 2.0f, (1.0f / (float)in_h) / 2.0f};
-  hipLaunchKernelGGL(k_fsr_easu, HK_AA_GRID(out_w, y1 - y0), dim3(256), 0, st, a, y0, y1);
+  hipLaunchKernelGGL(k_fsr_easu, HK_FSR_GRID(out_w, y1 - y0), dim3(256), 0, st, a, y0, y1);
 }
 void launch_fsr_rcas(hipStream_t st, const void* input, void* output, int w, int h, float sharpness, int y0, int y1) {
   if (y1 <= y0) return;
-  hipLaunchKernelGGL(k_fsr_rcas, HK_AA_GRID(w, y1 - y0), dim3(256), 0, st, (const uint2*)input, (uint2*)output, w, h, sharpness, y0, y1);
+  hipLaunchKernelGGL(k_fsr_rcas, HK_FSR_GRID(w, y1 - y0), dim3(256), 0, st, (const uint2*)input, (uint2*)output, w, h, sharpness, y0, y1);
 }
 
 }  // namespace hk
