@@ -644,6 +644,15 @@ int sync_all(hk_ctx* c) {
   return HK_OK;
 }
 
+// DScene::shared_xform: every instance has the same inverse model (bit for bit), so a traversal transforms its ray once instead of
+// once per instance entry (hk_device.hpp traverse_top).  Derived from the host mirrors: whoever changes an instance's pose - an
+// upload or a device refit - has to call this before the next frame is enqueued.
+void update_shared_transform(hk_ctx* c) {
+  c->scene.shared_xform = 1u;
+  for (const HkInstance& in : c->instances)
+    if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) c->scene.shared_xform = 0u;
+}
+
 // point c->scene at the arrays of the slot in use
 void point_scene_at_slot(hk_ctx* c) {
   const size_t slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
@@ -671,9 +680,7 @@ void point_scene_at_slot(hk_ctx* c) {
   s.tlas_stride = c->threaded ? (uint32_t)c->instance_nodes.size() : 0u;
   s.blas_stride = c->threaded ? (uint32_t)c->asset_nodes.size() : 0u;
   s.light_count = (uint32_t)c->emissive_nodes.size();
-  s.shared_xform = 1u;
-  for (const HkInstance& in : c->instances)
-    if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) s.shared_xform = 0u;
+  update_shared_transform(c);
 }
 
 int finalize_scene(hk_ctx* c) {
@@ -1362,20 +1369,20 @@ int prepare_refit(hk_ctx* c) {
   if (ni > c->rf_instances || na > c->rf_alias) {
     int rc = sync_all(c);
     if (rc) return rc;
-    const bool keep_updates = true;
-    (void)keep_updates;
     for (void* q : {(void*)c->rf_inst_lo, (void*)c->rf_inst_hi, (void*)c->rf_prev_models, (void*)c->rf_emissive_of_instance, (void*)c->rf_alias_scratch})
       if (q) (void)hipFree(q);
     c->rf_inst_lo = c->rf_inst_hi = c->rf_prev_models = nullptr;
     c->rf_emissive_of_instance = nullptr;
     c->rf_alias_scratch = nullptr;
-    c->rf_instances = ni + ni / 4;
-    c->rf_alias = na + na / 4 + 4;
-    HK_HIP(hipMalloc((void**)&c->rf_inst_lo, c->rf_instances * 16));
-    HK_HIP(hipMalloc((void**)&c->rf_inst_hi, c->rf_instances * 16));
-    HK_HIP(hipMalloc((void**)&c->rf_prev_models, c->rf_instances * 64));
-    HK_HIP(hipMalloc((void**)&c->rf_emissive_of_instance, c->rf_instances * 4));
-    HK_HIP(hipMalloc((void**)&c->rf_alias_scratch, c->rf_alias * 5 * 4));
+    c->rf_instances = c->rf_alias = 0;  // (stays 0 if an allocation below fails: the next call starts over)
+    const size_t cap_i = ni + ni / 4, cap_a = na + na / 4 + 4;
+    HK_HIP(hipMalloc((void**)&c->rf_inst_lo, cap_i * 16));
+    HK_HIP(hipMalloc((void**)&c->rf_inst_hi, cap_i * 16));
+    HK_HIP(hipMalloc((void**)&c->rf_prev_models, cap_i * 64));
+    HK_HIP(hipMalloc((void**)&c->rf_emissive_of_instance, cap_i * 4));
+    HK_HIP(hipMalloc((void**)&c->rf_alias_scratch, cap_a * 5 * 4));
+    c->rf_instances = cap_i;
+    c->rf_alias = cap_a;
   }
   std::vector<uint32_t> eoi(ni, 0xFFFFFFFFu);
   for (size_t e = 0; e < c->emissives.size(); ++e) eoi[c->emissives[e].instance] = (uint32_t)e;
@@ -1434,8 +1441,9 @@ int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
     if ((rc = sync_all(c))) return rc;
     if (c->lbvh_scratch) (void)hipFree(c->lbvh_scratch);
     c->lbvh_scratch = nullptr;
+    c->lbvh_scratch_cap = 0;
+    HK_HIP(hipMalloc(&c->lbvh_scratch, need + need / 4));
     c->lbvh_scratch_cap = need + need / 4;
-    HK_HIP(hipMalloc(&c->lbvh_scratch, c->lbvh_scratch_cap));
   }
   if ((rc = begin_device_update(c))) return rc;
   const hkd::RefitScene r = refit_scene(c);
@@ -1539,20 +1547,6 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
     if (commit) builder_commit_transforms(b);
     return HK_OK;
   }
-  // host mirrors of the moved instances
-  for (const hkd::RefitUpdate& u : records) {
-    if (!u.moved) continue;
-    HkInstance& in = c->instances[u.instance];
-    if (c->prev_models.size() != 16 * (size_t)ni) {
-      c->prev_models.resize(16 * (size_t)ni);
-      for (uint32_t j = 0; j < ni; ++j) memcpy(&c->prev_models[16 * (size_t)j], c->instances[j].model, 64);
-    }
-    memcpy(&c->prev_models[16 * (size_t)u.instance], in.model, 64);
-    memcpy(in.model, u.model, 64);
-    (void)instance_world_record(u.model, u.aabb_center, u.aabb_half, in.min, in.max, in.inverse_transpose_model);
-  }
-  for (const hkd::RefitUpdate& u : records)
-    if (!u.moved && c->prev_models.size() == 16 * (size_t)ni) memcpy(&c->prev_models[16 * (size_t)u.instance], c->instances[u.instance].model, 64);
   // pinned update records, double-buffered against the kernel that reads them
   const int k = c->rf_k;
   c->rf_k ^= 1;
@@ -1563,8 +1557,10 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
   if (c->rf_updates_cap[k] < records.size()) {
     if (c->rf_updates[k]) (void)hipHostFree(c->rf_updates[k]);
     c->rf_updates[k] = nullptr;
-    c->rf_updates_cap[k] = records.size() + records.size() / 2 + 16;
-    HK_HIP(hipHostMalloc((void**)&c->rf_updates[k], c->rf_updates_cap[k] * sizeof(hkd::RefitUpdate), hipHostMallocDefault));
+    c->rf_updates_cap[k] = 0;
+    const size_t cap = records.size() + records.size() / 2 + 16;
+    HK_HIP(hipHostMalloc((void**)&c->rf_updates[k], cap * sizeof(hkd::RefitUpdate), hipHostMallocDefault));
+    c->rf_updates_cap[k] = cap;
   }
   if (!c->rf_done[k]) HK_HIP(hipEventCreateWithFlags(&c->rf_done[k], hipEventDisableTiming));
   memcpy(c->rf_updates[k], records.data(), records.size() * sizeof(hkd::RefitUpdate));
@@ -1578,6 +1574,21 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
   HK_HIP(hipGetLastError());
   HK_HIP(hipEventRecord(c->rf_done[k], c->stream));
   c->rf_pending[k] = true;
+  // the update is enqueued: now the host mirrors of the moved instances follow (an error above leaves host and device agreeing)
+  for (const hkd::RefitUpdate& u : records) {
+    if (!u.moved) continue;
+    HkInstance& in = c->instances[u.instance];
+    if (c->prev_models.size() != 16 * (size_t)ni) {
+      c->prev_models.resize(16 * (size_t)ni);
+      for (uint32_t j = 0; j < ni; ++j) memcpy(&c->prev_models[16 * (size_t)j], c->instances[j].model, 64);
+    }
+    memcpy(&c->prev_models[16 * (size_t)u.instance], in.model, 64);
+    memcpy(in.model, u.model, 64);
+    (void)instance_world_record(u.model, u.aabb_center, u.aabb_half, in.min, in.max, in.inverse_transpose_model);
+  }
+  for (const hkd::RefitUpdate& u : records)
+    if (!u.moved && c->prev_models.size() == 16 * (size_t)ni) memcpy(&c->prev_models[16 * (size_t)u.instance], c->instances[u.instance].model, 64);
+  update_shared_transform(c);  // (a scene in one slot is refit in place: nothing else looks at the new poses before the next frame)
   c->d_prev_models = c->rf_prev_models;
   c->rf_last_moved = moved;
   c->mirrors_stale = true;

@@ -76,13 +76,16 @@ def same_links(a, b):
     return len(a) == len(b) and all(x.entry_index == y.entry_index and x.exit_index == y.exit_index for x, y in zip(a, b))
 
 
-def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCATTER, frames=5, settings=None, rebuild_on=(), rebuild_mode=F.TREE_LBVH):
+def run_refit_sequence(kw, size, movers_of_frame, flags=F.CTX_DETERMINISTIC_SCATTER, frames=5, settings=None, rebuild_on=(), rebuild_mode=F.TREE_LBVH,
+                       camera=None):
     """GPU: one upload, then hk_refit_scene_instances per frame.  Oracle: the expected arrays per frame (see the module docstring).
-    Moving objects make the reference's scatter-store race observable: it is resolved the oracle's way here."""
-    dev_scene, sun = synthetic_scene(**kw)     # its builder feeds the device refit
-    ref_scene, _ = synthetic_scene(**kw)       # a twin builder produces the host records for the same poses
+    Moving objects make the reference's scatter-store race observable: it is resolved the oracle's way here.
+    kw: keyword arguments of synthetic_scene, or a callable that makes (scene with its builder, sun or None)."""
+    make = kw if callable(kw) else (lambda: synthetic_scene(**kw))
+    dev_scene, sun = make()     # its builder feeds the device refit
+    ref_scene, _ = make()       # a twin builder produces the host records for the same poses
     s = settings or hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
-    cam, lights = synthetic_camera(*size), hk.lights_uniform(directional=sun)
+    cam, lights = camera or synthetic_camera(*size), (hk.lights_uniform(directional=sun) if sun else hk.lights_uniform())
     gpu, cpu = hk.HikariPlugin(device=0, flags=flags), oracle()
     gpu.set_scene(dev_scene)
     cpu.set_scene(ref_scene)
@@ -142,6 +145,17 @@ def test_refit_large_scene_vs_oracle():
     n = 1 + 20 + 5 + 3
     movers = [2, 7, 11, 22, n - 1, n - 3]  # boxes, a sphere, two of the three emitters
     run_refit_sequence(LARGE, (120, 72), lambda f: movers if f % 2 == 0 else movers[:3] + [14])  # some rest every other frame: their `moved` flag goes
+
+
+def test_refit_of_a_scene_whose_instances_shared_one_transform():
+    """The Cornell box: all eight instances carry the same model matrix at upload, so a traversal transforms its ray once
+    (DScene::shared_xform) - and the scene sits in ONE slot and is refit in place.  Moving one instance on the device has to
+    switch the shortcut off for the frames that follow (it did not, until the end of round 2: found by reading, not by a test)."""
+    scenes = lambda: (hk.load_cornell(), None)
+    first = scenes()[0]
+    models = {bytes(np.ctypeslib.as_array(i.model).tobytes()) for i in first.instances}
+    assert len(models) == 1, "the premise of this test: one shared transform"
+    run_refit_sequence(scenes, (96, 64), lambda f: [len(first.instances) - 2] if f < 4 else [1, len(first.instances) - 2], camera=hk.cornell_camera(96, 64), frames=5)
 
 
 def test_refit_with_three_bounces_and_aa_tail():
