@@ -458,10 +458,13 @@ typedef struct HkImageDesc {
  * per-emitter work with the host builder's exact arithmetic, two more REFIT the instance tree (in all of its direction-threaded
  * orderings) and the light tree: same topology, every inner box the union of the leaf boxes below it.  Stream-ordered, no host or
  * device wait; frames in flight keep the slot they were enqueued with.  What it does NOT do is change the shape of the trees: after
- * large displacements a host calls hk_upload_scene_instances now and then to get the reference's SAH tree back (any-hit identity
- * and tie-breaks follow the tree, so a refit frame equals the reference frame for THAT tree, not for the rebuilt one).
+ * large displacements a host calls hk_rebuild_scene_trees (below) now and then to get the reference's SAH tree back (any-hit
+ * identity and tie-breaks follow the tree, so a refit frame equals the reference frame for THAT tree, not for the rebuilt one).
  * Instances must be the ones uploaded (same count, meshes, materials); *moved (optional) = how many poses changed.  The builder's
- * previous-transform bookkeeping advances as it would in hk_scene_builder_finish. */
+ * previous-transform bookkeeping advances as it would in hk_scene_builder_finish.
+ * After a device-side update the host copies of the trees and emitter records are stale: an upload that re-lays the instance-level
+ * region out from them (hk_upload_materials, hk_upload_textures) is refused with HK_E_NOT_READY at the next frame until
+ * hk_upload_scene_instances / hk_upload_instances brings the host's version of the scene back. */
 int hk_refit_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t* moved);
 /* ... and the REBUILD on the device, for when refits have degraded a tree: new trees over the instances' and the emitters' current
  * boxes, written in place in the flatten_custom layout (all direction-threaded orderings of the instance tree; child order of
