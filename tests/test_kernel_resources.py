@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from kernel_resources import resources  # noqa: E402
+from kernel_resources import instruction_counts, resources  # noqa: E402
 
 LIB = os.path.join(ROOT, "bevy-hikari_amd", "libhikari_hip.so")
 
@@ -67,3 +67,26 @@ def test_lds_leaves_room_for_the_scene_copy(table):
     for name, r in table.items():
         if re.search(r"k_(direct_lit|indirect|prepass|wf_trace|wf_shade)", name):
             assert 4 * (r["group_segment_fixed_size"] + 32768) <= 160 * 1024 + 4 * 16640, name  # (k_direct_lit: its 16.6 KB store tile)
+
+
+# static VALU instruction counts of the kernels that are bound by VALU issue, as built at the end of round 2, + 4 % head room: the
+# counts move with every edit of the shared device headers, and on these kernels a few per cent of instructions are a few per
+# cent of time (k_denoise<0,3,6>: 2 937 -> 2 155 instructions was 0.072 -> 0.060 ms).  Raise a budget knowingly, with a measurement.
+VALU_BUDGETS = {
+    r"k_denoise<0, 3, 6>": 2155,
+    r"k_denoise<3, 3, 6>": 2260,
+    r"k_demodulation<3>": 514,
+    r"k_spatial_reuse<false>": 3770,
+    r"k_indirect<true, false, true>": 7941,
+    r"k_prepass<false, true>": 3274,
+    r"k_wf_trace<false>": 499,
+}
+
+
+def test_valu_bound_kernels_do_not_grow_unnoticed():
+    counts = instruction_counts(LIB)
+    for pattern, budget in VALU_BUDGETS.items():
+        hits = {n: c for n, c in counts.items() if re.search(pattern, n)}
+        assert hits, f"no kernel matches {pattern}"
+        for name, c in hits.items():
+            assert c["valu"] <= budget * 1.04, f"{name}: {c['valu']} VALU instructions, budget {budget} (+4 %)"

@@ -61,9 +61,48 @@ def resources(path):
     return {names[k]: v for k, v in out.items()}
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def instruction_counts(path):
+    """{demangled kernel name: {"valu": n, "salu": n, "vmem": n, "lds": n, "total": n}} - STATIC counts from the disassembly of the
+    kernels' code (every instruction once, whatever the control flow): what a VALU-bound kernel costs to first order."""
+    out = {}
+    for blob in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".o") as f:
+            f.write(blob)
+            f.flush()
+            text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        cur = None
+        for line in text.split("\n"):
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+            if m:
+                cur = out.setdefault(m.group(1), {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "total": 0})
+                continue
+            t = line.strip().split(" ", 1)[0] if cur is not None else ""
+            if not t or not re.match(r"^[a-z]+_", t):
+                continue
+            cur["total"] += 1
+            if t.startswith("v_"):
+                cur["valu"] += 1
+            elif t.startswith("s_"):
+                cur["salu"] += 1
+            elif t.startswith(("global_", "buffer_", "flat_", "scratch_")):
+                cur["vmem"] += 1
+            elif t.startswith("ds_"):
+                cur["lds"] += 1
+    names = demangle(list(out))
+    return {names[k]: v for k, v in out.items() if v["total"]}
+
+
 if __name__ == "__main__":
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bevy-hikari_amd", "libhikari_hip.so")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    lib = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bevy-hikari_amd", "libhikari_hip.so")
+    isa = instruction_counts(lib) if "--isa" in sys.argv else {}
     for name, r in sorted(resources(lib).items()):
         short = re.sub(r"\(.*", "", name.replace("void hkd::", "").replace("hkd::", ""))
+        if name in isa:
+            i = isa[name]
+            print(f"{short[:60]:<60} valu={i['valu']:>5} salu={i['salu']:>5} vmem={i['vmem']:>4} lds={i['lds']:>4} total={i['total']:>5}  ", end="")
         print(f"{short[:60]:<60} vgpr={r.get('vgpr_count'):>3} spill={r.get('vgpr_spill_count'):>3} scratch={r.get('private_segment_fixed_size'):>5} "
               f"lds={r.get('group_segment_fixed_size'):>6} sgpr={r.get('sgpr_count'):>3}")
