@@ -105,6 +105,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and rank != 0:
+        os.dup2(2, 1)  # the launcher merges the ranks' stdout: only rank 0's JSON line belongs there (libraries print banners at exit)
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -336,7 +338,15 @@ def main():
                       "the reference itself (wgpu + lavapipe) cannot be built or run here",
             "ms_per_frame": round(cdt / done * 1e3, 1),
         }
+    # the JSON line is the LAST thing on stdout: what C libraries (RCCL's start-up banner ...) left in their stdio buffers goes out
+    # first, and whatever they print later goes to stderr
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(out), flush=True)
+    os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
