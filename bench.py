@@ -305,6 +305,20 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "r02_indirect_hbm_traffic.json")
     if os.path.exists(tpath) and world == 1 and args.config == 2:
         out["traffic_profile"] = {"source": "profiles/r02_indirect_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"}
+        # The kernel's actual ceiling is VALU issue, not HBM: its VALU wave-instructions per launch (SQ_INSTS_VALU of the
+        # committed PMC pass - a property of the binary and the workload, not of this run) over this run's launch time, against the
+        # chip's issue rate: 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md).
+        try:
+            prof = json.load(open(tpath))
+            valu = float(prof["limiter"]["valu_wave_instructions"])
+            alone_ms = out["roofline"].get("alone", {}).get("avg_launch_ms") or out["roofline"]["avg_launch_ms"]
+            peak = 256 * 4 * 2.4e9 / 4
+            out["roofline"]["valu_issue"] = {"wave_instructions_per_launch": valu, "achieved_ginstr_s": round(valu / (alone_ms * 1e-3) / 1e9, 1),
+                                             "peak_ginstr_s": round(peak / 1e9, 1), "frac": round(valu / (alone_ms * 1e-3) / peak, 4),
+                                             "lane_utilisation": prof["limiter"].get("lane_utilisation"),
+                                             "source": "SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of profiles/r02_final_pmc_sq.txt; launch time of this run, kernel alone"}
+        except Exception:
+            pass
     if transport_used[0]:
         out["config"]["halo_transport"] = transport_used[0]
     if passes:
