@@ -217,9 +217,11 @@ _PRODUCT_ONLY = {
     "set_timing_mask": [_vp, u32],
     "indirect_schedule": [_vp, P(u32)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
+    "measure_valu": [_vp, u32, P(C.c_double)],
     "bvh_rethread": [P(HkNode), u32, u32, P(HkNode)],
     "band_schedule": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkTransfer), P(u32)],
     "comm_unique_id": [P(C.c_uint8)],
+    "comm_available": [_vp],
     "comm_init": [_vp, u32, u32, P(C.c_uint8)],
     "comm_destroy": [_vp],
     "comm_set_history_rows": [_vp, u32],

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <deque>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -47,9 +48,8 @@ struct Rccl {
 
 Rccl* rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;  // contexts may be initialised from different threads
+  std::call_once(once, [] {
     // a copy some other component of the process already mapped (PyTorch ships its own) is as good as the system one
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names)
@@ -63,7 +63,7 @@ Rccl* rccl() {
         r.lib = nullptr;
       }
     }
-  }
+  });
   return r.lib ? &r : nullptr;
 }
 
@@ -261,6 +261,16 @@ int hk_comm_unique_id(uint8_t id[HK_COMM_ID_BYTES]) {
   return HK_OK;
 }
 
+int hk_comm_available(hk_ctx* c) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_REQUIRE(rccl(), HK_E_UNSUPPORTED, "librccl could not be loaded (or lacks a symbol the exchange needs)");
+  CtxInfo ci;
+  const int rc = ctx_info(c, &ci);
+  if (rc) return rc;
+  HK_HIP(hipSetDevice(ci.device));
+  return HK_OK;
+}
+
 int hk_comm_init(hk_ctx* c, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK_COMM_ID_BYTES]) {
   HK_REQUIRE(c && id && n_ranks > 0 && rank < n_ranks, HK_E_INVALID, "bad argument");
   Rccl* R = rccl();
@@ -268,7 +278,10 @@ int hk_comm_init(hk_ctx* c, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK
   CtxInfo ci;
   int rc = ctx_info(c, &ci);
   if (rc) return rc;
-  comm_release(c);
+  if (*ctx_comm_slot(c)) {  // exchanges of the previous communicator may still be enqueued on the context's stream
+    if ((rc = hk_frame_wait(c))) return rc;
+    comm_release(c);
+  }
   HK_HIP(hipSetDevice(ci.device));
   Comm* cm = new (std::nothrow) Comm();
   HK_REQUIRE(cm, HK_E_NOMEM, "allocation failed");

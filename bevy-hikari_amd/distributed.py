@@ -66,7 +66,10 @@ class BandRenderer:
     """Drives one rank's band of the frame; `engine` is a bevy_hikari_amd.Engine (or, in the CPU tests, the oracle behind
     the same class).  transport: "rccl" (the product: exchanges inside the library) or "host" (tests, see the module text)."""
 
-    def __init__(self, engine, rank, world_size, backend_device="cuda", transport=None):
+    def __init__(self, engine, rank, world_size, backend_device="cuda", transport=None, fallback=None):
+        """fallback: what to do when transport "rccl" cannot come up on every rank.  None (default) raises the same
+        RuntimeError on ALL ranks - a job that asked for RCCL never silently becomes a PCIe-through-host job; "host" agrees
+        on the host-staged transport instead (slower, same bytes) and says so in `transport`."""
         import torch
 
         self.torch = torch
@@ -76,33 +79,50 @@ class BandRenderer:
         self._views = {}
         self._plans = {}
         self._generation = getattr(engine, "generation", 0)
+        self.rccl_error = None
         engine.set_band(rank, world_size)
         if self.transport == "rccl" and world_size > 1:
             import torch.distributed as dist
 
-            # rendezvous: rank 0 creates the RCCL id, the (gloo) process group carries its 128 bytes to the other ranks
-            # A rank whose RCCL will not come up (no librccl, no peer access ...) must not leave the others waiting inside
-            # ncclCommInitRank's rendezvous or the first exchange: the ranks agree on the outcome, and if any of them failed
-            # ALL fall back to the host-staged transport (slower, same bytes) and say so in `transport`.
-            self.rccl_error = None
-            try:
-                box = [engine.comm_unique_id() if rank == 0 else None]
-            except Exception as err:  # (HikariError from the library, OSError from the loader)
-                box, self.rccl_error = [None], repr(err)
-            dist.broadcast_object_list(box, src=0)
-            if box[0] is not None:
-                try:
-                    engine.comm_init(rank, world_size, box[0])
-                except Exception as err:
-                    self.rccl_error = repr(err)
+            # ncclCommInitRank blocks until every rank has called it, so the ranks AGREE before anyone enters it
+            # (ADVICE r02): 1. every rank reports hk_comm_available (librccl loads, the device can be made current)
+            # without raising; 2. all-reduce MIN over the (gloo) process group; 3. only if all passed, rank 0 creates the
+            # id, its 128 bytes travel by object broadcast, and every rank calls hk_comm_init; 4. a second all-reduce
+            # collects the outcome of the init itself.
+            ok, why = engine.comm_available() if hasattr(engine, "comm_available") else (False, "engine has no RCCL entry points")
+            if self._all_ok(ok):
+                box = [None]
+                if rank == 0:
+                    try:
+                        box = [engine.comm_unique_id()]
+                    except Exception as err:  # (HikariError from the library)
+                        why = repr(err)
+                dist.broadcast_object_list(box, src=0)
+                if box[0] is None:
+                    ok, why = False, why or "rank 0 could not create an RCCL id"
+                else:
+                    try:
+                        engine.comm_init(rank, world_size, box[0])
+                    except Exception as err:
+                        ok, why = False, repr(err)
+                    if not self._all_ok(ok) and ok:
+                        engine.comm_destroy()
+                        ok, why = False, "hk_comm_init failed on another rank"
             else:
-                self.rccl_error = self.rccl_error or "rank 0 could not create an RCCL id"
-            ok = torch.tensor([0 if self.rccl_error else 1], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if not self.rccl_error:
-                    engine.comm_destroy()
-                self.transport = "host (rccl unavailable on some rank" + (": " + self.rccl_error if self.rccl_error else "") + ")"
+                ok, why = False, why or "hk_comm_available failed on another rank"
+            if not ok:
+                self.rccl_error = why
+                if fallback != "host":
+                    raise RuntimeError(f"rank {rank}: the RCCL halo transport did not come up on every rank ({why}); "
+                                       "pass fallback='host' to stage the halos through host memory instead")
+                self.transport = "host (rccl unavailable on some rank: " + why + ")"
+
+    def _all_ok(self, ok):
+        import torch.distributed as dist
+
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
 
     # ------------------------------------------------------------------ host transport (tests)
     def _view(self, buf, parity=0):
@@ -231,6 +251,9 @@ class MultiEngine:
         if getattr(self, "h", None):
             self.api.raw("multi_destroy")(self.h)
             self.h = None
+            for e in self.contexts:  # the contexts died with the hk_multi: a later call through a borrowed Engine must not reach the library
+                e.ctx = C.c_void_p()
+            self.contexts = []
 
     def __del__(self):
         self.close()

@@ -542,6 +542,14 @@ class Engine:
         return self.device_ptr(buf)[1]
 
     # -- halo exchange inside the library (one process per GPU; bevy-hikari_amd/distributed.py does the rendezvous)
+    def comm_available(self):
+        """hk_comm_available as (ok, reason): never raises, so that every rank reaches the agreement step."""
+        try:
+            self.api.call("comm_available", self.ctx)
+            return True, ""
+        except Exception as err:  # HikariError from the library; KeyError / AttributeError behind a library without RCCL (the oracle)
+            return False, repr(err)
+
     def comm_unique_id(self):
         ident = (C.c_uint8 * 128)()
         self.api.call("comm_unique_id", ident)
@@ -589,6 +597,12 @@ class Engine:
         cp, tr = C.c_double(), C.c_double()
         self.api.call("measure_hbm", self.ctx, bytes_per_array, reps, C.byref(cp), C.byref(tr))
         return cp.value, tr.value
+
+    def measure_valu(self, iters=2048):
+        """VALU issue ceiling: {waves per SIMD: 1e9 wave64 instructions per second} for 1, 2, 4, 8 resident waves per SIMD."""
+        r = (C.c_double * 4)()
+        self.api.call("measure_valu", self.ctx, iters, r)
+        return {1 << k: r[k] for k in range(4)}
 
     def debug_math(self, op, x, y=None):
         x = np.ascontiguousarray(x, dtype=np.float32)

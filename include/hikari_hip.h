@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 5
+#define HK_ABI_VERSION 6
 
 /* ------------------------------------------------------------------ error codes */
 #define HK_OK 0
@@ -578,6 +578,11 @@ int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint3
  * does hk_set_band(rank, n_ranks) - and then simply renders frames. */
 #define HK_COMM_ID_BYTES 128
 int hk_comm_unique_id(uint8_t id[HK_COMM_ID_BYTES]);
+/* Pre-flight for the rendezvous: HK_OK iff librccl loads with every entry point the exchange uses and the context's device
+ * can be made current.  ncclCommInitRank blocks until all n_ranks have called it, so a launcher first lets every rank
+ * report this over its host channel and only calls hk_comm_init when ALL ranks passed - a rank that cannot bring RCCL up
+ * then fails the job instead of leaving the healthy ranks waiting inside the rendezvous. */
+int hk_comm_available(hk_ctx* ctx);
 int hk_comm_init(hk_ctx* ctx, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK_COMM_ID_BYTES]);
 int hk_comm_destroy(hk_ctx* ctx);
 /* rows of last frame's reservoirs / AA history fetched from the neighbours before TEMPORAL / ANTIALIAS (exchange C): the
@@ -636,6 +641,11 @@ int hk_indirect_schedule(hk_ctx* ctx, uint32_t* out);
  * on the context's stream and returns the sustained rates in GB/s (1e9), HIP events around the launches: copy a = b moves
  * 2 x bytes per pass, triad a = b + s * c moves 3 x bytes. */
 int hk_measure_hbm(hk_ctx* ctx, size_t bytes_per_array, uint32_t reps, double* copy_gbs, double* triad_gbs);
+/* Measurement hook for the OTHER roof of the ray kernels: the rate at which the chip issues wave64 VALU instructions, in
+ * 1e9 wave-instructions per second, from a register-only kernel of eight independent v_fma_f32 chains per lane (64 x iters
+ * instructions per wave) run with 1, 2, 4 and 8 waves resident per SIMD (ginstr_s[0..3]).  One wave alone issues about one
+ * instruction per 6 cycles; the ceiling (one per ~2 cycles per SIMD) needs four or more waves per SIMD. */
+int hk_measure_valu(hk_ctx* ctx, uint32_t iters, double ginstr_s[4]);
 
 /* Test hook: evaluate one of the library's device math routines elementwise (op: 0 sin, 1 cos,
  * 2 exp, 3 exp2, 4 log2, 5 pow(x, y), 6 min(x,y), 7 max(x,y), 8 f32->f16->f32, 9 x/y, 10 sqrt).

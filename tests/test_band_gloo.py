@@ -44,9 +44,15 @@ def _worker(rank, world, port, case_name, out_dir, transport=None):
     e.upload_scene(case.scene)
     w, h = case.camera.width, case.camera.height
     e.resize(w, h, s.upscale.ratio())
-    r = BandRenderer(e, rank, world, backend_device="cpu", transport=transport)
-    if transport == "rccl":  # (no RCCL behind the oracle: every rank must have agreed on the host-staged exchange)
+    if transport == "rccl":
+        # no RCCL behind the oracle.  Default: every rank raises (nobody is left waiting in a rendezvous, nobody silently
+        # takes a slower transport); with fallback="host" every rank agrees on the host-staged exchange.
+        with pytest.raises(RuntimeError, match="RCCL halo transport did not come up on every rank"):
+            BandRenderer(e, rank, world, backend_device="cpu", transport="rccl")
+        r = BandRenderer(e, rank, world, backend_device="cpu", transport="rccl", fallback="host")
         assert r.transport.startswith("host (rccl unavailable"), r.transport
+    else:
+        r = BandRenderer(e, rank, world, backend_device="cpu", transport=transport)
     view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
     for n in case.frames:
         r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h)
@@ -62,8 +68,9 @@ def _worker(rank, world, port, case_name, out_dir, transport=None):
 
 @pytest.mark.parametrize("world,case_name,transport", [(2, "cornell_b2", None), (3, "yard_sun", None), (2, "cornell_b2", "rccl")])
 def test_bands_equal_single_rank(tmp_path, world, case_name, transport):
-    """transport "rccl" where RCCL cannot come up (here: the oracle has no communicator): the ranks agree to stage the halos
-    through host memory instead of hanging in the rendezvous, and the frame is the same."""
+    """transport "rccl" where RCCL cannot come up (here: the oracle has no communicator): the ranks agree BEFORE anyone enters
+    the rendezvous - all of them raise, or with fallback="host" all of them stage the halos through host memory, and the frame
+    is the same."""
     from cases import make_case, run_case, snapshot
     from oracle_lib import oracle_plugin
 

@@ -13,15 +13,19 @@ from conftest import ROOT
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_band_path_runs_with_several_ranks_on_one_gpu(world):
+@pytest.mark.parametrize("world,launcher", [(2, "torchrun"), (3, "torchrun"), (2, "plain")])
+def test_bench_band_path_runs_with_several_ranks_on_one_gpu(world, launcher):
+    """launcher "torchrun": the driver's own command line.  "plain": `python bench.py --gpus N` with no launcher - bench.py
+    re-launches itself under torch.distributed.run (VERDICT r02 missing 1)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HIKARI_BENCH_TRANSPORT="host", HIKARI_BENCH_DEVICE="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "3", "--blocks", "2", "--width", "640", "--height", "360"]
+    cmd = [sys.executable]
+    if launcher == "torchrun":
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "3", "--blocks", "2", "--width", "640", "--height", "360"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -30,3 +34,23 @@ def test_bench_band_path_runs_with_several_ranks_on_one_gpu(world):
     assert d["n_gpus"] == world and d["steps"] == 6 and d["scaling"] == "strong" and d["config"]["parallelism"] == f"band{world}"
     assert d["value"] > 0 and d["rays_per_frame"] > 640 * 360 and "roofline" in d and d["config"]["halo_transport"] == "host"
     assert len(d["blocks_ms_per_step"]) == 2
+
+
+@pytest.mark.gpu
+def test_bench_fails_instead_of_falling_back_when_rccl_cannot_come_up():
+    """Two ranks on ONE device: RCCL refuses ("duplicate GPU").  bench.py must exit non-zero on every rank - an N-GPU line is
+    never a host-staged number in disguise - and print no JSON line."""
+    env = dict(os.environ, HIKARI_BENCH_DEVICE="0")
+    env.pop("HIKARI_BENCH_TRANSPORT", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "1", "--width", "320", "--height", "180",
+           "--no-hbm-probe"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "RCCL halo transport did not come up" in r.stderr or "ncclCommInitRank" in r.stderr, r.stderr[-3000:]
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_a_launcher():
+    """CPU container: no GPU at all -> a loud exit, not a CPU fallback."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and ("needs an MI355X" in r.stderr or "exposes" in r.stderr)
