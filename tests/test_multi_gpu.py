@@ -53,6 +53,37 @@ def test_multi_engine_union_equals_single_context(bands, case_name):
         assert a.shape == r.shape and (a.view(np.uint8) == r.view(np.uint8)).all(), f"{case_name} x{bands}: buffer {b} differs"
 
 
+@pytest.mark.parametrize("bands", [8, 5])
+def test_multi_engine_full_size_config2_equals_single_context(bands):
+    """BASELINE config 2 at its full 1920x1080 (2 bounces, ReSTIR, denoise), cut into 8 bands (135 rows each: the driver's
+    8-GPU run) and 5 bands (216 rows): the union of the bands equals the single-context frame bit for bit, every buffer the
+    frame's consumers read."""
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    w, h, frames = 1920, 1080, 4
+    cam = hk.cornell_camera(w, h)
+    view, pview, lights = cam.view_uniform(), cam.previous_view_uniform(), hk.lights_uniform()
+    scene = hk.load_cornell()
+    m = MultiEngine([0] * bands)
+    ref = hk.Engine(device=0)
+    for t in (m, ref):
+        t.upload_noise(); t.upload_scene(scene); t.resize(w, h, 1.0)
+    for n in range(1, frames + 1):
+        f = hk.frame_uniform(s, n)
+        m.frame_render(f, view, pview, lights, s.to_c())
+        ref.frame_render(f, view, pview, lights, s.to_c())
+    m.wait(); ref.wait()
+    prev = 1 - frames % 2
+    for b in [F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0, F.BUF_RENDER0 + 1, F.BUF_RENDER0 + 2,
+              F.BUF_VARIANCE0 + 2, F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8, F.BUF_POSITION, F.BUF_ALBEDO]:
+        a, r = m.read(b), ref.read(b)
+        assert a.shape == r.shape and (a.view(np.uint8) == r.view(np.uint8)).all(), f"x{bands}: buffer {b} differs at 1920x1080"
+    borrowed = m.contexts[0]
+    m.close()
+    assert m.contexts == [] and not borrowed.ctx   # (ADVICE r02: the borrowed contexts died with the hk_multi ...)
+    with pytest.raises(hk.HikariError):             # ... so a later call gets HK_E_INVALID for a NULL context, not freed memory
+        borrowed.stats()
+
+
 def test_multi_engine_history_rows_under_camera_motion():
     """Exchange C inside the library: with the camera moving vertically, reprojection crosses the band borders; with the
     history halo the union stays within the north star's 1e-3 of the single-context frame, without it it does not."""

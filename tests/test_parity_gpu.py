@@ -11,7 +11,7 @@ import pytest
 
 import bevy_hikari_amd as hk
 from bevy_hikari_amd import _ffi as F
-from cases import CASE_NAMES, diff_buffers, make_case, run_case, snapshot
+from cases import ALL_BUFFERS, CASE_NAMES, diff_buffers, make_case, run_case, snapshot
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
@@ -402,6 +402,116 @@ def test_threaded_traversal_config4_within_tolerance():
     scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
     _threaded_vs_exact("config4_1080p", scene, synthetic_camera(1920, 1080, extent=30.0), hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0),
                        hk.lights_uniform(directional=dict(sun, illuminance=10000.0)), (1, 2, 3), 1e-5)
+
+
+def test_threaded_traversal_config4_full_4k_within_tolerance():
+    """BASELINE config 4 at the size it is benchmarked at (3840x2160) in the mode it is benchmarked in - the product default:
+    threaded orderings + wavefront schedule - against HK_CTX_EXACT_TRAVERSAL on the same frames."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+    _threaded_vs_exact("config4_4k", scene, synthetic_camera(3840, 2160, extent=30.0), hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0),
+                       hk.lights_uniform(directional=dict(sun, illuminance=10000.0)), (1, 2, 3), 1e-5)
+
+
+def test_config4_full_4k_row_ranges_vs_oracle():
+    """Config 4 at its full 3840x2160, exact traversal, against the ORACLE on three row ranges of the frame (top edge, middle,
+    bottom edge): the oracle renders only those rows plus the aprons their passes read (orc_frame_stage_rows) - frame 1 with the
+    aprons frame 2's history needs, then frame 2 - and every buffer's rows must equal the GPU's full-frame rows bit for bit."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+    from oracle_lib import oracle_api, oracle_engine
+
+    scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    sc = s.to_c()
+    W, H = 3840, 2160
+    cam = synthetic_camera(W, H, extent=30.0)
+    lights = hk.lights_uniform(directional=dict(sun, illuminance=10000.0))
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    gpu = hk.Engine(device=0)           # (conftest: HK_CTX_EXACT_TRAVERSAL)
+    cpu = oracle_engine()
+    for e in (gpu, cpu):
+        e.upload_noise(); e.upload_scene(scene); e.resize(W, H, 1.0)
+    stage_rows = oracle_api().dll.orc_frame_stage_rows
+    ranges = [(0, 24), (1068, 1092), (2136, 2160)]
+    SP, DEN = 21, 16                     # spatial-reuse and denoiser aprons (rows), as in hk_band_plan_for
+    clamp = lambda v: min(max(v, 0), H)
+    checked = 0
+    for n in (1, 2):
+        f = hk.frame_uniform(s, n)
+        gpu.frame_render(f, view, pview, lights, sc)
+        cpu.frame_begin(f, view, pview, lights)
+        extra = (SP + DEN) if n == 1 else 0   # frame 1 also produces what frame 2 reads of it (same pixel: static camera)
+        for r0, r1 in ranges:
+            for stage, apron in ((F.STAGE_TEMPORAL, SP + DEN), (F.STAGE_SPATIAL, DEN), (F.STAGE_POST_PROCESS, 0)):
+                rc = stage_rows(cpu.ctx, stage, C.byref(sc), 0, clamp(r0 - apron - extra), clamp(r1 + apron + extra))
+                assert rc == 0, cpu.api.last_error()
+        gpu.wait()
+        cur, prev = n % 2, 1 - n % 2
+        for b, name in ALL_BUFFERS.items():
+            if name.startswith("previous_") or name in ("upscale_output", "taa_output", "upscale_sharpened"):
+                continue
+            if name.startswith("reservoir") and (int(name[9:]) % 2) != prev:
+                continue                  # (the buffers this frame wrote: the ping-pong half temporal / spatial store into)
+            if name.startswith("internal"):
+                continue                  # a-trous scratch: holds the last channel's intermediate levels with their shrinking aprons
+            a, o = gpu.read(b), cpu.read(b)
+            for r0, r1 in ranges:
+                x, y = a[r0:r1], o[r0:r1]
+                assert (x.view(np.uint8) == y.view(np.uint8)).all(), f"frame {n}: {name} rows [{r0},{r1}) differ from the oracle at 4K"
+                checked += 1
+    assert checked >= 2 * 3 * 20
+
+
+def test_config3_default_mode_under_instance_motion_with_refit_1080p():
+    """Config 3 at 1920x1080 in the PRODUCT DEFAULT (threaded orderings + wavefront), instances moving every frame through the
+    device refit: against HK_CTX_EXACT_TRAVERSAL fed the same poses - 1e-3 on the output, G-buffer hits equal but for ties.
+    Both contexts resolve the scatter race the same way (HK_CTX_DETERMINISTIC_SCATTER), so what is compared is the traversal."""
+    from cases import product_default_traversal
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+    from test_device_refit import pose
+
+    s = hk.HikariSettings(indirect_bounces=3, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = synthetic_camera(1920, 1080, extent=9.0)
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    engines, scenes = [], []
+    for default_mode in (False, True):
+        scene, sun = synthetic_large()
+        scenes.append(scene)
+        if default_mode:
+            with product_default_traversal():
+                e = hk.Engine(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)
+        else:
+            e = hk.Engine(device=0, flags=F.CTX_DETERMINISTIC_SCATTER | F.DEFAULT_CTX_FLAGS)
+        e.upload_noise(); e.upload_scene(scene); e.resize(1920, 1080, 1.0)
+        engines.append(e)
+    lights = hk.lights_uniform(directional=sun)
+    rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in scenes[0].instances], dtype=np.float32)
+    movers = list(range(3, len(rest), 9))
+    for n in range(1, 6):
+        if n > 1:
+            for e, scene in zip(engines, scenes):
+                for k, i in enumerate(movers):
+                    scene.builder.set_instance_transform(i, pose(rest[i], n - 1, k))
+                assert e.refit_instances(scene.builder) == len(movers)
+        for e in engines:
+            e.frame_render(hk.frame_uniform(s, n), view, pview, lights, s.to_c())
+    exact, fast = engines
+    assert fast.indirect_schedule() == "wavefront" and fast.stats().scene_device_refits == 4
+    a = np.stack([fast.read_f16(F.BUF_DENOISE_RENDER0 + i) for i in range(3)]).astype(np.float64)
+    b = np.stack([exact.read_f16(F.BUF_DENOISE_RENDER0 + i) for i in range(3)]).astype(np.float64)
+    rel = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    ia, ib = fast.read(F.BUF_INSTANCE_MATERIAL), exact.read(F.BUF_INSTANCE_MATERIAL)
+    hit_diff = float((ia[..., 0] != ib[..., 0]).mean())
+    report = {"case": "config3_1080p_motion_refit", "rel_l2": rel, "primary_hit_instance_differs": hit_diff, "movers": len(movers), "frames": 5}
+    print(report)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        with open(os.path.join(out_dir, "threaded_traversal_config3_1080p_motion_refit.json"), "w") as f:
+            json.dump(report, f, indent=1)
+    assert rel <= 1e-3 and hit_diff <= 1e-5, report
 
 
 def test_threaded_traversal_flight_helmet_vs_oracle():

@@ -1,21 +1,90 @@
 #!/usr/bin/env python3
-"""Per-pass GPU time of ONE band of an N-band split, on one GPU (no exchanges): what each rank of a
-multi-GPU run spends in kernels."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bevy_hikari_amd as hk
-from bevy_hikari_amd import _ffi as F
+"""What each rank of an N-GPU band-sharded run spends, measured on ONE GPU: for N = 1, 2, 4, 8 every band of the frame is
+rendered alone (hk_set_band, no exchanges) and timed by the wall clock over K frames; the halo bytes each rank receives per
+frame come from hk_band_schedule.  From that: the PREDICTED frame time and scaling curve of the real N-GPU run
+(max over bands + the exchanges priced with the stated link assumptions), to be compared with the driver's SCALE_rNN.json.
 
-W, H = 1920, 1080
-s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0); sc = s.to_c()
-cam = hk.cornell_camera(W, H); view, pview, lights = cam.view_uniform(), cam.previous_view_uniform(), hk.lights_uniform()
-nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-for band in range(nb):
-    e = hk.Engine(device=0); e.upload_noise(); e.upload_scene(hk.load_cornell()); e.resize(W, H, 1.0)
-    for n in range(1, 17): e.frame_render(hk.frame_uniform(s, n), view, pview, lights, sc)   # converge full-frame state first
-    e.set_band(band, nb); e.wait(); e.reset_stats(); e.set_timing_mask(0xFFFF)
-    N = 24
-    for n in range(17, 17 + N): e.frame_render(hk.frame_uniform(s, n), view, pview, lights, sc)
-    st = e.stats()
-    p = {F.PASS_NAMES[i][:10]: round(st.pass_ms_total[i] / N, 3) for i in range(F.PASS_COUNT) if st.pass_launches[i]}
-    print(f"band {band}/{nb}: sum {sum(p.values()):.3f} ms  {p}")
+    python tools/band_probe.py [--configs 2 4] [--frames 24] > profiles/r03_band_probe.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (workload definitions)
+import bevy_hikari_amd as hk  # noqa: E402
+from bevy_hikari_amd import _ffi as F  # noqa: E402
+from bevy_hikari_amd.distributed import band_schedule  # noqa: E402
+
+# assumptions of the prediction (xGMI is point-to-point: a neighbour exchange uses ONE link per direction)
+LINK_GBS = 50.0      # effective one-direction rate of one xGMI link for MB-sized ncclSend/Recv (7 links x ~153 GB/s bidirectional per GPU)
+EXCHANGE_US = 30.0   # fixed cost of one grouped send/recv exchange on the stream
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", type=int, nargs="+", default=[2, 4])
+    ap.add_argument("--frames", type=int, default=24)
+    args = ap.parse_args()
+    out = {"assumptions": {"link_gbs_one_direction": LINK_GBS, "exchange_fixed_us": EXCHANGE_US,
+                           "method": "every band rendered alone on one MI355X (hk_set_band), wall clock over K frames after a full-frame warm-up; "
+                                     "predicted N-GPU frame = max over bands + sum over the frame's exchanges of (fixed + max over ranks of received bytes / link rate)"},
+           "configs": {}}
+    for config in args.configs:
+        scene, camera, settings, lights, description = bench.workload(hk, config, None, None, None)
+        W, H = camera.width, camera.height
+        sc = settings.to_c()
+        view, pview = camera.view_uniform(), camera.previous_view_uniform()
+        e = hk.Engine(device=0)
+        e.upload_noise()
+        e.upload_scene(scene)
+        e.resize(W, H, 1.0)
+        K = args.frames if config == 2 else max(6, args.frames // 4)
+        n = 0
+
+        def frames(count):
+            nonlocal n
+            for _ in range(count):
+                n += 1
+                e.frame_render(hk.frame_uniform(settings, n), view, pview, lights, sc)
+            e.wait()
+
+        frames(12)
+        rows = {}
+        for bands in (1, 2, 4, 8):
+            per_band, recv = [], []
+            for b in range(bands):
+                e.set_band(0, 1)
+                frames(2)                      # whole-frame state stays current between the band measurements
+                e.set_band(b, bands)
+                frames(2)
+                t0 = time.perf_counter()
+                frames(K)
+                per_band.append((time.perf_counter() - t0) / K * 1e3)
+                # bytes this band receives per frame, per exchange (static view: no history rows)
+                ex = []
+                for stage in (F.STAGE_SPATIAL, F.STAGE_POST_PROCESS):
+                    ex.append(sum(t.bytes for t in band_schedule(W, H, 1.0, b, bands, stage, n, sc) if t.is_recv) if bands > 1 else 0)
+                recv.append(ex)
+            exch_ms = 0.0
+            if bands > 1:
+                for k in range(2):
+                    worst = max(r[k] for r in recv)
+                    if worst:
+                        exch_ms += EXCHANGE_US * 1e-3 + worst / (LINK_GBS * 1e9) * 1e3
+            rows[bands] = {"band_ms": [round(x, 4) for x in per_band], "max_band_ms": round(max(per_band), 4), "halo_bytes_received_per_band": recv,
+                           "exchange_ms_predicted": round(exch_ms, 4), "frame_ms_predicted": round(max(per_band) + exch_ms, 4)}
+        t1 = rows[1]["frame_ms_predicted"]
+        for bands in rows:
+            rows[bands]["speedup_predicted"] = round(t1 / rows[bands]["frame_ms_predicted"], 3)
+            rows[bands]["efficiency_predicted"] = round(t1 / rows[bands]["frame_ms_predicted"] / bands, 3)
+        out["configs"][str(config)] = {"workload": description, "frames_per_measurement": K, "bands": {str(k): v for k, v in rows.items()}}
+        e.close()
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
