@@ -215,6 +215,7 @@ def main():
         elapsed = float(np.median(blocks))
         st = eng.stats()
         schedule = eng.indirect_schedule()
+        traversal = eng.traversal_mode()
         ind_ms = st.pass_ms_total[F.PASS_INDIRECT] / max(1, st.pass_launches[F.PASS_INDIRECT])
         ind_launches = int(st.pass_launches[F.PASS_INDIRECT])
         eng.set_timing_mask(0)
@@ -254,7 +255,7 @@ def main():
         del ceng, crend
 
         res = {"config": config, "description": description, "W": W, "H": H, "steps": steps, "warmup": warmup, "blocks": blocks, "elapsed": elapsed,
-               "last_frame": last_frame, "schedule": schedule, "ind_ms": ind_ms, "ind_launches": ind_launches, "total_rays": total_rays, "same": same,
+               "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "total_rays": total_rays, "same": same,
                "sustained": sustained, "scene": scene, "settings": settings, "lights": lights, "view": view, "pview": pview, "sc": sc,
                "band_rows": H if rend is None else (rend.band(H)[1] - rend.band(H)[0])}
         if sustained:
@@ -300,7 +301,7 @@ def main():
             extra[str(cfg)] = {"workload": x["description"], "value": round(x["total_rays"] / x["elapsed"] / 1e6, 3), "unit": "Mray/s",
                                "ms_per_step": round(x["elapsed"] / steps_x * 1e3, 4), "steps": steps_x, "warmup": 6,
                                "blocks_ms_per_step": [round(b / steps_x * 1e3, 4) for b in x["blocks"]], "rays_per_frame": round(x["total_rays"] / steps_x, 1),
-                               "indirect_schedule": x["schedule"], "indirect_avg_launch_ms": round(x["ind_ms"], 5), "replay_bit_identical": x["same"]}
+                               "indirect_schedule": x["schedule"], "traversal": x["traversal"][0], "indirect_avg_launch_ms": round(x["ind_ms"], 5), "replay_bit_identical": x["same"]}
             del x
 
     # ------------------------------------------------------------------ empirical HBM ceiling, same run
@@ -344,6 +345,9 @@ def main():
             "baseline_config": args.config,
             "frames": f"warmup 1..{args.warmup}, then {len(blocks)} timed blocks of {args.steps} frames ({args.warmup + 1}..{last_frame}); value = median block",
             "parallelism": f"band{world}" if world > 1 else "single",
+            # hk_traversal_mode: "one-level" = one BVH over all triangles in the instances' shared local space (the Cornell box),
+            # "threaded" = two-level walk over 8 direction-ordered flattenings (scenes beyond LDS), "reference" = the reference's order
+            "traversal": {"mode": m["traversal"][0], "orderings": m["traversal"][1]},
         },
         "blocks_ms_per_step": ms_blocks,
         "min_ms_per_step": min(ms_blocks),

@@ -216,6 +216,7 @@ _PRODUCT_ONLY = {
     "set_stream": [_vp, _vp],
     "set_timing_mask": [_vp, u32],
     "indirect_schedule": [_vp, P(u32)],
+    "traversal_mode": [_vp, P(u32), P(u32)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],
     "bvh_rethread": [P(HkNode), u32, u32, P(HkNode)],

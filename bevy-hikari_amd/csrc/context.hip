@@ -8,6 +8,7 @@
 //   ping-pong      src/light.rs:376,480-481,518-546
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -163,7 +164,7 @@ inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 }  // namespace
 
 // byte offsets of the arrays inside the instance-level region of the scene allocation
-struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emissives, alias, materials, tex_info, srgb_lut; };
+struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emissives, alias, materials, tex_info, srgb_lut, flat; uint32_t flat_count, flat_orderings; };
 
 struct hk_ctx {
   int device = 0;
@@ -531,7 +532,130 @@ int build_static_region(hk_ctx* c, Blob& blob, size_t& off_nodes, size_t& off_v0
   return HK_OK;
 }
 
-int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o) {
+// ------------------------------------------------------------------ one-level BVH (DScene::flat, hk_device.hpp traverse_flat)
+// Built on the host at every instance-level rebuild of a scene whose instances all share one transform and that fits the LDS
+// copy: every triangle of every instance (local space = the one space they share), a top-down SAH build with an exact sweep
+// along the three axes (the scenes are a few hundred triangles at most), one triangle per leaf, flattened depth-first with
+// skip links once per ray-direction octant - each inner node's children in the order a ray of that octant meets them (axis
+// of the larger centre separation), so a closest-hit walk finds its hit early and skips the rest by their boxes.
+namespace flatbvh {
+struct Tri { float lo[3], hi[3], c[3]; uint32_t prim, inst; };
+struct Node { float lo[3], hi[3]; int left = -1, right = -1; uint32_t prim = 0, inst = 0; };
+inline float half_area(const float* lo, const float* hi) {
+  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+int build(std::vector<Node>& nodes, std::vector<Tri>& t, int b, int e) {
+  const int id = (int)nodes.size();
+  nodes.emplace_back();
+  {
+    Node& n = nodes[id];
+    for (int k = 0; k < 3; ++k) { n.lo[k] = t[b].lo[k]; n.hi[k] = t[b].hi[k]; }
+    for (int i = b + 1; i < e; ++i)
+      for (int k = 0; k < 3; ++k) { n.lo[k] = std::min(n.lo[k], t[i].lo[k]); n.hi[k] = std::max(n.hi[k], t[i].hi[k]); }
+  }
+  if (e - b == 1) {
+    nodes[id].prim = t[b].prim;
+    nodes[id].inst = t[b].inst;
+    return id;
+  }
+  const int n = e - b;
+  double best = 1e300;
+  int best_axis = 0, best_split = n / 2;
+  std::vector<float> right_area((size_t)n);
+  for (int axis = 0; axis < 3; ++axis) {
+    std::stable_sort(t.begin() + b, t.begin() + e, [axis](const Tri& x, const Tri& y) { return x.c[axis] < y.c[axis]; });
+    float lo[3], hi[3];
+    for (int i = n - 1; i >= 1; --i) {  // right_area[i] = area of the box of t[b + i .. e)
+      const Tri& q = t[b + i];
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = i == n - 1 ? q.lo[k] : std::min(lo[k], q.lo[k]);
+        hi[k] = i == n - 1 ? q.hi[k] : std::max(hi[k], q.hi[k]);
+      }
+      right_area[(size_t)i] = half_area(lo, hi);
+    }
+    for (int i = 1; i < n; ++i) {  // split: [b, b + i) | [b + i, e)
+      const Tri& q = t[b + i - 1];
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = i == 1 ? q.lo[k] : std::min(lo[k], q.lo[k]);
+        hi[k] = i == 1 ? q.hi[k] : std::max(hi[k], q.hi[k]);
+      }
+      const double cost = (double)half_area(lo, hi) * i + (double)right_area[(size_t)i] * (n - i);
+      if (cost < best) { best = cost; best_axis = axis; best_split = i; }
+    }
+  }
+  std::stable_sort(t.begin() + b, t.begin() + e, [best_axis](const Tri& x, const Tri& y) { return x.c[best_axis] < y.c[best_axis]; });
+  const int l = build(nodes, t, b, b + best_split);
+  const int r = build(nodes, t, b + best_split, e);
+  nodes[id].left = l;
+  nodes[id].right = r;
+  return id;
+}
+// depth-first flattening for direction octant `oct` (only the bits of `mask` are distinguished); returns the index after the subtree
+uint32_t emit(const std::vector<Node>& nodes, int id, uint32_t oct, uint32_t mask, std::vector<float4>& out, uint32_t at) {
+  const Node& n = nodes[id];
+  if (n.left < 0) {
+    out[2 * at] = make_float4(n.lo[0], n.lo[1], n.lo[2], as_f(HK_BVH_LEAF_FLAG | n.prim));
+    out[2 * at + 1] = make_float4(n.hi[0], n.hi[1], n.hi[2], as_f((at + 1u) | (n.inst << 16)));
+    return at + 1u;
+  }
+  const Node &a = nodes[n.left], &b = nodes[n.right];
+  int axis = 0;
+  float sep = -1.0f;
+  for (int k = 0; k < 3; ++k) {
+    const float d = std::fabs((b.lo[k] + b.hi[k]) - (a.lo[k] + a.hi[k]));
+    if (d > sep) { sep = d; axis = k; }
+  }
+  const bool a_smaller = (a.lo[axis] + a.hi[axis]) <= (b.lo[axis] + b.hi[axis]);
+  const bool negative = ((oct & mask) >> axis) & 1u;           // the ray travels towards smaller coordinates on this axis
+  const bool a_first = negative ? !a_smaller : a_smaller;
+  uint32_t next = emit(nodes, a_first ? n.left : n.right, oct, mask, out, at + 1u);
+  next = emit(nodes, a_first ? n.right : n.left, oct, mask, out, next);
+  out[2 * at] = make_float4(n.lo[0], n.lo[1], n.lo[2], as_f(at + 1u));
+  out[2 * at + 1] = make_float4(n.hi[0], n.hi[1], n.hi[2], as_f(next));
+  return next;
+}
+}  // namespace flatbvh
+
+// Fills `out` with `orderings` flattenings of (2 T - 1) nodes each; returns false when the scene does not qualify.
+bool build_flat_bvh(const hk_ctx* c, uint32_t orderings, std::vector<float4>& out, uint32_t& count) {
+  using namespace flatbvh;
+  std::vector<Tri> tris;
+  for (size_t i = 0; i < c->instances.size(); ++i) {
+    const HkInstance& in = c->instances[i];
+    for (uint32_t k = 0; k < in.mesh.node_count; ++k) {
+      const HkNode& nd = c->asset_nodes[in.mesh.node_offset + k];
+      if (nd.entry_index < HK_BVH_LEAF_FLAG) continue;
+      const size_t prim = (size_t)in.mesh.primitive + (nd.entry_index - HK_BVH_LEAF_FLAG);
+      if (prim >= c->primitives.size() || prim > 0xFFFFu) return false;
+      Tri t;
+      const HkPrimitiveVertex* v = c->primitives[prim].vertices;
+      for (int a = 0; a < 3; ++a) {
+        t.lo[a] = hmin(v[0].position[a], hmin(v[1].position[a], v[2].position[a]));  // = the BLAS leaf box (light.wgsl:408-412)
+        t.hi[a] = hmax(v[0].position[a], hmax(v[1].position[a], v[2].position[a]));
+        t.c[a] = 0.5f * (t.lo[a] + t.hi[a]);
+        if (!(t.lo[a] == t.lo[a]) || !(t.hi[a] == t.hi[a])) return false;  // NaN vertices: leave the scene to the reference walk
+      }
+      t.prim = (uint32_t)prim;
+      t.inst = (uint32_t)i;
+      tris.push_back(t);
+    }
+  }
+  if (tris.empty() || tris.size() > 0x7FFFu) return false;
+  std::vector<Node> nodes;
+  nodes.reserve(2 * tris.size());
+  build(nodes, tris, 0, (int)tris.size());
+  count = (uint32_t)nodes.size();
+  out.assign((size_t)orderings * count * 2, make_float4(0, 0, 0, 0));
+  std::vector<float4> one((size_t)count * 2);
+  for (uint32_t o = 0; o < orderings; ++o) {
+    if (emit(nodes, 0, o, orderings - 1u, one, 0u) != count) return false;
+    std::copy(one.begin(), one.end(), out.begin() + (size_t)o * count * 2);
+  }
+  return true;
+}
+
+int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_bytes) {
   const size_t n_tlas = c->instance_nodes.size();
   const int orderings = c->threaded ? 8 : 1;
   std::vector<std::vector<HkNode>> ordered;
@@ -663,6 +787,34 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o) {
   o.tex_info = blob.add(tex_info);
   o.srgb_lut = blob.add(srgb_lut);
   blob.bytes.resize((blob.bytes.size() + 31) & ~(size_t)31, 0);
+  // the one-level BVH (traverse_flat): only for scenes that stay inside the LDS copy WITH it, whose instances share one
+  // transform, outside the bit-exact verification mode; as many direction orderings (8, 4, 2, 1) as fit
+  o.flat = 0;
+  o.flat_count = o.flat_orderings = 0;
+  if (!(c->flags & HK_CTX_EXACT_TRAVERSAL) && !c->threaded && !c->instances.empty() && c->instances.size() <= 0xFFFFu && !getenv("HK_FLAT_DISABLE")) {
+    bool shared = true;
+    for (const HkInstance& in : c->instances)
+      if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) shared = false;
+    // direction orderings: as many (8, 4, 2, 1) as keep the node array within 4 KB - every workgroup copies the blob into LDS and
+    // the LDS a workgroup holds bounds the workgroups per CU; measured on the Cornell box (71 nodes, tools/ab_flat.sh): 1 / 2 / 4 / 8
+    // orderings walk equally fast (0.27 ms k_indirect) and the direct-light kernels lose 13 % with the 18 KB of eight
+    uint32_t want = 8, budget = 4096;
+    if (const char* e = getenv("HK_FLAT_ORDERINGS")) { want = (uint32_t)std::max(1, std::min(8, atoi(e))); budget = HK_LDS_SCENE_BYTES; }
+    while (want & (want - 1)) want &= want - 1;  // a power of two
+    std::vector<float4> flat;
+    uint32_t count = 0;
+    for (uint32_t ord = want; shared && ord >= 1; ord >>= 1) {
+      if (!build_flat_bvh(c, ord, flat, count)) break;
+      if (ord > 1 && flat.size() * 16 > budget) continue;
+      if (blob.bytes.size() + flat.size() * 16 + static_bytes <= HK_LDS_SCENE_BYTES && count <= 0xFFFFu) {
+        o.flat = blob.add(flat);
+        o.flat_count = count;
+        o.flat_orderings = ord;
+        blob.bytes.resize((blob.bytes.size() + 31) & ~(size_t)31, 0);
+        break;
+      }
+    }
+  }
   return HK_OK;
 }
 
@@ -683,6 +835,9 @@ void update_shared_transform(hk_ctx* c) {
   c->scene.shared_xform = 1u;
   for (const HkInstance& in : c->instances)
     if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) c->scene.shared_xform = 0u;
+  // the one-level BVH lives in the shared LOCAL space: it stays valid while the instances move together and is simply not
+  // walked once one of them moves on its own
+  c->scene.flat_mode = (c->dyn_off.flat_count && c->scene.shared_xform) ? 1u : 0u;
 }
 
 // point c->scene at the arrays of the slot in use
@@ -712,6 +867,9 @@ void point_scene_at_slot(hk_ctx* c) {
   s.tlas_stride = c->threaded ? (uint32_t)c->instance_nodes.size() : 0u;
   s.blas_stride = c->threaded ? (uint32_t)c->asset_nodes.size() : 0u;
   s.light_count = (uint32_t)c->emissive_nodes.size();
+  s.flat = (const float4*)(base + o.flat);
+  s.flat_count = o.flat_count;
+  s.flat_mask = o.flat_orderings ? o.flat_orderings - 1u : 0u;
   update_shared_transform(c);
 }
 
@@ -749,17 +907,17 @@ int finalize_scene(hk_ctx* c) {
   HK_REQUIRE(!(c->mirrors_stale && c->dynamic_dirty), HK_E_NOT_READY,
              "the instance-level arrays were last changed on the device (hk_refit_scene_instances): upload the instances again (hk_upload_scene_instances) "
              "before a change that rebuilds them on the host");
+  Blob st;  // (the mesh-level region first: whether the one-level BVH still fits the LDS copy depends on its size)
+  if (need_static && (rc = build_static_region(c, st, c->st_nodes, c->st_v0, c->st_v1, c->st_v2, c->st_vn, c->st_vuv))) return rc;
   Blob dyn;
   DynOffsets o{};
-  if ((rc = build_dynamic_region(c, dyn, o))) return rc;
+  if ((rc = build_dynamic_region(c, dyn, o, need_static ? st.bytes.size() : c->static_bytes))) return rc;
   c->dyn_off = o;
   c->rf_ready = false;
   c->rf_last_moved.clear();
   const bool in_place = !need_static && dyn.bytes.size() <= c->dyn_capacity;
   if (!(in_place && c->two_slots) && (rc = sync_all(c))) return rc;  // frames in flight still read the arrays rewritten below
   if (need_static) {
-    Blob st;
-    if ((rc = build_static_region(c, st, c->st_nodes, c->st_v0, c->st_v1, c->st_v2, c->st_vn, c->st_vuv))) return rc;
     if (c->scene_mem) { (void)hipFree(c->scene_mem); c->scene_mem = nullptr; }
     c->dyn_capacity = dyn.bytes.size();  // exact: a small scene stays small enough for the LDS copy
     c->static_bytes = st.bytes.size();
@@ -2032,6 +2190,16 @@ int hk_indirect_schedule(hk_ctx* c, uint32_t* out) {
   HK_HIP(hipSetDevice(c->device));
   { const int rc = finalize_scene(c); if (rc) return rc; }
   *out = use_wavefront(c) ? 1u : 0u;
+  return HK_OK;
+}
+
+int hk_traversal_mode(hk_ctx* c, uint32_t* out, uint32_t* orderings) {
+  HK_REQUIRE(c && out, HK_E_INVALID, "NULL argument");
+  HK_HIP(hipSetDevice(c->device));
+  { const int rc = finalize_scene(c); if (rc) return rc; }
+  HK_REQUIRE(c->scene_mem, HK_E_NOT_READY, "no scene uploaded");
+  *out = c->scene.flat_mode ? HK_TRAVERSAL_ONE_LEVEL : c->threaded ? HK_TRAVERSAL_THREADED : HK_TRAVERSAL_REFERENCE;
+  if (orderings) *orderings = c->scene.flat_mode ? c->scene.flat_mask + 1u : c->threaded ? 8u : 1u;
   return HK_OK;
 }
 

@@ -83,6 +83,12 @@ struct DScene {
   // 1 when every instance has the same (bitwise) inverse model matrix - a single-asset scene under one root transform, like the
   // Cornell box: the world -> local ray is then the same for every instance a ray enters (traverse_top)
   uint32_t shared_xform;
+  // One-level walk for scenes whose instances all share one transform (shared_xform) and that fit the LDS copy: ONE BVH over
+  // every triangle of every instance, in the shared local space (traverse_flat).  `flat` = flat_count 32-B nodes per ordering
+  // (lo = (min.xyz, entry), hi = (max.xyz, exit | instance << 16)), ordering k of flat_mask + 1 at node k * flat_count.
+  // flat_mode = 1: traverse_top takes this walk (stage_scene makes it a compile-time constant per kernel instantiation).
+  const float4* __restrict__ flat;
+  uint32_t flat_count, flat_mask, flat_mode;
 };
 // per-frame constants, passed by value (lands in SGPRs / scalar cache)
 struct DFrame {
@@ -434,12 +440,20 @@ HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t no
   }
   return intersected;
 }
-// Two-level stackless walk, light.wgsl:442-486 (TLAS) with light.wgsl:400-440 (BLAS) inlined as ONE
-// loop: every iteration each live lane takes exactly one node step - of the TLAS or of the BLAS it
-// is currently inside - so lanes that sit in different instances (or still in the TLAS) execute the
-// same load + slab-test stream instead of serialising nested loops under partial exec masks.  Only
-// the two rare events diverge: entering an instance (ray transform) and a triangle test.  Each
-// lane's own visit order, and therefore every result bit, is that of the reference's nested loops.
+// One-level walk (DScene::flat).  When every instance has the same transform - the Cornell box, any single asset under one
+// root - all triangles live in ONE local space and every instance entry of the reference's two-level walk forms the SAME
+// local ray.  A single BVH over all triangles, walked with that ray, therefore runs the reference's per-triangle arithmetic on
+// the reference's operands: distance, barycentrics, primitive and instance of the closest hit are the reference's bit for bit.
+// What can differ is only WHICH candidates are visited: the reference tests a triangle only if the world-space ray also
+// passed the slab test of its instance's world AABB (a ray grazing that box within rounding), and two candidates at exactly
+// the same distance are taken in visit order - both measure-zero events (tests: a handful of pixels per million), which is
+// why HK_CTX_EXACT_TRAVERSAL keeps the two-level walk for the bit-exact suite and this is the product default under the
+// north star's 1e-3 gate.
+// What it buys: one event kind instead of three.  In the two-level walk a 64-lane wave pays the node step, the triangle test
+// and the instance entry / BLAS exit bookkeeping in nearly every iteration because SOME lane needs each (lane utilisation
+// 0.36).  Here a leaf whose box is hit only QUEUES its triangle (up to HK_FLAT_CAP per lane) and the lane walks on; the
+// triangle-test block runs when some lane's queue is full or has nothing else to do, for every lane that has one queued - so
+// it runs in a third of the iterations with three times the lanes.
 #ifdef HK_PROFILE_SECTIONS
 extern __device__ unsigned long long g_walk_events[8];  // wave-iterations: all, with any triangle test, any instance entry, any BLAS exit; lane-iterations
 // exactly one lane - the lowest active one - counts each wave iteration, so early exits of other lanes lose nothing
@@ -448,7 +462,121 @@ extern __device__ unsigned long long g_walk_events[8];  // wave-iterations: all,
 #else
 #define HK_WALK_EVENT(k, cond) ((void)0)
 #endif
+#ifndef HK_FLAT_CAP
+#define HK_FLAT_CAP 2
+#endif
+HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, RayCounters& rc) {
+  rc.tlas++;
+  Hit hit;
+  hit.uv = F2(0.0f, 0.0f);
+  hit.distance = max_distance;
+  hit.instance_index = HK_U32_MAX;
+  hit.primitive_index = HK_U32_MAX;
+  const DInstance& in0 = sc.instances[0];
+  Ray lr;  // light.wgsl:459-461, the same for every instance
+  lr.origin = world_to_local_position(in0, ray.origin);
+  lr.direction = world_to_local_direction(in0, ray.direction);
+  lr.inv_direction = 1.0f / lr.direction;
+  const float4* __restrict__ nodes = sc.flat + 2u * ((ray_octant(lr.direction) & sc.flat_mask) * sc.flat_count);
+#ifdef HK_FLAT_FMA_SLAB
+  const f3 noi = F3(-lr.origin.x * lr.inv_direction.x, -lr.origin.y * lr.inv_direction.y, -lr.origin.z * lr.inv_direction.z);
+#endif
+  const uint32_t count = sc.flat_count;
+  uint32_t index = 0u, npend = 0u;
+  uint32_t pend[HK_FLAT_CAP];  // queued candidates, oldest first: primitive index | instance << 16
+#pragma unroll
+  for (int k = 0; k < HK_FLAT_CAP; ++k) pend[k] = 0u;
+#ifdef HK_PROFILE_SECTIONS
+  // [0] wave iterations, [1] of which ran the triangle-test block, [4] lanes walking a node (summed), [5] lanes testing a triangle
+  // (summed), [6] rays, [7] lanes inside the loop (summed)
+  uint32_t wev_[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  struct WalkFlush {
+    uint32_t* w;
+    __device__ ~WalkFlush() {
+      for (int k = 0; k < 8; ++k)
+        if (w[k]) atomicAdd(&g_walk_events[k], (unsigned long long)w[k]);
+    }
+  } wflush_{wev_};
+  {
+    const uint32_t lanes_ = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
+    if (HK_WALK_LEADER()) wev_[6] += lanes_;
+  }
+#endif
+  for (;;) {
+#ifdef HK_PROFILE_SECTIONS
+    {
+      const uint32_t in_ = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
+      const uint32_t walking_ = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(index < count));
+      if (HK_WALK_LEADER()) { wev_[0] += 1u; wev_[4] += walking_; wev_[7] += in_; }
+    }
+#endif
+    if (index < count) {
+      const float4 lo = nodes[2u * index];
+      const float4 hi = nodes[2u * index + 1u];
+      const uint32_t entry = f2u(lo.w), link = f2u(hi.w);
+#ifdef HK_FLAT_FMA_SLAB
+      const f3 t1 = F3(fmaf(lo.x, lr.inv_direction.x, noi.x), fmaf(lo.y, lr.inv_direction.y, noi.y), fmaf(lo.z, lr.inv_direction.z, noi.z));
+      const f3 t2 = F3(fmaf(hi.x, lr.inv_direction.x, noi.x), fmaf(hi.y, lr.inv_direction.y, noi.y), fmaf(hi.z, lr.inv_direction.z, noi.z));
+#else
+      const f3 t1 = (xyz(lo) - lr.origin) * lr.inv_direction;  // intersects_aabb, light.wgsl:344-362
+      const f3 t2 = (xyz(hi) - lr.origin) * lr.inv_direction;
+#endif
+      float t_min = fmin_(t1.x, t2.x);
+      float t_max = fmax_(t1.x, t2.x);
+      t_min = fmax_(t_min, fmin_(t1.y, t2.y));
+      t_max = fmin_(t_max, fmax_(t1.y, t2.y));
+      t_min = fmax_(t_min, fmin_(t1.z, t2.z));
+      t_max = fmin_(t_max, fmax_(t1.z, t2.z));
+      const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
+      const bool box_hit = t_box < hit.distance;
+      const bool leaf = entry >= HK_LEAF;
+      index = (leaf || !box_hit) ? (link & 0xFFFFu) : index + 1u;  // depth-first layout: an inner node's first child follows it
+      if (leaf && box_hit && (link >> 16) != exclude_instance) {
+        const uint32_t cand = (entry & 0xFFFFu) | (link & 0xFFFF0000u);
+#pragma unroll
+        for (int k = 0; k < HK_FLAT_CAP; ++k)
+          if (npend == (uint32_t)k) pend[k] = cand;
+        npend += 1u;
+      }
+    }
+    const bool want = npend == (uint32_t)HK_FLAT_CAP || (npend > 0u && index >= count);
+    if (__builtin_amdgcn_ballot_w64(want) != 0ull) {  // wave-uniform: everybody with a queued candidate tests its oldest
+#ifdef HK_PROFILE_SECTIONS
+      {
+        const uint32_t testing_ = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(npend > 0u));
+        if (HK_WALK_LEADER()) { wev_[1] += 1u; wev_[5] += testing_; }
+      }
+#endif
+      if (npend > 0u) {
+        const uint32_t cand = pend[0];
+#pragma unroll
+        for (int k = 0; k + 1 < HK_FLAT_CAP; ++k) pend[k] = pend[k + 1];
+        npend -= 1u;
+        const uint32_t primitive_index = cand & 0xFFFFu;
+        f2 uv;
+        const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+        if (d < hit.distance) {
+          hit.uv = uv;
+          hit.distance = d;
+          hit.primitive_index = primitive_index;
+          hit.instance_index = cand >> 16;
+          if (d < early_distance) return hit;  // light.wgsl:421-423, 466-469
+        }
+      }
+    }
+    if (index >= count && npend == 0u) break;
+  }
+  return hit;
+}
+
+// Two-level stackless walk, light.wgsl:442-486 (TLAS) with light.wgsl:400-440 (BLAS) inlined as ONE
+// loop: every iteration each live lane takes exactly one node step - of the TLAS or of the BLAS it
+// is currently inside - so lanes that sit in different instances (or still in the TLAS) execute the
+// same load + slab-test stream instead of serialising nested loops under partial exec masks.  Only
+// the two rare events diverge: entering an instance (ray transform) and a triangle test.  Each
+// lane's own visit order, and therefore every result bit, is that of the reference's nested loops.
 HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, RayCounters& rc) {
+  if (sc.flat_mode) return traverse_flat(sc, ray, max_distance, early_distance, exclude_instance, rc);
   rc.tlas++;
 #ifdef HK_PROFILE_SECTIONS
   uint32_t wev_[5] = {0u, 0u, 0u, 0u, 0u};

@@ -14,10 +14,15 @@ namespace hkd {
 // an L1-hit global load (~120+ cycles) in the dependent load -> slab test -> next-index chain.
 // (Skipping the copy in workgroups whose pixels are all background - 63 % of the Cornell frame - was measured and
 // rejected: the vote needs the depth first, which puts an HBM round trip in front of the copy; 0.417 vs 0.38 ms.)
-template <bool LDS>
+// MODE: 0 = global memory, two-level walk; 1 = LDS copy, two-level walk; 2 = LDS copy, one-level walk (DScene::flat);
+// 3 = global memory, one-level walk (the ray-counting replay of a scene the timed kernels walk in mode 2: same visits, same
+// bits).  (bool converts: true = 1, false = 0.)  The walk is a compile-time constant of the instantiation.
+template <int MODE>
 __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
-  if constexpr (!LDS) {
-    return sc;
+  if constexpr (MODE == 0 || MODE == 3) {
+    DScene g = sc;
+    g.flat_mode = MODE == 3 ? 1u : 0u;
+    return g;
   } else {
     extern __shared__ __attribute__((aligned(16))) float4 hk_smem[];
     for (uint32_t i = threadIdx.x; i < sc.blob_f4; i += 256u) hk_smem[i] = sc.blob[i];
@@ -25,10 +30,12 @@ __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
     DScene l = sc;
     l.tlas_stride = 0u;  // (a scene that fits the LDS copy keeps the reference's single order: compile-time zeros, the octant arithmetic folds away)
     l.blas_stride = 0u;
+    l.flat_mode = MODE == 2 ? 1u : 0u;
     const char* gb = reinterpret_cast<const char*>(sc.blob);
     const char* lb = reinterpret_cast<const char*>(hk_smem);
 #define HK_REBASE(field) l.field = reinterpret_cast<decltype(l.field)>(lb + (reinterpret_cast<const char*>(sc.field) - gb))
     HK_REBASE(nodes); HK_REBASE(instances);
+    if (MODE == 2) HK_REBASE(flat);
     HK_REBASE(tri_v0); HK_REBASE(tri_v1); HK_REBASE(tri_v2); HK_REBASE(vtx_normal); HK_REBASE(vtx_uv);
     HK_REBASE(materials); HK_REBASE(tex_info); HK_REBASE(srgb_lut); HK_REBASE(light_lo); HK_REBASE(light_hi); HK_REBASE(emissives); HK_REBASE(alias);
 #undef HK_REBASE

@@ -64,7 +64,7 @@ __device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams
   return ray;
 }
 
-template <bool COUNT, bool LDS>
+template <bool COUNT, int LDS>
 __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
                                                   unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_full_screen_albedo(DScene sc, DFrame fr
 }
 
 // ------------------------------------------------------------------ direct_lit
-template <bool EMISSIVE_LIT, bool COUNT, bool LDS>
+template <bool EMISSIVE_LIT, bool COUNT, int LDS>
 __global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                      unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
@@ -453,8 +453,11 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
 }
 
 // ------------------------------------------------------------------ indirect_lit_ambient
-template <bool MULTIPLE_BOUNCES, bool COUNT, bool LDS>
-__global__ __launch_bounds__(256, 4) void k_indirect(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+#ifndef HK_INDIRECT_FLAT_WAVES
+#define HK_INDIRECT_FLAT_WAVES 4
+#endif
+template <bool MULTIPLE_BOUNCES, bool COUNT, int LDS>
+__global__ __launch_bounds__(256, (LDS == 2 ? HK_INDIRECT_FLAT_WAVES : 4)) void k_indirect(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                    unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
@@ -862,12 +865,18 @@ void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const fl
   pp.jitter_y = jitter_y;
   dim3 grid = grid_for(fr.dw, y1 - y0);
   const size_t lds = lds_bytes_for(sc);
-  if (counters)
-    hipLaunchKernelGGL((k_prepass<true, false>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+  // (stage_scene's MODE: 0 global, 1 LDS copy, 2 LDS copy + one-level walk, 3 global + one-level walk for the counting replay)
+  const bool flat = sc.flat_mode != 0u && lds;
+  if (counters && flat)
+    hipLaunchKernelGGL((k_prepass<true, 3>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+  else if (counters)
+    hipLaunchKernelGGL((k_prepass<true, 0>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+  else if (flat)
+    hipLaunchKernelGGL((k_prepass<false, 2>), grid, dim3(256), lds, st, sc, fr, pp, g, y0, y1, counters);
   else if (lds)
-    hipLaunchKernelGGL((k_prepass<false, true>), grid, dim3(256), lds, st, sc, fr, pp, g, y0, y1, counters);
+    hipLaunchKernelGGL((k_prepass<false, 1>), grid, dim3(256), lds, st, sc, fr, pp, g, y0, y1, counters);
   else
-    hipLaunchKernelGGL((k_prepass<false, false>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+    hipLaunchKernelGGL((k_prepass<false, 0>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
 }
 void launch_albedo(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, void* albedo, int y0, int y1) {
   if (y1 <= y0) return;
@@ -878,10 +887,13 @@ void launch_direct(hipStream_t st, bool emissive_lit, const DScene& sc, const DF
   if (y1 <= y0) return;
   dim3 grid = grid_for(fr.rw, y1 - y0);
   const size_t lds = lds_bytes_for(sc);
-#define HK_LAUNCH(E)                                                                                                           \
-  if (counters) hipLaunchKernelGGL((k_direct_lit<E, true, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);      \
-  else if (lds) hipLaunchKernelGGL((k_direct_lit<E, false, true>), grid, dim3(256), lds, st, sc, fr, g, t, y0, y1, counters);    \
-  else hipLaunchKernelGGL((k_direct_lit<E, false, false>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
+  const bool flat = sc.flat_mode != 0u && lds;
+#define HK_LAUNCH(E)                                                                                                                     \
+  if (counters && flat) hipLaunchKernelGGL((k_direct_lit<E, true, 3>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);          \
+  else if (counters) hipLaunchKernelGGL((k_direct_lit<E, true, 0>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);             \
+  else if (flat) hipLaunchKernelGGL((k_direct_lit<E, false, 2>), grid, dim3(256), lds, st, sc, fr, g, t, y0, y1, counters);              \
+  else if (lds) hipLaunchKernelGGL((k_direct_lit<E, false, 1>), grid, dim3(256), lds, st, sc, fr, g, t, y0, y1, counters);               \
+  else hipLaunchKernelGGL((k_direct_lit<E, false, 0>), grid, dim3(256), 0, st, sc, fr, g, t, y0, y1, counters);
   if (emissive_lit) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
 #undef HK_LAUNCH
 }
@@ -892,10 +904,13 @@ void launch_indirect(hipStream_t st, bool multiple_bounces, const DScene& sc, co
   if (y1 <= y0) return;
   dim3 grid = grid_for(fr.rw, y1 - y0);
   const size_t lds = lds_bytes_for(sc);
+  const bool flat = sc.flat_mode != 0u && lds;
 #define HK_LAUNCH(M)                                                                                                                              \
-  if (counters) hipExtLaunchKernelGGL((k_indirect<M, true, false>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);      \
-  else if (lds) hipExtLaunchKernelGGL((k_indirect<M, false, true>), grid, dim3(256), (uint32_t)lds, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);    \
-  else hipExtLaunchKernelGGL((k_indirect<M, false, false>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);
+  if (counters && flat) hipExtLaunchKernelGGL((k_indirect<M, true, 3>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);  \
+  else if (counters) hipExtLaunchKernelGGL((k_indirect<M, true, 0>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);     \
+  else if (flat) hipExtLaunchKernelGGL((k_indirect<M, false, 2>), grid, dim3(256), (uint32_t)lds, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);   \
+  else if (lds) hipExtLaunchKernelGGL((k_indirect<M, false, 1>), grid, dim3(256), (uint32_t)lds, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);    \
+  else hipExtLaunchKernelGGL((k_indirect<M, false, 0>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, y0, y1, counters);
   if (multiple_bounces) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
 #undef HK_LAUNCH
 }

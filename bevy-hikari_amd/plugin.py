@@ -592,6 +592,12 @@ class Engine:
         self.api.call("indirect_schedule", self.ctx, C.byref(v))
         return "wavefront" if v.value else "fused"
 
+    def traversal_mode(self):
+        """('reference' | 'threaded' | 'one-level', stored direction orderings): hk_traversal_mode."""
+        v, n = C.c_uint32(), C.c_uint32()
+        self.api.call("traversal_mode", self.ctx, C.byref(v), C.byref(n))
+        return ("reference", "threaded", "one-level")[v.value], n.value
+
     def measure_hbm(self, bytes_per_array=1 << 30, reps=8):
         """Empirical HBM ceiling: (copy GB/s, triad GB/s) of grid-stride float4 streams over arrays too big for the Infinity Cache."""
         cp, tr = C.c_double(), C.c_double()

@@ -635,6 +635,19 @@ int hk_reset_stats(hk_ctx* ctx);
 /* Which schedule the indirect_lit_ambient dispatch of the frame most recently begun takes (see HK_CTX_WAVEFRONT): 0 = fused
  * kernel, 1 = wavefront (ray queues).  Depends on the flags, the frame's indirect_bounces and the size of the uploaded scene. */
 int hk_indirect_schedule(hk_ctx* ctx, uint32_t* out);
+/* How rays walk the scene currently uploaded (light.wgsl:400-486 is the reference walk):
+ *   HK_TRAVERSAL_REFERENCE  the reference's two-level walk in the reference's node order - bit-exact; always with
+ *                           HK_CTX_EXACT_TRAVERSAL, and for LDS-resident scenes whose instances do not share one transform
+ *   HK_TRAVERSAL_THREADED   the two-level walk over eight direction-ordered flattenings (scenes beyond the LDS copy)
+ *   HK_TRAVERSAL_ONE_LEVEL  ONE BVH over all triangles in the instances' shared local space (LDS-resident scenes whose
+ *                           instances all have the same transform, e.g. the Cornell box): the reference's per-triangle
+ *                           arithmetic on the reference's operands, so the closest hit is the reference's except where a
+ *                           ray grazes an instance's world box within rounding or two candidates tie exactly.
+ * orderings (may be NULL): how many direction orderings of the trees are stored (1, 2, 4 or 8). */
+#define HK_TRAVERSAL_REFERENCE 0u
+#define HK_TRAVERSAL_THREADED 1u
+#define HK_TRAVERSAL_ONE_LEVEL 2u
+int hk_traversal_mode(hk_ctx* ctx, uint32_t* out, uint32_t* orderings);
 
 /* Measurement hook ("measure the empirical HBM ceiling with a device copy/triad kernel in the same run"): streams
  * three private arrays of `bytes_per_array` bytes (use >= 1 GiB: the 256 MB Infinity Cache must not hold them) `reps` times

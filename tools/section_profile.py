@@ -17,7 +17,7 @@ NAMES = ["prologue+idle", "sample+ray setup", "closest-hit traversal", "hit_info
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
     csrc = os.path.join(ROOT, "bevy-hikari_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "context.hip", "host_logic.cpp", "scene_builder.cpp")]
+    srcs = [os.path.join(csrc, f) for f in ("kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "kernels_wavefront.hip", "kernels_scene.hip", "context.hip", "host_logic.cpp", "scene_builder.cpp", "comm.cpp")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DHK_ABLATE_WALK_TWICE" if TWICE else "-DHK_PROFILE_SECTIONS",
                     "-o", VARIANT] + srcs, check=True, cwd=csrc)
     print("built", VARIANT)
@@ -64,4 +64,11 @@ print(json.dumps({"workload": f"cornell {w}x{h} b{bounces}", "frames": 20,
                   # every walk of the frame (all ray kernels): what a wave pays per loop iteration
                   "walk": {"wave_iterations_per_frame": out[16] / 20, "with_a_triangle_test": round(out[17] / out[16], 4),
                            "with_an_instance_entry": round(out[18] / out[16], 4), "with_a_blas_exit": round(out[19] / out[16], 4),
-                           "active_lanes_per_iteration": round(out[20] / out[16], 2)}}, indent=1))
+                           "active_lanes_per_iteration": round(out[20] / out[16], 2)},
+                  # the one-level walk counts differently (hk_device.hpp traverse_flat): slots 0 / 1 / 4..7
+                  "one_level_walk": {"traversal": list(p.engine.traversal_mode()), "rays_per_frame": out[22] / 20, "wave_iterations_per_frame": out[16] / 20,
+                                     "iterations_with_the_test_block": round(out[17] / max(out[16], 1), 4),
+                                     "lanes_in_the_loop_per_iteration": round(out[23] / max(out[16], 1), 2),
+                                     "lanes_walking_a_node_per_iteration": round(out[20] / max(out[16], 1), 2),
+                                     "lanes_testing_per_test_block": round(out[21] / max(out[17], 1), 2),
+                                     "node_steps_per_ray": round(out[20] / max(out[22], 1), 2), "triangle_tests_per_ray": round(out[21] / max(out[22], 1), 2)}}, indent=1))
