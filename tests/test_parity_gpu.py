@@ -375,8 +375,9 @@ def _threaded_vs_exact(name, scene, cam, s, lights, frames, tol_pixels):
     hit_diff = float((ia[..., 0] != ib[..., 0]).mean())
     pos_diff = float((pa.view(np.uint32) != pb.view(np.uint32)).any(axis=2).mean())
     sf, se = fast.engine.stats(), exact.engine.stats()
-    report = {"case": name, "rel_l2": rel, "primary_hit_instance_differs": hit_diff, "gbuffer_position_differs": pos_diff,
-              "rays": [int(sf.rays_tlas + sf.rays_blas), int(se.rays_tlas + se.rays_blas)]}
+    report = {"case": name, "traversal": list(fast.engine.traversal_mode()), "rel_l2": rel, "primary_hit_instance_differs": hit_diff,
+              "gbuffer_position_differs": pos_diff, "rays": [int(sf.rays_tlas + sf.rays_blas), int(se.rays_tlas + se.rays_blas)]}
+    assert fast.engine.traversal_mode()[0] == "threaded" and exact.engine.traversal_mode()[0] == "reference"
     print("threaded vs exact traversal:", report)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
