@@ -193,6 +193,9 @@ _PRODUCT_ONLY = {
     "scene_builder_add_material": [_vp, P(HkMaterial), P(u32)],
     "scene_builder_add_instance": [_vp, u32, u32, P(f32), P(u32)],
     "scene_builder_finish": [_vp],
+    "scene_builder_finish_instances": [_vp],
+    "scene_builder_remove_instance": [_vp, u32],
+    "scene_builder_set_instance_material": [_vp, u32, u32],
     "scene_builder_set_instance_transform": [_vp, u32, P(f32)],
     "scene_builder_previous_transforms": [_vp, P(P(f32)), P(u32)],
     "scene_builder_vertices": [_vp, P(P(HkVertex)), P(u32)],
@@ -208,6 +211,7 @@ _PRODUCT_ONLY = {
     "upload_scene_instances": [_vp, _vp],
     "refit_scene_instances": [_vp, _vp, P(u32)],
     "rebuild_scene_trees": [_vp, u32],
+    "update_scene_instances": [_vp, _vp, u32],
     "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
@@ -233,6 +237,7 @@ _PRODUCT_ONLY = {
     "multi_upload_scene_instances": [_vp, _vp],
     "multi_refit_scene_instances": [_vp, _vp, P(u32)],
     "multi_rebuild_scene_trees": [_vp, u32],
+    "multi_update_scene_instances": [_vp, _vp, u32],
     "multi_upload_textures": [_vp, P(HkImageDesc), u32],
     "multi_upload_noise": [_vp, _vp, C.c_size_t],
     "multi_resize": [_vp, u32, u32, f32],

@@ -391,6 +391,22 @@ int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out) {
 int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene(c, b)); }
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene_instances(c, b)); }
 int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode) { HK_EACH(hk_rebuild_scene_trees(c, mode)); }
+// the builder is finished ONCE (its transform bookkeeping advances once), every band's replica takes the records and builds its trees
+int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t tree_mode) {
+  HK_REQUIRE(m && b, HK_E_INVALID, "NULL argument");
+  const int rc = hk_scene_builder_finish_instances(b);
+  if (rc) return rc;
+  uint32_t ni = 0;
+  const HkInstance* inst = nullptr;
+  const int rq = hk_scene_builder_instances(b, &inst, &ni);
+  if (rq) return rq;
+  for (hk_ctx* c : m->ctx) {
+    int r = hk_upload_scene_instances(c, b);
+    if (!r && ni >= 2) r = hk_rebuild_scene_trees(c, tree_mode);
+    if (r) return r;
+  }
+  return HK_OK;
+}
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n) { HK_EACH(hk_upload_textures(c, images, n)); }
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes) { HK_EACH(hk_upload_noise(c, rgba, bytes)); }
 int hk_multi_resize(hk_multi* m, uint32_t w, uint32_t h, float ratio) {

@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <thread>
 #include <utility>
@@ -201,6 +202,10 @@ struct hk_ctx {
   // order, so neither the host nor the GPU waits (animated scenes must not stall on the host).
   bool two_slots = false;
   int slot = 0;
+  Blob dyn_blob;                // the instance-level region as last laid out: kept so that a per-frame update re-uses warm pages
+  std::vector<float4> tlas_tmp;  // (20 MB of fresh allocations per update cost more in page faults than the layout itself)
+  bool trees_pending_on_device = false;  // hk_update_scene_instances: the trees about to be uploaded are stand-ins the device overwrites in
+                                         // stream order - no point threading their orderings on the host
   bool threaded = false;  // eight direction-ordered flattenings of every TLAS / BLAS are stored (hikari_hip.h HK_CTX_EXACT_TRAVERSAL)
   uint8_t* staging[2] = {nullptr, nullptr};
   size_t staging_bytes[2] = {0, 0};
@@ -453,16 +458,39 @@ void thread_orderings(const std::vector<HkNode>& src, const std::vector<std::pai
   out.assign((size_t)orderings, std::vector<HkNode>());
   out[0] = src;
   if (orderings <= 1) return;
-  std::vector<std::thread> workers;
-  for (int o = 1; o < orderings; ++o) {
-    out[o] = src;
-    workers.emplace_back([&, o]() {
-      for (const auto& r : ranges)
-        if (r.second && !rethread_flat_bvh(src.data() + r.first, r.second, (uint32_t)o, out[o].data() + r.first))
-          std::copy(src.begin() + r.first, src.begin() + r.first + r.second, out[o].begin() + r.first);
-    });
+  auto rethread = [&](int o) {
+    for (const auto& r : ranges)
+      if (r.second && !rethread_flat_bvh(src.data() + r.first, r.second, (uint32_t)o, out[o].data() + r.first))
+        std::copy(src.begin() + r.first, src.begin() + r.first + r.second, out[o].begin() + r.first);
+  };
+  for (int o = 1; o < orderings; ++o) out[o] = src;
+  // Small trees (the instance tree of an animated frame, a few thousand nodes) are re-threaded on the calling thread: spawning
+  // seven threads costs more than the work and sits on the per-frame path.  Large mesh trees use worker threads; a thread that
+  // cannot be created, or a worker that throws (bad_alloc), must not escape through the extern "C" boundary: the orderings it did
+  // not produce are redone serially here.
+  size_t total = 0;
+  for (const auto& r : ranges) total += r.second;
+  std::vector<uint8_t> done((size_t)orderings, 0);
+  if (total >= 8192) {
+    std::vector<std::thread> workers;
+    try {
+      for (int o = 1; o < orderings; ++o)
+        workers.emplace_back([&, o]() {
+          try {
+            rethread(o);
+            done[(size_t)o] = 1;
+          } catch (...) {
+          }
+        });
+    } catch (...) {
+    }
+    for (std::thread& w : workers) w.join();
   }
-  for (std::thread& w : workers) w.join();
+  for (int o = 1; o < orderings; ++o)
+    if (!done[(size_t)o]) {
+      out[o] = src;
+      rethread(o);
+    }
 }
 
 // mesh-level region; fills c->node_prim_offset.  Needs the instances' mesh records to know which
@@ -659,11 +687,16 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_byt
   const size_t n_tlas = c->instance_nodes.size();
   const int orderings = c->threaded ? 8 : 1;
   std::vector<std::vector<HkNode>> ordered;
-  thread_orderings(c->instance_nodes, {{0u, (uint32_t)n_tlas}}, orderings, ordered);
+  // hk_update_scene_instances: the device is about to build every ordering of this tree in stream order - ordering 0 is laid
+  // out (its leaf boxes are where the device build reads the instances' boxes from), the other seven slots stay zero
+  const int host_orderings = c->trees_pending_on_device ? 1 : orderings;
+  if (c->trees_pending_on_device) ordered.assign(1, c->instance_nodes);
+  else thread_orderings(c->instance_nodes, {{0u, (uint32_t)n_tlas}}, orderings, ordered);
   std::vector<float4> tlo(n_tlas), thi(n_tlas);
-  std::vector<float4> tlas;
+  std::vector<float4>& tlas = c->tlas_tmp;
+  tlas.clear();
   tlas.reserve(2 * n_tlas * (size_t)orderings);
-  for (int ord = 0; ord < orderings; ++ord) {
+  for (int ord = 0; ord < host_orderings; ++ord) {
     for (size_t i = 0; i < n_tlas; ++i) {
       const HkNode& n = ordered[ord][i];
       const float* mn = n.min;
@@ -680,6 +713,7 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_byt
     fold_leaf_navigators(tlo, thi, 0, n_tlas);
     for (size_t i = 0; i < n_tlas; ++i) { tlas.push_back(tlo[i]); tlas.push_back(thi[i]); }
   }
+  tlas.resize(2 * n_tlas * (size_t)orderings, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   o.tlas = blob.add(tlas);  // offset 0: ordering `ord` starts at node ord * n_tlas
 
   const bool have_prev = c->prev_models.size() == 16 * c->instances.size();
@@ -909,9 +943,12 @@ int finalize_scene(hk_ctx* c) {
              "before a change that rebuilds them on the host");
   Blob st;  // (the mesh-level region first: whether the one-level BVH still fits the LDS copy depends on its size)
   if (need_static && (rc = build_static_region(c, st, c->st_nodes, c->st_v0, c->st_v1, c->st_v2, c->st_vn, c->st_vuv))) return rc;
-  Blob dyn;
+  Blob& dyn = c->dyn_blob;
+  dyn.bytes.clear();
   DynOffsets o{};
+  const double tb0_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   if ((rc = build_dynamic_region(c, dyn, o, need_static ? st.bytes.size() : c->static_bytes))) return rc;
+  if (getenv("HK_TRACE_UPDATE")) fprintf(stderr, "  build_dynamic_region %.2f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tb0_, dyn.bytes.size());
   c->dyn_off = o;
   c->rf_ready = false;
   c->rf_last_moved.clear();
@@ -1510,6 +1547,34 @@ int hk_upload_scene_instances(hk_ctx* c, const hk_scene_builder* b) {
   if ((rc = hk_scene_builder_previous_transforms(b, &pm, &npm))) return rc;
   if ((rc = hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal))) return rc;
   return hk_upload_previous_transforms(c, pm, npm);
+}
+
+// Instances added, removed or re-materialed (the reference re-runs prepare_instances for ANY instance change, instance.rs:352-437):
+// the per-instance / per-emitter records are laid out on the host - O(instances), no tree build - and go to the spare slot through
+// the asynchronous upload; both trees are then built on the device (hk_rebuild_scene_trees: HK_TREE_SAH = the reference's own
+// tree, link for link).  What the host no longer does is the two `BVH::build` calls: 1.1 ms of 1.7 ms at 2 000 instances, 30 of
+// 32 ms at 20 000.
+int hk_update_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t tree_mode) {
+  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(tree_mode == HK_TREE_SAH || tree_mode == HK_TREE_LBVH, HK_E_INVALID, "unknown tree build mode %u", tree_mode);
+  int rc;
+  const bool trace = getenv("HK_TRACE_UPDATE") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
+  if ((rc = hk_scene_builder_finish_instances(b))) return rc;
+  const double t1 = now();
+  if ((rc = hk_upload_scene_instances(c, b))) return rc;
+  const double t2 = now();
+  uint32_t ni = 0;
+  const HkInstance* inst = nullptr;
+  if ((rc = hk_scene_builder_instances(b, &inst, &ni))) return rc;
+  c->trees_pending_on_device = ni >= 2;
+  rc = finalize_scene(c);
+  c->trees_pending_on_device = false;
+  const double t3 = now();
+  if (!rc && ni >= 2) rc = hk_rebuild_scene_trees(c, tree_mode);  // (a tree of one leaf is what the host just laid out)
+  if (trace) fprintf(stderr, "hk_update_scene_instances: finish_instances %.2f ms, mirrors %.2f ms, layout + upload %.2f ms, device build enqueue %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
+  return rc;
 }
 
 // ---- instance motion on the device (kernels_scene.hip) --------------------------------------------------

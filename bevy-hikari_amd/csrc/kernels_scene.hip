@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void k_refit_instances(RefitScene s, const Refi
   }
   float itm[16];
   if (!inverse_transpose(up.model, itm)) {
-    atomicMax(failed, id + 1u);
+    if (failed) atomicMax(failed, id + 1u);  // (the host has checked every pose with the same arithmetic: it passes NULL)
     return;
   }
   // previous model = the model this instance was rendered with so far (prepass.wgsl:50,96)
@@ -132,16 +132,45 @@ __global__ __launch_bounds__(64) void k_refit_instances(RefitScene s, const Refi
   }
   const float radius = 0.5f * sqrtf(d2) + sqrtf(intensity);
   em.position_radius = make_float4(pos[0], pos[1], pos[2], radius);
-  // GpuMesh::transformed_primitive_areas (mod.rs:307-318) and build_alias_table (mod.rs:320-376) on this emitter's triangles
+  // (its area sum and alias table: k_refit_emitters, one WAVE per emitter)
+}
+
+// GpuMesh::transformed_primitive_areas (mod.rs:307-318) and build_alias_table (mod.rs:320-376) of every emitter among the update
+// records: one WAVE per record (one THREAD per emitter ran all of it until round 3 - O(n) dependent global loads for the
+// 2 000-triangle emissive sphere of examples/scene.rs:231-235).  What has to be sequential stays sequential, so every bit is the
+// host builder's:
+//   1. the n triangle areas: lanes stride over the triangles (independent values, the sequential code's arithmetic each);
+//   2. surface_area: ONE lane adds them in index order (f32 addition does not associate);
+//   3. the two stacks of the alias construction hold the over- / under-full indices in increasing order: a wave-wide ordered
+//      compaction, 64 triangles per step, writes exactly those sequences;
+//   4. the pairing loop pops and pushes the stacks one element at a time: one lane - but on stacks that live in LDS whenever the
+//      five work arrays fit (n <= 3 264), so its dependent loads cost ~100 cycles instead of a trip to L2 each.
+constexpr uint32_t HK_EMITTER_LDS_TRIANGLES = 3264u;  // 5 arrays x 4 B x n <= 65 280 B of dynamic LDS
+__global__ __launch_bounds__(64) void k_refit_emitters(RefitScene s, const RefitUpdate* __restrict__ updates, uint32_t n_updates) {
+  extern __shared__ __attribute__((aligned(16))) float emitter_lds[];
+  const uint32_t u = blockIdx.x, lane = threadIdx.x;
+  if (u >= n_updates) return;
+  if (updates[u].moved == 0u) return;
+  const uint32_t id = updates[u].instance;
+  const uint32_t e = s.emissive_of_instance[id];
+  if (e == HK_U32_MAX) return;
+  float m[16];  // (the records sit in pinned host memory: read once)
+  for (int k = 0; k < 16; ++k) m[k] = updates[u].model[k];
+  {  // a singular pose leaves the instance record alone (k_refit_instances): then the emitter record stays as well
+    float itm[16];
+    if (!inverse_transpose(m, itm)) return;
+  }
+  DEmissive& em = s.emissives[e];
+  const uint32_t prim0 = s.instances[id].primitive;
   const uint32_t n = em.alias_count;  // = the mesh's triangle count
-  float* areas = s.alias_scratch + 5u * (size_t)em.alias_offset;  // [n] areas, then the two stacks (id, prob) x 2
-  uint32_t* over_id = reinterpret_cast<uint32_t*>(areas + n);
-  float* over_p = areas + 2u * n;
-  uint32_t* under_id = reinterpret_cast<uint32_t*>(areas + 3u * n);
-  float* under_p = areas + 4u * n;
-  float surface_area = 0.0f;
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint32_t prim = d.primitive + i;
+  float* work = n <= HK_EMITTER_LDS_TRIANGLES ? emitter_lds : s.alias_scratch + 5u * (size_t)em.alias_offset;
+  float* areas = work;  // [n] areas, then the two stacks (id, prob) x 2
+  uint32_t* over_id = reinterpret_cast<uint32_t*>(work + n);
+  float* over_p = work + 2u * (size_t)n;
+  uint32_t* under_id = reinterpret_cast<uint32_t*>(work + 3u * (size_t)n);
+  float* under_p = work + 4u * (size_t)n;
+  for (uint32_t i = lane; i < n; i += 64u) {
+    const uint32_t prim = prim0 + i;
     const float4 q0 = s.tri_v0[prim], q1 = s.tri_v1[prim], q2 = s.tri_v2[prim];
     const float l0[3] = {q0.x, q0.y, q0.z}, l1[3] = {q1.x, q1.y, q1.z}, l2[3] = {q2.x, q2.y, q2.z};
     float v0[3], v1[3], v2[3];
@@ -151,23 +180,39 @@ __global__ __launch_bounds__(64) void k_refit_instances(RefitScene s, const Refi
     const float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
     const float b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
     const float c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-    const float area = 0.5f * fabsf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]));
-    areas[i] = area;
-    surface_area += area;
+    areas[i] = 0.5f * fabsf(sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]));
   }
-  em.surface_area = surface_area;
+  __syncthreads();
+  float surface_area = 0.0f;
+  if (lane == 0u) {
+    for (uint32_t i = 0; i < n; ++i) surface_area += areas[i];
+    em.surface_area = surface_area;
+  }
+  surface_area = __shfl(surface_area, 0);
   const float mean_area = surface_area / (float)n;
-  uint32_t n_over = 0u, n_under = 0u;
-  for (uint32_t i = 0; i < n; ++i) {
-    const float p = areas[i] / mean_area;
-    if (p > 1.0f) { over_id[n_over] = i; over_p[n_over] = p; ++n_over; }
-  }
-  for (uint32_t i = 0; i < n; ++i) {
-    const float p = areas[i] / mean_area;
-    if (p < 1.0f) { under_id[n_under] = i; under_p[n_under] = p; ++n_under; }
-  }
+  uint32_t n_over = 0u, n_under = 0u;  // wave-uniform
   float2* table = s.alias + em.alias_offset;
-  for (uint32_t i = 0; i < n; ++i) table[i] = make_float2(0.0f, u2f(i));
+  for (uint32_t base = 0; base < n; base += 64u) {
+    const uint32_t i = base + lane;
+    const float p = i < n ? areas[i] / mean_area : 1.0f;
+    const unsigned long long mo = __ballot(p > 1.0f), mu = __ballot(p < 1.0f);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (p > 1.0f) {
+      const uint32_t at = n_over + (uint32_t)__popcll(mo & below);
+      over_id[at] = i;
+      over_p[at] = p;
+    }
+    if (p < 1.0f) {
+      const uint32_t at = n_under + (uint32_t)__popcll(mu & below);
+      under_id[at] = i;
+      under_p[at] = p;
+    }
+    n_over += (uint32_t)__popcll(mo);
+    n_under += (uint32_t)__popcll(mu);
+    if (i < n) table[i] = make_float2(0.0f, u2f(i));
+  }
+  __syncthreads();
+  if (lane != 0u) return;
   while (n_under != 0u && n_over != 0u) {
     --n_over;
     const uint32_t oid = over_id[n_over];
@@ -849,7 +894,10 @@ void launch_gather_instance_boxes(hipStream_t st, const RefitScene& s, const flo
 }
 void launch_refit(hipStream_t st, const RefitScene& s, const RefitUpdate* updates, uint32_t n_updates, uint32_t* failed, float4* tlas, uint32_t tlas_count,
                   uint32_t orderings, float4* light_lo, float4* light_hi, uint32_t light_count) {
-  if (n_updates) hipLaunchKernelGGL(k_refit_instances, dim3((n_updates + 63u) / 64u), dim3(64), 0, st, s, updates, n_updates, failed);
+  if (n_updates) {
+    hipLaunchKernelGGL(k_refit_instances, dim3((n_updates + 63u) / 64u), dim3(64), 0, st, s, updates, n_updates, failed);
+    hipLaunchKernelGGL(k_refit_emitters, dim3(n_updates), dim3(64), HK_EMITTER_LDS_TRIANGLES * 5u * 4u, st, s, updates, n_updates);
+  }
   // TLAS nodes are interleaved (lo, hi) pairs, the light BVH two planes
   if (tlas_count) {
     const uint32_t waves = tlas_count * orderings;

@@ -200,6 +200,48 @@ std::vector<HkNode> build_flat_bvh(const std::vector<float>& boxes_min_max /* n 
   return out;
 }
 
+// A VALID flat tree over the same shapes without the SAH work: the index list halved recursively, O(n log n) box unions.  It is
+// what hk_scene_builder_finish_instances uploads when the device is about to build the real trees (hk_update_scene_instances):
+// the right size, every leaf present, correct navigator boxes - a frame rendered from it would still be right, only slower.
+static int build_halving(const std::vector<Box>& shapes, uint32_t begin, uint32_t end, std::vector<TreeNode>& nodes, Box* box_out) {
+  if (end - begin == 1) {
+    nodes.push_back(TreeNode{true, begin, Box::empty(), Box::empty(), -1, -1});
+    *box_out = shapes[begin];
+    return (int)nodes.size() - 1;
+  }
+  const int node_index = (int)nodes.size();
+  nodes.push_back(TreeNode{false, 0, Box::empty(), Box::empty(), -1, -1});
+  const uint32_t mid = begin + (end - begin) / 2;
+  Box lb, rb;
+  const int l = build_halving(shapes, begin, mid, nodes, &lb);
+  const int r = build_halving(shapes, mid, end, nodes, &rb);
+  nodes[node_index].child_l = lb;
+  nodes[node_index].child_r = rb;
+  nodes[node_index].l = l;
+  nodes[node_index].r = r;
+  *box_out = lb;
+  box_out->join(rb);
+  return node_index;
+}
+std::vector<HkNode> build_flat_placeholder(const std::vector<float>& boxes_min_max /* n x 6 */) {
+  const size_t n = boxes_min_max.size() / 6;
+  std::vector<HkNode> out;
+  if (n == 0) return out;
+  std::vector<Box> shapes(n);
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      shapes[i].mn[k] = boxes_min_max[6 * i + k];
+      shapes[i].mx[k] = boxes_min_max[6 * i + 3 + k];
+    }
+  std::vector<TreeNode> tree;
+  tree.reserve(2 * n);
+  Box all;
+  build_halving(shapes, 0u, (uint32_t)n, tree, &all);
+  out.reserve(3 * n);
+  flatten(tree, 0, out, 0);
+  return out;
+}
+
 // ------------------------------------------------------------------------------------------
 struct BuilderMesh {
   std::vector<HkVertex> vertices;
@@ -478,7 +520,30 @@ int hk_scene_builder_set_instance_transform(hk_scene_builder* b, uint32_t instan
   return HK_OK;
 }
 
-int hk_scene_builder_finish(hk_scene_builder* b) {
+static int finish_impl(hk_scene_builder* b, bool build_trees);
+int hk_scene_builder_finish(hk_scene_builder* b) { return finish_impl(b, true); }
+int hk_scene_builder_finish_instances(hk_scene_builder* b) { return finish_impl(b, false); }
+
+int hk_scene_builder_remove_instance(hk_scene_builder* b, uint32_t instance_id) {
+  HK_REQUIRE(b, HK_E_INVALID, "builder is NULL");
+  HK_REQUIRE(instance_id < b->instance_decl.size(), HK_E_INVALID, "unknown instance id");
+  b->instance_decl.erase(b->instance_decl.begin() + instance_id);
+  // the transform history is kept per instance: the rows of the removed one go with it
+  for (std::vector<float>* v : {&b->finished_transforms, &b->previous_transforms})
+    if (v->size() >= 16 * ((size_t)instance_id + 1)) v->erase(v->begin() + 16 * (size_t)instance_id, v->begin() + 16 * ((size_t)instance_id + 1));
+  b->finished = false;
+  return HK_OK;
+}
+
+int hk_scene_builder_set_instance_material(hk_scene_builder* b, uint32_t instance_id, uint32_t material_id) {
+  HK_REQUIRE(b, HK_E_INVALID, "builder is NULL");
+  HK_REQUIRE(instance_id < b->instance_decl.size() && material_id < b->materials.size(), HK_E_INVALID, "unknown instance or material id");
+  b->instance_decl[instance_id].material = material_id;
+  b->finished = false;
+  return HK_OK;
+}
+
+static int finish_impl(hk_scene_builder* b, bool build_trees) {
   HK_REQUIRE(b, HK_E_INVALID, "builder is NULL");
   if (b->meshes_dirty) {  // mesh.rs:141-163: concatenate, remember offsets (only when a mesh was added)
     b->vertices.clear(); b->primitives.clear(); b->asset_nodes.clear(); b->mesh_index.clear();
@@ -512,7 +577,7 @@ int hk_scene_builder_finish(hk_scene_builder* b) {
     boxes.insert(boxes.end(), inst.min, inst.min + 3);
     boxes.insert(boxes.end(), inst.max, inst.max + 3);
   }
-  b->instance_nodes = build_flat_bvh(boxes);  // instance.rs:365-371
+  b->instance_nodes = build_trees ? build_flat_bvh(boxes) : build_flat_placeholder(boxes);  // instance.rs:365-371
   // `BHShape::set_bh_node_index` bookkeeping (unused by the shaders): position of the leaf node
   for (uint32_t n = 0; n < b->instance_nodes.size(); ++n)
     if (b->instance_nodes[n].entry_index >= HK_BVH_LEAF_FLAG) b->instances[b->instance_nodes[n].entry_index - HK_BVH_LEAF_FLAG].node_index = n;
@@ -549,7 +614,7 @@ int hk_scene_builder_finish(hk_scene_builder* b) {
     for (int k = 0; k < 3; ++k) eboxes.push_back(em.position[k] - em.radius);
     for (int k = 0; k < 3; ++k) eboxes.push_back(em.position[k] + em.radius);
   }
-  b->emissive_nodes = build_flat_bvh(eboxes);  // instance.rs:422-428
+  b->emissive_nodes = build_trees ? build_flat_bvh(eboxes) : build_flat_placeholder(eboxes);  // instance.rs:422-428
   for (uint32_t n = 0; n < b->emissive_nodes.size(); ++n)
     if (b->emissive_nodes[n].entry_index >= HK_BVH_LEAF_FLAG) b->emissives[b->emissive_nodes[n].entry_index - HK_BVH_LEAF_FLAG].node_index = n;
   b->finished = true;

@@ -275,6 +275,9 @@ class MultiEngine:
     def rebuild_trees(self, mode=F.TREE_SAH):
         self.api.call("multi_rebuild_scene_trees", self.h, mode)
 
+    def update_instances_on_device(self, builder, mode=F.TREE_SAH):
+        self.api.call("multi_update_scene_instances", self.h, builder.h, mode)
+
     def resize(self, width, height, upscale_ratio=1.0):
         self.api.call("multi_resize", self.h, width, height, upscale_ratio)
         for e in self.contexts:

@@ -342,8 +342,16 @@ class SceneBuilder:
         t = np.ascontiguousarray(transform, dtype=np.float32).reshape(-1)
         self.api.call("scene_builder_set_instance_transform", self.h, instance_id, t.ctypes.data_as(C.POINTER(F.f32)))
 
-    def finish(self):
-        self.api.call("scene_builder_finish", self.h)
+    def remove_instance(self, instance_id):
+        """Take an instance out of the scene (ids of later instances shift down by one)."""
+        self.api.call("scene_builder_remove_instance", self.h, instance_id)
+
+    def set_instance_material(self, instance_id, material_id):
+        self.api.call("scene_builder_set_instance_material", self.h, instance_id, material_id)
+
+    def finish(self, build_trees=True):
+        """hk_scene_builder_finish; build_trees=False: hk_scene_builder_finish_instances (stand-in trees, for a device-side build)."""
+        self.api.call("scene_builder_finish" if build_trees else "scene_builder_finish_instances", self.h)
         arrays = {}
         for name, typ in (("vertices", F.HkVertex), ("primitives", F.HkPrimitive), ("asset_nodes", F.HkNode), ("materials", F.HkMaterial),
                           ("instances", F.HkInstance), ("instance_nodes", F.HkNode), ("emissives", F.HkEmissive),
@@ -440,6 +448,11 @@ class Engine:
         moved = C.c_uint32()
         self.api.call("refit_scene_instances", self.ctx, builder.h, C.byref(moved))
         return moved.value
+
+    def update_instances_on_device(self, builder, mode=F.TREE_SAH):
+        """Instances added / removed / re-materialed on `builder`: hk_update_scene_instances (host lays out the records, the device
+        builds both trees)."""
+        self.api.call("update_scene_instances", self.ctx, builder.h, mode)
 
     def rebuild_trees(self, mode=F.TREE_SAH):
         """New instance tree and light tree over the current boxes, built on the device (hk_rebuild_scene_trees): F.TREE_SAH = the

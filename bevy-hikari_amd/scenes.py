@@ -90,7 +90,7 @@ def _test_textures(rng):
             dict(rgba=glow, srgb=True, linear=True, address_u=F.ADDRESS_REPEAT, address_v=F.ADDRESS_CLAMP_TO_EDGE)]
 
 
-def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, extent=4.0, sphere_rings=8, sphere_segs=12, textured=False):
+def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, extent=4.0, sphere_rings=8, sphere_segs=12, textured=False, n_emissive_spheres=0):
     """A room-less yard: ground slab, random boxes and spheres with rotated / non-uniformly scaled
     instances of a few shared meshes, `n_emitters` emissive strip-quads above it.  Returns
     (SceneData, suggested sun dict).  textured=True binds four procedural textures (base colour,
@@ -132,6 +132,9 @@ def synthetic_scene(seed=0x5EED0003, n_boxes=24, n_spheres=6, n_emitters=4, exte
         t = (rng.uniform(-extent, extent) * 0.8, rng.uniform(2.2, 3.2), rng.uniform(-extent, extent) * 0.8)
         # flipped so the strip's +Y normal faces down
         b.add_instance(quad, emat[i], _trs(t, (math.pi + rng.uniform(-0.3, 0.3), rng.uniform(-1, 1), 0.0), (rng.uniform(0.4, 1.0), 1.0, rng.uniform(0.4, 1.0))))
+    for i in range(n_emissive_spheres):  # examples/scene.rs:231-235: an emissive sphere - an emitter with as many triangles as the sphere mesh
+        t = (rng.uniform(-extent, extent) * 0.6, rng.uniform(1.6, 2.4), rng.uniform(-extent, extent) * 0.6)
+        b.add_instance(sphere, emat[i % len(emat)], _trs(t, rng.uniform(-1, 1, 3), rng.uniform(0.25, 0.5, 3)))
     sun = dict(color=(1.0, 0.96, 0.9), illuminance=20000.0, direction_to_light=(0.35, 0.8, 0.45))
     scene = b.finish()
     scene.textures = textures

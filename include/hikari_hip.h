@@ -406,6 +406,14 @@ int hk_scene_builder_add_material(hk_scene_builder* b, const HkMaterial* materia
 int hk_scene_builder_add_instance(hk_scene_builder* b, uint32_t mesh_id, uint32_t material_id,
                                   const float transform[16], uint32_t* instance_id);
 int hk_scene_builder_finish(hk_scene_builder* b);
+/* hk_scene_builder_finish WITHOUT its two `BVH::build` calls (instance.rs:365-371,422-428): every per-instance and per-emitter
+ * record as above, the instance tree and the light tree as cheap valid stand-ins (index list halved recursively) of the final
+ * size - for hosts that let the device build the trees (hk_update_scene_instances). */
+int hk_scene_builder_finish_instances(hk_scene_builder* b);
+/* Instance set edits (the reference's prepare_instances runs again on any of them, instance.rs:352-437).  Removing an instance
+ * shifts the ids of the instances added after it down by one; its transform history goes with it. */
+int hk_scene_builder_remove_instance(hk_scene_builder* b, uint32_t instance_id);
+int hk_scene_builder_set_instance_material(hk_scene_builder* b, uint32_t instance_id, uint32_t material_id);
 /* Dynamic scenes (instance.rs:352-437 re-runs whenever an instance changes): replace an instance's
  * transform after a finish; the next finish redoes only the instance-level work (world AABBs, TLAS,
  * emissive list, alias tables, light BVH) - meshes and their BLAS are kept.  The transform the
@@ -478,6 +486,12 @@ int hk_refit_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t* moved);
  *                 reference's up to exact ties between candidates, like any other valid tree over the same instances. */
 #define HK_TREE_SAH 0u
 #define HK_TREE_LBVH 1u
+/* Instances ADDED, REMOVED or given another material (hk_scene_builder_add_instance / _remove_instance /
+ * _set_instance_material, any number of pose changes with them): hk_scene_builder_finish_instances lays the instance-level
+ * records out on the host (O(instances); no tree build), the asynchronous upload puts them into the spare slot and both trees
+ * are built on the device in `tree_mode` - with HK_TREE_SAH the result is what hk_scene_builder_finish +
+ * hk_upload_scene_instances gives (the reference's path), minus the two host-side SAH builds that dominate it. */
+int hk_update_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t tree_mode);
 int hk_rebuild_scene_trees(hk_ctx* ctx, uint32_t mode);
 /* Test hook: the instance tree (ordering 0) and the light tree as the device holds them, in the reference's HkNode layout. */
 int hk_debug_read_trees(hk_ctx* ctx, HkNode* instance_nodes, uint32_t instance_cap, HkNode* emissive_nodes, uint32_t emissive_cap);
@@ -604,6 +618,7 @@ int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* moved); /* hk_refit_scene_instances on every band's replica */
 int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode);
+int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t tree_mode);  /* hk_update_scene_instances on every band's replica */
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n_images);
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes);
 int hk_multi_resize(hk_multi* m, uint32_t width, uint32_t height, float upscale_ratio);

@@ -294,3 +294,96 @@ def test_refit_refuses_what_it_cannot_do():
     scene.builder.set_instance_transform(1, np.zeros(16, np.float32))
     with pytest.raises(hk.HikariError):   # singular transform
         gpu.engine.refit_instances(scene.builder)
+
+
+@pytest.mark.parametrize("rings,segs", [(24, 40), (40, 48)])
+def test_refit_of_a_moving_emissive_sphere(rings, segs):
+    """examples/scene.rs:231-235: a rotating emissive SPHERE - an emitter whose area sum and alias table run over ~1 900 (LDS work
+    arrays) / ~3 700 (global work arrays) triangles.  k_refit_emitters computes them with one wave per emitter; the oracle is fed
+    the host builder's records for the same poses: every buffer of every frame bit for bit."""
+    kw = dict(n_boxes=3, n_spheres=1, n_emitters=1, sphere_rings=rings, sphere_segs=segs, n_emissive_spheres=1)
+    n = 1 + 3 + 1 + 1 + 1
+    scene, _ = synthetic_scene(**kw)
+    assert scene.emissives[-1].alias_table[1] >= (1800 if rings == 24 else 3300), "the premise: a many-triangle emitter"
+    run_refit_sequence(kw, (96, 64), lambda f: [n - 1, 2] if f % 2 else [n - 1, n - 2], frames=4)
+
+
+def _edit_sequence(kw, size, edits, settings=None, tree_mode=F.TREE_SAH):
+    """edits: {frame: callable(builder, rng)} applied to BOTH builders before that frame.  Device: hk_update_scene_instances (host
+    lays out the records, the device builds both trees).  Oracle: the twin builder's full finish() - the reference's path."""
+    dev_scene, sun = synthetic_scene(**kw)
+    ref_scene, _ = synthetic_scene(**kw)
+    s = settings or hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam, lights = synthetic_camera(*size), hk.lights_uniform(directional=sun)
+    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_DETERMINISTIC_SCATTER), oracle()
+    gpu.set_scene(dev_scene)
+    cpu.set_scene(ref_scene)
+    builds = 0
+    for n in range(1, max(edits) + 2):
+        if n in edits:
+            for b in (dev_scene.builder, ref_scene.builder):
+                edits[n](b)
+            gpu.engine.update_instances_on_device(dev_scene.builder, tree_mode)
+            builds += 1
+            new = ref_scene.builder.finish()
+            cpu.update_instances(new)
+            tlas, light = gpu.engine.read_trees(len(new.instance_nodes), len(new.emissive_nodes))
+            boxes = np.array([[list(i.min), list(i.max)] for i in new.instances], dtype=np.float32)
+            check_tree(tlas, len(new.instances), boxes)
+            if tree_mode == F.TREE_SAH:   # the device ran the reference's own build: the host builder's tree, link for link
+                assert same_links(tlas, new.instance_nodes), "instance tree differs from the host's bvh 0.7.1 build"
+                assert same_links(light, new.emissive_nodes), "light tree differs from the host's bvh 0.7.1 build"
+        for p in (gpu, cpu):
+            p.render(cam, s, lights=lights, frame_number=n)
+        if tree_mode == F.TREE_SAH:
+            bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+            assert bad == {}, f"frame {n}: {bad}"
+    assert gpu.engine.stats().scene_device_tree_builds == builds
+    return gpu
+
+
+def test_instances_added_removed_and_rematerialed_with_device_built_trees():
+    """VERDICT r02 missing 3: the reference re-runs prepare_instances on ANY instance change (instance.rs:352-437).  Here: add two
+    instances (one of them an emitter), remove one, give one another material (non-emissive -> emissive: the emitter list grows),
+    move some - and after every edit hk_update_scene_instances; the trees the device builds are the host builder's (links
+    compared), every buffer of every frame equals the oracle fed the host builder's full finish()."""
+    kw = dict(n_boxes=6, n_spheres=2, n_emitters=2, sphere_rings=6, sphere_segs=8)
+
+    def add_two(b):
+        # (mesh ids in synthetic_scene: 0 box, 1 sphere, 2 quad strip; material ids 0..7 plain, 8.. emissive)
+        b.add_instance(0, 3, _pose_matrix((0.7, 0.9, -0.4), 0.3, (0.5, 0.8, 0.4)))
+        b.add_instance(2, 9, _pose_matrix((-0.8, 2.6, 0.6), math.pi, (0.6, 1.0, 0.5)))
+
+    def remove_one(b):
+        b.remove_instance(4)
+
+    def rematerial_and_move(b):
+        b.set_instance_material(2, 8)     # a box becomes an emitter
+        b.set_instance_transform(5, _pose_matrix((1.2, 0.6, 1.1), -0.4, (0.7, 0.7, 0.7)))
+
+    _edit_sequence(kw, (104, 72), {2: add_two, 3: remove_one, 4: rematerial_and_move})
+
+
+def test_instance_edits_on_a_two_slot_scene_and_lbvh_trees():
+    """... on a scene beyond the LDS copy (two slots: the records go to the spare slot in stream order), SAH trees compared link for
+    link; and with HK_TREE_LBVH (another valid tree over the same instances: checked structurally, frames finite and lit)."""
+    kw = dict(n_boxes=20, n_spheres=5, n_emitters=3, sphere_rings=12, sphere_segs=16)
+
+    def grow(b):
+        for k in range(5):
+            b.add_instance(k % 2, 1 + k, _pose_matrix((-2.0 + k, 0.8, 2.0 - 0.7 * k), 0.2 * k, (0.5, 0.6, 0.5)))
+
+    def shrink(b):
+        for i in (27, 11, 3):
+            b.remove_instance(i)
+
+    _edit_sequence(kw, (120, 72), {2: grow, 4: shrink})
+    gpu = _edit_sequence(kw, (120, 72), {2: grow, 3: shrink}, tree_mode=F.TREE_LBVH)
+    out = gpu.output(hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0))
+    assert np.isfinite(out).all() and out[..., :3].max() > 0.05
+
+
+def _pose_matrix(t, yaw, scale):
+    c, s = math.cos(yaw), math.sin(yaw)
+    m = np.array([[c * scale[0], 0, s * scale[2], t[0]], [0, scale[1], 0, t[1]], [-s * scale[0], 0, c * scale[2], t[2]], [0, 0, 0, 1]], dtype=np.float64)
+    return m.T.astype(np.float32).reshape(-1)

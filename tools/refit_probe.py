@@ -98,10 +98,77 @@ def probe(n_instances):
         if mode == "device":   # leave the builder finished for the next scene
             b.api.call("scene_builder_finish", b.h)
         del p
+    # instance SET edits (round 3): every update adds one instance and removes another.  "host" = the reference's path
+    # (hk_scene_builder_finish: both SAH tree builds on the host + upload); "device" = hk_update_scene_instances (records laid out
+    # on the host, both trees built on the device: HK_TREE_SAH = the same trees).
+    extra = rest[int(movers[0])].copy()
+    for mode in ("host", "device"):
+        p = hk.HikariPlugin(device=0)
+        p.set_scene(scene)
+        p.render(cam, s, lights=lights, frame_number=1)
+        p.engine.wait()
+        stream = torch.cuda.ExternalStream(p.engine.stream())
+        t_host, t_gpu = [], []
+        for n in range(2, 12):
+            m = extra.copy()
+            m[12] += 0.37 * n
+            b.add_instance(0, 1, m)
+            b.remove_instance(int(movers[n]))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            p.engine.wait()
+            e0.record(stream)
+            t0 = time.perf_counter()
+            if mode == "host":
+                b.api.call("scene_builder_finish", b.h)
+                p.engine.api.call("upload_scene_instances", p.engine.ctx, b.h)
+                p.engine.frame_begin(hk.frame_uniform(s, n), cam.view_uniform(), cam.previous_view_uniform(), lights)
+                p.engine.api.call("indirect_schedule", p.engine.ctx, C.byref(C.c_uint32()))
+            else:
+                p.engine.update_instances_on_device(b, F.TREE_SAH)
+            t1 = time.perf_counter()
+            e1.record(stream)
+            p.engine.wait()
+            t_host.append(t1 - t0)
+            t_gpu.append(e0.elapsed_time(e1))
+        out["edit_" + mode] = {"host_ms_per_update": round(float(np.median(t_host)) * 1e3, 3), "stream_ms_per_update": round(float(np.median(t_gpu)), 3)}
+        del p
+    b.api.call("scene_builder_finish", b.h)
     return out
+
+
+def emitter_probe():
+    """The emitter half of the refit: an emissive sphere of ~1 900 / ~3 700 triangles moving (examples/scene.rs:231-235)."""
+    from bevy_hikari_amd.scenes import synthetic_scene
+
+    res = {}
+    for rings, segs in ((24, 40), (40, 48)):
+        scene, sun = synthetic_scene(n_boxes=12, n_spheres=2, n_emitters=2, sphere_rings=rings, sphere_segs=segs, n_emissive_spheres=1)
+        p = hk.HikariPlugin(device=0)
+        p.set_scene(scene)
+        cam, s = synthetic_camera(640, 360), hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.SMAA_TU_1_0)
+        p.render(cam, s, lights=hk.lights_uniform(directional=sun), frame_number=1)
+        p.engine.wait()
+        stream = torch.cuda.ExternalStream(p.engine.stream())
+        idx = len(scene.instances) - 1
+        rest = np.ctypeslib.as_array(scene.instances[idx].model).copy()
+        t_gpu = []
+        for n in range(2, 14):
+            m = rest.copy()
+            m[12] += 0.02 * n
+            scene.builder.set_instance_transform(idx, m)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            p.engine.wait()
+            e0.record(stream)
+            p.engine.refit_instances(scene.builder)
+            e1.record(stream)
+            p.engine.wait()
+            t_gpu.append(e0.elapsed_time(e1))
+        res[f"{int(scene.emissives[-1].alias_table[1])}_triangles"] = {"refit_stream_ms": round(float(np.median(t_gpu)), 4)}
+    return {"emissive_sphere_refit": res}
 
 
 if __name__ == "__main__":
     sizes = [int(a) for a in sys.argv[1:]] or [2000, 20000]
     for n in sizes:
         print(json.dumps(probe(n)), flush=True)
+    print(json.dumps(emitter_probe()), flush=True)
