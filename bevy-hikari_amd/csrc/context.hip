@@ -175,6 +175,16 @@ struct hk_ctx {
   hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
   hipEvent_t fork_event = nullptr, join_event = nullptr;
   bool forked = false;                 // side_stream holds work the main stream has not waited for yet
+  // Frame pipelining (round 3): the a-trous levels + tone mapping of frame n run on a third stream, so that the main stream goes
+  // straight on to frame n + 1's primary rays and light passes (which read none of the denoiser's buffers).  What both touch is
+  // double-buffered by frame parity: albedo, depth gradient and the derived planes (dn_g, depth) the a-trous taps read.
+  hipStream_t post_stream = nullptr;
+  hipEvent_t post_fork = nullptr, post_done = nullptr;
+  bool post_pending = false;           // post_stream holds work the main stream has not waited for yet
+  uint32_t post_parity = 0;            // mapped_parity of the frame whose a-trous levels are (were last) on post_stream
+  void* albedo_twin = nullptr;         // the planes of the OTHER frame parity (swapped with buf[HK_BUF_ALBEDO] ... in hk_frame_begin)
+  void* depth_gradient_twin = nullptr;
+  void* dn_g_twin = nullptr;
 
   // host copies of the reference-layout scene (kept for the layout conversion)
   std::vector<HkVertex> vertices;
@@ -353,6 +363,11 @@ int free_screen(hk_ctx* c) {
   if (c->dn_g) (void)hipFree(c->dn_g);
   c->depth_plane = nullptr;
   c->dn_g = nullptr;
+  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin}) {
+    if (*q) (void)hipFree(*q);
+    *q = nullptr;
+  }
+  c->post_pending = false;
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
       if (c->dn_extra[k][l]) (void)hipFree(c->dn_extra[k][l]);
@@ -853,10 +868,12 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_byt
 }
 
 int join_side(hk_ctx* c);
-// wait for everything the context has enqueued, on BOTH streams (the direct-light dispatches of a frame may still be
+int join_post(hk_ctx* c);
+int join_all(hk_ctx* c);
+// wait for everything the context has enqueued, on ALL streams (the direct-light dispatches of a frame may still be
 // running on the side stream when a host uploads, resizes or reads statistics between two stages)
 int sync_all(hk_ctx* c) {
-  const int rc = join_side(c);
+  const int rc = join_all(c);
   if (rc) return rc;
   HK_HIP(hipStreamSynchronize(c->stream));
   return HK_OK;
@@ -1237,6 +1254,17 @@ int join_side(hk_ctx* c) {
   c->forked = false;
   return HK_OK;
 }
+// make the main stream wait for the a-trous levels of the last frame (post_stream)
+int join_post(hk_ctx* c) {
+  if (!c->post_pending) return HK_OK;
+  HK_HIP(hipStreamWaitEvent(c->stream, c->post_done, 0));
+  c->post_pending = false;
+  return HK_OK;
+}
+int join_all(hk_ctx* c) {
+  const int rc = join_side(c);
+  return rc ? rc : join_post(c);
+}
 // run one dispatch on the side stream (timers record there too)
 int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1);
 int run_pass_on_side(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
@@ -1395,7 +1423,7 @@ void* ctx_buffer(hk_ctx* c, uint32_t b, size_t* logical_bytes) {
 }
 void** ctx_comm_slot(hk_ctx* c) { return &c->comm; }
 uint32_t* ctx_history_rows(hk_ctx* c) { return &c->history_rows; }
-int ctx_join_side(hk_ctx* c) { return join_side(c); }
+int ctx_join_side(hk_ctx* c) { return join_all(c); }
 }  // namespace hk
 
 extern "C" {
@@ -1441,6 +1469,14 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
       hk_destroy(c);
       return HK_E_HIP;
     }
+    if (!getenv("HK_NO_FRAME_PIPELINE") && !(flags & (HK_CTX_DETERMINISTIC_SCATTER | HK_CTX_COUNT_RAYS | HK_CTX_TIME_PASSES))) {
+      if (hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->post_fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c->post_done, hipEventDisableTiming) != hipSuccess) {
+        set_error("cannot create the post-process stream");
+        hk_destroy(c);
+        return HK_E_HIP;
+      }
+    }
   }
   *out = c;
   return HK_OK;
@@ -1450,7 +1486,7 @@ namespace { void free_refit(hk_ctx* c); }
 void hk_destroy(hk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)join_side(c);
+  (void)join_all(c);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   comm_release(c);
   drain_timers(c);
@@ -1468,6 +1504,9 @@ void hk_destroy(hk_ctx* c) {
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+  if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
+  if (c->post_fork) (void)hipEventDestroy(c->post_fork);
+  if (c->post_done) (void)hipEventDestroy(c->post_done);
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->join_event) (void)hipEventDestroy(c->join_event);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1940,6 +1979,14 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
   HK_HIP(hipMemset(c->prev_depth_plane, 0, nf * 4));
   HK_HIP(hipMalloc(&c->dn_g, nf * 16));
   HK_HIP(hipMemset(c->dn_g, 0, nf * 16));
+  if (c->post_stream) {  // the other frame parity's planes of what the a-trous levels read of the G-buffer (frame pipelining)
+    HK_HIP(hipMalloc(&c->albedo_twin, c->buf_bytes[HK_BUF_ALBEDO]));
+    HK_HIP(hipMemset(c->albedo_twin, 0, c->buf_bytes[HK_BUF_ALBEDO]));
+    HK_HIP(hipMalloc(&c->depth_gradient_twin, c->buf_bytes[HK_BUF_DEPTH_GRADIENT]));
+    HK_HIP(hipMemset(c->depth_gradient_twin, 0, c->buf_bytes[HK_BUF_DEPTH_GRADIENT]));
+    HK_HIP(hipMalloc(&c->dn_g_twin, nf * 16));
+    HK_HIP(hipMemset(c->dn_g_twin, 0, nf * 16));
+  }
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
       HK_HIP(hipMalloc(&c->dn_extra[k][l], nr * 8));
@@ -1978,6 +2025,11 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
     std::swap(c->buf[HK_BUF_VELOCITY_UV], c->buf[HK_BUF_PREVIOUS_VELOCITY_UV]);
     std::swap(c->buf[HK_BUF_TONE_MAPPED], c->buf[HK_BUF_PREVIOUS_TONE_MAPPED]);
     std::swap(c->buf[HK_BUF_TAA_OUTPUT], c->buf[HK_BUF_PREVIOUS_TAA_OUTPUT]);
+    if (c->albedo_twin) {  // (frame pipelining: the planes last frame's a-trous levels may still be reading stay untouched)
+      std::swap(c->buf[HK_BUF_ALBEDO], c->albedo_twin);
+      std::swap(c->buf[HK_BUF_DEPTH_GRADIENT], c->depth_gradient_twin);
+      std::swap(c->dn_g, c->dn_g_twin);
+    }
     c->mapped_parity = f->number & 1u;
   }
   return HK_OK;
@@ -1986,7 +2038,7 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
 int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint32_t row_end) {
   int rc = ready(c);
   if (rc) return rc;
-  if ((rc = join_side(c))) return rc;
+  if ((rc = join_all(c))) return rc;
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
   int rows = full_grid ? c->H : c->RH;
   if (pass == HK_PASS_TAA_JASMINE) { int w; buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &rows); }
@@ -2036,6 +2088,10 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
   } while (0)
   if (stage == HK_STAGE_TEMPORAL) {
     if ((rc = join_side(c))) return rc;
+    // last frame's a-trous levels may still be running on post_stream: this frame's primary rays and light passes do not touch
+    // what they read - provided the double-buffered planes really flipped (a host that renders two frames of the same parity in a
+    // row, or shards the frame into bands, or timed passes, gets the serial order)
+    if (c->post_pending && (c->mapped_parity == c->post_parity || c->band_count > 1 || (flags & HK_FRAME_EXTERNAL_GBUFFER)) && (rc = join_post(c))) return rc;
     if (c->timing_mask) {
       (void)hipEventRecord(c->frame_start, c->stream);
     }
@@ -2089,6 +2145,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     if ((rc = join_side(c))) return rc;              // exchange B / demodulation read all three channels
   } else if (stage == HK_STAGE_POST_PROCESS) {
     if ((rc = join_side(c))) return rc;
+    if ((rc = join_post(c))) return rc;              // the denoiser's internal planes: last frame's levels come first
     if (st->denoise) {                               // post_process.rs:1190-1224
       const uint32_t nch = st->indirect_bounces == 0 ? 2u : 3u;  // post_process.rs:949-954
       if (c->derived_dirty) {
@@ -2097,19 +2154,41 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       }
       // the reference's per-channel loop, with the channels of each step fused into one launch
       if ((rc = run_demodulation_fused(c, nch, clampr(b0 - 15), clampr(b1 + 15)))) return rc;
-      if ((rc = run_denoise_fused(c, nch, 0, clampr(b0 - 7), clampr(b1 + 7)))) return rc;
-      if ((rc = run_denoise_fused(c, nch, 1, clampr(b0 - 3), clampr(b1 + 3)))) return rc;
-      if ((rc = run_denoise_fused(c, nch, 2, clampr(b0 - 1), clampr(b1 + 1)))) return rc;
-      if ((rc = run_denoise_fused(c, nch, 3, b0, b1, true))) return rc;  // + tone mapping (post_process.rs:1226-1234) in the same launch
+      // demodulation was the last reader of the light passes' render / variance planes: from here on nothing this frame still
+      // does is touched by the next frame's light passes - the four levels go to post_stream (a single-band, untimed frame)
+      const uint32_t level_bits = (1u << HK_PASS_DENOISE_L0) | (1u << HK_PASS_DENOISE_L1) | (1u << HK_PASS_DENOISE_L2) | (1u << HK_PASS_DENOISE_L3);
+      const bool pipelined = c->post_stream && c->band_count == 1 && !(c->timing_mask & level_bits) && !c->comm && c->albedo_twin;
+      hipStream_t main_stream = c->stream;
+      if (pipelined) {
+        HK_HIP(hipEventRecord(c->post_fork, c->stream));
+        HK_HIP(hipStreamWaitEvent(c->post_stream, c->post_fork, 0));
+        c->stream = c->post_stream;
+      }
+      rc = run_denoise_fused(c, nch, 0, clampr(b0 - 7), clampr(b1 + 7));
+      if (!rc) rc = run_denoise_fused(c, nch, 1, clampr(b0 - 3), clampr(b1 + 3));
+      if (!rc) rc = run_denoise_fused(c, nch, 2, clampr(b0 - 1), clampr(b1 + 1));
+      if (!rc) rc = run_denoise_fused(c, nch, 3, b0, b1, true);  // + tone mapping (post_process.rs:1226-1234) in the same launch
+      c->stream = main_stream;
+      if (rc) return rc;
+      if (pipelined) {
+        HK_HIP(hipEventRecord(c->post_done, c->post_stream));
+        c->post_pending = true;
+        c->post_parity = c->mapped_parity;
+      }
+      if (c->timing_mask) {
+        (void)hipEventRecord(c->frame_stop, pipelined ? c->post_stream : c->stream);
+        c->frame_timed = true;
+      }
     } else {
       HK_RUN(HK_PASS_TONE_MAPPING, 0u, b0, b1);                   // post_process.rs:1226-1234
-    }
-    if (c->timing_mask) {
-      (void)hipEventRecord(c->frame_stop, c->stream);
-      c->frame_timed = true;
+      if (c->timing_mask) {
+        (void)hipEventRecord(c->frame_stop, c->stream);
+        c->frame_timed = true;
+      }
     }
     c->frames += 1;
   } else if (stage == HK_STAGE_ANTIALIAS) {            // post_process.rs:1236-1272
+    if ((rc = join_post(c))) return rc;                // (reads the tone-mapped image)
     // band: TAA on the band's output rows; its input row beyond the border comes from the extrapolation of the
     // neighbouring quad row, which needs the SMAA samples one more row out (footprints: hk_band_plan_for, exchange D)
     const bool smaa = st->upscale_kind == HK_UPSCALE_SMAA_TU4X;
@@ -2124,6 +2203,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       HK_RUN(HK_PASS_TAA_JASMINE, 0, std::min(h, scale * b0), b1 == c->RH ? h : std::min(h, scale * b1));
     }
   } else if (stage == HK_STAGE_UPSCALE) {              // post_process.rs:1277-1308
+    if ((rc = join_post(c))) return rc;
     if (st->upscale_kind == HK_UPSCALE_FSR1) {
       uint32_t w0, w1;
       band_rows((uint32_t)c->H, c->band_index, c->band_count, &w0, &w1);
@@ -2160,7 +2240,7 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
 int hk_frame_wait(hk_ctx* c) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   HK_HIP(hipSetDevice(c->device));
-  { int rc = join_side(c); if (rc) return rc; }
+  { int rc = join_all(c); if (rc) return rc; }
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   return HK_OK;
@@ -2179,7 +2259,7 @@ int hk_read_buffer(hk_ctx* c, uint32_t buffer, void* dst, size_t bytes) {
   HK_REQUIRE(c && dst && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
   HK_REQUIRE(bytes == buffer_logical_bytes(c, buffer), HK_E_INVALID, "size mismatch: buffer has %zu bytes", buffer_logical_bytes(c, buffer));
   HK_HIP(hipSetDevice(c->device));
-  { int rc_ = join_side(c); if (rc_) return rc_; }
+  { int rc_ = join_all(c); if (rc_) return rc_; }
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(dst, c->buf[buffer], bytes, hipMemcpyDeviceToHost));
   return HK_OK;
@@ -2188,7 +2268,7 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
   HK_REQUIRE(c && src && buffer < HK_BUF_COUNT && c->buf[buffer], HK_E_INVALID, "bad argument");
   HK_REQUIRE(bytes == buffer_logical_bytes(c, buffer), HK_E_INVALID, "size mismatch: buffer has %zu bytes", buffer_logical_bytes(c, buffer));
   HK_HIP(hipSetDevice(c->device));
-  { int rc_ = join_side(c); if (rc_) return rc_; }
+  { int rc_ = join_all(c); if (rc_) return rc_; }
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
   if (buffer >= HK_BUF_RESERVOIR0 && buffer < HK_BUF_RESERVOIR0 + 10 && c->tile_meta[buffer - HK_BUF_RESERVOIR0]) {  // host-written reservoirs: tiles unknown
@@ -2208,7 +2288,7 @@ int hk_device_ptr(hk_ctx* c, uint32_t buffer, void** ptr, size_t* bytes) {
 int hk_set_stream(hk_ctx* c, void* s) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   HK_HIP(hipSetDevice(c->device));
-  { int rc = join_side(c); if (rc) return rc; }
+  { int rc = join_all(c); if (rc) return rc; }
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   c->stream = s ? (hipStream_t)s : c->own_stream;
@@ -2227,7 +2307,7 @@ int hk_set_timing_mask(hk_ctx* c, uint32_t mask) {
 int hk_get_stats(hk_ctx* c, HkStats* out) {
   HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
   HK_HIP(hipSetDevice(c->device));
-  { int rc = join_side(c); if (rc) return rc; }
+  { int rc = join_all(c); if (rc) return rc; }
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   memset(out, 0, sizeof(*out));

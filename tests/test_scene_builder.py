@@ -228,3 +228,43 @@ def test_direction_threaded_flattenings(cornell):
     import pytest
     with pytest.raises(F.HikariError):
         api.call("bvh_rethread", bad, 3, 0, (F.HkNode * 3)())
+
+
+def test_finish_instances_lays_out_the_records_with_stand_in_trees_and_edits_keep_the_history():
+    """hk_scene_builder_finish_instances (for hk_update_scene_instances: the device builds the real trees): every per-instance /
+    per-emitter record equals hk_scene_builder_finish's, the two trees are VALID flatten_custom trees of the final size over
+    the same shapes (3n - 2 nodes, every shape in one leaf, navigator boxes = union of their leaves).  remove_instance /
+    set_instance_material edit the declared set; the transform history follows the instances."""
+    import ctypes as C
+
+    from bevy_hikari_amd.scenes import synthetic_scene
+    from test_device_refit import check_tree
+
+    scene, _ = synthetic_scene(n_boxes=9, n_spheres=2, n_emitters=3, sphere_rings=4, sphere_segs=5)
+    twin, _ = synthetic_scene(n_boxes=9, n_spheres=2, n_emitters=3, sphere_rings=4, sphere_segs=5)
+    b, t = scene.builder, twin.builder
+    moved = np.ctypeslib.as_array(scene.instances[5].model).copy()
+    moved[12] += 0.5
+    for x in (b, t):
+        x.set_instance_transform(5, moved)
+        x.remove_instance(3)                  # instance 5 becomes instance 4
+        x.set_instance_material(2, 8)         # a plain box becomes an emitter (material 8 is emissive in synthetic_scene)
+        x.add_instance(0, 1, np.eye(4, dtype=np.float32).reshape(-1))
+    full, light = t.finish(), b.finish(build_trees=False)
+    n = len(full.instances)
+    assert n == len(scene.instances) and len(light.instances) == n and len(full.emissives) == len(scene.emissives) + 1
+    for name in ("instances", "emissives", "alias_table"):
+        fa, la = getattr(full, name), getattr(light, name)
+        if name in ("instances", "emissives"):   # (node_index = the leaf's position in the tree: differs with the tree, unused by the shaders)
+            strip = lambda arr: [bytes(bytearray(x))[:C.sizeof(type(x)) - 0] for x in arr]
+            for x, y in zip(fa, la):
+                x.node_index = y.node_index = 0
+        assert bytes(fa) == bytes(la), name
+    assert bytes(full.previous_transforms) == bytes(light.previous_transforms)
+    # the moved instance's previous transform is its pose at the first finish - although its index changed from 5 to 4
+    prev = np.frombuffer(bytes(light.previous_transforms), dtype=np.float32).reshape(-1, 16)
+    assert (prev[4] == np.ctypeslib.as_array(scene.instances[5].model)).all() and (np.ctypeslib.as_array(light.instances[4].model) == moved).all()
+    boxes = np.array([[list(i.min), list(i.max)] for i in light.instances], dtype=np.float32)
+    check_tree(light.instance_nodes, n, boxes)
+    eboxes = np.array([[[e.position[k] - e.radius for k in range(3)], [e.position[k] + e.radius for k in range(3)]] for e in light.emissives], dtype=np.float32)
+    check_tree(light.emissive_nodes, len(light.emissives), eboxes)
