@@ -98,8 +98,11 @@ __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d,
 // is_nan(c) || c > F32_MAX for some component c - "not (c <= F32_MAX)": one compare per component
 __device__ __forceinline__ bool nan_or_above_max(f3 v) { return !(v.x <= HK_F32_MAX) || !(v.y <= HK_F32_MAX) || !(v.z <= HK_F32_MAX); }
 
+#ifndef HK_DENOISE_WAVES
+#define HK_DENOISE_WAVES 8  // waves per SIMD the a-trous kernel is compiled for: 62-64 VGPRs without spills (unconstrained: 68-70 = 7 waves; frame -0.5 %, three interleaved A/B runs)
+#endif
 template <int LEVEL, int NCH, int FFMASK>
-__global__ __launch_bounds__(256) void k_denoise(DFrame fr, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:164-319
+__global__ __launch_bounds__(256, HK_DENOISE_WAVES) void k_denoise(DFrame fr, DenoiseTargets d, int row_begin, int row_end) {  // denoise.wgsl:164-319
 #if defined(HK_DENOISE_TILES_RR)
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
 #else

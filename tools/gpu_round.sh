@@ -17,13 +17,13 @@ done
 cd /tmp && export TMPDIR=/tmp
 for C in 2 3 4 5; do
   STEPS=6; [ $C != 2 ] && STEPS=3
-  CMD="python $OLDPWD/bench.py --config $C --steps $STEPS --warmup 4 --blocks 1 --no-cpu-baseline --no-hbm-probe"
+  CMD="python $OLDPWD/bench.py --config $C --steps $STEPS --warmup 4 --blocks 1 --no-cpu-baseline --no-hbm-probe --no-extra-configs --sustained-seconds 0"
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof_trace_c$C -- $CMD > /dev/null 2>&1
   DB=$(find $OUT/prof_trace_c$C -name "*.db" | head -1)
   [ -n "$DB" ] && python $OLDPWD/tools/rocpd_summary.py $DB > $OUT/${TAG}_config${C}_kernel_stats.txt
   head -12 $OUT/${TAG}_config${C}_kernel_stats.txt | cut -c1-180
 done
-CMD="python $OLDPWD/bench.py --steps 6 --warmup 4 --blocks 1 --no-cpu-baseline --no-hbm-probe"
+CMD="python $OLDPWD/bench.py --steps 6 --warmup 4 --blocks 1 --no-cpu-baseline --no-hbm-probe --no-extra-configs --sustained-seconds 0"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/prof_sq -- $CMD > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof_fetch -- $CMD > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof_write -- $CMD > /dev/null 2>&1
