@@ -334,6 +334,23 @@ HKD void temporal_restir(Reservoir& r, const Sample& s, float w_new, uint32_t ma
     r.count = m;
   }
 }
+// compute_jacobian for a caller that already holds d = normalize(q.sample_position - r.visible_position) and the length of that
+// vector (k_spatial_reuse forms both for its facing test).  The reference normalises the OPPOSITE vector, r.visible_position -
+// q.sample_position: IEEE subtraction is antisymmetric, the squares under the root are the same numbers, and a dot product of
+// negated operands is the negated dot product (round-to-nearest is symmetric) - so |dot| and the squared length come out bit for
+// bit (a zero component may carry the other sign; fabsf and the squares remove it).  One sqrt, one division, two dots fewer.
+HKD float compute_jacobian_shared(const Sample& q, f3 d, float d_length) {
+  f3 normal = q.sample_normal;
+  float cos_phi_1 = fabsf(dot(d, normal));
+  float cos_phi_2 = fabsf(dot(normalize(xyz(q.visible_position) - xyz(q.sample_position)), normal));
+  float term_1 = cos_phi_1 / fmax_(0.0001f, cos_phi_2);
+  float num = length(xyz(q.visible_position) - xyz(q.sample_position));
+  num *= num;
+  float denom = d_length;
+  denom *= denom;
+  float term_2 = num / fmax_(denom, 0.0001f);
+  return clamp_(term_1 * term_2, 1.0f, 50.0f);
+}
 HKD float compute_jacobian(const Sample& q, const Sample& r) {  // light.wgsl:985-1004
   f3 normal = q.sample_normal;
   float cos_phi_1 = fabsf(dot(normalize(xyz(r.visible_position) - xyz(q.sample_position)), normal));

@@ -706,7 +706,10 @@ __global__ __launch_bounds__(256, HK_SPATIAL_WGS) void k_spatial_reuse(DScene sc
     const bool normal_miss = dot(s.visible_normal, q.s.visible_normal) < 0.866f;
     if (q.count < HK_F32_EPSILON || normal_miss) continue;
 
-    const f3 sample_direction = normalize(xyz(q.s.sample_position) - xyz(s.visible_position));
+    // normalize(q.s.sample_position - s.visible_position), keeping the length for the Jacobian below (compute_jacobian_shared)
+    const f3 to_sample = xyz(q.s.sample_position) - xyz(s.visible_position);
+    const float to_sample_length = sqrtf(dot(to_sample, to_sample));
+    const f3 sample_direction = to_sample * (1.0f / to_sample_length);
     if (dot(sample_direction, s.visible_normal) < 0.0f) continue;
 
     const float tap_interval = taps.tap_interval[i - 1u];
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(256, HK_SPATIAL_WGS) void k_spatial_reuse(DScene sc
     }
     if (occluded) continue;
 
-    const float jacobian = (q.s.sample_position.w > 0.5f) ? compute_jacobian(q.s, s) : 1.0f;
+    const float jacobian = (q.s.sample_position.w > 0.5f) ? compute_jacobian_shared(q.s, sample_direction, to_sample_length) : 1.0f;
     if (EMISSIVE_LIT) {
       merge_reservoir(r, q, luminance(xyz(q.s.radiance)) / jacobian);
     } else {
