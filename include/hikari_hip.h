@@ -237,7 +237,11 @@ typedef enum HkBuffer {
    * (post_process.rs:737,866-867).  Here all four follow frame.number % 2 of hk_frame_begin: ids
    * without PREVIOUS name the plane frame n writes, PREVIOUS_* the plane frame n-1 wrote.
    * hk_device_ptr of these ids is therefore only valid until the next hk_frame_begin, and a host
-   * that supplies its own G-buffer writes it AFTER hk_frame_begin of that frame. */
+   * that supplies its own G-buffer writes it AFTER hk_frame_begin of that frame.
+   * Since ABI 6 the same holds for HK_BUF_ALBEDO and HK_BUF_DEPTH_GRADIENT (no PREVIOUS ids: nothing reads last frame's): the
+   * a-trous levels of frame n may still be reading them on their own stream while frame n + 1's primary rays write the other
+   * parity's planes (frame pipelining; contexts created with HK_CTX_SINGLE_STREAM / _DETERMINISTIC_SCATTER / _COUNT_RAYS /
+   * _TIME_PASSES keep one plane).  hk_read_buffer / hk_write_buffer always address the current frame's plane. */
   HK_BUF_PREVIOUS_POSITION = 31,
   HK_BUF_PREVIOUS_VELOCITY_UV = 32,
   HK_BUF_PREVIOUS_TONE_MAPPED = 33,
