@@ -852,15 +852,16 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_byt
     while (want & (want - 1)) want &= want - 1;  // a power of two
     std::vector<float4> flat;
     uint32_t count = 0;
-    for (uint32_t ord = want; shared && ord >= 1; ord >>= 1) {
-      if (!build_flat_bvh(c, ord, flat, count)) break;
-      if (ord > 1 && flat.size() * 16 > budget) continue;
-      if (blob.bytes.size() + flat.size() * 16 + static_bytes <= HK_LDS_SCENE_BYTES && count <= 0xFFFFu) {
+    if (shared && build_flat_bvh(c, 1u, flat, count)) {  // (a first build tells the node count: 2 T - 1)
+      const size_t per_ordering = flat.size() * 16;
+      uint32_t ord = want;
+      while (ord > 1 && (per_ordering * ord > budget || blob.bytes.size() + per_ordering * ord + static_bytes > HK_LDS_SCENE_BYTES)) ord >>= 1;
+      if (ord > 1 && !build_flat_bvh(c, ord, flat, count)) ord = 0;
+      if (ord >= 1 && blob.bytes.size() + flat.size() * 16 + static_bytes <= HK_LDS_SCENE_BYTES && count <= 0xFFFFu) {
         o.flat = blob.add(flat);
         o.flat_count = count;
         o.flat_orderings = ord;
         blob.bytes.resize((blob.bytes.size() + 31) & ~(size_t)31, 0);
-        break;
       }
     }
   }
