@@ -87,7 +87,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="frames per timed block (default 48; 12 for --config 3/4/5)")
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up frames (default 512 for the headline config: half a second, enough for the clocks to settle "
+                    "- with 16 the five timed blocks of a run still drifted 2.5 %% downwards; 16 for --config 3/4/5)")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps frames each; the median is reported")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
     ap.add_argument("--width", type=int, default=None)
@@ -104,6 +105,8 @@ def main():
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 48 if args.config == 2 else 12
+    if args.warmup is None:
+        args.warmup = 512 if args.config == 2 else 16
 
     import numpy as np
     import torch
