@@ -271,10 +271,11 @@ def main():
             run_frames(xeng, xrend, 1, warmup)
             xeng.wait()
             xeng.reset_stats()
-            xeng.set_timing_mask(1 << F.PASS_INDIRECT)
+            xeng.set_timing_mask((1 << F.PASS_INDIRECT) | (1 << F.PASS_INDIRECT_SPATIAL_REUSE))
             run_frames(xeng, xrend, warmup + 1, warmup + min(steps, 16))
             xst = xeng.stats()
             res["ind_ms_alone"] = xst.pass_ms_total[F.PASS_INDIRECT] / max(1, xst.pass_launches[F.PASS_INDIRECT])
+            res["spatial_ms_alone"] = xst.pass_ms_total[F.PASS_INDIRECT_SPATIAL_REUSE] / max(1, xst.pass_launches[F.PASS_INDIRECT_SPATIAL_REUSE])
             if passes and world == 1:   # per-pass times with every dispatch alone on the GPU
                 xeng.reset_stats()
                 xeng.set_timing_mask(0xFFFF)
@@ -372,11 +373,22 @@ def main():
             "algorithmic_bytes_per_launch": algo_bytes,
             "avg_launch_ms": round(ind_ms, 5),
             "launches": m["ind_launches"],
-            # the same kernel with nothing else on the GPU (HK_CTX_SINGLE_STREAM replay of the same frames)
+            # the same kernel with nothing else on the GPU (HK_CTX_SINGLE_STREAM replay of the same frames).  In the timed run the
+            # direct-light dispatches (second stream) and the previous frame's a-trous levels (third stream) share the GPU with
+            # it: the frame gets shorter, this dispatch's own duration longer - `frac` above is the contract's in-run figure, this
+            # one is the kernel's.
             "alone": {"avg_launch_ms": round(ind_ms_alone, 5), "achieved": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9, 3) if ind_ms_alone > 0 else 0.0,
                       "frac": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ind_ms_alone > 0 else 0.0},
         },
     }
+    if m.get("spatial_ms_alone"):
+        # the second large kernel of the frame (by now as long as the first): spatial_reuse, light.wgsl:1503-1684 - SURVEY 8d: reads
+        # G-buffer 40 + own reservoir 64 + previous spatial 64, writes reservoir 64 + render 8 (the 16 neighbour records it gathers,
+        # ~1 KB per pixel, are re-reads of lines other pixels own and do not count as compulsory traffic)
+        sp_bytes = 240 * W * band_rows
+        out["roofline"]["second_kernel"] = {"kernel": "k_spatial_reuse<false> (spatial_reuse, light.wgsl:1503-1684)", "algorithmic_bytes_per_launch": sp_bytes,
+                                            "alone": {"avg_launch_ms": round(m["spatial_ms_alone"], 5), "achieved": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9, 3),
+                                                      "frac": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
     if hbm:
         out["roofline"]["hbm_ceiling_measured"] = hbm
         out["roofline"]["frac_of_measured_copy"] = round(achieved / hbm["copy_gbs"], 6) if hbm["copy_gbs"] > 0 else None
