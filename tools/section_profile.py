@@ -58,13 +58,18 @@ for n in range(9, 29):
     p.render(cam, s, frame_number=n)
 p.engine.wait()
 assert read(out, 0) == 0
-tot = float(sum(out[:12]))
+tot = float(sum(out[:10]))
 print(json.dumps({"workload": f"cornell {w}x{h} b{bounces}", "frames": 20,
                   "share": {NAMES[i]: round(out[i] / tot, 4) for i in range(len(NAMES))},
                   # every walk of the frame (all ray kernels): what a wave pays per loop iteration
                   "walk": {"wave_iterations_per_frame": out[16] / 20, "with_a_triangle_test": round(out[17] / out[16], 4),
                            "with_an_instance_entry": round(out[18] / out[16], 4), "with_a_blas_exit": round(out[19] / out[16], 4),
                            "active_lanes_per_iteration": round(out[20] / out[16], 2)},
+                  # k_spatial_reuse<false>'s sixteen taps per pixel: where they end (per frame; emissive pass off in this config)
+                  "spatial_reuse_taps": {"taps_per_frame": out[10] / 20, "outside_the_image": round(out[11] / max(out[10], 1), 4),
+                                         "rejected_by_depth_ratio": round(out[12] / max(out[10], 1), 4), "empty_or_normal_miss": round(out[13] / max(out[10], 1), 4),
+                                         "facing_away": round(out[14] / max(out[10], 1), 4), "occluded_by_the_depth_march": round(out[15] / max(out[10], 1), 4),
+                                         "merged": round(1.0 - sum(out[11:16]) / max(out[10], 1), 4)},
                   # the one-level walk counts differently (hk_device.hpp traverse_flat): slots 0 / 1 / 4..7
                   "one_level_walk": {"traversal": list(p.engine.traversal_mode()), "rays_per_frame": out[22] / 20, "wave_iterations_per_frame": out[16] / 20,
                                      "iterations_with_the_test_block": round(out[17] / max(out[16], 1), 4),
