@@ -94,6 +94,10 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
+    ap.add_argument("--band-split", choices=("auto", "balanced", "equal"), default="auto",
+                    help="--gpus N: bands of equal cost (geometry pixels per row, counted on frame 1 by every rank: HK_FRAME_BALANCE_BANDS) or of equal height; "
+                         "auto = balanced for scenes beyond LDS (configs 3, 4: sky rows cost nothing, city rows everything - predicted 3.2x instead of 2.75x at 8 GPUs), "
+                         "equal for the Cornell configs (every row costs about the same: 1.97x against 2.01x, profiles/r03_band_balance_probe.json)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -194,8 +198,8 @@ def main():
                 frame = hk.frame_uniform(settings, n)
                 if r is None:
                     e.frame_render(frame, view, pview, lights, sc)
-                else:
-                    r.render(frame, view, pview, lights, settings, W, H)
+                else:   # frame 1 splits the rows by cost (hk_balance_bands: every rank derives the same boundaries), the rest keep them
+                    r.render(frame, view, pview, lights, settings, W, H, balance=(n == 1 and (args.band_split == "balanced" or (args.band_split == "auto" and config in (3, 4)))))
 
         eng, rend = make_engine(args.ctx_flags)
         run_frames(eng, rend, 1, warmup)
@@ -258,6 +262,7 @@ def main():
         del ceng, crend
 
         res = {"config": config, "description": description, "W": W, "H": H, "steps": steps, "warmup": warmup, "blocks": blocks, "elapsed": elapsed,
+               "band_bounds": (rend.bounds if rend is not None else None),
                "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "total_rays": total_rays, "same": same,
                "sustained": sustained, "scene": scene, "settings": settings, "lights": lights, "view": view, "pview": pview, "sc": sc,
                "band_rows": H if rend is None else (rend.band(H)[1] - rend.band(H)[0])}
@@ -349,6 +354,7 @@ def main():
             "baseline_config": args.config,
             "frames": f"warmup 1..{args.warmup}, then {len(blocks)} timed blocks of {args.steps} frames ({args.warmup + 1}..{last_frame}); value = median block",
             "parallelism": f"band{world}" if world > 1 else "single",
+            **({"band_split": ("balanced" if m["band_bounds"] else "equal"), "band_bounds": m["band_bounds"]} if world > 1 else {}),
             # hk_traversal_mode: "one-level" = one BVH over all triangles in the instances' shared local space (the Cornell box),
             # "threaded" = two-level walk over 8 direction-ordered flattenings (scenes beyond LDS), "reference" = the reference's order
             "traversal": {"mode": m["traversal"][0], "orderings": m["traversal"][1]},

@@ -41,7 +41,7 @@ DEFAULT_CTX_FLAGS = int(os.environ.get("HIKARI_HIP_DEFAULT_CTX_FLAGS", "0"))
 CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER, CTX_EXACT_TRAVERSAL = 1, 2, 4, 8, 16, 32
 TREE_SAH, TREE_LBVH = 0, 1  # hk_rebuild_scene_trees
 CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient with >= 2 bounces (hikari_hip.h)
-FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS = 1, 2
+FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS = 1, 2, 4
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1
 UPSCALE_FSR1, UPSCALE_SMAA_TU4X = 0, 1
@@ -174,6 +174,8 @@ _SIGNATURES = {
     "frame_render": [_vp, P(HkFrame), P(HkView), P(HkPreviousView), P(HkLights), P(HkSettings), u32],
     "frame_wait": [_vp],
     "set_band": [_vp, u32, u32],
+    "set_band_bounds": [_vp, P(u32), u32],
+    "row_costs": [_vp, P(u32), u32],
     "buffer_info": [_vp, u32, P(u32), P(u32), P(u32)],
     "read_buffer": [_vp, u32, _vp, C.c_size_t],
     "write_buffer": [_vp, u32, _vp, C.c_size_t],
@@ -214,6 +216,12 @@ _PRODUCT_ONLY = {
     "update_scene_instances": [_vp, _vp, u32],
     "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
+    "balanced_band_bounds": [P(u32), u32, u32, u32, u32, u32, f32, P(u32)],
+    "balance_bands": [_vp, u32, P(u32), u32],
+    "get_band_bounds": [_vp, P(u32), u32],
+    "get_band": [_vp, P(u32), P(u32)],
+    "band_plan_bounds": [u32, u32, f32, P(u32), u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],
+    "band_schedule_bounds": [u32, u32, f32, P(u32), u32, u32, u32, u32, P(HkSettings), P(HkTransfer), P(u32)],
     "band_plan": [_vp, u32, P(HkSettings), P(HkHaloOp), P(u32)],
     "band_plan_for": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],
     "stream": [_vp, P(_vp)],
@@ -238,6 +246,7 @@ _PRODUCT_ONLY = {
     "multi_refit_scene_instances": [_vp, _vp, P(u32)],
     "multi_rebuild_scene_trees": [_vp, u32],
     "multi_update_scene_instances": [_vp, _vp, u32],
+    "multi_set_band_bounds": [_vp, P(u32), u32],
     "multi_upload_textures": [_vp, P(HkImageDesc), u32],
     "multi_upload_noise": [_vp, _vp, C.c_size_t],
     "multi_resize": [_vp, u32, u32, f32],

@@ -82,7 +82,7 @@ struct Comm {
   // schedules are cached per (stage argument, frame parity, settings): a band's frame is a few hundred microseconds at
   // 8 GPUs, so nothing is re-planned per frame
   struct Cached {
-    uint32_t stage_arg, rank, parity, width, height;
+    uint32_t stage_arg, rank, parity, width, height, n_ranks, bounds_generation;
     float ratio;
     HkSettings st;
     std::vector<HkTransfer> tr;
@@ -94,24 +94,26 @@ struct Comm {
 int schedule_for(std::deque<Comm::Cached>& cache, const CtxInfo& ci, uint32_t rank, uint32_t n_ranks, uint32_t stage_arg, const HkSettings* st,
                  const std::vector<HkTransfer>** out) {
   for (const Comm::Cached& e : cache)
-    if (e.stage_arg == stage_arg && e.rank == rank && e.parity == (ci.frame_number & 1u) && e.width == ci.width && e.height == ci.height &&
-        e.ratio == ci.ratio && memcmp(&e.st, st, sizeof(HkSettings)) == 0) {
+    if (e.stage_arg == stage_arg && e.rank == rank && e.n_ranks == n_ranks && e.bounds_generation == ci.bounds_generation && e.parity == (ci.frame_number & 1u) &&
+        e.width == ci.width && e.height == ci.height && e.ratio == ci.ratio && memcmp(&e.st, st, sizeof(HkSettings)) == 0) {
       *out = &e.tr;
       return HK_OK;
     }
   Comm::Cached e;
   e.stage_arg = stage_arg;
   e.rank = rank;
+  e.n_ranks = n_ranks;
+  e.bounds_generation = ci.bounds_generation;
   e.parity = ci.frame_number & 1u;
   e.width = ci.width;
   e.height = ci.height;
   e.ratio = ci.ratio;
   e.st = *st;
   uint32_t n = 0;
-  int rc = hk_band_schedule(ci.width, ci.height, ci.ratio, rank, n_ranks, stage_arg, ci.frame_number, st, nullptr, &n);
+  int rc = hk_band_schedule_bounds(ci.width, ci.height, ci.ratio, ci.band_bounds, rank, n_ranks, stage_arg, ci.frame_number, st, nullptr, &n);
   if (rc) return rc;
   e.tr.resize(n);
-  if (n && (rc = hk_band_schedule(ci.width, ci.height, ci.ratio, rank, n_ranks, stage_arg, ci.frame_number, st, e.tr.data(), &n))) return rc;
+  if (n && (rc = hk_band_schedule_bounds(ci.width, ci.height, ci.ratio, ci.band_bounds, rank, n_ranks, stage_arg, ci.frame_number, st, e.tr.data(), &n))) return rc;
   cache.push_back(std::move(e));  // (bounded by the callers: they clear the cache when it grows past a few hundred entries)
   *out = &cache.back().tr;
   return HK_OK;
@@ -391,6 +393,8 @@ int hk_multi_context(hk_multi* m, uint32_t i, hk_ctx** out) {
 int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene(c, b)); }
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b) { HK_EACH(hk_upload_scene_instances(c, b)); }
 int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode) { HK_EACH(hk_rebuild_scene_trees(c, mode)); }
+// the same explicit split on every band's context (all of them must agree: the schedules are derived per context)
+int hk_multi_set_band_bounds(hk_multi* m, const uint32_t* bounds, uint32_t n_bounds) { HK_EACH(hk_set_band_bounds(c, bounds, n_bounds)); }
 // the builder is finished ONCE (its transform bookkeeping advances once), every band's replica takes the records and builds its trees
 int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t tree_mode) {
   HK_REQUIRE(m && b, HK_E_INVALID, "NULL argument");
@@ -437,6 +441,12 @@ int hk_multi_frame_render(hk_multi* m, const HkFrame* f, const HkView* v, const 
   int rc;
   for (hk_ctx* c : m->ctx)
     if ((rc = hk_frame_begin(c, f, v, pv, l))) return rc;
+  if ((flags & HK_FRAME_BALANCE_BANDS) && m->ctx.size() > 1) {  // one context counts (they all hold the same G-buffer), all take the split
+    std::vector<uint32_t> bounds(m->ctx.size() + 1);
+    if ((rc = hk_set_view_options(m->ctx[0], st->taa, st->upscale_kind, st->upscale_sharpness))) return rc;  // (jitter of the primary rays)
+    if ((rc = hk_balance_bands(m->ctx[0], 0, bounds.data(), (uint32_t)bounds.size()))) return rc;
+    if ((rc = hk_multi_set_band_bounds(m, bounds.data(), (uint32_t)bounds.size()))) return rc;
+  }
   const uint32_t hist = m->history_rows << 8;
   auto stage = [&](uint32_t s) {
     for (hk_ctx* c : m->ctx) {
@@ -485,9 +495,9 @@ int hk_multi_read_buffer(hk_multi* m, uint32_t buffer, void* dst, size_t bytes) 
   memset(dst, 0, bytes);
   for (uint32_t i = 0; i < n; ++i) {
     uint32_t b0, b1, y0, y1;
-    if ((rc = hk_band_rows(rh, i, n, &b0, &b1))) return rc;
+    band_rows_in(ci.band_bounds, rh, rh, i, n, &b0, &b1);
     if (fsr_window) {
-      if ((rc = hk_band_rows(ci.height, i, n, &y0, &y1))) return rc;
+      band_rows_in(ci.band_bounds, rh, ci.height, i, n, &y0, &y1);
     } else if (rows == rh) {
       y0 = b0; y1 = b1;
     } else if (upscaled && ci.upscale_kind == HK_UPSCALE_SMAA_TU4X) {

@@ -290,6 +290,8 @@ struct hk_ctx {
   float upscale_sharpness = 0.0f;
 
   uint32_t band_index = 0, band_count = 1;
+  std::vector<uint32_t> band_bounds;   // explicit split of the scaled render rows (hk_set_band_bounds): band_count + 1 entries, or empty = equal split
+  uint32_t bounds_generation = 0;
   void* comm = nullptr;        // RCCL communicator state, owned by comm.cpp (hk_comm_init)
   uint32_t history_rows = 0;   // exchange C rows (hk_comm_set_history_rows)
 
@@ -1415,6 +1417,8 @@ int ctx_info(hk_ctx* c, CtxInfo* o) {
   o->band_count = c->band_count;
   o->upscale_kind = c->upscale_kind;
   o->taa = c->taa;
+  o->band_bounds = c->band_bounds.size() == (size_t)c->band_count + 1 ? c->band_bounds.data() : nullptr;
+  o->bounds_generation = c->bounds_generation;
   return HK_OK;
 }
 void* ctx_buffer(hk_ctx* c, uint32_t b, size_t* logical_bytes) {
@@ -1939,6 +1943,10 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
   HK_HIP(hipSetDevice(c->device));
   { const int rc_ = sync_all(c); if (rc_) return rc_; }
   free_screen(c);
+  if (!c->band_bounds.empty()) {  // an explicit band split is in rows of the OLD render image
+    c->band_bounds.clear();
+    c->bounds_generation += 1;
+  }
   uint32_t rw, rh;
   int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
   if (rc) return rc;
@@ -2051,15 +2059,99 @@ int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint
 
 int hk_set_band(hk_ctx* c, uint32_t band_index, uint32_t band_count) {
   HK_REQUIRE(c && band_count > 0 && band_index < band_count, HK_E_INVALID, "bad band");
+  if (band_count != c->band_count && !c->band_bounds.empty()) {  // another band count: the explicit split no longer applies
+    c->band_bounds.clear();
+    c->bounds_generation += 1;
+  }
   c->band_index = band_index;
   c->band_count = band_count;
+  return HK_OK;
+}
+
+int hk_set_band_bounds(hk_ctx* c, const uint32_t* bounds, uint32_t n_bounds) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  if (!bounds || n_bounds == 0) {  // back to the equal split
+    if (!c->band_bounds.empty()) c->bounds_generation += 1;
+    c->band_bounds.clear();
+    return HK_OK;
+  }
+  HK_REQUIRE(c->RH > 0, HK_E_NOT_READY, "hk_resize has not been called");
+  HK_REQUIRE(n_bounds == c->band_count + 1, HK_E_INVALID, "need band_count + 1 = %u boundaries (hk_set_band first), got %u", c->band_count + 1, n_bounds);
+  HK_REQUIRE(band_bounds_valid(bounds, c->band_count, (uint32_t)c->RH), HK_E_INVALID,
+             "band bounds must run 0 = b[0] < b[1] < ... < b[%u] = %d (scaled render rows)", c->band_count, c->RH);
+  c->band_bounds.assign(bounds, bounds + n_bounds);
+  c->bounds_generation += 1;
+  return HK_OK;
+}
+
+int hk_get_band(hk_ctx* c, uint32_t* band_index, uint32_t* band_count) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  if (band_index) *band_index = c->band_index;
+  if (band_count) *band_count = c->band_count;
+  return HK_OK;
+}
+int hk_get_band_bounds(hk_ctx* c, uint32_t* bounds, uint32_t n_bounds) {  // the split in force, explicit or equal
+  HK_REQUIRE(c && bounds, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(c->RH > 0, HK_E_NOT_READY, "hk_resize has not been called");
+  HK_REQUIRE(n_bounds == c->band_count + 1, HK_E_INVALID, "need band_count + 1 = %u entries", c->band_count + 1);
+  const uint32_t* explicit_split = c->band_bounds.size() == (size_t)c->band_count + 1 ? c->band_bounds.data() : nullptr;
+  for (uint32_t i = 0; i < c->band_count; ++i) {
+    uint32_t b0, b1;
+    band_rows_in(explicit_split, (uint32_t)c->RH, (uint32_t)c->RH, i, c->band_count, &b0, &b1);
+    bounds[i] = b0;
+    bounds[i + 1] = b1;
+  }
+  return HK_OK;
+}
+
+// geometry pixels (depth >= epsilon) per row of the full-size G-buffer of the frame most recently begun: the cost estimate
+// hk_balanced_band_bounds splits by.  A host shards a frame by cost like this: every rank ray-casts the WHOLE frame's primary rays
+// once (hk_frame_begin + hk_pass_run(HK_PASS_PREPASS) over all rows - cheap next to a frame), counts, and derives the same
+// boundaries as every other rank without a word of communication.
+int hk_row_costs(hk_ctx* c, uint32_t* out, uint32_t n_rows) {
+  HK_REQUIRE(c && out, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(c->H > 0 && c->depth_plane, HK_E_NOT_READY, "hk_resize has not been called");
+  HK_REQUIRE(n_rows == (uint32_t)c->H, HK_E_INVALID, "need one counter per full-size row: %d", c->H);
+  HK_HIP(hipSetDevice(c->device));
+  { const int rc_ = sync_all(c); if (rc_) return rc_; }
+  uint32_t* d = nullptr;
+  HK_HIP(hipMalloc((void**)&d, (size_t)n_rows * 4));
+  launch_count_geometry_rows(c->stream, c->depth_plane, c->W, c->H, d);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n_rows * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HK_REQUIRE(e == hipSuccess, HK_E_HIP, "hk_row_costs failed: %s", hipGetErrorString(e));
+  return HK_OK;
+}
+
+// hk_frame_begin has run: ray-cast the whole frame's primary rays, count, split by cost, set the split on this context.  Every rank
+// (or band context) that does this for the same frame arrives at the same boundaries - the G-buffer is bit-identical everywhere.
+int hk_balance_bands(hk_ctx* c, uint32_t min_rows, uint32_t* bounds_out, uint32_t n_bounds) {
+  int rc = ready(c);
+  if (rc) return rc;
+  HK_REQUIRE(c->have_frame, HK_E_NOT_READY, "hk_frame_begin has not been called");
+  HK_REQUIRE(!bounds_out || n_bounds == c->band_count + 1, HK_E_INVALID, "need band_count + 1 = %u boundaries", c->band_count + 1);
+  std::vector<uint32_t> bounds(c->band_count + 1);
+  if (c->band_count > 1) {
+    if ((rc = hk_pass_run(c, HK_PASS_PREPASS, 0, 0, 0))) return rc;
+    std::vector<uint32_t> cost((size_t)c->H);
+    if ((rc = hk_row_costs(c, cost.data(), (uint32_t)c->H))) return rc;
+    if ((rc = hk_balanced_band_bounds(cost.data(), (uint32_t)c->H, (uint32_t)c->W, (uint32_t)c->RH, c->band_count, min_rows ? min_rows : 8u,
+                                      (size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES ? 1.0f / 16.0f : 0.25f, bounds.data()))) return rc;
+    if ((rc = hk_set_band_bounds(c, bounds.data(), c->band_count + 1))) return rc;
+  } else {
+    bounds[0] = 0u;
+    bounds[1] = (uint32_t)c->RH;
+  }
+  if (bounds_out) std::copy(bounds.begin(), bounds.end(), bounds_out);
   return HK_OK;
 }
 
 int hk_band_plan(hk_ctx* c, uint32_t stage, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
   HK_REQUIRE(c && c->W > 0, HK_E_NOT_READY, "hk_resize has not been called");
   HK_REQUIRE(c->have_frame, HK_E_NOT_READY, "hk_frame_begin has not been called");
-  return hk_band_plan_for((uint32_t)c->W, (uint32_t)c->H, c->ratio, c->band_index, c->band_count, stage, c->frame.number, st, ops, n_ops);
+  const uint32_t* bounds = c->band_bounds.size() == (size_t)c->band_count + 1 ? c->band_bounds.data() : nullptr;
+  return hk_band_plan_bounds((uint32_t)c->W, (uint32_t)c->H, c->ratio, bounds, c->band_index, c->band_count, stage, c->frame.number, st, ops, n_ops);
 }
 
 int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t flags) {
@@ -2077,7 +2169,9 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
   c->upscale_kind = st->upscale_kind;
   c->upscale_sharpness = st->upscale_sharpness;
   uint32_t ub0, ub1;
-  band_rows((uint32_t)c->RH, c->band_index, c->band_count, &ub0, &ub1);
+  const uint32_t* bounds = c->band_bounds.size() == (size_t)c->band_count + 1 ? c->band_bounds.data() : nullptr;
+  HK_REQUIRE(band_bounds_valid(bounds, c->band_count, (uint32_t)c->RH), HK_E_INVALID, "the band boundaries do not fit the current render size (hk_set_band_bounds after hk_resize)");
+  band_rows_in(bounds, (uint32_t)c->RH, (uint32_t)c->RH, c->band_index, c->band_count, &ub0, &ub1);
   const int b0 = (int)ub0, b1 = (int)ub1;
   auto clampr = [&](int v) { return std::min(std::max(v, 0), c->RH); };
   const Aprons ap = band_aprons(st);
@@ -2207,7 +2301,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     if ((rc = join_post(c))) return rc;
     if (st->upscale_kind == HK_UPSCALE_FSR1) {
       uint32_t w0, w1;
-      band_rows((uint32_t)c->H, c->band_index, c->band_count, &w0, &w1);
+      band_rows_in(bounds, (uint32_t)c->RH, (uint32_t)c->H, c->band_index, c->band_count, &w0, &w1);
       HK_RUN(HK_PASS_FSR_EASU, 0, std::max((int)w0 - 1, 0), std::min((int)w1 + 1, c->H));
       HK_RUN(HK_PASS_FSR_RCAS, 0, (int)w0, (int)w1);
     }
@@ -2222,6 +2316,11 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
   int rc = hk_frame_begin(c, f, v, pv, l);
   if (rc) return rc;
   HK_REQUIRE(st, HK_E_INVALID, "settings is NULL");
+  if (flags & HK_FRAME_BALANCE_BANDS) {
+    c->taa = st->taa;  // (the sub-pixel jitter of the primary rays follows the settings: hk_frame_stage would set them only later)
+    c->upscale_kind = st->upscale_kind;
+    if ((rc = hk_balance_bands(c, 0, nullptr, 0))) return rc;
+  }
   // with a communicator attached (hk_comm_init) the halo exchanges of the band plan run here, on the context's stream
   const bool ex = c->comm != nullptr && c->band_count > 1;
   const uint32_t hist = c->history_rows << 8;

@@ -51,6 +51,10 @@ bool buffer_is_upscaled(uint32_t buffer);  // allocated at the SMAA Tu4x output 
 
 // rows [b0,b1) of band i of n over `height` rows
 void band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32_t* b0, uint32_t* b1);
+// ... when the split of the `render_rows` scaled render rows is explicit (bounds[0..n], NULL = equal split); `rows` = the height of
+// the plane being cut (render_rows, or the window rows FSR1 writes)
+void band_rows_in(const uint32_t* bounds, uint32_t render_rows, uint32_t rows, uint32_t band_index, uint32_t band_count, uint32_t* b0, uint32_t* b1);
+bool band_bounds_valid(const uint32_t* bounds, uint32_t band_count, uint32_t render_rows);
 
 // apron rows (in scaled render rows) each stage needs around a band, from the kernel footprints
 struct Aprons {
@@ -67,6 +71,8 @@ struct CtxInfo {
   uint32_t width, height;  // window size
   float ratio;
   uint32_t frame_number, band_index, band_count, upscale_kind, taa;
+  const uint32_t* band_bounds;   // explicit split of the scaled render rows (hk_set_band_bounds; band_count + 1 entries) or NULL
+  uint32_t bounds_generation;    // changes whenever the split does (cached schedules compare it)
 };
 int ctx_info(hk_ctx* c, CtxInfo* out);
 void* ctx_buffer(hk_ctx* c, uint32_t buffer, size_t* logical_bytes);

@@ -266,6 +266,7 @@ int launch_tree_build(hipStream_t st, int mode /* 0 LBVH, 1 the reference's binn
 void launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                     int y0, int y1);
 void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);
+void launch_count_geometry_rows(hipStream_t st, const float* depth, int width, int height, uint32_t* out);
 void launch_demodulation(hipStream_t st, int nch, const hkd::DFrame& fr, const hkd::DemodTargets& d, int y0, int y1);
 void launch_denoise(hipStream_t st, int level, int nch, int ffmask, const hkd::DFrame& fr, const hkd::DenoiseTargets& d, int y0, int y1);
 void launch_tone_mapping(hipStream_t st, const hkd::DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1);

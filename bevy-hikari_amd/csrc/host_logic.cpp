@@ -52,6 +52,29 @@ void band_rows(uint32_t height, uint32_t i, uint32_t n, uint32_t* b0, uint32_t* 
   *b0 = i * base + std::min(i, rem);
   *b1 = *b0 + base + (i < rem ? 1u : 0u);
 }
+// Band i of n over `rows` rows when the split of the `render_rows` rows of the scaled render image is given explicitly
+// (bounds[0] = 0 < bounds[1] < ... < bounds[n] = render_rows; NULL = the equal split).  Planes of another height (the window
+// rows FSR1 writes) are cut where the render rows' boundaries fall in them.
+void band_rows_in(const uint32_t* bounds, uint32_t render_rows, uint32_t rows, uint32_t i, uint32_t n, uint32_t* b0, uint32_t* b1) {
+  if (!bounds) {
+    band_rows(rows, i, n, b0, b1);
+    return;
+  }
+  auto cut = [&](uint32_t k) -> uint32_t {
+    if (k == 0) return 0u;
+    if (k == n) return rows;
+    return rows == render_rows ? bounds[k] : (uint32_t)(((uint64_t)bounds[k] * rows) / render_rows);
+  };
+  *b0 = cut(i);
+  *b1 = cut(i + 1);
+}
+bool band_bounds_valid(const uint32_t* bounds, uint32_t n, uint32_t render_rows) {
+  if (!bounds) return true;
+  if (bounds[0] != 0u || bounds[n] != render_rows) return false;
+  for (uint32_t k = 0; k < n; ++k)
+    if (bounds[k + 1] <= bounds[k]) return false;
+  return true;
+}
 
 // Kernel footprints in scaled render rows:
 //  spatial_reuse reads neighbour reservoirs within SPATIAL_REUSE_RANGE px (20 indirect / 10
@@ -219,12 +242,12 @@ int hk_band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint
 
 // Rows [lo,hi) of `buffer` are needed by band `band_index`; emit one op per other band that owns a
 // piece of them.
-static void emit(uint32_t buffer, uint32_t width, uint32_t height, uint32_t lo, uint32_t hi, uint32_t band_index, uint32_t band_count,
+static void emit(const uint32_t* bounds, uint32_t buffer, uint32_t width, uint32_t height, uint32_t lo, uint32_t hi, uint32_t band_index, uint32_t band_count,
                  HkHaloOp* ops, uint32_t* n, uint32_t cap) {
   for (uint32_t j = 0; j < band_count; ++j) {
     if (j == band_index) continue;
     uint32_t o0, o1;
-    band_rows(height, j, band_count, &o0, &o1);
+    band_rows_in(bounds, height, height, j, band_count, &o0, &o1);
     uint32_t a = std::max(lo, o0), b = std::min(hi, o1);
     if (a >= b) continue;
     if (ops && *n < cap) {
@@ -240,6 +263,11 @@ static void emit(uint32_t buffer, uint32_t width, uint32_t height, uint32_t lo, 
 
 int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count, uint32_t stage_arg,
                      uint32_t frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
+  return hk_band_plan_bounds(width, height, upscale_ratio, nullptr, band_index, band_count, stage_arg, frame_number, st, ops, n_ops);
+}
+
+int hk_band_plan_bounds(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* bounds, uint32_t band_index, uint32_t band_count,
+                        uint32_t stage_arg, uint32_t frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
   const uint32_t stage = stage_arg & 0xffu, history_rows = stage_arg >> 8;  // HK_STAGE_TEMPORAL_WITH_HISTORY
   HK_REQUIRE(history_rows == 0 || stage == HK_STAGE_TEMPORAL || stage == HK_STAGE_ANTIALIAS, HK_E_INVALID, "history rows only apply to the temporal and antialias stages");
   HK_REQUIRE(st && n_ops && band_count > 0 && band_index < band_count && stage < HK_STAGE_COUNT, HK_E_INVALID, "bad argument");
@@ -247,10 +275,11 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
   int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
   if (rc) return rc;
   HK_REQUIRE(rh >= band_count, HK_E_INVALID, "more bands than rows");  // then height >= band_count too
+  HK_REQUIRE(band_bounds_valid(bounds, band_count, rh), HK_E_INVALID, "band bounds must run 0 = b[0] < b[1] < ... < b[%u] = %u (scaled render rows)", band_count, rh);
   const uint32_t cap = ops ? *n_ops : 0;
   uint32_t n = 0;
   uint32_t b0, b1;
-  band_rows(rh, band_index, band_count, &b0, &b1);
+  band_rows_in(bounds, rh, rh, band_index, band_count, &b0, &b1);
   auto lo = [&](uint32_t a) { return b0 > a ? b0 - a : 0u; };
   auto hi = [&](uint32_t a) { return std::min(rh, b1 + a); };
   // reservoir ping-pong, light.rs:376,480-481: the temporal dispatch writes buf[previous + T]
@@ -260,26 +289,26 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
     // previous_spatial = buf[current + S] with (T, S) = (0, 4) sun, (2, 4) emissive, (6, 8) indirect.
     const uint32_t current = frame_number % 2u;
     const uint32_t temporal[3] = {0u, 2u, 6u};
-    for (uint32_t t : temporal) emit(HK_BUF_RESERVOIR0 + current + t, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
-    if (st->emissive_spatial_reuse) emit(HK_BUF_RESERVOIR0 + current + 4u, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
-    if (st->indirect_spatial_reuse) emit(HK_BUF_RESERVOIR0 + current + 8u, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
+    for (uint32_t t : temporal) emit(bounds, HK_BUF_RESERVOIR0 + current + t, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
+    if (st->emissive_spatial_reuse) emit(bounds, HK_BUF_RESERVOIR0 + current + 4u, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
+    if (st->indirect_spatial_reuse) emit(bounds, HK_BUF_RESERVOIR0 + current + 8u, rw, rh, lo(history_rows), hi(history_rows), band_index, band_count, ops, &n, cap);
   } else if (stage == HK_STAGE_SPATIAL) {
     // reservoirs are allocated at full width (light.rs:344) but indexed with the scaled width
     // (light.wgsl:1061): a "row" of the exchange is rw reservoirs
     if (st->emissive_spatial_reuse) {
       uint32_t buf = HK_BUF_RESERVOIR0 + previous + 2;
-      emit(buf, rw, rh, lo(10), hi(10), band_index, band_count, ops, &n, cap);
+      emit(bounds, buf, rw, rh, lo(10), hi(10), band_index, band_count, ops, &n, cap);
     }
     if (st->indirect_spatial_reuse) {
       uint32_t buf = HK_BUF_RESERVOIR0 + previous + 6;
-      emit(buf, rw, rh, lo(20), hi(20), band_index, band_count, ops, &n, cap);
+      emit(bounds, buf, rw, rh, lo(20), hi(20), band_index, band_count, ops, &n, cap);
     }
   } else if (stage == HK_STAGE_POST_PROCESS) {
     if (st->denoise) {
       uint32_t nch = st->indirect_bounces == 0 ? 2u : 3u;  // post_process.rs:949-954
       for (uint32_t ch = 0; ch < nch; ++ch) {
-        emit(HK_BUF_RENDER0 + ch, rw, rh, lo(15), hi(15), band_index, band_count, ops, &n, cap);
-        emit(HK_BUF_VARIANCE0 + ch, rw, rh, lo(16), hi(16), band_index, band_count, ops, &n, cap);
+        emit(bounds, HK_BUF_RENDER0 + ch, rw, rh, lo(15), hi(15), band_index, band_count, ops, &n, cap);
+        emit(bounds, HK_BUF_VARIANCE0 + ch, rw, rh, lo(16), hi(16), band_index, band_count, ops, &n, cap);
       }
     }
   }
@@ -293,8 +322,8 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
     // over bilinear taps reaches 3 output rows.  history_rows (scaled render rows) extends the history planes.
     const bool smaa = st->upscale_kind == HK_UPSCALE_SMAA_TU4X, taa = st->taa == HK_TAA_JASMINE;
     const uint32_t tm = smaa ? 4u : (taa ? 1u : 0u);
-    if (tm) emit(HK_BUF_TONE_MAPPED, rw, rh, lo(tm), hi(tm), band_index, band_count, ops, &n, cap);
-    if (smaa && history_rows) emit(HK_BUF_PREVIOUS_TONE_MAPPED, rw, rh, lo(tm + history_rows), hi(tm + history_rows), band_index, band_count, ops, &n, cap);
+    if (tm) emit(bounds, HK_BUF_TONE_MAPPED, rw, rh, lo(tm), hi(tm), band_index, band_count, ops, &n, cap);
+    if (smaa && history_rows) emit(bounds, HK_BUF_PREVIOUS_TONE_MAPPED, rw, rh, lo(tm + history_rows), hi(tm + history_rows), band_index, band_count, ops, &n, cap);
     if (taa) {
       // taa_output rows are output rows: 2 per render row with SMAA Tu4x (ceil(size * 2 / ratio) of them), 1 otherwise
       const uint32_t scale = smaa ? 2u : 1u;
@@ -305,7 +334,7 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
       for (uint32_t j = 0; j < band_count; ++j) {
         if (j == band_index) continue;
         uint32_t o0, o1;
-        band_rows(rh, j, band_count, &o0, &o1);
+        band_rows_in(bounds, rh, rh, j, band_count, &o0, &o1);
         const uint32_t a = std::max(need_lo, scale * o0), b = std::min(need_hi, std::min(th, scale * o1));
         if (a >= b) continue;
         if (ops && n < cap) {
@@ -323,13 +352,13 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
     // exchange E.  EASU (ffx_fsr1.h:315-441) of window row y reads input rows f-1..f+2 with f = floor(y * con0.y + con0.w),
     // the same two f32 operations as the kernel; the band's EASU rows are its window rows +-1 for RCAS's cross.
     uint32_t w0, w1;
-    band_rows(height, band_index, band_count, &w0, &w1);
+    band_rows_in(bounds, rh, height, band_index, band_count, &w0, &w1);
     const uint32_t e0 = w0 > 0 ? w0 - 1 : 0, e1 = std::min(height, w1 + 1);
     const float ivy = (float)rh, osy = (float)height;
     const float con0y = ivy * (1.0f / osy), con0w = 0.5f * ivy * (1.0f / osy) - 0.5f;
     const int f_lo = (int)floorf((float)e0 * con0y + con0w) - 1, f_hi = (int)floorf((float)(e1 - 1) * con0y + con0w) + 2;
     const uint32_t need_lo = (uint32_t)std::max(f_lo, 0), need_hi = (uint32_t)std::min(f_hi, (int)rh - 1) + 1u;
-    emit(st->taa == HK_TAA_JASMINE ? HK_BUF_TAA_OUTPUT : HK_BUF_TONE_MAPPED, rw, rh, need_lo, need_hi, band_index, band_count, ops, &n, cap);
+    emit(bounds, st->taa == HK_TAA_JASMINE ? HK_BUF_TAA_OUTPUT : HK_BUF_TONE_MAPPED, rw, rh, need_lo, need_hi, band_index, band_count, ops, &n, cap);
   }
   if (ops && n > cap) {
     *n_ops = n;
@@ -347,16 +376,21 @@ int hk_bvh_rethread(const HkNode* nodes, uint32_t count, uint32_t octant, HkNode
 
 int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint32_t rank, uint32_t n_ranks, uint32_t stage,
                      uint32_t frame_number, const HkSettings* st, HkTransfer* out, uint32_t* n_out) {
+  return hk_band_schedule_bounds(width, height, upscale_ratio, nullptr, rank, n_ranks, stage, frame_number, st, out, n_out);
+}
+
+int hk_band_schedule_bounds(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* bounds, uint32_t rank, uint32_t n_ranks, uint32_t stage,
+                            uint32_t frame_number, const HkSettings* st, HkTransfer* out, uint32_t* n_out) {
   HK_REQUIRE(st && n_out && n_ranks > 0 && rank < n_ranks, HK_E_INVALID, "bad argument");
   const uint32_t cap = out ? *n_out : 0;
   uint32_t n = 0;
   std::vector<HkHaloOp> ops;
   for (uint32_t r = 0; r < n_ranks; ++r) {  // the fixed global order: receive plan of rank 0, 1, ...
     uint32_t k = 0;
-    int rc = hk_band_plan_for(width, height, upscale_ratio, r, n_ranks, stage, frame_number, st, nullptr, &k);
+    int rc = hk_band_plan_bounds(width, height, upscale_ratio, bounds, r, n_ranks, stage, frame_number, st, nullptr, &k);
     if (rc) return rc;
     ops.resize(k);
-    if (k && (rc = hk_band_plan_for(width, height, upscale_ratio, r, n_ranks, stage, frame_number, st, ops.data(), &k))) return rc;
+    if (k && (rc = hk_band_plan_bounds(width, height, upscale_ratio, bounds, r, n_ranks, stage, frame_number, st, ops.data(), &k))) return rc;
     for (uint32_t i = 0; i < k; ++i) {
       const HkHaloOp& op = ops[i];
       const bool recv = r == rank, send = op.peer == rank;
@@ -377,6 +411,36 @@ int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint3
     HK_REQUIRE(false, HK_E_INVALID, "transfer array too small: need %u", n);
   }
   *n_out = n;
+  return HK_OK;
+}
+
+// Row boundaries that give every band about the same COST: cost(row) = geometry pixels in it + width x background_cost, the cost
+// of a background pixel in units of a geometry pixel (<= 0: 1/16).  Measured (profiles/r03_band_balance_probe.json): a sky band of
+// config 4 takes 0.3 ms, a city band 6.3 ms; in the Cornell frame, whose geometry pixels are cheap, a background pixel costs ~1/4.  row_cost
+// has cost_rows entries (the rows of the plane it was counted on); the boundaries are in scaled render rows, every band gets at
+// least min_rows of them.  Pure host logic, deterministic: ranks that counted the same G-buffer derive the same split.
+int hk_balanced_band_bounds(const uint32_t* row_cost, uint32_t cost_rows, uint32_t width, uint32_t render_rows, uint32_t band_count, uint32_t min_rows,
+                            float background_cost, uint32_t* bounds) {
+  HK_REQUIRE(row_cost && bounds && cost_rows > 0 && band_count > 0 && render_rows >= band_count, HK_E_INVALID, "bad argument");
+  min_rows = std::max(min_rows, 1u);
+  HK_REQUIRE(std::isfinite(background_cost) && background_cost <= 1.0f, HK_E_INVALID, "background_cost is the cost of a background pixel relative to a geometry pixel (0..1]");
+  const double per_row = (double)width * (background_cost > 0.0f ? (double)background_cost : 1.0 / 16.0);
+  HK_REQUIRE((uint64_t)min_rows * band_count <= render_rows, HK_E_INVALID, "min_rows x band_count exceeds the %u render rows", render_rows);
+  std::vector<double> prefix(render_rows + 1, 0.0);  // cost of render rows [0, k)
+  for (uint32_t y = 0; y < render_rows; ++y) {
+    const uint32_t src = (uint32_t)(((uint64_t)y * cost_rows) / render_rows);
+    prefix[y + 1] = prefix[y] + (double)row_cost[src] + per_row;
+  }
+  const double total = prefix[render_rows];
+  bounds[0] = 0u;
+  for (uint32_t k = 1; k < band_count; ++k) {
+    const double target = total * (double)k / (double)band_count;
+    uint32_t y = (uint32_t)(std::lower_bound(prefix.begin(), prefix.end(), target) - prefix.begin());
+    y = std::max(y, bounds[k - 1] + min_rows);                                 // at least min_rows in the band before
+    y = std::min(y, render_rows - (band_count - k) * min_rows);                // ... and in every band after
+    bounds[k] = y;
+  }
+  bounds[band_count] = render_rows;
   return HK_OK;
 }
 

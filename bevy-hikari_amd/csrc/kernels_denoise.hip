@@ -34,6 +34,18 @@ __global__ __launch_bounds__(256) void k_derive_planes(GBuffer g, float* __restr
   dn_g[idx] = denoise_geometry(g.normal[idx], g.instance_material[idx].x);
 }
 
+// geometry pixels per row of the depth plane (hk_row_costs): one workgroup per row
+__global__ __launch_bounds__(256) void k_count_geometry_rows(const float* __restrict__ depth, int width, uint32_t* __restrict__ out) {
+  __shared__ uint32_t partial[4];
+  const int y = (int)blockIdx.x;
+  uint32_t n = 0;
+  for (int x = (int)threadIdx.x; x < width; x += 256) n += !(depth[(size_t)y * width + x] < HK_F32_EPSILON) ? 1u : 0u;
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+  if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) out[y] = partial[0] + partial[1] + partial[2] + partial[3];
+}
+
 template <int NCH>
 __global__ __launch_bounds__(256) void k_demodulation(DFrame fr, DemodTargets d, int row_begin, int row_end) {  // denoise.wgsl:135-162
   const Pixel px = pixel_of_thread_rows<64, true>(fr.rw, row_begin, row_end);
@@ -236,6 +248,11 @@ using namespace hkd;
 void launch_derive_planes(hipStream_t st, const GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1) {
   if (y1 <= y0) return;
   hipLaunchKernelGGL(k_derive_planes, grid_for(width, y1 - y0), dim3(256), 0, st, g, depth_plane, (float4*)dn_g, width, y0, y1);
+}
+
+void launch_count_geometry_rows(hipStream_t st, const float* depth, int width, int height, uint32_t* out) {
+  if (height <= 0) return;
+  hipLaunchKernelGGL(k_count_geometry_rows, dim3((unsigned)height), dim3(256), 0, st, depth, width, out);
 }
 
 void launch_demodulation(hipStream_t st, int nch, const DFrame& fr, const DemodTargets& d, int y0, int y1) {

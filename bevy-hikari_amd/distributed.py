@@ -37,36 +37,47 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def halo_plan(width, height, upscale_ratio, band_index, band_count, stage, frame_number, settings_c):
-    """Halo transfers band `band_index` must RECEIVE before `stage` (list of HkHaloOp)."""
+def halo_plan(width, height, upscale_ratio, band_index, band_count, stage, frame_number, settings_c, bounds=None):
+    """Halo transfers band `band_index` must RECEIVE before `stage` (list of HkHaloOp); bounds: an explicit split or None."""
     api = F.api()
     n = F.u32(0)
-    api.call("band_plan_for", width, height, upscale_ratio, band_index, band_count, stage, frame_number, C.byref(settings_c), None, C.byref(n))
+    b = None if bounds is None else (C.c_uint32 * len(bounds))(*[int(x) for x in bounds])
+    api.call("band_plan_bounds", width, height, upscale_ratio, b, band_index, band_count, stage, frame_number, C.byref(settings_c), None, C.byref(n))
     ops = (F.HkHaloOp * max(n.value, 1))()
     n2 = F.u32(n.value)
     if n.value:
-        api.call("band_plan_for", width, height, upscale_ratio, band_index, band_count, stage, frame_number, C.byref(settings_c), ops, C.byref(n2))
+        api.call("band_plan_bounds", width, height, upscale_ratio, b, band_index, band_count, stage, frame_number, C.byref(settings_c), ops, C.byref(n2))
     return [ops[i] for i in range(n2.value)]
 
 
-def band_schedule(width, height, upscale_ratio, rank, n_ranks, stage, frame_number, settings_c):
-    """hk_band_schedule: every transfer `rank` takes part in before `stage`, sends and receives, in the global order all
-    ranks agree on (list of HkTransfer)."""
+def band_schedule(width, height, upscale_ratio, rank, n_ranks, stage, frame_number, settings_c, bounds=None):
+    """hk_band_schedule(_bounds): every transfer `rank` takes part in before `stage`, sends and receives, in the global order all
+    ranks agree on (list of HkTransfer).  bounds: explicit split of the scaled render rows (n_ranks + 1 entries) or None."""
     api = F.api()
     n = F.u32(0)
-    api.call("band_schedule", width, height, upscale_ratio, rank, n_ranks, stage, frame_number, C.byref(settings_c), None, C.byref(n))
+    b = None if bounds is None else (C.c_uint32 * len(bounds))(*[int(x) for x in bounds])
+    api.call("band_schedule_bounds", width, height, upscale_ratio, b, rank, n_ranks, stage, frame_number, C.byref(settings_c), None, C.byref(n))
     tr = (F.HkTransfer * max(n.value, 1))()
     n2 = F.u32(n.value)
     if n.value:
-        api.call("band_schedule", width, height, upscale_ratio, rank, n_ranks, stage, frame_number, C.byref(settings_c), tr, C.byref(n2))
+        api.call("band_schedule_bounds", width, height, upscale_ratio, b, rank, n_ranks, stage, frame_number, C.byref(settings_c), tr, C.byref(n2))
     return [tr[i] for i in range(n2.value)]
+
+
+def balanced_band_bounds(row_costs, width, render_rows, band_count, min_rows=8, background_cost=0.0):
+    """hk_balanced_band_bounds: boundaries (band_count + 1 scaled render rows) that give every band about the same cost
+    (geometry pixels + width x background_cost per row; 0 = 1/16)."""
+    rc = np.ascontiguousarray(row_costs, dtype=np.uint32)
+    out = (C.c_uint32 * (band_count + 1))()
+    F.api().call("balanced_band_bounds", rc.ctypes.data_as(C.POINTER(C.c_uint32)), len(rc), width, render_rows, band_count, min_rows, background_cost, out)
+    return [int(x) for x in out]
 
 
 class BandRenderer:
     """Drives one rank's band of the frame; `engine` is a bevy_hikari_amd.Engine (or, in the CPU tests, the oracle behind
     the same class).  transport: "rccl" (the product: exchanges inside the library) or "host" (tests, see the module text)."""
 
-    def __init__(self, engine, rank, world_size, backend_device="cuda", transport=None, fallback=None):
+    def __init__(self, engine, rank, world_size, backend_device="cuda", transport=None, fallback=None, bounds=None):
         """fallback: what to do when transport "rccl" cannot come up on every rank.  None (default) raises the same
         RuntimeError on ALL ranks - a job that asked for RCCL never silently becomes a PCIe-through-host job; "host" agrees
         on the host-staged transport instead (slower, same bytes) and says so in `transport`."""
@@ -80,7 +91,10 @@ class BandRenderer:
         self._plans = {}
         self._generation = getattr(engine, "generation", 0)
         self.rccl_error = None
+        self.bounds = None
         engine.set_band(rank, world_size)
+        if bounds is not None:
+            self.set_bounds(bounds)
         if self.transport == "rccl" and world_size > 1:
             import torch.distributed as dist
 
@@ -124,6 +138,12 @@ class BandRenderer:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return int(t.item()) == 1
 
+    def set_bounds(self, bounds):
+        """Bands of unequal height (hk_set_band_bounds): EVERY rank must set the same boundaries.  None = the equal split."""
+        self.bounds = None if bounds is None else [int(b) for b in bounds]
+        self.engine.set_band_bounds(self.bounds)
+        self._plans = {}
+
     # ------------------------------------------------------------------ host transport (tests)
     def _view(self, buf, parity=0):
         # the double-buffered ids (HkBuffer: position, velocity, tone-mapped, TAA) name a different plane on odd and
@@ -160,7 +180,7 @@ class BandRenderer:
         if hit is not None:
             return hit
         out = []
-        for t in band_schedule(width, height, upscale_ratio, self.rank, self.world, stage, frame_number, settings_c):
+        for t in band_schedule(width, height, upscale_ratio, self.rank, self.world, stage, frame_number, settings_c, self.bounds):
             out.append((bool(t.is_recv), self._view(t.buffer, frame_number & 1)[t.offset:t.offset + t.bytes], t.peer))
         self._plans[key] = out
         return out
@@ -192,18 +212,26 @@ class BandRenderer:
             self.torch.cuda.synchronize()  # the halo rows are in place before the next stage is enqueued on the engine's stream
         return nbytes
 
-    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0, antialias=False):
+    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0, antialias=False, balance=False):
         """One frame of this rank's band.  history_rows > 0 (camera or objects moved since the last frame) first fetches
-        that many rows of last frame's reservoirs from the neighbouring bands (exchange C)."""
+        that many rows of last frame's reservoirs from the neighbouring bands (exchange C).  balance: split THIS frame's rows by
+        cost first (HK_FRAME_BALANCE_BANDS / hk_balance_bands - every rank derives the same split from its own full-frame primary
+        rays) and keep the split; meant for the first frame or a cut (rows that change owner lose their history)."""
         e = self.engine
         sc = settings.to_c()
         if self.transport == "rccl":
             if self.world > 1:
                 e.comm_set_history_rows(int(history_rows))
-            e.frame_render(frame, view, previous_view, lights, sc, F.FRAME_ANTIALIAS if antialias else 0)
+            e.frame_render(frame, view, previous_view, lights, sc, (F.FRAME_ANTIALIAS if antialias else 0) | (F.FRAME_BALANCE_BANDS if balance else 0))
+            if balance:
+                self.bounds = e.band_bounds()
             return
         ratio = settings.upscale.ratio()
         e.frame_begin(frame, view, previous_view, lights)
+        if balance and self.world > 1:
+            e.set_view_options(sc.taa, sc.upscale_kind, sc.upscale_sharpness)   # (the primary rays' sub-pixel jitter follows the settings)
+            self.bounds = e.balance_bands()
+            self._plans = {}
         if history_rows > 0:
             e.wait()
             self.exchange(F.STAGE_TEMPORAL | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
@@ -224,6 +252,11 @@ class BandRenderer:
                 e.frame_stage(F.STAGE_UPSCALE, sc)
 
     def band(self, rows):
+        """Rows [b0, b1) of a plane of `rows` rows this rank owns (the render rows; other heights are cut where the boundaries fall)."""
+        if self.bounds is not None:
+            rr = self.bounds[-1]
+            cut = lambda k: 0 if k == 0 else (rows if k == self.world else (self.bounds[k] if rows == rr else self.bounds[k] * rows // rr))
+            return cut(self.rank), cut(self.rank + 1)
         base, rem = divmod(rows, self.world)
         b0 = self.rank * base + min(self.rank, rem)
         return b0, b0 + base + (1 if self.rank < rem else 0)
@@ -277,6 +310,14 @@ class MultiEngine:
 
     def update_instances_on_device(self, builder, mode=F.TREE_SAH):
         self.api.call("multi_update_scene_instances", self.h, builder.h, mode)
+
+    def set_band_bounds(self, bounds=None):
+        """hk_multi_set_band_bounds: bands of unequal height, the same split on every context (None = equal)."""
+        if bounds is None:
+            self.api.call("multi_set_band_bounds", self.h, None, 0)
+        else:
+            arr = (C.c_uint32 * len(bounds))(*[int(b) for b in bounds])
+            self.api.call("multi_set_band_bounds", self.h, arr, len(bounds))
 
     def resize(self, width, height, upscale_ratio=1.0):
         self.api.call("multi_resize", self.h, width, height, upscale_ratio)

@@ -510,6 +510,59 @@ class Engine:
 
     def set_band(self, index, count):
         self.api.call("set_band", self.ctx, index, count)
+        self._band = (index, count)
+
+    def band_count(self):
+        if "get_band" in self.api._fns:
+            n = F.u32(0)
+            self.api.call("get_band", self.ctx, None, C.byref(n))
+            return n.value
+        return getattr(self, "_band", (0, 1))[1]
+
+    def set_band_bounds(self, bounds=None):
+        """hk_set_band_bounds: band i renders scaled render rows [bounds[i], bounds[i + 1]); None = the equal split."""
+        self._bounds = None if bounds is None else [int(b) for b in bounds]
+        if bounds is None:
+            self.api.call("set_band_bounds", self.ctx, None, 0)
+            return
+        arr = (C.c_uint32 * len(bounds))(*[int(b) for b in bounds])
+        self.api.call("set_band_bounds", self.ctx, arr, len(bounds))
+
+    def band_bounds(self):
+        """hk_get_band_bounds: the split in force (band_count + 1 scaled render rows), explicit or equal."""
+        n = self.band_count() + 1
+        if "get_band_bounds" not in self.api._fns:   # (the oracle behind the same table)
+            return getattr(self, "_bounds", None)
+        out = (C.c_uint32 * n)()
+        self.api.call("get_band_bounds", self.ctx, out, n)
+        return [int(x) for x in out]
+
+    def balance_bands(self, min_rows=0):
+        """hk_balance_bands (after frame_begin): ray-cast the whole frame's primary rays, count geometry pixels per row, split the
+        render rows by cost and keep the split.  Returns the boundaries - the same on every rank that does this for the frame."""
+        _w, rh, _b = self.buffer_info(F.BUF_TONE_MAPPED)
+        n = self.band_count() + 1
+        if "balance_bands" in self.api._fns:
+            out = (C.c_uint32 * n)()
+            self.api.call("balance_bands", self.ctx, min_rows, out, n)
+            return [int(x) for x in out]
+        # (a library without the composite - the oracle behind the same ctypes table in the CPU tests: the same three steps)
+        from .distributed import balanced_band_bounds
+
+        if n == 2:
+            return [0, rh]
+        self.pass_run(F.PASS_PREPASS)
+        w, _h, _b = self.buffer_info(F.BUF_POSITION)
+        bounds = balanced_band_bounds(self.row_costs(), w, rh, n - 1, min_rows or 8, 0.25)   # (the CPU test scenes are LDS-sized)
+        self.set_band_bounds(bounds)
+        return bounds
+
+    def row_costs(self):
+        """hk_row_costs: geometry pixels per full-size row of the frame most recently begun (numpy uint32[height])."""
+        _w, h, _b = self.buffer_info(F.BUF_POSITION)
+        out = np.zeros(h, dtype=np.uint32)
+        self.api.call("row_costs", self.ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), h)
+        return out
 
     # -- buffers
     def buffer_info(self, buf):

@@ -541,6 +541,10 @@ int hk_pass_run(hk_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, ui
 #define HK_FRAME_EXTERNAL_GBUFFER 1u
 /* flags bit1 (hk_frame_render): also run HK_STAGE_ANTIALIAS */
 #define HK_FRAME_ANTIALIAS 2u
+/* flags bit2 (hk_frame_render, hk_multi_frame_render): hk_balance_bands right after hk_frame_begin - split THIS frame's rows by
+ * cost and keep the split from here on.  Rows that change owner find the new owner's (stale) reservoirs as history: use it on
+ * the first frame, after a cut, or accept a few frames of re-convergence in the moved rows. */
+#define HK_FRAME_BALANCE_BANDS 4u
 int hk_frame_stage(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, uint32_t flags);
 /* hk_frame_begin + TEMPORAL, SPATIAL, POST_PROCESS (+ ANTIALIAS with HK_FRAME_ANTIALIAS): single GPU, no halo exchange */
 int hk_frame_render(hk_ctx* ctx, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
@@ -552,6 +556,27 @@ int hk_frame_wait(hk_ctx* ctx);
  * (bands are contiguous row ranges, remainder rows spread over the first bands). */
 int hk_set_band(hk_ctx* ctx, uint32_t band_index, uint32_t band_count);
 int hk_band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32_t* row_begin, uint32_t* row_end);
+/* Bands of unequal height (round 3).  Equal row counts are equal WORK only when the rows are alike: a sky band of the city-class
+ * 4K frame takes 0.3 ms, a band full of buildings 6.3 ms.  bounds[0] = 0 < bounds[1] < ... < bounds[band_count] = the scaled render
+ * height: band i renders rows [bounds[i], bounds[i + 1]).  Every rank of a sharded frame must set the SAME boundaries (the halo
+ * schedules are derived from them on each rank); NULL / 0 returns to the equal split; hk_set_band with another band count and
+ * hk_resize drop them.
+ *   hk_row_costs           geometry pixels (depth >= epsilon) per full-size row of the frame most recently begun.  A rank that
+ *                          ray-casts the WHOLE frame's primary rays once (hk_frame_begin + hk_pass_run(HK_PASS_PREPASS, 0, 0, 0))
+ *                          holds what every other rank holds, bit for bit, so all ranks derive the same split without talking.
+ *   hk_balanced_band_bounds  pure host logic: boundaries that give every band about the same cost, cost(row) = its geometry
+ *                          pixels + width x background_cost, at least min_rows rows per band; row_cost has cost_rows entries
+ *                          (hk_row_costs: the full-size height).  hk_balance_bands uses 1/4 for scenes walked from LDS (cheap
+ *                          geometry pixels: the Cornell box) and 1/16 beyond (profiles/r03_band_balance_probe.json).
+ *   hk_balance_bands       the three steps in one call, after hk_frame_begin: full-frame primary rays, count, split, set on this
+ *                          context (min_rows 0 = 8); bounds_out (optional) receives the split.  Deterministic across ranks. */
+int hk_set_band_bounds(hk_ctx* ctx, const uint32_t* bounds, uint32_t n_bounds /* band_count + 1 */);
+int hk_get_band(hk_ctx* ctx, uint32_t* band_index, uint32_t* band_count); /* what hk_set_band set (either pointer may be NULL) */
+int hk_get_band_bounds(hk_ctx* ctx, uint32_t* bounds, uint32_t n_bounds /* band_count + 1 */); /* the split in force (explicit or equal) */
+int hk_balance_bands(hk_ctx* ctx, uint32_t min_rows, uint32_t* bounds_out, uint32_t n_bounds /* band_count + 1, or 0 with NULL */);
+int hk_row_costs(hk_ctx* ctx, uint32_t* geometry_pixels_per_row, uint32_t n_rows /* = the full-size height */);
+int hk_balanced_band_bounds(const uint32_t* row_cost, uint32_t cost_rows, uint32_t width, uint32_t render_rows, uint32_t band_count,
+                            uint32_t min_rows, float background_cost /* of a background pixel, geometry pixel = 1; <= 0: 1/16 */, uint32_t* bounds);
 /* Halo transfers that must complete before `stage` runs on this context.  Pure host logic.
  * ops may be NULL to query the count.
  * Moving cameras / objects: the temporal and spatial dispatches read LAST frame's reservoirs at reprojected
@@ -566,6 +591,10 @@ int hk_band_plan(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, HkHalo
 /* Same plan without a context (used by hosts that only schedule): */
 int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count,
                      uint32_t stage, uint32_t frame_number, const HkSettings* settings, HkHaloOp* ops, uint32_t* n_ops);
+/* ... with an explicit split (bounds: band_count + 1 scaled render rows, see hk_set_band_bounds; NULL = hk_band_plan_for) */
+int hk_band_plan_bounds(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* bounds, uint32_t band_index,
+                        uint32_t band_count, uint32_t stage, uint32_t frame_number, const HkSettings* settings, HkHaloOp* ops,
+                        uint32_t* n_ops);
 
 /* One side of a halo transfer, as the executor needs it: a byte range of a buffer (the same range on both sides - buffers are
  * allocated full-frame on every rank, so a halo row lands at the address it has on its owner) moving between this rank and
@@ -584,6 +613,9 @@ typedef struct HkTransfer {
  * logic; out may be NULL to query the count. */
 int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint32_t rank, uint32_t n_ranks, uint32_t stage,
                      uint32_t frame_number, const HkSettings* settings, HkTransfer* out, uint32_t* n_out);
+int hk_band_schedule_bounds(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* bounds, uint32_t rank,
+                            uint32_t n_ranks, uint32_t stage, uint32_t frame_number, const HkSettings* settings, HkTransfer* out,
+                            uint32_t* n_out);
 
 /* ------------------------------------------------------------------ halo exchange inside the boundary: one process per GPU, RCCL over xGMI */
 /* The reference's LightNode / PostProcessNode record every dispatch of a frame into one command encoder (light.rs:590-702);
@@ -622,6 +654,7 @@ int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* moved); /* hk_refit_scene_instances on every band's replica */
 int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode);
+int hk_multi_set_band_bounds(hk_multi* m, const uint32_t* bounds, uint32_t n_bounds);  /* hk_set_band_bounds on every band's context */
 int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t tree_mode);  /* hk_update_scene_instances on every band's replica */
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n_images);
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes);

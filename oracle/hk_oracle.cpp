@@ -110,6 +110,7 @@ struct Ctx {
   float upscale_sharpness = 0.0f;                                       // Upscale::sharpness(), FSR1 RCAS
 
   uint32_t band_index = 0, band_count = 1;
+  std::vector<uint32_t> band_bounds;  // orc_set_band_bounds: explicit split of the scaled render rows (band_count + 1 entries) or empty
   Stats stats;
   uint32_t flags = 0;
 };
@@ -2368,6 +2369,7 @@ int orc_resize(orc_ctx* ctx, uint32_t width, uint32_t height, float upscale_rati
   c.RH = (int)ceilf(scale * (float)height);
   c.UW = (int)ceilf((float)width * (scale * 2.0f));  // post_process.rs:718-722
   c.UH = (int)ceilf((float)height * (scale * 2.0f));
+  c.band_bounds.clear();  // (boundaries are render rows of the old size)
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
     size_t n = buf_full_size(b) ? (size_t)c.W * c.H : (buf_upscaled(b) ? (size_t)c.UW * c.UH : (size_t)c.RW * c.RH);
     c.buf[b].assign(n * buf_bpp(b), 0);
@@ -2507,7 +2509,12 @@ int orc_frame_stage_rows(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uin
   } else if (stage == HK_STAGE_UPSCALE) {  // post_process.rs:1277-1308
     if (st->upscale_kind == HK_UPSCALE_FSR1) {
       const int bi = (int)c.band_index, bn = (int)c.band_count, base = c.H / bn, rem = c.H % bn;  // hk_band_rows over the window height
-      const int w0 = bi * base + std::min(bi, rem), w1 = w0 + base + (bi < rem ? 1 : 0);
+      int w0 = bi * base + std::min(bi, rem), w1 = w0 + base + (bi < rem ? 1 : 0);
+      if (c.band_bounds.size() == (size_t)bn + 1) {  // an explicit split of the render rows cuts the window rows where its boundaries fall in them
+        auto cut = [&](int k) { return k == 0 ? 0 : (k == bn ? c.H : (int)(((uint64_t)c.band_bounds[k] * (uint64_t)c.H) / (uint64_t)c.RH)); };
+        w0 = cut(bi);
+        w1 = cut(bi + 1);
+      }
       pass_fsr_easu(&c, std::max(w0 - 1, 0), std::min(w1 + 1, c.H));
       pass_fsr_rcas(&c, w0, w1);
     }
@@ -2516,8 +2523,30 @@ int orc_frame_stage_rows(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uin
   }
   return HK_OK;
 }
+int orc_set_band_bounds(orc_ctx* ctx, const uint32_t* bounds, uint32_t n_bounds) {  // hk_set_band_bounds
+  ORC_CHECK(ctx, HK_E_INVALID, "null ctx");
+  if (!bounds || n_bounds == 0) {
+    ctx->c.band_bounds.clear();
+    return HK_OK;
+  }
+  ORC_CHECK(n_bounds == ctx->c.band_count + 1 && bounds[0] == 0 && (int)bounds[n_bounds - 1] == ctx->c.RH, HK_E_INVALID, "band bounds");
+  for (uint32_t k = 0; k + 1 < n_bounds; ++k) ORC_CHECK(bounds[k + 1] > bounds[k], HK_E_INVALID, "band bounds must increase");
+  ctx->c.band_bounds.assign(bounds, bounds + n_bounds);
+  return HK_OK;
+}
+int orc_row_costs(orc_ctx* ctx, uint32_t* out, uint32_t n_rows) {  // hk_row_costs: pixels of a row whose depth (position.w) is not < epsilon
+  ORC_CHECK(ctx && out && (int)n_rows == ctx->c.H && ctx->c.H > 0, HK_E_INVALID, "one counter per full-size row");
+  const float* p = reinterpret_cast<const float*>(ctx->c.buf[HK_BUF_POSITION].data());
+  for (int y = 0; y < ctx->c.H; ++y) {
+    uint32_t n = 0;
+    for (int x = 0; x < ctx->c.W; ++x) n += !(p[4 * ((size_t)y * ctx->c.W + x) + 3] < 1.1920929e-7f) ? 1u : 0u;
+    out[y] = n;
+  }
+  return HK_OK;
+}
 int orc_set_band(orc_ctx* ctx, uint32_t band_index, uint32_t band_count) {
   ORC_CHECK(ctx && band_count > 0 && band_index < band_count, HK_E_INVALID, "band");
+  if (band_count != ctx->c.band_count) ctx->c.band_bounds.clear();
   ctx->c.band_index = band_index;
   ctx->c.band_count = band_count;
   return HK_OK;
@@ -2531,6 +2560,10 @@ int orc_frame_stage(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uint32_t
   ORC_CHECK(ctx, HK_E_INVALID, "null ctx");
   uint32_t b0, b1;
   band_rows((uint32_t)ctx->c.RH, ctx->c.band_index, ctx->c.band_count, &b0, &b1);
+  if (ctx->c.band_bounds.size() == (size_t)ctx->c.band_count + 1) {
+    b0 = ctx->c.band_bounds[ctx->c.band_index];
+    b1 = ctx->c.band_bounds[ctx->c.band_index + 1];
+  }
   return orc_frame_stage_rows(ctx, stage, st, flags, b0, b1);
 }
 int orc_frame_render(orc_ctx* ctx, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case_name, out_dir, transport=None):
+def _worker(rank, world, port, case_name, out_dir, transport=None, split=None):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -53,10 +53,19 @@ def _worker(rank, world, port, case_name, out_dir, transport=None):
         assert r.transport.startswith("host (rccl unavailable"), r.transport
     else:
         r = BandRenderer(e, rank, world, backend_device="cpu", transport=transport)
-    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
-    for n in case.frames:
-        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h)
     _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
+    if split == "uneven":   # explicit boundaries (hk_set_band_bounds): thin first band, fat last one
+        fractions = np.array([0.0, 0.11, 0.37, 0.52, 1.0])[[0, 1, 2, 4] if world == 3 else [0, 2, 4]]
+        r.set_bounds([int(round(f * rh)) for f in fractions])
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    for k, n in enumerate(case.frames):
+        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, balance=(split == "balanced" and k == 0))
+    if split == "balanced":   # every rank derived the split from its own full-frame primary rays: the same one
+        mine = torch.tensor(r.bounds, dtype=torch.int64)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        assert all((t == mine).all() for t in everyone), everyone
+        assert r.bounds == e.band_bounds() and r.bounds[0] == 0 and r.bounds[-1] == rh
     b0, b1 = r.band(rh)
     want = [F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2]
     cur, prev = case.frames[-1] % 2, 1 - case.frames[-1] % 2
@@ -66,16 +75,19 @@ def _worker(rank, world, port, case_name, out_dir, transport=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,case_name,transport", [(2, "cornell_b2", None), (3, "yard_sun", None), (2, "cornell_b2", "rccl")])
-def test_bands_equal_single_rank(tmp_path, world, case_name, transport):
-    """transport "rccl" where RCCL cannot come up (here: the oracle has no communicator): the ranks agree BEFORE anyone enters
+@pytest.mark.parametrize("world,case_name,transport,split", [(2, "cornell_b2", None, None), (3, "yard_sun", None, None), (2, "cornell_b2", "rccl", None),
+                                                             (3, "cornell_b2", None, "uneven"), (2, "yard_sun", None, "uneven"),
+                                                             (3, "yard_sun", None, "balanced"), (2, "cornell_upscale2", None, "balanced")])
+def test_bands_equal_single_rank(tmp_path, world, case_name, transport, split):
+    """split: bands of unequal height - explicit boundaries, or the cost-balanced split every rank derives on the first frame.
+    transport "rccl" where RCCL cannot come up (here: the oracle has no communicator): the ranks agree BEFORE anyone enters
     the rendezvous - all of them raise, or with fallback="host" all of them stage the halos through host memory, and the frame
     is the same."""
     from cases import make_case, run_case, snapshot
     from oracle_lib import oracle_plugin
 
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path), transport), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path), transport, split), nprocs=world, join=True)
     case = make_case(case_name)
     ref = oracle_plugin()
     run_case(ref, case)

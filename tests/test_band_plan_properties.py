@@ -22,10 +22,21 @@ def make_settings(ratio, fl):
              emissive_spatial_reuse=emissive, indirect_spatial_reuse=indirect, denoise=denoise, indirect_bounces=bounces)
 
 
-def band(rows, i, n):
+def band(rows, i, n, bounds=None):
+    if bounds is not None:   # explicit boundaries (hk_band_plan_bounds): in scaled render rows
+        assert rows == bounds[-1]
+        return bounds[i], bounds[i + 1]
     base, rem = divmod(rows, n)
     b0 = i * base + min(i, rem)
     return b0, b0 + base + (1 if i < rem else 0)
+
+
+def random_bounds(seed, rows, world):
+    """None (the equal split) for seed 0, else world + 1 strictly increasing boundaries of [0, rows] (bands of >= 1 row)."""
+    if seed == 0 or rows <= world:
+        return None
+    cuts = np.random.default_rng(seed).choice(np.arange(1, rows), size=world - 1, replace=False)
+    return [0] + sorted(int(c) for c in cuts) + [rows]
 
 
 def buffer_rows(width, height, ratio, s, buf):
@@ -39,23 +50,24 @@ def buffer_rows(width, height, ratio, s, buf):
 
 @settings(max_examples=150, deadline=None)
 @given(sizes, ratios, st.integers(2, 8), flags, st.integers(1, 64), st.integers(0, 6),
-       st.sampled_from([F.STAGE_TEMPORAL, F.STAGE_SPATIAL, F.STAGE_POST_PROCESS, F.STAGE_ANTIALIAS, F.STAGE_UPSCALE]))
-def test_plans_name_foreign_rows_once_and_contiguously(size, ratio, world, fl, frame, history, stage):
+       st.sampled_from([F.STAGE_TEMPORAL, F.STAGE_SPATIAL, F.STAGE_POST_PROCESS, F.STAGE_ANTIALIAS, F.STAGE_UPSCALE]), st.integers(0, 5))
+def test_plans_name_foreign_rows_once_and_contiguously(size, ratio, world, fl, frame, history, stage, split):
     width, height = size
     s = make_settings(ratio, fl)
     sc = s.to_c()
+    bounds = random_bounds(split, buffer_rows(width, height, ratio, s, F.BUF_TONE_MAPPED)[0], world)
     stage_arg = stage | ((history << 8) if stage in (F.STAGE_TEMPORAL, F.STAGE_ANTIALIAS) else 0)
     per_band = []
     for i in range(world):
-        ops = halo_plan(width, height, ratio, i, world, stage_arg, frame, sc)
+        ops = halo_plan(width, height, ratio, i, world, stage_arg, frame, sc, bounds)
         per_band.append(ops)
         by_buffer = {}
         for o in ops:
             assert o.peer != i and 0 <= o.peer < world and o.row_begin < o.row_end
             rows, scale = buffer_rows(width, height, ratio, s, o.buffer)
             rh = buffer_rows(width, height, ratio, s, F.BUF_TONE_MAPPED)[0]
-            p0, p1 = band(rh, o.peer, world)
-            own0, own1 = band(rh, i, world)
+            p0, p1 = band(rh, o.peer, world, bounds)
+            own0, own1 = band(rh, i, world, bounds)
             lo, hi = scale * p0, (rows if p1 == rh else min(rows, scale * p1))
             assert lo <= o.row_begin and o.row_end <= hi, "rows the peer does not own"
             assert o.row_end <= scale * own0 or o.row_begin >= min(rows, scale * own1), "rows this band owns itself"
@@ -75,10 +87,10 @@ def test_plans_name_foreign_rows_once_and_contiguously(size, ratio, world, fl, f
         for buf in {o.buffer for o in per_band[i]}:
             rows, scale = buffer_rows(width, height, ratio, s, buf)
             rh = buffer_rows(width, height, ratio, s, F.BUF_TONE_MAPPED)[0]
-            own0, own1 = band(rh, i, world)
+            own0, own1 = band(rh, i, world, bounds)
             below = sum(o.row_end - o.row_begin for o in per_band[i] if o.buffer == buf and o.row_end <= scale * own0)
             above = sum(o.row_end - o.row_begin for o in per_band[i] if o.buffer == buf and o.row_begin >= scale * own1)
-            if stage != F.STAGE_UPSCALE and scale * own0 >= below + 8 and rows - scale * own1 >= above + 8 and below and above:
+            if stage != F.STAGE_UPSCALE and scale * own0 >= below + 8 and rows - scale * own1 >= above + 8 and below and above:   # (narrow neighbours: the halo spans several bands, same total)
                 assert below == above, (buf, below, above)
 
 
@@ -98,8 +110,8 @@ def test_band_rows_partition_the_image(size, ratio, world):
 
 @settings(max_examples=80, deadline=None)
 @given(sizes, ratios, st.integers(2, 8), flags, st.integers(1, 64), st.integers(0, 6),
-       st.sampled_from([F.STAGE_TEMPORAL, F.STAGE_SPATIAL, F.STAGE_POST_PROCESS, F.STAGE_ANTIALIAS, F.STAGE_UPSCALE]))
-def test_schedules_pair_up_in_issue_order(size, ratio, world, fl, frame, history, stage):
+       st.sampled_from([F.STAGE_TEMPORAL, F.STAGE_SPATIAL, F.STAGE_POST_PROCESS, F.STAGE_ANTIALIAS, F.STAGE_UPSCALE]), st.integers(0, 5))
+def test_schedules_pair_up_in_issue_order(size, ratio, world, fl, frame, history, stage, split):
     """hk_band_schedule is what the transports execute (RCCL inside the library, peer copies in hk_multi, gloo in the tests).
     RCCL pairs the sends and receives of two ranks BY ISSUE ORDER, so for every ordered pair (a -> b) the sequence of sends a
     issues to b must be, element for element (buffer, offset, bytes), the sequence of receives b issues from a; and the
@@ -107,9 +119,11 @@ def test_schedules_pair_up_in_issue_order(size, ratio, world, fl, frame, history
     from bevy_hikari_amd.distributed import band_schedule
 
     width, height = size
-    sc = make_settings(ratio, fl).to_c()
+    s = make_settings(ratio, fl)
+    sc = s.to_c()
+    bounds = random_bounds(split, buffer_rows(width, height, ratio, s, F.BUF_TONE_MAPPED)[0], world)
     stage_arg = stage | ((history << 8) if stage in (F.STAGE_TEMPORAL, F.STAGE_ANTIALIAS) else 0)
-    sched = [band_schedule(width, height, ratio, r, world, stage_arg, frame, sc) for r in range(world)]
+    sched = [band_schedule(width, height, ratio, r, world, stage_arg, frame, sc, bounds) for r in range(world)]
     for a in range(world):
         for b in range(world):
             if a == b:
@@ -118,6 +132,43 @@ def test_schedules_pair_up_in_issue_order(size, ratio, world, fl, frame, history
             recvs = [(t.buffer, t.offset, t.bytes) for t in sched[b] if t.is_recv and t.peer == a]
             assert sends == recvs, (a, b)
     for r in range(world):
-        plan = sorted((o.buffer, o.peer, o.row_begin * o.row_bytes, (o.row_end - o.row_begin) * o.row_bytes) for o in halo_plan(width, height, ratio, r, world, stage_arg, frame, sc))
+        plan = sorted((o.buffer, o.peer, o.row_begin * o.row_bytes, (o.row_end - o.row_begin) * o.row_bytes) for o in halo_plan(width, height, ratio, r, world, stage_arg, frame, sc, bounds))
         assert plan == sorted((t.buffer, t.peer, t.offset, t.bytes) for t in sched[r] if t.is_recv)
         assert all(t.peer != r and t.bytes > 0 for t in sched[r])
+
+
+@settings(max_examples=100, deadline=None)
+@given(st.integers(16, 4096), st.integers(64, 2400), st.integers(1, 8), st.integers(1, 32), st.integers(0, 2 ** 31))
+def test_balanced_bounds_are_valid_and_balance_the_cost(width, rows, world, min_rows, seed):
+    """hk_balanced_band_bounds: strictly increasing boundaries from 0 to the render rows, every band at least min_rows tall,
+    and no band's cost exceeds the mean by more than the two heaviest rows + what min_rows forces."""
+    from bevy_hikari_amd.distributed import balanced_band_bounds
+
+    if min_rows * world > rows:
+        min_rows = 1
+    if world > rows:
+        return
+    rng = np.random.default_rng(seed)
+    cost_rows = int(rng.integers(rows // 2 + 1, 2 * rows))
+    # a frame like config 4: empty sky on top, dense geometry below, noise in between
+    cost = np.where(np.arange(cost_rows) < cost_rows * rng.uniform(0, 0.7), 0, rng.integers(0, width + 1, cost_rows)).astype(np.uint32)
+    bg = [0.0, 1.0 / 6.0, 0.01][seed % 3]
+    b = balanced_band_bounds(cost, width, rows, world, min_rows, bg)
+    assert b[0] == 0 and b[-1] == rows and len(b) == world + 1
+    assert all(b1 - b0 >= min_rows for b0, b1 in zip(b, b[1:]))
+    per_row = np.array([cost[y * cost_rows // rows] + width * (bg or 1.0 / 16.0) for y in range(rows)])
+    band_cost = [per_row[b0:b1].sum() for b0, b1 in zip(b, b[1:])]
+    slack = 2 * per_row.max() + min_rows * per_row.max() * world
+    assert max(band_cost) <= per_row.sum() / world + slack
+    # and it is what every rank derives from the same counts (deterministic)
+    assert b == balanced_band_bounds(cost.copy(), width, rows, world, min_rows, bg)
+
+
+def test_bad_bounds_are_refused():
+    import pytest
+
+    sc = S().to_c()
+    for bad in ([0, 10, 10, 64], [1, 10, 20, 64], [0, 10, 20, 63], [0, 30, 20, 64]):
+        with pytest.raises(F.HikariError, match="band bounds"):
+            halo_plan(64, 64, 1.0, 0, 3, F.STAGE_SPATIAL, 1, sc, bad)
+    assert halo_plan(64, 64, 1.0, 0, 3, F.STAGE_SPATIAL, 1, sc, [0, 10, 20, 64]) is not None

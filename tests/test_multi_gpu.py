@@ -84,6 +84,97 @@ def test_multi_engine_full_size_config2_equals_single_context(bands):
         borrowed.stats()
 
 
+def _uneven(rh, bands, seed):
+    cuts = np.random.default_rng(seed).choice(np.arange(1, rh), size=bands - 1, replace=False)
+    return [0] + sorted(int(c) for c in cuts) + [rh]
+
+
+@pytest.mark.parametrize("bands,case_name,split", [(3, "cornell_b2", "uneven"), (4, "yard_sun", "uneven"), (3, "cornell_aa_default", "uneven"), (2, "cornell_aa_fsr", "uneven"),
+                                                   (5, "random12", "uneven"), (3, "yard_sun", "balanced"), (4, "cornell_aa_default", "balanced"),
+                                                   (3, "cornell_aa_fsr", "balanced"), (4, "cornell_upscale2", "balanced")])
+def test_multi_engine_bands_of_unequal_height(bands, case_name, split):
+    """hk_set_band_bounds / HK_FRAME_BALANCE_BANDS: the bands need not be equally tall - random boundaries (bands of a single
+    row included), or the split by cost the library derives on the first frame.  The union equals the single context, bit for bit."""
+    case = case_of(case_name)
+    s = case.settings
+    m = MultiEngine([0] * bands)
+    m.upload_noise(); m.upload_scene(case.scene)
+    w, h = case.camera.width, case.camera.height
+    m.resize(w, h, s.upscale.ratio())
+    _, rh, _ = m.contexts[0].buffer_info(F.BUF_TONE_MAPPED)
+    if split == "uneven":
+        bounds = _uneven(rh, bands, 7 * bands + len(case_name))
+        m.set_band_bounds(bounds)
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    for k, n in enumerate(case.frames):
+        flags = (F.FRAME_ANTIALIAS if case.antialias else 0) | (F.FRAME_BALANCE_BANDS if split == "balanced" and k == 0 else 0)
+        m.frame_render(hk.frame_uniform(s, n), view, pview, case.lights, s.to_c(), flags)
+    m.wait()
+    got = [e.band_bounds() for e in m.contexts]
+    assert all(g == got[0] for g in got) and got[0][0] == 0 and got[0][-1] == rh
+    if split == "uneven":
+        assert got[0] == bounds
+    else:   # the split follows the geometry: it is what the counts of the single context's G-buffer give
+        from bevy_hikari_amd.distributed import balanced_band_bounds
+
+        m2 = hk.Engine(device=0)   # (frame 1's G-buffer: the sub-pixel jitter of later frames moves a boundary by a row)
+        m2.upload_noise(); m2.upload_scene(case.scene); m2.resize(w, h, s.upscale.ratio())
+        m2.frame_render(hk.frame_uniform(s, case.frames[0]), view, pview, case.lights, s.to_c())
+        assert got[0] == balanced_band_bounds(m2.row_costs(), w, rh, bands, 8, 0.25)   # (scenes walked from LDS: a background pixel costs 1/4 of a geometry pixel)
+    ref = hk.HikariPlugin(device=0)
+    run_case(ref, case)
+    e = ref.engine
+    costs = e.row_costs()
+    depth = e.read(F.BUF_POSITION)[..., 3]
+    assert (costs == (~(depth < np.float32(1.1920929e-7))).sum(axis=1)).all()
+    prev = 1 - case.frames[-1] % 2
+    want = [F.BUF_TONE_MAPPED, F.BUF_RENDER0, F.BUF_RENDER0 + 1, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2, F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8,
+            F.BUF_POSITION, F.BUF_ALBEDO]
+    if s.denoise:
+        want += [F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1] + ([F.BUF_DENOISE_RENDER0 + 2] if s.indirect_bounces else [])
+    if case.antialias:
+        want += [F.BUF_TAA_OUTPUT] if s.taa == hk.Taa.Jasmine else []
+        want += [F.BUF_UPSCALE_OUTPUT] + ([F.BUF_UPSCALE_SHARPENED] if s.upscale.kind == F.UPSCALE_FSR1 else [])
+    for b in want:
+        a, r = m.read(b), e.read(b)
+        if F.BUF_RESERVOIR0 <= b < F.BUF_RESERVOIR0 + 10:
+            rw, rh2, _ = e.buffer_info(F.BUF_TONE_MAPPED)
+            a, r = a.reshape(-1, 16)[:rw * rh2], r.reshape(-1, 16)[:rw * rh2]
+        assert a.shape == r.shape and (a.view(np.uint8) == r.view(np.uint8)).all(), f"{case_name} x{bands} {split} {got[0]}: buffer {b} differs"
+
+
+def test_multi_engine_balanced_config4_class_frame_at_1080p():
+    """A frame shaped like BASELINE config 4 (sky above, a city below: equal-row bands take 0.3 ms and 6.3 ms) at 1920x1080 in 8
+    bands split by cost: the sky bands come out tall, the city bands thin, the union equals the single context bit for bit, and
+    the heaviest band holds far fewer geometry pixels than under the equal split."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0004, 12, 16, 32, 600, 20, 1, 40.0)   # bench.py's config-4 layout and camera, lighter meshes
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    w, h, bands = 1920, 1080, 8
+    cam, lights = synthetic_camera(w, h, extent=30.0), hk.lights_uniform(directional=dict(sun, illuminance=10000.0))
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    m, ref = MultiEngine([0] * bands), hk.Engine(device=0)
+    for t in (m, ref):
+        t.upload_noise(); t.upload_scene(scene); t.resize(w, h, 1.0)
+    for n in range(1, 4):
+        f = hk.frame_uniform(s, n)
+        m.frame_render(f, view, pview, lights, s.to_c(), F.FRAME_BALANCE_BANDS if n == 1 else 0)
+        ref.frame_render(f, view, pview, lights, s.to_c())
+    m.wait(); ref.wait()
+    bounds = m.contexts[0].band_bounds()
+    costs = ref.row_costs().astype(np.int64)
+    per_band = [int(costs[a:b].sum()) for a, b in zip(bounds, bounds[1:])]
+    equal = [int(c.sum()) for c in np.array_split(costs, bands)]
+    print("balanced split:", bounds, "geometry px per band:", per_band, "equal split:", equal)
+    assert max(per_band) <= 0.75 * max(equal) or max(equal) <= 1.15 * sum(equal) / bands, (per_band, equal)
+    prev = 1 - 3 % 2
+    for b in [F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2,
+              F.BUF_RESERVOIR0 + prev + 6, F.BUF_RESERVOIR0 + prev + 8, F.BUF_POSITION]:
+        a, r = m.read(b), ref.read(b)
+        assert (a.view(np.uint8) == r.view(np.uint8)).all(), f"balanced x{bands}: buffer {b} differs at 1920x1080"
+
+
 def test_multi_engine_history_rows_under_camera_motion():
     """Exchange C inside the library: with the camera moving vertically, reprojection crosses the band borders; with the
     history halo the union stays within the north star's 1e-3 of the single-context frame, without it it does not."""

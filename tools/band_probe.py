@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What each rank of an N-GPU band-sharded run spends, measured on ONE GPU: for N = 1, 2, 4, 8 every band of the frame is
-rendered alone (hk_set_band, no exchanges) and timed by the wall clock over K frames; the halo bytes each rank receives per
+rendered alone (hk_set_band, no exchanges; once with equal-row bands, once with the split by cost of hk_balance_bands) and timed
+by the wall clock over K frames; the halo bytes each rank receives per
 frame come from hk_band_schedule.  From that: the PREDICTED frame time and scaling curve of the real N-GPU run
 (max over bands + the exchanges priced with the stated link assumptions), to be compared with the driver's SCALE_rNN.json.
 
@@ -54,12 +55,19 @@ def main():
 
         frames(12)
         rows = {}
-        for bands in (1, 2, 4, 8):
+        for bands, balanced in ((1, False), (2, False), (4, False), (8, False), (2, True), (4, True), (8, True)):
             per_band, recv = [], []
+            bounds = None
+            if balanced:   # the split by cost (hk_balance_bands), derived once from this frame's primary rays
+                e.set_band(0, bands)
+                n += 1
+                e.frame_begin(hk.frame_uniform(settings, n), view, pview, lights)
+                bounds = e.balance_bands()
             for b in range(bands):
                 e.set_band(0, 1)
                 frames(2)                      # whole-frame state stays current between the band measurements
                 e.set_band(b, bands)
+                e.set_band_bounds(bounds)
                 frames(2)
                 t0 = time.perf_counter()
                 frames(K)
@@ -67,7 +75,7 @@ def main():
                 # bytes this band receives per frame, per exchange (static view: no history rows)
                 ex = []
                 for stage in (F.STAGE_SPATIAL, F.STAGE_POST_PROCESS):
-                    ex.append(sum(t.bytes for t in band_schedule(W, H, 1.0, b, bands, stage, n, sc) if t.is_recv) if bands > 1 else 0)
+                    ex.append(sum(t.bytes for t in band_schedule(W, H, 1.0, b, bands, stage, n, sc, bounds) if t.is_recv) if bands > 1 else 0)
                 recv.append(ex)
             exch_ms = 0.0
             if bands > 1:
@@ -75,12 +83,13 @@ def main():
                     worst = max(r[k] for r in recv)
                     if worst:
                         exch_ms += EXCHANGE_US * 1e-3 + worst / (LINK_GBS * 1e9) * 1e3
-            rows[bands] = {"band_ms": [round(x, 4) for x in per_band], "max_band_ms": round(max(per_band), 4), "halo_bytes_received_per_band": recv,
+            rows[f"{bands}_balanced" if balanced else bands] = {"bounds": bounds, "band_ms": [round(x, 4) for x in per_band], "max_band_ms": round(max(per_band), 4), "halo_bytes_received_per_band": recv,
                            "exchange_ms_predicted": round(exch_ms, 4), "frame_ms_predicted": round(max(per_band) + exch_ms, 4)}
         t1 = rows[1]["frame_ms_predicted"]
-        for bands in rows:
-            rows[bands]["speedup_predicted"] = round(t1 / rows[bands]["frame_ms_predicted"], 3)
-            rows[bands]["efficiency_predicted"] = round(t1 / rows[bands]["frame_ms_predicted"] / bands, 3)
+        for key in rows:
+            bands = int(str(key).split("_")[0])
+            rows[key]["speedup_predicted"] = round(t1 / rows[key]["frame_ms_predicted"], 3)
+            rows[key]["efficiency_predicted"] = round(t1 / rows[key]["frame_ms_predicted"] / bands, 3)
         out["configs"][str(config)] = {"workload": description, "frames_per_measurement": K, "bands": {str(k): v for k, v in rows.items()}}
         e.close()
     print(json.dumps(out, indent=1))
