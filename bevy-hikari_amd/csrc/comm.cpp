@@ -14,9 +14,13 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is resolved at run time
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "hk_internal.hpp"
@@ -177,6 +181,7 @@ void comm_release(hk_ctx* c) {
 }  // namespace hk
 
 // ------------------------------------------------------------------ hk_multi
+struct MultiPool;
 struct hk_multi {
   std::vector<hk_ctx*> ctx;
   std::vector<int> device;
@@ -184,6 +189,52 @@ struct hk_multi {
   std::deque<Comm::Cached> cache;
   uint32_t history_rows = 0;
   uint64_t exchanges = 0, bytes_copied = 0;
+  MultiPool* pool = nullptr;  // one enqueue thread per band (hk_multi_frame_render), created on first use
+};
+
+// A frame of n bands is n x (10-25 launches + event traffic) of host work: enqueued band after band by the calling thread it
+// costs n x ~60 us - more than a 135-row band's GPU time at 8 GPUs.  Each band therefore has a thread
+// of its own that enqueues ITS stages and ITS side of the exchanges; the threads meet at two spin barriers per exchange
+// (every "produced" event is recorded before anybody waits for one; every "copied" event before its owner waits for it), so
+// an event is never re-recorded while some other thread still means its previous recording.  The GPU-side order is the
+// serial path's (multi_exchange below): same events, same waits, same copies.  HK_MULTI_SERIAL=1 keeps the one-thread path.
+struct MultiJob {
+  const HkFrame* f = nullptr;
+  const HkView* v = nullptr;
+  const HkPreviousView* pv = nullptr;
+  const HkLights* l = nullptr;
+  const HkSettings* st = nullptr;
+  uint32_t flags = 0, hist = 0;
+};
+struct MultiPool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  uint64_t job_id = 0;
+  uint32_t done = 0;
+  bool quit = false;
+  MultiJob job;
+  std::vector<int> rc;
+  std::vector<std::string> err;
+  std::vector<std::deque<Comm::Cached>> cache;  // per band: schedule_for is not thread-safe on a shared cache
+  std::vector<uint64_t> bytes;
+  // spin barrier (sense = generation); `failed` releases everybody
+  std::atomic<uint32_t> arrived{0}, generation{0};
+  std::atomic<int> failed{0};
+  uint32_t n = 0;
+  bool barrier() {
+    const uint32_t gen = generation.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      arrived.store(0, std::memory_order_relaxed);
+      generation.store(gen + 1, std::memory_order_release);
+      return !failed.load(std::memory_order_acquire);
+    }
+    for (uint32_t spins = 0; generation.load(std::memory_order_acquire) == gen; ++spins) {
+      if (failed.load(std::memory_order_acquire)) return false;
+      if (spins > 2000) std::this_thread::yield();
+    }
+    return !failed.load(std::memory_order_acquire);
+  }
 };
 
 namespace {
@@ -246,6 +297,132 @@ int multi_exchange(hk_multi* m, uint32_t stage_arg, const HkSettings* st) {
   }
   m->exchanges += 1;
   return HK_OK;
+}
+
+// band i's side of multi_exchange, on band i's thread.  Returns HK_OK or the error; false from a barrier = some other band failed.
+int band_exchange(hk_multi* m, uint32_t i, uint32_t stage_arg, const HkSettings* st) {
+  MultiPool* P = m->pool;
+  const uint32_t n = (uint32_t)m->ctx.size();
+  CtxInfo ci;
+  int rc = ctx_info(m->ctx[i], &ci);
+  const std::vector<HkTransfer>* plan = nullptr;
+  if (!rc) {
+    if (P->cache[i].size() > 256) P->cache[i].clear();
+    rc = schedule_for(P->cache[i], ci, i, n, stage_arg, st, &plan);
+  }
+  hipStream_t stream = (hipStream_t)ci.stream;
+  // 1. "produced" on my stream
+  if (!rc && hipEventRecord(m->produced[i], stream) != hipSuccess) { set_error("hipEventRecord failed (band %u)", i); rc = HK_E_HIP; }
+  if (rc) P->failed.store(1, std::memory_order_release);
+  if (!P->barrier()) return rc ? rc : HK_E_HIP;
+  // 2. wait for the owners of the rows I receive, copy them in, "copied" on my stream
+  std::vector<uint8_t> waited(n, 0);
+  bool copies = false;
+  for (const HkTransfer& t : *plan) {
+    if (!t.is_recv || rc) continue;
+    if (t.peer >= n) { set_error("bad peer in schedule"); rc = HK_E_INVALID; break; }
+    if (!waited[t.peer]) {
+      if (hipStreamWaitEvent(stream, m->produced[t.peer], 0) != hipSuccess) { set_error("hipStreamWaitEvent failed (band %u)", i); rc = HK_E_HIP; break; }
+      waited[t.peer] = 1;
+    }
+    size_t ldst = 0, lsrc = 0;
+    char* dst = static_cast<char*>(ctx_buffer(m->ctx[i], t.buffer, &ldst));
+    const char* src = static_cast<const char*>(ctx_buffer(m->ctx[t.peer], t.buffer, &lsrc));
+    if (!dst || !src || t.offset + t.bytes > ldst || t.offset + t.bytes > lsrc) { set_error("halo transfer outside buffer %u", t.buffer); rc = HK_E_INVALID; break; }
+    const hipError_t e = m->device[i] == m->device[t.peer] ? hipMemcpyAsync(dst + t.offset, src + t.offset, t.bytes, hipMemcpyDeviceToDevice, stream)
+                                                             : hipMemcpyPeerAsync(dst + t.offset, m->device[i], src + t.offset, m->device[t.peer], t.bytes, stream);
+    if (e != hipSuccess) { set_error("halo copy failed (band %u): %s", i, hipGetErrorString(e)); rc = HK_E_HIP; break; }
+    P->bytes[i] += t.bytes;
+    copies = true;
+  }
+  if (!rc && copies && hipEventRecord(m->copied[i], stream) != hipSuccess) { set_error("hipEventRecord failed (band %u)", i); rc = HK_E_HIP; }
+  if (rc) P->failed.store(1, std::memory_order_release);
+  if (!P->barrier()) return rc ? rc : HK_E_HIP;
+  // 3. I do not run ahead of the copies that read my rows: every transfer I "send" names a band that copied from me
+  std::fill(waited.begin(), waited.end(), 0);
+  for (const HkTransfer& t : *plan) {
+    if (t.is_recv || t.peer >= n || waited[t.peer]) continue;
+    waited[t.peer] = 1;
+    if (hipStreamWaitEvent(stream, m->copied[t.peer], 0) != hipSuccess) { set_error("hipStreamWaitEvent failed (band %u)", i); return HK_E_HIP; }
+  }
+  return HK_OK;
+}
+
+int band_frame(hk_multi* m, uint32_t i, const MultiJob& j) {
+  hk_ctx* c = m->ctx[i];
+  MultiPool* P = m->pool;
+  if (hipSetDevice(m->device[i]) != hipSuccess) { set_error("hipSetDevice(%d) failed", m->device[i]); P->failed.store(1); return HK_E_HIP; }
+  int rc = hk_frame_begin(c, j.f, j.v, j.pv, j.l);
+  auto step = [&](uint32_t s, bool exchange, uint32_t stage_arg) {
+    if (exchange) {
+      if (rc) P->failed.store(1, std::memory_order_release);
+      const int e = band_exchange(m, i, stage_arg, j.st);  // (a failed band still enters: the others leave the barrier through `failed`)
+      if (!rc) rc = e;
+    }
+    if (!rc) rc = hk_frame_stage(c, s, j.st, j.flags);
+    if (rc) P->failed.store(1, std::memory_order_release);
+  };
+  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) step(s, s != HK_STAGE_TEMPORAL || j.hist, s == HK_STAGE_TEMPORAL ? (s | j.hist) : s);
+  if (j.flags & HK_FRAME_ANTIALIAS) {
+    step(HK_STAGE_ANTIALIAS, true, HK_STAGE_ANTIALIAS | j.hist);
+    step(HK_STAGE_UPSCALE, j.st->upscale_kind == HK_UPSCALE_FSR1, HK_STAGE_UPSCALE);
+  }
+  return rc;
+}
+
+void pool_worker(hk_multi* m, uint32_t i) {
+  MultiPool* P = m->pool;
+  uint64_t seen = 0;
+  for (;;) {
+    MultiJob job;
+    {
+      std::unique_lock<std::mutex> lk(P->mu);
+      P->cv_job.wait(lk, [&] { return P->quit || P->job_id != seen; });
+      if (P->quit) return;
+      seen = P->job_id;
+      job = P->job;
+    }
+    const int rc = band_frame(m, i, job);
+    {
+      std::lock_guard<std::mutex> lk(P->mu);
+      P->rc[i] = rc;
+      P->err[i] = rc ? hk_last_error() : "";
+      if (++P->done == P->n) P->cv_done.notify_one();
+    }
+  }
+}
+
+int pool_start(hk_multi* m) {
+  if (m->pool) return HK_OK;
+  MultiPool* P = new (std::nothrow) MultiPool();
+  HK_REQUIRE(P, HK_E_NOMEM, "allocation failed");
+  P->n = (uint32_t)m->ctx.size();
+  P->rc.assign(P->n, 0);
+  P->err.assign(P->n, "");
+  P->cache.resize(P->n);
+  P->bytes.assign(P->n, 0);
+  m->pool = P;
+  try {
+    for (uint32_t i = 0; i < P->n; ++i) P->threads.emplace_back(pool_worker, m, i);
+  } catch (...) {
+    set_error("could not start the enqueue threads");
+    return HK_E_NOMEM;  // (hk_multi_destroy joins what did start)
+  }
+  return HK_OK;
+}
+
+void pool_stop(hk_multi* m) {
+  MultiPool* P = m->pool;
+  if (!P) return;
+  {
+    std::lock_guard<std::mutex> lk(P->mu);
+    P->quit = true;
+  }
+  P->cv_job.notify_all();
+  for (std::thread& t : P->threads)
+    if (t.joinable()) t.join();
+  delete P;
+  m->pool = nullptr;
 }
 
 }  // namespace
@@ -365,6 +542,7 @@ int hk_multi_create(uint32_t n, const int* device_ids, uint32_t flags, hk_multi*
 
 void hk_multi_destroy(hk_multi* m) {
   if (!m) return;
+  pool_stop(m);
   for (size_t i = 0; i < m->ctx.size(); ++i) {
     hk_destroy(m->ctx[i]);
     if (i < m->produced.size()) {
@@ -439,6 +617,39 @@ int hk_multi_set_history_rows(hk_multi* m, uint32_t rows) {
 int hk_multi_frame_render(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   HK_REQUIRE(m && st, HK_E_INVALID, "bad argument");
   int rc;
+  {
+    const uint32_t hist = m->history_rows << 8;
+    // every band's enqueue work on its own thread (the frame that re-splits the bands sets state on every context: serial)
+    static const bool serial_env = getenv("HK_MULTI_SERIAL") != nullptr;
+    if (m->ctx.size() > 1 && !serial_env && !(flags & HK_FRAME_BALANCE_BANDS)) {
+      if ((rc = pool_start(m))) return rc;
+      MultiPool* P = m->pool;
+      HK_REQUIRE(P->threads.size() == m->ctx.size(), HK_E_NOMEM, "the enqueue threads did not start");
+      {
+        std::unique_lock<std::mutex> lk(P->mu);
+        P->job = MultiJob{f, v, pv, l, st, flags, hist};
+        P->done = 0;
+        P->failed.store(0);
+        P->arrived.store(0);  // (a failed frame leaves its barriers half-entered; every thread is idle here)
+        P->job_id += 1;
+        P->cv_job.notify_all();
+        P->cv_done.wait(lk, [&] { return P->done == P->n; });
+      }
+      m->exchanges += 1;
+      for (uint32_t i = 0; i < P->n; ++i) {
+        m->bytes_copied += P->bytes[i];
+        P->bytes[i] = 0;
+      }
+      for (uint32_t i = 0; i < P->n; ++i)
+        if (P->rc[i] && !P->err[i].empty()) {  // the band that failed first-hand (the others report "some band failed")
+          set_error("band %u: %s", i, P->err[i].c_str());
+          return P->rc[i];
+        }
+      for (uint32_t i = 0; i < P->n; ++i)
+        if (P->rc[i]) return P->rc[i];
+      return HK_OK;
+    }
+  }
   for (hk_ctx* c : m->ctx)
     if ((rc = hk_frame_begin(c, f, v, pv, l))) return rc;
   if ((flags & HK_FRAME_BALANCE_BANDS) && m->ctx.size() > 1) {  // one context counts (they all hold the same G-buffer), all take the split
