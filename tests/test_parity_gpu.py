@@ -530,6 +530,100 @@ def test_threaded_traversal_flight_helmet_vs_oracle():
     assert rel <= 1e-3, rel
 
 
+@pytest.mark.parametrize("size", [(1, 1), (1, 37), (41, 1), (2, 2), (9, 8), (8, 9)])
+def test_degenerate_image_sizes_vs_oracle(size):
+    """Images of one pixel, one row, one column, and just over / under one 8x8 tile: every buffer against the oracle, with the
+    spatial passes, the denoiser and the SMAA Tu4x + TAA tail on (their footprints all reach past such an image)."""
+    from oracle_lib import oracle_plugin
+
+    w, h = size
+    s = hk.HikariSettings(indirect_bounces=2, emissive_spatial_reuse=True, upscale=hk.Upscale.SmaaTu4x(1.5), taa=hk.Taa.Jasmine)
+    cam = hk.cornell_camera(w, h)
+    gpu, cpu = hk.HikariPlugin(device=0), oracle_plugin()
+    for p in (gpu, cpu):
+        p.set_scene(hk.load_cornell())
+        for n in range(1, 5):
+            p.render(cam, s, frame_number=n, antialias=True)
+    d = diff_buffers(snapshot(gpu), snapshot(cpu))
+    assert not d, f"{w}x{h}: {d}"
+
+
+def test_single_triangle_scene_vs_oracle():
+    """The smallest scene the builders accept: one instance of a one-triangle mesh (a tree of a single leaf at both levels), lit by
+    the sun only."""
+    from bevy_hikari_amd.plugin import SceneBuilder, standard_material
+    from oracle_lib import oracle_plugin
+
+    b = SceneBuilder()
+    pos = np.array([[-1.0, 0.0, -1.0], [1.0, 0.0, -1.0], [0.0, 0.0, 1.5]], dtype=np.float32)
+    nrm = np.tile(np.array([[0.0, 1.0, 0.0]], dtype=np.float32), (3, 1))
+    uv = np.array([[0.0, 0.0], [1.0, 0.0], [0.5, 1.0]], dtype=np.float32)
+    mesh = b.add_mesh(pos, nrm, uv, np.array([0, 1, 2], dtype=np.uint32))
+    mat = b.add_material(standard_material((0.8, 0.6, 0.4, 1.0), (0, 0, 0), 0.7, 0.0, 0.5))
+    b.add_instance(mesh, mat, np.eye(4, dtype=np.float32))
+    scene = b.finish()
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = hk.Camera(hk.look_at_transform((0.0, 3.0, 3.0), (0.0, 0.0, 0.0)), 64, 48)
+    lights = hk.lights_uniform(directional=dict(color=(1.0, 1.0, 1.0), illuminance=50000.0, direction_to_light=(0.2, 0.9, 0.3)))
+    gpu, cpu = hk.HikariPlugin(device=0), oracle_plugin()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+        for n in range(1, 4):
+            p.render(cam, s, lights=lights, frame_number=n)
+    d = diff_buffers(snapshot(gpu), snapshot(cpu))
+    assert not d, d
+    assert np.isfinite(gpu.output(s)).all() and gpu.output(s).max() > 0.0
+
+
+def test_cornell_8k_row_ranges_vs_oracle():
+    """The largest frame a 16:9 display asks for, 7680x4320 (33 M pixels, 21 GB of reservoir buffers - sized for 288 GB of HBM):
+    two frames of Cornell, 2 bounces, exact traversal, against the oracle on three row ranges (top edge, the middle of the box,
+    bottom edge) with the aprons their passes read, bit for bit; plus whole-frame properties."""
+    import psutil
+    from oracle_lib import oracle_api, oracle_engine
+
+    if psutil.virtual_memory().available < 96 * 2 ** 30:   # the ORACLE's 8K context is ~30 GB of host memory
+        pytest.skip("not enough host memory for the oracle's 8K buffers")
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    sc = s.to_c()
+    W, H = 7680, 4320
+    cam = hk.cornell_camera(W, H)
+    lights = hk.lights_uniform()
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    scene = hk.load_cornell()
+    gpu, cpu = hk.Engine(device=0), oracle_engine()
+    for e in (gpu, cpu):
+        e.upload_noise(); e.upload_scene(scene); e.resize(W, H, 1.0)
+    stage_rows = oracle_api().dll.orc_frame_stage_rows
+    ranges = [(0, 8), (2156, 2164), (4312, 4320)]
+    SP, DEN = 21, 16
+    clamp = lambda v: min(max(v, 0), H)
+    checked = 0
+    for n in (1, 2):
+        f = hk.frame_uniform(s, n)
+        gpu.frame_render(f, view, pview, lights, sc)
+        cpu.frame_begin(f, view, pview, lights)
+        extra = (SP + DEN) if n == 1 else 0
+        for r0, r1 in ranges:
+            for stage, apron in ((F.STAGE_TEMPORAL, SP + DEN), (F.STAGE_SPATIAL, DEN), (F.STAGE_POST_PROCESS, 0)):
+                rc = stage_rows(cpu.ctx, stage, C.byref(sc), 0, clamp(r0 - apron - extra), clamp(r1 + apron + extra))
+                assert rc == 0, cpu.api.last_error()
+        gpu.wait()
+        prev = 1 - n % 2
+        for b, name in ALL_BUFFERS.items():
+            if name.startswith("previous_") or name in ("upscale_output", "taa_output", "upscale_sharpened") or name.startswith("internal"):
+                continue
+            if name.startswith("reservoir") and (int(name[9:]) % 2) != prev:
+                continue
+            a, o = gpu.read(b), cpu.read(b)
+            for r0, r1 in ranges:
+                assert (a[r0:r1].view(np.uint8) == o[r0:r1].view(np.uint8)).all(), f"frame {n}: {name} rows [{r0},{r1}) differ from the oracle at 8K"
+                checked += 1
+    assert checked >= 2 * 3 * 20
+    tone = gpu.read_f16(F.BUF_TONE_MAPPED)
+    assert tone.shape[:2] == (H, W) and np.isfinite(tone).all() and tone[H // 2].max() > 0.0 and (tone[0] == tone[0, 0]).all()
+
+
 def test_city_class_4k_properties():
     """BASELINE config 4 stand-in at its full size on one GPU (seeded synthetic, ~1.5 M unique
     triangles, 2002 instances, 3840x2160, 2 bounces): determinism, dispatch row-range independence
