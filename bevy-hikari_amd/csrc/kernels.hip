@@ -161,8 +161,14 @@ __global__ __launch_bounds__(256) void k_full_screen_albedo(DScene sc, DFrame fr
 }
 
 // ------------------------------------------------------------------ direct_lit
+// (scenes beyond LDS, LDS == 0: the walk waits on global loads 59 % of a wave's time - profiles/r03_compact16_ab.txt - and the
+// compiler's free choice, 141 / 154 VGPRs, leaves 3 waves per SIMD to hide them.  4 waves (128 VGPRs, 9 / 54 spilled): direct passes of
+// config 4 2.93 + 1.31 -> 2.34 + 1.17 ms, frame -4 %; 5 waves (96 VGPRs, 112 / 233 spilled) is slower again - profiles/r03_occupancy_ab.txt)
+#ifndef HK_DIRECT_GLOBAL_WAVES
+#define HK_DIRECT_GLOBAL_WAVES 4
+#endif
 template <bool EMISSIVE_LIT, bool COUNT, int LDS>
-__global__ __launch_bounds__(256) void k_direct_lit(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+__global__ __launch_bounds__(256, (LDS == 0 ? HK_DIRECT_GLOBAL_WAVES : 1)) void k_direct_lit(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                      unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);

@@ -367,8 +367,11 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
 }
 
 // ------------------------------------------------------------------ shade: bounce n of every live path
+#ifndef HK_WF_SHADE_WAVES
+#define HK_WF_SHADE_WAVES 4
+#endif
 template <bool LDS>
-__global__ __launch_bounds__(256) void k_wf_shade(DScene gsc, DFrame fr, WfBuffers w, uint32_t n) {
+__global__ __launch_bounds__(256, HK_WF_SHADE_WAVES) void k_wf_shade(DScene gsc, DFrame fr, WfBuffers w, uint32_t n) {
   const DScene sc = stage_scene<LDS>(gsc);
   const uint32_t count = w.ctr[WF_ALIVE + n];
   const uint32_t* __restrict__ alive_in = w.alive[n & 1u];

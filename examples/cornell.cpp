@@ -7,6 +7,7 @@
 //           [--animate [--rebuild-at F]]   the boxes drift every frame; the poses go to the GPU, which redoes the instance records and refits
 //                                          both trees (hk_refit_scene_instances); at frame F the trees are rebuilt on the device (LBVH)
 //           [--gpus N [--devices a,b,..]]   band-sharded over N GPUs from this one process (hk_multi_*); --devices may repeat an id
+//           [--balance]                     ... with the bands split by cost on the first frame (HK_FRAME_BALANCE_BANDS)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,6 +84,7 @@ int main(int argc, char** argv) {
   uint32_t ctx_flags = 0;
   int gpus = 1;
   std::vector<int> devices;
+  bool balance = false;  // --balance: split the bands by cost on the first frame (HK_FRAME_BALANCE_BANDS)
   std::string ppm, raw, assets = "bevy-hikari_amd/assets";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -101,6 +103,7 @@ int main(int argc, char** argv) {
     else if (a == "--deterministic") ctx_flags |= HK_CTX_DETERMINISTIC_SCATTER;  // resolve the reference's scatter-store race reproducibly (motion)
     else if (a == "--rebuild-at" && i + 1 < argc) rebuild_at = (size_t)atoi(argv[++i]);
     else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
+    else if (a == "--balance") balance = true;
     else if (a == "--devices" && i + 1 < argc) {
       std::string list = argv[++i];
       for (size_t p = 0; p < list.size();) {
@@ -133,8 +136,14 @@ int main(int argc, char** argv) {
     load_cornell(assets + "/cornell.hkscene", scene);
     plugin.set_scene(scene);
     Camera camera = Camera::looking_at({0.0, 1.0, 4.0}, {0.0, 1.0, 0.0}, {0.0, 1.0, 0.0}, w, h);
+    if (balance) plugin.balance_bands_on_next_frame();
     for (size_t n = 1; n <= frames; ++n) plugin.render(camera, settings, n, nullptr, antialias);
     plugin.wait();
+    if (balance) {
+      std::printf("band bounds:");
+      for (uint32_t b : plugin.band_bounds((uint32_t)devices.size())) std::printf(" %u", b);
+      std::printf("\n");
+    }
     uint32_t rw = 0, rh = 0;
     std::vector<uint8_t> tm = plugin.read(HikariPlugin::final_buffer(settings, antialias), &rw, &rh);
     if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)tm.data(), (std::streamsize)tm.size());

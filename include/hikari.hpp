@@ -393,6 +393,7 @@ class HikariPlugin {
   FrameCounter counter_;
   uint32_t width_ = 0, height_ = 0;
   float ratio_ = 0.0f;
+  bool balance_next_ = false;
   std::optional<Camera> previous_;
 };
 
@@ -419,6 +420,20 @@ class HikariMultiGpuPlugin {
   void rebuild_trees(uint32_t mode = HK_TREE_SAH) { check(hk_multi_rebuild_scene_trees(m_, mode), "hk_multi_rebuild_scene_trees"); }
   // rows of last frame's reservoirs fetched across the band borders before reprojection (0 for a static camera)
   void set_history_rows(uint32_t rows) { check(hk_multi_set_history_rows(m_, rows), "hk_multi_set_history_rows"); }
+  // bands of unequal height: explicit boundaries (scaled render rows, bands + 1 entries; empty = the equal split) ...
+  void set_band_bounds(const std::vector<uint32_t>& bounds) {
+    check(hk_multi_set_band_bounds(m_, bounds.empty() ? nullptr : bounds.data(), (uint32_t)bounds.size()), "hk_multi_set_band_bounds");
+  }
+  // ... or the split by cost, derived from the NEXT rendered frame's primary rays and kept from then on (HK_FRAME_BALANCE_BANDS):
+  // for the first frame or after a cut - rows that change owner lose their reservoir history
+  void balance_bands_on_next_frame() { balance_next_ = true; }
+  std::vector<uint32_t> band_bounds(uint32_t bands) const {
+    hk_ctx* c0 = nullptr;
+    check(hk_multi_context(m_, 0, &c0), "hk_multi_context");
+    std::vector<uint32_t> b(bands + 1u);
+    check(hk_get_band_bounds(c0, b.data(), (uint32_t)b.size()), "hk_get_band_bounds");
+    return b;
+  }
   size_t render(const Camera& camera, const HikariSettings& settings, std::optional<size_t> frame_number = std::nullopt, const HkLights* lights = nullptr,
                 bool antialias = false) {
     if (camera.width != width_ || camera.height != height_ || settings.upscale.ratio() != ratio_) {
@@ -434,7 +449,9 @@ class HikariMultiGpuPlugin {
     const HkView view = camera.view_uniform();
     const HkPreviousView pview = previous_ ? previous_->previous_view_uniform() : camera.previous_view_uniform();
     const HkLights l = lights ? *lights : lights_uniform();
-    check(hk_multi_frame_render(m_, &frame, &view, &pview, &l, &sc, antialias ? HK_FRAME_ANTIALIAS : 0u), "hk_multi_frame_render");
+    check(hk_multi_frame_render(m_, &frame, &view, &pview, &l, &sc, (antialias ? HK_FRAME_ANTIALIAS : 0u) | (balance_next_ ? HK_FRAME_BALANCE_BANDS : 0u)),
+          "hk_multi_frame_render");
+    balance_next_ = false;
     previous_ = camera;
     return n;
   }
@@ -457,6 +474,7 @@ class HikariMultiGpuPlugin {
   FrameCounter counter_;
   uint32_t width_ = 0, height_ = 0;
   float ratio_ = 0.0f;
+  bool balance_next_ = false;
   std::optional<Camera> previous_;
 };
 
