@@ -305,7 +305,7 @@ def main():
     extra = None
     if default_run and not args.no_extra_configs:
         extra = {}
-        for cfg, steps_x in ((3, 8), (5, 8)):
+        for cfg, steps_x in ((3, 8), (4, 6), (5, 8)):
             x = measure(cfg, steps_x, 6, 3, alone=False)
             extra[str(cfg)] = {"workload": x["description"], "value": round(x["total_rays"] / x["elapsed"] / 1e6, 3), "unit": "Mray/s",
                                "ms_per_step": round(x["elapsed"] / steps_x * 1e3, 4), "steps": steps_x, "warmup": 6,
