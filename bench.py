@@ -394,6 +394,9 @@ def main():
                       "frac": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ind_ms_alone > 0 else 0.0},
         },
     }
+    tpath = os.path.join(ROOT, "profiles", "r03_indirect_hbm_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r02_indirect_hbm_traffic.json")
     if m.get("spatial_ms_alone"):
         # the second large kernel of the frame (by now as long as the first): spatial_reuse, light.wgsl:1503-1684 - SURVEY 8d: reads
         # G-buffer 40 + own reservoir 64 + previous spatial 64, writes reservoir 64 + render 8 (the 16 neighbour records it gathers,
@@ -402,6 +405,11 @@ def main():
         out["roofline"]["second_kernel"] = {"kernel": "k_spatial_reuse<false> (spatial_reuse, light.wgsl:1503-1684)", "algorithmic_bytes_per_launch": sp_bytes,
                                             "alone": {"avg_launch_ms": round(m["spatial_ms_alone"], 5), "achieved": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9, 3),
                                                       "frac": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
+        if os.path.exists(tpath):   # its counter traffic (same committed PMC passes as roofline.traffic; round 2: 1.8x the algorithmic bytes)
+            t2 = json.load(open(tpath)).get("second_kernel")
+            if t2:
+                out["roofline"]["second_kernel"]["traffic"] = t2["hbm_bytes_per_launch"]
+                out["roofline"]["second_kernel"]["traffic_ratio_to_algorithmic"] = t2["ratio_to_algorithmic"]
     if hbm:
         out["roofline"]["hbm_ceiling_measured"] = hbm
         out["roofline"]["frac_of_measured_copy"] = round(achieved / hbm["copy_gbs"], 6) if hbm["copy_gbs"] > 0 else None
@@ -410,9 +418,6 @@ def main():
             frame_bytes = 1700.0 * W * H
             out["frame_roofline"] = {"algorithmic_bytes_per_frame": frame_bytes, "achieved_gbs": round(frame_bytes / (elapsed / args.steps) / 1e9, 1),
                                      "frac_of_peak": round(frame_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
-    tpath = os.path.join(ROOT, "profiles", "r03_indirect_hbm_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r02_indirect_hbm_traffic.json")
     if valu:
         # VALU issue: the peak is MEASURED in this run (hk_measure_valu).  MI355X_MICROARCH.md: a wave64 VALU instruction issues
         # over 2 cycles on a SIMD-32, i.e. 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1 229 G wave-instructions/s nominal; the probe

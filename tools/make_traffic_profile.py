@@ -55,6 +55,18 @@ def main():
             "source": "SQ_INSTS_VALU; SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)",
         },
     }
+    # the second kernel of the frame (bench.py roofline.second_kernel): k_spatial_reuse<false>, 240 B/px algorithmic
+    try:
+        n2, s2 = pick(sq, "k_spatial_reuse<false>")
+        _, f2 = pick(fetch, "k_spatial_reuse<false>")
+        _, w2 = pick(write, "k_spatial_reuse<false>")
+        hbm2, algo2 = int(2 * f2["FETCH_SIZE"][0] * 1024 + w2["WRITE_SIZE"][0] * 1024), 240 * 1920 * 1080
+        out["second_kernel"] = {"kernel": "k_spatial_reuse<false> (spatial_reuse, light.wgsl:1503-1684)", "FETCH_SIZE_KB_raw": round(f2["FETCH_SIZE"][0], 1),
+                                "WRITE_SIZE_KB": round(w2["WRITE_SIZE"][0], 1), "hbm_bytes_per_launch": hbm2, "algorithmic_bytes_per_launch": algo2,
+                                "ratio_to_algorithmic": round(hbm2 / algo2, 3), "valu_wave_instructions": round(s2["SQ_INSTS_VALU"][0], 1),
+                                "lane_utilisation": round(s2["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * s2["SQ_ACTIVE_INST_VALU"][0]), 3)}
+    except SystemExit:
+        pass
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out["limiter"]), out["ratio_to_algorithmic"])
 
