@@ -98,6 +98,8 @@ def main():
                     help="--gpus N: bands of equal cost (geometry pixels per row, counted on frame 1 by every rank: HK_FRAME_BALANCE_BANDS) or of equal height; "
                          "auto = balanced for scenes beyond LDS (configs 3, 4: sky rows cost nothing, city rows everything - predicted 3.2x instead of 2.75x at 8 GPUs), "
                          "equal for the Cornell configs (every row costs about the same: 1.97x against 2.01x, profiles/r03_band_balance_probe.json)")
+    ap.add_argument("--no-gather", action="store_true", help="--gpus N: leave every band's rows of the tone-mapped image on the GPU that rendered them (default: rank 0 "
+                    "collects them every frame, HK_FRAME_GATHER - SURVEY 8e step 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -199,7 +201,8 @@ def main():
                 if r is None:
                     e.frame_render(frame, view, pview, lights, sc)
                 else:   # frame 1 splits the rows by cost (hk_balance_bands: every rank derives the same boundaries), the rest keep them
-                    r.render(frame, view, pview, lights, settings, W, H, balance=(n == 1 and (args.band_split == "balanced" or (args.band_split == "auto" and config in (3, 4)))))
+                    r.render(frame, view, pview, lights, settings, W, H, balance=(n == 1 and (args.band_split == "balanced" or (args.band_split == "auto" and config in (3, 4)))),
+                             gather=not args.no_gather)   # rank 0 collects the finished image, every frame, inside the timed region
 
         eng, rend = make_engine(args.ctx_flags)
         if warmup < 256 and config == args.config:
@@ -361,7 +364,8 @@ def main():
             "baseline_config": args.config,
             "frames": f"warmup 1..{args.warmup}, then {len(blocks)} timed blocks of {args.steps} frames ({args.warmup + 1}..{last_frame}); value = median block",
             "parallelism": f"band{world}" if world > 1 else "single",
-            **({"band_split": ("balanced" if m["band_bounds"] else "equal"), "band_bounds": m["band_bounds"]} if world > 1 else {}),
+            **({"band_split": ("balanced" if m["band_bounds"] else "equal"), "band_bounds": m["band_bounds"],
+                "gather": "none" if args.no_gather else "rank 0 collects the tone-mapped image every frame (HK_FRAME_GATHER), inside the timed region"} if world > 1 else {}),
             # hk_traversal_mode: "one-level" = one BVH over all triangles in the instances' shared local space (the Cornell box),
             # "threaded" = two-level walk over 8 direction-ordered flattenings (scenes beyond LDS), "reference" = the reference's order
             "traversal": {"mode": m["traversal"][0], "orderings": m["traversal"][1]},

@@ -41,7 +41,7 @@ DEFAULT_CTX_FLAGS = int(os.environ.get("HIKARI_HIP_DEFAULT_CTX_FLAGS", "0"))
 CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER, CTX_EXACT_TRAVERSAL = 1, 2, 4, 8, 16, 32
 TREE_SAH, TREE_LBVH = 0, 1  # hk_rebuild_scene_trees
 CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient with >= 2 bounces (hikari_hip.h)
-FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS = 1, 2, 4
+FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS, FRAME_GATHER = 1, 2, 4, 8
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1
 UPSCALE_FSR1, UPSCALE_SMAA_TU4X = 0, 1
@@ -218,6 +218,9 @@ _PRODUCT_ONLY = {
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "balanced_band_bounds": [P(u32), u32, u32, u32, u32, u32, f32, P(u32)],
     "balance_bands": [_vp, u32, P(u32), u32],
+    "band_gather_schedule": [u32, u32, f32, u32, P(u32), u32, u32, u32, u32, P(HkTransfer), P(u32)],
+    "comm_gather": [_vp, u32, u32],
+    "multi_gather": [_vp, u32, u32],
     "get_band_bounds": [_vp, P(u32), u32],
     "get_band": [_vp, P(u32), P(u32)],
     "band_plan_bounds": [u32, u32, f32, P(u32), u32, u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],
@@ -258,7 +261,7 @@ _PRODUCT_ONLY = {
 _VOID = {"destroy": [_vp], "scene_builder_destroy": [_vp], "multi_destroy": [_vp]}
 
 #: every symbol include/hikari_hip.h declares (checked by tests/test_abi.py)
-DECLARED_SYMBOLS = sorted(["hk_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY) + list(_VOID)] + ["hk_abi_version", "hk_last_error"])
+DECLARED_SYMBOLS = sorted(["hk_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY) + list(_VOID)] + ["hk_abi_version", "hk_last_error", "hk_final_buffer"])
 
 
 class Api:
@@ -289,6 +292,13 @@ class Api:
         self._last_error.restype = C.c_char_p
         self._abi = getattr(self.dll, prefix + "abi_version")
         self._abi.restype = u32
+        if prefix == "hk_":
+            self._final_buffer = self.dll.hk_final_buffer
+            self._final_buffer.argtypes, self._final_buffer.restype = [P(HkSettings), u32], u32
+
+    def final_buffer(self, settings_c, frame_flags=0):
+        """hk_final_buffer: the HkBuffer id of the image a frame rendered with these settings / flags presents."""
+        return int(self._final_buffer(C.byref(settings_c), frame_flags))
 
     def abi_version(self):
         return int(self._abi())

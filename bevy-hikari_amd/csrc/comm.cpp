@@ -168,6 +168,47 @@ int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
   return HK_OK;
 }
 
+// the root collects every other band's rows of `buffer` (ncclSend / ncclRecv pairs in one group, on the stream)
+int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root) {
+  Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
+  HK_REQUIRE(cm && cm->comm, HK_E_NOT_READY, "no communicator attached (hk_comm_init)");
+  Rccl* R = rccl();
+  HK_REQUIRE(R, HK_E_UNSUPPORTED, "librccl could not be loaded");
+  CtxInfo ci;
+  int rc = ctx_info(c, &ci);
+  if (rc) return rc;
+  HK_REQUIRE(ci.width > 0, HK_E_NOT_READY, "hk_resize has not been called");
+  HK_REQUIRE(root < cm->n_ranks, HK_E_INVALID, "root %u of %u ranks", root, cm->n_ranks);
+  if (cm->n_ranks < 2) return HK_OK;
+  uint32_t n = 0;
+  if ((rc = hk_band_gather_schedule(ci.width, ci.height, ci.ratio, ci.upscale_kind, ci.band_bounds, cm->rank, cm->n_ranks, root, buffer, nullptr, &n))) return rc;
+  std::vector<HkTransfer> tr(n);
+  if (n && (rc = hk_band_gather_schedule(ci.width, ci.height, ci.ratio, ci.upscale_kind, ci.band_bounds, cm->rank, cm->n_ranks, root, buffer, tr.data(), &n))) return rc;
+  if (tr.empty()) return HK_OK;
+  HK_HIP(hipSetDevice(ci.device));
+  hipStream_t stream = (hipStream_t)ci.stream;
+  size_t limit = 0;
+  char* base = static_cast<char*>(ctx_buffer(c, buffer, &limit));
+  HK_REQUIRE(base, HK_E_INVALID, "buffer %u is not allocated", buffer);
+  HK_NCCL(R, R->GroupStart());
+  for (const HkTransfer& t : tr) {
+    if (t.offset + t.bytes > limit) {
+      (void)R->GroupEnd();
+      HK_REQUIRE(false, HK_E_INVALID, "gather transfer outside buffer %u", buffer);
+    }
+    const ncclResult_t e = t.is_recv ? R->Recv(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream)
+                                     : R->Send(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream);
+    if (e != ncclSuccess) {
+      (void)R->GroupEnd();
+      set_error("ncclSend/ncclRecv failed: %s", R->GetErrorString(e));
+      return HK_E_HIP;
+    }
+    if (t.is_recv) cm->bytes_received += t.bytes;
+  }
+  HK_NCCL(R, R->GroupEnd());
+  return HK_OK;
+}
+
 void comm_release(hk_ctx* c) {
   void** slot = ctx_comm_slot(c);
   Comm* cm = static_cast<Comm*>(*slot);
@@ -496,6 +537,56 @@ int hk_comm_exchange(hk_ctx* c, uint32_t stage, const HkSettings* st) {
   return comm_exchange(c, stage, st);
 }
 
+int hk_comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  return comm_gather(c, buffer, root);
+}
+
+// one process, n bands: the root band's context ends up holding the whole image on ITS device (peer copies on the root's stream,
+// each ordered behind the owner's stream by an event); nothing waits on the host
+int hk_multi_gather(hk_multi* m, uint32_t buffer, uint32_t root) {
+  HK_REQUIRE(m && root < m->ctx.size(), HK_E_INVALID, "bad argument");
+  const uint32_t n = (uint32_t)m->ctx.size();
+  if (n < 2) return HK_OK;
+  CtxInfo cr;
+  int rc = ctx_info(m->ctx[root], &cr);
+  if (rc) return rc;
+  HK_REQUIRE(cr.width > 0, HK_E_NOT_READY, "hk_multi_resize has not been called");
+  uint32_t nt = 0;
+  if ((rc = hk_band_gather_schedule(cr.width, cr.height, cr.ratio, cr.upscale_kind, cr.band_bounds, root, n, root, buffer, nullptr, &nt))) return rc;
+  std::vector<HkTransfer> tr(nt);
+  if (nt && (rc = hk_band_gather_schedule(cr.width, cr.height, cr.ratio, cr.upscale_kind, cr.band_bounds, root, n, root, buffer, tr.data(), &nt))) return rc;
+  size_t ldst = 0;
+  char* dst = static_cast<char*>(ctx_buffer(m->ctx[root], buffer, &ldst));
+  HK_REQUIRE(dst, HK_E_INVALID, "buffer %u is not allocated", buffer);
+  for (const HkTransfer& t : tr) {
+    HK_REQUIRE(t.is_recv && t.peer < n, HK_E_INVALID, "bad gather schedule");
+    CtxInfo cp;
+    if ((rc = ctx_info(m->ctx[t.peer], &cp))) return rc;
+    size_t lsrc = 0;
+    const char* src = static_cast<const char*>(ctx_buffer(m->ctx[t.peer], buffer, &lsrc));
+    HK_REQUIRE(src && t.offset + t.bytes <= ldst && t.offset + t.bytes <= lsrc, HK_E_INVALID, "gather transfer outside buffer %u", buffer);
+    HK_HIP(hipSetDevice(m->device[t.peer]));
+    HK_HIP(hipEventRecord(m->produced[t.peer], (hipStream_t)cp.stream));
+    HK_HIP(hipSetDevice(m->device[root]));
+    HK_HIP(hipStreamWaitEvent((hipStream_t)cr.stream, m->produced[t.peer], 0));
+    if (m->device[root] == m->device[t.peer])
+      HK_HIP(hipMemcpyAsync(dst + t.offset, src + t.offset, t.bytes, hipMemcpyDeviceToDevice, (hipStream_t)cr.stream));
+    else
+      HK_HIP(hipMemcpyPeerAsync(dst + t.offset, m->device[root], src + t.offset, m->device[t.peer], t.bytes, (hipStream_t)cr.stream));
+    m->bytes_copied += t.bytes;
+  }
+  // the owners do not overwrite their rows (next frame) before the root has copied them
+  HK_HIP(hipEventRecord(m->copied[root], (hipStream_t)cr.stream));
+  for (const HkTransfer& t : tr) {
+    CtxInfo cp;
+    if ((rc = ctx_info(m->ctx[t.peer], &cp))) return rc;
+    HK_HIP(hipSetDevice(m->device[t.peer]));
+    HK_HIP(hipStreamWaitEvent((hipStream_t)cp.stream, m->copied[root], 0));
+  }
+  return HK_OK;
+}
+
 int hk_multi_create(uint32_t n, const int* device_ids, uint32_t flags, hk_multi** out) {
   HK_REQUIRE(out && device_ids && n > 0 && n <= 64, HK_E_INVALID, "bad argument");
   *out = nullptr;
@@ -614,8 +705,14 @@ int hk_multi_set_history_rows(hk_multi* m, uint32_t rows) {
   return HK_OK;
 }
 
+static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags);
 int hk_multi_frame_render(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   HK_REQUIRE(m && st, HK_E_INVALID, "bad argument");
+  const int rc = multi_frame_render_bands(m, f, v, pv, l, st, flags);
+  if (rc || !(flags & HK_FRAME_GATHER)) return rc;
+  return hk_multi_gather(m, hk_final_buffer(st, flags), 0);  // band 0's device presents the image
+}
+static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   int rc;
   {
     const uint32_t hist = m->history_rows << 8;

@@ -2332,7 +2332,12 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
     if (ex && (rc = comm_exchange(c, HK_STAGE_ANTIALIAS | hist, st))) return rc;
     if ((rc = hk_frame_stage(c, HK_STAGE_ANTIALIAS, st, flags))) return rc;
     if (ex && st->upscale_kind == HK_UPSCALE_FSR1 && (rc = comm_exchange(c, HK_STAGE_UPSCALE, st))) return rc;
-    return hk_frame_stage(c, HK_STAGE_UPSCALE, st, flags);
+    if ((rc = hk_frame_stage(c, HK_STAGE_UPSCALE, st, flags))) return rc;
+  }
+  // rank 0 collects the finished image (the post stream's tone mapping has to be in before the rows leave)
+  if (ex && (flags & HK_FRAME_GATHER)) {
+    if ((rc = join_all(c))) return rc;
+    return comm_gather(c, hk_final_buffer(st, flags), 0u);
   }
   return HK_OK;
 }

@@ -54,6 +54,8 @@ void band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint32
 // ... when the split of the `render_rows` scaled render rows is explicit (bounds[0..n], NULL = equal split); `rows` = the height of
 // the plane being cut (render_rows, or the window rows FSR1 writes)
 void band_rows_in(const uint32_t* bounds, uint32_t render_rows, uint32_t rows, uint32_t band_index, uint32_t band_count, uint32_t* b0, uint32_t* b1);
+int band_buffer_rows(uint32_t width, uint32_t height, float ratio, uint32_t upscale_kind, const uint32_t* bounds, uint32_t buffer, uint32_t i, uint32_t n,
+                     uint32_t* y0, uint32_t* y1, uint64_t* row_bytes);  // rows of `buffer` band i owns (host_logic.cpp)
 bool band_bounds_valid(const uint32_t* bounds, uint32_t band_count, uint32_t render_rows);
 
 // apron rows (in scaled render rows) each stage needs around a band, from the kernel footprints
@@ -75,6 +77,7 @@ struct CtxInfo {
   uint32_t bounds_generation;    // changes whenever the split does (cached schedules compare it)
 };
 int ctx_info(hk_ctx* c, CtxInfo* out);
+int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root);  // comm.cpp
 void* ctx_buffer(hk_ctx* c, uint32_t buffer, size_t* logical_bytes);
 void** ctx_comm_slot(hk_ctx* c);       // owned by comm.cpp (NULL = no communicator)
 uint32_t* ctx_history_rows(hk_ctx* c);

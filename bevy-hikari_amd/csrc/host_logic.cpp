@@ -76,6 +76,49 @@ bool band_bounds_valid(const uint32_t* bounds, uint32_t n, uint32_t render_rows)
   return true;
 }
 
+// the finished image lives in bands, one per rank; the rank that presents it collects the others' rows.
+// Which rows of `buffer` band i owns (bands partition the RENDER rows [b0, b1)):
+//   render-size buffers (and the rw x rh records of a reservoir buffer)      [b0, b1)
+//   SMAA Tu4x outputs (upscale_output / taa_output, two rows per render row) [2 b0, 2 b1) clamped, the last band to the end
+//   FSR1 window-size outputs                                                 the boundaries scaled to the window height
+//   full-size planes (G-buffer, albedo) at ratio > 1                         the window rows under [b0, b1)
+int band_buffer_rows(uint32_t width, uint32_t height, float ratio, uint32_t upscale_kind, const uint32_t* bounds, uint32_t buffer, uint32_t i, uint32_t n,
+                     uint32_t* y0, uint32_t* y1, uint64_t* row_bytes) {
+  uint32_t rw, rh;
+  int rc = hk_scaled_size(width, height, ratio, &rw, &rh);
+  if (rc) return rc;
+  HK_REQUIRE(buffer < HK_BUF_COUNT && buffer_bpp(buffer) && i < n && n > 0, HK_E_INVALID, "bad buffer or band");
+  HK_REQUIRE(band_bounds_valid(bounds, n, rh), HK_E_INVALID, "band bounds do not fit the render size");
+  const float cr = ratio < 1.0f ? 1.0f : (ratio > 2.0f ? 2.0f : ratio);  // Upscale::ratio, lib.rs:500-504
+  const float s2 = (1.0f / cr) * 2.0f;                                    // post_process.rs:718-722
+  const uint32_t uw = (uint32_t)ceilf((float)width * s2), uh = (uint32_t)ceilf((float)height * s2);
+  uint32_t bw = rw, bh = rh;  // context.hip buffer_dims
+  if (buffer_is_full_size(buffer)) { bw = width; bh = height; }
+  else if (buffer_is_upscaled(buffer) && upscale_kind == HK_UPSCALE_SMAA_TU4X) { bw = uw; bh = uh; }
+  else if (buffer == HK_BUF_UPSCALE_OUTPUT) { bw = width; bh = height; }
+  const bool reservoir = buffer >= HK_BUF_RESERVOIR0 && buffer < HK_BUF_RESERVOIR0 + 10;
+  const uint32_t rows = reservoir ? rh : bh;
+  *row_bytes = (uint64_t)(reservoir ? rw : bw) * buffer_bpp(buffer);
+  const bool upscaled = buffer_is_upscaled(buffer);
+  const bool fsr_window = upscale_kind == HK_UPSCALE_FSR1 && (buffer == HK_BUF_UPSCALE_OUTPUT || buffer == HK_BUF_UPSCALE_SHARPENED);
+  uint32_t b0, b1;
+  band_rows_in(bounds, rh, rh, i, n, &b0, &b1);
+  if (fsr_window) {
+    band_rows_in(bounds, rh, height, i, n, y0, y1);
+  } else if (rows == rh) {
+    *y0 = b0;
+    *y1 = b1;
+  } else if (upscaled && upscale_kind == HK_UPSCALE_SMAA_TU4X) {
+    *y0 = 2 * b0 < rows ? 2 * b0 : rows;
+    *y1 = (b1 == rh) ? rows : (2 * b1 < rows ? 2 * b1 : rows);
+  } else {
+    *y0 = (uint32_t)((uint64_t)b0 * rows / rh);
+    *y1 = (b1 == rh) ? rows : (uint32_t)((uint64_t)b1 * rows / rh);
+  }
+  return HK_OK;
+}
+
+
 // Kernel footprints in scaled render rows:
 //  spatial_reuse reads neighbour reservoirs within SPATIAL_REUSE_RANGE px (20 indirect / 10
 //  emissive, light.wgsl:246-252); its depth ray-march taps (light.wgsl:1609-1625) can land one
@@ -412,6 +455,45 @@ int hk_band_schedule_bounds(uint32_t width, uint32_t height, float upscale_ratio
   }
   *n_out = n;
   return HK_OK;
+}
+
+// The gather as a list of transfers for `rank`: the root receives every other band's rows of `buffer` (one transfer per band, in
+// band order), band r sends its rows to the root.  Same contract as hk_band_schedule: every rank derives the same global order.
+int hk_band_gather_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint32_t upscale_kind, const uint32_t* bounds, uint32_t rank, uint32_t n_ranks,
+                            uint32_t root, uint32_t buffer, HkTransfer* out, uint32_t* n_out) {
+  HK_REQUIRE(n_out && n_ranks > 0 && rank < n_ranks && root < n_ranks, HK_E_INVALID, "bad argument");
+  const uint32_t cap = out ? *n_out : 0;
+  uint32_t n = 0;
+  for (uint32_t r = 0; r < n_ranks; ++r) {
+    if (r == root || (rank != root && rank != r)) continue;
+    uint32_t y0, y1;
+    uint64_t row_bytes;
+    const int rc = band_buffer_rows(width, height, upscale_ratio, upscale_kind, bounds, buffer, r, n_ranks, &y0, &y1, &row_bytes);
+    if (rc) return rc;
+    if (y1 <= y0) continue;
+    if (out && n < cap) {
+      out[n].buffer = buffer;
+      out[n].peer = rank == root ? r : root;
+      out[n].is_recv = rank == root ? 1u : 0u;
+      out[n]._pad = 0;
+      out[n].offset = (uint64_t)y0 * row_bytes;
+      out[n].bytes = (uint64_t)(y1 - y0) * row_bytes;
+    }
+    n += 1;
+  }
+  if (out && n > cap) {
+    *n_out = n;
+    HK_REQUIRE(false, HK_E_INVALID, "transfer array too small: need %u", n);
+  }
+  *n_out = n;
+  return HK_OK;
+}
+
+// the image the overlay presents (overlay.rs:226-231) for these settings: what a frame's gather moves
+uint32_t hk_final_buffer(const HkSettings* st, uint32_t frame_flags) {
+  if (!st || !(frame_flags & HK_FRAME_ANTIALIAS)) return HK_BUF_TONE_MAPPED;
+  if (st->upscale_kind == HK_UPSCALE_FSR1) return HK_BUF_UPSCALE_SHARPENED;
+  return st->taa == HK_TAA_JASMINE ? HK_BUF_TAA_OUTPUT : HK_BUF_UPSCALE_OUTPUT;
 }
 
 // Row boundaries that give every band about the same COST: cost(row) = geometry pixels in it + width x background_cost, the cost

@@ -64,6 +64,28 @@ def band_schedule(width, height, upscale_ratio, rank, n_ranks, stage, frame_numb
     return [tr[i] for i in range(n2.value)]
 
 
+def _final_buffer(settings, antialias):
+    """hk_final_buffer for a library without it (the oracle behind the same table in the CPU tests)."""
+    if not antialias:
+        return F.BUF_TONE_MAPPED
+    if settings.upscale.kind == F.UPSCALE_FSR1:
+        return F.BUF_UPSCALE_SHARPENED
+    return F.BUF_TAA_OUTPUT if settings.taa == F.TAA_JASMINE else F.BUF_UPSCALE_OUTPUT
+
+
+def band_gather_schedule(width, height, upscale_ratio, upscale_kind, rank, n_ranks, root, buffer, bounds=None):
+    """hk_band_gather_schedule: the transfers of `rank` when band `root` collects every band's rows of `buffer` (list of HkTransfer)."""
+    api = F.api()
+    b = None if bounds is None else (C.c_uint32 * len(bounds))(*[int(x) for x in bounds])
+    n = F.u32(0)
+    api.call("band_gather_schedule", width, height, upscale_ratio, upscale_kind, b, rank, n_ranks, root, buffer, None, C.byref(n))
+    tr = (F.HkTransfer * max(n.value, 1))()
+    n2 = F.u32(n.value)
+    if n.value:
+        api.call("band_gather_schedule", width, height, upscale_ratio, upscale_kind, b, rank, n_ranks, root, buffer, tr, C.byref(n2))
+    return [tr[i] for i in range(n2.value)]
+
+
 def balanced_band_bounds(row_costs, width, render_rows, band_count, min_rows=8, background_cost=0.0):
     """hk_balanced_band_bounds: boundaries (band_count + 1 scaled render rows) that give every band about the same cost
     (geometry pixels + width x background_cost per row; 0 = 1/16)."""
@@ -212,7 +234,33 @@ class BandRenderer:
             self.torch.cuda.synchronize()  # the halo rows are in place before the next stage is enqueued on the engine's stream
         return nbytes
 
-    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0, antialias=False, balance=False):
+    def gather(self, buffer, settings, width, height, frame_number, root=0):
+        """SURVEY 8e step 7 through the host transport (tests): band `root` collects every band's rows of `buffer`."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return
+        self.engine.wait()
+        ops, landing = [], []
+        for t in band_gather_schedule(width, height, settings.upscale.ratio(), settings.upscale.kind, self.rank, self.world, root, buffer, self.bounds):
+            view = self._view(t.buffer, frame_number & 1)[t.offset:t.offset + t.bytes]
+            if t.is_recv:
+                if self.device == "cuda":
+                    tmp = self.torch.empty(view.numel(), dtype=self.torch.uint8)
+                    landing.append((view, tmp))
+                    view = tmp
+                ops.append(dist.P2POp(dist.irecv, view, t.peer))
+            else:
+                ops.append(dist.P2POp(dist.isend, view.cpu() if self.device == "cuda" else view, t.peer))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for view, tmp in landing:
+            view.copy_(tmp)
+        if landing:
+            self.torch.cuda.synchronize()
+
+    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0, antialias=False, balance=False, gather=False):
         """One frame of this rank's band.  history_rows > 0 (camera or objects moved since the last frame) first fetches
         that many rows of last frame's reservoirs from the neighbouring bands (exchange C).  balance: split THIS frame's rows by
         cost first (HK_FRAME_BALANCE_BANDS / hk_balance_bands - every rank derives the same split from its own full-frame primary
@@ -222,7 +270,8 @@ class BandRenderer:
         if self.transport == "rccl":
             if self.world > 1:
                 e.comm_set_history_rows(int(history_rows))
-            e.frame_render(frame, view, previous_view, lights, sc, (F.FRAME_ANTIALIAS if antialias else 0) | (F.FRAME_BALANCE_BANDS if balance else 0))
+            e.frame_render(frame, view, previous_view, lights, sc,
+                           (F.FRAME_ANTIALIAS if antialias else 0) | (F.FRAME_BALANCE_BANDS if balance else 0) | (F.FRAME_GATHER if gather else 0))
             if balance:
                 self.bounds = e.band_bounds()
             return
@@ -250,6 +299,9 @@ class BandRenderer:
                 e.wait()
                 self.exchange(F.STAGE_UPSCALE, frame.number, sc, width, height, ratio)
                 e.frame_stage(F.STAGE_UPSCALE, sc)
+        if gather:   # rank 0 collects the finished image
+            self.gather(F.api().final_buffer(sc, F.FRAME_ANTIALIAS if antialias else 0) if e.api.prefix == "hk_" else _final_buffer(settings, antialias),
+                        settings, width, height, frame.number)
 
     def band(self, rows):
         """Rows [b0, b1) of a plane of `rows` rows this rank owns (the render rows; other heights are cut where the boundaries fall)."""
@@ -310,6 +362,10 @@ class MultiEngine:
 
     def update_instances_on_device(self, builder, mode=F.TREE_SAH):
         self.api.call("multi_update_scene_instances", self.h, builder.h, mode)
+
+    def gather(self, buffer, root=0):
+        """hk_multi_gather: band `root`'s context collects every band's rows of `buffer` on its own device."""
+        self.api.call("multi_gather", self.h, buffer, root)
 
     def set_band_bounds(self, bounds=None):
         """hk_multi_set_band_bounds: bands of unequal height, the same split on every context (None = equal)."""

@@ -628,6 +628,10 @@ class Engine:
     def comm_set_history_rows(self, rows):
         self.api.call("comm_set_history_rows", self.ctx, rows)
 
+    def comm_gather(self, buffer, root=0):
+        """hk_comm_gather: rank `root` collects every other rank's rows of `buffer` (RCCL, on the context's stream)."""
+        self.api.call("comm_gather", self.ctx, buffer, root)
+
     def comm_destroy(self):
         self.api.call("comm_destroy", self.ctx)
 

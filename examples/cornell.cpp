@@ -8,6 +8,7 @@
 //                                          both trees (hk_refit_scene_instances); at frame F the trees are rebuilt on the device (LBVH)
 //           [--gpus N [--devices a,b,..]]   band-sharded over N GPUs from this one process (hk_multi_*); --devices may repeat an id
 //           [--balance]                     ... with the bands split by cost on the first frame (HK_FRAME_BALANCE_BANDS)
+//           [--gather]                      ... band 0's device collects the finished image every frame (HK_FRAME_GATHER)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,6 +86,7 @@ int main(int argc, char** argv) {
   int gpus = 1;
   std::vector<int> devices;
   bool balance = false;  // --balance: split the bands by cost on the first frame (HK_FRAME_BALANCE_BANDS)
+  bool gather = false;   // --gather: band 0's device collects the finished image every frame (HK_FRAME_GATHER); --raw then reads that one context
   std::string ppm, raw, assets = "bevy-hikari_amd/assets";
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
@@ -104,6 +106,7 @@ int main(int argc, char** argv) {
     else if (a == "--rebuild-at" && i + 1 < argc) rebuild_at = (size_t)atoi(argv[++i]);
     else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
     else if (a == "--balance") balance = true;
+    else if (a == "--gather") gather = true;
     else if (a == "--devices" && i + 1 < argc) {
       std::string list = argv[++i];
       for (size_t p = 0; p < list.size();) {
@@ -137,6 +140,7 @@ int main(int argc, char** argv) {
     plugin.set_scene(scene);
     Camera camera = Camera::looking_at({0.0, 1.0, 4.0}, {0.0, 1.0, 0.0}, {0.0, 1.0, 0.0}, w, h);
     if (balance) plugin.balance_bands_on_next_frame();
+    plugin.set_gather(gather);
     for (size_t n = 1; n <= frames; ++n) plugin.render(camera, settings, n, nullptr, antialias);
     plugin.wait();
     if (balance) {
@@ -145,7 +149,8 @@ int main(int argc, char** argv) {
       std::printf("\n");
     }
     uint32_t rw = 0, rh = 0;
-    std::vector<uint8_t> tm = plugin.read(HikariPlugin::final_buffer(settings, antialias), &rw, &rh);
+    std::vector<uint8_t> tm = gather ? plugin.read_gathered(HikariPlugin::final_buffer(settings, antialias), &rw, &rh)
+                                     : plugin.read(HikariPlugin::final_buffer(settings, antialias), &rw, &rh);
     if (!raw.empty()) std::ofstream(raw, std::ios::binary).write((const char*)tm.data(), (std::streamsize)tm.size());
     std::printf("rendered %zu frames at %ux%u on %zu bands (output size %ux%u)\n", frames, w, h, devices.size(), rw, rh);
     return 0;

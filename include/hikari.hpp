@@ -393,7 +393,7 @@ class HikariPlugin {
   FrameCounter counter_;
   uint32_t width_ = 0, height_ = 0;
   float ratio_ = 0.0f;
-  bool balance_next_ = false;
+  bool balance_next_ = false, gather_ = false;
   std::optional<Camera> previous_;
 };
 
@@ -427,6 +427,20 @@ class HikariMultiGpuPlugin {
   // ... or the split by cost, derived from the NEXT rendered frame's primary rays and kept from then on (HK_FRAME_BALANCE_BANDS):
   // for the first frame or after a cut - rows that change owner lose their reservoir history
   void balance_bands_on_next_frame() { balance_next_ = true; }
+  // after every frame band 0's device collects the other bands' rows of the image the overlay presents
+  // (HK_FRAME_GATHER: peer copies on its stream); read_gathered() then reads that one context instead of merging on the host
+  void set_gather(bool on) { gather_ = on; }
+  std::vector<uint8_t> read_gathered(uint32_t buffer, uint32_t* w = nullptr, uint32_t* h = nullptr) const {
+    hk_ctx* c0 = nullptr;
+    check(hk_multi_context(m_, 0, &c0), "hk_multi_context");
+    uint32_t bw, bh, bpp;
+    check(hk_buffer_info(c0, buffer, &bw, &bh, &bpp), "hk_buffer_info");
+    std::vector<uint8_t> out((size_t)bw * bh * bpp);
+    check(hk_read_buffer(c0, buffer, out.data(), out.size()), "hk_read_buffer");
+    if (w) *w = bw;
+    if (h) *h = bh;
+    return out;
+  }
   std::vector<uint32_t> band_bounds(uint32_t bands) const {
     hk_ctx* c0 = nullptr;
     check(hk_multi_context(m_, 0, &c0), "hk_multi_context");
@@ -449,7 +463,7 @@ class HikariMultiGpuPlugin {
     const HkView view = camera.view_uniform();
     const HkPreviousView pview = previous_ ? previous_->previous_view_uniform() : camera.previous_view_uniform();
     const HkLights l = lights ? *lights : lights_uniform();
-    check(hk_multi_frame_render(m_, &frame, &view, &pview, &l, &sc, (antialias ? HK_FRAME_ANTIALIAS : 0u) | (balance_next_ ? HK_FRAME_BALANCE_BANDS : 0u)),
+    check(hk_multi_frame_render(m_, &frame, &view, &pview, &l, &sc, (antialias ? HK_FRAME_ANTIALIAS : 0u) | (balance_next_ ? HK_FRAME_BALANCE_BANDS : 0u) | (gather_ ? HK_FRAME_GATHER : 0u)),
           "hk_multi_frame_render");
     balance_next_ = false;
     previous_ = camera;
@@ -474,7 +488,7 @@ class HikariMultiGpuPlugin {
   FrameCounter counter_;
   uint32_t width_ = 0, height_ = 0;
   float ratio_ = 0.0f;
-  bool balance_next_ = false;
+  bool balance_next_ = false, gather_ = false;
   std::optional<Camera> previous_;
 };
 

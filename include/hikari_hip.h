@@ -545,6 +545,9 @@ int hk_pass_run(hk_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, ui
  * cost and keep the split from here on.  Rows that change owner find the new owner's (stale) reservoirs as history: use it on
  * the first frame, after a cut, or accept a few frames of re-convergence in the moved rows. */
 #define HK_FRAME_BALANCE_BANDS 4u
+/* flags bit3 (hk_frame_render with a communicator, hk_multi_frame_render): after the last stage, band 0 collects the other bands' rows of
+ * the frame's final image (hk_final_buffer) - SURVEY 8e step 7, hk_comm_gather / hk_multi_gather */
+#define HK_FRAME_GATHER 8u
 int hk_frame_stage(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, uint32_t flags);
 /* hk_frame_begin + TEMPORAL, SPATIAL, POST_PROCESS (+ ANTIALIAS with HK_FRAME_ANTIALIAS): single GPU, no halo exchange */
 int hk_frame_render(hk_ctx* ctx, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
@@ -616,6 +619,15 @@ int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint3
 int hk_band_schedule_bounds(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* bounds, uint32_t rank,
                             uint32_t n_ranks, uint32_t stage, uint32_t frame_number, const HkSettings* settings, HkTransfer* out,
                             uint32_t* n_out);
+/* SURVEY 8e step 7, the gather of a finished image: the transfers of `rank` when band `root` collects every band's rows of
+ * `buffer` (the root: one receive per other band, in band order; band r: one send).  Which rows of a buffer a band owns follows
+ * the buffer's kind: render rows, two rows per render row for the SMAA Tu4x outputs, window rows for the FSR1 outputs.
+ * upscale_kind: HkUpscaleKind of the settings the frame was rendered with; bounds: NULL = the equal split. */
+int hk_band_gather_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint32_t upscale_kind, const uint32_t* bounds,
+                            uint32_t rank, uint32_t n_ranks, uint32_t root, uint32_t buffer, HkTransfer* out, uint32_t* n_out);
+/* the image the overlay presents (overlay.rs:226-231) after a frame rendered with these settings and frame flags: the tone-mapped
+ * image, or with HK_FRAME_ANTIALIAS the TAA / SMAA Tu4x / sharpened FSR1 output */
+uint32_t hk_final_buffer(const HkSettings* settings, uint32_t frame_flags);
 
 /* ------------------------------------------------------------------ halo exchange inside the boundary: one process per GPU, RCCL over xGMI */
 /* The reference's LightNode / PostProcessNode record every dispatch of a frame into one command encoder (light.rs:590-702);
@@ -640,6 +652,9 @@ int hk_comm_destroy(hk_ctx* ctx);
 int hk_comm_set_history_rows(hk_ctx* ctx, uint32_t rows);
 /* one exchange by hand (hosts that drive hk_frame_stage themselves): everything hk_band_schedule lists for `stage` */
 int hk_comm_exchange(hk_ctx* ctx, uint32_t stage, const HkSettings* settings);
+/* rank `root` collects every other rank's rows of `buffer` (hk_band_gather_schedule as ncclSend / ncclRecv in one group, on the
+ * context's stream); hk_frame_render(.., HK_FRAME_GATHER) does it for hk_final_buffer with root 0 */
+int hk_comm_gather(hk_ctx* ctx, uint32_t buffer, uint32_t root);
 
 /* ------------------------------------------------------------------ one process, several GPUs (hk_create(n_gpus, device_ids)) */
 /* Bevy renders from ONE process and one render thread: hk_multi is the same band-sharded frame driven by a single host
@@ -654,7 +669,9 @@ int hk_multi_upload_scene(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* moved); /* hk_refit_scene_instances on every band's replica */
 int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode);
-int hk_multi_set_band_bounds(hk_multi* m, const uint32_t* bounds, uint32_t n_bounds);  /* hk_set_band_bounds on every band's context */
+int hk_multi_set_band_bounds(hk_multi* m, const uint32_t* bounds, uint32_t n_bounds);
+/* the root band's context collects every other band's rows of `buffer` on its own device (peer copies ordered by events, no host wait) */
+int hk_multi_gather(hk_multi* m, uint32_t buffer, uint32_t root);  /* hk_set_band_bounds on every band's context */
 int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t tree_mode);  /* hk_update_scene_instances on every band's replica */
 int hk_multi_upload_textures(hk_multi* m, const HkImageDesc* images, uint32_t n_images);
 int hk_multi_upload_noise(hk_multi* m, const uint8_t* rgba, size_t bytes);

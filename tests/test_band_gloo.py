@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case_name, out_dir, transport=None, split=None):
+def _worker(rank, world, port, case_name, out_dir, transport=None, split=None, gather=False):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -59,13 +59,22 @@ def _worker(rank, world, port, case_name, out_dir, transport=None, split=None):
         r.set_bounds([int(round(f * rh)) for f in fractions])
     view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
     for k, n in enumerate(case.frames):
-        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, balance=(split == "balanced" and k == 0))
+        r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, balance=(split == "balanced" and k == 0),
+                 antialias=case.antialias and gather, gather=gather and n == case.frames[-1])
     if split == "balanced":   # every rank derived the split from its own full-frame primary rays: the same one
         mine = torch.tensor(r.bounds, dtype=torch.int64)
         everyone = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)
         assert all((t == mine).all() for t in everyone), everyone
         assert r.bounds == e.band_bounds() and r.bounds[0] == 0 and r.bounds[-1] == rh
+    if gather:   # rank 0 holds the whole final image after the last frame
+        if rank == 0:
+            from bevy_hikari_amd.distributed import _final_buffer
+
+            np.save(os.path.join(out_dir, "gathered.npy"), e.read(_final_buffer(s, case.antialias)))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     b0, b1 = r.band(rh)
     want = [F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_DENOISE_RENDER0 + 1, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 2]
     cur, prev = case.frames[-1] % 2, 1 - case.frames[-1] % 2
@@ -239,3 +248,23 @@ def test_antialias_bands_equal_single_rank(tmp_path, world, case_name):
             covered += y1 - y0
             assert (d[name].view(np.uint8) == full[name][y0:y1].view(np.uint8)).all(), f"rank {rank} rows [{y0},{y1}) differ in {name}"
         assert covered == full[name].shape[0], name
+
+
+@pytest.mark.parametrize("world,case_name,split", [(3, "cornell_b2", None), (2, "cornell_aa_default", None), (3, "cornell_aa_fsr", "uneven"), (4, "yard_aa_smaa2x", "balanced"),
+                                                   (2, "yard_aa_fsr_notaa", None)])
+def test_rank_0_gathers_the_final_image(tmp_path, world, case_name, split):
+    """SURVEY 8e step 7 over the host transport: after the last frame rank 0 collects every band's rows of the image the overlay
+    presents (tone-mapped; with the anti-aliasing tail the TAA / SMAA Tu4x / sharpened FSR1 output, whose rows are cut where the
+    boundaries fall at THEIR heights) - and holds the single-rank image, bit for bit."""
+    from bevy_hikari_amd.distributed import _final_buffer
+    from cases import make_case, run_case
+    from oracle_lib import oracle_plugin
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, case_name, str(tmp_path), None, split, True), nprocs=world, join=True)
+    case = make_case(case_name)
+    ref = oracle_plugin()
+    run_case(ref, case)
+    want = ref.engine.read(_final_buffer(case.settings, case.antialias))
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.shape == want.shape and (got.view(np.uint8) == want.view(np.uint8)).all()

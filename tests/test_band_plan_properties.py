@@ -172,3 +172,34 @@ def test_bad_bounds_are_refused():
         with pytest.raises(F.HikariError, match="band bounds"):
             halo_plan(64, 64, 1.0, 0, 3, F.STAGE_SPATIAL, 1, sc, bad)
     assert halo_plan(64, 64, 1.0, 0, 3, F.STAGE_SPATIAL, 1, sc, [0, 10, 20, 64]) is not None
+
+
+@settings(max_examples=120, deadline=None)
+@given(sizes, ratios, st.integers(1, 8), st.integers(0, 7), st.integers(0, 5),
+       st.sampled_from([F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, F.BUF_TAA_OUTPUT, F.BUF_UPSCALE_OUTPUT, F.BUF_UPSCALE_SHARPENED, F.BUF_POSITION, F.BUF_RESERVOIR0 + 3]),
+       st.sampled_from([F.UPSCALE_FSR1, F.UPSCALE_SMAA_TU4X]))
+def test_gather_schedules_pair_up_and_partition_the_buffer(size, ratio, world, root, split, buf, kind):
+    """hk_band_gather_schedule: band r's only transfer is the send the root's r-th receive expects (same offset, same
+    bytes), and the root's own rows plus what it receives tile the buffer's rows exactly once, whatever the buffer's kind."""
+    from bevy_hikari_amd.distributed import band_gather_schedule
+
+    width, height = size
+    root %= world
+    rw, rh = F.u32(), F.u32()
+    F.api().call("scaled_size", width, height, ratio, rw, rh)
+    bounds = random_bounds(split, rh.value, world)
+    sched = [band_gather_schedule(width, height, ratio, kind, r, world, root, buf, bounds) for r in range(world)]
+    recvs = [(t.peer, t.offset, t.bytes) for t in sched[root]]
+    assert all(t.is_recv and t.peer != root for t in sched[root]) and [p for p, _, _ in recvs] == sorted(p for p, _, _ in recvs)
+    for r in range(world):
+        if r == root:
+            continue
+        assert len(sched[r]) <= 1 and all((not t.is_recv) and t.peer == root for t in sched[r])
+        mine = [(t.offset, t.bytes) for t in sched[r]]
+        assert mine == [(o, b) for p, o, b in recvs if p == r], (r, mine, recvs)
+    # the rows the root does not receive are its own band: the spans tile [0, buffer bytes) with at most one gap, the root's
+    spans = sorted((o, o + b) for _, o, b in recvs)
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0, "overlapping receives"
+    gaps = [(a1, b0) for (a0, a1), (b0, b1) in zip([(0, 0)] + spans, spans + [(None, None)]) if b0 is not None and b0 > a1]
+    assert len(gaps) <= 1, (gaps, spans)

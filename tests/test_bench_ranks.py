@@ -42,6 +42,7 @@ def test_bench_band_path_runs_with_several_ranks_on_one_gpu(world, launcher):
     assert d["n_gpus"] == world and d["steps"] == 6 and d["scaling"] == "strong" and d["config"]["parallelism"] == f"band{world}"
     assert d["value"] > 0 and d["rays_per_frame"] > 640 * 360 and "roofline" in d and d["config"]["halo_transport"] == "host"
     assert len(d["blocks_ms_per_step"]) == 2
+    assert d["config"]["gather"].startswith("rank 0 collects") and d["replay_bit_identical"]   # (SURVEY 8e step 7 runs inside the timed frames)
 
 
 @pytest.mark.gpu

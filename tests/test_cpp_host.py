@@ -85,13 +85,13 @@ def test_cpp_host_fsr_matches_the_python_host(tmp_path, by_nodes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("bands,antialias,balance", [(2, False, False), (3, True, False), (3, False, True), (4, True, True)])
-def test_cpp_host_multi_gpu_bands_equal_the_single_context_frame(tmp_path, bands, antialias, balance):
+@pytest.mark.parametrize("bands,antialias,balance,gather", [(2, False, False, False), (3, True, False, False), (3, False, True, False), (4, True, True, True), (3, False, False, True)])
+def test_cpp_host_multi_gpu_bands_equal_the_single_context_frame(tmp_path, bands, antialias, balance, gather):
     """--devices 0,0[,0]: the one-process multi-GPU path (hk_multi_*: bands + peer-copy halo exchanges ordered by events) with
     every band on device 0; the gathered image equals the single-context frame bit for bit."""
     raw = tmp_path / "multi.bin"
     args = ["--size", "96", "64", "--frames", "5", "--bounces", "2", "--ratio", "2.0" if antialias else "1.0", "--devices", ",".join(["0"] * bands), "--raw", str(raw)]
-    r = run(*(args + (["--antialias"] if antialias else []) + (["--balance"] if balance else [])))
+    r = run(*(args + (["--antialias"] if antialias else []) + (["--balance"] if balance else []) + (["--gather"] if gather else [])))   # --gather: --raw reads band 0's context alone
     assert r.returncode == 0, r.stderr
     assert f"on {bands} bands" in r.stdout
     if balance:   # HikariMultiGpuPlugin::balance_bands_on_next_frame: the split follows the box (thin bands through it), not the row count

@@ -175,6 +175,31 @@ def test_multi_engine_balanced_config4_class_frame_at_1080p():
         assert (a.view(np.uint8) == r.view(np.uint8)).all(), f"balanced x{bands}: buffer {b} differs at 1920x1080"
 
 
+@pytest.mark.parametrize("bands,case_name,balanced", [(3, "cornell_b2", False), (4, "cornell_aa_default", True), (3, "cornell_aa_fsr", False), (2, "yard_aa_fsr_notaa", False),
+                                                      (5, "yard_aa_smaa2x", True), (8, "cornell_b2", False)])
+def test_multi_engine_gathers_the_final_image_on_band_0(bands, case_name, balanced):
+    """HK_FRAME_GATHER: after the frame, band 0's CONTEXT holds the whole image the overlay presents - peer
+    copies on its stream, no host merge - equal to the single context's, bit for bit."""
+    case = case_of(case_name)
+    s = case.settings
+    m = MultiEngine([0] * bands)
+    m.upload_noise(); m.upload_scene(case.scene)
+    w, h = case.camera.width, case.camera.height
+    m.resize(w, h, s.upscale.ratio())
+    view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
+    aa = F.FRAME_ANTIALIAS if case.antialias else 0
+    for k, n in enumerate(case.frames):
+        m.frame_render(hk.frame_uniform(s, n), view, pview, case.lights, s.to_c(), aa | F.FRAME_GATHER | (F.FRAME_BALANCE_BANDS if balanced and k == 0 else 0))
+    m.wait()
+    final = F.api().final_buffer(s.to_c(), aa)
+    ref = hk.HikariPlugin(device=0)
+    run_case(ref, case)
+    got, want = m.contexts[0].read(final), ref.engine.read(final)
+    assert got.shape == want.shape and (got.view(np.uint8) == want.view(np.uint8)).all(), f"{case_name} x{bands}: band 0 does not hold the gathered image"
+    # every frame gathered: the bands' own state must not have been disturbed (the union still equals the single context)
+    assert (m.read(F.BUF_TONE_MAPPED).view(np.uint8) == ref.engine.read(F.BUF_TONE_MAPPED).view(np.uint8)).all()
+
+
 def test_multi_engine_history_rows_under_camera_motion():
     """Exchange C inside the library: with the camera moving vertically, reprojection crosses the band borders; with the
     history halo the union stays within the north star's 1e-3 of the single-context frame, without it it does not."""

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (workload definitions)
 import bevy_hikari_amd as hk  # noqa: E402
 from bevy_hikari_amd import _ffi as F  # noqa: E402
-from bevy_hikari_amd.distributed import band_schedule  # noqa: E402
+from bevy_hikari_amd.distributed import band_gather_schedule, band_schedule  # noqa: E402
 
 # assumptions of the prediction (xGMI is point-to-point: a neighbour exchange uses ONE link per direction)
 LINK_GBS = 50.0      # effective one-direction rate of one xGMI link for MB-sized ncclSend/Recv (7 links x ~153 GB/s bidirectional per GPU)
@@ -32,7 +32,7 @@ def main():
     args = ap.parse_args()
     out = {"assumptions": {"link_gbs_one_direction": LINK_GBS, "exchange_fixed_us": EXCHANGE_US,
                            "method": "every band rendered alone on one MI355X (hk_set_band), wall clock over K frames after a full-frame warm-up; "
-                                     "predicted N-GPU frame = max over bands + sum over the frame's exchanges of (fixed + max over ranks of received bytes / link rate)"},
+                                     "predicted N-GPU frame = max over bands + sum over the frame's exchanges (two halo exchanges + the gather of the tone-mapped image on rank 0) of (fixed + largest transfer of a rank / link rate)"},
            "configs": {}}
     for config in args.configs:
         scene, camera, settings, lights, description = bench.workload(hk, config, None, None, None)
@@ -78,12 +78,16 @@ def main():
                     ex.append(sum(t.bytes for t in band_schedule(W, H, 1.0, b, bands, stage, n, sc, bounds) if t.is_recv) if bands > 1 else 0)
                 recv.append(ex)
             exch_ms = 0.0
+            gather_bytes = 0
             if bands > 1:
                 for k in range(2):
                     worst = max(r[k] for r in recv)
                     if worst:
                         exch_ms += EXCHANGE_US * 1e-3 + worst / (LINK_GBS * 1e9) * 1e3
-            rows[f"{bands}_balanced" if balanced else bands] = {"bounds": bounds, "band_ms": [round(x, 4) for x in per_band], "max_band_ms": round(max(per_band), 4), "halo_bytes_received_per_band": recv,
+                # rank 0 collects the tone-mapped rows of the others, one link per sender in parallel
+                gather_bytes = max(t.bytes for b in range(1, bands) for t in band_gather_schedule(W, H, 1.0, settings.upscale.kind, b, bands, 0, F.BUF_TONE_MAPPED, bounds))
+                exch_ms += EXCHANGE_US * 1e-3 + gather_bytes / (LINK_GBS * 1e9) * 1e3
+            rows[f"{bands}_balanced" if balanced else bands] = {"bounds": bounds, "band_ms": [round(x, 4) for x in per_band], "max_band_ms": round(max(per_band), 4), "halo_bytes_received_per_band": recv, "gather_bytes_largest_band": gather_bytes,
                            "exchange_ms_predicted": round(exch_ms, 4), "frame_ms_predicted": round(max(per_band) + exch_ms, 4)}
         t1 = rows[1]["frame_ms_predicted"]
         for key in rows:
