@@ -2136,7 +2136,8 @@ int hk_balance_bands(hk_ctx* c, uint32_t min_rows, uint32_t* bounds_out, uint32_
     if ((rc = hk_pass_run(c, HK_PASS_PREPASS, 0, 0, 0))) return rc;
     std::vector<uint32_t> cost((size_t)c->H);
     if ((rc = hk_row_costs(c, cost.data(), (uint32_t)c->H))) return rc;
-    if ((rc = hk_balanced_band_bounds(cost.data(), (uint32_t)c->H, (uint32_t)c->W, (uint32_t)c->RH, c->band_count, min_rows ? min_rows : 8u,
+    if ((rc = hk_balanced_band_bounds(cost.data(), (uint32_t)c->H, (uint32_t)c->W, (uint32_t)c->RH, c->band_count,
+                                      std::max(1u, std::min(min_rows ? min_rows : 8u, (uint32_t)c->RH / c->band_count)) /* (a short frame: what fits) */,
                                       (size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES ? 1.0f / 16.0f : 0.25f, bounds.data()))) return rc;
     if ((rc = hk_set_band_bounds(c, bounds.data(), c->band_count + 1))) return rc;
   } else {

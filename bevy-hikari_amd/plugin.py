@@ -553,7 +553,7 @@ class Engine:
             return [0, rh]
         self.pass_run(F.PASS_PREPASS)
         w, _h, _b = self.buffer_info(F.BUF_POSITION)
-        bounds = balanced_band_bounds(self.row_costs(), w, rh, n - 1, min_rows or 8, 0.25)   # (the CPU test scenes are LDS-sized)
+        bounds = balanced_band_bounds(self.row_costs(), w, rh, n - 1, max(1, min(min_rows or 8, rh // (n - 1))), 0.25)   # (the CPU test scenes are LDS-sized)
         self.set_band_bounds(bounds)
         return bounds
 

@@ -572,7 +572,7 @@ int hk_band_rows(uint32_t height, uint32_t band_index, uint32_t band_count, uint
  *                          (hk_row_costs: the full-size height).  hk_balance_bands uses 1/4 for scenes walked from LDS (cheap
  *                          geometry pixels: the Cornell box) and 1/16 beyond (profiles/r03_band_balance_probe.json).
  *   hk_balance_bands       the three steps in one call, after hk_frame_begin: full-frame primary rays, count, split, set on this
- *                          context (min_rows 0 = 8); bounds_out (optional) receives the split.  Deterministic across ranks. */
+ *                          context (min_rows 0 = 8, never more than rows / bands); bounds_out (optional) receives the split.  Deterministic across ranks. */
 int hk_set_band_bounds(hk_ctx* ctx, const uint32_t* bounds, uint32_t n_bounds /* band_count + 1 */);
 int hk_get_band(hk_ctx* ctx, uint32_t* band_index, uint32_t* band_count); /* what hk_set_band set (either pointer may be NULL) */
 int hk_get_band_bounds(hk_ctx* ctx, uint32_t* bounds, uint32_t n_bounds /* band_count + 1 */); /* the split in force (explicit or equal) */

@@ -251,7 +251,7 @@ def test_antialias_bands_equal_single_rank(tmp_path, world, case_name):
 
 
 @pytest.mark.parametrize("world,case_name,split", [(3, "cornell_b2", None), (2, "cornell_aa_default", None), (3, "cornell_aa_fsr", "uneven"), (4, "yard_aa_smaa2x", "balanced"),
-                                                   (2, "yard_aa_fsr_notaa", None)])
+                                                   (2, "yard_aa_fsr_notaa", None), (8, "cornell_b2", None), (8, "cornell_aa_default", "balanced")])
 def test_rank_0_gathers_the_final_image(tmp_path, world, case_name, split):
     """SURVEY 8e step 7 over the host transport: after the last frame rank 0 collects every band's rows of the image the overlay
     presents (tone-mapped; with the anti-aliasing tail the TAA / SMAA Tu4x / sharpened FSR1 output, whose rows are cut where the
