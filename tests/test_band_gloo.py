@@ -55,8 +55,12 @@ def _worker(rank, world, port, case_name, out_dir, transport=None, split=None, g
         r = BandRenderer(e, rank, world, backend_device="cpu", transport=transport)
     _, rh, _ = e.buffer_info(F.BUF_TONE_MAPPED)
     if split == "uneven":   # explicit boundaries (hk_set_band_bounds): thin first band, fat last one
-        fractions = np.array([0.0, 0.11, 0.37, 0.52, 1.0])[[0, 1, 2, 4] if world == 3 else [0, 2, 4]]
-        r.set_bounds([int(round(f * rh)) for f in fractions])
+        if world <= 3:
+            fractions = np.array([0.0, 0.11, 0.37, 0.52, 1.0])[[0, 1, 2, 4] if world == 3 else [0, 2, 4]]
+            r.set_bounds([int(round(f * rh)) for f in fractions])
+        else:   # many thin bands: the 20-row halos span several of them
+            cuts = np.random.default_rng(world).choice(np.arange(1, rh), size=world - 1, replace=False)
+            r.set_bounds([0] + sorted(int(c) for c in cuts) + [rh])
     view, pview = case.camera.view_uniform(), case.camera.previous_view_uniform()
     for k, n in enumerate(case.frames):
         r.render(hk.frame_uniform(s, n), view, pview, case.lights, s, w, h, balance=(split == "balanced" and k == 0),
@@ -86,7 +90,8 @@ def _worker(rank, world, port, case_name, out_dir, transport=None, split=None, g
 
 @pytest.mark.parametrize("world,case_name,transport,split", [(2, "cornell_b2", None, None), (3, "yard_sun", None, None), (2, "cornell_b2", "rccl", None),
                                                              (3, "cornell_b2", None, "uneven"), (2, "yard_sun", None, "uneven"),
-                                                             (3, "yard_sun", None, "balanced"), (2, "cornell_upscale2", None, "balanced")])
+                                                             (3, "yard_sun", None, "balanced"), (2, "cornell_upscale2", None, "balanced"),
+                                                             (8, "cornell_b2", None, None), (6, "yard_sun", None, "balanced"), (7, "cornell_b2", None, "uneven")])
 def test_bands_equal_single_rank(tmp_path, world, case_name, transport, split):
     """split: bands of unequal height - explicit boundaries, or the cost-balanced split every rank derives on the first frame.
     transport "rccl" where RCCL cannot come up (here: the oracle has no communicator): the ranks agree BEFORE anyone enters
