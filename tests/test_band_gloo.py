@@ -231,7 +231,8 @@ def _aa_worker(rank, world, port, case_name, out_dir):
 
 
 @pytest.mark.parametrize("world,case_name", [(2, "cornell_aa_default"), (3, "yard_aa_smaa2x"), (2, "cornell_aa_fsr"), (3, "yard_aa_fsr_notaa"), (2, "random3"), (3, "random7"), (4, "random12"),
-                                              (3, "random21"), (2, "random30"), (4, "random35"), (3, "random22"), (4, "random33"), (2, "random46"), (3, "random5")])
+                                              (3, "random21"), (2, "random30"), (4, "random35"), (3, "random22"), (4, "random33"), (2, "random46"), (3, "random5"),
+                                              (8, "cornell_aa_default"), (6, "cornell_aa_fsr"), (7, "yard_aa_smaa2x"), (8, "yard_aa_fsr_notaa")])
 def test_antialias_bands_equal_single_rank(tmp_path, world, case_name):
     """All five stages on bands - for the named cases SMAA Tu4x + TAA (exchange D) or TAA + FSR1 (exchange E), for the random ones whatever the
     seeded settings say (aprons depend on them: emissive spatial reuse, denoise off, ratio != 1, 0 bounces ...): the
