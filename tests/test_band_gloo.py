@@ -158,7 +158,8 @@ def _motion_worker(rank, world, port, history_rows, out_dir):
     dist.destroy_process_group()
 
 
-def test_history_halo_for_a_moving_camera(tmp_path):
+@pytest.mark.parametrize("world", [2, 5])
+def test_history_halo_for_a_moving_camera(tmp_path, world):
     """Exchange C (HK_STAGE_TEMPORAL_WITH_HISTORY): with the camera moving, reprojection crosses the band border.
     Without the history halo a band reads its own stale copy of the neighbour's rows; with it the union of the bands
     is within the north-star tolerance of the single-rank frame (not bit-equal: the reference's scatter-store into
@@ -176,15 +177,18 @@ def test_history_halo_for_a_moving_camera(tmp_path):
     for rows in (0, 12):
         out = tmp_path / f"rows{rows}"
         out.mkdir()
-        mp.spawn(_motion_worker, args=(2, _free_port(), rows, str(out)), nprocs=2, join=True)
+        mp.spawn(_motion_worker, args=(world, _free_port(), rows, str(out)), nprocs=world, join=True)
         got = np.zeros_like(want)
-        for rank in range(2):
+        for rank in range(world):
             d = np.load(out / f"rank{rank}.npz")
             for i in range(3):
                 got[i, int(d["b0"]):int(d["b1"])] = d[f"d{i}"].view(np.float16).astype(np.float32)
         err[rows] = float(np.linalg.norm(got - want) / np.linalg.norm(want))
-    assert err[12] <= 1e-3, err
-    assert err[12] < err[0], err
+    # world 5 on a 64-row image: a border every 13 rows and a 12-row halo that spans whole neighbours.  What remains is the documented
+    # deviation (a band's scatter-stores into previous_spatial that land in a neighbour's rows stay local), which grows
+    # with the borders per image row: 4 borders on 64 rows here against 7 on 1080 in the 8-GPU frame.
+    assert err[12] <= (1e-3 if world == 2 else 6e-3), err
+    assert err[12] < 0.5 * err[0], err
 
 
 def _aa_worker(rank, world, port, case_name, out_dir):
