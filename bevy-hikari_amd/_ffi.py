@@ -24,7 +24,9 @@ BUF_POSITION, BUF_NORMAL, BUF_DEPTH_GRADIENT, BUF_INSTANCE_MATERIAL, BUF_VELOCIT
 BUF_VARIANCE0, BUF_RENDER0, BUF_RESERVOIR0 = 6, 9, 12
 BUF_DENOISE_INTERNAL0, BUF_DENOISE_INTERNAL_VARIANCE, BUF_DENOISE_RENDER0, BUF_TONE_MAPPED = 22, 26, 27, 30
 (BUF_PREVIOUS_POSITION, BUF_PREVIOUS_VELOCITY_UV, BUF_PREVIOUS_TONE_MAPPED, BUF_UPSCALE_OUTPUT, BUF_TAA_OUTPUT, BUF_PREVIOUS_TAA_OUTPUT,
- BUF_UPSCALE_SHARPENED, BUF_COUNT) = range(31, 39)
+ BUF_UPSCALE_SHARPENED) = range(31, 38)
+BUF_PARKED_TO0, BUF_PARKED_RECORD0, BUF_COUNT = 38, 41, 44   # parked scatter stores, + channel (allocated on first use)
+HISTORY_AUTO = 0xFFFF
 # HkPass
 (PASS_PREPASS, PASS_FULL_SCREEN_ALBEDO, PASS_DIRECT_LIT, PASS_DIRECT_EMISSIVE, PASS_INDIRECT, PASS_EMISSIVE_SPATIAL_REUSE,
  PASS_INDIRECT_SPATIAL_REUSE, PASS_DEMODULATION, PASS_DENOISE_L0, PASS_DENOISE_L1, PASS_DENOISE_L2, PASS_DENOISE_L3,
@@ -136,6 +138,10 @@ class HkTransfer(C.Structure):
     _fields_ = [("buffer", u32), ("peer", u32), ("is_recv", u32), ("_pad", u32), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
 
 
+class HkMovedBox(C.Structure):
+    _fields_ = [("min", f32 * 3), ("_pad0", f32), ("max", f32 * 3), ("_pad1", f32), ("previous_from_current", f32 * 16)]
+
+
 class HkStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
@@ -174,6 +180,9 @@ _SIGNATURES = {
     "frame_render": [_vp, P(HkFrame), P(HkView), P(HkPreviousView), P(HkLights), P(HkSettings), u32],
     "frame_wait": [_vp],
     "set_band": [_vp, u32, u32],
+    "set_history_rows": [_vp, u32],
+    "history_rows": [_vp, P(u32)],
+    "scene_bounds": [_vp, P(f32), P(f32)],
     "set_band_bounds": [_vp, P(u32), u32],
     "row_costs": [_vp, P(u32), u32],
     "buffer_info": [_vp, u32, P(u32), P(u32), P(u32)],
@@ -241,6 +250,7 @@ _PRODUCT_ONLY = {
     "comm_init": [_vp, u32, u32, P(C.c_uint8)],
     "comm_destroy": [_vp],
     "comm_set_history_rows": [_vp, u32],
+    "history_rows_bound": [P(HkView), P(HkPreviousView), u32, P(f32), P(f32), P(HkMovedBox), u32, P(u32)],
     "comm_exchange": [_vp, u32, P(HkSettings)],
     "multi_create": [u32, P(C.c_int), u32, P(_vp)],
     "multi_context": [_vp, u32, P(_vp)],

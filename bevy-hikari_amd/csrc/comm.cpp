@@ -228,7 +228,6 @@ struct hk_multi {
   std::vector<int> device;
   std::vector<hipEvent_t> produced, copied;  // per context: "my stage is enqueued up to here" / "my incoming copies are enqueued up to here"
   std::deque<Comm::Cached> cache;
-  uint32_t history_rows = 0;
   uint64_t exchanges = 0, bytes_copied = 0;
   MultiPool* pool = nullptr;  // one enqueue thread per band (hk_multi_frame_render), created on first use
 };
@@ -245,7 +244,7 @@ struct MultiJob {
   const HkPreviousView* pv = nullptr;
   const HkLights* l = nullptr;
   const HkSettings* st = nullptr;
-  uint32_t flags = 0, hist = 0;
+  uint32_t flags = 0;
 };
 struct MultiPool {
   std::vector<std::thread> threads;
@@ -394,6 +393,9 @@ int band_frame(hk_multi* m, uint32_t i, const MultiJob& j) {
   MultiPool* P = m->pool;
   if (hipSetDevice(m->device[i]) != hipSuccess) { set_error("hipSetDevice(%d) failed", m->device[i]); P->failed.store(1); return HK_E_HIP; }
   int rc = hk_frame_begin(c, j.f, j.v, j.pv, j.l);
+  uint32_t hist = 0;  // the frame's history halo: every band derives the same count from the same uniforms (a failed band leaves 0,
+  if (!rc) rc = hk_history_rows(c, &hist);  // and the others through the barrier's `failed`)
+  hist <<= 8;
   auto step = [&](uint32_t s, bool exchange, uint32_t stage_arg) {
     if (exchange) {
       if (rc) P->failed.store(1, std::memory_order_release);
@@ -403,9 +405,9 @@ int band_frame(hk_multi* m, uint32_t i, const MultiJob& j) {
     if (!rc) rc = hk_frame_stage(c, s, j.st, j.flags);
     if (rc) P->failed.store(1, std::memory_order_release);
   };
-  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) step(s, s != HK_STAGE_TEMPORAL || j.hist, s == HK_STAGE_TEMPORAL ? (s | j.hist) : s);
+  for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) step(s, s != HK_STAGE_TEMPORAL || hist, s <= HK_STAGE_SPATIAL ? (s | hist) : s);
   if (j.flags & HK_FRAME_ANTIALIAS) {
-    step(HK_STAGE_ANTIALIAS, true, HK_STAGE_ANTIALIAS | j.hist);
+    step(HK_STAGE_ANTIALIAS, true, HK_STAGE_ANTIALIAS | hist);
     step(HK_STAGE_UPSCALE, j.st->upscale_kind == HK_UPSCALE_FSR1, HK_STAGE_UPSCALE);
   }
   return rc;
@@ -526,11 +528,7 @@ int hk_comm_destroy(hk_ctx* c) {
   return rc;
 }
 
-int hk_comm_set_history_rows(hk_ctx* c, uint32_t rows) {
-  HK_REQUIRE(c && rows < (1u << 16), HK_E_INVALID, "bad argument");
-  *ctx_history_rows(c) = rows;
-  return HK_OK;
-}
+int hk_comm_set_history_rows(hk_ctx* c, uint32_t rows) { return hk_set_history_rows(c, rows); }  // (the ABI 6 name)
 
 int hk_comm_exchange(hk_ctx* c, uint32_t stage, const HkSettings* st) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
@@ -699,9 +697,13 @@ int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* m
   return HK_OK;
 }
 
+// a count, or HK_HISTORY_AUTO (the default): every band's context derives the same halo from the frame's uniforms (hk_frame_begin)
 int hk_multi_set_history_rows(hk_multi* m, uint32_t rows) {
-  HK_REQUIRE(m && rows < (1u << 16), HK_E_INVALID, "bad argument");
-  m->history_rows = rows;
+  HK_REQUIRE(m && rows <= HK_HISTORY_AUTO, HK_E_INVALID, "bad argument");
+  for (hk_ctx* c : m->ctx) {
+    const int rc = hk_set_history_rows(c, rows);
+    if (rc) return rc;
+  }
   return HK_OK;
 }
 
@@ -715,7 +717,6 @@ int hk_multi_frame_render(hk_multi* m, const HkFrame* f, const HkView* v, const 
 static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   int rc;
   {
-    const uint32_t hist = m->history_rows << 8;
     // every band's enqueue work on its own thread (the frame that re-splits the bands sets state on every context: serial)
     static const bool serial_env = getenv("HK_MULTI_SERIAL") != nullptr;
     if (m->ctx.size() > 1 && !serial_env && !(flags & HK_FRAME_BALANCE_BANDS)) {
@@ -724,7 +725,7 @@ static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView*
       HK_REQUIRE(P->threads.size() == m->ctx.size(), HK_E_NOMEM, "the enqueue threads did not start");
       {
         std::unique_lock<std::mutex> lk(P->mu);
-        P->job = MultiJob{f, v, pv, l, st, flags, hist};
+        P->job = MultiJob{f, v, pv, l, st, flags};
         P->done = 0;
         P->failed.store(0);
         P->arrived.store(0);  // (a failed frame leaves its barriers half-entered; every thread is idle here)
@@ -755,7 +756,9 @@ static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView*
     if ((rc = hk_balance_bands(m->ctx[0], 0, bounds.data(), (uint32_t)bounds.size()))) return rc;
     if ((rc = hk_multi_set_band_bounds(m, bounds.data(), (uint32_t)bounds.size()))) return rc;
   }
-  const uint32_t hist = m->history_rows << 8;
+  uint32_t hist = 0;
+  if ((rc = hk_history_rows(m->ctx[0], &hist))) return rc;  // (the same on every band: derived from the same uniforms)
+  hist <<= 8;
   auto stage = [&](uint32_t s) {
     for (hk_ctx* c : m->ctx) {
       const int r = hk_frame_stage(c, s, st, flags);
@@ -764,7 +767,7 @@ static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView*
     return (int)HK_OK;
   };
   for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) {
-    if ((s != HK_STAGE_TEMPORAL || hist) && (rc = multi_exchange(m, s == HK_STAGE_TEMPORAL ? (s | hist) : s, st))) return rc;
+    if ((s != HK_STAGE_TEMPORAL || hist) && (rc = multi_exchange(m, s <= HK_STAGE_SPATIAL ? (s | hist) : s, st))) return rc;
     if ((rc = stage(s))) return rc;
   }
   if (flags & HK_FRAME_ANTIALIAS) {

@@ -224,11 +224,10 @@ struct hk_ctx {
   uint64_t async_instance_uploads = 0;
   size_t st_nodes = 0, st_v0 = 0, st_v1 = 0, st_v2 = 0, st_vn = 0, st_vuv = 0;  // offsets inside the mesh-level region
   uint64_t static_rebuilds = 0, dynamic_rebuilds = 0;
-  // HK_CTX_DETERMINISTIC_SCATTER: parked previous_spatial stores; set 0 serves the two direct-light dispatches (in order
-  // on one stream), set 1 indirect_lit_ambient, which may run beside them
-  int* det_winner[2] = {nullptr, nullptr};
-  int* det_to[2] = {nullptr, nullptr};
-  void* det_pending[2] = {nullptr, nullptr};
+  // Parked previous_spatial stores (HK_CTX_DETERMINISTIC_SCATTER; every band of a sharded frame with a history halo: SURVEY 8e
+  // step 6), one set per light channel.  `to` and the records are the HK_BUF_PARKED_* planes (c->buf: bands exchange their rows),
+  // the winners are private.  Allocated on first use (ensure_parked).
+  int* det_winner[3] = {nullptr, nullptr, nullptr};
   // uniform-tile store elision (hk_kernels.hpp TileMeta): one record per 8x8 tile per reservoir buffer; tile_meta_zero[k] = the
   // device array of buffer k is known to be all zero ("contents unknown" everywhere)
   TileMeta* tile_meta[10] = {};
@@ -293,7 +292,8 @@ struct hk_ctx {
   std::vector<uint32_t> band_bounds;   // explicit split of the scaled render rows (hk_set_band_bounds): band_count + 1 entries, or empty = equal split
   uint32_t bounds_generation = 0;
   void* comm = nullptr;        // RCCL communicator state, owned by comm.cpp (hk_comm_init)
-  uint32_t history_rows = 0;   // exchange C rows (hk_comm_set_history_rows)
+  uint32_t history_rows = HK_HISTORY_AUTO;  // exchange C rows asked for (hk_set_history_rows): a count, or derived per frame
+  uint32_t history_now = 0;    // ... in force for the frame most recently begun (0 for a single band)
 
   // statistics
   unsigned long long* d_counters = nullptr;  // primary, tlas, blas
@@ -339,12 +339,9 @@ bool certify_uv_division(int size) {
 }
 
 int free_screen(hk_ctx* c) {
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < 3; ++k) {
     if (c->det_winner[k]) (void)hipFree(c->det_winner[k]);
-    if (c->det_to[k]) (void)hipFree(c->det_to[k]);
-    if (c->det_pending[k]) (void)hipFree(c->det_pending[k]);
-    c->det_winner[k] = c->det_to[k] = nullptr;
-    c->det_pending[k] = nullptr;
+    c->det_winner[k] = nullptr;
   }
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
     if (c->buf[b]) (void)hipFree(c->buf[b]);
@@ -1081,6 +1078,61 @@ GBuffer make_gbuffer(const hk_ctx* c) {
   g.albedo_out = nullptr;
   return g;
 }
+// A band of a sharded frame whose history halo is not empty parks the scatter stores of its temporal dispatches instead of
+// racing them into its local copy of previous_spatial: the neighbours need them (and this band theirs) before spatial_reuse
+bool parks_across_bands(const hk_ctx* c) { return c->band_count > 1 && c->history_now > 0; }
+// the parked planes, on first use (3 x 72 B per render pixel)
+int ensure_parked(hk_ctx* c) {
+  if (c->det_winner[0]) return HK_OK;
+  const size_t nr = (size_t)c->RW * c->RH;
+  for (int k = 0; k < 3; ++k) {
+    HK_HIP(hipMalloc((void**)&c->det_winner[k], nr * sizeof(int)));
+    for (uint32_t b : {(uint32_t)HK_BUF_PARKED_TO0 + k, (uint32_t)HK_BUF_PARKED_RECORD0 + k}) {
+      const size_t bytes = nr * buffer_bpp(b);
+      HK_HIP(hipMalloc(&c->buf[b], bytes));
+      HK_HIP(hipMemsetAsync(c->buf[b], b < HK_BUF_PARKED_RECORD0 ? 0xFF : 0, bytes, c->stream));  // nothing parked
+      c->buf_bytes[b] = bytes;
+    }
+  }
+  return HK_OK;
+}
+// world bounds of the scene = the union of the instances' boxes (the host mirrors follow device refits: refit_impl)
+void scene_bounds(const hk_ctx* c, float mn[3], float mx[3]) {
+  for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+  for (const HkInstance& in : c->instances)
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = std::min(mn[k], in.min[k]);
+      mx[k] = std::max(mx[k], in.max[k]);
+    }
+}
+// hk_history_rows_bound on this context's frame: the view pair, the scene's bounds and every instance whose previous model differs
+int derive_history_rows(const hk_ctx* c, uint32_t* rows) {
+  *rows = 0;
+  if (c->instances.empty()) return HK_OK;
+  std::vector<HkMovedBox> moved;
+  const size_t ni = c->instances.size();
+  if (c->prev_models.size() == 16 * ni)
+    for (size_t i = 0; i < ni; ++i) {
+      const HkInstance& in = c->instances[i];
+      const float* pm = &c->prev_models[16 * i];
+      if (memcmp(pm, in.model, 64) == 0) continue;
+      HkMovedBox b{};
+      memcpy(b.min, in.min, 12);
+      memcpy(b.max, in.max, 12);
+      // previous_model x model^-1; model^-1 = transpose(inverse_transpose_model); column-major: out[col][row]
+      for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row) {
+          double s = 0.0;
+          for (int k = 0; k < 4; ++k) s += (double)pm[4 * k + row] * (double)in.inverse_transpose_model[4 * k + col];  // inv[k][col] = itm[col][k] -> itm column k, row col
+          b.previous_from_current[4 * col + row] = (float)s;
+        }
+      moved.push_back(b);
+    }
+  if (moved.empty() && memcmp(c->view.view_proj, c->pview.view_proj, 64) == 0) return HK_OK;
+  float mn[3], mx[3];
+  scene_bounds(c, mn, mx);
+  return hk_history_rows_bound(&c->view, &c->pview, (uint32_t)c->RH, mn, mx, moved.empty() ? nullptr : moved.data(), (uint32_t)moved.size(), rows);
+}
 // group 6 ping-pong, light.rs:376,480-481,518-546
 LightTargets make_light_targets(const hk_ctx* c, int channel) {
   static const int T[3] = {0, 2, 6}, S[3] = {4, 4, 8};
@@ -1092,10 +1144,11 @@ LightTargets make_light_targets(const hk_ctx* c, int channel) {
   t.spatial = (PackedReservoir*)c->buf[HK_BUF_RESERVOIR0 + prev + S[channel]];
   t.variance = (float*)c->buf[HK_BUF_VARIANCE0 + channel];
   t.render = (uint2*)c->buf[HK_BUF_RENDER0 + channel];
-  const int set = channel == 2 ? 1 : 0;
-  t.det_winner = c->det_winner[set];
-  t.det_to = c->det_to[set];
-  t.det_pending = (PackedReservoir*)c->det_pending[set];
+  // parked scatter stores: the verification mode, and a band of a sharded frame with a history halo
+  const bool parked = c->det_winner[channel] && ((c->flags & HK_CTX_DETERMINISTIC_SCATTER) || parks_across_bands(c));
+  t.det_winner = parked ? c->det_winner[channel] : nullptr;
+  t.det_to = parked ? (int*)c->buf[HK_BUF_PARKED_TO0 + channel] : nullptr;
+  t.det_pending = parked ? (PackedReservoir*)c->buf[HK_BUF_PARKED_RECORD0 + channel] : nullptr;
   t.m_current = t.m_spatial = t.m_previous_spatial = nullptr;
   t.serial = 0;
   t.tiles_x = c->tiles_x;
@@ -1298,12 +1351,15 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     case HK_PASS_DIRECT_EMISSIVE:
     case HK_PASS_INDIRECT: {
       const int channel = pass == HK_PASS_DIRECT_LIT ? 0 : (pass == HK_PASS_DIRECT_EMISSIVE ? 1 : 2);
+      const bool across = parks_across_bands(c);
+      if (across || (c->flags & HK_CTX_DETERMINISTIC_SCATTER)) { const int rc_ = ensure_parked(c); if (rc_) return rc_; }
       LightTargets t = make_light_targets(c, channel);
       { const int rc_ = attach_tile_meta(c, t, channel, false, y0, y1); if (rc_) return rc_; }
       const size_t px = (size_t)c->RW * c->RH;
-      if (t.det_winner) {  // nothing parked, no winner: -1 everywhere
+      if (t.det_winner) {  // nothing parked, no winner: -1 everywhere (a band: in the rows it dispatches - the others arrive with exchange A)
         HK_HIP(hipMemsetAsync(t.det_winner, 0xFF, px * sizeof(int), c->stream));
-        HK_HIP(hipMemsetAsync(t.det_to, 0xFF, px * sizeof(int), c->stream));
+        if (across) HK_HIP(hipMemsetAsync(t.det_to + (size_t)y0 * c->RW, 0xFF, (size_t)(y1 - y0) * c->RW * sizeof(int), c->stream));
+        else HK_HIP(hipMemsetAsync(t.det_to, 0xFF, px * sizeof(int), c->stream));
       }
       if (pass == HK_PASS_INDIRECT && use_wavefront(c)) {
         { const int rc_ = ensure_wavefront(c); if (rc_) return rc_; }
@@ -1314,7 +1370,8 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
                         timer.on ? timer.t.stop : nullptr);
       else
         launch_direct(c->stream, pass == HK_PASS_DIRECT_EMISSIVE, c->scene, fr, g, t, y0, y1, counters);
-      if (t.det_winner) launch_resolve_scatter(c->stream, t, (int)px);
+      // (a band with a history halo resolves at the start of stage SPATIAL, once the neighbours' parked rows are in)
+      if (t.det_winner && !across) launch_resolve_scatter(c->stream, t, 0, (int)px, 0, 0);
       break;
     }
     case HK_PASS_EMISSIVE_SPATIAL_REUSE:
@@ -1427,7 +1484,6 @@ void* ctx_buffer(hk_ctx* c, uint32_t b, size_t* logical_bytes) {
   return c->buf[b];
 }
 void** ctx_comm_slot(hk_ctx* c) { return &c->comm; }
-uint32_t* ctx_history_rows(hk_ctx* c) { return &c->history_rows; }
 int ctx_join_side(hk_ctx* c) { return join_all(c); }
 }  // namespace hk
 
@@ -1958,7 +2014,7 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     c->UH = (int)ceilf((float)height * scale2);
     c->mapped_parity = 0;
   }
-  for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
+  for (uint32_t b = 0; b < HK_BUF_PARKED_TO0; ++b) {  // (the parked-store planes beyond: on first use, ensure_parked)
     size_t n = buffer_is_full_size(b) ? (size_t)c->W * c->H : (buffer_is_upscaled(b) ? (size_t)c->UW * c->UH : (size_t)c->RW * c->RH);
     size_t bytes = n * buffer_bpp(b);
     HK_HIP(hipMalloc(&c->buf[b], bytes));
@@ -1966,12 +2022,7 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     c->buf_bytes[b] = bytes;
   }
   const size_t nf = (size_t)c->W * c->H, nr = (size_t)c->RW * c->RH;
-  if (c->flags & HK_CTX_DETERMINISTIC_SCATTER)
-    for (int k = 0; k < 2; ++k) {
-      HK_HIP(hipMalloc((void**)&c->det_winner[k], nr * sizeof(int)));
-      HK_HIP(hipMalloc((void**)&c->det_to[k], nr * sizeof(int)));
-      HK_HIP(hipMalloc(&c->det_pending[k], nr * 64));
-    }
+  if (c->flags & HK_CTX_DETERMINISTIC_SCATTER) { const int rc_ = ensure_parked(c); if (rc_) return rc_; }
   if (!(c->flags & HK_CTX_DETERMINISTIC_SCATTER)) {  // (the verification mode parks its scatter stores: no elision there)
     c->tiles_x = (c->RW + 7) / 8;
     c->tiles_y = (c->RH + 7) / 8;
@@ -2041,6 +2092,34 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
     }
     c->mapped_parity = f->number & 1u;
   }
+  // the history halo of this frame: a count the host set, or the bound every rank derives from the same uniforms
+  c->history_now = 0;
+  if (c->band_count > 1 && c->RH > 0) {
+    if (c->history_rows != HK_HISTORY_AUTO) {
+      c->history_now = std::min(c->history_rows, (uint32_t)c->RH);
+    } else {
+      const int rc = derive_history_rows(c, &c->history_now);
+      if (rc) return rc;
+    }
+    if (parks_across_bands(c)) { const int rc = ensure_parked(c); if (rc) return rc; }
+  }
+  return HK_OK;
+}
+
+int hk_set_history_rows(hk_ctx* c, uint32_t rows) {
+  HK_REQUIRE(c && rows <= HK_HISTORY_AUTO, HK_E_INVALID, "bad argument");
+  c->history_rows = rows;
+  return HK_OK;
+}
+int hk_history_rows(hk_ctx* c, uint32_t* rows) {
+  HK_REQUIRE(c && rows, HK_E_INVALID, "bad argument");
+  *rows = c->history_now;
+  return HK_OK;
+}
+int hk_scene_bounds(hk_ctx* c, float mn[3], float mx[3]) {
+  HK_REQUIRE(c && mn && mx, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(c->have_instances, HK_E_NOT_READY, "no scene uploaded");
+  scene_bounds(c, mn, mx);
   return HK_OK;
 }
 
@@ -2230,6 +2309,23 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
     }
   } else if (stage == HK_STAGE_SPATIAL) {            // light.rs:689-697
+    if (parks_across_bands(c) && c->det_winner[0]) {
+      // exchange A delivered the parked stores of the pixels up to 2 x history rows outside the band.  Per
+      // channel, in dispatch order (sun and emissive store into the same buffer): the foreign pixels join the winners their
+      // slots have so far, then every parked store that is its slot's winner is applied - own rows and foreign rows alike.
+      // A channel whose spatial pass is off has no reader of its previous_spatial: its rows are not exchanged (hk_band_plan_for)
+      // and its stores are resolved among the band's own pixels, so that the buffer holds what a band can know.
+      const int reach = 2 * (int)c->history_now, r0 = clampr(b0 - reach), r1 = clampr(b1 + reach);
+      if ((rc = join_side(c))) return rc;  // (the direct-light dispatches parked on the side stream)
+      for (int channel = 0; channel < 3; ++channel) {
+        const bool exchanged = channel == 2 ? st->indirect_spatial_reuse != 0 : st->emissive_spatial_reuse != 0;
+        const LightTargets t = make_light_targets(c, channel);
+        if (!t.det_winner) continue;
+        if (exchanged) launch_resolve_scatter(c->stream, t, r0 * c->RW, r1 * c->RW, b0 * c->RW, b1 * c->RW);
+        else launch_resolve_scatter(c->stream, t, b0 * c->RW, b1 * c->RW, 0, 0);
+      }
+      HK_HIP(hipGetLastError());
+    }
     if (st->emissive_spatial_reuse) {
       if (c->forked) {
         if ((rc = run_pass_on_side(c, HK_PASS_EMISSIVE_SPATIAL_REUSE, 0, b0, b1))) return rc;
@@ -2324,9 +2420,9 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
   }
   // with a communicator attached (hk_comm_init) the halo exchanges of the band plan run here, on the context's stream
   const bool ex = c->comm != nullptr && c->band_count > 1;
-  const uint32_t hist = c->history_rows << 8;
+  const uint32_t hist = c->history_now << 8;
   for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) {
-    if (ex && (s != HK_STAGE_TEMPORAL || hist) && (rc = comm_exchange(c, s == HK_STAGE_TEMPORAL ? (s | hist) : s, st))) return rc;
+    if (ex && (s != HK_STAGE_TEMPORAL || hist) && (rc = comm_exchange(c, s <= HK_STAGE_SPATIAL ? (s | hist) : s, st))) return rc;
     if ((rc = hk_frame_stage(c, s, st, flags))) return rc;
   }
   if (flags & HK_FRAME_ANTIALIAS) {

@@ -80,7 +80,6 @@ int ctx_info(hk_ctx* c, CtxInfo* out);
 int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root);  // comm.cpp
 void* ctx_buffer(hk_ctx* c, uint32_t buffer, size_t* logical_bytes);
 void** ctx_comm_slot(hk_ctx* c);       // owned by comm.cpp (NULL = no communicator)
-uint32_t* ctx_history_rows(hk_ctx* c);
 int ctx_join_side(hk_ctx* c);          // main stream waits for the side stream
 // run before `stage` by hk_frame_render when a communicator is attached
 int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st);

@@ -287,6 +287,8 @@ void launch_smaa_tu4x_extrapolate(hipStream_t st, void* output, int out_w, int o
 void launch_taa_jasmine(hipStream_t st, const AaBuffers& b, float blend, const float clear_color[4], int y0, int y1);
 void launch_fsr_easu(hipStream_t st, const void* input, int in_w, int in_h, void* output, int out_w, int out_h, int y0, int y1);
 void launch_fsr_rcas(hipStream_t st, const void* input, void* output, int w, int h, float sharpness, int y0, int y1);
-void launch_resolve_scatter(hipStream_t st, const hkd::LightTargets& t, int pixels);
+// apply the parked scatter stores of pixels [p0, p1); [own0, own1) = the pixels this context dispatched itself (their winners are
+// in), empty = all of them
+void launch_resolve_scatter(hipStream_t st, const hkd::LightTargets& t, int p0, int p1, int own0, int own1);
 void launch_debug_math(hipStream_t st, uint32_t op, const float* x, const float* y, float* out, size_t n);
 }  // namespace hk

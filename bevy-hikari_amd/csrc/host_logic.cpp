@@ -39,6 +39,8 @@ uint32_t buffer_bpp(uint32_t b) {
   if (b == HK_BUF_TONE_MAPPED || b == HK_BUF_PREVIOUS_TONE_MAPPED) return 8;
   if (b == HK_BUF_PREVIOUS_POSITION || b == HK_BUF_PREVIOUS_VELOCITY_UV) return 16;
   if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT || b == HK_BUF_UPSCALE_SHARPENED) return 8;
+  if (b >= HK_BUF_PARKED_TO0 && b < HK_BUF_PARKED_TO0 + 3) return 4;
+  if (b >= HK_BUF_PARKED_RECORD0 && b < HK_BUF_PARKED_RECORD0 + 3) return 64;
   return 0;
 }
 bool buffer_is_full_size(uint32_t b) {
@@ -312,7 +314,8 @@ int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint3
 int hk_band_plan_bounds(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* bounds, uint32_t band_index, uint32_t band_count,
                         uint32_t stage_arg, uint32_t frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
   const uint32_t stage = stage_arg & 0xffu, history_rows = stage_arg >> 8;  // HK_STAGE_TEMPORAL_WITH_HISTORY
-  HK_REQUIRE(history_rows == 0 || stage == HK_STAGE_TEMPORAL || stage == HK_STAGE_ANTIALIAS, HK_E_INVALID, "history rows only apply to the temporal and antialias stages");
+  HK_REQUIRE(history_rows == 0 || stage == HK_STAGE_TEMPORAL || stage == HK_STAGE_SPATIAL || stage == HK_STAGE_ANTIALIAS, HK_E_INVALID,
+             "history rows only apply to the temporal, spatial and antialias stages");
   HK_REQUIRE(st && n_ops && band_count > 0 && band_index < band_count && stage < HK_STAGE_COUNT, HK_E_INVALID, "bad argument");
   uint32_t rw, rh;
   int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
@@ -327,7 +330,7 @@ int hk_band_plan_bounds(uint32_t width, uint32_t height, float upscale_ratio, co
   auto hi = [&](uint32_t a) { return std::min(rh, b1 + a); };
   // reservoir ping-pong, light.rs:376,480-481: the temporal dispatch writes buf[previous + T]
   const uint32_t previous = 1u - (frame_number % 2u);
-  if (stage == HK_STAGE_TEMPORAL && history_rows > 0 && st->temporal_reuse) {
+  if (stage == HK_STAGE_TEMPORAL && history_rows > 0) {  // (whatever temporal_reuse says: the dispatches load `previous` and store to previous_spatial regardless, light.wgsl:1091-1095)
     // exchange C: what frame n reads as history = what frame n-1 wrote.  light.rs:518-546: previous = buf[current + T],
     // previous_spatial = buf[current + S] with (T, S) = (0, 4) sun, (2, 4) emissive, (6, 8) indirect.
     const uint32_t current = frame_number % 2u;
@@ -345,6 +348,22 @@ int hk_band_plan_bounds(uint32_t width, uint32_t height, float upscale_ratio, co
     if (st->indirect_spatial_reuse) {
       uint32_t buf = HK_BUF_RESERVOIR0 + previous + 6;
       emit(bounds, buf, rw, rh, lo(20), hi(20), band_index, band_count, ops, &n, cap);
+    }
+    // SURVEY 8e step 6 (HK_STAGE_SPATIAL_WITH_HISTORY): the parked scatter stores of the temporal dispatches.  A slot this band's
+    // spatial pass reads lies at most history_rows rows outside it, and a pixel that stores to such a slot at most history_rows
+    // rows beyond the slot: 2 x history_rows rows of the parked planes per side.  Sun (0) and emissive (1) store into the same
+    // buffer (S = 4 for both, light.rs:518-546), which only the emissive spatial pass reads: both or neither.
+    if (history_rows > 0) {
+      const uint32_t reach = 2u * history_rows;
+      auto parked = [&](uint32_t channel) {
+        emit(bounds, HK_BUF_PARKED_TO0 + channel, rw, rh, lo(reach), hi(reach), band_index, band_count, ops, &n, cap);
+        emit(bounds, HK_BUF_PARKED_RECORD0 + channel, rw, rh, lo(reach), hi(reach), band_index, band_count, ops, &n, cap);
+      };
+      if (st->emissive_spatial_reuse) {
+        parked(0u);
+        parked(1u);
+      }
+      if (st->indirect_spatial_reuse) parked(2u);
     }
   } else if (stage == HK_STAGE_POST_PROCESS) {
     if (st->denoise) {
@@ -408,6 +427,144 @@ int hk_band_plan_bounds(uint32_t width, uint32_t height, float upscale_ratio, co
     HK_REQUIRE(false, HK_E_INVALID, "ops array too small: need %u", n);
   }
   *n_ops = n;
+  return HK_OK;
+}
+
+
+// ---- hk_history_rows_bound (the history halo a frame needs, derived instead of supplied) -----------------
+// Everything in double on the f32 uniforms: the bound has to dominate what the kernels compute in f32 from the same matrices,
+// and it ends with + 2 rows of slack (deferred-texel jitter, truncation) that the rounding differences vanish in.
+namespace {
+struct M4 { double m[4][4]; };  // m[row][col]
+M4 from_columns(const float* c) {
+  M4 r;
+  for (int col = 0; col < 4; ++col)
+    for (int row = 0; row < 4; ++row) r.m[row][col] = (double)c[4 * col + row];
+  return r;
+}
+M4 mul(const M4& a, const M4& b) {
+  M4 r;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += a.m[i][k] * b.m[k][j];
+      r.m[i][j] = s;
+    }
+  return r;
+}
+struct Box3 { double lo[3], hi[3]; };
+// NDC box of a world box under view_proj.  false: nothing of it is in front of the camera.  A box that reaches behind the camera
+// (or the near plane) takes the whole screen and every depth up to the near plane (z = 1 in reverse-Z clip space; the prepass
+// stores clip z / w and 0 is the background, prepass.wgsl:85, light.wgsl:1057).
+bool ndc_box(const M4& vp, const float mn[3], const float mx[3], Box3* out) {
+  bool behind = false, front = false;
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+  for (int k = 0; k < 8; ++k) {
+    const double p[4] = {(double)((k & 1) ? mx[0] : mn[0]), (double)((k & 2) ? mx[1] : mn[1]), (double)((k & 4) ? mx[2] : mn[2]), 1.0};
+    double c[4];
+    for (int i = 0; i < 4; ++i) c[i] = vp.m[i][0] * p[0] + vp.m[i][1] * p[1] + vp.m[i][2] * p[2] + vp.m[i][3];
+    if (!(c[3] > 1e-6)) {
+      behind = true;
+      continue;
+    }
+    front = true;
+    for (int i = 0; i < 3; ++i) {
+      const double v = c[i] / c[3];
+      lo[i] = std::min(lo[i], v);
+      hi[i] = std::max(hi[i], v);
+    }
+  }
+  if (!front) return false;
+  for (int i = 0; i < 2; ++i) {
+    out->lo[i] = behind ? -1.0 : std::max(-1.0, lo[i]);
+    out->hi[i] = behind ? 1.0 : std::min(1.0, hi[i]);
+    if (out->lo[i] > out->hi[i]) return false;  // beside the screen
+  }
+  out->lo[2] = std::max(0.0, lo[2]);
+  out->hi[2] = behind ? 1.0 : std::min(1.0, hi[2]);
+  if (behind) out->lo[2] = std::min(out->lo[2], 1.0);
+  return out->lo[2] <= out->hi[2];
+}
+// Upper bound, in NDC units, of |y - (M v).y / (M v).w| over v = (x, y, z, 1) in `box`, among the v whose image is on screen.
+// Returns a negative number when it cannot bound it (the denominator reaches zero inside the box where the image may be on screen).
+double reprojection_bound(const M4& M, const Box3& box, int gx, int gy, int gz, double screen_slack) {
+  const double* rx = M.m[0];
+  const double* ry = M.m[1];
+  const double* rw = M.m[3];
+  double worst = 0.0;
+  for (int iz = 0; iz < gz; ++iz)
+    for (int iy = 0; iy < gy; ++iy)
+      for (int ix = 0; ix < gx; ++ix) {
+        const double x0 = box.lo[0] + (box.hi[0] - box.lo[0]) * ix / gx, x1 = box.lo[0] + (box.hi[0] - box.lo[0]) * (ix + 1) / gx;
+        const double y0 = box.lo[1] + (box.hi[1] - box.lo[1]) * iy / gy, y1 = box.lo[1] + (box.hi[1] - box.lo[1]) * (iy + 1) / gy;
+        const double z0 = box.lo[2] + (box.hi[2] - box.lo[2]) * iz / gz, z1 = box.lo[2] + (box.hi[2] - box.lo[2]) * (iz + 1) / gz;
+        // the affine forms at the 8 corners: exact extremes over the cell
+        double dmin = 1e300, dmax = -1e300, py_max = 0.0;
+        double a_min = 1e300, a_max = -1e300, b_min = 1e300, b_max = -1e300, c_min = 1e300, c_max = -1e300, e_min = 1e300, e_max = -1e300;
+        const double s = 1.0 + screen_slack;
+        for (int k = 0; k < 8; ++k) {
+          const double x = (k & 1) ? x1 : x0, y = (k & 2) ? y1 : y0, z = (k & 4) ? z1 : z0;
+          const double d = rw[0] * x + rw[1] * y + rw[2] * z + rw[3];
+          const double ny = ry[0] * x + ry[1] * y + ry[2] * z + ry[3];
+          const double nx = rx[0] * x + rx[1] * y + rx[2] * z + rx[3];
+          dmin = std::min(dmin, d);
+          dmax = std::max(dmax, d);
+          const double a = ny - s * d, b = ny + s * d, c = nx - s * d, e = nx + s * d;
+          a_min = std::min(a_min, a); a_max = std::max(a_max, a);
+          b_min = std::min(b_min, b); b_max = std::max(b_max, b);
+          c_min = std::min(c_min, c); c_max = std::max(c_max, c);
+          e_min = std::min(e_min, e); e_max = std::max(e_max, e);
+          py_max = std::max(py_max, fabs(d + y * rw[1] - ry[1]));  // dP/dy, affine in v
+        }
+        // the image (ny / d, nx / d) certainly off screen (|.| > s): the temporal kernels neither load nor store there
+        if (dmin > 0.0 && (a_min > 0.0 || b_max < 0.0 || c_min > 0.0 || e_max < 0.0)) continue;
+        if (dmax < 0.0 && (b_min > 0.0 || a_max < 0.0 || e_min > 0.0 || c_max < 0.0)) continue;  // (behind the previous camera: the quotient flips)
+        const double dabs = dmin > 0.0 ? dmin : -dmax;
+        if (!(dabs > 1e-9)) return -1.0;
+        // P(v) = y (M v).w - (M v).y in centred form: |P| <= |P(c)| + sum_i max|dP/dv_i| r_i
+        const double cx = 0.5 * (x0 + x1), cy = 0.5 * (y0 + y1), cz = 0.5 * (z0 + z1);
+        const double pc = cy * (rw[0] * cx + rw[1] * cy + rw[2] * cz + rw[3]) - (ry[0] * cx + ry[1] * cy + ry[2] * cz + ry[3]);
+        const double px_max = std::max(fabs(y0 * rw[0] - ry[0]), fabs(y1 * rw[0] - ry[0]));
+        const double pz_max = std::max(fabs(y0 * rw[2] - ry[2]), fabs(y1 * rw[2] - ry[2]));
+        const double p = fabs(pc) + px_max * 0.5 * (x1 - x0) + py_max * 0.5 * (y1 - y0) + pz_max * 0.5 * (z1 - z0);
+        worst = std::max(worst, p / dabs);
+      }
+  return worst;
+}
+}  // namespace
+
+int hk_history_rows_bound(const HkView* view, const HkPreviousView* pview, uint32_t render_rows, const float scene_min[3], const float scene_max[3],
+                          const HkMovedBox* moved, uint32_t n_moved, uint32_t* rows) {
+  HK_REQUIRE(view && pview && rows && scene_min && scene_max && render_rows > 0 && (moved || n_moved == 0), HK_E_INVALID, "bad argument");
+  *rows = 0;
+  const bool same_view = memcmp(view->view_proj, pview->view_proj, sizeof(view->view_proj)) == 0;
+  if (same_view && n_moved == 0) return HK_OK;
+  for (int k = 0; k < 3; ++k)
+    if (!(scene_min[k] <= scene_max[k])) return HK_OK;  // an empty scene: every pixel is background, nothing reprojects
+  const M4 vp = from_columns(view->view_proj), ivp = from_columns(view->inverse_view_proj), pvp = from_columns(pview->view_proj);
+  const double slack = 8.0 / (double)render_rows;  // on-screen test of the kernels: previous_uv in [0, 1], +- the deferred jitter
+  double worst = 0.0;  // NDC units; a row is 2 / render_rows of them
+  bool unbounded = false;
+  if (!same_view) {
+    Box3 box;
+    if (ndc_box(vp, scene_min, scene_max, &box)) {
+      const double b = reprojection_bound(mul(pvp, ivp), box, 16, 16, 8, slack);
+      if (b < 0.0) unbounded = true; else worst = b;
+    }
+  }
+  for (uint32_t i = 0; i < n_moved && !unbounded; ++i) {
+    Box3 box;
+    if (!ndc_box(vp, moved[i].min, moved[i].max, &box)) continue;
+    // cells of about 1/8 of the screen: the centred form is second-order in the cell size
+    const int gx = std::max(1, std::min(16, (int)ceil((box.hi[0] - box.lo[0]) * 4.0))), gy = std::max(1, std::min(16, (int)ceil((box.hi[1] - box.lo[1]) * 4.0)));
+    const double b = reprojection_bound(mul(mul(pvp, from_columns(moved[i].previous_from_current)), ivp), box, gx, gy, 2, slack);
+    if (b < 0.0) unbounded = true; else worst = std::max(worst, b);
+  }
+  double r = unbounded ? (double)render_rows : worst * 0.5 * (double)render_rows;
+  if (!(r < (double)render_rows)) r = (double)render_rows;   // (also NaN)
+  uint32_t h = (uint32_t)ceil(r) + 2u;
+  h = (h + 3u) & ~3u;
+  *rows = std::min(h, render_rows);
   return HK_OK;
 }
 

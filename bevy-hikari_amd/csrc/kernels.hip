@@ -30,9 +30,20 @@
 
 namespace hkd {
 
-__global__ __launch_bounds__(256) void k_resolve_scatter(LightTargets t, int pixels) {
-  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
-  if (i >= pixels) return;
+// Parked scatter stores (hk_light.hpp store_previous_spatial): pixel i left its slot in det_to[i], its record in det_pending[i]
+// and - if this context dispatched it - its index in det_winner[slot] (atomicMax).  Pixels [p0, p1) outside [own0, own1) were
+// dispatched by ANOTHER band (their rows of the two planes arrived with exchange A): k_join_winners lets them compete for the
+// slots first, then k_resolve_scatter applies every store that is its slot's highest index - the oracle's resolution of the
+// reference's write-write race (light.wgsl:1063,1092-1095,1199-1202,1456-1459), across band borders as within a band.
+__global__ __launch_bounds__(256) void k_join_winners(LightTargets t, int p0, int p1, int own0, int own1) {
+  const int i = p0 + (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= p1 || (i >= own0 && i < own1)) return;
+  const int to = t.det_to[i];
+  if (to >= 0) atomicMax(&t.det_winner[to], i);
+}
+__global__ __launch_bounds__(256) void k_resolve_scatter(LightTargets t, int p0, int p1) {
+  const int i = p0 + (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i >= p1) return;
   const int to = t.det_to[i];
   if (to >= 0 && t.det_winner[to] == i) store_packed(t.previous_spatial, to, load_packed(t.det_pending, i));
 }
@@ -943,8 +954,11 @@ void launch_indirect(hipStream_t st, bool multiple_bounces, const DScene& sc, co
   if (multiple_bounces) { HK_LAUNCH(true) } else { HK_LAUNCH(false) }
 #undef HK_LAUNCH
 }
-void launch_resolve_scatter(hipStream_t st, const LightTargets& t, int pixels) {
-  hipLaunchKernelGGL(k_resolve_scatter, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, st, t, pixels);
+void launch_resolve_scatter(hipStream_t st, const LightTargets& t, int p0, int p1, int own0, int own1) {
+  if (p1 <= p0) return;
+  const dim3 grid((unsigned)((p1 - p0 + 255) / 256));
+  if (own1 > own0 && (p0 < own0 || p1 > own1)) hipLaunchKernelGGL(k_join_winners, grid, dim3(256), 0, st, t, p0, p1, own0, own1);
+  hipLaunchKernelGGL(k_resolve_scatter, grid, dim3(256), 0, st, t, p0, p1);
 }
 void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1) {
   if (y1 <= y0) return;

@@ -86,6 +86,16 @@ def band_gather_schedule(width, height, upscale_ratio, upscale_kind, rank, n_ran
     return [tr[i] for i in range(n2.value)]
 
 
+def history_rows_bound(view, previous_view, render_rows, scene_min, scene_max, moved=()):
+    """hk_history_rows_bound (pure host logic): the history halo a frame with these uniforms needs over a scene with these world
+    bounds; moved: HkMovedBox records of the instances whose model changed since the last frame."""
+    n = F.u32(0)
+    mn, mx = (F.f32 * 3)(*scene_min), (F.f32 * 3)(*scene_max)
+    arr = (F.HkMovedBox * max(len(moved), 1))(*moved)
+    F.api().call("history_rows_bound", C.byref(view), C.byref(previous_view), int(render_rows), mn, mx, arr if moved else None, len(moved), C.byref(n))
+    return n.value
+
+
 def balanced_band_bounds(row_costs, width, render_rows, band_count, min_rows=8, background_cost=0.0):
     """hk_balanced_band_bounds: boundaries (band_count + 1 scaled render rows) that give every band about the same cost
     (geometry pixels + width x background_cost per row; 0 = 1/16)."""
@@ -260,16 +270,23 @@ class BandRenderer:
         if landing:
             self.torch.cuda.synchronize()
 
-    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=0, antialias=False, balance=False, gather=False):
-        """One frame of this rank's band.  history_rows > 0 (camera or objects moved since the last frame) first fetches
-        that many rows of last frame's reservoirs from the neighbouring bands (exchange C).  balance: split THIS frame's rows by
+    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=None, antialias=False, balance=False, gather=False):
+        """One frame of this rank's band.  history_rows: rows of last frame's reservoirs fetched from the neighbouring bands before
+        stage TEMPORAL (exchange C; the bands then also hand each other the scatter stores that cross a border, with exchange A).
+        None = derived per frame by the library from the frame's own uniforms (hk_history_rows_bound: 0 for a static view), a
+        number overrides it.  balance: split THIS frame's rows by
         cost first (HK_FRAME_BALANCE_BANDS / hk_balance_bands - every rank derives the same split from its own full-frame primary
         rays) and keep the split; meant for the first frame or a cut (rows that change owner lose their history)."""
         e = self.engine
         sc = settings.to_c()
+        if self.world > 1:
+            if history_rows is None and e.api.prefix != "hk_":
+                # (the CPU tests' oracle behind the same class has no host logic of its own: the bound comes from the product
+                # library's pure function, for the static scenes those tests render)
+                _w, rh, _b = e.buffer_info(F.BUF_TONE_MAPPED)
+                history_rows = history_rows_bound(view, previous_view, rh, *e.scene_bounds())
+            e.set_history_rows(F.HISTORY_AUTO if history_rows is None else int(history_rows))
         if self.transport == "rccl":
-            if self.world > 1:
-                e.comm_set_history_rows(int(history_rows))
             e.frame_render(frame, view, previous_view, lights, sc,
                            (F.FRAME_ANTIALIAS if antialias else 0) | (F.FRAME_BALANCE_BANDS if balance else 0) | (F.FRAME_GATHER if gather else 0))
             if balance:
@@ -277,6 +294,7 @@ class BandRenderer:
             return
         ratio = settings.upscale.ratio()
         e.frame_begin(frame, view, previous_view, lights)
+        history_rows = e.history_rows() if self.world > 1 else 0   # what the library settled on (every rank: the same number)
         if balance and self.world > 1:
             e.set_view_options(sc.taa, sc.upscale_kind, sc.upscale_sharpness)   # (the primary rays' sub-pixel jitter follows the settings)
             self.bounds = e.balance_bands()
@@ -286,7 +304,7 @@ class BandRenderer:
             self.exchange(F.STAGE_TEMPORAL | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_TEMPORAL, sc)
         e.wait()
-        self.exchange(F.STAGE_SPATIAL, frame.number, sc, width, height, ratio)
+        self.exchange(F.STAGE_SPATIAL | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_SPATIAL, sc)
         e.wait()
         self.exchange(F.STAGE_POST_PROCESS, frame.number, sc, width, height, ratio)

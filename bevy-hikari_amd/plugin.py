@@ -626,7 +626,23 @@ class Engine:
         self.api.call("comm_init", self.ctx, rank, n_ranks, buf)
 
     def comm_set_history_rows(self, rows):
-        self.api.call("comm_set_history_rows", self.ctx, rows)
+        self.set_history_rows(rows)
+
+    def set_history_rows(self, rows=F.HISTORY_AUTO):
+        """hk_set_history_rows: rows of last frame's reservoirs a band fetches from its neighbours before TEMPORAL (and, doubled,
+        of the parked scatter stores before SPATIAL).  F.HISTORY_AUTO (the default of a context): derived per frame."""
+        self.api.call("set_history_rows", self.ctx, int(rows))
+
+    def history_rows(self):
+        """hk_history_rows: the count in force for the frame most recently begun (0 for a single band or a static view)."""
+        n = F.u32(0)
+        self.api.call("history_rows", self.ctx, C.byref(n))
+        return n.value
+
+    def scene_bounds(self):
+        mn, mx = (F.f32 * 3)(), (F.f32 * 3)()
+        self.api.call("scene_bounds", self.ctx, mn, mx)
+        return list(mn), list(mx)
 
     def comm_gather(self, buffer, root=0):
         """hk_comm_gather: rank `root` collects every other rank's rows of `buffer` (RCCL, on the context's stream)."""

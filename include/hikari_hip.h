@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HK_ABI_VERSION 6
+#define HK_ABI_VERSION 7
 
 /* ------------------------------------------------------------------ error codes */
 #define HK_OK 0
@@ -251,7 +251,16 @@ typedef enum HkBuffer {
   /* FSR1 (Upscale::Fsr1): upscale_output[0] (EASU result) is HK_BUF_UPSCALE_OUTPUT at the window size, upscale_output[1]
    * (RCAS result, what OverlayNode presents, overlay.rs:228) is this one: rgba16f, window size */
   HK_BUF_UPSCALE_SHARPENED = 37,
-  HK_BUF_COUNT = 38
+  /* Parked scatter stores (ABI 7).  A temporal dispatch stores a rejected history reservoir at the REPROJECTED
+   * pixel of previous_spatial (light.wgsl:1063,1092-1095,1199-1202,1456-1459) - a slot some other thread, possibly some other
+   * BAND, owns.  Where those stores are parked instead of raced (HK_CTX_DETERMINISTIC_SCATTER, and every band of a sharded frame
+   * whose history halo is not empty) pixel i of channel c (0 sun, 1 emissive, 2 indirect) leaves the slot it stores to in
+   * PARKED_TO0 + c (i32 per render pixel, -1 = no store) and the 64-B record in PARKED_RECORD0 + c; the highest pixel index that
+   * stores to a slot wins.  Rows of these planes are what bands hand each other with exchange A under motion
+   * (HK_STAGE_SPATIAL_WITH_HISTORY).  Allocated on first use: hk_device_ptr / hk_read_buffer fail with HK_E_INVALID before. */
+  HK_BUF_PARKED_TO0 = 38,       /* i32, scaled; +channel */
+  HK_BUF_PARKED_RECORD0 = 41,   /* 64 B, scaled; +channel */
+  HK_BUF_COUNT = 44
 } HkBuffer;
 
 /* One compute dispatch of the reference.  `arg` selects the render channel for
@@ -590,6 +599,37 @@ int hk_balanced_band_bounds(const uint32_t* row_cost, uint32_t cost_rows, uint32
  * beyond the halo reads the local, stale rows - the documented deviation; rows = 0 (static camera) is
  * plain HK_STAGE_TEMPORAL and has no transfers. */
 #define HK_STAGE_TEMPORAL_WITH_HISTORY(rows) ((uint32_t)HK_STAGE_TEMPORAL | ((uint32_t)(rows) << 8))
+/* ... and the scatter stores of frame n's temporal dispatches that cross a band border (ABI 7).  A pixel of
+ * band B whose history reservoir was rejected stores it at the reprojected slot of previous_spatial, up to `rows` rows away - in
+ * the rows of a neighbour, whose spatial pass reads that slot - and B's own spatial pass reads slots up to `rows` rows outside B
+ * that pixels of OTHER bands store to.  With a history halo the temporal dispatches of a band therefore PARK their stores
+ * (HK_BUF_PARKED_TO0 / _RECORD0 + channel) and HK_STAGE_SPATIAL_WITH_HISTORY(rows) adds to exchange A, for every channel whose
+ * spatial pass is enabled (sun and emissive share their spatial buffers: both, in dispatch order), 2 x rows rows of the parked
+ * planes per side: every store that can reach a slot the band reads comes from a pixel at most 2 x rows rows outside it.  Stage
+ * SPATIAL then resolves them - the highest storing pixel index wins, the rule HK_CTX_DETERMINISTIC_SCATTER and the oracle apply
+ * to the reference's write-write race - before spatial_reuse runs: the union of the bands equals the single context bit for bit
+ * under camera and object motion. */
+#define HK_STAGE_SPATIAL_WITH_HISTORY(rows) ((uint32_t)HK_STAGE_SPATIAL | ((uint32_t)(rows) << 8))
+/* How many history rows does this frame need?  Pure host logic, the same number on every rank (all of them hold the same
+ * uniforms and the same scene).  Returns in *rows an upper bound of |row of the reprojected pixel - row of the pixel| over every
+ * surface point the frame can show: the reprojection is previous_uv = uv - velocity with velocity = clip_to_uv(view_proj x p) -
+ * clip_to_uv(previous_view_proj x p_previous) (prepass.wgsl:94-95), i.e. in NDC a projective map M = previous_view_proj x T x
+ * inverse_view_proj of the pixel's own (x, y, depth), T = identity for static geometry and previous_model x model^-1 for an
+ * instance that moved.  The bound is taken over the NDC box of the scene's world bounds (static part) and of every moved box with
+ * interval arithmetic on y x (M v).w - (M v).y in centred form over a grid of cells, divided by the smallest (M v).w of the cell;
+ * cells whose reprojection is certainly off screen do not count (the temporal kernels neither load nor store there).  + 2 rows
+ * for the sub-pixel jitter of the deferred texel and the truncation to a row index, rounded up to a multiple of 4 (schedules are
+ * cached per row count).  0 when the view did not change and nothing moved.  A reprojection that cannot be bounded (the previous
+ * camera's plane cuts through the visible volume) gives render_rows: every band then needs all of last frame's rows. */
+typedef struct HkMovedBox {
+  float min[3];
+  float _pad0;
+  float max[3];
+  float _pad1;
+  float previous_from_current[16]; /* previous_model x model^-1, column-major: where a point of the box was last frame */
+} HkMovedBox;
+int hk_history_rows_bound(const HkView* view, const HkPreviousView* previous_view, uint32_t render_rows, const float scene_min[3],
+                          const float scene_max[3], const HkMovedBox* moved, uint32_t n_moved, uint32_t* rows);
 int hk_band_plan(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, HkHaloOp* ops, uint32_t* n_ops);
 /* Same plan without a context (used by hosts that only schedule): */
 int hk_band_plan_for(uint32_t width, uint32_t height, float upscale_ratio, uint32_t band_index, uint32_t band_count,
@@ -647,9 +687,17 @@ int hk_comm_unique_id(uint8_t id[HK_COMM_ID_BYTES]);
 int hk_comm_available(hk_ctx* ctx);
 int hk_comm_init(hk_ctx* ctx, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK_COMM_ID_BYTES]);
 int hk_comm_destroy(hk_ctx* ctx);
-/* rows of last frame's reservoirs / AA history fetched from the neighbours before TEMPORAL / ANTIALIAS (exchange C): the
- * host sets what its camera / object motion needs, 0 (default) for a static view */
+/* rows of last frame's reservoirs / AA history fetched from the neighbours before TEMPORAL / ANTIALIAS (exchange C).  Since ABI 7
+ * the default is HK_HISTORY_AUTO: hk_frame_begin derives the count from the frame's own uniforms, the scene's bounds and the
+ * instances that moved (hk_history_rows_bound; 0 for a static view, so a static frame exchanges nothing).  An explicit count
+ * overrides it (tests; hosts that know better).  hk_history_rows returns the count in force for the frame most recently begun.
+ * hk_comm_set_history_rows is the ABI 6 name of hk_set_history_rows. */
+#define HK_HISTORY_AUTO 0xFFFFu
+int hk_set_history_rows(hk_ctx* ctx, uint32_t rows);
+int hk_history_rows(hk_ctx* ctx, uint32_t* rows);
 int hk_comm_set_history_rows(hk_ctx* ctx, uint32_t rows);
+/* world bounds of the uploaded scene (the union of the instances' boxes; what hk_history_rows_bound takes) */
+int hk_scene_bounds(hk_ctx* ctx, float min[3], float max[3]);
 /* one exchange by hand (hosts that drive hk_frame_stage themselves): everything hk_band_schedule lists for `stage` */
 int hk_comm_exchange(hk_ctx* ctx, uint32_t stage, const HkSettings* settings);
 /* rank `root` collects every other rank's rows of `buffer` (hk_band_gather_schedule as ncclSend / ncclRecv in one group, on the

@@ -110,6 +110,7 @@ struct Ctx {
   float upscale_sharpness = 0.0f;                                       // Upscale::sharpness(), FSR1 RCAS
 
   uint32_t band_index = 0, band_count = 1;
+  uint32_t history_rows = 0;  // orc_set_history_rows: > 0 on a band = its scatter stores are parked and resolved across bands
   std::vector<uint32_t> band_bounds;  // orc_set_band_bounds: explicit split of the scaled render rows (band_count + 1 entries) or empty
   Stats stats;
   uint32_t flags = 0;
@@ -131,6 +132,8 @@ static int buf_bpp(uint32_t b) {
   if (b == HK_BUF_TONE_MAPPED || b == HK_BUF_PREVIOUS_TONE_MAPPED) return 8;
   if (b == HK_BUF_PREVIOUS_POSITION || b == HK_BUF_PREVIOUS_VELOCITY_UV) return 16;
   if (b == HK_BUF_UPSCALE_OUTPUT || b == HK_BUF_TAA_OUTPUT || b == HK_BUF_PREVIOUS_TAA_OUTPUT || b == HK_BUF_UPSCALE_SHARPENED) return 8;
+  if (b >= HK_BUF_PARKED_TO0 && b < HK_BUF_PARKED_TO0 + 3) return 4;        // parked scatter stores (bands under motion, below)
+  if (b >= HK_BUF_PARKED_RECORD0 && b < HK_BUF_PARKED_RECORD0 + 3) return 64;
   return 0;
 }
 static bool buf_full_size(uint32_t b) {
@@ -1032,6 +1035,32 @@ static v4 noise_fetch(Ctx* c, int x, int y, uint32_t n) {  // light.wgsl:1075-10
   return V4((float)t[0] / 255.0f, (float)t[1] / 255.0f, (float)t[2] / 255.0f, (float)t[3] / 255.0f);
 }
 
+// A band of a sharded frame with a history halo (hk_frame_stage in hikari_hip.h, HK_STAGE_SPATIAL_WITH_HISTORY): the stores are
+// not applied but PARKED in the HK_BUF_PARKED_* planes of the channel - pixel `from` leaves its slot and its record, a background
+// pixel its own slot - so that the bands can hand each other the rows near their borders; resolve_parked applies them at the
+// start of stage SPATIAL, the highest pixel index winning as in apply_scatter.
+static bool parks_across_bands(const Ctx* c) { return c->band_count > 1 && c->history_rows > 0; }
+static void park_scatter(Ctx* c, int channel, std::vector<std::vector<ScatterStore>>& rows, const PackedReservoir* dst, const std::vector<uint8_t>& own_written,
+                         int y0, int y1) {
+  int32_t* to = (int32_t*)c->buf[HK_BUF_PARKED_TO0 + channel].data();
+  PackedReservoir* rec = (PackedReservoir*)c->buf[HK_BUF_PARKED_RECORD0 + channel].data();
+  const int rw = c->RW;
+  for (int i = y0 * rw; i < y1 * rw; ++i) {
+    to[i] = own_written[i] ? i : -1;
+    if (own_written[i]) rec[i] = dst[i];
+  }
+  for (auto& row : rows)
+    for (auto& st : row) {  // (a pixel that stores twice, light.wgsl:1092-1095 then 1199-1202, keeps the later record: same slot)
+      to[st.from] = st.to;
+      rec[st.from] = st.value;
+    }
+}
+static void resolve_parked(Ctx* c, int channel, PackedReservoir* dst, int y0, int y1) {
+  const int32_t* to = (const int32_t*)c->buf[HK_BUF_PARKED_TO0 + channel].data();
+  const PackedReservoir* rec = (const PackedReservoir*)c->buf[HK_BUF_PARKED_RECORD0 + channel].data();
+  for (int i = y0 * c->RW; i < y1 * c->RW; ++i)
+    if (to[i] >= 0) dst[to[i]] = rec[i];  // increasing pixel index: the highest one that stores to a slot stays
+}
 static void apply_scatter(std::vector<std::vector<ScatterStore>>& rows, PackedReservoir* dst, const std::vector<uint8_t>& own_written) {
   for (auto& row : rows)
     for (auto& st : row) {
@@ -1334,7 +1363,8 @@ static void pass_direct_lit(Ctx* c, bool emissive_lit, int y0, int y1) {
     n_tlas += sc.n_tlas;
     n_blas += sc.n_blas;
   }
-  apply_scatter(scatter, rs.previous_spatial, own_written);
+  if (parks_across_bands(c)) park_scatter(c, channel, scatter, rs.previous_spatial, own_written, y0, y1);
+  else apply_scatter(scatter, rs.previous_spatial, own_written);
   c->stats.rays_tlas += n_tlas;
   c->stats.rays_blas += n_blas;
 }
@@ -1540,7 +1570,8 @@ static void pass_indirect(Ctx* c, int y0, int y1) {
     n_tlas += sc.n_tlas;
     n_blas += sc.n_blas;
   }
-  apply_scatter(scatter, rs.previous_spatial, own_written);
+  if (parks_across_bands(c)) park_scatter(c, channel, scatter, rs.previous_spatial, own_written, y0, y1);
+  else apply_scatter(scatter, rs.previous_spatial, own_written);
   c->stats.rays_tlas += n_tlas;
   c->stats.rays_blas += n_blas;
 }
@@ -2372,7 +2403,7 @@ int orc_resize(orc_ctx* ctx, uint32_t width, uint32_t height, float upscale_rati
   c.band_bounds.clear();  // (boundaries are render rows of the old size)
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
     size_t n = buf_full_size(b) ? (size_t)c.W * c.H : (buf_upscaled(b) ? (size_t)c.UW * c.UH : (size_t)c.RW * c.RH);
-    c.buf[b].assign(n * buf_bpp(b), 0);
+    c.buf[b].assign(n * buf_bpp(b), (b >= HK_BUF_PARKED_TO0 && b < HK_BUF_PARKED_TO0 + 3) ? 0xFF : 0);  // (-1: nothing parked)
   }
   c.mapped_parity = 0;
   return HK_OK;
@@ -2479,6 +2510,17 @@ int orc_frame_stage_rows(orc_ctx* ctx, uint32_t stage, const HkSettings* st, uin
     pass_direct_lit(&c, true, b0, b1);
     pass_indirect(&c, b0, b1);
   } else if (stage == HK_STAGE_SPATIAL) {
+    if (parks_across_bands(&c)) {
+      // exchange A brought the parked stores of the pixels up to 2 x history rows outside the band (HK_STAGE_SPATIAL_WITH_HISTORY);
+      // per channel in dispatch order - sun and emissive store into the same buffer.  A channel whose spatial pass is off has
+      // no reader and no exchanged rows: its stores are resolved among the band's own pixels.
+      const int reach = 2 * (int)c.history_rows;
+      for (int channel = 0; channel < 3; ++channel) {
+        const bool exchanged = channel == 2 ? st->indirect_spatial_reuse != 0 : st->emissive_spatial_reuse != 0;
+        ReservoirSet rs = reservoir_set(&c, channel);
+        resolve_parked(&c, channel, rs.previous_spatial, exchanged ? clampr(b0 - reach) : b0, exchanged ? clampr(b1 + reach) : b1);
+      }
+    }
     if (st->emissive_spatial_reuse) pass_spatial_reuse(&c, true, b0, b1);       // light.rs:675,689-697
     if (st->indirect_spatial_reuse) pass_spatial_reuse(&c, false, b0, b1);      // light.rs:676
   } else if (stage == HK_STAGE_POST_PROCESS) {
@@ -2542,6 +2584,26 @@ int orc_row_costs(orc_ctx* ctx, uint32_t* out, uint32_t n_rows) {  // hk_row_cos
     for (int x = 0; x < ctx->c.W; ++x) n += !(p[4 * ((size_t)y * ctx->c.W + x) + 3] < 1.1920929e-7f) ? 1u : 0u;
     out[y] = n;
   }
+  return HK_OK;
+}
+int orc_set_history_rows(orc_ctx* ctx, uint32_t rows) {  // hk_set_history_rows; the oracle takes counts only (no HK_HISTORY_AUTO: the bound is host logic of the product)
+  ORC_CHECK(ctx && rows < HK_HISTORY_AUTO, HK_E_INVALID, "history rows: a count");
+  ctx->c.history_rows = rows;
+  return HK_OK;
+}
+int orc_history_rows(orc_ctx* ctx, uint32_t* rows) {
+  ORC_CHECK(ctx && rows, HK_E_INVALID, "argument");
+  *rows = ctx->c.band_count > 1 ? std::min(ctx->c.history_rows, (uint32_t)ctx->c.RH) : 0u;
+  return HK_OK;
+}
+int orc_scene_bounds(orc_ctx* ctx, float mn[3], float mx[3]) {  // the union of the instances' boxes
+  ORC_CHECK(ctx && mn && mx && !ctx->c.instances.empty(), HK_E_INVALID, "argument");
+  for (int k = 0; k < 3; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+  for (const HkInstance& in : ctx->c.instances)
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = std::min(mn[k], in.min[k]);
+      mx[k] = std::max(mx[k], in.max[k]);
+    }
   return HK_OK;
 }
 int orc_set_band(orc_ctx* ctx, uint32_t band_index, uint32_t band_count) {

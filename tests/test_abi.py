@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the binding table covers the header (no silently unbound entry points)
     assert set(names) == set(F.DECLARED_SYMBOLS), set(names) ^ set(F.DECLARED_SYMBOLS)
-    assert api.abi_version() == 6
+    assert api.abi_version() == 7
 
 
 def test_struct_layouts_are_std430():
