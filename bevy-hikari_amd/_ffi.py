@@ -1,13 +1,13 @@
-"""ctypes binding of the C ABI in include/hikari_hip.h.
+"""ctypes binding of the C ABI in include/hikari_hip.h (+ the test / measurement hooks of include/hikari_hip_debug.h).
 
 This is the stub a host language binds (INTEGRATION.md shows the Rust `extern "C"` equivalent).
-The structs are field-for-field the ones in the header; `Api` resolves every entry point once and
-turns negative return codes into `HikariError`.
+The structs are field-for-field the ones in the header; `Api` resolves every entry point of
+libhikari_hip.so once and turns negative return codes into `HikariError`.  There is no fallback: if
+the HIP library is missing or no GPU is present the calls fail loudly.
 
-`Api` takes the symbol prefix as an argument because the CPU oracle under oracle/ exports the same
-entry points with the prefix `orc_` (tests drive both through this one class).  The product only
-ever instantiates it with `hk_` on libhikari_hip.so; there is no fallback: if the HIP library is
-missing or no GPU is present the calls fail loudly.
+(`_SIGNATURES` is the part of the table the frame path itself uses; the test suite builds the table of
+its CPU oracle from it - tests/oracle_lib.py - so that one driver class serves both.  Nothing in this
+package knows about that library.)
 """
 import ctypes as C
 import os
@@ -191,9 +191,16 @@ _SIGNATURES = {
     "device_ptr": [_vp, u32, P(_vp), P(C.c_size_t)],
     "get_stats": [_vp, P(HkStats)],
     "reset_stats": [_vp],
-    "debug_math": [_vp, u32, P(f32), P(f32), P(f32), C.c_size_t],
 }
-# entry points only the product library exports (host logic + builders + GPU-only hooks)
+# include/hikari_hip_debug.h: test and measurement hooks (not part of the boundary a host binds)
+_DEBUG = {
+    "debug_math": [_vp, u32, P(f32), P(f32), P(f32), C.c_size_t],
+    "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
+    "debug_comm_loopback": [_vp, u32, u32, u32, u32],
+    "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
+    "measure_valu": [_vp, u32, P(C.c_double)],
+}
+# host logic, builders, multi-GPU and GPU-only entry points
 _PRODUCT_ONLY = {
     "device_count": [P(C.c_int)],
     "settings_default": [P(HkSettings)],
@@ -223,7 +230,6 @@ _PRODUCT_ONLY = {
     "refit_scene_instances": [_vp, _vp, P(u32)],
     "rebuild_scene_trees": [_vp, u32],
     "update_scene_instances": [_vp, _vp, u32],
-    "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "balanced_band_bounds": [P(u32), u32, u32, u32, u32, u32, f32, P(u32)],
     "balance_bands": [_vp, u32, P(u32), u32],
@@ -241,8 +247,6 @@ _PRODUCT_ONLY = {
     "set_timing_mask": [_vp, u32],
     "indirect_schedule": [_vp, P(u32)],
     "traversal_mode": [_vp, P(u32), P(u32)],
-    "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
-    "measure_valu": [_vp, u32, P(C.c_double)],
     "bvh_rethread": [P(HkNode), u32, u32, P(HkNode)],
     "band_schedule": [u32, u32, f32, u32, u32, u32, u32, P(HkSettings), P(HkTransfer), P(u32)],
     "comm_unique_id": [P(C.c_uint8)],
@@ -270,41 +274,35 @@ _PRODUCT_ONLY = {
 }
 _VOID = {"destroy": [_vp], "scene_builder_destroy": [_vp], "multi_destroy": [_vp]}
 
-#: every symbol include/hikari_hip.h declares (checked by tests/test_abi.py)
+#: every symbol include/hikari_hip.h declares / include/hikari_hip_debug.h declares (checked by tests/test_abi.py)
 DECLARED_SYMBOLS = sorted(["hk_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY) + list(_VOID)] + ["hk_abi_version", "hk_last_error", "hk_final_buffer"])
+DECLARED_DEBUG_SYMBOLS = sorted("hk_" + n for n in _DEBUG)
 
 
 class Api:
-    """Resolved entry points of one shared library."""
+    """Resolved entry points of libhikari_hip.so."""
 
-    def __init__(self, path, prefix="hk_"):
+    prefix = "hk_"
+
+    def __init__(self, path):
         if not os.path.exists(path):
             raise FileNotFoundError(
                 f"{path} not found - build it first (python -c 'import __graft_entry__ as g; g.build()'). "
                 "There is no CPU fallback for the product path.")
-        self.path, self.prefix = path, prefix
+        self.path = path
         self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
         self._fns = {}
-        names = dict(_SIGNATURES)
-        if prefix == "hk_":
-            names.update(_PRODUCT_ONLY)
-        for name, argtypes in names.items():
-            fn = getattr(self.dll, prefix + name)
-            fn.argtypes, fn.restype = argtypes, C.c_int
-            self._fns[name] = fn
-        for name, argtypes in _VOID.items():
-            if prefix != "hk_" and (name.startswith("scene_builder") or name.startswith("multi_")):
-                continue
-            fn = getattr(self.dll, prefix + name)
-            fn.argtypes, fn.restype = argtypes, None
-            self._fns[name] = fn
-        self._last_error = getattr(self.dll, prefix + "last_error")
+        for table, restype in ((_SIGNATURES, C.c_int), (_PRODUCT_ONLY, C.c_int), (_DEBUG, C.c_int), (_VOID, None)):
+            for name, argtypes in table.items():
+                fn = getattr(self.dll, "hk_" + name)
+                fn.argtypes, fn.restype = argtypes, restype
+                self._fns[name] = fn
+        self._last_error = self.dll.hk_last_error
         self._last_error.restype = C.c_char_p
-        self._abi = getattr(self.dll, prefix + "abi_version")
+        self._abi = self.dll.hk_abi_version
         self._abi.restype = u32
-        if prefix == "hk_":
-            self._final_buffer = self.dll.hk_final_buffer
-            self._final_buffer.argtypes, self._final_buffer.restype = [P(HkSettings), u32], u32
+        self._final_buffer = self.dll.hk_final_buffer
+        self._final_buffer.argtypes, self._final_buffer.restype = [P(HkSettings), u32], u32
 
     def final_buffer(self, settings_c, frame_flags=0):
         """hk_final_buffer: the HkBuffer id of the image a frame rendered with these settings / flags presents."""
@@ -334,5 +332,5 @@ def api():
     """The product library (loaded once)."""
     global _API
     if _API is None:
-        _API = Api(LIB_PATH, "hk_")
+        _API = Api(LIB_PATH)
     return _API

@@ -123,6 +123,31 @@ int schedule_for(std::deque<Comm::Cached>& cache, const CtxInfo& ci, uint32_t ra
   return HK_OK;
 }
 
+// One exchange: every transfer of the list as an ncclSend / ncclRecv on `stream`, inside ONE group (the sends and receives of a
+// rank pair up across ranks by issue order; inside a group nothing blocks before ncclGroupEnd).
+int run_transfers(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, hipStream_t stream) {
+  HK_NCCL(R, R->GroupStart());
+  for (size_t k = 0; k < n; ++k) {
+    const HkTransfer& t = tr[k];
+    size_t logical = 0;
+    char* base = static_cast<char*>(ctx_buffer(c, t.buffer, &logical));
+    if (!base || t.offset + t.bytes > logical) {
+      (void)R->GroupEnd();
+      HK_REQUIRE(false, HK_E_INVALID, "halo transfer outside buffer %u", t.buffer);
+    }
+    ncclResult_t e = t.is_recv ? R->Recv(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream)
+                               : R->Send(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream);
+    if (e != ncclSuccess) {
+      (void)R->GroupEnd();
+      set_error("ncclSend/ncclRecv failed: %s", R->GetErrorString(e));
+      return HK_E_HIP;
+    }
+    if (t.is_recv) cm->bytes_received += t.bytes;
+  }
+  HK_NCCL(R, R->GroupEnd());
+  return HK_OK;
+}
+
 }  // namespace
 
 namespace hk {
@@ -145,25 +170,7 @@ int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
   // No join with the side stream here: hk_frame_stage joins it exactly where an exchange reads what the direct-light
   // dispatches wrote (end of TEMPORAL when the emissive channel has a spatial pass, end of SPATIAL before exchange B), so
   // exchange A (indirect reservoirs, main stream) overlaps the direct-light kernels still running on the side stream.
-  hipStream_t stream = (hipStream_t)ci.stream;
-  HK_NCCL(R, R->GroupStart());
-  for (const HkTransfer& t : *tr) {
-    size_t logical = 0;
-    char* base = static_cast<char*>(ctx_buffer(c, t.buffer, &logical));
-    if (!base || t.offset + t.bytes > logical) {
-      (void)R->GroupEnd();
-      HK_REQUIRE(false, HK_E_INVALID, "halo transfer outside buffer %u", t.buffer);
-    }
-    ncclResult_t e = t.is_recv ? R->Recv(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream)
-                               : R->Send(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream);
-    if (e != ncclSuccess) {
-      (void)R->GroupEnd();
-      set_error("ncclSend/ncclRecv failed: %s", R->GetErrorString(e));
-      return HK_E_HIP;
-    }
-    if (t.is_recv) cm->bytes_received += t.bytes;
-  }
-  HK_NCCL(R, R->GroupEnd());
+  if ((rc = run_transfers(c, cm, R, tr->data(), tr->size(), (hipStream_t)ci.stream))) return rc;
   cm->exchanges += 1;
   return HK_OK;
 }
@@ -186,27 +193,7 @@ int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root) {
   if (n && (rc = hk_band_gather_schedule(ci.width, ci.height, ci.ratio, ci.upscale_kind, ci.band_bounds, cm->rank, cm->n_ranks, root, buffer, tr.data(), &n))) return rc;
   if (tr.empty()) return HK_OK;
   HK_HIP(hipSetDevice(ci.device));
-  hipStream_t stream = (hipStream_t)ci.stream;
-  size_t limit = 0;
-  char* base = static_cast<char*>(ctx_buffer(c, buffer, &limit));
-  HK_REQUIRE(base, HK_E_INVALID, "buffer %u is not allocated", buffer);
-  HK_NCCL(R, R->GroupStart());
-  for (const HkTransfer& t : tr) {
-    if (t.offset + t.bytes > limit) {
-      (void)R->GroupEnd();
-      HK_REQUIRE(false, HK_E_INVALID, "gather transfer outside buffer %u", buffer);
-    }
-    const ncclResult_t e = t.is_recv ? R->Recv(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream)
-                                     : R->Send(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream);
-    if (e != ncclSuccess) {
-      (void)R->GroupEnd();
-      set_error("ncclSend/ncclRecv failed: %s", R->GetErrorString(e));
-      return HK_E_HIP;
-    }
-    if (t.is_recv) cm->bytes_received += t.bytes;
-  }
-  HK_NCCL(R, R->GroupEnd());
-  return HK_OK;
+  return run_transfers(c, cm, R, tr.data(), tr.size(), (hipStream_t)ci.stream);
 }
 
 void comm_release(hk_ctx* c) {
@@ -533,6 +520,32 @@ int hk_comm_set_history_rows(hk_ctx* c, uint32_t rows) { return hk_set_history_r
 int hk_comm_exchange(hk_ctx* c, uint32_t stage, const HkSettings* st) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   return comm_exchange(c, stage, st);
+}
+
+// hikari_hip_debug.h: rows [row_begin, row_end) of `src_buffer` travel to the same rows of `dst_buffer` of the SAME context as an
+// ncclSend to the own rank paired with an ncclRecv from it - the group, the calls and the stream the halo exchanges use, on a box
+// with one GPU (RCCL refuses two ranks on one device, so this is the one way the send / receive path can execute there)
+int hk_debug_comm_loopback(hk_ctx* c, uint32_t src_buffer, uint32_t dst_buffer, uint32_t row_begin, uint32_t row_end) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
+  HK_REQUIRE(cm && cm->comm, HK_E_NOT_READY, "no communicator attached (hk_comm_init)");
+  Rccl* R = rccl();
+  HK_REQUIRE(R, HK_E_UNSUPPORTED, "librccl could not be loaded");
+  CtxInfo ci;
+  int rc = ctx_info(c, &ci);
+  if (rc) return rc;
+  uint32_t sw = 0, sh = 0, sb = 0, dw = 0, dh = 0, db = 0;
+  if ((rc = hk_buffer_info(c, src_buffer, &sw, &sh, &sb)) || (rc = hk_buffer_info(c, dst_buffer, &dw, &dh, &db))) return rc;
+  HK_REQUIRE(src_buffer != dst_buffer && sw == dw && sh == dh && sb == db && row_begin < row_end && row_end <= sh, HK_E_INVALID, "the two buffers must have one shape and the rows lie inside it");
+  const uint64_t row_bytes = (uint64_t)sw * sb;
+  HkTransfer tr[2] = {};
+  tr[0].buffer = src_buffer; tr[0].peer = cm->rank; tr[0].is_recv = 0; tr[0].offset = row_begin * row_bytes; tr[0].bytes = (row_end - row_begin) * row_bytes;
+  tr[1] = tr[0];
+  tr[1].buffer = dst_buffer; tr[1].is_recv = 1;
+  HK_HIP(hipSetDevice(ci.device));
+  if ((rc = run_transfers(c, cm, R, tr, 2, (hipStream_t)ci.stream))) return rc;
+  cm->exchanges += 1;
+  return HK_OK;
 }
 
 int hk_comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root) {

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/hikari_hip.h"
+#include "../../include/hikari_hip_debug.h"
 
 namespace hk {
 

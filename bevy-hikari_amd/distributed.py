@@ -280,9 +280,9 @@ class BandRenderer:
         e = self.engine
         sc = settings.to_c()
         if self.world > 1:
-            if history_rows is None and e.api.prefix != "hk_":
-                # (the CPU tests' oracle behind the same class has no host logic of its own: the bound comes from the product
-                # library's pure function, for the static scenes those tests render)
+            if history_rows is None and "history_rows_bound" not in e.api._fns:
+                # (an engine whose library has no host logic of its own - the CPU tests' checker behind the same class: the bound
+                # comes from the product library's pure function, for the static scenes those tests render)
                 _w, rh, _b = e.buffer_info(F.BUF_TONE_MAPPED)
                 history_rows = history_rows_bound(view, previous_view, rh, *e.scene_bounds())
             e.set_history_rows(F.HISTORY_AUTO if history_rows is None else int(history_rows))
@@ -318,7 +318,7 @@ class BandRenderer:
                 self.exchange(F.STAGE_UPSCALE, frame.number, sc, width, height, ratio)
                 e.frame_stage(F.STAGE_UPSCALE, sc)
         if gather:   # rank 0 collects the finished image
-            self.gather(F.api().final_buffer(sc, F.FRAME_ANTIALIAS if antialias else 0) if e.api.prefix == "hk_" else _final_buffer(settings, antialias),
+            self.gather(e.api.final_buffer(sc, F.FRAME_ANTIALIAS if antialias else 0) if hasattr(e.api, "final_buffer") else _final_buffer(settings, antialias),
                         settings, width, height, frame.number)
 
     def band(self, rows):

@@ -410,7 +410,7 @@ class Engine:
     def __init__(self, api=None, device=0, flags=0):
         self.api = api or F.api()
         self.ctx = C.c_void_p()
-        self.api.call("create", device, flags | (F.DEFAULT_CTX_FLAGS if self.api.prefix == "hk_" else 0), C.byref(self.ctx))
+        self.api.call("create", device, flags | F.DEFAULT_CTX_FLAGS, C.byref(self.ctx))
         self.width = self.height = 0
         self.owned = True
         self.generation = 0  # bumped by resize(): holders of device pointers / views compare it (distributed.BandRenderer)
@@ -647,6 +647,11 @@ class Engine:
     def comm_gather(self, buffer, root=0):
         """hk_comm_gather: rank `root` collects every other rank's rows of `buffer` (RCCL, on the context's stream)."""
         self.api.call("comm_gather", self.ctx, buffer, root)
+
+    def debug_comm_loopback(self, src_buffer, dst_buffer, row_begin, row_end):
+        """hk_debug_comm_loopback (hikari_hip_debug.h): rows of one buffer to the same rows of another through ncclSend / ncclRecv
+        to the context's own rank, on the context's stream."""
+        self.api.call("debug_comm_loopback", self.ctx, src_buffer, dst_buffer, row_begin, row_end)
 
     def comm_destroy(self):
         self.api.call("comm_destroy", self.ctx)

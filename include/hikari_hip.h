@@ -506,8 +506,6 @@ int hk_refit_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t* moved);
  * hk_upload_scene_instances gives (the reference's path), minus the two host-side SAH builds that dominate it. */
 int hk_update_scene_instances(hk_ctx* ctx, hk_scene_builder* b, uint32_t tree_mode);
 int hk_rebuild_scene_trees(hk_ctx* ctx, uint32_t mode);
-/* Test hook: the instance tree (ordering 0) and the light tree as the device holds them, in the reference's HkNode layout. */
-int hk_debug_read_trees(hk_ctx* ctx, HkNode* instance_nodes, uint32_t instance_cap, HkNode* emissive_nodes, uint32_t emissive_cap);
 int hk_upload_textures(hk_ctx* ctx, const HkImageDesc* images, uint32_t n_images);
 /* InstanceRenderAssets::set + write_buffer, instance.rs:82-108 */
 int hk_upload_instances(hk_ctx* ctx, const HkInstance* instances, uint32_t n_instances, const HkNode* instance_nodes,
@@ -766,21 +764,7 @@ int hk_indirect_schedule(hk_ctx* ctx, uint32_t* out);
 #define HK_TRAVERSAL_ONE_LEVEL 2u
 int hk_traversal_mode(hk_ctx* ctx, uint32_t* out, uint32_t* orderings);
 
-/* Measurement hook ("measure the empirical HBM ceiling with a device copy/triad kernel in the same run"): streams
- * three private arrays of `bytes_per_array` bytes (use >= 1 GiB: the 256 MB Infinity Cache must not hold them) `reps` times
- * on the context's stream and returns the sustained rates in GB/s (1e9), HIP events around the launches: copy a = b moves
- * 2 x bytes per pass, triad a = b + s * c moves 3 x bytes. */
-int hk_measure_hbm(hk_ctx* ctx, size_t bytes_per_array, uint32_t reps, double* copy_gbs, double* triad_gbs);
-/* Measurement hook for the OTHER roof of the ray kernels: the rate at which the chip issues wave64 VALU instructions, in
- * 1e9 wave-instructions per second, from a register-only kernel of eight independent v_fma_f32 chains per lane (64 x iters
- * instructions per wave) run with 1, 2, 4 and 8 waves resident per SIMD (ginstr_s[0..3]).  One wave alone issues about one
- * instruction per 6 cycles; the ceiling (one per ~2 cycles per SIMD) needs four or more waves per SIMD. */
-int hk_measure_valu(hk_ctx* ctx, uint32_t iters, double ginstr_s[4]);
-
-/* Test hook: evaluate one of the library's device math routines elementwise (op: 0 sin, 1 cos,
- * 2 exp, 3 exp2, 4 log2, 5 pow(x, y), 6 min(x,y), 7 max(x,y), 8 f32->f16->f32, 9 x/y, 10 sqrt).
- * x, y, out are HOST arrays. */
-int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, float* out, size_t n);
+/* Test and measurement hooks (hk_debug_*, hk_measure_*) are declared in hikari_hip_debug.h: a host that renders binds none of them. */
 
 #ifdef __cplusplus
 }

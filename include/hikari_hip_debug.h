@@ -1,0 +1,43 @@
+/* hikari_hip_debug.h - test and measurement hooks of libhikari_hip.so.
+ *
+ * Not part of the drop-in boundary (include/hikari_hip.h is what a Bevy host binds): these entry points exist for the parity
+ * tests (tests/), the benchmark's in-run ceilings (bench.py) and the profiling tools (tools/).  Same library, same C ABI rules. */
+#ifndef HIKARI_HIP_DEBUG_H
+#define HIKARI_HIP_DEBUG_H
+
+#include "hikari_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: the instance tree (ordering 0) and the light tree as the device holds them, in the reference's HkNode layout. */
+int hk_debug_read_trees(hk_ctx* ctx, HkNode* instance_nodes, uint32_t instance_cap, HkNode* emissive_nodes, uint32_t emissive_cap);
+
+/* Measurement hook ("measure the empirical HBM ceiling with a device copy/triad kernel in the same run"): streams
+ * three private arrays of `bytes_per_array` bytes (use >= 1 GiB: the 256 MB Infinity Cache must not hold them) `reps` times
+ * on the context's stream and returns the sustained rates in GB/s (1e9), HIP events around the launches: copy a = b moves
+ * 2 x bytes per pass, triad a = b + s * c moves 3 x bytes. */
+int hk_measure_hbm(hk_ctx* ctx, size_t bytes_per_array, uint32_t reps, double* copy_gbs, double* triad_gbs);
+/* Measurement hook for the OTHER roof of the ray kernels: the rate at which the chip issues wave64 VALU instructions, in
+ * 1e9 wave-instructions per second, from a register-only kernel of eight independent v_fma_f32 chains per lane (64 x iters
+ * instructions per wave) run with 1, 2, 4 and 8 waves resident per SIMD (ginstr_s[0..3]).  One wave alone issues about one
+ * instruction per 6 cycles; the ceiling (one per ~2 cycles per SIMD) needs four or more waves per SIMD. */
+int hk_measure_valu(hk_ctx* ctx, uint32_t iters, double ginstr_s[4]);
+
+/* Test hook: evaluate one of the library's device math routines elementwise (op: 0 sin, 1 cos,
+ * 2 exp, 3 exp2, 4 log2, 5 pow(x, y), 6 min(x,y), 7 max(x,y), 8 f32->f16->f32, 9 x/y, 10 sqrt).
+ * x, y, out are HOST arrays. */
+int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, float* out, size_t n);
+
+/* Test hook for the RCCL data path on a box with ONE GPU (RCCL refuses two ranks on one device, so no halo exchange between
+ * ranks can run there): rows [row_begin, row_end) of `src_buffer` travel to the same rows of `dst_buffer` (same shape) of the
+ * SAME context as an ncclSend to the context's own rank paired with an ncclRecv from it, inside one ncclGroupStart / ncclGroupEnd,
+ * on the context's stream - the very function (comm.cpp run_transfers) hk_frame_render's exchanges and hk_comm_gather go
+ * through.  Needs hk_comm_init (a communicator of any size; 1 rank on a one-GPU box). */
+int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer, uint32_t row_begin, uint32_t row_end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -12,10 +12,50 @@ ORACLE_LIB = os.path.join(ROOT, "oracle", "_build", "libhikari_oracle.so")
 _API = None
 
 
+class OracleApi:
+    """The oracle's entry points behind the interface of bevy_hikari_amd._ffi.Api (call / raw / _fns / last_error / abi_version):
+    the oracle exports the frame-path part of the C ABI (F._SIGNATURES) with the prefix `orc_`, plus orc_debug_math."""
+
+    prefix = "orc_"
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found - build it first (make -C oracle)")
+        self.path = path
+        self.dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self._fns = {}
+        table = dict(F._SIGNATURES)
+        table["debug_math"] = F._DEBUG["debug_math"]
+        for name, argtypes in table.items():
+            fn = getattr(self.dll, "orc_" + name)
+            fn.argtypes, fn.restype = argtypes, C.c_int
+            self._fns[name] = fn
+        self.dll.orc_destroy.argtypes, self.dll.orc_destroy.restype = [C.c_void_p], None
+        self._fns["destroy"] = self.dll.orc_destroy
+        self.dll.orc_last_error.restype = C.c_char_p
+        self.dll.orc_abi_version.restype = F.u32
+
+    def abi_version(self):
+        return int(self.dll.orc_abi_version())
+
+    def last_error(self):
+        msg = self.dll.orc_last_error()
+        return msg.decode() if msg else ""
+
+    def raw(self, name):
+        return self._fns[name]
+
+    def call(self, name, *args):
+        rc = self._fns[name](*args)
+        if rc is not None and rc != F.HK_OK:
+            raise F.HikariError(rc, "orc_" + name, self.last_error())
+        return rc
+
+
 def oracle_api():
     global _API
     if _API is None:
-        _API = F.Api(ORACLE_LIB, "orc_")
+        _API = OracleApi(ORACLE_LIB)
         for name, argtypes in {
             "orc_set_threads": [C.c_int],
             "orc_kat_intersects_aabb": [C.POINTER(F.f32)] * 4 + [C.POINTER(F.f32)],

@@ -10,10 +10,11 @@ from bevy_hikari_amd import _ffi as F
 from conftest import ROOT, has_gpu
 
 HEADER = os.path.join(ROOT, "include", "hikari_hip.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "hikari_hip_debug.h")
 
 
-def header_functions():
-    text = open(HEADER).read()
+def header_functions(path=HEADER):
+    text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hk_[a-z_0-9]+)\s*\(", text)))
 
@@ -27,6 +28,10 @@ def test_library_exports_every_declared_symbol():
     # and the binding table covers the header (no silently unbound entry points)
     assert set(names) == set(F.DECLARED_SYMBOLS), set(names) ^ set(F.DECLARED_SYMBOLS)
     assert api.abi_version() == 7
+    # the boundary a host binds carries no test or measurement hooks: those live in hikari_hip_debug.h (same library)
+    assert not [n for n in names if n.startswith(("hk_debug_", "hk_measure_"))]
+    debug = header_functions(DEBUG_HEADER)
+    assert set(debug) == set(F.DECLARED_DEBUG_SYMBOLS) and all(hasattr(api.dll, n) for n in debug), set(debug) ^ set(F.DECLARED_DEBUG_SYMBOLS)
 
 
 def test_struct_layouts_are_std430():

@@ -305,6 +305,42 @@ def test_rccl_single_rank_communicator():
     e.comm_destroy()
 
 
+def test_rccl_send_and_receive_execute_on_the_stream():
+    """RCCL refuses two ranks on one device, so on a one-GPU box no halo exchange BETWEEN ranks can run - but
+    a rank may send to itself inside a group.  hk_debug_comm_loopback moves rows of one buffer to another buffer of the same
+    context through the very function hk_frame_render's exchanges use (comm.cpp run_transfers: ncclGroupStart, ncclSend,
+    ncclRecv, ncclGroupEnd on the context's stream).  Enqueued between two frames with no host wait anywhere: the rows that arrive
+    are what the frame BEFORE wrote (the exchange is ordered behind the kernels) and not what the frame AFTER writes over the
+    source (the kernels are ordered behind the exchange); rows outside the range stay untouched."""
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0, denoise=False)   # (denoise off: the denoiser's outputs are free scratch)
+    w, h = 256, 144
+    cam = hk.cornell_camera(w, h)
+    view, pview, lights = cam.view_uniform(), cam.previous_view_uniform(), hk.lights_uniform()
+    e, ref = hk.Engine(device=0), hk.Engine(device=0)
+    for t in (e, ref):
+        t.upload_noise(); t.upload_scene(hk.load_cornell()); t.resize(w, h, 1.0)
+    e.comm_init(0, 1, e.comm_unique_id())
+    src, dst, rows = F.BUF_RENDER0 + 2, F.BUF_DENOISE_RENDER0 + 2, (37, 101)
+    ref.frame_render(hk.frame_uniform(s, 1), view, pview, lights, s.to_c())
+    first = ref.read(src)
+    ref.frame_render(hk.frame_uniform(s, 2), view, pview, lights, s.to_c())
+    second = ref.read(src)
+    assert (first[rows[0]:rows[1]] != second[rows[0]:rows[1]]).any() and first[rows[0]:rows[1]].any()
+    e.frame_render(hk.frame_uniform(s, 1), view, pview, lights, s.to_c())
+    e.debug_comm_loopback(src, dst, *rows)
+    e.frame_render(hk.frame_uniform(s, 2), view, pview, lights, s.to_c())
+    e.wait()
+    got = e.read(dst)
+    assert (got[rows[0]:rows[1]] == first[rows[0]:rows[1]]).all(), "the rows RCCL delivered are not what the frame before the exchange wrote"
+    assert not got[:rows[0]].any() and not got[rows[1]:].any()
+    assert (e.read(src) == second).all()
+    with pytest.raises(hk.HikariError):
+        e.debug_comm_loopback(src, F.BUF_POSITION, *rows)    # another shape
+    e.comm_destroy()
+    with pytest.raises(hk.HikariError):
+        e.debug_comm_loopback(src, dst, *rows)               # no communicator
+
+
 def test_multi_create_rejects_bad_devices():
     with pytest.raises(hk.HikariError) as err:
         MultiEngine([0, 99])
