@@ -685,7 +685,7 @@ int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t t
   const int rq = hk_scene_builder_instances(b, &inst, &ni);
   if (rq) return rq;
   for (hk_ctx* c : m->ctx) {
-    int r = hk_upload_scene_instances(c, b);
+    int r = upload_scene_instances_unchecked(c, b);   // (stand-in trees: the device build follows)
     if (!r && ni >= 2) r = hk_rebuild_scene_trees(c, tree_mode);
     if (r) return r;
   }

@@ -1612,8 +1612,13 @@ int hk_upload_previous_transforms(hk_ctx* c, const float* models, uint32_t n) {
   c->dynamic_dirty = true;
   return HK_OK;
 }
+#define HK_NO_STANDINS(b)                                                                                                        \
+  HK_REQUIRE(!builder_has_standin_trees(b), HK_E_NOT_READY,                                                                      \
+             "the builder holds stand-in trees (hk_scene_builder_finish_instances): finish it with hk_scene_builder_finish, or use " \
+             "hk_update_scene_instances, which builds the trees on the device")
 int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
+  HK_NO_STANDINS(b);  // (frames from stand-in trees would differ silently in tie-breaks and visit order)
   const HkVertex* v; const HkPrimitive* p; const HkNode *an, *in_, *en; const HkMaterial* m; const HkInstance* inst; const HkEmissive* em; const HkAliasEntry* al;
   uint32_t nv, np, nan_, nm, ni, nin, ne, nen, nal;
   int rc;
@@ -1635,6 +1640,12 @@ int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
 }
 int hk_upload_scene_instances(hk_ctx* c, const hk_scene_builder* b) {
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
+  HK_NO_STANDINS(b);
+  return hk::upload_scene_instances_unchecked(c, b);
+}
+}  // extern "C"
+int hk::upload_scene_instances_unchecked(hk_ctx* c, const hk_scene_builder* b) {
+  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
   HK_REQUIRE(c->have_meshes && c->have_materials, HK_E_NOT_READY, "hk_upload_scene must come first");
   const HkNode *in_, *en; const HkInstance* inst; const HkEmissive* em; const HkAliasEntry* al; const float* pm;
   uint32_t ni, nin, ne, nen, nal, npm;
@@ -1648,6 +1659,7 @@ int hk_upload_scene_instances(hk_ctx* c, const hk_scene_builder* b) {
   if ((rc = hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal))) return rc;
   return hk_upload_previous_transforms(c, pm, npm);
 }
+extern "C" {
 
 // Instances added, removed or re-materialed (the reference re-runs prepare_instances for ANY instance change, instance.rs:352-437):
 // the per-instance / per-emitter records are laid out on the host - O(instances), no tree build - and go to the spare slot through
@@ -1663,7 +1675,7 @@ int hk_update_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t tree_mode
   const double t0 = now();
   if ((rc = hk_scene_builder_finish_instances(b))) return rc;
   const double t1 = now();
-  if ((rc = hk_upload_scene_instances(c, b))) return rc;
+  if ((rc = upload_scene_instances_unchecked(c, b))) return rc;
   const double t2 = now();
   uint32_t ni = 0;
   const HkInstance* inst = nullptr;
@@ -1673,6 +1685,10 @@ int hk_update_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t tree_mode
   c->trees_pending_on_device = false;
   const double t3 = now();
   if (!rc && ni >= 2) rc = hk_rebuild_scene_trees(c, tree_mode);  // (a tree of one leaf is what the host just laid out)
+  // the region just uploaded carries stand-in trees with orderings 1..7 left zero (the device build was to overwrite
+  // them in stream order).  If that build did not get enqueued, a threaded walk over zero nodes would never leave node 0: the
+  // next use of the scene lays the region out again, from the host's (valid) stand-in trees, all orderings threaded.
+  if (rc) c->dynamic_dirty = true;
   if (trace) fprintf(stderr, "hk_update_scene_instances: finish_instances %.2f ms, mirrors %.2f ms, layout + upload %.2f ms, device build enqueue %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
   return rc;
 }

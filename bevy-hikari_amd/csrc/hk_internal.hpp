@@ -36,6 +36,10 @@ struct InstanceDecl {
   const float* aabb_half;
 };
 uint32_t builder_instance_count(const hk_scene_builder* b);
+// the builder was finished by hk_scene_builder_finish_instances: its two trees are valid STAND-INS (index list halved recursively)
+// for a device-side build, not the reference's SAH trees - only hk_update_scene_instances may upload them
+bool builder_has_standin_trees(const hk_scene_builder* b);
+int upload_scene_instances_unchecked(hk_ctx* c, const hk_scene_builder* b);  // hk_upload_scene_instances without that check (context.hip)
 bool builder_instance_decl(const hk_scene_builder* b, uint32_t i, InstanceDecl* out);
 // what hk_scene_builder_finish does to the PreviousMeshUniform bookkeeping, without building anything
 void builder_commit_transforms(hk_scene_builder* b);

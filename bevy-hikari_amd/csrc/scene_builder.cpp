@@ -261,6 +261,7 @@ struct hk_scene_builder {
   std::vector<HkMaterial> materials;
   std::vector<hk::BuilderInstance> instance_decl;
   bool finished = false;
+  bool standin_trees = false;             // finished by hk_scene_builder_finish_instances: the two trees are valid stand-ins, not the reference's
   bool meshes_dirty = true;               // the concatenated mesh buffers must be rebuilt
   std::vector<float> finished_transforms;  // transforms at the last finish ...
   std::vector<float> previous_transforms;  // ... and at the one before (PreviousMeshUniform)
@@ -388,6 +389,7 @@ bool instance_world_record(const float transform[16], const float aabb_center[3]
   }
   return inverse_transpose(transform, itm);
 }
+bool builder_has_standin_trees(const hk_scene_builder* b) { return b && b->finished && b->standin_trees; }
 uint32_t builder_instance_count(const hk_scene_builder* b) { return b ? (uint32_t)b->instance_decl.size() : 0u; }
 bool builder_instance_decl(const hk_scene_builder* b, uint32_t i, InstanceDecl* out) {
   // (poses set since the last finish are exactly what the caller is after; the MESH buffers must be the finished ones)
@@ -618,6 +620,7 @@ static int finish_impl(hk_scene_builder* b, bool build_trees) {
   for (uint32_t n = 0; n < b->emissive_nodes.size(); ++n)
     if (b->emissive_nodes[n].entry_index >= HK_BVH_LEAF_FLAG) b->emissives[b->emissive_nodes[n].entry_index - HK_BVH_LEAF_FLAG].node_index = n;
   b->finished = true;
+  b->standin_trees = !build_trees && (b->instances.size() > 1 || b->emissives.size() > 1);  // (a tree of one leaf has one shape)
   return HK_OK;
 }
 

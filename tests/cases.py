@@ -158,6 +158,50 @@ def diff_buffers(a, b):
     return bad
 
 
+def product_default_plugin(flags=0):
+    """A plugin in the mode bench.py times: no suite-wide HK_CTX_EXACT_TRAVERSAL, no ray counters - one-level walk from LDS for
+    scenes under one transform, direction-threaded trees + the queue-based indirect pass beyond LDS."""
+    with product_default_traversal():
+        return hk.HikariPlugin(device=0, flags=flags)
+
+
+def _as_float(x):
+    if x.dtype == np.uint16:   # rgba16f
+        return x.view(np.float16).astype(np.float32)
+    if x.dtype == np.uint32:   # rgba8snorm normals
+        b = x.view(np.int8).astype(np.float32)
+        return np.maximum(b / 127.0, -1.0)
+    return x.astype(np.float32)
+
+
+def rendered_deviation(a, b):
+    """{name: (relative L2, fraction of pixels with any differing byte)} over every RENDERED buffer of two snapshots - everything a
+    frame's consumers see: the G-buffer, albedo, render / variance, the denoiser's planes, the tone-mapped image and the
+    anti-aliasing tail.  (Not the reservoir records: an any-hit walk in another order may report another occluder in the
+    sample_position of an occluded shadow sample, which nothing rendered reads - DESIGN 0.)"""
+    out = {}
+    for name in a:
+        if name.startswith("reservoir"):
+            continue
+        x, y = a[name], b[name]
+        ne = (x.view(np.uint8).reshape(x.shape[0], x.shape[1], -1) != y.view(np.uint8).reshape(y.shape[0], y.shape[1], -1)).any(axis=2)
+        if not ne.any():
+            out[name] = (0.0, 0.0)
+            continue
+        fx, fy = np.nan_to_num(_as_float(x), posinf=0.0, neginf=0.0), np.nan_to_num(_as_float(y), posinf=0.0, neginf=0.0)
+        out[name] = (float(np.linalg.norm(fx - fy) / max(float(np.linalg.norm(fy)), 1e-30)), float(ne.mean()))
+    return out
+
+
+def assert_rendered_within(a, b, what, tol=1e-3):
+    """The north star's bar for a mode that may visit candidates in another order than the reference: relative L2 <= 1e-3 per
+    buffer.  Returns (worst relative L2, worst differing-pixel fraction) for the report."""
+    dev = rendered_deviation(a, b)
+    bad = {k: v for k, v in dev.items() if not v[0] <= tol}
+    assert not bad, f"{what}: {bad}"
+    return max(v[0] for v in dev.values()), max(v[1] for v in dev.values())
+
+
 GBUFFER_IDS = (F.BUF_POSITION, F.BUF_NORMAL, F.BUF_DEPTH_GRADIENT, F.BUF_INSTANCE_MATERIAL, F.BUF_VELOCITY_UV)
 
 

@@ -383,6 +383,29 @@ def test_instance_edits_on_a_two_slot_scene_and_lbvh_trees():
     assert np.isfinite(out).all() and out[..., :3].max() > 0.05
 
 
+def test_stand_in_trees_only_reach_the_device_through_the_update_that_rebuilds_them():
+    """hk_scene_builder_finish_instances leaves valid but NON-reference trees in the builder (for the device build of
+    hk_update_scene_instances).  The plain upload paths refuse such a builder - frames from stand-in trees would differ silently in
+    tie-breaks and visit order - and hk_update_scene_instances, which does take it, leaves the device with the reference's trees."""
+    from bevy_hikari_amd.scenes import synthetic_scene
+
+    scene, _ = synthetic_scene(n_boxes=9, n_spheres=2, n_emitters=3, sphere_rings=4, sphere_segs=5)
+    e = hk.Engine(device=0)
+    e.upload_noise(); e.upload_scene(scene); e.resize(64, 48, 1.0)
+    b = scene.builder
+    b.add_instance(0, 1, _pose_matrix((0.3, 0.9, -0.4), 0.4, (0.5, 0.5, 0.5)))
+    b.finish(build_trees=False)
+    for call in ("upload_scene", "upload_scene_instances"):
+        with pytest.raises(hk.HikariError) as err:
+            e.api.call(call, e.ctx, b.h)
+        assert err.value.code == F.HK_E_NOT_READY and "stand-in" in str(err.value)
+    e.update_instances_on_device(b)             # finishes again (stand-ins), uploads, builds both trees on the device
+    full = b.finish()                           # the reference's trees for the same instances
+    got = e.read_trees(len(full.instance_nodes), len(full.emissive_nodes))
+    assert same_links(got[0], full.instance_nodes) and same_links(got[1], full.emissive_nodes)
+    e.api.call("upload_scene_instances", e.ctx, b.h)   # a fully finished builder is welcome again
+
+
 def _pose_matrix(t, yaw, scale):
     c, s = math.cos(yaw), math.sin(yaw)
     m = np.array([[c * scale[0], 0, s * scale[2], t[0]], [0, scale[1], 0, t[1]], [-s * scale[0], 0, c * scale[2], t[2]], [0, 0, 0, 1]], dtype=np.float64)

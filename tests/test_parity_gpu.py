@@ -11,7 +11,7 @@ import pytest
 
 import bevy_hikari_amd as hk
 from bevy_hikari_amd import _ffi as F
-from cases import ALL_BUFFERS, CASE_NAMES, diff_buffers, make_case, run_case, snapshot
+from cases import ALL_BUFFERS, CASE_NAMES, assert_rendered_within, diff_buffers, make_case, product_default_plugin, run_case, snapshot
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
@@ -24,17 +24,33 @@ def oracle():
     return oracle_plugin()
 
 
+def report(name, data):
+    """Printed, and kept under gpurun_out/ when the suite runs on the GPU box (copied to profiles/ by the round's scripts)."""
+    print(name, data)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        with open(os.path.join(out_dir, name + ".json"), "w") as f:
+            json.dump(data, f, indent=1)
+
+
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_bit_exact_vs_oracle_every_frame(name):
+    """Every buffer of every frame, bit for bit, in the reference's walk (the suite's HK_CTX_EXACT_TRAVERSAL) - and, beside it, the
+    SAME frames from a context in the product default (what bench.py times: flags 0, no counters) held to the oracle directly:
+    every rendered buffer within the north star's 1e-3."""
     case = make_case(name)
-    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
-    gpu.set_scene(case.scene)
-    cpu.set_scene(case.scene)
+    gpu, cpu, dflt = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle(), product_default_plugin()
+    for p in (gpu, cpu, dflt):
+        p.set_scene(case.scene)
     for n in case.frames:
-        for p in (gpu, cpu):
+        for p in (gpu, cpu, dflt):
             p.render(case.camera, case.settings, lights=case.lights, frame_number=n, antialias=case.antialias)
-        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        want = snapshot(cpu)
+        bad = diff_buffers(snapshot(gpu), want)
         assert bad == {}, f"{name} frame {n}: {bad}"
+        assert_rendered_within(snapshot(dflt), want, f"{name} frame {n}, product default mode")
     sg, sc = gpu.engine.stats(), cpu.engine.stats()
     assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)
 
@@ -56,6 +72,11 @@ def test_matches_golden_fixture(name):
     if base == "denoise_render":
         b = np.stack([g[f"denoise_render{i}"].view(np.float16).astype(np.float32) for i in range(3)])
         assert np.linalg.norm(a - b) <= 1e-3 * np.linalg.norm(b)
+        # the product default mode (what bench.py times) against the same committed frames, no oracle in the loop
+        dflt = product_default_plugin()
+        run_case(dflt, case)
+        a = dflt.output(case.settings)
+        assert np.linalg.norm(a - b) <= 1e-3 * np.linalg.norm(b), f"{name}: product default mode vs the golden fixture"
 
 
 def test_nodes_path_equals_frame_render():
@@ -72,14 +93,20 @@ def test_full_size_1080p_vs_oracle():
     """BASELINE config 2 at its real size: three frames, every buffer, bit for bit."""
     s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
     scene, cam = hk.load_cornell(), hk.cornell_camera(1920, 1080)
-    gpu, cpu = hk.HikariPlugin(device=0), oracle()
-    for p in (gpu, cpu):
+    gpu, cpu, dflt = hk.HikariPlugin(device=0), oracle(), product_default_plugin()
+    for p in (gpu, cpu, dflt):
         p.set_scene(scene)
+    assert dflt.engine.traversal_mode()[0] == "one-level"
     for n in (1, 2, 3):
-        for p in (gpu, cpu):
+        for p in (gpu, cpu, dflt):
             p.render(cam, s, frame_number=n)
-    bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+    want = snapshot(cpu)
+    bad = diff_buffers(snapshot(gpu), want)
     assert bad == {}, bad
+    # the kernels bench.py TIMES - one-level walk from LDS, no counters, frame pipelining - against the oracle directly, at the size
+    # the metric is quoted on (VERDICT r03 weak 2: until now only through a chain of replays)
+    rel, frac = assert_rendered_within(snapshot(dflt), want, "config 2 at 1920x1080, product default mode")
+    report("default_mode_config2_1080p_vs_oracle", {"worst_relative_l2": rel, "worst_fraction_of_pixels_differing": frac, "frames": 3})
 
 
 def test_full_size_properties_4k_8_bounces():
@@ -300,14 +327,20 @@ def test_config3_full_1080p_vs_oracle():
     s = hk.HikariSettings(indirect_bounces=3, upscale=hk.Upscale.SMAA_TU_1_0)
     cam = synthetic_camera(1920, 1080, extent=9.0)
     lights = hk.lights_uniform(directional=sun)
-    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
-    for p in (gpu, cpu):
+    gpu, cpu, dflt = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle(), product_default_plugin()
+    for p in (gpu, cpu, dflt):
         p.set_scene(scene)
+    worst = (0.0, 0.0)
     for n in (1, 2):
-        for p in (gpu, cpu):
+        for p in (gpu, cpu, dflt):
             p.render(cam, s, lights=lights, frame_number=n)
-        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        want = snapshot(cpu)
+        bad = diff_buffers(snapshot(gpu), want)
         assert bad == {}, (n, bad)
+        # what bench.py times for this config - direction-threaded trees, the queue-based indirect pass - against the oracle directly
+        worst = max(worst, assert_rendered_within(snapshot(dflt), want, f"config 3 at 1920x1080 frame {n}, product default mode"))
+    assert dflt.engine.traversal_mode()[0] == "threaded" and dflt.engine.indirect_schedule() == "wavefront"
+    report("default_mode_config3_1080p_vs_oracle", {"worst_relative_l2": worst[0], "worst_fraction_of_pixels_differing": worst[1], "frames": 2})
     sg, sc = gpu.engine.stats(), cpu.engine.stats()
     assert (sg.rays_tlas, sg.rays_blas) == (sc.rays_tlas, sc.rays_blas) and sg.rays_tlas > 1920 * 1080 * 2
 
@@ -322,14 +355,19 @@ def test_config4_city_class_vs_oracle():
     s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
     cam = synthetic_camera(640, 360, extent=30.0)
     lights = hk.lights_uniform(directional=sun)
-    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
-    for p in (gpu, cpu):
+    gpu, cpu, dflt = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle(), product_default_plugin()
+    for p in (gpu, cpu, dflt):
         p.set_scene(scene)
+    worst = (0.0, 0.0)
     for n in (1, 2):
-        for p in (gpu, cpu):
+        for p in (gpu, cpu, dflt):
             p.render(cam, s, lights=lights, frame_number=n)
-        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        want = snapshot(cpu)
+        bad = diff_buffers(snapshot(gpu), want)
         assert bad == {}, (n, bad)
+        worst = max(worst, assert_rendered_within(snapshot(dflt), want, f"config 4 (city class) frame {n}, product default mode"))
+    assert dflt.engine.traversal_mode()[0] == "threaded" and dflt.engine.indirect_schedule() == "wavefront"
+    report("default_mode_config4_city_class_vs_oracle", {"worst_relative_l2": worst[0], "worst_fraction_of_pixels_differing": worst[1], "frames": 2})
     sg, sc = gpu.engine.stats(), cpu.engine.stats()
     assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)
     out = gpu.output(s)
@@ -341,14 +379,18 @@ def test_config5_full_4k_8_bounces_vs_oracle():
     frames, every buffer bit for bit against the oracle."""
     s = hk.HikariSettings(indirect_bounces=8, emissive_spatial_reuse=True, denoise=False, upscale=hk.Upscale.SMAA_TU_1_0)
     scene, cam = hk.load_cornell(), hk.cornell_camera(3840, 2160)
-    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
-    for p in (gpu, cpu):
+    gpu, cpu, dflt = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle(), product_default_plugin()
+    for p in (gpu, cpu, dflt):
         p.set_scene(scene)
     for n in (1, 2):
-        for p in (gpu, cpu):
+        for p in (gpu, cpu, dflt):
             p.render(cam, s, frame_number=n)
-    bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+    want = snapshot(cpu)
+    bad = diff_buffers(snapshot(gpu), want)
     assert bad == {}, bad
+    rel, frac = assert_rendered_within(snapshot(dflt), want, "config 5 at 3840x2160 x 8 bounces, product default mode")
+    assert dflt.engine.traversal_mode()[0] == "one-level"
+    report("default_mode_config5_4k_vs_oracle", {"worst_relative_l2": rel, "worst_fraction_of_pixels_differing": frac, "frames": 2})
     sg, sc = gpu.engine.stats(), cpu.engine.stats()
     assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)
 
