@@ -215,7 +215,7 @@ struct hk_multi {
   std::vector<int> device;
   std::vector<hipEvent_t> produced, copied;  // per context: "my stage is enqueued up to here" / "my incoming copies are enqueued up to here"
   std::deque<Comm::Cached> cache;
-  uint64_t exchanges = 0, bytes_copied = 0;
+  uint64_t bytes_copied = 0;
   MultiPool* pool = nullptr;  // one enqueue thread per band (hk_multi_frame_render), created on first use
 };
 
@@ -322,7 +322,6 @@ int multi_exchange(hk_multi* m, uint32_t stage_arg, const HkSettings* st) {
     for (uint32_t i = 0; i < n; ++i)
       if (read_by[p * n + i]) HK_HIP(hipStreamWaitEvent((hipStream_t)ci[p].stream, m->copied[i], 0));
   }
-  m->exchanges += 1;
   return HK_OK;
 }
 
@@ -412,6 +411,7 @@ void pool_worker(hk_multi* m, uint32_t i) {
       seen = P->job_id;
       job = P->job;
     }
+    set_error("%s", "");  // (this thread's error string: a band that fails only because another one did must not report a message of an earlier frame)
     const int rc = band_frame(m, i, job);
     {
       std::lock_guard<std::mutex> lk(P->mu);
@@ -746,7 +746,6 @@ static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView*
         P->cv_job.notify_all();
         P->cv_done.wait(lk, [&] { return P->done == P->n; });
       }
-      m->exchanges += 1;
       for (uint32_t i = 0; i < P->n; ++i) {
         m->bytes_copied += P->bytes[i];
         P->bytes[i] = 0;

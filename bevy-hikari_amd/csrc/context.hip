@@ -1918,6 +1918,17 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
     if (commit) builder_commit_transforms(b);
     return HK_OK;
   }
+  // the records of moved emitters first (k_refit_emitters runs one wave per such record and on no other)
+  uint32_t n_emitter_updates = 0, emitter_triangles = 0;
+  {
+    std::vector<uint8_t> is_emitter(ni, 0);
+    for (const HkEmissive& e : c->emissives)
+      if (e.instance < ni) is_emitter[e.instance] = 1;
+    auto mid = std::stable_partition(records.begin(), records.end(), [&](const hkd::RefitUpdate& u) { return u.moved && is_emitter[u.instance]; });
+    n_emitter_updates = (uint32_t)(mid - records.begin());
+    for (uint32_t k = 0; k < n_emitter_updates; ++k)
+      emitter_triangles = std::max(emitter_triangles, (c->instances[records[k].instance].mesh.node_count + 2u) / 3u);  // a BLAS over n triangles: 3n - 2 nodes
+  }
   // pinned update records, double-buffered against the kernel that reads them
   const int k = c->rf_k;
   c->rf_k ^= 1;
@@ -1940,7 +1951,7 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
   if ((rc = begin_device_update(c))) return rc;
   const hkd::RefitScene r = refit_scene(c);
   uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  launch_refit(c->stream, r, c->rf_updates[k], (uint32_t)records.size(), nullptr, (float4*)(base + c->dyn_off.tlas), (uint32_t)c->instance_nodes.size(),
+  launch_refit(c->stream, r, c->rf_updates[k], (uint32_t)records.size(), n_emitter_updates, emitter_triangles, nullptr, (float4*)(base + c->dyn_off.tlas), (uint32_t)c->instance_nodes.size(),
                c->threaded ? 8u : 1u, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi), (uint32_t)c->emissive_nodes.size());
   HK_HIP(hipGetLastError());
   HK_HIP(hipEventRecord(c->rf_done[k], c->stream));

@@ -256,7 +256,9 @@ void launch_indirect_wavefront(hipStream_t st, const hkd::DScene& sc, const hkd:
                                const hkd::WfBuffers& w, int y0, int y1, int compute_units, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 void launch_copy_region(hipStream_t st, void* dst, const void* src, size_t bytes);
 void launch_gather_instance_boxes(hipStream_t st, const hkd::RefitScene& s, const float4* tlas, uint32_t tlas_count);
-void launch_refit(hipStream_t st, const hkd::RefitScene& s, const hkd::RefitUpdate* updates, uint32_t n_updates, uint32_t* failed, float4* tlas,
+// the first n_emitter_updates records are the moved emitters (the largest of their meshes has emitter_triangles triangles)
+void launch_refit(hipStream_t st, const hkd::RefitScene& s, const hkd::RefitUpdate* updates, uint32_t n_updates, uint32_t n_emitter_updates, uint32_t emitter_triangles,
+                  uint32_t* failed, float4* tlas,
                   uint32_t tlas_count, uint32_t orderings, float4* light_lo, float4* light_hi, uint32_t light_count);
 // LBVH rebuild of a flat skip-link BVH over n shapes (kernels_scene.hip): scratch size, and the build into `lo` / `hi` (`stride`
 // float4 between consecutive nodes: 2 for the interleaved TLAS, 1 for the two planes of the light BVH)

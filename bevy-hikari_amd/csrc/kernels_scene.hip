@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64) void k_refit_instances(RefitScene s, const Refi
 //   4. the pairing loop pops and pushes the stacks one element at a time: one lane - but on stacks that live in LDS whenever the
 //      five work arrays fit (n <= 3 264), so its dependent loads cost ~100 cycles instead of a trip to L2 each.
 constexpr uint32_t HK_EMITTER_LDS_TRIANGLES = 3264u;  // 5 arrays x 4 B x n <= 65 280 B of dynamic LDS
-__global__ __launch_bounds__(64) void k_refit_emitters(RefitScene s, const RefitUpdate* __restrict__ updates, uint32_t n_updates) {
+__global__ __launch_bounds__(64) void k_refit_emitters(RefitScene s, const RefitUpdate* __restrict__ updates, uint32_t n_updates, uint32_t lds_triangles) {
   extern __shared__ __attribute__((aligned(16))) float emitter_lds[];
   const uint32_t u = blockIdx.x, lane = threadIdx.x;
   if (u >= n_updates) return;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void k_refit_emitters(RefitScene s, const Refit
   DEmissive& em = s.emissives[e];
   const uint32_t prim0 = s.instances[id].primitive;
   const uint32_t n = em.alias_count;  // = the mesh's triangle count
-  float* work = n <= HK_EMITTER_LDS_TRIANGLES ? emitter_lds : s.alias_scratch + 5u * (size_t)em.alias_offset;
+  float* work = n <= lds_triangles ? emitter_lds : s.alias_scratch + 5u * (size_t)em.alias_offset;  // (lds_triangles: what the launch reserved)
   float* areas = work;  // [n] areas, then the two stacks (id, prob) x 2
   uint32_t* over_id = reinterpret_cast<uint32_t*>(work + n);
   float* over_p = work + 2u * (size_t)n;
@@ -892,11 +892,17 @@ void launch_gather_instance_boxes(hipStream_t st, const RefitScene& s, const flo
   if (!tlas_count) return;
   hipLaunchKernelGGL(k_gather_instance_boxes, dim3((tlas_count + 255u) / 256u), dim3(256), 0, st, s, tlas, tlas_count);
 }
-void launch_refit(hipStream_t st, const RefitScene& s, const RefitUpdate* updates, uint32_t n_updates, uint32_t* failed, float4* tlas, uint32_t tlas_count,
+void launch_refit(hipStream_t st, const RefitScene& s, const RefitUpdate* updates, uint32_t n_updates, uint32_t n_emitter_updates, uint32_t emitter_triangles,
+                  uint32_t* failed, float4* tlas, uint32_t tlas_count,
                   uint32_t orderings, float4* light_lo, float4* light_hi, uint32_t light_count) {
   if (n_updates) {
     hipLaunchKernelGGL(k_refit_instances, dim3((n_updates + 63u) / 64u), dim3(64), 0, st, s, updates, n_updates, failed);
-    hipLaunchKernelGGL(k_refit_emitters, dim3(n_updates), dim3(64), HK_EMITTER_LDS_TRIANGLES * 5u * 4u, st, s, updates, n_updates);
+    // the host puts the records of moved EMITTERS first: one workgroup (= one wave) per such record only, with the LDS its largest
+    // mesh needs (a 64 KB reservation on thousands of workgroups that exit at once capped everybody's occupancy)
+    if (n_emitter_updates) {
+      const uint32_t lds_triangles = std::min(emitter_triangles, HK_EMITTER_LDS_TRIANGLES);
+      hipLaunchKernelGGL(k_refit_emitters, dim3(n_emitter_updates), dim3(64), lds_triangles * 5u * 4u, st, s, updates, n_emitter_updates, lds_triangles);
+    }
   }
   // TLAS nodes are interleaved (lo, hi) pairs, the light BVH two planes
   if (tlas_count) {

@@ -176,14 +176,21 @@ class BandRenderer:
         self.engine.set_band_bounds(self.bounds)
         self._plans = {}
 
+    def _follow_resize(self):
+        """Engine.resize frees every buffer, bumps engine.generation and - on the C side - drops an explicit band split (it was in
+        rows of the old render image): views, plans AND the split of an older generation go (a stale split here would
+        move the wrong halo rows while hk_frame_stage renders the equal split)."""
+        gen = getattr(self.engine, "generation", 0)
+        if gen != self._generation:
+            self._views, self._plans, self._generation = {}, {}, gen
+            self.bounds = None
+
     # ------------------------------------------------------------------ host transport (tests)
     def _view(self, buf, parity=0):
         # the double-buffered ids (HkBuffer: position, velocity, tone-mapped, TAA) name a different plane on odd and
         # even frames, so views are kept per frame parity; they are taken after hk_frame_begin of such a frame.
         # Engine.resize frees every buffer and bumps engine.generation: views and plans of an older generation are dropped.
-        gen = getattr(self.engine, "generation", 0)
-        if gen != self._generation:
-            self._views, self._plans, self._generation = {}, {}, gen
+        self._follow_resize()
         key = (buf, parity)
         if key not in self._views:
             torch = self.torch
@@ -204,9 +211,7 @@ class BandRenderer:
     def _transfers(self, stage, frame_number, settings_c, width, height, upscale_ratio):
         """(is_recv, view slice, peer) of hk_band_schedule.  The schedule depends on the frame number only through its
         parity (reservoir ping-pong), so it is built once per (stage, parity, settings) and reused."""
-        gen = getattr(self.engine, "generation", 0)
-        if gen != self._generation:
-            self._views, self._plans, self._generation = {}, {}, gen
+        self._follow_resize()
         key = (stage, frame_number & 1, width, height, upscale_ratio, bytes(settings_c))
         hit = self._plans.get(key)
         if hit is not None:
@@ -279,6 +284,7 @@ class BandRenderer:
         rays) and keep the split; meant for the first frame or a cut (rows that change owner lose their history)."""
         e = self.engine
         sc = settings.to_c()
+        self._follow_resize()
         if self.world > 1:
             if history_rows is None and "history_rows_bound" not in e.api._fns:
                 # (an engine whose library has no host logic of its own - the CPU tests' checker behind the same class: the bound
@@ -323,6 +329,7 @@ class BandRenderer:
 
     def band(self, rows):
         """Rows [b0, b1) of a plane of `rows` rows this rank owns (the render rows; other heights are cut where the boundaries fall)."""
+        self._follow_resize()
         if self.bounds is not None:
             rr = self.bounds[-1]
             cut = lambda k: 0 if k == 0 else (rows if k == self.world else (self.bounds[k] if rows == rr else self.bounds[k] * rows // rr))

@@ -487,6 +487,7 @@ class Engine:
     def resize(self, width, height, upscale_ratio=1.0):
         self.api.call("resize", self.ctx, width, height, upscale_ratio)
         self.width, self.height = width, height
+        self._bounds = None   # (hk_resize drops an explicit band split: it was in rows of the old render image)
         self.generation += 1  # every buffer was freed and reallocated: device pointers / views of an older generation are dead
 
     # -- per frame
