@@ -146,7 +146,8 @@ class HkStats(C.Structure):
     _fields_ = [("rays_primary", u64), ("rays_tlas", u64), ("rays_blas", u64), ("frames", u64),
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
                 ("_pad", u32), ("scene_mesh_builds", u64), ("scene_instance_builds", u64),
-                ("scene_async_instance_uploads", u64), ("scene_device_refits", u64), ("scene_device_tree_builds", u64)]
+                ("scene_async_instance_uploads", u64), ("scene_device_refits", u64), ("scene_device_tree_builds", u64),
+                ("walk_node_steps", u64), ("walk_triangle_tests", u64), ("walk_instance_entries", u64), ("walk_closest_hits", u64)]
 
 
 assert C.sizeof(HkVertex) == 32 and C.sizeof(HkPrimitive) == 48 and C.sizeof(HkNode) == 32 and C.sizeof(HkInstance) == 176
@@ -199,6 +200,7 @@ _DEBUG = {
     "debug_comm_loopback": [_vp, u32, u32, u32, u32],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],
+    "measure_gather": [_vp, C.c_size_t, u32, u32, u32, P(C.c_double), P(C.c_double)],
 }
 # host logic, builders, multi-GPU and GPU-only entry points
 _PRODUCT_ONLY = {

@@ -40,67 +40,6 @@ __global__ void k_copy_u4(uint4* __restrict__ dst, const uint4* __restrict__ src
   if (i < n) dst[i] = src[i];
 }
 
-// HBM ceiling probes (hk_measure_hbm): grid-stride float4 streams, 16 B per lane per access
-__global__ __launch_bounds__(256) void k_stream_copy(float4* __restrict__ a, const float4* __restrict__ b, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] = b[i];
-}
-__global__ __launch_bounds__(256) void k_stream_triad(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, float s, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float4 x = b[i], y = c[i];
-    a[i] = make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
-  }
-}
-
-// one-shot variants: every thread moves four float4 that are a whole grid apart (four independent 16-B loads in flight per lane,
-// every wave-instruction one contiguous 1 KiB), no loop
-__global__ __launch_bounds__(256) void k_stream_copy4(float4* __restrict__ a, const float4* __restrict__ b, size_t quarter) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= quarter) return;
-  const float4 x0 = b[i], x1 = b[i + quarter], x2 = b[i + 2 * quarter], x3 = b[i + 3 * quarter];
-  a[i] = x0; a[i + quarter] = x1; a[i + 2 * quarter] = x2; a[i + 3 * quarter] = x3;
-}
-__global__ __launch_bounds__(256) void k_stream_triad4(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, float s, size_t quarter) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= quarter) return;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float4 x = b[i + k * quarter], y = c[i + k * quarter];
-    a[i + k * quarter] = make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
-  }
-}
-
-// the shape that reaches the chip's copy ceiling (tools/ubench.hip, profiles/r03_ubench.json: 6.2 TB/s against 4.6-5.6 for
-// the looped / multi-access shapes): ONE 16-B access per lane, no loop, the grid covers the array
-__global__ __launch_bounds__(256) void k_stream_copy1(float4* __restrict__ a, const float4* __restrict__ b, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) a[i] = b[i];
-}
-__global__ __launch_bounds__(256) void k_stream_triad1(float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c, float s, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float4 x = b[i], y = c[i];
-  a[i] = make_float4(fmaf(s, y.x, x.x), fmaf(s, y.y, x.y), fmaf(s, y.z, x.z), fmaf(s, y.w, x.w));
-}
-
-// VALU issue probe (hk_measure_valu): eight independent v_fma_f32 chains per lane, no memory traffic; the grid decides how
-// many waves share a SIMD (one 256-thread workgroup = one wave on each of a CU's four SIMDs)
-__global__ __launch_bounds__(256) void k_valu_issue(float* out, float x, float y, int iters) {
-  float a[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k] = (float)threadIdx.x + k;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));
-    }
-  }
-  float s = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) s += a[k];
-  if (s == 123.456f) out[0] = s;
-}
-
 template <typename T>
 struct DevArray {
   T* p = nullptr;
@@ -296,7 +235,7 @@ struct hk_ctx {
   uint32_t history_now = 0;    // ... in force for the frame most recently begun (0 for a single band)
 
   // statistics
-  unsigned long long* d_counters = nullptr;  // primary, tlas, blas
+  unsigned long long* d_counters = nullptr;  // primary, tlas, blas, node steps, triangle tests, instance entries, closest hits (hk_light.hpp flush_counters)
   uint64_t frames = 0;
   uint32_t timing_mask = 0;
   std::vector<TimedLaunch> pending;
@@ -1515,8 +1454,8 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   c->device = device_id;
   c->flags = flags;
   c->timing_mask = (flags & HK_CTX_TIME_PASSES) ? 0xFFFFFFFFu : 0u;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 3 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&c->frame_start) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&c->frame_start) != hipSuccess ||
       hipEventCreate(&c->frame_stop) != hipSuccess) {
     set_error("HIP resource creation failed: %s", hipGetErrorString(hipGetLastError()));
     hk_destroy(c);
@@ -2540,11 +2479,15 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   memset(out, 0, sizeof(*out));
-  unsigned long long h[3] = {0, 0, 0};
+  unsigned long long h[8] = {};
   HK_HIP(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
   out->rays_primary = h[0];
   out->rays_tlas = h[1];
   out->rays_blas = h[2];
+  out->walk_node_steps = h[3];
+  out->walk_triangle_tests = h[4];
+  out->walk_instance_entries = h[5];
+  out->walk_closest_hits = h[6];
   out->frames = c->frames;
   out->last_frame_ms = c->last_frame_ms;
   out->scene_mesh_builds = c->static_rebuilds;
@@ -2582,97 +2525,13 @@ int hk_reset_stats(hk_ctx* c) {
   HK_HIP(hipSetDevice(c->device));
   { const int rc_ = sync_all(c); if (rc_) return rc_; }
   drain_timers(c);
-  HK_HIP(hipMemset(c->d_counters, 0, 3 * sizeof(unsigned long long)));
+  HK_HIP(hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
   c->frames = 0;
   for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
     c->slot_ms[i] = 0.0;
     c->slot_launches[i] = 0;
   }
   return HK_OK;
-}
-
-int hk_measure_hbm(hk_ctx* c, size_t bytes, uint32_t reps, double* copy_gbs, double* triad_gbs) {
-  HK_REQUIRE(c && copy_gbs && triad_gbs && bytes >= 4096 && reps > 0, HK_E_INVALID, "bad argument");
-  HK_HIP(hipSetDevice(c->device));
-  { const int rc_ = sync_all(c); if (rc_) return rc_; }
-  const size_t n = bytes / 16;
-  float4 *a = nullptr, *b = nullptr, *d = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  int rc = HK_OK;
-  auto fail = [&](const char* what, hipError_t e) { set_error("%s failed: %s", what, hipGetErrorString(e)); rc = HK_E_HIP; };
-  hipError_t e;
-  if ((e = hipMalloc((void**)&a, n * 16)) != hipSuccess || (e = hipMalloc((void**)&b, n * 16)) != hipSuccess || (e = hipMalloc((void**)&d, n * 16)) != hipSuccess) fail("hipMalloc", e);
-  if (!rc && ((e = hipMemsetAsync(a, 0, n * 16, c->stream)) != hipSuccess || (e = hipMemsetAsync(b, 0, n * 16, c->stream)) != hipSuccess ||
-              (e = hipMemsetAsync(d, 0, n * 16, c->stream)) != hipSuccess)) fail("hipMemsetAsync", e);
-  if (!rc && ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess)) fail("hipEventCreate", e);
-  const dim3 grid(256 * 32);  // 32 workgroups per CU of grid-stride work
-  const size_t quarter = n / 4;
-  const dim3 grid4((unsigned)((quarter + 255) / 256));
-  const dim3 grid1((unsigned)((n + 255) / 256));
-  *copy_gbs = *triad_gbs = 0.0;
-  // three access shapes per probe (a grid-stride loop; a one-shot launch with four independent 16-B accesses per lane; a
-  // one-shot launch with ONE access per lane - the shape that reaches the guide's 6.3 TB/s): the ceiling is the best of them
-  for (int pass = 0; pass < 6 && !rc; ++pass) {
-    const bool triad = pass & 1;
-    const int shape = pass >> 1;
-    for (uint32_t k = 0; k <= reps && !rc; ++k) {  // k = 0 warms up
-      if (k == 1) (void)hipEventRecord(e0, c->stream);
-      if (shape == 0 && !triad) hipLaunchKernelGGL(k_stream_copy, grid, dim3(256), 0, c->stream, a, (const float4*)b, n);
-      else if (shape == 0) hipLaunchKernelGGL(k_stream_triad, grid, dim3(256), 0, c->stream, a, (const float4*)b, (const float4*)d, 0.5f, n);
-      else if (shape == 1 && !triad) hipLaunchKernelGGL(k_stream_copy4, grid4, dim3(256), 0, c->stream, a, (const float4*)b, quarter);
-      else if (shape == 1) hipLaunchKernelGGL(k_stream_triad4, grid4, dim3(256), 0, c->stream, a, (const float4*)b, (const float4*)d, 0.5f, quarter);
-      else if (!triad) hipLaunchKernelGGL(k_stream_copy1, grid1, dim3(256), 0, c->stream, a, (const float4*)b, n);
-      else hipLaunchKernelGGL(k_stream_triad1, grid1, dim3(256), 0, c->stream, a, (const float4*)b, (const float4*)d, 0.5f, n);
-    }
-    (void)hipEventRecord(e1, c->stream);
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) { fail("hipStreamSynchronize", e); break; }
-    float ms = 0.0f;
-    if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) { fail("hipEventElapsedTime", e); break; }
-    const double moved = (double)((shape == 1 ? 4 * quarter : n) * 16);
-    const double gbs = (double)(triad ? 3 : 2) * moved * reps / ((double)ms * 1e-3) / 1e9;
-    if (!triad) *copy_gbs = std::max(*copy_gbs, gbs); else *triad_gbs = std::max(*triad_gbs, gbs);
-  }
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  if (a) (void)hipFree(a);
-  if (b) (void)hipFree(b);
-  if (d) (void)hipFree(d);
-  return rc;
-}
-
-int hk_measure_valu(hk_ctx* c, uint32_t iters, double ginstr_s[4]) {
-  HK_REQUIRE(c && ginstr_s && iters > 0 && iters <= (1u << 20), HK_E_INVALID, "bad argument");
-  HK_HIP(hipSetDevice(c->device));
-  { const int rc_ = sync_all(c); if (rc_) return rc_; }
-  hipDeviceProp_t prop;
-  HK_HIP(hipGetDeviceProperties(&prop, c->device));
-  const int cus = prop.multiProcessorCount;
-  float* out = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HK_HIP(hipMalloc((void**)&out, 4));
-  int rc = HK_OK;
-  hipError_t e;
-  if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) { set_error("hipEventCreate failed: %s", hipGetErrorString(e)); rc = HK_E_HIP; }
-  for (int k = 0; k < 4 && !rc; ++k) {
-    const int waves_per_simd = 1 << k;
-    const dim3 grid(cus * waves_per_simd);
-    hipLaunchKernelGGL(k_valu_issue, grid, dim3(256), 0, c->stream, out, 1.0001f, 0.5f, (int)iters);  // warm-up
-    (void)hipEventRecord(e0, c->stream);
-    for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(k_valu_issue, grid, dim3(256), 0, c->stream, out, 1.0001f, 0.5f, (int)iters);
-    (void)hipEventRecord(e1, c->stream);
-    float ms = 0.0f;
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess || (e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) {
-      set_error("VALU probe failed: %s", hipGetErrorString(e));
-      rc = HK_E_HIP;
-      break;
-    }
-    // wave-instructions: waves x 64 v_fma_f32 per iteration
-    ginstr_s[k] = (double)cus * 4.0 * waves_per_simd * 64.0 * iters * 4.0 / ((double)ms * 1e-3) / 1e9;
-  }
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  (void)hipFree(out);
-  return rc;
 }
 
 int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float* out, size_t n) {

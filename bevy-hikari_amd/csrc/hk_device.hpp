@@ -140,7 +140,10 @@ struct Hit { f2 uv; float distance; uint32_t instance_index, primitive_index; };
 struct Surface { f4 base_color, emissive; float reflectance, metallic, roughness, occlusion; };
 struct HitInfo { f4 position; f3 normal; f2 uv; uint32_t instance_index, material_index; };
 struct LightCandidate { f3 direction; float max_distance, min_distance; uint32_t emissive_instance; float p; };
-struct RayCounters { uint32_t tlas, blas; };
+// tlas / blas: walks started (SURVEY 8d's ray definition).  The other four price a walk in the terms of SURVEY 8d's algorithmic BVH
+// bytes per ray - node steps x 32 B, triangle tests x 48 B, instance entries x 208 B, closest hits whose attributes are fetched
+// (hit_info: three vertex records) x 96 B.  Only the COUNT instantiations of the kernels read them; everywhere else they are dead.
+struct RayCounters { uint32_t tlas, blas, nodes = 0u, tris = 0u, entries = 0u, hits = 0u; };
 
 HKD Sample zero_sample() {
   Sample s;
@@ -427,7 +430,7 @@ HKD uint32_t ray_octant(f3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u
 
 // stackless skip-link walk of one BLAS, light.wgsl:400-440
 HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t node_offset, uint32_t node_count, uint32_t primitive_offset,
-                         float early_distance) {
+                         float early_distance, RayCounters& rc) {
   bool intersected = false;
   uint32_t index = 0u;
   const uint32_t nbase = sc.blas_base + ray_octant(ray.direction) * sc.blas_stride + node_offset;
@@ -435,11 +438,13 @@ HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t no
     const float4* __restrict__ nd = sc.nodes + 2u * (nbase + index);
     const float4 lo = nd[0];
     const float4 hi = nd[1];
+    rc.nodes++;
     const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
     const bool box_hit = intersects_aabb(ray, xyz(lo), xyz(hi)) < hit.distance;
     if (entry >= HK_LEAF) {
       if (box_hit) {
         const uint32_t primitive_index = primitive_offset + entry - HK_LEAF;
+        rc.tris++;
         f2 uv;
         float d = intersects_triangle(ray, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
         if (d < hit.distance) {
@@ -530,6 +535,7 @@ HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, floa
     if (index < count) {
       const float4 lo = nodes[2u * index];
       const float4 hi = nodes[2u * index + 1u];
+      rc.nodes++;
       const uint32_t entry = f2u(lo.w), link = f2u(hi.w);
 #ifdef HK_FLAT_FMA_SLAB
       const f3 t1 = F3(fmaf(lo.x, lr.inv_direction.x, noi.x), fmaf(lo.y, lr.inv_direction.y, noi.y), fmaf(lo.z, lr.inv_direction.z, noi.z));
@@ -570,6 +576,7 @@ HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, floa
         for (int k = 0; k + 1 < HK_FLAT_CAP; ++k) pend[k] = pend[k + 1];
         npend -= 1u;
         const uint32_t primitive_index = cand & 0xFFFFu;
+        rc.tris++;
         f2 uv;
         const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
         if (d < hit.distance) {
@@ -655,6 +662,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
     const float4* __restrict__ nd = sc.nodes + 2u * (base + index);
     const float4 lo = nd[0];
     const float4 hi = nd[1];
+    rc.nodes++;
     const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
     // intersects_aabb, light.wgsl:344-362, on the current level's ray
     const f3 t1 = (xyz(lo) - co) * cinv;
@@ -675,6 +683,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
     if (leaf && box_hit) {  // the two rare events
       if (in_blas) {
         const uint32_t primitive_index = prim_base + entry - HK_LEAF;
+        rc.tris++;
         Ray lr;
         lr.origin = co;
         lr.direction = ld;
@@ -695,6 +704,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
         const uint32_t instance_index = entry - HK_LEAF;
         if (instance_index != exclude_instance) {
           const DInstance& in = sc.instances[instance_index];
+          rc.entries++;
           if (sc.shared_xform) {
             co = hco;
             ld = hld;
@@ -861,8 +871,9 @@ HKD LightCandidate select_light_candidate(const DScene& sc, const DFrame& fr, f4
     candidate.direction = ray.direction;
     const bool front = dot(candidate.direction, normal) > 0.0f;
     if (front) rc.blas++;
-    if (front && traverse_bottom(sc, hit, r, ein.node_offset, ein.node_count, ein.primitive, 0.0f)) {
+    if (front && traverse_bottom(sc, hit, r, ein.node_offset, ein.node_count, ein.primitive, 0.0f, rc)) {
       hit.instance_index = em.instance;
+      rc.hits++;
       info = hit_info(sc, ray, hit);
       candidate.max_distance = hit.distance;
       candidate.min_distance = hit.distance - 0.1f;

@@ -61,17 +61,14 @@ __device__ __forceinline__ void store_previous_spatial(const LightTargets& t, in
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const RayCounters& rc, uint32_t primary, unsigned long long* counters) {
   if (!COUNT) return;
-  uint32_t a = rc.tlas, b = rc.blas, c = primary;
-  for (int off = 32; off > 0; off >>= 1) {
-    a += __shfl_down(a, off);
-    b += __shfl_down(b, off);
-    c += __shfl_down(c, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    if (c) atomicAdd(&counters[0], (unsigned long long)c);
-    if (a) atomicAdd(&counters[1], (unsigned long long)a);
-    if (b) atomicAdd(&counters[2], (unsigned long long)b);
-  }
+  // counters: [0] primary rays, [1] traverse_top walks, [2] stand-alone traverse_bottom walks, [3] node steps, [4] triangle tests,
+  // [5] instance entries, [6] closest hits whose attributes were fetched (HkStats)
+  uint32_t v[7] = {primary, rc.tlas, rc.blas, rc.nodes, rc.tris, rc.entries, rc.hits};
+  for (int off = 32; off > 0; off >>= 1)
+    for (int k = 0; k < 7; ++k) v[k] += __shfl_down(v[k], off);
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 7; ++k)
+      if (v[k]) atomicAdd(&counters[k], (unsigned long long)v[k]);
 }
 
 // The temporal-reuse tail of indirect_lit_ambient, light.wgsl:1452-1497: reproject, reject, merge the new sample into last

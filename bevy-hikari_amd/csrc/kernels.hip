@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
     Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
     rc.tlas = 0;  // counted as a primary ray
     primary = 1;
+    rc.hits += hit.instance_index != HK_U32_MAX ? 1u : 0u;
     if (hit.instance_index == HK_U32_MAX) {
       g.position[idx] = make_float4(0, 0, 0, 0);
       g.normal[idx] = 0u;
@@ -412,6 +413,7 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
   HK_ABLATE_WALK(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
   Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
   HK_SEC(tm, 3);
+  rc.hits += hit.instance_index != HK_U32_MAX ? 1u : 0u;
   HitInfo info = hit_info(sc, ray, hit);
   if (n == 0u) {
     p.first_position = info.position;
@@ -576,6 +578,7 @@ __global__ __launch_bounds__(256, (LDS == 2 ? HK_INDIRECT_FLAT_WAVES : 4)) void 
         ray.direction = mul(normal_basis(s.visible_normal), xyz(rand_sample));
         ray.inv_direction = 1.0f / ray.direction;
         Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+        rc.hits += hit.instance_index != HK_U32_MAX ? 1u : 0u;
         HitInfo info = hit_info(sc, ray, hit);
         s.sample_position = info.position;
         s.sample_normal = info.normal;

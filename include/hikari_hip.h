@@ -340,6 +340,14 @@ typedef struct HkStats {
   /* instance updates that ran on the device (hk_refit_scene_instances): no host tree build, no scene buffer over PCIe */
   uint64_t scene_device_refits;
   uint64_t scene_device_tree_builds;  /* hk_rebuild_scene_trees */
+  /* ABI 7, HK_CTX_COUNT_RAYS: what the counted walks did, in the terms of SURVEY 8d's algorithmic BVH bytes per ray - node steps
+   * (32 B each: two 16-B loads), triangle tests (48 B), instance entries (a 208-B record; the survey's formula leaves them out),
+   * closest hits whose attributes were fetched (three 32-B vertex records).  bench.py prices the trace kernels of the large-scene
+   * configs with them (roofline of extra_configs 3 / 4). */
+  uint64_t walk_node_steps;
+  uint64_t walk_triangle_tests;
+  uint64_t walk_instance_entries;
+  uint64_t walk_closest_hits;
 } HkStats;
 
 typedef struct hk_ctx hk_ctx;

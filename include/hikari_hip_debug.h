@@ -30,6 +30,15 @@ int hk_measure_valu(hk_ctx* ctx, uint32_t iters, double ginstr_s[4]);
  * x, y, out are HOST arrays. */
 int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, float* out, size_t n);
 
+/* Measurement hook for the roof of the BVH walks of scenes beyond the LDS copy (round 4): every lane of
+ * `waves_per_simd` resident waves per SIMD follows its own chain of `steps` DEPENDENT loads through a random permutation cycle over
+ * `footprint_bytes` of records - `bytes_per_step` = 16 (one 16-B load per step) or 32 (the two adjacent 16-B loads of a node step) -
+ * i.e. 64 unrelated addresses per wave-level load instruction and no reuse.  Returns the rate of wave-level load instructions
+ * (1e9 / s) and of loaded bytes (lanes x bytes_per_step per step; GB/s).  No walk of that shape runs faster on the chip: the
+ * trace kernels of configs 3 / 4 are priced against it in bench.py (the HBM roof is meaningless for them - they move little). */
+int hk_measure_gather(hk_ctx* ctx, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps,
+                      double* gloads_s, double* gbytes_s);
+
 /* Test hook for the RCCL data path on a box with ONE GPU (RCCL refuses two ranks on one device, so no halo exchange between
  * ranks can run there): rows [row_begin, row_end) of `src_buffer` travel to the same rows of `dst_buffer` (same shape) of the
  * SAME context as an ncclSend to the context's own rank paired with an ncclRecv from it, inside one ncclGroupStart / ncclGroupEnd,

@@ -35,11 +35,12 @@ BUDGETS = {
 # default path of an LDS-resident scene
 SCRATCH_ALLOWED = {
     r"k_indirect<true, false, 0>": 32,         # fused schedule on a scene in global memory (the default there is the wavefront)
-    r"k_indirect<true, true, (0|3)>": 64,      # ray-counting replays (two-level / one-level walk from global memory)
+    r"k_indirect<true, true, (0|3)>": 96,      # ray-counting replays (two-level / one-level walk from global memory; + the walk counters of HkStats)
     r"k_wf_final": 16,
     # scenes beyond LDS: 4 waves per SIMD with 9 / 54 spilled VGPRs beat 3 without (profiles/r03_occupancy_ab.txt); COUNT = the replays
     r"k_direct_lit<false, (true|false), 0>": 48,
     r"k_direct_lit<true, (true|false), 0>": 112,
+    r"k_direct_lit<(true|false), true, 0>": 160,   # ... their ray-counting replays also carry the walk counters (HkStats walk_*: round 4)
 }
 
 
