@@ -269,12 +269,22 @@ def main():
         # primary rays: one per pixel per frame (apron rows ray-cast redundantly by neighbouring bands are not counted)
         total_rays = traced + float(W) * H * steps
         same = bool((ceng.read(F.BUF_TONE_MAPPED) == tone).all())  # the replay must reproduce the timed frames bit for bit
+        # what the walks of those frames did (HkStats walk_*: node steps, triangle tests, instance entries, closest hits) - per frame,
+        # and for the indirect pass alone (its dispatch repeated once on the last frame's inputs: same rays, same walks)
+        walk = {"per_frame": {k: getattr(cst, "walk_" + k) / steps for k in ("node_steps", "triangle_tests", "instance_entries", "closest_hits")},
+                "rays_per_frame": (cst.rays_tlas + cst.rays_blas + cst.rays_primary) / steps}
+        if crend is None:
+            ceng.reset_stats()
+            ceng.pass_run(F.PASS_INDIRECT)
+            ist = ceng.stats()
+            walk["indirect_pass"] = {k: float(getattr(ist, "walk_" + k)) for k in ("node_steps", "triangle_tests", "instance_entries", "closest_hits")}
+            walk["indirect_pass"]["rays"] = float(ist.rays_tlas + ist.rays_blas)
         del ceng, crend
 
         res = {"config": config, "description": description, "W": W, "H": H, "steps": steps, "warmup": warmup, "blocks": blocks, "elapsed": elapsed,
                "band_bounds": (rend.bounds if rend is not None else None),
                "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "total_rays": total_rays, "same": same,
-               "sustained": sustained, "scene": scene, "settings": settings, "lights": lights, "view": view, "pview": pview, "sc": sc,
+               "walk": walk, "sustained": sustained, "scene": scene, "settings": settings, "lights": lights, "view": view, "pview": pview, "sc": sc,
                "band_rows": H if rend is None else (rend.band(H)[1] - rend.band(H)[0])}
         if sustained:
             sustained["value"] = round(total_rays / steps * sustained["frames"] / sustained["seconds"] / 1e6, 3)
@@ -312,6 +322,40 @@ def main():
     xeng = m["_probe_engine"]
 
     # ------------------------------------------------------------------ the other single-GPU configs, briefly, in the same invocation
+    def walk_roofline(x, probe_engine):
+        """SURVEY 8d for scenes beyond LDS: the indirect pass priced by what its walks MUST fetch - visited nodes x 32 B + triangle
+        tests x 48 B + 96 B per closest hit (counted by the replay) - against the HBM peak (the contract's roof: a walk moves little,
+        the fraction is small by nature) and against the roof that applies, MEASURED in this run: the rate at which the chip serves
+        dependent divergent 32-B gathers over a table as large as the scene's trees, at the trace kernel's occupancy."""
+        ip = x["walk"].get("indirect_pass")
+        if not ip or x["ind_ms"] <= 0:
+            return None
+        scene = x["scene"]
+        orderings = x["traversal"][1]
+        tree_bytes = (len(scene.asset_nodes) + len(scene.instance_nodes)) * 32 * orderings + len(scene.primitives) * 48
+        bvh_bytes = ip["node_steps"] * 32 + ip["triangle_tests"] * 48 + ip["closest_hits"] * 96
+        t = x["ind_ms"] * 1e-3
+        r = {"kernel": "indirect_lit_ambient as k_wf_setup + (k_wf_trace + k_wf_shade) per bounce + k_wf_trace + k_wf_final" if x["schedule"] == "wavefront" else "k_indirect",
+             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+             "algorithmic_bvh_bytes_per_launch": bvh_bytes, "achieved": round(bvh_bytes / t / 1e9, 2), "frac": round(bvh_bytes / t / 1e9 / HBM_PEAK_GBS, 5),
+             "avg_launch_ms": round(x["ind_ms"], 4),
+             "walk_counts_per_launch": {k: int(v) for k, v in ip.items()},
+             "per_ray": {"node_steps": round(ip["node_steps"] / ip["rays"], 2), "triangle_tests": round(ip["triangle_tests"] / ip["rays"], 2),
+                         "instance_entries": round(ip["instance_entries"] / ip["rays"], 2), "bvh_bytes": round(bvh_bytes / ip["rays"], 1)},
+             "formula": "SURVEY 8d: visited nodes x 32 + leaf (triangle) tests x 48 + 96 per closest hit; instance entries (208-B records) counted, not priced",
+             "tree_bytes_walked": tree_bytes, "traffic": None}
+        if probe_engine is not None:
+            # 7 waves per SIMD = k_wf_trace's occupancy (HK_WF_TRACE_WAVES); 32 B per step = a node step's two 16-B loads
+            gl, gb = probe_engine.measure_gather(max(tree_bytes, 1 << 20), 32, 7, 512)
+            steps_s = ip["node_steps"] / t / 1e9   # G node steps / s over the whole pass (trace + shade + set-up + tail launches)
+            r["gather_ceiling_measured"] = {"footprint_bytes": tree_bytes, "bytes_per_step": 32, "waves_per_simd": 7, "g_lane_steps_s": round(gl / 2 * 64, 2),
+                                            "g_wave_loads_s": round(gl, 3), "gbytes_s": round(gb, 1),
+                                            "note": "hk_measure_gather in this run: every lane its own chain of dependent 32-B loads through a random cycle over a table of "
+                                                    "the size of the scene's trees (all stored orderings): the rate no walk of that shape can exceed"}
+            r["achieved_g_node_steps_s"] = round(steps_s, 3)
+            r["frac_of_gather_ceiling"] = round(steps_s / (gl / 2 * 64), 4) if gl > 0 else None
+        return r
+
     extra = None
     if default_run and not args.no_extra_configs:
         extra = {}
@@ -321,6 +365,8 @@ def main():
                                "ms_per_step": round(x["elapsed"] / steps_x * 1e3, 4), "steps": steps_x, "warmup": 6,
                                "blocks_ms_per_step": [round(b / steps_x * 1e3, 4) for b in x["blocks"]], "rays_per_frame": round(x["total_rays"] / steps_x, 1),
                                "indirect_schedule": x["schedule"], "traversal": x["traversal"][0], "indirect_avg_launch_ms": round(x["ind_ms"], 5), "replay_bit_identical": x["same"]}
+            if cfg in (3, 4) and rank == 0 and not args.no_hbm_probe:
+                extra[str(cfg)]["roofline"] = walk_roofline(x, xeng)
             del x
 
     # ------------------------------------------------------------------ empirical HBM ceiling, same run
@@ -398,9 +444,7 @@ def main():
                       "frac": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ind_ms_alone > 0 else 0.0},
         },
     }
-    tpath = os.path.join(ROOT, "profiles", "r03_indirect_hbm_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r02_indirect_hbm_traffic.json")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_indirect_hbm_traffic.json") for k in (4, 3, 2)) if os.path.exists(q)), "")
     if m.get("spatial_ms_alone"):
         # the second large kernel of the frame (by now as long as the first): spatial_reuse, light.wgsl:1503-1684 - SURVEY 8d: reads
         # G-buffer 40 + own reservoir 64 + previous spatial 64, writes reservoir 64 + render 8 (the 16 neighbour records it gathers,
@@ -409,7 +453,7 @@ def main():
         out["roofline"]["second_kernel"] = {"kernel": "k_spatial_reuse<false> (spatial_reuse, light.wgsl:1503-1684)", "algorithmic_bytes_per_launch": sp_bytes,
                                             "alone": {"avg_launch_ms": round(m["spatial_ms_alone"], 5), "achieved": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9, 3),
                                                       "frac": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
-        if os.path.exists(tpath):   # its counter traffic (same committed PMC passes as roofline.traffic; round 2: 1.8x the algorithmic bytes)
+        if tpath:   # its counter traffic (same committed PMC passes as roofline.traffic; round 2: 1.8x the algorithmic bytes)
             t2 = json.load(open(tpath)).get("second_kernel")
             if t2:
                 out["roofline"]["second_kernel"]["traffic"] = t2["hbm_bytes_per_launch"]
@@ -421,7 +465,18 @@ def main():
         if args.config == 2:
             frame_bytes = 1700.0 * W * H
             out["frame_roofline"] = {"algorithmic_bytes_per_frame": frame_bytes, "achieved_gbs": round(frame_bytes / (elapsed / args.steps) / 1e9, 1),
-                                     "frac_of_peak": round(frame_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+                                     "frac_of_peak": round(frame_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "SURVEY 8d's 1.70 KB/px charged to all pixels; the counter figure below is what the frame really moves"}
+            try:  # what the frame's kernels move by the PMC counters (committed passes of this command): the honest figure
+                fr_prof = json.load(open(tpath)).get("frame") if tpath else None
+                if fr_prof and world == 1:
+                    cb = float(fr_prof["hbm_bytes_per_frame"])
+                    out["frame_roofline"]["counter"] = {"hbm_bytes_per_frame": cb, "achieved_gbs": round(cb / (elapsed / args.steps) / 1e9, 1),
+                                                        "frac_of_peak": round(cb / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                                        "frac_of_measured_copy": round(cb / (elapsed / args.steps) / 1e9 / hbm["copy_gbs"], 4) if hbm["copy_gbs"] > 0 else None,
+                                                        "source": os.path.relpath(tpath, ROOT) + " (sum of 2 x FETCH_SIZE + WRITE_SIZE over the frame's kernels; not measured in this run)"}
+            except Exception:
+                pass
     if valu:
         # VALU issue: the peak is MEASURED in this run (hk_measure_valu).  MI355X_MICROARCH.md: a wave64 VALU instruction issues
         # over 2 cycles on a SIMD-32, i.e. 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1 229 G wave-instructions/s nominal; the probe
@@ -430,7 +485,7 @@ def main():
         # that was wrong.)
         vi = {"peak_measured_ginstr_s": valu, "peak_nominal_ginstr_s": round(256 * 4 * 2.4e9 / 2 / 1e9, 1),
               "peak_source": "hk_measure_valu in this run; nominal = MI355X_MICROARCH.md (wave64 VALU: 2 cycles on a SIMD-32, 2.4 GHz)"}
-        if os.path.exists(tpath) and world == 1 and args.config == 2:
+        if tpath and world == 1 and args.config == 2:
             # the kernel's VALU wave-instructions per launch come from the committed SQ PMC pass of this command (counters cannot be
             # read inside this process); its launch time is this run's
             try:
@@ -448,13 +503,15 @@ def main():
             except Exception:
                 pass
         out["roofline"]["valu_issue"] = vi
-    if os.path.exists(tpath) and world == 1 and args.config == 2:
+    if tpath and world == 1 and args.config == 2:
         out["traffic_profile"] = {"source": os.path.relpath(tpath, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"}
         try:  # separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction (MI355X_MICROARCH.md, HBM section), per launch
             out["roofline"]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
             out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
         except Exception:
             pass
+    if args.config in (3, 4) and world == 1 and not args.no_hbm_probe:
+        out["roofline"]["bvh_walk"] = walk_roofline(m, xeng)
     if m["sustained"]:
         out["sustained"] = m["sustained"]
     if extra:

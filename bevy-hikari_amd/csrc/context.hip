@@ -294,6 +294,7 @@ int free_screen(hk_ctx* c) {
   }
   if (c->wf_mem) (void)hipFree(c->wf_mem);
   c->wf_mem = nullptr;
+  if (c->wf.timeline) (void)hipFree(c->wf.timeline);
   c->wf = hkd::WfBuffers{};
   if (c->depth_plane) (void)hipFree(c->depth_plane);
   if (c->prev_depth_plane) (void)hipFree(c->prev_depth_plane);
@@ -1238,6 +1239,7 @@ int ensure_wavefront(hk_ctx* c) {
   w.alive[0] = u32(1); w.alive[1] = u32(1);
   w.shadow[0] = u32(1); w.shadow[1] = u32(1);
   w.cap = (uint32_t)n;
+  if (getenv("HK_WF_TIMELINE") && !w.timeline) HK_HIP(hipMalloc((void**)&w.timeline, 64 * 32 * sizeof(unsigned long long)));  // tools/wf_timeline.py
   return HK_OK;
 }
 
@@ -1767,6 +1769,16 @@ int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
                                  1u, 1u) == 0, HK_E_HIP, "device build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
   c->mirrors_stale = true;
   c->device_tree_builds += 1;
+  return HK_OK;
+}
+
+// tools/wf_timeline.py: the 64 x 32 u64 the instrumented trace kernel left for the frame most recently rendered (HK_WF_TIMELINE=1)
+int hk_debug_read_wf_timeline(hk_ctx* c, unsigned long long* out, uint32_t n) {
+  HK_REQUIRE(c && out && n == 64u * 32u, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(c->wf.timeline, HK_E_NOT_READY, "no timeline: set HK_WF_TIMELINE=1 before the first frame of a scene beyond the LDS copy");
+  HK_HIP(hipSetDevice(c->device));
+  { const int rc = sync_all(c); if (rc) return rc; }
+  HK_HIP(hipMemcpy(out, c->wf.timeline, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return HK_OK;
 }
 

@@ -71,6 +71,11 @@ struct WfBuffers {
   uint32_t* alive[2];  // slots alive at a bounce (= the closest-hit rays of that bounce's trace stage), ping-pong
   uint32_t* shadow[2]; // slots whose shadow ray the trace stage walks, ping-pong
   uint32_t cap;
+  // HK_WF_TIMELINE=1 (tools/wf_timeline.py; null otherwise, and then the instrumented instantiation of k_wf_trace never runs): 32
+  // u64 per trace stage, zeroed per dispatch - [0] ~first wave start, [1] ~first time a wave found the queue exhausted, [2] last
+  // wave exit (wall_clock64 ticks; ~x = UINT64_MAX - x so that atomicMax keeps the minimum), [3] sum of the waves' resident ticks,
+  // [4] waves, [5] most node steps of one ray, [6] node steps, [7] rays, [8..23] rays by floor(log2(node steps + 1))
+  unsigned long long* timeline;
 };
 // Instance motion on the device (kernels_scene.hip): the arrays of the instance-level region the refit kernels rewrite, plus
 // the refit's own side arrays.

@@ -276,9 +276,21 @@ __device__ __forceinline__ void walk_enter(Walk& k, const DScene& sc, uint32_t i
 
 // Stage `stage` walks the closest-hit rays of the paths alive at bounce `stage` and the shadow rays the shade stage of bounce
 // `stage - 1` emitted: queue entry i is alive[i] for i < n_alive, else shadow[i - n_alive].
-template <bool LDS>
+// TL: the instrumented twin for tools/wf_timeline.py (WfBuffers::timeline) - when the queue ran dry, when the last wave left, how
+// long the rays were; the product launches TL = false.
+template <bool LDS, bool TL>
 __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc, WfBuffers w, uint32_t stage) {
   const DScene sc = stage_scene<LDS>(gsc);
+  __shared__ uint32_t tl_hist[16];
+  unsigned long long tl_start = 0ull;
+  uint32_t tl_steps = 0u, tl_max = 0u, tl_sum = 0u, tl_rays = 0u;
+  bool tl_seen_dry = false;
+  if (TL) {
+    if (threadIdx.x < 16u) tl_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    tl_start = wall_clock64();
+    if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 0u], ~tl_start);
+  }
   const uint32_t n_alive = w.ctr[WF_ALIVE + stage], tail = n_alive + w.ctr[WF_SHADOWS + stage];
   const uint32_t* __restrict__ alive = w.alive[stage & 1u];
   const uint32_t* __restrict__ shadow = w.shadow[stage & 1u];
@@ -292,6 +304,13 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
   Walk k;
   walk_begin(k, sc, F3(0, 0, 0), F3(1, 1, 1), 0.0f, 0.0f, HK_DONT_EXCLUDE);
   auto finish = [&]() {  // the lane's walk has ended: its result goes to the slot, the lane is free
+    if (TL) {
+      tl_max = max(tl_max, tl_steps);
+      tl_sum += tl_steps;
+      tl_rays += 1u;
+      atomicAdd(&tl_hist[min(15u, 31u - (uint32_t)__clz((int)(tl_steps + 1u)))], 1u);
+      tl_steps = 0u;
+    }
     const uint32_t slot = entry_id & ~WF_SHADOW;
     if (entry_id & WF_SHADOW) {
       w.sh[slot] = k.hit.instance_index;
@@ -304,6 +323,10 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
     const unsigned long long idle_mask = __ballot(phase == PH_IDLE);
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     const bool dry = exhausted && res_count == 0u;
+    if (TL && exhausted && !tl_seen_dry) {
+      tl_seen_dry = true;
+      if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 1u], ~wall_clock64());
+    }
     if (dry && n_idle == 64u) break;
     if (!dry && (n_idle >= HK_WF_REFILL_MIN || n_idle == 64u)) {
       const bool idle = phase == PH_IDLE;
@@ -348,6 +371,7 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
 #pragma unroll 1
       for (int s = 0; s < HK_WF_STEPS; ++s) {
         if (phase == PH_NODE) {
+          if (TL) tl_steps += 1u;
           phase = walk_node(k, sc, pending);
           if (phase == PH_IDLE) finish();
         }
@@ -363,6 +387,25 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
         phase = PH_NODE;
       }
     }
+  }
+  if (TL) {
+    const unsigned long long now = wall_clock64();
+    for (int off = 32; off > 0; off >>= 1) {
+      tl_max = max(tl_max, (uint32_t)__shfl_down(tl_max, off));
+      tl_sum += __shfl_down(tl_sum, off);
+      tl_rays += __shfl_down(tl_rays, off);
+    }
+    unsigned long long* tl = w.timeline + 32u * stage;
+    if ((threadIdx.x & 63u) == 0u) {
+      atomicMax(&tl[2], now);
+      atomicAdd(&tl[3], now - tl_start);
+      atomicAdd(&tl[4], 1ull);
+      atomicMax(&tl[5], (unsigned long long)tl_max);
+      atomicAdd(&tl[6], (unsigned long long)tl_sum);
+      atomicAdd(&tl[7], (unsigned long long)tl_rays);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16u && tl_hist[threadIdx.x]) atomicAdd(&tl[8u + threadIdx.x], (unsigned long long)tl_hist[threadIdx.x]);
   }
 }
 
@@ -525,13 +568,15 @@ void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& f
                                int y1, int compute_units, hipEvent_t start, hipEvent_t stop) {
   if (y1 <= y0) return;
   (void)hipMemsetAsync(w.ctr, 0, 192 * sizeof(uint32_t), st);
+  if (w.timeline) (void)hipMemsetAsync(w.timeline, 0, 64 * 32 * sizeof(unsigned long long), st);
   hipExtLaunchKernelGGL(k_wf_setup, grid_for(fr.rw, y1 - y0), dim3(256), 0, st, start, nullptr, 0, sc, fr, g, t, w, y0, y1);
   const size_t lds = (size_t)sc.blob_f4 * 16 <= HK_LDS_SCENE_BYTES ? (size_t)sc.blob_f4 * 16 : 0;
   const dim3 persistent((unsigned)(compute_units * 8));  // 8 workgroups of 4 waves per CU: what 64 VGPRs leave resident
   const uint32_t bounces = fr.indirect_bounces;
   for (uint32_t n = 0; n <= bounces; ++n) {
-    if (lds) hipLaunchKernelGGL((k_wf_trace<true>), persistent, dim3(256), lds, st, sc, w, n);
-    else hipLaunchKernelGGL((k_wf_trace<false>), persistent, dim3(256), 0, st, sc, w, n);
+    if (w.timeline && !lds) hipLaunchKernelGGL((k_wf_trace<false, true>), persistent, dim3(256), 0, st, sc, w, n);
+    else if (lds) hipLaunchKernelGGL((k_wf_trace<true, false>), persistent, dim3(256), lds, st, sc, w, n);
+    else hipLaunchKernelGGL((k_wf_trace<false, false>), persistent, dim3(256), 0, st, sc, w, n);
     if (n == bounces) break;
     if (lds) hipLaunchKernelGGL((k_wf_shade<true>), persistent, dim3(256), lds, st, sc, fr, w, n);
     else hipLaunchKernelGGL((k_wf_shade<false>), persistent, dim3(256), 0, st, sc, fr, w, n);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_valu_issue(float* out, float x, float y
 // What a BVH walk of a scene beyond LDS asks of the memory system, with everything else taken away: every lane follows its own
 // chain of dependent loads through a table far larger than any cache - the address of step k + 1 comes out of the bytes step k
 // loaded - 64 unrelated addresses per wave-level load instruction, `LOADS` adjacent 16-B loads per step (2 = one 32-B node: the
-// two float4 of a node step, hk_device.hpp traverse_top).  The table is a random permutation cycle laid out by the host's LCG, so
+// two float4 of a node step, hk_device.hpp traverse_top; 4 = one 64-B reservoir record, the gather of spatial_reuse's taps).  The table is a random permutation cycle laid out by the host's LCG, so
 // no two lanes meet and no prefetcher helps.  Reported: wave-level load instructions per second and bytes per second (lanes x
 // 16 B x LOADS per step) at a given number of resident waves per SIMD - the rate NO walk of that shape can exceed on this chip.
 template <int LOADS>
@@ -107,10 +107,8 @@ __global__ __launch_bounds__(256) void k_gather_chase(const uint4* __restrict__ 
   uint32_t acc = 0u;
   for (uint32_t k = 0; k < steps; ++k) {
     const uint4 a = table[(size_t)at * LOADS];
-    if (LOADS == 2) {
-      const uint4 b = table[(size_t)at * LOADS + 1u];
-      acc += b.w;
-    }
+#pragma unroll
+    for (int l = 1; l < LOADS; ++l) acc += table[(size_t)at * LOADS + l].w;  // the rest of the record: adjacent 16-B loads, issued together
     acc += a.y;
     at = a.x;  // the next record: known only now
   }
@@ -213,7 +211,7 @@ int hk_measure_valu(hk_ctx* c, uint32_t iters, double ginstr_s[4]) {
 
 // hikari_hip_debug.h
 int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps, double* gloads_s, double* gbytes_s) {
-  HK_REQUIRE(c && gloads_s && gbytes_s && (bytes_per_step == 16u || bytes_per_step == 32u) && waves_per_simd >= 1u && waves_per_simd <= 8u && steps >= 16u &&
+  HK_REQUIRE(c && gloads_s && gbytes_s && (bytes_per_step == 16u || bytes_per_step == 32u || bytes_per_step == 64u) && waves_per_simd >= 1u && waves_per_simd <= 8u && steps >= 16u &&
                  footprint_bytes >= (1u << 20) && footprint_bytes <= ((size_t)32 << 30), HK_E_INVALID, "bad argument");
   PROBE_BEGIN(c);
   uint32_t n_records = 1u;
@@ -237,7 +235,8 @@ int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step
     for (int pass = 0; pass < 2; ++pass) {  // (pass 0 warms up: page tables, clocks)
       (void)hipEventRecord(e0, stream);
       if (loads == 1u) hipLaunchKernelGGL(k_gather_chase<1>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
-      else hipLaunchKernelGGL(k_gather_chase<2>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
+      else if (loads == 2u) hipLaunchKernelGGL(k_gather_chase<2>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
+      else hipLaunchKernelGGL(k_gather_chase<4>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
       (void)hipEventRecord(e1, stream);
     }
     float ms = 0.0f;

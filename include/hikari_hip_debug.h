@@ -32,12 +32,17 @@ int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, floa
 
 /* Measurement hook for the roof of the BVH walks of scenes beyond the LDS copy (round 4): every lane of
  * `waves_per_simd` resident waves per SIMD follows its own chain of `steps` DEPENDENT loads through a random permutation cycle over
- * `footprint_bytes` of records - `bytes_per_step` = 16 (one 16-B load per step) or 32 (the two adjacent 16-B loads of a node step) -
+ * `footprint_bytes` of records - `bytes_per_step` = 16 (one 16-B load per step), 32 (the two adjacent 16-B loads of a node step) or 64 (a reservoir record) -
  * i.e. 64 unrelated addresses per wave-level load instruction and no reuse.  Returns the rate of wave-level load instructions
  * (1e9 / s) and of loaded bytes (lanes x bytes_per_step per step; GB/s).  No walk of that shape runs faster on the chip: the
  * trace kernels of configs 3 / 4 are priced against it in bench.py (the HBM roof is meaningless for them - they move little). */
 int hk_measure_gather(hk_ctx* ctx, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps,
                       double* gloads_s, double* gbytes_s);
+
+/* Profiling hook (tools/wf_timeline.py): with HK_WF_TIMELINE=1 in the environment the trace stages of the queue-based indirect pass
+ * run an instrumented twin that records, per stage, when the ray queue ran dry, when the last persistent wave left and how long
+ * the rays' walks were (hk_kernels.hpp WfBuffers::timeline: 64 stages x 32 u64, wall_clock64 ticks of 10 ns). */
+int hk_debug_read_wf_timeline(hk_ctx* ctx, unsigned long long* out, uint32_t n /* 64 * 32 */);
 
 /* Test hook for the RCCL data path on a box with ONE GPU (RCCL refuses two ranks on one device, so no halo exchange between
  * ranks can run there): rows [row_begin, row_end) of `src_buffer` travel to the same rows of `dst_buffer` (same shape) of the

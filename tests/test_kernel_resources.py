@@ -22,7 +22,7 @@ BUDGETS = {
     r"k_spatial_reuse<false>": 128,
     r"k_spatial_reuse<true>": 128,
     r"k_prepass<false, (1|2)>": 128,
-    r"k_wf_trace<(true|false)>": 72,           # HK_WF_TRACE_WAVES = 7
+    r"k_wf_trace<(true|false), false>": 72,          # HK_WF_TRACE_WAVES = 7
     r"k_wf_shade<(true|false)>": 128,
     r"k_wf_setup": 64,
     r"k_denoise<\d, 3, 6>": 64,                # HK_DENOISE_WAVES = 8
@@ -37,6 +37,7 @@ SCRATCH_ALLOWED = {
     r"k_indirect<true, false, 0>": 32,         # fused schedule on a scene in global memory (the default there is the wavefront)
     r"k_indirect<true, true, (0|3)>": 96,      # ray-counting replays (two-level / one-level walk from global memory; + the walk counters of HkStats)
     r"k_wf_final": 16,
+    r"k_wf_trace<false, true>": 64,            # the instrumented twin of tools/wf_timeline.py (never launched by the product)
     # scenes beyond LDS: 4 waves per SIMD with 9 / 54 spilled VGPRs beat 3 without (profiles/r03_occupancy_ab.txt); COUNT = the replays
     r"k_direct_lit<false, (true|false), 0>": 48,
     r"k_direct_lit<true, (true|false), 0>": 112,
@@ -88,7 +89,7 @@ VALU_BUDGETS = {
     r"k_indirect<true, false, 2>": 7751,
     r"k_prepass<false, 1>": 3274,
     r"k_prepass<false, 2>": 3048,
-    r"k_wf_trace<false>": 499,
+    r"k_wf_trace<false, false>": 499,
 }
 
 

@@ -67,6 +67,22 @@ def main():
                                 "lane_utilisation": round(s2["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * s2["SQ_ACTIVE_INST_VALU"][0]), 3)}
     except SystemExit:
         pass
+    # the whole frame from the same passes: every production kernel of a config-2 frame runs once per frame, so
+    # the frame's counter traffic is the sum of their per-launch averages (COUNT-variant replays and the probes excluded)
+    frame = {}
+    for kname, f1 in fetch.items():
+        short = kname.replace("void hkd::", "").split("(")[0]
+        if not short.startswith("k_") or "FETCH_SIZE" not in f1:
+            continue
+        if re.search(r"<(true|false), true, \d>|k_prepass<true|k_stream|k_valu|k_gather|k_copy|k_resolve|k_join|k_count", short):
+            continue
+        w1 = next((v for k, v in write.items() if k == kname), None)
+        if not w1 or "WRITE_SIZE" not in w1:
+            continue
+        frame[short] = int(2 * f1["FETCH_SIZE"][0] * 1024 + w1["WRITE_SIZE"][0] * 1024)
+    out["frame"] = {"hbm_bytes_per_frame": sum(frame.values()), "per_kernel": frame, "algorithmic_bytes_per_frame": 1700 * 1920 * 1080,
+                    "note": "sum over the production kernels of a config-2 frame of (2 x FETCH_SIZE + WRITE_SIZE) per launch; uniform-tile store elision "
+                            "skips the background tiles' reservoir stores, which SURVEY 8d's 1.70 KB/px charges to every pixel"}
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out["limiter"]), out["ratio_to_algorithmic"])
 

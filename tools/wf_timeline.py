@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Bulk / tail split of the trace stages of the queue-based indirect pass: with HK_WF_TIMELINE=1 the trace
+kernel's instrumented twin records per stage when the ray queue ran dry, when the last persistent wave left and how long the rays'
+walks were.  Prints one JSON object per config.    python tools/wf_timeline.py [3 4]"""
+import ctypes as C
+import json
+import os
+import sys
+
+os.environ["HK_WF_TIMELINE"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import bevy_hikari_amd as hk  # noqa: E402
+from bench import workload  # noqa: E402
+
+
+def main():
+    configs = [int(a) for a in sys.argv[1:]] or [3, 4]
+    out = {}
+    for cfg in configs:
+        scene, camera, settings, lights, description = workload(hk, cfg, None, None, None)
+        e = hk.Engine(device=0)
+        e.upload_noise(); e.upload_scene(scene); e.resize(camera.width, camera.height, 1.0)
+        view, pview, sc = camera.view_uniform(), camera.previous_view_uniform(), settings.to_c()
+        for n in range(1, 9):
+            e.frame_render(hk.frame_uniform(settings, n), view, pview, lights, sc)
+        e.wait()
+        raw = np.zeros(64 * 32, dtype=np.uint64)
+        e.api.call("debug_read_wf_timeline", e.ctx, raw.ctypes.data_as(C.POINTER(C.c_uint64)), raw.size)
+        raw = raw.reshape(64, 32)
+        stages = []
+        inv = np.uint64(0xFFFFFFFFFFFFFFFF)
+        for s in range(settings.indirect_bounces + 1):
+            r = raw[s]
+            if r[4] == 0:
+                continue
+            t0, tdry, tend = int(inv - r[0]), int(inv - r[1]), int(r[2])
+            total, bulk = (tend - t0) * 10e-3, (tdry - t0) * 10e-3   # microseconds (10 ns ticks)
+            stages.append({"stage": s, "launch_us": round(total, 1), "queue_dry_after_us": round(bulk, 1), "tail_us": round(total - bulk, 1),
+                           "tail_fraction": round((total - bulk) / total, 3), "mean_wave_residency": round(int(r[3]) / int(r[4]) / (tend - t0), 3),
+                           "rays": int(r[7]), "mean_node_steps": round(int(r[6]) / max(1, int(r[7])), 1), "max_node_steps": int(r[5]),
+                           "rays_by_log2_steps": [int(x) for x in r[8:24]]})
+        out[str(cfg)] = {"workload": description, "trace_stages": stages}
+        del e
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
