@@ -201,7 +201,7 @@ _DEBUG = {
     "debug_read_wf_timeline": [_vp, P(C.c_uint64), u32],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],
-    "measure_gather": [_vp, C.c_size_t, u32, u32, u32, P(C.c_double), P(C.c_double)],
+    "measure_gather": [_vp, C.c_size_t, u32, u32, u32, u32, P(C.c_double), P(C.c_double)],
 }
 # host logic, builders, multi-GPU and GPU-only entry points
 _PRODUCT_ONLY = {

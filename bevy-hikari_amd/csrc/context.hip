@@ -1779,6 +1779,9 @@ int hk_debug_read_wf_timeline(hk_ctx* c, unsigned long long* out, uint32_t n) {
   HK_HIP(hipSetDevice(c->device));
   { const int rc = sync_all(c); if (rc) return rc; }
   HK_HIP(hipMemcpy(out, c->wf.timeline, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  int khz = 0;
+  HK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+  out[n - 1] = (unsigned long long)khz;  // (slot 31 of stage 63 - never a real stage: the rate of wall_clock64, kHz)
   return HK_OK;
 }
 

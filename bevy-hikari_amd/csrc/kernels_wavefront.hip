@@ -30,6 +30,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 #include "hk_light.hpp"
@@ -48,6 +51,9 @@ constexpr uint32_t WF_QHEAD = 128u;   // [s] rays of trace stage s claimed so fa
 #endif
 #ifndef HK_WF_TRACE_WAVES
 #define HK_WF_TRACE_WAVES 7   // waves per SIMD the trace kernel is compiled for (69 VGPRs, no spills; 8 would spill 44 B per lane)
+#endif
+#ifndef HK_WF_TRACE_WG_PER_CU
+#define HK_WF_TRACE_WG_PER_CU 8  // 256-thread workgroups of the persistent trace launch per CU (7 are resident at 69 VGPRs)
 #endif
 #ifndef HK_WF_STEPS
 #define HK_WF_STEPS 4         // node steps per turn of the node phase
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
   const DScene sc = stage_scene<LDS>(gsc);
   __shared__ uint32_t tl_hist[16];
   unsigned long long tl_start = 0ull;
-  uint32_t tl_steps = 0u, tl_max = 0u, tl_sum = 0u, tl_rays = 0u;
+  uint32_t tl_steps = 0u, tl_max = 0u, tl_sum = 0u, tl_rays = 0u, tl_claimed = 0u;  // tl_claimed: ticks after the wave's start at which the lane's ray was handed out
   bool tl_seen_dry = false;
   if (TL) {
     if (threadIdx.x < 16u) tl_hist[threadIdx.x] = 0u;
@@ -309,6 +315,15 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
       tl_sum += tl_steps;
       tl_rays += 1u;
       atomicAdd(&tl_hist[min(15u, 31u - (uint32_t)__clz((int)(tl_steps + 1u)))], 1u);
+      if (tl_steps >= 256u) {  // the long walks: how long they took, and when they were handed out
+        const uint32_t now_rel = (uint32_t)(wall_clock64() - tl_start);
+        unsigned long long* tl = w.timeline + 32u * stage;
+        atomicAdd(&tl[24], (unsigned long long)(now_rel - tl_claimed));  // ticks in flight, summed
+        atomicAdd(&tl[25], (unsigned long long)tl_steps);
+        atomicAdd(&tl[26], 1ull);
+        atomicMax(&tl[27], ((unsigned long long)(now_rel - tl_claimed) << 32) | tl_steps);  // the slowest of them: ticks | its steps
+        atomicMax(&tl[28], ((unsigned long long)tl_claimed << 32) | tl_steps);              // the one handed out last: ticks after start | its steps
+      }
       tl_steps = 0u;
     }
     const uint32_t slot = entry_id & ~WF_SHADOW;
@@ -337,7 +352,11 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
         given = res_count;
         if (idle && rank < given) mine = res_base + rank;
         // one atomic per 256 rays while every lane of the launch can still be fed four more times from what is left, per 64
-        // near the end of the queue (short blocks there keep the last waves from walking a long reserve alone)
+        // near the end of the queue (short blocks there keep the last waves from walking a long reserve alone).
+        // (Round 4, tools/wf_timeline.py: when the queue runs dry up to 60 rays still sit in each wave's PRIVATE reserve, behind
+        // lanes busy with long walks.  Guided self-scheduling - a wave takes 1/4 of an even share of what is left, at least its idle
+        // lanes - hands the last ray out right when the queue empties, as intended, and makes the frames 2-8 % SLOWER: twice the
+        // atomics on one hot counter, and the stage's end is set by its longest walks either way - see DESIGN 8.1.)
         const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : 64u;
         uint32_t b = 0u;
         if ((threadIdx.x & 63u) == 0u) b = atomicAdd(head_ptr, block);
@@ -361,9 +380,12 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
           walk_begin(k, sc, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE);
         }
         phase = PH_NODE;
+        if (TL) tl_claimed = (uint32_t)(wall_clock64() - tl_start);
       }
     }
-    // the phase with the most lanes waiting runs (ties: nodes, then triangles)
+    // the phase with the most lanes waiting runs (ties: nodes, then triangles).
+    // (Round 4: serving EVERY parked lane every turn once the wave can no longer be refilled - latency instead of lane utilisation
+    // for the walks that end the launch - changes no stage by more than 1 %: tools/wf_timeline.py)
     const uint32_t n_node = (uint32_t)__popcll(__ballot(phase == PH_NODE));
     const uint32_t n_tri = (uint32_t)__popcll(__ballot(phase == PH_TRI));
     const uint32_t n_entry = (uint32_t)__popcll(__ballot(phase == PH_ENTRY));
@@ -572,11 +594,16 @@ void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& f
   hipExtLaunchKernelGGL(k_wf_setup, grid_for(fr.rw, y1 - y0), dim3(256), 0, st, start, nullptr, 0, sc, fr, g, t, w, y0, y1);
   const size_t lds = (size_t)sc.blob_f4 * 16 <= HK_LDS_SCENE_BYTES ? (size_t)sc.blob_f4 * 16 : 0;
   const dim3 persistent((unsigned)(compute_units * 8));  // 8 workgroups of 4 waves per CU: what 64 VGPRs leave resident
+  // rays in flight = lanes of the trace launch.  Little's law: with R node steps per second served by the memory system, a step of
+  // one ray takes (rays in flight) / R - every ray beyond what saturates R only makes all of them slower, and the launch ends with
+  // its longest walk (tools/wf_timeline.py; HK_WF_TRACE_WG_PER_CU for the A/B)
+  static const int trace_wg_per_cu = getenv("HK_WF_TRACE_WG_PER_CU") ? std::max(1, atoi(getenv("HK_WF_TRACE_WG_PER_CU"))) : HK_WF_TRACE_WG_PER_CU;
+  const dim3 tracers((unsigned)(compute_units * trace_wg_per_cu));
   const uint32_t bounces = fr.indirect_bounces;
   for (uint32_t n = 0; n <= bounces; ++n) {
-    if (w.timeline && !lds) hipLaunchKernelGGL((k_wf_trace<false, true>), persistent, dim3(256), 0, st, sc, w, n);
-    else if (lds) hipLaunchKernelGGL((k_wf_trace<true, false>), persistent, dim3(256), lds, st, sc, w, n);
-    else hipLaunchKernelGGL((k_wf_trace<false, false>), persistent, dim3(256), 0, st, sc, w, n);
+    if (w.timeline && !lds) hipLaunchKernelGGL((k_wf_trace<false, true>), tracers, dim3(256), 0, st, sc, w, n);
+    else if (lds) hipLaunchKernelGGL((k_wf_trace<true, false>), tracers, dim3(256), lds, st, sc, w, n);
+    else hipLaunchKernelGGL((k_wf_trace<false, false>), tracers, dim3(256), 0, st, sc, w, n);
     if (n == bounces) break;
     if (lds) hipLaunchKernelGGL((k_wf_shade<true>), persistent, dim3(256), lds, st, sc, fr, w, n);
     else hipLaunchKernelGGL((k_wf_shade<false>), persistent, dim3(256), 0, st, sc, fr, w, n);

@@ -210,9 +210,10 @@ int hk_measure_valu(hk_ctx* c, uint32_t iters, double ginstr_s[4]) {
 
 
 // hikari_hip_debug.h
-int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps, double* gloads_s, double* gbytes_s) {
+int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps, uint32_t workgroups, double* gloads_s,
+                      double* gbytes_s) {
   HK_REQUIRE(c && gloads_s && gbytes_s && (bytes_per_step == 16u || bytes_per_step == 32u || bytes_per_step == 64u) && waves_per_simd >= 1u && waves_per_simd <= 8u && steps >= 16u &&
-                 footprint_bytes >= (1u << 20) && footprint_bytes <= ((size_t)32 << 30), HK_E_INVALID, "bad argument");
+                 footprint_bytes >= 4096u && footprint_bytes <= ((size_t)32 << 30), HK_E_INVALID, "bad argument");
   PROBE_BEGIN(c);
   uint32_t n_records = 1u;
   while ((size_t)n_records * 2u * bytes_per_step <= footprint_bytes && n_records < (1u << 30)) n_records *= 2u;  // a power of two: the LCG's period
@@ -231,7 +232,8 @@ int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step
   }
   if (!rc) {
     hipLaunchKernelGGL(k_gather_fill, dim3((n_records + 255u) / 256u), dim3(256), 0, stream, table, n_records, loads, 1664525u, 1013904223u);
-    const dim3 grid((unsigned)prop.multiProcessorCount * waves_per_simd);  // one 256-thread workgroup = one wave on each SIMD of a CU
+    // one 256-thread workgroup = one wave on each SIMD of a CU; `workgroups` (0 = CUs x waves_per_simd) lets a sweep load only part of the chip
+    const dim3 grid(workgroups ? workgroups : (unsigned)prop.multiProcessorCount * waves_per_simd);
     for (int pass = 0; pass < 2; ++pass) {  // (pass 0 warms up: page tables, clocks)
       (void)hipEventRecord(e0, stream);
       if (loads == 1u) hipLaunchKernelGGL(k_gather_chase<1>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
@@ -244,7 +246,7 @@ int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step
       set_error("gather probe failed: %s", hipGetErrorString(e));
       rc = HK_E_HIP;
     } else {
-      const double waves = (double)prop.multiProcessorCount * 4.0 * waves_per_simd;
+      const double waves = 4.0 * (double)grid.x;
       *gloads_s = waves * steps * loads / ((double)ms * 1e-3) / 1e9;
       *gbytes_s = waves * 64.0 * steps * bytes_per_step / ((double)ms * 1e-3) / 1e9;
     }

@@ -696,10 +696,10 @@ class Engine:
         self.api.call("measure_hbm", self.ctx, bytes_per_array, reps, C.byref(cp), C.byref(tr))
         return cp.value, tr.value
 
-    def measure_gather(self, footprint_bytes, bytes_per_step=32, waves_per_simd=7, steps=512):
+    def measure_gather(self, footprint_bytes, bytes_per_step=32, waves_per_simd=7, steps=512, workgroups=0):
         """hk_measure_gather: (G wave-level loads / s, GB/s) of dependent divergent gathers over `footprint_bytes` of records."""
         a, b = C.c_double(), C.c_double()
-        self.api.call("measure_gather", self.ctx, int(footprint_bytes), bytes_per_step, waves_per_simd, steps, C.byref(a), C.byref(b))
+        self.api.call("measure_gather", self.ctx, int(footprint_bytes), bytes_per_step, waves_per_simd, steps, workgroups, C.byref(a), C.byref(b))
         return a.value, b.value
 
     def measure_valu(self, iters=2048):

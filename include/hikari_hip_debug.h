@@ -37,7 +37,7 @@ int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, floa
  * (1e9 / s) and of loaded bytes (lanes x bytes_per_step per step; GB/s).  No walk of that shape runs faster on the chip: the
  * trace kernels of configs 3 / 4 are priced against it in bench.py (the HBM roof is meaningless for them - they move little). */
 int hk_measure_gather(hk_ctx* ctx, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps,
-                      double* gloads_s, double* gbytes_s);
+                      uint32_t workgroups /* 0 = CUs x waves_per_simd (the whole chip); else that many 256-thread workgroups */, double* gloads_s, double* gbytes_s);
 
 /* Profiling hook (tools/wf_timeline.py): with HK_WF_TIMELINE=1 in the environment the trace stages of the queue-based indirect pass
  * run an instrumented twin that records, per stage, when the ray queue ran dry, when the last persistent wave left and how long

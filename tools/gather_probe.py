@@ -28,6 +28,15 @@ def main():
         return
     out = {"what": "hk_measure_gather: every lane chases its own chain of dependent loads through a random permutation cycle (64 unrelated addresses per wave-level "
                    "load, no reuse); rates in 1e9 wave-level load instructions / s and GB/s of loaded bytes", "steps": 512, "sweep": []}
+    # what limits the rate?  (a) the level that serves the request: 16 KiB sits in every CU's L1, 2 MiB in every XCD's L2, 32 MiB in the
+    # Infinity Cache; (b) the number of CUs asking: 1, 8, 32, 64, 128 workgroups of one wave per SIMD
+    out["by_level_and_width"] = []
+    for footprint in (16 << 10, 256 << 10, 2 << 20, 32 << 20, 1 << 30):
+        for wgs in (1, 8, 32, 64, 128, 256, 1024):
+            loads, gbs = e.measure_gather(footprint, 32, 1, 512, wgs)
+            out["by_level_and_width"].append({"footprint_KiB": footprint >> 10, "workgroups": wgs, "g_lane_steps_s": round(loads / 2 * 64, 2),
+                                              "ns_per_step": round(wgs * 4 / (loads / 2), 1) if loads else None,
+                                              "lane_steps_per_us_per_workgroup": round(loads / 2 * 64 * 1e3 / wgs, 1)})
     for footprint in (32 << 20, 393 << 20, 1200 << 20, 4 << 30):
         for rec in (16, 32, 64):
             for waves in (1, 2, 4, 7, 8):

@@ -30,6 +30,7 @@ def main():
         raw = np.zeros(64 * 32, dtype=np.uint64)
         e.api.call("debug_read_wf_timeline", e.ctx, raw.ctypes.data_as(C.POINTER(C.c_uint64)), raw.size)
         raw = raw.reshape(64, 32)
+        tick_us = 1e3 / float(raw[63, 31])   # wall_clock64 rate in kHz -> microseconds per tick
         stages = []
         inv = np.uint64(0xFFFFFFFFFFFFFFFF)
         for s in range(settings.indirect_bounces + 1):
@@ -37,12 +38,15 @@ def main():
             if r[4] == 0:
                 continue
             t0, tdry, tend = int(inv - r[0]), int(inv - r[1]), int(r[2])
-            total, bulk = (tend - t0) * 10e-3, (tdry - t0) * 10e-3   # microseconds (10 ns ticks)
+            total, bulk = (tend - t0) * tick_us, (tdry - t0) * tick_us
             stages.append({"stage": s, "launch_us": round(total, 1), "queue_dry_after_us": round(bulk, 1), "tail_us": round(total - bulk, 1),
                            "tail_fraction": round((total - bulk) / total, 3), "mean_wave_residency": round(int(r[3]) / int(r[4]) / (tend - t0), 3),
                            "rays": int(r[7]), "mean_node_steps": round(int(r[6]) / max(1, int(r[7])), 1), "max_node_steps": int(r[5]),
-                           "rays_by_log2_steps": [int(x) for x in r[8:24]]})
-        out[str(cfg)] = {"workload": description, "trace_stages": stages}
+                           "rays_by_log2_steps": [int(x) for x in r[8:24]],
+                           "long_walks_256_steps_up": {"rays": int(r[26]), "mean_us_per_node_step": round(int(r[24]) * tick_us / max(1, int(r[25])), 3),
+                                                       "slowest": {"us": round((int(r[27]) >> 32) * tick_us, 1), "node_steps": int(r[27]) & 0xFFFFFFFF},
+                                                       "handed_out_last": {"us_after_wave_start": round((int(r[28]) >> 32) * tick_us, 1), "node_steps": int(r[28]) & 0xFFFFFFFF}}})
+        out[str(cfg)] = {"workload": description, "wall_clock_khz": int(raw[63, 31]), "trace_stages": stages}
         del e
     print(json.dumps(out, indent=1))
 
