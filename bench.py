@@ -458,6 +458,8 @@ def main():
             if t2:
                 out["roofline"]["second_kernel"]["traffic"] = t2["hbm_bytes_per_launch"]
                 out["roofline"]["second_kernel"]["traffic_ratio_to_algorithmic"] = t2["ratio_to_algorithmic"]
+                if "ratio_to_algorithmic_lower_bound" in t2:   # FETCH_SIZE x 1 (right for 64-B record gathers) .. x 2 (right for coalesced streams): profiles/r04_fetch_calibration.json
+                    out["roofline"]["second_kernel"]["traffic_ratio_bounds"] = [t2["ratio_to_algorithmic_lower_bound"], t2["ratio_to_algorithmic"]]
     if hbm:
         out["roofline"]["hbm_ceiling_measured"] = hbm
         out["roofline"]["frac_of_measured_copy"] = round(achieved / hbm["copy_gbs"], 6) if hbm["copy_gbs"] > 0 else None

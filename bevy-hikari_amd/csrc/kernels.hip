@@ -75,6 +75,14 @@ __device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams
   return ray;
 }
 
+// Round 4 experiment, OFF: the wave-coherent walk of hk_device.hpp (traverse_top_wave) for the primary rays of scenes in global
+// memory.  Bit-exact in the reference order, inside the default mode's bars with threaded trees (the parity tests of configs 3 / 4
+// pass with it), scalar node loads as intended - and config 3's prepass goes 1.04 -> 0.99 ms, config 4's (4K, distant small
+// instances: the UNION of 64 neighbouring rays' node sequences is several times one ray's) 4.1 -> 6.7 ms
+// (profiles/r04_wave_walk_ab.txt).  Kept behind the switch for coherent rays over coarser geometry.
+#ifndef HK_PREPASS_WAVE_WALK
+#define HK_PREPASS_WAVE_WALK 0
+#endif
 template <bool COUNT, int LDS>
 __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
                                                   unsigned long long* counters) {
@@ -82,10 +90,20 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
   const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
   RayCounters rc{0, 0};
   uint32_t primary = 0;
+  // scenes walked from global memory: the 64 primary rays of the wave's 8x8 tile travel together - one wave-uniform cursor, the
+  // node fetched once for everybody (hk_device.hpp traverse_top_wave); scenes in LDS keep one walk per lane
+  constexpr bool WAVE_WALK = LDS == 0 && HK_PREPASS_WAVE_WALK;
+  Ray wray;
+  wray.origin = wray.direction = wray.inv_direction = F3(0, 0, 0);
+  Hit whit;
+  if (WAVE_WALK) {
+    if (px.valid) wray = primary_ray(fr, pp, (float)px.x, (float)px.y);
+    whit = traverse_top_wave(sc, wray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, px.valid, rc);
+  }
   if (px.valid) {
     const int idx = px.x + fr.dw * px.y;
-    Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
-    Hit hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+    Ray ray = WAVE_WALK ? wray : primary_ray(fr, pp, (float)px.x, (float)px.y);
+    Hit hit = WAVE_WALK ? whit : traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
     rc.tlas = 0;  // counted as a primary ray
     primary = 1;
     rc.hits += hit.instance_index != HK_U32_MAX ? 1u : 0u;

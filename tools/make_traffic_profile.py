@@ -63,7 +63,12 @@ def main():
         hbm2, algo2 = int(2 * f2["FETCH_SIZE"][0] * 1024 + w2["WRITE_SIZE"][0] * 1024), 240 * 1920 * 1080
         out["second_kernel"] = {"kernel": "k_spatial_reuse<false> (spatial_reuse, light.wgsl:1503-1684)", "FETCH_SIZE_KB_raw": round(f2["FETCH_SIZE"][0], 1),
                                 "WRITE_SIZE_KB": round(w2["WRITE_SIZE"][0], 1), "hbm_bytes_per_launch": hbm2, "algorithmic_bytes_per_launch": algo2,
-                                "ratio_to_algorithmic": round(hbm2 / algo2, 3), "valu_wave_instructions": round(s2["SQ_INSTS_VALU"][0], 1),
+                                "ratio_to_algorithmic": round(hbm2 / algo2, 3),
+                                # profiles/r04_fetch_calibration.json: FETCH_SIZE tallies 64 B per memory-side read request; a coalesced stream issues 128-B
+                                # requests (x 2 is right), a gather of 64-B records 64-B requests (x 1 is right).  This kernel does both: the truth lies between.
+                                "hbm_bytes_per_launch_lower_bound": int(f2["FETCH_SIZE"][0] * 1024 + w2["WRITE_SIZE"][0] * 1024),
+                                "ratio_to_algorithmic_lower_bound": round((f2["FETCH_SIZE"][0] * 1024 + w2["WRITE_SIZE"][0] * 1024) / algo2, 3),
+                                "valu_wave_instructions": round(s2["SQ_INSTS_VALU"][0], 1),
                                 "lane_utilisation": round(s2["SQ_THREAD_CYCLES_VALU"][0] / (64.0 * s2["SQ_ACTIVE_INST_VALU"][0]), 3)}
     except SystemExit:
         pass
