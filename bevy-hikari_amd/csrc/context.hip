@@ -1,253 +1,17 @@
-// context.hip - the C ABI of libhikari_hip.so: context, uploads, per-frame dispatch order.
+// context.hip - the C ABI of libhikari_hip.so: context lifetime, screen-space resources, per-frame dispatch order.
 //
 // Reference call sites this file stands in for (cryscan/bevy-hikari v0.3.15):
-//   uploads        src/mesh_material/mesh.rs:43-64, material.rs:201-202, instance.rs:82-108, src/lib.rs:189-219
 //   resources      src/light.rs:307-383 (render/variance/albedo textures, 10 reservoir buffers),
 //                  src/prepass.rs:285-318 (G-buffer), src/post_process.rs:621-633 (denoise textures)
 //   dispatch order src/prepass.rs:769-852, src/light.rs:590-702, src/post_process.rs:1190-1234
 //   ping-pong      src/light.rs:376,480-481,518-546
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <algorithm>
-#include <chrono>
-#include <new>
-#include <thread>
-#include <utility>
-#include <vector>
-
-#include "hk_internal.hpp"
-#include "hk_kernels.hpp"
+// (uploads and the scene layout: scene_layout.hip; instance motion on the device: scene_refit.hip; hk_ctx: hk_context.hpp)
+#include "hk_context.hpp"
 
 using namespace hk;
 using namespace hkd;
 
-#define HK_HIP(expr)                                                                     \
-  do {                                                                                   \
-    hipError_t e_ = (expr);                                                              \
-    if (e_ != hipSuccess) {                                                              \
-      ::hk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-      return HK_E_HIP;                                                                   \
-    }                                                                                    \
-  } while (0)
-
-namespace {
-
-__global__ void k_copy_u4(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t n) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dst[i] = src[i];
-}
-
-template <typename T>
-struct DevArray {
-  T* p = nullptr;
-  size_t n = 0;
-  int upload(const std::vector<T>& h) {
-    if (p) { (void)hipFree(p); p = nullptr; }
-    n = h.size();
-    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    HK_HIP(hipMalloc((void**)&p, bytes));
-    if (n) HK_HIP(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
-    return HK_OK;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-};
-
-// One device allocation for all scene arrays, each 16-B aligned.
-struct Blob {
-  std::vector<uint8_t> bytes;
-  template <typename T>
-  size_t add(const std::vector<T>& v) {
-    size_t off = (bytes.size() + 15) & ~(size_t)15;
-    bytes.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T), 0);
-    if (!v.empty()) memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
-    return off;
-  }
-};
-
-struct TimedLaunch {
-  uint32_t slot;
-  hipEvent_t start, stop;
-};
-
-// IEEE minNum / maxNum with -0 < +0 (the numeric contract of hk_device_math.hpp) on the host
-inline float hmin(float a, float b) {
-  if (a != a) return b;
-  if (b != b) return a;
-  if (a == b) return signbit(a) ? a : b;
-  return a < b ? a : b;
-}
-inline float hmax(float a, float b) {
-  if (a != a) return b;
-  if (b != b) return a;
-  if (a == b) return signbit(a) ? b : a;
-  return a > b ? a : b;
-}
-inline uint32_t hash_u32(uint32_t value) {  // utils.wgsl:15-24
-  uint32_t state = value;
-  state = state ^ 2747636419u;
-  state = state * 2654435769u;
-  state = state ^ (state >> 16u);
-  state = state * 2654435769u;
-  state = state ^ (state >> 16u);
-  state = state * 2654435769u;
-  return state;
-}
-inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-
-}  // namespace
-
-// byte offsets of the arrays inside the instance-level region of the scene allocation
-struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emissives, alias, materials, tex_info, srgb_lut, flat; uint32_t flat_count, flat_orderings; };
-
-struct hk_ctx {
-  int device = 0;
-  uint32_t flags = 0;
-  hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless hk_set_stream)
-  hipStream_t own_stream = nullptr;
-  hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
-  hipEvent_t fork_event = nullptr, join_event = nullptr;
-  bool forked = false;                 // side_stream holds work the main stream has not waited for yet
-  // Frame pipelining (round 3): the a-trous levels + tone mapping of frame n run on a third stream, so that the main stream goes
-  // straight on to frame n + 1's primary rays and light passes (which read none of the denoiser's buffers).  What both touch is
-  // double-buffered by frame parity: albedo, depth gradient and the derived planes (dn_g, depth) the a-trous taps read.
-  hipStream_t post_stream = nullptr;
-  hipEvent_t post_fork = nullptr, post_done = nullptr;
-  bool post_pending = false;           // post_stream holds work the main stream has not waited for yet
-  uint32_t post_parity = 0;            // mapped_parity of the frame whose a-trous levels are (were last) on post_stream
-  void* albedo_twin = nullptr;         // the planes of the OTHER frame parity (swapped with buf[HK_BUF_ALBEDO] ... in hk_frame_begin)
-  void* depth_gradient_twin = nullptr;
-  void* dn_g_twin = nullptr;
-
-  // host copies of the reference-layout scene (kept for the layout conversion)
-  std::vector<HkVertex> vertices;
-  std::vector<HkPrimitive> primitives;
-  std::vector<HkNode> asset_nodes;
-  std::vector<HkMaterial> materials;
-  std::vector<HkInstance> instances;
-  std::vector<HkNode> instance_nodes;
-  std::vector<HkEmissive> emissives;
-  std::vector<HkNode> emissive_nodes;
-  std::vector<HkAliasEntry> alias_table;
-  struct HostTexture { std::vector<uint32_t> texels; uint32_t w, h, flags; };
-  std::vector<HostTexture> textures;
-  bool have_meshes = false, have_materials = false, have_instances = false, have_noise = false;
-  // what finalize_scene has to redo: the mesh-level region, the instance-level region, the texel buffer
-  bool mesh_dirty = true, dynamic_dirty = true, textures_dirty = true;
-  std::vector<float> prev_models;          // PreviousMeshUniform::transform per instance (optional)
-  std::vector<int64_t> node_prim_offset;   // primitive offset each BLAS node's leaves index (from the last mesh-level build)
-
-  // device scene
-  uint8_t* scene_mem = nullptr;  // every scene array in one allocation (so small scenes can be staged in LDS by one copy loop)
-  size_t dyn_capacity = 0, static_bytes = 0;
-  // Scenes too big for the LDS copy keep TWO slots of the instance-level region, [slot 0][slot 1][mesh region]: an
-  // instance-only update goes through pinned staging into the slot the frames in flight do NOT read, in stream
-  // order, so neither the host nor the GPU waits (animated scenes must not stall on the host).
-  bool two_slots = false;
-  int slot = 0;
-  Blob dyn_blob;                // the instance-level region as last laid out: kept so that a per-frame update re-uses warm pages
-  std::vector<float4> tlas_tmp;  // (20 MB of fresh allocations per update cost more in page faults than the layout itself)
-  bool trees_pending_on_device = false;  // hk_update_scene_instances: the trees about to be uploaded are stand-ins the device overwrites in
-                                         // stream order - no point threading their orderings on the host
-  bool threaded = false;  // eight direction-ordered flattenings of every TLAS / BLAS are stored (hikari_hip.h HK_CTX_EXACT_TRAVERSAL)
-  uint8_t* staging[2] = {nullptr, nullptr};
-  size_t staging_bytes[2] = {0, 0};
-  hipEvent_t staging_done[2] = {nullptr, nullptr};
-  bool staging_pending[2] = {false, false};
-  uint64_t async_instance_uploads = 0;
-  size_t st_nodes = 0, st_v0 = 0, st_v1 = 0, st_v2 = 0, st_vn = 0, st_vuv = 0;  // offsets inside the mesh-level region
-  uint64_t static_rebuilds = 0, dynamic_rebuilds = 0;
-  // Parked previous_spatial stores (HK_CTX_DETERMINISTIC_SCATTER; every band of a sharded frame with a history halo: SURVEY 8e
-  // step 6), one set per light channel.  `to` and the records are the HK_BUF_PARKED_* planes (c->buf: bands exchange their rows),
-  // the winners are private.  Allocated on first use (ensure_parked).
-  int* det_winner[3] = {nullptr, nullptr, nullptr};
-  // uniform-tile store elision (hk_kernels.hpp TileMeta): one record per 8x8 tile per reservoir buffer; tile_meta_zero[k] = the
-  // device array of buffer k is known to be all zero ("contents unknown" everywhere)
-  TileMeta* tile_meta[10] = {};
-  bool tile_meta_zero[10] = {};
-  int tiles_x = 0, tiles_y = 0;
-  uint32_t elide_serial = 0;
-  // ---- instance motion on the device (hk_refit_scene_instances, kernels_scene.hip)
-  DynOffsets dyn_off{};                   // where the arrays of the instance-level region are (the slot in use)
-  float4 *rf_inst_lo = nullptr, *rf_inst_hi = nullptr, *rf_prev_models = nullptr;  // world AABB / previous model per instance
-  uint32_t* rf_emissive_of_instance = nullptr;
-  float* rf_alias_scratch = nullptr;
-  size_t rf_instances = 0, rf_alias = 0;  // sizes the side arrays were allocated for
-  bool rf_ready = false;                  // side arrays describe the scene as uploaded (cleared by every host-side rebuild)
-  hkd::RefitUpdate* rf_updates[2] = {nullptr, nullptr};  // pinned, read by the kernel over PCIe
-  size_t rf_updates_cap[2] = {0, 0};
-  hipEvent_t rf_done[2] = {nullptr, nullptr};
-  bool rf_pending[2] = {false, false};
-  int rf_k = 0;
-  std::vector<uint32_t> rf_last_moved;    // instances whose `moved` flag is set on the device
-  bool mirrors_stale = false;             // the host copies of emissives / tree boxes no longer describe the device scene
-  uint64_t device_refits = 0, device_tree_builds = 0;
-  void* lbvh_scratch = nullptr;           // hk_rebuild_scene_trees
-  size_t lbvh_scratch_cap = 0;
-  const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
-  DevArray<uint32_t> d_noise;
-  DevArray<uint32_t> d_tex_data;
-  DScene scene{};
-
-  // screen-space resources
-  int W = 0, H = 0, RW = 0, RH = 0;
-  int UW = 0, UH = 0;           // SMAA Tu4x output size, ceil(size * 2 / ratio) (post_process.rs:718-722)
-  bool uv_fast = false;         // (k + 0.5) / size certified for div_by() on all four sizes (certify_uv_division)
-  uint32_t mapped_parity = 0;   // frame parity whose planes the non-PREVIOUS ids of the double-buffered set name
-  float ratio = 1.0f;
-  void* buf[HK_BUF_COUNT] = {};
-  size_t buf_bytes[HK_BUF_COUNT] = {};
-  // private planes (no HkBuffer id): derived G-buffer planes and the denoiser's per-channel sets used
-  // when all channels of a level run in one launch (the exposed internals hold the LAST channel, which
-  // is what they hold after the reference's channel-by-channel loop)
-  float* depth_plane = nullptr;       // position.w of the current frame's G-buffer (4-B taps)
-  float* prev_depth_plane = nullptr;  // ... of the previous frame's (follows the frame parity like HK_BUF_PREVIOUS_POSITION)
-  void* dn_g = nullptr;
-  void* dn_extra[2][4] = {};
-  float* dn_extra_var[2] = {};
-  bool derived_dirty = false;
-  // scratch of the queue-based schedule of indirect_lit_ambient (hikari_hip.h HK_CTX_WAVEFRONT): ONE allocation, carved into
-  // the planes of hkd::WfBuffers on first use and again after hk_resize
-  void* wf_mem = nullptr;
-  hkd::WfBuffers wf{};
-  int compute_units = 0;
-
-  // uniforms
-  HkFrame frame{};
-  HkView view{};
-  HkPreviousView pview{};
-  HkLights lights{};
-  bool have_frame = false;
-  uint32_t taa = HK_TAA_JASMINE, upscale_kind = HK_UPSCALE_SMAA_TU4X;
-  float upscale_sharpness = 0.0f;
-
-  uint32_t band_index = 0, band_count = 1;
-  std::vector<uint32_t> band_bounds;   // explicit split of the scaled render rows (hk_set_band_bounds): band_count + 1 entries, or empty = equal split
-  uint32_t bounds_generation = 0;
-  void* comm = nullptr;        // RCCL communicator state, owned by comm.cpp (hk_comm_init)
-  uint32_t history_rows = HK_HISTORY_AUTO;  // exchange C rows asked for (hk_set_history_rows): a count, or derived per frame
-  uint32_t history_now = 0;    // ... in force for the frame most recently begun (0 for a single band)
-
-  // statistics
-  unsigned long long* d_counters = nullptr;  // primary, tlas, blas, node steps, triangle tests, instance entries, closest hits (hk_light.hpp flush_counters)
-  uint64_t frames = 0;
-  uint32_t timing_mask = 0;
-  std::vector<TimedLaunch> pending;
-  std::vector<hipEvent_t> event_pool;
-  double slot_ms[HK_TIMING_SLOTS] = {};
-  uint64_t slot_launches[HK_TIMING_SLOTS] = {};
-  hipEvent_t frame_start = nullptr, frame_stop = nullptr;
-  bool frame_timed = false;
-  float last_frame_ms = 0.0f;
-};
-
-namespace {
+namespace hk {
 
 // logical size of a buffer: upscale_output is created at scale 2/ratio for SMAA Tu4x and taa_output at the
 // scale in effect after the upscale match (post_process.rs:712-733): 2/ratio for SMAA Tu4x, 1/ratio for FSR1
@@ -368,611 +132,6 @@ struct ScopedTimer {
     }
   }
 };
-
-// `bvh` 0.7.1's flat format puts a "navigator" node (child box, entry = next) in front of EVERY subtree,
-// including single-leaf subtrees, and the reference then tests the leaf's own (re-derived) box again:
-// two steps with the same box for every leaf reached.  With leaf boxes filled in at upload, a navigator
-// whose subtree is one leaf with an equal box can take over the leaf's role (entry := leaf entry): the
-// walk performs box test -> leaf action -> continue at the same exit index, i.e. exactly the outcomes
-// of the two-step sequence, and the original leaf slot is simply never visited.  No index changes.
-// entry/exit are LOCAL to [begin, begin + count).  Returns the number of folded navigators.
-size_t fold_leaf_navigators(std::vector<float4>& lo, std::vector<float4>& hi, size_t begin, size_t count) {
-  auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
-  size_t folded = 0;
-  for (size_t k = 0; k + 1 < count; ++k) {
-    float4& nlo = lo[begin + k];
-    const float4& nhi = hi[begin + k];
-    const uint32_t entry = bits(nlo.w), exit_ = bits(nhi.w);
-    if (entry >= HK_BVH_LEAF_FLAG || entry != k + 1) continue;
-    const float4& clo = lo[begin + k + 1];
-    const float4& chi = hi[begin + k + 1];
-    if (bits(clo.w) < HK_BVH_LEAF_FLAG || bits(chi.w) != exit_) continue;
-    if (!(nlo.x == clo.x && nlo.y == clo.y && nlo.z == clo.z && nhi.x == chi.x && nhi.y == chi.y && nhi.z == chi.z)) continue;
-    nlo.w = clo.w;
-    ++folded;
-  }
-  return folded;
-}
-
-// Convert the reference-layout scene to the device layout (hk_device.hpp header comment).
-//
-// One device allocation, two regions:
-//   [ instance-level region, `dyn_capacity` bytes ][ mesh-level region, `static_bytes` bytes ]
-// The instance-level region (TLAS nodes first, instances, light BVH, emissives, alias tables,
-// materials, texture descriptors) is what prepare_instances / prepare_material_assets rewrite when
-// something moves (instance.rs:352-437); it is small (0.6 MB at 2 000 instances) and is the only part
-// rebuilt and re-sent for an instance-only change.  The mesh-level region (BLAS nodes with their leaf
-// boxes, triangle planes, vertex planes) changes only with the mesh assets (mesh.rs:106-166).
-// Node indices are in 32-B units from the start of the allocation: TLAS node i is node i, BLAS node k
-// of a mesh is node blas_base + node_offset + k with blas_base = dyn_capacity / 32.
-
-// `orderings` flattenings of the reference-layout array `src` (ordering 0 = the reference's own order), each range
-// [offset, offset + count) of `ranges` re-threaded on its own (hk_bvh_rethread); a malformed range keeps the reference order
-void thread_orderings(const std::vector<HkNode>& src, const std::vector<std::pair<uint32_t, uint32_t>>& ranges, int orderings, std::vector<std::vector<HkNode>>& out) {
-  out.assign((size_t)orderings, std::vector<HkNode>());
-  out[0] = src;
-  if (orderings <= 1) return;
-  auto rethread = [&](int o) {
-    for (const auto& r : ranges)
-      if (r.second && !rethread_flat_bvh(src.data() + r.first, r.second, (uint32_t)o, out[o].data() + r.first))
-        std::copy(src.begin() + r.first, src.begin() + r.first + r.second, out[o].begin() + r.first);
-  };
-  for (int o = 1; o < orderings; ++o) out[o] = src;
-  // Small trees (the instance tree of an animated frame, a few thousand nodes) are re-threaded on the calling thread: spawning
-  // seven threads costs more than the work and sits on the per-frame path.  Large mesh trees use worker threads; a thread that
-  // cannot be created, or a worker that throws (bad_alloc), must not escape through the extern "C" boundary: the orderings it did
-  // not produce are redone serially here.
-  size_t total = 0;
-  for (const auto& r : ranges) total += r.second;
-  std::vector<uint8_t> done((size_t)orderings, 0);
-  if (total >= 8192) {
-    std::vector<std::thread> workers;
-    try {
-      for (int o = 1; o < orderings; ++o)
-        workers.emplace_back([&, o]() {
-          try {
-            rethread(o);
-            done[(size_t)o] = 1;
-          } catch (...) {
-          }
-        });
-    } catch (...) {
-    }
-    for (std::thread& w : workers) w.join();
-  }
-  for (int o = 1; o < orderings; ++o)
-    if (!done[(size_t)o]) {
-      out[o] = src;
-      rethread(o);
-    }
-}
-
-// mesh-level region; fills c->node_prim_offset.  Needs the instances' mesh records to know which
-// primitive range a BLAS leaf indexes (GpuMeshIndex travels with the instance, mod.rs:147-156).
-int build_static_region(hk_ctx* c, Blob& blob, size_t& off_nodes, size_t& off_v0, size_t& off_v1, size_t& off_v2, size_t& off_vn, size_t& off_vuv) {
-  const size_t n_nodes = c->asset_nodes.size(), n_prims = c->primitives.size(), n_verts = c->vertices.size();
-  std::vector<int64_t>& node_prim_offset = c->node_prim_offset;
-  node_prim_offset.assign(n_nodes, -1);
-  for (const HkInstance& in : c->instances)
-    for (uint32_t k = 0; k < in.mesh.node_count; ++k) node_prim_offset[in.mesh.node_offset + k] = in.mesh.primitive;
-  std::vector<std::pair<uint32_t, uint32_t>> ranges;  // distinct mesh ranges
-  {
-    std::vector<uint8_t> done(n_nodes + 1, 0);
-    for (const HkInstance& in : c->instances) {
-      if (in.mesh.node_count == 0 || done[in.mesh.node_offset]) continue;
-      done[in.mesh.node_offset] = 1;
-      ranges.emplace_back(in.mesh.node_offset, in.mesh.node_count);
-    }
-  }
-  const int orderings = c->threaded ? 8 : 1;
-  std::vector<std::vector<HkNode>> ordered;
-  thread_orderings(c->asset_nodes, ranges, orderings, ordered);
-  std::vector<float4> nodes;
-  nodes.reserve(2 * n_nodes * (size_t)orderings);
-  std::vector<float4> lo(n_nodes), hi(n_nodes);
-  for (int o = 0; o < orderings; ++o) {
-    const std::vector<HkNode>& src = ordered[o];
-    for (size_t i = 0; i < n_nodes; ++i) {
-      const HkNode& n = src[i];
-      float mn[3] = {n.min[0], n.min[1], n.min[2]}, mx[3] = {n.max[0], n.max[1], n.max[2]};
-      if (n.entry_index >= HK_BVH_LEAF_FLAG && node_prim_offset[i] >= 0) {  // light.wgsl:408-412
-        size_t prim = (size_t)node_prim_offset[i] + (n.entry_index - HK_BVH_LEAF_FLAG);
-        HK_REQUIRE(prim < n_prims, HK_E_INVALID, "BLAS leaf primitive out of bounds");
-        const HkPrimitiveVertex* v = c->primitives[prim].vertices;
-        for (int k = 0; k < 3; ++k) {
-          mn[k] = hmin(v[0].position[k], hmin(v[1].position[k], v[2].position[k]));
-          mx[k] = hmax(v[0].position[k], hmax(v[1].position[k], v[2].position[k]));
-        }
-      }
-      lo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
-      hi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
-    }
-    for (const auto& r : ranges) fold_leaf_navigators(lo, hi, r.first, r.second);  // fold single-leaf navigators, once per distinct mesh range
-    for (size_t i = 0; i < n_nodes; ++i) { nodes.push_back(lo[i]); nodes.push_back(hi[i]); }
-  }
-  off_nodes = blob.add(nodes);  // offset 0: the region itself starts on a 32-B boundary
-
-  std::vector<float4> v0(n_prims), v1(n_prims), v2(n_prims);
-  for (size_t i = 0; i < n_prims; ++i) {
-    const HkPrimitiveVertex* v = c->primitives[i].vertices;
-    v0[i] = make_float4(v[0].position[0], v[0].position[1], v[0].position[2], as_f(v[0].index));
-    v1[i] = make_float4(v[1].position[0], v[1].position[1], v[1].position[2], as_f(v[1].index));
-    v2[i] = make_float4(v[2].position[0], v[2].position[1], v[2].position[2], as_f(v[2].index));
-  }
-  off_v0 = blob.add(v0);
-  off_v1 = blob.add(v1);
-  off_v2 = blob.add(v2);
-  std::vector<float4> vn(n_verts);
-  std::vector<float2> vuv(n_verts);
-  for (size_t i = 0; i < n_verts; ++i) {
-    vn[i] = make_float4(c->vertices[i].normal[0], c->vertices[i].normal[1], c->vertices[i].normal[2], 0.0f);
-    vuv[i] = make_float2(c->vertices[i].u, c->vertices[i].v);
-  }
-  off_vn = blob.add(vn);
-  off_vuv = blob.add(vuv);
-  blob.bytes.resize((blob.bytes.size() + 15) & ~(size_t)15, 0);
-  return HK_OK;
-}
-
-// ------------------------------------------------------------------ one-level BVH (DScene::flat, hk_device.hpp traverse_flat)
-// Built on the host at every instance-level rebuild of a scene whose instances all share one transform and that fits the LDS
-// copy: every triangle of every instance (local space = the one space they share), a top-down SAH build with an exact sweep
-// along the three axes (the scenes are a few hundred triangles at most), one triangle per leaf, flattened depth-first with
-// skip links once per ray-direction octant - each inner node's children in the order a ray of that octant meets them (axis
-// of the larger centre separation), so a closest-hit walk finds its hit early and skips the rest by their boxes.
-namespace flatbvh {
-struct Tri { float lo[3], hi[3], c[3]; uint32_t prim, inst; };
-struct Node { float lo[3], hi[3]; int left = -1, right = -1; uint32_t prim = 0, inst = 0; };
-inline float half_area(const float* lo, const float* hi) {
-  const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-  return dx * dy + dy * dz + dz * dx;
-}
-int build(std::vector<Node>& nodes, std::vector<Tri>& t, int b, int e) {
-  const int id = (int)nodes.size();
-  nodes.emplace_back();
-  {
-    Node& n = nodes[id];
-    for (int k = 0; k < 3; ++k) { n.lo[k] = t[b].lo[k]; n.hi[k] = t[b].hi[k]; }
-    for (int i = b + 1; i < e; ++i)
-      for (int k = 0; k < 3; ++k) { n.lo[k] = std::min(n.lo[k], t[i].lo[k]); n.hi[k] = std::max(n.hi[k], t[i].hi[k]); }
-  }
-  if (e - b == 1) {
-    nodes[id].prim = t[b].prim;
-    nodes[id].inst = t[b].inst;
-    return id;
-  }
-  const int n = e - b;
-  double best = 1e300;
-  int best_axis = 0, best_split = n / 2;
-  std::vector<float> right_area((size_t)n);
-  for (int axis = 0; axis < 3; ++axis) {
-    std::stable_sort(t.begin() + b, t.begin() + e, [axis](const Tri& x, const Tri& y) { return x.c[axis] < y.c[axis]; });
-    float lo[3], hi[3];
-    for (int i = n - 1; i >= 1; --i) {  // right_area[i] = area of the box of t[b + i .. e)
-      const Tri& q = t[b + i];
-      for (int k = 0; k < 3; ++k) {
-        lo[k] = i == n - 1 ? q.lo[k] : std::min(lo[k], q.lo[k]);
-        hi[k] = i == n - 1 ? q.hi[k] : std::max(hi[k], q.hi[k]);
-      }
-      right_area[(size_t)i] = half_area(lo, hi);
-    }
-    for (int i = 1; i < n; ++i) {  // split: [b, b + i) | [b + i, e)
-      const Tri& q = t[b + i - 1];
-      for (int k = 0; k < 3; ++k) {
-        lo[k] = i == 1 ? q.lo[k] : std::min(lo[k], q.lo[k]);
-        hi[k] = i == 1 ? q.hi[k] : std::max(hi[k], q.hi[k]);
-      }
-      const double cost = (double)half_area(lo, hi) * i + (double)right_area[(size_t)i] * (n - i);
-      if (cost < best) { best = cost; best_axis = axis; best_split = i; }
-    }
-  }
-  std::stable_sort(t.begin() + b, t.begin() + e, [best_axis](const Tri& x, const Tri& y) { return x.c[best_axis] < y.c[best_axis]; });
-  const int l = build(nodes, t, b, b + best_split);
-  const int r = build(nodes, t, b + best_split, e);
-  nodes[id].left = l;
-  nodes[id].right = r;
-  return id;
-}
-// depth-first flattening for direction octant `oct` (only the bits of `mask` are distinguished); returns the index after the subtree
-uint32_t emit(const std::vector<Node>& nodes, int id, uint32_t oct, uint32_t mask, std::vector<float4>& out, uint32_t at) {
-  const Node& n = nodes[id];
-  if (n.left < 0) {
-    out[2 * at] = make_float4(n.lo[0], n.lo[1], n.lo[2], as_f(HK_BVH_LEAF_FLAG | n.prim));
-    out[2 * at + 1] = make_float4(n.hi[0], n.hi[1], n.hi[2], as_f((at + 1u) | (n.inst << 16)));
-    return at + 1u;
-  }
-  const Node &a = nodes[n.left], &b = nodes[n.right];
-  int axis = 0;
-  float sep = -1.0f;
-  for (int k = 0; k < 3; ++k) {
-    const float d = std::fabs((b.lo[k] + b.hi[k]) - (a.lo[k] + a.hi[k]));
-    if (d > sep) { sep = d; axis = k; }
-  }
-  const bool a_smaller = (a.lo[axis] + a.hi[axis]) <= (b.lo[axis] + b.hi[axis]);
-  const bool negative = ((oct & mask) >> axis) & 1u;           // the ray travels towards smaller coordinates on this axis
-  const bool a_first = negative ? !a_smaller : a_smaller;
-  uint32_t next = emit(nodes, a_first ? n.left : n.right, oct, mask, out, at + 1u);
-  next = emit(nodes, a_first ? n.right : n.left, oct, mask, out, next);
-  out[2 * at] = make_float4(n.lo[0], n.lo[1], n.lo[2], as_f(at + 1u));
-  out[2 * at + 1] = make_float4(n.hi[0], n.hi[1], n.hi[2], as_f(next));
-  return next;
-}
-}  // namespace flatbvh
-
-// Fills `out` with `orderings` flattenings of (2 T - 1) nodes each; returns false when the scene does not qualify.
-bool build_flat_bvh(const hk_ctx* c, uint32_t orderings, std::vector<float4>& out, uint32_t& count) {
-  using namespace flatbvh;
-  std::vector<Tri> tris;
-  for (size_t i = 0; i < c->instances.size(); ++i) {
-    const HkInstance& in = c->instances[i];
-    for (uint32_t k = 0; k < in.mesh.node_count; ++k) {
-      const HkNode& nd = c->asset_nodes[in.mesh.node_offset + k];
-      if (nd.entry_index < HK_BVH_LEAF_FLAG) continue;
-      const size_t prim = (size_t)in.mesh.primitive + (nd.entry_index - HK_BVH_LEAF_FLAG);
-      if (prim >= c->primitives.size() || prim > 0xFFFFu) return false;
-      Tri t;
-      const HkPrimitiveVertex* v = c->primitives[prim].vertices;
-      for (int a = 0; a < 3; ++a) {
-        t.lo[a] = hmin(v[0].position[a], hmin(v[1].position[a], v[2].position[a]));  // = the BLAS leaf box (light.wgsl:408-412)
-        t.hi[a] = hmax(v[0].position[a], hmax(v[1].position[a], v[2].position[a]));
-        t.c[a] = 0.5f * (t.lo[a] + t.hi[a]);
-        if (!(t.lo[a] == t.lo[a]) || !(t.hi[a] == t.hi[a])) return false;  // NaN vertices: leave the scene to the reference walk
-      }
-      t.prim = (uint32_t)prim;
-      t.inst = (uint32_t)i;
-      tris.push_back(t);
-    }
-  }
-  if (tris.empty() || tris.size() > 0x7FFFu) return false;
-  std::vector<Node> nodes;
-  nodes.reserve(2 * tris.size());
-  build(nodes, tris, 0, (int)tris.size());
-  count = (uint32_t)nodes.size();
-  out.assign((size_t)orderings * count * 2, make_float4(0, 0, 0, 0));
-  std::vector<float4> one((size_t)count * 2);
-  for (uint32_t o = 0; o < orderings; ++o) {
-    if (emit(nodes, 0, o, orderings - 1u, one, 0u) != count) return false;
-    std::copy(one.begin(), one.end(), out.begin() + (size_t)o * count * 2);
-  }
-  return true;
-}
-
-int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_bytes) {
-  const size_t n_tlas = c->instance_nodes.size();
-  const int orderings = c->threaded ? 8 : 1;
-  std::vector<std::vector<HkNode>> ordered;
-  // hk_update_scene_instances: the device is about to build every ordering of this tree in stream order - ordering 0 is laid
-  // out (its leaf boxes are where the device build reads the instances' boxes from), the other seven slots stay zero
-  const int host_orderings = c->trees_pending_on_device ? 1 : orderings;
-  if (c->trees_pending_on_device) ordered.assign(1, c->instance_nodes);
-  else thread_orderings(c->instance_nodes, {{0u, (uint32_t)n_tlas}}, orderings, ordered);
-  std::vector<float4> tlo(n_tlas), thi(n_tlas);
-  std::vector<float4>& tlas = c->tlas_tmp;
-  tlas.clear();
-  tlas.reserve(2 * n_tlas * (size_t)orderings);
-  for (int ord = 0; ord < host_orderings; ++ord) {
-    for (size_t i = 0; i < n_tlas; ++i) {
-      const HkNode& n = ordered[ord][i];
-      const float* mn = n.min;
-      const float* mx = n.max;
-      if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:454-457: the leaf box is the instance's world AABB
-        uint32_t inst = n.entry_index - HK_BVH_LEAF_FLAG;
-        HK_REQUIRE(inst < c->instances.size(), HK_E_INVALID, "TLAS leaf instance out of bounds");
-        mn = c->instances[inst].min;
-        mx = c->instances[inst].max;
-      }
-      tlo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
-      thi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
-    }
-    fold_leaf_navigators(tlo, thi, 0, n_tlas);
-    for (size_t i = 0; i < n_tlas; ++i) { tlas.push_back(tlo[i]); tlas.push_back(thi[i]); }
-  }
-  tlas.resize(2 * n_tlas * (size_t)orderings, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-  o.tlas = blob.add(tlas);  // offset 0: ordering `ord` starts at node ord * n_tlas
-
-  const bool have_prev = c->prev_models.size() == 16 * c->instances.size();
-  std::vector<DInstance> di(c->instances.size());
-  std::vector<float4> pm;
-  bool any_moved = false;
-  for (size_t i = 0; i < di.size(); ++i) {
-    const HkInstance& in = c->instances[i];
-    const float* t = in.inverse_transpose_model;
-    const float* m = in.model;
-    DInstance& d = di[i];
-    d.im0 = make_float4(t[0], t[4], t[8], t[12]);  // column j of transpose(itm) = row j of itm
-    d.im1 = make_float4(t[1], t[5], t[9], t[13]);
-    d.im2 = make_float4(t[2], t[6], t[10], t[14]);
-    d.im3 = make_float4(t[3], t[7], t[11], t[15]);
-    d.m0 = make_float4(m[0], m[1], m[2], m[3]);
-    d.m1 = make_float4(m[4], m[5], m[6], m[7]);
-    d.m2 = make_float4(m[8], m[9], m[10], m[11]);
-    d.m3 = make_float4(m[12], m[13], m[14], m[15]);
-    d.n0 = make_float4(t[0], t[1], t[2], 0.0f);
-    d.n1 = make_float4(t[4], t[5], t[6], 0.0f);
-    d.n2 = make_float4(t[8], t[9], t[10], 0.0f);
-    d.material = in.material;
-    d.vertex = in.mesh.vertex;
-    d.primitive = in.mesh.primitive;
-    d.node_offset = in.mesh.node_offset;
-    d.node_count = in.mesh.node_count;
-    d.moved = (have_prev && memcmp(&c->prev_models[16 * i], m, 64) != 0) ? 1u : 0u;
-    any_moved = any_moved || d.moved;
-    d.pad1 = d.pad2 = 0;
-  }
-  if (any_moved) {  // previous model matrices, 4 columns per instance (only when something moves)
-    pm.resize(4 * di.size());
-    for (size_t i = 0; i < di.size(); ++i)
-      for (int col = 0; col < 4; ++col) {
-        const float* q = &c->prev_models[16 * i + 4 * col];
-        pm[4 * i + col] = make_float4(q[0], q[1], q[2], q[3]);
-      }
-  }
-  o.instances = blob.add(di);
-  o.prev_models = blob.add(pm);
-
-  const size_t n_light = c->emissive_nodes.size();
-  std::vector<float4> llo(n_light), lhi(n_light);
-  for (size_t i = 0; i < n_light; ++i) {
-    const HkNode& n = c->emissive_nodes[i];
-    float mn[3] = {n.min[0], n.min[1], n.min[2]}, mx[3] = {n.max[0], n.max[1], n.max[2]};
-    if (n.entry_index >= HK_BVH_LEAF_FLAG) {  // light.wgsl:633-636: position -/+ radius
-      uint32_t e = n.entry_index - HK_BVH_LEAF_FLAG;
-      HK_REQUIRE(e < c->emissives.size(), HK_E_INVALID, "light BVH leaf out of bounds");
-      for (int k = 0; k < 3; ++k) {
-        mn[k] = c->emissives[e].position[k] - c->emissives[e].radius;
-        mx[k] = c->emissives[e].position[k] + c->emissives[e].radius;
-      }
-    }
-    llo[i] = make_float4(mn[0], mn[1], mn[2], as_f(n.entry_index));
-    lhi[i] = make_float4(mx[0], mx[1], mx[2], as_f(n.exit_index));
-  }
-  fold_leaf_navigators(llo, lhi, 0, n_light);
-  o.light_lo = blob.add(llo);
-  o.light_hi = blob.add(lhi);
-
-  std::vector<DEmissive> de(c->emissives.size());
-  for (size_t i = 0; i < de.size(); ++i) {
-    const HkEmissive& e = c->emissives[i];
-    HK_REQUIRE(e.instance < c->instances.size(), HK_E_INVALID, "emissive instance out of bounds");
-    HK_REQUIRE((size_t)e.alias_table[0] + e.alias_table[1] <= c->alias_table.size() && e.alias_table[1] > 0, HK_E_INVALID, "emissive alias slice out of bounds");
-    de[i].position_radius = make_float4(e.position[0], e.position[1], e.position[2], e.radius);
-    de[i].instance = e.instance;
-    de[i].alias_offset = e.alias_table[0];
-    de[i].alias_count = e.alias_table[1];
-    de[i].surface_area = e.surface_area;
-  }
-  o.emissives = blob.add(de);
-  std::vector<float2> al(c->alias_table.size());
-  for (size_t i = 0; i < al.size(); ++i) al[i] = make_float2(c->alias_table[i].prob, as_f(c->alias_table[i].index));
-  o.alias = blob.add(al);
-
-  const uint32_t n_tex = (uint32_t)c->textures.size();
-  std::vector<float4> mats(4 * c->materials.size());
-  for (size_t i = 0; i < c->materials.size(); ++i) {
-    const HkMaterial& m = c->materials[i];
-    const uint32_t ids[4] = {m.base_color_texture, m.emissive_texture, m.metallic_roughness_texture, m.occlusion_texture};
-    for (uint32_t id : ids)  // MaterialTextures::id, material.rs:76-86: an index into the texture array or u32::MAX
-      HK_REQUIRE(id == HK_NO_TEXTURE || id < n_tex, HK_E_INVALID, "material %zu references texture %u but only %u textures are uploaded", i, id, n_tex);
-    mats[4 * i] = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
-    mats[4 * i + 1] = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], m.emissive[3]);
-    mats[4 * i + 2] = make_float4(m.perceptual_roughness, m.metallic, m.reflectance, 0.0f);
-    mats[4 * i + 3] = make_float4(as_f(ids[0]), as_f(ids[1]), as_f(ids[2]), as_f(ids[3]));
-  }
-  o.materials = blob.add(mats);
-  // material textures: a 16-B descriptor per texture + the sRGB decode table (texels live in their own buffer)
-  std::vector<uint4> tex_info(n_tex);
-  size_t texel_offset = 0;
-  for (uint32_t i = 0; i < n_tex; ++i) {
-    const hk_ctx::HostTexture& t = c->textures[i];
-    tex_info[i] = make_uint4((uint32_t)texel_offset, t.w, t.h, t.flags);
-    texel_offset += t.texels.size();
-  }
-  std::vector<float> srgb_lut(256);
-  for (int i = 0; i < 256; ++i) {  // sRGB EOTF in double, rounded once
-    double v = i / 255.0;
-    srgb_lut[i] = (float)(v <= 0.04045 ? v / 12.92 : pow((v + 0.055) / 1.055, 2.4));
-  }
-  o.tex_info = blob.add(tex_info);
-  o.srgb_lut = blob.add(srgb_lut);
-  blob.bytes.resize((blob.bytes.size() + 31) & ~(size_t)31, 0);
-  // the one-level BVH (traverse_flat): only for scenes that stay inside the LDS copy WITH it, whose instances share one
-  // transform, outside the bit-exact verification mode; as many direction orderings (8, 4, 2, 1) as fit
-  o.flat = 0;
-  o.flat_count = o.flat_orderings = 0;
-  if (!(c->flags & HK_CTX_EXACT_TRAVERSAL) && !c->threaded && !c->instances.empty() && c->instances.size() <= 0xFFFFu && !getenv("HK_FLAT_DISABLE")) {
-    bool shared = true;
-    for (const HkInstance& in : c->instances)
-      if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) shared = false;
-    // direction orderings: as many (8, 4, 2, 1) as keep the node array within 4 KB - every workgroup copies the blob into LDS and
-    // the LDS a workgroup holds bounds the workgroups per CU; measured on the Cornell box (71 nodes, tools/ab_flat.sh): 1 / 2 / 4 / 8
-    // orderings walk equally fast (0.27 ms k_indirect) and the direct-light kernels lose 13 % with the 18 KB of eight
-    uint32_t want = 8, budget = 4096;
-    if (const char* e = getenv("HK_FLAT_ORDERINGS")) { want = (uint32_t)std::max(1, std::min(8, atoi(e))); budget = HK_LDS_SCENE_BYTES; }
-    while (want & (want - 1)) want &= want - 1;  // a power of two
-    std::vector<float4> flat;
-    uint32_t count = 0;
-    if (shared && build_flat_bvh(c, 1u, flat, count)) {  // (a first build tells the node count: 2 T - 1)
-      const size_t per_ordering = flat.size() * 16;
-      uint32_t ord = want;
-      while (ord > 1 && (per_ordering * ord > budget || blob.bytes.size() + per_ordering * ord + static_bytes > HK_LDS_SCENE_BYTES)) ord >>= 1;
-      if (ord > 1 && !build_flat_bvh(c, ord, flat, count)) ord = 0;
-      if (ord >= 1 && blob.bytes.size() + flat.size() * 16 + static_bytes <= HK_LDS_SCENE_BYTES && count <= 0xFFFFu) {
-        o.flat = blob.add(flat);
-        o.flat_count = count;
-        o.flat_orderings = ord;
-        blob.bytes.resize((blob.bytes.size() + 31) & ~(size_t)31, 0);
-      }
-    }
-  }
-  return HK_OK;
-}
-
-int join_side(hk_ctx* c);
-int join_post(hk_ctx* c);
-int join_all(hk_ctx* c);
-// wait for everything the context has enqueued, on ALL streams (the direct-light dispatches of a frame may still be
-// running on the side stream when a host uploads, resizes or reads statistics between two stages)
-int sync_all(hk_ctx* c) {
-  const int rc = join_all(c);
-  if (rc) return rc;
-  HK_HIP(hipStreamSynchronize(c->stream));
-  return HK_OK;
-}
-
-// DScene::shared_xform: every instance has the same inverse model (bit for bit), so a traversal transforms its ray once instead of
-// once per instance entry (hk_device.hpp traverse_top).  Derived from the host mirrors: whoever changes an instance's pose - an
-// upload or a device refit - has to call this before the next frame is enqueued.
-void update_shared_transform(hk_ctx* c) {
-  c->scene.shared_xform = 1u;
-  for (const HkInstance& in : c->instances)
-    if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) c->scene.shared_xform = 0u;
-  // the one-level BVH lives in the shared LOCAL space: it stays valid while the instances move together and is simply not
-  // walked once one of them moves on its own
-  c->scene.flat_mode = (c->dyn_off.flat_count && c->scene.shared_xform) ? 1u : 0u;
-}
-
-// point c->scene at the arrays of the slot in use
-void point_scene_at_slot(hk_ctx* c) {
-  const size_t slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
-  const DynOffsets& o = c->dyn_off;
-  const uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  const uint8_t* sbase = c->scene_mem + slots;
-  DScene& s = c->scene;
-  s.blob = (const float4*)base;  // (two slots: the scene is too big for the LDS copy, blob is not read)
-  s.blob_f4 = (uint32_t)((slots + c->static_bytes) / 16);
-  s.nodes = (const float4*)base;
-  s.blas_base = (uint32_t)(((size_t)(sbase - base) + c->st_nodes) / 32);
-  s.instances = (const DInstance*)(base + o.instances);
-  c->d_prev_models = (const float4*)(base + o.prev_models);
-  s.tri_v0 = (const float4*)(sbase + c->st_v0); s.tri_v1 = (const float4*)(sbase + c->st_v1); s.tri_v2 = (const float4*)(sbase + c->st_v2);
-  s.vtx_normal = (const float4*)(sbase + c->st_vn); s.vtx_uv = (const float2*)(sbase + c->st_vuv);
-  s.materials = (const float4*)(base + o.materials);
-  s.tex_info = (const uint4*)(base + o.tex_info);
-  s.srgb_lut = (const float*)(base + o.srgb_lut);
-  s.tex_data = c->d_tex_data.p;
-  s.n_textures = (uint32_t)c->textures.size();
-  s.light_lo = (const float4*)(base + o.light_lo); s.light_hi = (const float4*)(base + o.light_hi);
-  s.emissives = (const DEmissive*)(base + o.emissives); s.alias = (const float2*)(base + o.alias);
-  s.noise = c->d_noise.p;
-  s.tlas_count = (uint32_t)c->instance_nodes.size();
-  s.tlas_stride = c->threaded ? (uint32_t)c->instance_nodes.size() : 0u;
-  s.blas_stride = c->threaded ? (uint32_t)c->asset_nodes.size() : 0u;
-  s.light_count = (uint32_t)c->emissive_nodes.size();
-  s.flat = (const float4*)(base + o.flat);
-  s.flat_count = o.flat_count;
-  s.flat_mask = o.flat_orderings ? o.flat_orderings - 1u : 0u;
-  update_shared_transform(c);
-}
-
-int finalize_scene(hk_ctx* c) {
-  if (!c->mesh_dirty && !c->dynamic_dirty && !c->textures_dirty) return HK_OK;
-  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
-  const size_t n_nodes = c->asset_nodes.size();
-  bool need_static = c->mesh_dirty || !c->scene_mem || c->node_prim_offset.size() != n_nodes;
-  {  // direction-threaded flattenings for everything that will not be traversed from the LDS copy (an estimate of the blob size decides;
-     // a scene near the limit that ends up outside LDS without them merely walks in the reference's order)
-    const size_t est = n_nodes * 32 + c->primitives.size() * 48 + c->vertices.size() * 24 + c->instance_nodes.size() * 32 + c->instances.size() * 208 +
-                       c->materials.size() * 64 + c->emissive_nodes.size() * 32 + c->alias_table.size() * 8;
-    const bool want = !(c->flags & HK_CTX_EXACT_TRAVERSAL) && est > HK_LDS_SCENE_BYTES;
-    if (want != c->threaded) {
-      c->threaded = want;
-      need_static = true;
-    }
-  }
-  for (const HkInstance& in : c->instances) {
-    HK_REQUIRE((size_t)in.mesh.node_offset + in.mesh.node_count <= n_nodes, HK_E_INVALID, "instance mesh node range out of bounds");
-    HK_REQUIRE(in.material < c->materials.size(), HK_E_INVALID, "instance material out of bounds");
-    // a mesh range no earlier instance used: its leaf boxes have not been derived yet
-    if (!need_static && in.mesh.node_count && (c->node_prim_offset[in.mesh.node_offset] != (int64_t)in.mesh.primitive ||
-                                                c->node_prim_offset[in.mesh.node_offset + in.mesh.node_count - 1] != (int64_t)in.mesh.primitive))
-      need_static = true;
-  }
-  int rc;
-  if (c->textures_dirty) {
-    std::vector<uint32_t> tex_data;
-    for (const hk_ctx::HostTexture& t : c->textures) tex_data.insert(tex_data.end(), t.texels.begin(), t.texels.end());
-    if ((rc = sync_all(c))) return rc;
-    if ((rc = c->d_tex_data.upload(tex_data))) return rc;
-    c->textures_dirty = false;
-  }
-  HK_REQUIRE(!(c->mirrors_stale && c->dynamic_dirty), HK_E_NOT_READY,
-             "the instance-level arrays were last changed on the device (hk_refit_scene_instances): upload the instances again (hk_upload_scene_instances) "
-             "before a change that rebuilds them on the host");
-  Blob st;  // (the mesh-level region first: whether the one-level BVH still fits the LDS copy depends on its size)
-  if (need_static && (rc = build_static_region(c, st, c->st_nodes, c->st_v0, c->st_v1, c->st_v2, c->st_vn, c->st_vuv))) return rc;
-  Blob& dyn = c->dyn_blob;
-  dyn.bytes.clear();
-  DynOffsets o{};
-  const double tb0_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  if ((rc = build_dynamic_region(c, dyn, o, need_static ? st.bytes.size() : c->static_bytes))) return rc;
-  if (getenv("HK_TRACE_UPDATE")) fprintf(stderr, "  build_dynamic_region %.2f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tb0_, dyn.bytes.size());
-  c->dyn_off = o;
-  c->rf_ready = false;
-  c->rf_last_moved.clear();
-  const bool in_place = !need_static && dyn.bytes.size() <= c->dyn_capacity;
-  if (!(in_place && c->two_slots) && (rc = sync_all(c))) return rc;  // frames in flight still read the arrays rewritten below
-  if (need_static) {
-    if (c->scene_mem) { (void)hipFree(c->scene_mem); c->scene_mem = nullptr; }
-    c->dyn_capacity = dyn.bytes.size();  // exact: a small scene stays small enough for the LDS copy
-    c->static_bytes = st.bytes.size();
-    c->two_slots = c->dyn_capacity + c->static_bytes > HK_LDS_SCENE_BYTES;
-    c->slot = 0;
-    // room for the previous model matrix of every instance, so that the first moving frame already fits its slot
-    if (c->two_slots) c->dyn_capacity = (c->dyn_capacity + 64 * c->instances.size() + 31) & ~(size_t)31;
-    const size_t slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
-    HK_HIP(hipMalloc((void**)&c->scene_mem, slots + c->static_bytes));
-    HK_HIP(hipMemcpy(c->scene_mem + slots, st.bytes.data(), st.bytes.size(), hipMemcpyHostToDevice));
-  } else if (!in_place) {  // instance count grew: move the mesh region behind larger slots, device to device
-    const size_t cap = ((dyn.bytes.size() + dyn.bytes.size() / 2) + 31) & ~(size_t)31;
-    const size_t old_slots = (c->two_slots ? 2 : 1) * c->dyn_capacity;
-    c->two_slots = c->two_slots || cap + c->static_bytes > HK_LDS_SCENE_BYTES;
-    c->slot = 0;
-    const size_t slots = (c->two_slots ? 2 : 1) * cap;
-    uint8_t* mem = nullptr;
-    HK_HIP(hipMalloc((void**)&mem, slots + c->static_bytes));
-    HK_HIP(hipMemcpy(mem + slots, c->scene_mem + old_slots, c->static_bytes, hipMemcpyDeviceToDevice));
-    (void)hipFree(c->scene_mem);
-    c->scene_mem = mem;
-    c->dyn_capacity = cap;
-  } else if (c->two_slots) {
-    c->slot ^= 1;
-  }
-  uint8_t* const slot_mem = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  if (in_place && c->two_slots) {
-    const int k = c->slot;
-    if (c->staging_pending[k]) {  // the copy that last read this staging buffer (two updates ago)
-      HK_HIP(hipEventSynchronize(c->staging_done[k]));
-      c->staging_pending[k] = false;
-    }
-    if (c->staging_bytes[k] < c->dyn_capacity) {
-      if (c->staging[k]) (void)hipHostFree(c->staging[k]);
-      c->staging[k] = nullptr;
-      c->staging_bytes[k] = 0;
-      HK_HIP(hipHostMalloc((void**)&c->staging[k], c->dyn_capacity, hipHostMallocDefault));
-      c->staging_bytes[k] = c->dyn_capacity;
-    }
-    if (!c->staging_done[k]) HK_HIP(hipEventCreateWithFlags(&c->staging_done[k], hipEventDisableTiming));
-    memcpy(c->staging[k], dyn.bytes.data(), dyn.bytes.size());
-    memset(c->staging[k] + dyn.bytes.size(), 0, c->dyn_capacity - dyn.bytes.size());
-    // a copy KERNEL reading the pinned buffer over PCIe: the update stays on the compute queue of the stream, between
-    // the kernels of two frames, instead of a hand-off to an SDMA engine and back
-    hipLaunchKernelGGL(k_copy_u4, dim3((unsigned)((c->dyn_capacity / 16 + 255) / 256)), dim3(256), 0, c->stream, (uint4*)slot_mem,
-                       (const uint4*)c->staging[k], c->dyn_capacity / 16);
-    HK_HIP(hipGetLastError());
-    HK_HIP(hipEventRecord(c->staging_done[k], c->stream));
-    c->staging_pending[k] = true;
-    c->async_instance_uploads += 1;
-  } else {
-    HK_HIP(hipMemcpy(slot_mem, dyn.bytes.data(), dyn.bytes.size(), hipMemcpyHostToDevice));
-    if (dyn.bytes.size() < c->dyn_capacity) HK_HIP(hipMemset(slot_mem + dyn.bytes.size(), 0, c->dyn_capacity - dyn.bytes.size()));
-  }
-
-  point_scene_at_slot(c);
-  c->mesh_dirty = c->dynamic_dirty = false;
-  c->static_rebuilds += need_static ? 1 : 0;
-  c->dynamic_rebuilds += 1;
-  return HK_OK;
-}
 
 DFrame make_dframe(const hk_ctx* c) {
   DFrame f;
@@ -1400,7 +559,7 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
   return HK_OK;
 }
 
-}  // namespace
+}  // namespace hk
 
 namespace hk {
 int ctx_info(hk_ctx* c, CtxInfo* o) {
@@ -1484,7 +643,6 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   return HK_OK;
 }
 
-namespace { void free_refit(hk_ctx* c); }
 void hk_destroy(hk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
@@ -1514,264 +672,6 @@ void hk_destroy(hk_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
-
-int hk_upload_meshes(hk_ctx* c, const HkVertex* v, uint32_t nv, const HkPrimitive* p, uint32_t np, const HkNode* n, uint32_t nn) {
-  HK_REQUIRE(c && v && p && n && nv && np && nn, HK_E_INVALID, "NULL or empty mesh buffers");
-  c->vertices.assign(v, v + nv);
-  c->primitives.assign(p, p + np);
-  c->asset_nodes.assign(n, n + nn);
-  c->have_meshes = true;
-  c->mesh_dirty = true;
-  return HK_OK;
-}
-int hk_upload_materials(hk_ctx* c, const HkMaterial* m, uint32_t n) {
-  HK_REQUIRE(c && m && n, HK_E_INVALID, "NULL or empty material buffer");
-  c->materials.assign(m, m + n);
-  c->have_materials = true;
-  c->dynamic_dirty = true;
-  return HK_OK;
-}
-int hk_upload_instances(hk_ctx* c, const HkInstance* inst, uint32_t ni, const HkNode* inodes, uint32_t nin, const HkEmissive* em, uint32_t ne,
-                        const HkNode* enodes, uint32_t nen, const HkAliasEntry* alias, uint32_t na) {
-  HK_REQUIRE(c && inst && inodes && ni && nin, HK_E_INVALID, "NULL or empty instance buffers");
-  HK_REQUIRE((em || !ne) && (enodes || !nen) && (alias || !na), HK_E_INVALID, "NULL emissive buffers");
-  c->instances.assign(inst, inst + ni);
-  c->instance_nodes.assign(inodes, inodes + nin);
-  c->emissives.assign(em, em + ne);
-  c->emissive_nodes.assign(enodes, enodes + nen);
-  c->alias_table.assign(alias, alias + na);
-  c->prev_models.clear();
-  c->have_instances = true;
-  c->dynamic_dirty = true;
-  c->mirrors_stale = false;
-  return HK_OK;
-}
-int hk_upload_previous_transforms(hk_ctx* c, const float* models, uint32_t n) {
-  HK_REQUIRE(c && (models || !n), HK_E_INVALID, "NULL argument");
-  HK_REQUIRE(c->have_instances && n == c->instances.size(), HK_E_INVALID, "previous transforms must match the %zu uploaded instances", c->instances.size());
-  c->prev_models.assign(models, models + 16 * (size_t)n);
-  c->dynamic_dirty = true;
-  return HK_OK;
-}
-#define HK_NO_STANDINS(b)                                                                                                        \
-  HK_REQUIRE(!builder_has_standin_trees(b), HK_E_NOT_READY,                                                                      \
-             "the builder holds stand-in trees (hk_scene_builder_finish_instances): finish it with hk_scene_builder_finish, or use " \
-             "hk_update_scene_instances, which builds the trees on the device")
-int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
-  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
-  HK_NO_STANDINS(b);  // (frames from stand-in trees would differ silently in tie-breaks and visit order)
-  const HkVertex* v; const HkPrimitive* p; const HkNode *an, *in_, *en; const HkMaterial* m; const HkInstance* inst; const HkEmissive* em; const HkAliasEntry* al;
-  uint32_t nv, np, nan_, nm, ni, nin, ne, nen, nal;
-  int rc;
-  if ((rc = hk_scene_builder_vertices(b, &v, &nv))) return rc;
-  if ((rc = hk_scene_builder_primitives(b, &p, &np))) return rc;
-  if ((rc = hk_scene_builder_asset_nodes(b, &an, &nan_))) return rc;
-  if ((rc = hk_scene_builder_materials(b, &m, &nm))) return rc;
-  if ((rc = hk_scene_builder_instances(b, &inst, &ni))) return rc;
-  if ((rc = hk_scene_builder_instance_nodes(b, &in_, &nin))) return rc;
-  if ((rc = hk_scene_builder_emissives(b, &em, &ne))) return rc;
-  if ((rc = hk_scene_builder_emissive_nodes(b, &en, &nen))) return rc;
-  if ((rc = hk_scene_builder_alias_table(b, &al, &nal))) return rc;
-  if ((rc = hk_upload_meshes(c, v, nv, p, np, an, nan_))) return rc;
-  if ((rc = hk_upload_materials(c, m, nm))) return rc;
-  if ((rc = hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal))) return rc;
-  const float* pm; uint32_t npm;
-  if ((rc = hk_scene_builder_previous_transforms(b, &pm, &npm))) return rc;
-  return hk_upload_previous_transforms(c, pm, npm);
-}
-int hk_upload_scene_instances(hk_ctx* c, const hk_scene_builder* b) {
-  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
-  HK_NO_STANDINS(b);
-  return hk::upload_scene_instances_unchecked(c, b);
-}
-}  // extern "C"
-int hk::upload_scene_instances_unchecked(hk_ctx* c, const hk_scene_builder* b) {
-  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
-  HK_REQUIRE(c->have_meshes && c->have_materials, HK_E_NOT_READY, "hk_upload_scene must come first");
-  const HkNode *in_, *en; const HkInstance* inst; const HkEmissive* em; const HkAliasEntry* al; const float* pm;
-  uint32_t ni, nin, ne, nen, nal, npm;
-  int rc;
-  if ((rc = hk_scene_builder_instances(b, &inst, &ni))) return rc;
-  if ((rc = hk_scene_builder_instance_nodes(b, &in_, &nin))) return rc;
-  if ((rc = hk_scene_builder_emissives(b, &em, &ne))) return rc;
-  if ((rc = hk_scene_builder_emissive_nodes(b, &en, &nen))) return rc;
-  if ((rc = hk_scene_builder_alias_table(b, &al, &nal))) return rc;
-  if ((rc = hk_scene_builder_previous_transforms(b, &pm, &npm))) return rc;
-  if ((rc = hk_upload_instances(c, inst, ni, in_, nin, em, ne, en, nen, al, nal))) return rc;
-  return hk_upload_previous_transforms(c, pm, npm);
-}
-extern "C" {
-
-// Instances added, removed or re-materialed (the reference re-runs prepare_instances for ANY instance change, instance.rs:352-437):
-// the per-instance / per-emitter records are laid out on the host - O(instances), no tree build - and go to the spare slot through
-// the asynchronous upload; both trees are then built on the device (hk_rebuild_scene_trees: HK_TREE_SAH = the reference's own
-// tree, link for link).  What the host no longer does is the two `BVH::build` calls: 1.1 ms of 1.7 ms at 2 000 instances, 30 of
-// 32 ms at 20 000.
-int hk_update_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t tree_mode) {
-  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
-  HK_REQUIRE(tree_mode == HK_TREE_SAH || tree_mode == HK_TREE_LBVH, HK_E_INVALID, "unknown tree build mode %u", tree_mode);
-  int rc;
-  const bool trace = getenv("HK_TRACE_UPDATE") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t0 = now();
-  if ((rc = hk_scene_builder_finish_instances(b))) return rc;
-  const double t1 = now();
-  if ((rc = upload_scene_instances_unchecked(c, b))) return rc;
-  const double t2 = now();
-  uint32_t ni = 0;
-  const HkInstance* inst = nullptr;
-  if ((rc = hk_scene_builder_instances(b, &inst, &ni))) return rc;
-  c->trees_pending_on_device = ni >= 2;
-  rc = finalize_scene(c);
-  c->trees_pending_on_device = false;
-  const double t3 = now();
-  if (!rc && ni >= 2) rc = hk_rebuild_scene_trees(c, tree_mode);  // (a tree of one leaf is what the host just laid out)
-  // the region just uploaded carries stand-in trees with orderings 1..7 left zero (the device build was to overwrite
-  // them in stream order).  If that build did not get enqueued, a threaded walk over zero nodes would never leave node 0: the
-  // next use of the scene lays the region out again, from the host's (valid) stand-in trees, all orderings threaded.
-  if (rc) c->dynamic_dirty = true;
-  if (trace) fprintf(stderr, "hk_update_scene_instances: finish_instances %.2f ms, mirrors %.2f ms, layout + upload %.2f ms, device build enqueue %.2f ms\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
-  return rc;
-}
-
-// ---- instance motion on the device (kernels_scene.hip) --------------------------------------------------
-namespace {
-void free_refit(hk_ctx* c) {
-  for (void* q : {(void*)c->rf_inst_lo, (void*)c->rf_inst_hi, (void*)c->rf_prev_models, (void*)c->rf_emissive_of_instance, (void*)c->rf_alias_scratch})
-    if (q) (void)hipFree(q);
-  c->rf_inst_lo = c->rf_inst_hi = c->rf_prev_models = nullptr;
-  c->rf_emissive_of_instance = nullptr;
-  c->rf_alias_scratch = nullptr;
-  c->rf_instances = c->rf_alias = 0;
-  c->rf_ready = false;
-  if (c->lbvh_scratch) (void)hipFree(c->lbvh_scratch);
-  c->lbvh_scratch = nullptr;
-  c->lbvh_scratch_cap = 0;
-  for (int k = 0; k < 2; ++k) {
-    if (c->rf_updates[k]) (void)hipHostFree(c->rf_updates[k]);
-    if (c->rf_done[k]) (void)hipEventDestroy(c->rf_done[k]);
-    c->rf_updates[k] = nullptr;
-    c->rf_done[k] = nullptr;
-    c->rf_updates_cap[k] = 0;
-    c->rf_pending[k] = false;
-  }
-}
-hkd::RefitScene refit_scene(hk_ctx* c) {
-  uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  hkd::RefitScene r;
-  r.instances = (DInstance*)(base + c->dyn_off.instances);
-  r.prev_models = c->rf_prev_models;
-  r.inst_lo = c->rf_inst_lo;
-  r.inst_hi = c->rf_inst_hi;
-  r.emissive_of_instance = c->rf_emissive_of_instance;
-  r.emissives = (DEmissive*)(base + c->dyn_off.emissives);
-  r.alias = (float2*)(base + c->dyn_off.alias);
-  r.alias_scratch = c->rf_alias_scratch;
-  r.materials = (const float4*)(base + c->dyn_off.materials);
-  r.tri_v0 = c->scene.tri_v0;
-  r.tri_v1 = c->scene.tri_v1;
-  r.tri_v2 = c->scene.tri_v2;
-  return r;
-}
-// side arrays of the refit, (re)filled from the scene as the host last laid it out: world AABB per instance from the TLAS
-// leaves, emitter of an instance, previous models
-int prepare_refit(hk_ctx* c) {
-  if (c->rf_ready) return HK_OK;
-  const size_t ni = c->instances.size(), na = c->alias_table.size();
-  if (ni > c->rf_instances || na > c->rf_alias) {
-    int rc = sync_all(c);
-    if (rc) return rc;
-    for (void* q : {(void*)c->rf_inst_lo, (void*)c->rf_inst_hi, (void*)c->rf_prev_models, (void*)c->rf_emissive_of_instance, (void*)c->rf_alias_scratch})
-      if (q) (void)hipFree(q);
-    c->rf_inst_lo = c->rf_inst_hi = c->rf_prev_models = nullptr;
-    c->rf_emissive_of_instance = nullptr;
-    c->rf_alias_scratch = nullptr;
-    c->rf_instances = c->rf_alias = 0;  // (stays 0 if an allocation below fails: the next call starts over)
-    const size_t cap_i = ni + ni / 4, cap_a = na + na / 4 + 4;
-    HK_HIP(hipMalloc((void**)&c->rf_inst_lo, cap_i * 16));
-    HK_HIP(hipMalloc((void**)&c->rf_inst_hi, cap_i * 16));
-    HK_HIP(hipMalloc((void**)&c->rf_prev_models, cap_i * 64));
-    HK_HIP(hipMalloc((void**)&c->rf_emissive_of_instance, cap_i * 4));
-    HK_HIP(hipMalloc((void**)&c->rf_alias_scratch, cap_a * 5 * 4));
-    c->rf_instances = cap_i;
-    c->rf_alias = cap_a;
-  }
-  std::vector<uint32_t> eoi(ni, 0xFFFFFFFFu);
-  for (size_t e = 0; e < c->emissives.size(); ++e) eoi[c->emissives[e].instance] = (uint32_t)e;
-  HK_HIP(hipMemcpyAsync(c->rf_emissive_of_instance, eoi.data(), ni * 4, hipMemcpyHostToDevice, c->stream));
-  HK_HIP(hipStreamSynchronize(c->stream));  // (eoi is a local; once per host-side rebuild)
-  const hkd::RefitScene r = refit_scene(c);
-  const uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  launch_gather_instance_boxes(c->stream, r, (const float4*)(base + c->dyn_off.tlas), (uint32_t)c->instance_nodes.size());
-  // previous models of the instances the host marked as moved (the plane exists only then)
-  if (c->prev_models.size() == 16 * ni && c->dyn_off.prev_models + ni * 64 <= c->dyn_capacity && c->d_prev_models && c->d_prev_models != c->rf_prev_models) {
-    bool any = false;
-    for (size_t i = 0; i < ni && !any; ++i) any = memcmp(&c->prev_models[16 * i], c->instances[i].model, 64) != 0;
-    if (any) launch_copy_region(c->stream, c->rf_prev_models, base + c->dyn_off.prev_models, ni * 64);
-  }
-  HK_HIP(hipGetLastError());
-  c->rf_last_moved.clear();
-  for (size_t i = 0; i < ni; ++i)
-    if (c->prev_models.size() == 16 * ni && memcmp(&c->prev_models[16 * i], c->instances[i].model, 64) != 0) c->rf_last_moved.push_back((uint32_t)i);
-  c->rf_ready = true;
-  return HK_OK;
-}
-}  // namespace
-
-namespace {
-// frames in flight keep reading the slot they were enqueued with: a device-side update works on a copy in the spare slot
-// (two-slot scenes), or in place behind everything enqueued so far (scenes small enough for the LDS copy have one slot)
-int begin_device_update(hk_ctx* c) {
-  const int rc = join_side(c);
-  if (rc) return rc;
-  if (c->two_slots) {
-    uint8_t* from = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-    c->slot ^= 1;
-    uint8_t* to = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-    launch_copy_region(c->stream, to, from, c->dyn_capacity);
-    const float4* prev = c->d_prev_models;
-    point_scene_at_slot(c);
-    if (prev == c->rf_prev_models) c->d_prev_models = prev;  // (the refit's own plane is not part of the slot)
-  }
-  return HK_OK;
-}
-}  // namespace
-
-int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
-  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
-  HK_REQUIRE(mode == HK_TREE_SAH || mode == HK_TREE_LBVH, HK_E_INVALID, "unknown tree build mode %u", mode);
-  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
-  HK_HIP(hipSetDevice(c->device));
-  int rc;
-  if ((rc = finalize_scene(c))) return rc;
-  const uint32_t ni = (uint32_t)c->instances.size(), ne = (uint32_t)c->emissives.size();
-  HK_REQUIRE(c->instance_nodes.size() == 3 * (size_t)ni - 2 && (ne == 0 || c->emissive_nodes.size() == 3 * (size_t)ne - 2), HK_E_UNSUPPORTED,
-             "the uploaded trees are not in the flatten_custom layout of a binary tree (3n - 2 nodes): nothing to rebuild in place");
-  if ((rc = prepare_refit(c))) return rc;
-  const size_t need = std::max(lbvh_scratch_bytes(ni, nullptr), lbvh_scratch_bytes(std::max(ne, 1u), nullptr));
-  if (need > c->lbvh_scratch_cap) {
-    if ((rc = sync_all(c))) return rc;
-    if (c->lbvh_scratch) (void)hipFree(c->lbvh_scratch);
-    c->lbvh_scratch = nullptr;
-    c->lbvh_scratch_cap = 0;
-    HK_HIP(hipMalloc(&c->lbvh_scratch, need + need / 4));
-    c->lbvh_scratch_cap = need + need / 4;
-  }
-  if ((rc = begin_device_update(c))) return rc;
-  const hkd::RefitScene r = refit_scene(c);
-  uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  float4* tlas = (float4*)(base + c->dyn_off.tlas);
-  const int build = mode == HK_TREE_SAH ? 1 : 0;
-  HK_REQUIRE(launch_tree_build(c->stream, build, false, r, ni, c->rf_inst_lo, c->rf_inst_hi, c->lbvh_scratch, tlas, tlas + 1, 2u, c->threaded ? 8u : 1u) == 0, HK_E_HIP,
-             "device build of the instance tree failed: %s", hipGetErrorString(hipGetLastError()));
-  if (ne)
-    HK_REQUIRE(launch_tree_build(c->stream, build, true, r, ne, nullptr, nullptr, c->lbvh_scratch, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi),
-                                 1u, 1u) == 0, HK_E_HIP, "device build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
-  c->mirrors_stale = true;
-  c->device_tree_builds += 1;
-  return HK_OK;
-}
-
 // tools/wf_timeline.py: the 64 x 32 u64 the instrumented trace kernel left for the frame most recently rendered (HK_WF_TIMELINE=1)
 int hk_debug_read_wf_timeline(hk_ctx* c, unsigned long long* out, uint32_t n) {
   HK_REQUIRE(c && out && n == 64u * 32u, HK_E_INVALID, "bad argument");
@@ -1782,184 +682,6 @@ int hk_debug_read_wf_timeline(hk_ctx* c, unsigned long long* out, uint32_t n) {
   int khz = 0;
   HK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
   out[n - 1] = (unsigned long long)khz;  // (slot 31 of stage 63 - never a real stage: the rate of wall_clock64, kHz)
-  return HK_OK;
-}
-
-// Test hook: the instance tree (ordering 0) and the light tree as the device holds them, converted back to the reference layout
-// (navigators that took over their single leaf's role - fold_leaf_navigators - point at the leaf again)
-int hk_debug_read_trees(hk_ctx* c, HkNode* tlas, uint32_t tlas_cap, HkNode* light, uint32_t light_cap) {
-  HK_REQUIRE(c && (tlas || !tlas_cap) && (light || !light_cap), HK_E_INVALID, "NULL argument");
-  HK_HIP(hipSetDevice(c->device));
-  int rc;
-  if ((rc = finalize_scene(c))) return rc;
-  if ((rc = sync_all(c))) return rc;
-  const uint32_t nt = (uint32_t)c->instance_nodes.size(), nl = (uint32_t)c->emissive_nodes.size();
-  HK_REQUIRE(tlas_cap >= nt && light_cap >= nl, HK_E_INVALID, "need room for %u + %u nodes", nt, nl);
-  const uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  auto convert = [](const std::vector<float4>& lo, const std::vector<float4>& hi, HkNode* out) {
-    const uint32_t n = (uint32_t)lo.size();
-    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
-    for (uint32_t k = 0; k < n; ++k) {
-      out[k].min[0] = lo[k].x; out[k].min[1] = lo[k].y; out[k].min[2] = lo[k].z;
-      out[k].max[0] = hi[k].x; out[k].max[1] = hi[k].y; out[k].max[2] = hi[k].z;
-      out[k].entry_index = bits(lo[k].w);
-      out[k].exit_index = bits(hi[k].w);
-    }
-    for (uint32_t k = 0; k + 1 < n; ++k)
-      if (out[k].entry_index >= HK_BVH_LEAF_FLAG && out[k + 1].entry_index == out[k].entry_index && out[k + 1].exit_index == out[k].exit_index) out[k].entry_index = k + 1;
-  };
-  if (nt) {
-    std::vector<float4> both(2 * (size_t)nt), lo(nt), hi(nt);
-    HK_HIP(hipMemcpy(both.data(), base + c->dyn_off.tlas, both.size() * 16, hipMemcpyDeviceToHost));
-    for (uint32_t k = 0; k < nt; ++k) { lo[k] = both[2 * k]; hi[k] = both[2 * k + 1]; }
-    convert(lo, hi, tlas);
-  }
-  if (nl) {
-    std::vector<float4> lo(nl), hi(nl);
-    HK_HIP(hipMemcpy(lo.data(), base + c->dyn_off.light_lo, (size_t)nl * 16, hipMemcpyDeviceToHost));
-    HK_HIP(hipMemcpy(hi.data(), base + c->dyn_off.light_hi, (size_t)nl * 16, hipMemcpyDeviceToHost));
-    convert(lo, hi, light);
-  }
-  return HK_OK;
-}
-
-// `commit`: advance the builder's previous-transform bookkeeping (once per update, whichever context sees it last)
-static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool commit) {
-  HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
-  HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
-  HK_HIP(hipSetDevice(c->device));
-  int rc;
-  if ((rc = finalize_scene(c))) return rc;
-  const uint32_t ni = (uint32_t)c->instances.size();
-  HK_REQUIRE(builder_instance_count(b) == ni, HK_E_INVALID, "the builder has %u instances, the uploaded scene %u: instances were added or removed (use hk_upload_scene_instances)",
-             builder_instance_count(b), ni);
-  // which instances moved since the pose the device holds; their new host-side records (the reference's per-instance work,
-  // instance.rs:286-325, kept in step so that a later host-side rebuild starts from the right poses)
-  std::vector<uint32_t> moved;
-  std::vector<hkd::RefitUpdate> records;
-  for (uint32_t i = 0; i < ni; ++i) {
-    InstanceDecl d;
-    HK_REQUIRE(builder_instance_decl(b, i, &d), HK_E_NOT_READY, "the builder has unfinished mesh changes (hk_scene_builder_finish + hk_upload_scene first)");
-    HkInstance& in = c->instances[i];
-    HK_REQUIRE(d.material == in.material && memcmp(&d.mesh, &in.mesh, sizeof(HkMeshIndex)) == 0, HK_E_INVALID,
-               "instance %u changed its mesh or material (use hk_upload_scene_instances)", i);
-    if (memcmp(d.transform, in.model, 64) == 0) continue;
-    float mn[3], mx[3], itm[16];
-    HK_REQUIRE(instance_world_record(d.transform, d.aabb_center, d.aabb_half, mn, mx, itm), HK_E_INVALID, "singular transform of instance %u", i);
-    hkd::RefitUpdate u;
-    u.instance = i;
-    u.moved = 1u;
-    memcpy(u.model, d.transform, 64);
-    memcpy(u.aabb_center, d.aabb_center, 12);
-    memcpy(u.aabb_half, d.aabb_half, 12);
-    records.push_back(u);
-    moved.push_back(i);
-  }
-  if (moved_out) *moved_out = (uint32_t)moved.size();
-  if ((rc = prepare_refit(c))) return rc;
-  {  // instances that moved in the previous update and rest now: their `moved` flag goes (previous model = model)
-    std::vector<uint8_t> now(ni, 0);
-    for (uint32_t i : moved) now[i] = 1;
-    for (uint32_t i : c->rf_last_moved)
-      if (!now[i]) {
-        hkd::RefitUpdate u{};
-        u.instance = i;
-        u.moved = 0u;
-        records.push_back(u);
-      }
-  }
-  if (records.empty()) {
-    if (commit) builder_commit_transforms(b);
-    return HK_OK;
-  }
-  // the records of moved emitters first (k_refit_emitters runs one wave per such record and on no other)
-  uint32_t n_emitter_updates = 0, emitter_triangles = 0;
-  {
-    std::vector<uint8_t> is_emitter(ni, 0);
-    for (const HkEmissive& e : c->emissives)
-      if (e.instance < ni) is_emitter[e.instance] = 1;
-    auto mid = std::stable_partition(records.begin(), records.end(), [&](const hkd::RefitUpdate& u) { return u.moved && is_emitter[u.instance]; });
-    n_emitter_updates = (uint32_t)(mid - records.begin());
-    for (uint32_t k = 0; k < n_emitter_updates; ++k)
-      emitter_triangles = std::max(emitter_triangles, (c->instances[records[k].instance].mesh.node_count + 2u) / 3u);  // a BLAS over n triangles: 3n - 2 nodes
-  }
-  // pinned update records, double-buffered against the kernel that reads them
-  const int k = c->rf_k;
-  c->rf_k ^= 1;
-  if (c->rf_pending[k]) {
-    HK_HIP(hipEventSynchronize(c->rf_done[k]));
-    c->rf_pending[k] = false;
-  }
-  if (c->rf_updates_cap[k] < records.size()) {
-    if (c->rf_updates[k]) (void)hipHostFree(c->rf_updates[k]);
-    c->rf_updates[k] = nullptr;
-    c->rf_updates_cap[k] = 0;
-    const size_t cap = records.size() + records.size() / 2 + 16;
-    HK_HIP(hipHostMalloc((void**)&c->rf_updates[k], cap * sizeof(hkd::RefitUpdate), hipHostMallocDefault));
-    c->rf_updates_cap[k] = cap;
-  }
-  if (!c->rf_done[k]) HK_HIP(hipEventCreateWithFlags(&c->rf_done[k], hipEventDisableTiming));
-  memcpy(c->rf_updates[k], records.data(), records.size() * sizeof(hkd::RefitUpdate));
-  // frames in flight keep reading the slot they were enqueued with: refit a copy in the spare slot (two-slot scenes), or in
-  // place behind everything enqueued so far (scenes small enough for the LDS copy have one slot)
-  if ((rc = begin_device_update(c))) return rc;
-  const hkd::RefitScene r = refit_scene(c);
-  uint8_t* base = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
-  launch_refit(c->stream, r, c->rf_updates[k], (uint32_t)records.size(), n_emitter_updates, emitter_triangles, nullptr, (float4*)(base + c->dyn_off.tlas), (uint32_t)c->instance_nodes.size(),
-               c->threaded ? 8u : 1u, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi), (uint32_t)c->emissive_nodes.size());
-  HK_HIP(hipGetLastError());
-  HK_HIP(hipEventRecord(c->rf_done[k], c->stream));
-  c->rf_pending[k] = true;
-  // the update is enqueued: now the host mirrors of the moved instances follow (an error above leaves host and device agreeing)
-  for (const hkd::RefitUpdate& u : records) {
-    if (!u.moved) continue;
-    HkInstance& in = c->instances[u.instance];
-    if (c->prev_models.size() != 16 * (size_t)ni) {
-      c->prev_models.resize(16 * (size_t)ni);
-      for (uint32_t j = 0; j < ni; ++j) memcpy(&c->prev_models[16 * (size_t)j], c->instances[j].model, 64);
-    }
-    memcpy(&c->prev_models[16 * (size_t)u.instance], in.model, 64);
-    memcpy(in.model, u.model, 64);
-    (void)instance_world_record(u.model, u.aabb_center, u.aabb_half, in.min, in.max, in.inverse_transpose_model);
-  }
-  for (const hkd::RefitUpdate& u : records)
-    if (!u.moved && c->prev_models.size() == 16 * (size_t)ni) memcpy(&c->prev_models[16 * (size_t)u.instance], c->instances[u.instance].model, 64);
-  update_shared_transform(c);  // (a scene in one slot is refit in place: nothing else looks at the new poses before the next frame)
-  c->d_prev_models = c->rf_prev_models;
-  c->rf_last_moved = moved;
-  c->mirrors_stale = true;
-  c->device_refits += 1;
-  if (commit) builder_commit_transforms(b);
-  return HK_OK;
-}
-int hk_refit_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out) { return refit_impl(c, b, moved_out, true); }
-int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
-  HK_REQUIRE(c && (images || !n), HK_E_INVALID, "NULL argument");
-  std::vector<hk_ctx::HostTexture> tex(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    const HkImageDesc& d = images[i];
-    HK_REQUIRE(d.rgba8 && d.width && d.height && d.width <= 16384 && d.height <= 16384, HK_E_INVALID, "image %u: bad pointer or size", i);
-    HK_REQUIRE(d.address_u <= HK_ADDRESS_MIRROR_REPEAT && d.address_v <= HK_ADDRESS_MIRROR_REPEAT, HK_E_INVALID, "image %u: bad address mode", i);
-    tex[i].w = d.width;
-    tex[i].h = d.height;
-    tex[i].flags = (d.is_srgb ? 1u : 0u) | (d.filter_linear ? 2u : 0u) | (d.address_u << 4) | (d.address_v << 6);
-    tex[i].texels.resize((size_t)d.width * d.height);
-    memcpy(tex[i].texels.data(), d.rgba8, tex[i].texels.size() * 4);
-  }
-  c->textures.swap(tex);
-  c->textures_dirty = true;
-  c->dynamic_dirty = true;
-  return HK_OK;
-}
-int hk_upload_noise(hk_ctx* c, const uint8_t* rgba, size_t bytes) {
-  HK_REQUIRE(c && rgba && bytes == 16u * 64u * 64u * 4u, HK_E_INVALID, "noise must be 16 tiles of 64x64 RGBA8 (262144 bytes)");
-  HK_HIP(hipSetDevice(c->device));
-  std::vector<uint32_t> words(16u * 64u * 64u);
-  memcpy(words.data(), rgba, bytes);
-  int rc = c->d_noise.upload(words);
-  if (rc) return rc;
-  c->scene.noise = c->d_noise.p;
-  c->have_noise = true;
   return HK_OK;
 }
 
@@ -2548,29 +1270,4 @@ int hk_reset_stats(hk_ctx* c) {
   }
   return HK_OK;
 }
-
-int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float* out, size_t n) {
-  HK_REQUIRE(c && x && out && op <= 20, HK_E_INVALID, "bad argument");
-  const size_t xin = (op >= 16 && op <= 19 ? 16 : 1) * n;
-  if (n == 0) return HK_OK;
-  HK_HIP(hipSetDevice(c->device));
-  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-  HK_HIP(hipMalloc((void**)&dx, xin * 4));
-  HK_HIP(hipMalloc((void**)&dout, n * 4));
-  HK_HIP(hipMemcpy(dx, x, xin * 4, hipMemcpyHostToDevice));
-  if (y) {
-    HK_HIP(hipMalloc((void**)&dy, n * 4));
-    HK_HIP(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
-  }
-  launch_debug_math(c->stream, op, dx, dy, dout, n);
-  HK_HIP(hipStreamSynchronize(c->stream));
-  HK_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(dx);
-  (void)hipFree(dout);
-  if (dy) (void)hipFree(dy);
-  return HK_OK;
-}
-
 }  // extern "C"
-
-int hk::refit_instances_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved, bool commit) { return refit_impl(c, b, moved, commit); }

@@ -1,0 +1,259 @@
+// hk_context.hpp - the context behind the C ABI (private to libhikari_hip.so): `struct hk_ctx` and what the translation units that
+// work on it share.
+//   context.hip       lifetime, screen-space resources, the frame graph (hk_frame_*, hk_pass_run), bands, buffers, statistics
+//   scene_layout.hip  uploads and the layout conversion: reference-layout scene arrays -> the device's scene blob (finalize_scene)
+//   scene_refit.hip   instance motion and instance-set changes on the device (hk_refit_scene_instances, hk_rebuild_scene_trees, ...)
+//   probes.hip        measurement hooks (hk_measure_*, hk_debug_math)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <new>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "hk_internal.hpp"
+#include "hk_kernels.hpp"
+
+#define HK_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ::hk::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return HK_E_HIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+using namespace hk;   // (a private header: every translation unit that includes it works inside these two namespaces)
+using namespace hkd;
+
+namespace hk {
+
+template <typename T>
+struct DevArray {
+  T* p = nullptr;
+  size_t n = 0;
+  int upload(const std::vector<T>& h) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    n = h.size();
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HK_HIP(hipMalloc((void**)&p, bytes));
+    if (n) HK_HIP(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    return HK_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+// One device allocation for all scene arrays, each 16-B aligned.
+struct Blob {
+  std::vector<uint8_t> bytes;
+  template <typename T>
+  size_t add(const std::vector<T>& v) {
+    size_t off = (bytes.size() + 15) & ~(size_t)15;
+    bytes.resize(off + std::max<size_t>(v.size(), 1) * sizeof(T), 0);
+    if (!v.empty()) memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+  }
+};
+
+struct TimedLaunch {
+  uint32_t slot;
+  hipEvent_t start, stop;
+};
+
+// IEEE minNum / maxNum with -0 < +0 (the numeric contract of hk_device_math.hpp) on the host
+inline float hmin(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return signbit(a) ? a : b;
+  return a < b ? a : b;
+}
+inline float hmax(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return signbit(a) ? b : a;
+  return a > b ? a : b;
+}
+inline uint32_t hash_u32(uint32_t value) {  // utils.wgsl:15-24
+  uint32_t state = value;
+  state = state ^ 2747636419u;
+  state = state * 2654435769u;
+  state = state ^ (state >> 16u);
+  state = state * 2654435769u;
+  state = state ^ (state >> 16u);
+  state = state * 2654435769u;
+  return state;
+}
+inline float as_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+}  // namespace hk
+
+
+// byte offsets of the arrays inside the instance-level region of the scene allocation
+struct DynOffsets { size_t tlas, instances, prev_models, light_lo, light_hi, emissives, alias, materials, tex_info, srgb_lut, flat; uint32_t flat_count, flat_orderings; };
+
+struct hk_ctx {
+  int device = 0;
+  uint32_t flags = 0;
+  hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless hk_set_stream)
+  hipStream_t own_stream = nullptr;
+  hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
+  hipEvent_t fork_event = nullptr, join_event = nullptr;
+  bool forked = false;                 // side_stream holds work the main stream has not waited for yet
+  // Frame pipelining (round 3): the a-trous levels + tone mapping of frame n run on a third stream, so that the main stream goes
+  // straight on to frame n + 1's primary rays and light passes (which read none of the denoiser's buffers).  What both touch is
+  // double-buffered by frame parity: albedo, depth gradient and the derived planes (dn_g, depth) the a-trous taps read.
+  hipStream_t post_stream = nullptr;
+  hipEvent_t post_fork = nullptr, post_done = nullptr;
+  bool post_pending = false;           // post_stream holds work the main stream has not waited for yet
+  uint32_t post_parity = 0;            // mapped_parity of the frame whose a-trous levels are (were last) on post_stream
+  void* albedo_twin = nullptr;         // the planes of the OTHER frame parity (swapped with buf[HK_BUF_ALBEDO] ... in hk_frame_begin)
+  void* depth_gradient_twin = nullptr;
+  void* dn_g_twin = nullptr;
+
+  // host copies of the reference-layout scene (kept for the layout conversion)
+  std::vector<HkVertex> vertices;
+  std::vector<HkPrimitive> primitives;
+  std::vector<HkNode> asset_nodes;
+  std::vector<HkMaterial> materials;
+  std::vector<HkInstance> instances;
+  std::vector<HkNode> instance_nodes;
+  std::vector<HkEmissive> emissives;
+  std::vector<HkNode> emissive_nodes;
+  std::vector<HkAliasEntry> alias_table;
+  struct HostTexture { std::vector<uint32_t> texels; uint32_t w, h, flags; };
+  std::vector<HostTexture> textures;
+  bool have_meshes = false, have_materials = false, have_instances = false, have_noise = false;
+  // what finalize_scene has to redo: the mesh-level region, the instance-level region, the texel buffer
+  bool mesh_dirty = true, dynamic_dirty = true, textures_dirty = true;
+  std::vector<float> prev_models;          // PreviousMeshUniform::transform per instance (optional)
+  std::vector<int64_t> node_prim_offset;   // primitive offset each BLAS node's leaves index (from the last mesh-level build)
+
+  // device scene
+  uint8_t* scene_mem = nullptr;  // every scene array in one allocation (so small scenes can be staged in LDS by one copy loop)
+  size_t dyn_capacity = 0, static_bytes = 0;
+  // Scenes too big for the LDS copy keep TWO slots of the instance-level region, [slot 0][slot 1][mesh region]: an
+  // instance-only update goes through pinned staging into the slot the frames in flight do NOT read, in stream
+  // order, so neither the host nor the GPU waits (animated scenes must not stall on the host).
+  bool two_slots = false;
+  int slot = 0;
+  Blob dyn_blob;                // the instance-level region as last laid out: kept so that a per-frame update re-uses warm pages
+  std::vector<float4> tlas_tmp;  // (20 MB of fresh allocations per update cost more in page faults than the layout itself)
+  bool trees_pending_on_device = false;  // hk_update_scene_instances: the trees about to be uploaded are stand-ins the device overwrites in
+                                         // stream order - no point threading their orderings on the host
+  bool threaded = false;  // eight direction-ordered flattenings of every TLAS / BLAS are stored (hikari_hip.h HK_CTX_EXACT_TRAVERSAL)
+  uint8_t* staging[2] = {nullptr, nullptr};
+  size_t staging_bytes[2] = {0, 0};
+  hipEvent_t staging_done[2] = {nullptr, nullptr};
+  bool staging_pending[2] = {false, false};
+  uint64_t async_instance_uploads = 0;
+  size_t st_nodes = 0, st_v0 = 0, st_v1 = 0, st_v2 = 0, st_vn = 0, st_vuv = 0;  // offsets inside the mesh-level region
+  uint64_t static_rebuilds = 0, dynamic_rebuilds = 0;
+  // Parked previous_spatial stores (HK_CTX_DETERMINISTIC_SCATTER; every band of a sharded frame with a history halo: SURVEY 8e
+  // step 6), one set per light channel.  `to` and the records are the HK_BUF_PARKED_* planes (c->buf: bands exchange their rows),
+  // the winners are private.  Allocated on first use (ensure_parked).
+  int* det_winner[3] = {nullptr, nullptr, nullptr};
+  // uniform-tile store elision (hk_kernels.hpp TileMeta): one record per 8x8 tile per reservoir buffer; tile_meta_zero[k] = the
+  // device array of buffer k is known to be all zero ("contents unknown" everywhere)
+  TileMeta* tile_meta[10] = {};
+  bool tile_meta_zero[10] = {};
+  int tiles_x = 0, tiles_y = 0;
+  uint32_t elide_serial = 0;
+  // ---- instance motion on the device (hk_refit_scene_instances, kernels_scene.hip)
+  DynOffsets dyn_off{};                   // where the arrays of the instance-level region are (the slot in use)
+  float4 *rf_inst_lo = nullptr, *rf_inst_hi = nullptr, *rf_prev_models = nullptr;  // world AABB / previous model per instance
+  uint32_t* rf_emissive_of_instance = nullptr;
+  float* rf_alias_scratch = nullptr;
+  size_t rf_instances = 0, rf_alias = 0;  // sizes the side arrays were allocated for
+  bool rf_ready = false;                  // side arrays describe the scene as uploaded (cleared by every host-side rebuild)
+  hkd::RefitUpdate* rf_updates[2] = {nullptr, nullptr};  // pinned, read by the kernel over PCIe
+  size_t rf_updates_cap[2] = {0, 0};
+  hipEvent_t rf_done[2] = {nullptr, nullptr};
+  bool rf_pending[2] = {false, false};
+  int rf_k = 0;
+  std::vector<uint32_t> rf_last_moved;    // instances whose `moved` flag is set on the device
+  bool mirrors_stale = false;             // the host copies of emissives / tree boxes no longer describe the device scene
+  uint64_t device_refits = 0, device_tree_builds = 0;
+  void* lbvh_scratch = nullptr;           // hk_rebuild_scene_trees
+  size_t lbvh_scratch_cap = 0;
+  const float4* d_prev_models = nullptr;  // 4 columns per instance, valid where DInstance::moved
+  DevArray<uint32_t> d_noise;
+  DevArray<uint32_t> d_tex_data;
+  DScene scene{};
+
+  // screen-space resources
+  int W = 0, H = 0, RW = 0, RH = 0;
+  int UW = 0, UH = 0;           // SMAA Tu4x output size, ceil(size * 2 / ratio) (post_process.rs:718-722)
+  bool uv_fast = false;         // (k + 0.5) / size certified for div_by() on all four sizes (certify_uv_division)
+  uint32_t mapped_parity = 0;   // frame parity whose planes the non-PREVIOUS ids of the double-buffered set name
+  float ratio = 1.0f;
+  void* buf[HK_BUF_COUNT] = {};
+  size_t buf_bytes[HK_BUF_COUNT] = {};
+  // private planes (no HkBuffer id): derived G-buffer planes and the denoiser's per-channel sets used
+  // when all channels of a level run in one launch (the exposed internals hold the LAST channel, which
+  // is what they hold after the reference's channel-by-channel loop)
+  float* depth_plane = nullptr;       // position.w of the current frame's G-buffer (4-B taps)
+  float* prev_depth_plane = nullptr;  // ... of the previous frame's (follows the frame parity like HK_BUF_PREVIOUS_POSITION)
+  void* dn_g = nullptr;
+  void* dn_extra[2][4] = {};
+  float* dn_extra_var[2] = {};
+  bool derived_dirty = false;
+  // scratch of the queue-based schedule of indirect_lit_ambient (hikari_hip.h HK_CTX_WAVEFRONT): ONE allocation, carved into
+  // the planes of hkd::WfBuffers on first use and again after hk_resize
+  void* wf_mem = nullptr;
+  hkd::WfBuffers wf{};
+  int compute_units = 0;
+
+  // uniforms
+  HkFrame frame{};
+  HkView view{};
+  HkPreviousView pview{};
+  HkLights lights{};
+  bool have_frame = false;
+  uint32_t taa = HK_TAA_JASMINE, upscale_kind = HK_UPSCALE_SMAA_TU4X;
+  float upscale_sharpness = 0.0f;
+
+  uint32_t band_index = 0, band_count = 1;
+  std::vector<uint32_t> band_bounds;   // explicit split of the scaled render rows (hk_set_band_bounds): band_count + 1 entries, or empty = equal split
+  uint32_t bounds_generation = 0;
+  void* comm = nullptr;        // RCCL communicator state, owned by comm.cpp (hk_comm_init)
+  uint32_t history_rows = HK_HISTORY_AUTO;  // exchange C rows asked for (hk_set_history_rows): a count, or derived per frame
+  uint32_t history_now = 0;    // ... in force for the frame most recently begun (0 for a single band)
+
+  // statistics
+  unsigned long long* d_counters = nullptr;  // primary, tlas, blas, node steps, triangle tests, instance entries, closest hits (hk_light.hpp flush_counters)
+  uint64_t frames = 0;
+  uint32_t timing_mask = 0;
+  std::vector<TimedLaunch> pending;
+  std::vector<hipEvent_t> event_pool;
+  double slot_ms[HK_TIMING_SLOTS] = {};
+  uint64_t slot_launches[HK_TIMING_SLOTS] = {};
+  hipEvent_t frame_start = nullptr, frame_stop = nullptr;
+  bool frame_timed = false;
+  float last_frame_ms = 0.0f;
+};
+
+namespace hk {
+// ---- context.hip
+int join_side(hk_ctx* c);   // the main stream waits for what was enqueued on the side stream (direct-light dispatches)
+int join_post(hk_ctx* c);   // ... for the a-trous levels of the last frame (post_stream)
+int join_all(hk_ctx* c);
+// ---- scene_layout.hip
+// wait for everything the context has enqueued, on ALL streams
+int sync_all(hk_ctx* c);
+// bring the device scene up to date with the host-side arrays (no-op when nothing is dirty)
+int finalize_scene(hk_ctx* c);
+void update_shared_transform(hk_ctx* c);
+void point_scene_at_slot(hk_ctx* c);
+// ---- scene_refit.hip
+void free_refit(hk_ctx* c);
+}  // namespace hk

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "hk_internal.hpp"
+#include "hk_kernels.hpp"
 
 using namespace hk;
 
@@ -258,4 +259,26 @@ int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step
   return rc;
 }
 
+// Test hook of the numeric contract (tests/test_math_contract.py)
+int hk_debug_math(hk_ctx* c, uint32_t op, const float* x, const float* y, float* out, size_t n) {
+  HK_REQUIRE(c && x && out && op <= 20, HK_E_INVALID, "bad argument");
+  const size_t xin = (op >= 16 && op <= 19 ? 16 : 1) * n;
+  if (n == 0) return HK_OK;
+  PROBE_BEGIN(c);
+  float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  HK_HIP(hipMalloc((void**)&dx, xin * 4));
+  HK_HIP(hipMalloc((void**)&dout, n * 4));
+  HK_HIP(hipMemcpy(dx, x, xin * 4, hipMemcpyHostToDevice));
+  if (y) {
+    HK_HIP(hipMalloc((void**)&dy, n * 4));
+    HK_HIP(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice));
+  }
+  launch_debug_math(stream, op, dx, dy, dout, n);
+  HK_HIP(hipStreamSynchronize(stream));
+  HK_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(dx);
+  (void)hipFree(dout);
+  if (dy) (void)hipFree(dy);
+  return HK_OK;
+}
 }  // extern "C"

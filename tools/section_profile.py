@@ -17,7 +17,7 @@ NAMES = ["prologue+idle", "sample+ray setup", "closest-hit traversal", "hit_info
 if "--build" in sys.argv:
     os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
     csrc = os.path.join(ROOT, "bevy-hikari_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "kernels_wavefront.hip", "kernels_scene.hip", "context.hip", "probes.hip", "host_logic.cpp", "scene_builder.cpp", "comm.cpp")]
+    srcs = [os.path.join(csrc, f) for f in ("kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "kernels_wavefront.hip", "kernels_scene.hip", "context.hip", "scene_layout.hip", "scene_refit.hip", "probes.hip", "host_logic.cpp", "scene_builder.cpp", "comm.cpp")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DHK_ABLATE_WALK_TWICE" if TWICE else "-DHK_PROFILE_SECTIONS",
                     "-o", VARIANT] + srcs, check=True, cwd=csrc)
     print("built", VARIANT)
