@@ -167,6 +167,8 @@ int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
   if ((rc = schedule_for(cm->cache, ci, cm->rank, cm->n_ranks, stage_arg, st, &tr))) return rc;
   if (tr->empty()) return HK_OK;
   HK_HIP(hipSetDevice(ci.device));
+  // exchanges D / E read what the a-trous levels + tone mapping left on the post stream (frame pipelining)
+  if ((stage_arg & 0xffu) >= HK_STAGE_ANTIALIAS && (rc = ctx_join_side(c))) return rc;
   // No join with the side stream here: hk_frame_stage joins it exactly where an exchange reads what the direct-light
   // dispatches wrote (end of TEMPORAL when the emissive channel has a spatial pass, end of SPATIAL before exchange B), so
   // exchange A (indirect reservoirs, main stream) overlaps the direct-light kernels still running on the side stream.
@@ -282,6 +284,11 @@ int multi_exchange(hk_multi* m, uint32_t stage_arg, const HkSettings* st) {
     any = any || !plans[i]->empty();
   }
   if (!any) return HK_OK;
+  if ((stage_arg & 0xffu) >= HK_STAGE_ANTIALIAS)  // exchanges D / E read what the post stream wrote (frame pipelining)
+    for (uint32_t i = 0; i < n; ++i) {
+      const int rj = ctx_join_side(m->ctx[i]);
+      if (rj) return rj;
+    }
   // 1. every band: "produced" recorded on its stream (hk_frame_stage has joined the side stream wherever an exchange reads
   //    what the direct-light dispatches wrote; exchange A therefore overlaps them)
   for (uint32_t i = 0; i < n; ++i) {
@@ -337,6 +344,7 @@ int band_exchange(hk_multi* m, uint32_t i, uint32_t stage_arg, const HkSettings*
     rc = schedule_for(P->cache[i], ci, i, n, stage_arg, st, &plan);
   }
   hipStream_t stream = (hipStream_t)ci.stream;
+  if (!rc && (stage_arg & 0xffu) >= HK_STAGE_ANTIALIAS) rc = ctx_join_side(m->ctx[i]);  // (exchanges D / E read what the post stream wrote)
   // 1. "produced" on my stream
   if (!rc && hipEventRecord(m->produced[i], stream) != hipSuccess) { set_error("hipEventRecord failed (band %u)", i); rc = HK_E_HIP; }
   if (rc) P->failed.store(1, std::memory_order_release);
@@ -578,6 +586,7 @@ int hk_multi_gather(hk_multi* m, uint32_t buffer, uint32_t root) {
     const char* src = static_cast<const char*>(ctx_buffer(m->ctx[t.peer], buffer, &lsrc));
     HK_REQUIRE(src && t.offset + t.bytes <= ldst && t.offset + t.bytes <= lsrc, HK_E_INVALID, "gather transfer outside buffer %u", buffer);
     HK_HIP(hipSetDevice(m->device[t.peer]));
+    if ((rc = ctx_join_side(m->ctx[t.peer]))) return rc;  // (the image may have been finished on the owner's post stream)
     HK_HIP(hipEventRecord(m->produced[t.peer], (hipStream_t)cp.stream));
     HK_HIP(hipSetDevice(m->device[root]));
     HK_HIP(hipStreamWaitEvent((hipStream_t)cr.stream, m->produced[t.peer], 0));

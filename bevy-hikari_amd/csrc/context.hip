@@ -969,7 +969,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     // last frame's a-trous levels may still be running on post_stream: this frame's primary rays and light passes do not touch
     // what they read - provided the double-buffered planes really flipped (a host that renders two frames of the same parity in a
     // row, or shards the frame into bands, or timed passes, gets the serial order)
-    if (c->post_pending && (c->mapped_parity == c->post_parity || c->band_count > 1 || (flags & HK_FRAME_EXTERNAL_GBUFFER)) && (rc = join_post(c))) return rc;
+    if (c->post_pending && (c->mapped_parity == c->post_parity || (flags & HK_FRAME_EXTERNAL_GBUFFER)) && (rc = join_post(c))) return rc;
     if (c->timing_mask) {
       (void)hipEventRecord(c->frame_start, c->stream);
     }
@@ -1052,7 +1052,9 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       // demodulation was the last reader of the light passes' render / variance planes: from here on nothing this frame still
       // does is touched by the next frame's light passes - the four levels go to post_stream (a single-band, untimed frame)
       const uint32_t level_bits = (1u << HK_PASS_DENOISE_L0) | (1u << HK_PASS_DENOISE_L1) | (1u << HK_PASS_DENOISE_L2) | (1u << HK_PASS_DENOISE_L3);
-      const bool pipelined = c->post_stream && c->band_count == 1 && !(c->timing_mask & level_bits) && !c->comm && c->albedo_twin;
+      // (round 4: bands too - a 135-row band leaves most of the chip idle, the next frame's light passes fit beside its a-trous levels;
+      // whoever reads the frame's output - exchange D, the gather, a host - joins the post stream first)
+      const bool pipelined = c->post_stream && !(c->timing_mask & level_bits) && c->albedo_twin;
       hipStream_t main_stream = c->stream;
       if (pipelined) {
         HK_HIP(hipEventRecord(c->post_fork, c->stream));

@@ -32,7 +32,8 @@ def main():
     args = ap.parse_args()
     out = {"assumptions": {"link_gbs_one_direction": LINK_GBS, "exchange_fixed_us": EXCHANGE_US,
                            "method": "every band rendered alone on one MI355X (hk_set_band), wall clock over K frames after a full-frame warm-up; "
-                                     "predicted N-GPU frame = max over bands + sum over the frame's exchanges (two halo exchanges + the gather of the tone-mapped image on rank 0) of (fixed + largest transfer of a rank / link rate)"},
+                                     "predicted N-GPU frame = max over bands + sum over the frame's exchanges (two halo exchanges + the gather of the tone-mapped image on rank 0) of (fixed + largest transfer "
+                                     "from ONE peer / link rate): xGMI is point-to-point with a link per peer, the rows of the upper and of the lower neighbour arrive side by side (round 3 priced their sum on one link)"},
            "configs": {}}
     for config in args.configs:
         scene, camera, settings, lights, description = bench.workload(hk, config, None, None, None)
@@ -75,19 +76,25 @@ def main():
                 # bytes this band receives per frame, per exchange (static view: no history rows)
                 ex = []
                 for stage in (F.STAGE_SPATIAL, F.STAGE_POST_PROCESS):
-                    ex.append(sum(t.bytes for t in band_schedule(W, H, 1.0, b, bands, stage, n, sc, bounds) if t.is_recv) if bands > 1 else 0)
+                    per_peer = {}
+                    if bands > 1:
+                        for t in band_schedule(W, H, 1.0, b, bands, stage, n, sc, bounds):
+                            if t.is_recv:
+                                per_peer[t.peer] = per_peer.get(t.peer, 0) + t.bytes
+                    # (total received, most from ONE peer): every peer has its own xGMI link, the neighbours' rows arrive side by side
+                    ex.append((sum(per_peer.values()), max(per_peer.values(), default=0)))
                 recv.append(ex)
             exch_ms = 0.0
             gather_bytes = 0
             if bands > 1:
                 for k in range(2):
-                    worst = max(r[k] for r in recv)
+                    worst = max(r[k][1] for r in recv)
                     if worst:
                         exch_ms += EXCHANGE_US * 1e-3 + worst / (LINK_GBS * 1e9) * 1e3
                 # rank 0 collects the tone-mapped rows of the others, one link per sender in parallel
                 gather_bytes = max(t.bytes for b in range(1, bands) for t in band_gather_schedule(W, H, 1.0, settings.upscale.kind, b, bands, 0, F.BUF_TONE_MAPPED, bounds))
                 exch_ms += EXCHANGE_US * 1e-3 + gather_bytes / (LINK_GBS * 1e9) * 1e3
-            rows[f"{bands}_balanced" if balanced else bands] = {"bounds": bounds, "band_ms": [round(x, 4) for x in per_band], "max_band_ms": round(max(per_band), 4), "halo_bytes_received_per_band": recv, "gather_bytes_largest_band": gather_bytes,
+            rows[f"{bands}_balanced" if balanced else bands] = {"bounds": bounds, "band_ms": [round(x, 4) for x in per_band], "max_band_ms": round(max(per_band), 4), "halo_bytes_received_per_band": [[x[0] for x in r] for r in recv], "halo_bytes_from_one_peer_per_band": [[x[1] for x in r] for r in recv], "gather_bytes_largest_band": gather_bytes,
                            "exchange_ms_predicted": round(exch_ms, 4), "frame_ms_predicted": round(max(per_band) + exch_ms, 4)}
         t1 = rows[1]["frame_ms_predicted"]
         for key in rows:
