@@ -197,7 +197,7 @@ _SIGNATURES = {
 _DEBUG = {
     "debug_math": [_vp, u32, P(f32), P(f32), P(f32), C.c_size_t],
     "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
-    "debug_comm_loopback": [_vp, u32, u32, u32, u32],
+    "debug_comm_loopback": [_vp, u32, u32, u32, u32, u32],
     "debug_read_wf_timeline": [_vp, P(C.c_uint64), u32],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],

@@ -93,6 +93,14 @@ struct Comm {
   };
   std::deque<Cached> cache;  // (deque: references stay valid while entries are appended)
   uint64_t exchanges = 0, bytes_received = 0;
+  // Every RCCL call of this context goes to ONE stream of its own, ordered against the context's stream with events: an exchange
+  // waits for what the context has enqueued (`ready`) and the context's stream waits for the exchange (`done`) - the order a
+  // single stream would give - while the GATHER of a finished frame makes nobody wait: the next frame renders while rank 0
+  // collects the rows (`gather_done`; comm_join before the plane is written again, or before anybody reads the image).
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr, gather_done = nullptr;
+  bool gather_pending = false;
+  uint32_t gather_parity = 0;  // frame parity of the plane a pending gather reads / fills
 };
 
 int schedule_for(std::deque<Comm::Cached>& cache, const CtxInfo& ci, uint32_t rank, uint32_t n_ranks, uint32_t stage_arg, const HkSettings* st,
@@ -148,9 +156,33 @@ int run_transfers(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, 
   return HK_OK;
 }
 
+// the transfers on the communicator's stream, behind everything `main` holds; wait = `main` continues only after them
+int run_ordered(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, hipStream_t main, bool wait) {
+  HK_HIP(hipEventRecord(cm->ready, main));
+  HK_HIP(hipStreamWaitEvent(cm->stream, cm->ready, 0));
+  const int rc = run_transfers(c, cm, R, tr, n, cm->stream);
+  if (rc) return rc;
+  HK_HIP(hipEventRecord(wait ? cm->done : cm->gather_done, cm->stream));
+  if (wait) HK_HIP(hipStreamWaitEvent(main, cm->done, 0));
+  return HK_OK;
+}
+
 }  // namespace
 
 namespace hk {
+
+// the context's stream waits for a gather still in flight: parity < 0 = whatever is pending (somebody is about to look at the image),
+// else only a gather of that frame parity's plane (the frame being begun will write it)
+int comm_join(hk_ctx* c, int parity) {
+  Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
+  if (!cm || !cm->gather_pending || (parity >= 0 && (uint32_t)parity != cm->gather_parity)) return HK_OK;
+  CtxInfo ci;
+  const int rc = ctx_info(c, &ci);
+  if (rc) return rc;
+  HK_HIP(hipStreamWaitEvent((hipStream_t)ci.stream, cm->gather_done, 0));
+  cm->gather_pending = false;
+  return HK_OK;
+}
 
 int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
   Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
@@ -172,13 +204,13 @@ int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
   // No join with the side stream here: hk_frame_stage joins it exactly where an exchange reads what the direct-light
   // dispatches wrote (end of TEMPORAL when the emissive channel has a spatial pass, end of SPATIAL before exchange B), so
   // exchange A (indirect reservoirs, main stream) overlaps the direct-light kernels still running on the side stream.
-  if ((rc = run_transfers(c, cm, R, tr->data(), tr->size(), (hipStream_t)ci.stream))) return rc;
+  if ((rc = run_ordered(c, cm, R, tr->data(), tr->size(), (hipStream_t)ci.stream, true))) return rc;
   cm->exchanges += 1;
   return HK_OK;
 }
 
 // the root collects every other band's rows of `buffer` (ncclSend / ncclRecv pairs in one group, on the stream)
-int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root) {
+int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root, bool overlap) {
   Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
   HK_REQUIRE(cm && cm->comm, HK_E_NOT_READY, "no communicator attached (hk_comm_init)");
   Rccl* R = rccl();
@@ -195,7 +227,15 @@ int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root) {
   if (n && (rc = hk_band_gather_schedule(ci.width, ci.height, ci.ratio, ci.upscale_kind, ci.band_bounds, cm->rank, cm->n_ranks, root, buffer, tr.data(), &n))) return rc;
   if (tr.empty()) return HK_OK;
   HK_HIP(hipSetDevice(ci.device));
-  return run_transfers(c, cm, R, tr.data(), tr.size(), (hipStream_t)ci.stream);
+  // overlap: nobody waits - the next frame writes the OTHER parity's plane, and the frame after it (or whoever reads the image
+  // first) joins.  Only for a plane that is double-buffered by frame parity and that the next frame does not read.
+  overlap = overlap && buffer == HK_BUF_TONE_MAPPED;
+  if ((rc = run_ordered(c, cm, R, tr.data(), tr.size(), (hipStream_t)ci.stream, !overlap))) return rc;
+  if (overlap) {
+    cm->gather_pending = true;
+    cm->gather_parity = ci.frame_number & 1u;
+  }
+  return HK_OK;
 }
 
 void comm_release(hk_ctx* c) {
@@ -203,7 +243,11 @@ void comm_release(hk_ctx* c) {
   Comm* cm = static_cast<Comm*>(*slot);
   if (!cm) return;
   Rccl* R = rccl();
+  if (cm->stream) (void)hipStreamSynchronize(cm->stream);
   if (R && cm->comm) (void)R->CommDestroy(cm->comm);
+  for (hipEvent_t e : {cm->ready, cm->done, cm->gather_done})
+    if (e) (void)hipEventDestroy(e);
+  if (cm->stream) (void)hipStreamDestroy(cm->stream);
   delete cm;
   *slot = nullptr;
 }
@@ -512,6 +556,13 @@ int hk_comm_init(hk_ctx* c, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK
   }
   cm->rank = rank;
   cm->n_ranks = n_ranks;
+  if (hipStreamCreateWithFlags(&cm->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&cm->ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&cm->done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&cm->gather_done, hipEventDisableTiming) != hipSuccess) {
+    set_error("cannot create the communicator's stream / events: %s", hipGetErrorString(hipGetLastError()));
+    *ctx_comm_slot(c) = cm;  // (comm_release tears down what exists)
+    comm_release(c);
+    return HK_E_HIP;
+  }
   *ctx_comm_slot(c) = cm;
   return hk_set_band(c, rank, n_ranks);
 }
@@ -533,7 +584,7 @@ int hk_comm_exchange(hk_ctx* c, uint32_t stage, const HkSettings* st) {
 // hikari_hip_debug.h: rows [row_begin, row_end) of `src_buffer` travel to the same rows of `dst_buffer` of the SAME context as an
 // ncclSend to the own rank paired with an ncclRecv from it - the group, the calls and the stream the halo exchanges use, on a box
 // with one GPU (RCCL refuses two ranks on one device, so this is the one way the send / receive path can execute there)
-int hk_debug_comm_loopback(hk_ctx* c, uint32_t src_buffer, uint32_t dst_buffer, uint32_t row_begin, uint32_t row_end) {
+int hk_debug_comm_loopback(hk_ctx* c, uint32_t src_buffer, uint32_t dst_buffer, uint32_t row_begin, uint32_t row_end, uint32_t mode) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
   HK_REQUIRE(cm && cm->comm, HK_E_NOT_READY, "no communicator attached (hk_comm_init)");
@@ -551,14 +602,19 @@ int hk_debug_comm_loopback(hk_ctx* c, uint32_t src_buffer, uint32_t dst_buffer, 
   tr[1] = tr[0];
   tr[1].buffer = dst_buffer; tr[1].is_recv = 1;
   HK_HIP(hipSetDevice(ci.device));
-  if ((rc = run_transfers(c, cm, R, tr, 2, (hipStream_t)ci.stream))) return rc;
+  const bool overlap = mode == 1u;  // 1: like the gather of a finished frame - nobody waits, comm_join does (hk_frame_begin of the same parity, any read)
+  if ((rc = run_ordered(c, cm, R, tr, 2, (hipStream_t)ci.stream, !overlap))) return rc;
+  if (overlap) {
+    cm->gather_pending = true;
+    cm->gather_parity = ci.frame_number & 1u;
+  }
   cm->exchanges += 1;
   return HK_OK;
 }
 
 int hk_comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root) {
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
-  return comm_gather(c, buffer, root);
+  return comm_gather(c, buffer, root, false);   // by hand: complete in stream order, like the exchanges
 }
 
 // one process, n bands: the root band's context ends up holding the whole image on ITS device (peer copies on the root's stream,

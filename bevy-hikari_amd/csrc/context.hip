@@ -418,8 +418,10 @@ int join_post(hk_ctx* c) {
   return HK_OK;
 }
 int join_all(hk_ctx* c) {
-  const int rc = join_side(c);
-  return rc ? rc : join_post(c);
+  int rc = join_side(c);
+  if (!rc) rc = join_post(c);
+  if (!rc && c->comm) rc = comm_join(c, -1);  // a gather of the last frame still collecting rows on the communicator's stream
+  return rc;
 }
 // run one dispatch on the side stream (timers record there too)
 int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1);
@@ -795,6 +797,7 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
     }
     c->mapped_parity = f->number & 1u;
   }
+  if (c->comm) { const int rc = comm_join(c, (int)(f->number & 1u)); if (rc) return rc; }  // a gather still reading the plane this frame writes
   // the history halo of this frame: a count the host set, or the bound every rank derives from the same uniforms
   c->history_now = 0;
   if (c->band_count > 1 && c->RH > 0) {
@@ -1139,7 +1142,9 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
   // rank 0 collects the finished image (the post stream's tone mapping has to be in before the rows leave)
   if (ex && (flags & HK_FRAME_GATHER)) {
     if ((rc = join_all(c))) return rc;
-    return comm_gather(c, hk_final_buffer(st, flags), 0u);
+    // (round 4: rank 0 collects the rows WHILE the next frame renders - the tone-mapped image is double-buffered by frame parity;
+    // with the anti-aliasing tail, whose next frame reads this frame's outputs, the gather completes in stream order as before)
+    return comm_gather(c, hk_final_buffer(st, flags), 0u, !(flags & HK_FRAME_ANTIALIAS));
   }
   return HK_OK;
 }

@@ -82,7 +82,8 @@ struct CtxInfo {
   uint32_t bounds_generation;    // changes whenever the split does (cached schedules compare it)
 };
 int ctx_info(hk_ctx* c, CtxInfo* out);
-int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root);  // comm.cpp
+int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root, bool overlap);  // comm.cpp; overlap: see Comm
+int comm_join(hk_ctx* c, int parity);  // the context's stream waits for a gather in flight (parity < 0: any)
 void* ctx_buffer(hk_ctx* c, uint32_t buffer, size_t* logical_bytes);
 void** ctx_comm_slot(hk_ctx* c);       // owned by comm.cpp (NULL = no communicator)
 int ctx_join_side(hk_ctx* c);          // main stream waits for the side stream

@@ -649,10 +649,10 @@ class Engine:
         """hk_comm_gather: rank `root` collects every other rank's rows of `buffer` (RCCL, on the context's stream)."""
         self.api.call("comm_gather", self.ctx, buffer, root)
 
-    def debug_comm_loopback(self, src_buffer, dst_buffer, row_begin, row_end):
+    def debug_comm_loopback(self, src_buffer, dst_buffer, row_begin, row_end, overlapped=False):
         """hk_debug_comm_loopback (hikari_hip_debug.h): rows of one buffer to the same rows of another through ncclSend / ncclRecv
         to the context's own rank, on the context's stream."""
-        self.api.call("debug_comm_loopback", self.ctx, src_buffer, dst_buffer, row_begin, row_end)
+        self.api.call("debug_comm_loopback", self.ctx, src_buffer, dst_buffer, row_begin, row_end, 1 if overlapped else 0)
 
     def comm_destroy(self):
         self.api.call("comm_destroy", self.ctx)

@@ -561,7 +561,10 @@ int hk_pass_run(hk_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, ui
  * the first frame, after a cut, or accept a few frames of re-convergence in the moved rows. */
 #define HK_FRAME_BALANCE_BANDS 4u
 /* flags bit3 (hk_frame_render with a communicator, hk_multi_frame_render): after the last stage, band 0 collects the other bands' rows of
- * the frame's final image (hk_final_buffer) - SURVEY 8e step 7, hk_comm_gather / hk_multi_gather */
+ * the frame's final image (hk_final_buffer) - SURVEY 8e step 7, hk_comm_gather / hk_multi_gather.  With a communicator and without
+ * HK_FRAME_ANTIALIAS the rows travel WHILE the next frame renders (ABI 7: every RCCL call runs on a stream of the communicator's own,
+ * ordered against the context's stream by events; the tone-mapped image is double-buffered by frame parity): the image on band 0 is
+ * complete once hk_frame_wait, any buffer access, or the hk_frame_begin of the frame after next has been passed. */
 #define HK_FRAME_GATHER 8u
 int hk_frame_stage(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, uint32_t flags);
 /* hk_frame_begin + TEMPORAL, SPATIAL, POST_PROCESS (+ ANTIALIAS with HK_FRAME_ANTIALIAS): single GPU, no halo exchange */

@@ -47,9 +47,12 @@ int hk_debug_read_wf_timeline(hk_ctx* ctx, unsigned long long* out, uint32_t n /
 /* Test hook for the RCCL data path on a box with ONE GPU (RCCL refuses two ranks on one device, so no halo exchange between
  * ranks can run there): rows [row_begin, row_end) of `src_buffer` travel to the same rows of `dst_buffer` (same shape) of the
  * SAME context as an ncclSend to the context's own rank paired with an ncclRecv from it, inside one ncclGroupStart / ncclGroupEnd,
- * on the context's stream - the very function (comm.cpp run_transfers) hk_frame_render's exchanges and hk_comm_gather go
+ * ordered against the context's stream - the very function (comm.cpp run_transfers) hk_frame_render's exchanges and hk_comm_gather go
  * through.  Needs hk_comm_init (a communicator of any size; 1 rank on a one-GPU box). */
-int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer, uint32_t row_begin, uint32_t row_end);
+int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer, uint32_t row_begin, uint32_t row_end,
+                           uint32_t mode /* 0: in stream order, like a halo exchange; 1: overlapped with what follows, like the gather of a finished
+                                            frame (hk_frame_render with HK_FRAME_GATHER) - complete before the frame of the same parity begins or
+                                            anybody reads a buffer */);
 
 #ifdef __cplusplus
 }

@@ -334,6 +334,19 @@ def test_rccl_send_and_receive_execute_on_the_stream():
     assert (got[rows[0]:rows[1]] == first[rows[0]:rows[1]]).all(), "the rows RCCL delivered are not what the frame before the exchange wrote"
     assert not got[:rows[0]].any() and not got[rows[1]:].any()
     assert (e.read(src) == second).all()
+    # ... and the way the GATHER of a finished frame runs (hk_frame_render with HK_FRAME_GATHER): on the communicator's stream, nobody
+    # waits - frame 4 (the other parity's planes) renders meanwhile; frame 5 writes the plane the transfer reads and therefore joins
+    # first (hk_frame_begin), as does anybody who reads a buffer.  What arrives is frame 3's tone-mapped image.
+    ref.frame_render(hk.frame_uniform(s, 3), view, pview, lights, s.to_c())
+    third = ref.read(F.BUF_TONE_MAPPED)
+    e.frame_render(hk.frame_uniform(s, 3), view, pview, lights, s.to_c())
+    e.debug_comm_loopback(F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0, 11, 133, overlapped=True)
+    for n in (4, 5, 6):
+        ref.frame_render(hk.frame_uniform(s, n), view, pview, lights, s.to_c())
+        e.frame_render(hk.frame_uniform(s, n), view, pview, lights, s.to_c())
+    got = e.read(F.BUF_DENOISE_RENDER0)
+    assert (got[11:133] == third[11:133]).all() and third[11:133].any() and not got[:11].any() and not got[133:].any()
+    assert (e.read(F.BUF_TONE_MAPPED) == ref.read(F.BUF_TONE_MAPPED)).all()
     with pytest.raises(hk.HikariError):
         e.debug_comm_loopback(src, F.BUF_POSITION, *rows)    # another shape
     e.comm_destroy()
