@@ -11,7 +11,7 @@ fi
 timeout 600 python bench.py --passes > $OUT/${TAG}_bench_config2.json 2> $OUT/${TAG}_bench_config2.err
 tail -1 $OUT/${TAG}_bench_config2.json | cut -c1-600
 for C in 3 4 5; do
-  timeout 900 python bench.py --config $C --passes --no-cpu-baseline --no-hbm-probe --blocks 3 > $OUT/${TAG}_bench_config$C.json 2> $OUT/${TAG}_bench_config$C.err
+  timeout 900 python bench.py --config $C --passes --no-cpu-baseline --blocks 3 > $OUT/${TAG}_bench_config$C.json 2> $OUT/${TAG}_bench_config$C.err
   tail -1 $OUT/${TAG}_bench_config$C.json | cut -c1-400
 done
 cd /tmp && export TMPDIR=/tmp
