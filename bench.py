@@ -271,13 +271,13 @@ def main():
         same = bool((ceng.read(F.BUF_TONE_MAPPED) == tone).all())  # the replay must reproduce the timed frames bit for bit
         # what the walks of those frames did (HkStats walk_*: node steps, triangle tests, instance entries, closest hits) - per frame,
         # and for the indirect pass alone (its dispatch repeated once on the last frame's inputs: same rays, same walks)
-        walk = {"per_frame": {k: getattr(cst, "walk_" + k) / steps for k in ("node_steps", "triangle_tests", "instance_entries", "closest_hits")},
+        walk = {"per_frame": {k: getattr(cst, "walk_" + k) / steps for k in ("node_steps", "triangle_tests", "instance_entries", "closest_hits", "top_node_steps")},
                 "rays_per_frame": (cst.rays_tlas + cst.rays_blas + cst.rays_primary) / steps}
         if crend is None:
             ceng.reset_stats()
             ceng.pass_run(F.PASS_INDIRECT)
             ist = ceng.stats()
-            walk["indirect_pass"] = {k: float(getattr(ist, "walk_" + k)) for k in ("node_steps", "triangle_tests", "instance_entries", "closest_hits")}
+            walk["indirect_pass"] = {k: float(getattr(ist, "walk_" + k)) for k in ("node_steps", "triangle_tests", "instance_entries", "closest_hits", "top_node_steps")}
             walk["indirect_pass"]["rays"] = float(ist.rays_tlas + ist.rays_blas)
         del ceng, crend
 
@@ -341,7 +341,7 @@ def main():
              "avg_launch_ms": round(x["ind_ms"], 4),
              "walk_counts_per_launch": {k: int(v) for k, v in ip.items()},
              "per_ray": {"node_steps": round(ip["node_steps"] / ip["rays"], 2), "triangle_tests": round(ip["triangle_tests"] / ip["rays"], 2),
-                         "instance_entries": round(ip["instance_entries"] / ip["rays"], 2), "bvh_bytes": round(bvh_bytes / ip["rays"], 1)},
+                         "instance_entries": round(ip["instance_entries"] / ip["rays"], 2), "node_steps_in_the_instance_tree": round(ip["top_node_steps"] / ip["rays"], 2), "bvh_bytes": round(bvh_bytes / ip["rays"], 1)},
              "formula": "SURVEY 8d: visited nodes x 32 + leaf (triangle) tests x 48 + 96 per closest hit; instance entries (208-B records) counted, not priced",
              "tree_bytes_walked": tree_bytes, "traffic": None}
         if probe_engine is not None:

@@ -1232,6 +1232,7 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   out->walk_triangle_tests = h[4];
   out->walk_instance_entries = h[5];
   out->walk_closest_hits = h[6];
+  out->walk_top_node_steps = h[7];
   out->frames = c->frames;
   out->last_frame_ms = c->last_frame_ms;
   out->scene_mesh_builds = c->static_rebuilds;

@@ -143,7 +143,7 @@ struct LightCandidate { f3 direction; float max_distance, min_distance; uint32_t
 // tlas / blas: walks started (SURVEY 8d's ray definition).  The other four price a walk in the terms of SURVEY 8d's algorithmic BVH
 // bytes per ray - node steps x 32 B, triangle tests x 48 B, instance entries x 208 B, closest hits whose attributes are fetched
 // (hit_info: three vertex records) x 96 B.  Only the COUNT instantiations of the kernels read them; everywhere else they are dead.
-struct RayCounters { uint32_t tlas, blas, nodes = 0u, tris = 0u, entries = 0u, hits = 0u; };
+struct RayCounters { uint32_t tlas, blas, nodes = 0u, tris = 0u, entries = 0u, hits = 0u, top_nodes = 0u; };  // top_nodes: the node steps taken in the instance tree
 
 HKD Sample zero_sample() {
   Sample s;
@@ -663,6 +663,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
     const float4 lo = nd[0];
     const float4 hi = nd[1];
     rc.nodes++;
+    rc.top_nodes += in_blas ? 0u : 1u;
     const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
     // intersects_aabb, light.wgsl:344-362, on the current level's ray
     const f3 t1 = (xyz(lo) - co) * cinv;

@@ -62,12 +62,12 @@ template <bool COUNT>
 __device__ __forceinline__ void flush_counters(const RayCounters& rc, uint32_t primary, unsigned long long* counters) {
   if (!COUNT) return;
   // counters: [0] primary rays, [1] traverse_top walks, [2] stand-alone traverse_bottom walks, [3] node steps, [4] triangle tests,
-  // [5] instance entries, [6] closest hits whose attributes were fetched (HkStats)
-  uint32_t v[7] = {primary, rc.tlas, rc.blas, rc.nodes, rc.tris, rc.entries, rc.hits};
+  // [5] instance entries, [6] closest hits whose attributes were fetched, [7] node steps in the instance tree (HkStats)
+  uint32_t v[8] = {primary, rc.tlas, rc.blas, rc.nodes, rc.tris, rc.entries, rc.hits, rc.top_nodes};
   for (int off = 32; off > 0; off >>= 1)
-    for (int k = 0; k < 7; ++k) v[k] += __shfl_down(v[k], off);
+    for (int k = 0; k < 8; ++k) v[k] += __shfl_down(v[k], off);
   if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 7; ++k)
+    for (int k = 0; k < 8; ++k)
       if (v[k]) atomicAdd(&counters[k], (unsigned long long)v[k]);
 }
 

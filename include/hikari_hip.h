@@ -348,6 +348,7 @@ typedef struct HkStats {
   uint64_t walk_triangle_tests;
   uint64_t walk_instance_entries;
   uint64_t walk_closest_hits;
+  uint64_t walk_top_node_steps;  /* ... of walk_node_steps, those taken in the instance tree (the rest walk mesh trees) */
 } HkStats;
 
 typedef struct hk_ctx hk_ctx;
