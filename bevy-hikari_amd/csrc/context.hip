@@ -368,6 +368,59 @@ bool use_wavefront(const hk_ctx* c) {
   if (c->flags & HK_CTX_WAVEFRONT) return true;
   return (size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES;
 }
+// The wide walk (kernels_wavefront.hip k_wf_trace_wide) is the trace stage of scenes beyond LDS in the product default; the
+// reference's order (HK_CTX_EXACT_TRAVERSAL) and the instrumented twin keep the skip-link walk.  HK_NO_WIDE_WALK=1: A/B switch.
+bool use_wide(const hk_ctx* c) {
+  static const bool off = getenv("HK_NO_WIDE_WALK") != nullptr;
+  return !off && c->threaded && !c->wf.timeline && !c->scene.flat_mode;
+}
+// records of the trees the next trace stages walk, (re)derived from what the scene blob holds now
+int ensure_wide(hk_ctx* c) {
+  const size_t tlas_slots = c->instance_nodes.size(), blas_slots = c->asset_nodes.size();
+  if (tlas_slots == 0 || blas_slots == 0) return HK_OK;
+  if (tlas_slots > c->wide_tlas_slots) {
+    if (c->wide_tlas) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_tlas); c->wide_tlas = nullptr; }
+    HK_HIP(hipMalloc((void**)&c->wide_tlas, (tlas_slots + tlas_slots / 2 + 16) * 128));
+    c->wide_tlas_slots = tlas_slots + tlas_slots / 2 + 16;
+    c->wide_tlas_dirty = true;
+  }
+  if (blas_slots > c->wide_blas_slots) {
+    if (c->wide_blas) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_blas); c->wide_blas = nullptr; }
+    HK_HIP(hipMalloc((void**)&c->wide_blas, blas_slots * 128));
+    c->wide_blas_slots = blas_slots;
+    c->wide_blas_dirty = true;
+  }
+  if (!c->compute_units) {
+    hipDeviceProp_t prop;
+    HK_HIP(hipGetDeviceProperties(&prop, c->device));
+    c->compute_units = prop.multiProcessorCount;
+  }
+  const size_t lanes = (size_t)c->compute_units * 4 * 256;  // HK_WF_WIDE_WAVES workgroups per CU
+  if (lanes > c->wide_spill_lanes) {
+    if (c->wide_spill) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_spill); c->wide_spill = nullptr; }
+    HK_HIP(hipMalloc((void**)&c->wide_spill, lanes * 96 * sizeof(uint32_t)));  // HK_WIDE_SPILL entries per lane
+    c->wide_spill_lanes = lanes;
+  }
+  if (c->wide_blas_dirty) {  // one launch per mesh tree (links are local to a tree): once per mesh-level build
+    std::vector<uint8_t> seen;
+    std::vector<std::pair<uint32_t, uint32_t>> meshes;
+    for (const HkInstance& in : c->instances) meshes.emplace_back(in.mesh.node_offset, in.mesh.node_count);
+    std::sort(meshes.begin(), meshes.end());
+    meshes.erase(std::unique(meshes.begin(), meshes.end()), meshes.end());
+    for (const auto& m : meshes) {
+      HK_REQUIRE((size_t)m.first + m.second <= blas_slots, HK_E_INVALID, "an instance's mesh nodes lie outside the uploaded mesh nodes");
+      launch_build_wide(c->stream, c->scene.nodes + 2u * ((size_t)c->scene.blas_base + m.first), m.second, c->wide_blas + 8u * (size_t)m.first);
+    }
+    HK_HIP(hipGetLastError());
+    c->wide_blas_dirty = false;
+  }
+  if (c->wide_tlas_dirty) {
+    launch_build_wide(c->stream, c->scene.nodes, (uint32_t)tlas_slots, c->wide_tlas);
+    HK_HIP(hipGetLastError());
+    c->wide_tlas_dirty = false;
+  }
+  return HK_OK;
+}
 // the scratch of the queue-based schedule: allocated on first use for the current render size
 int ensure_wavefront(hk_ctx* c) {
   const size_t cap = (size_t)c->RW * c->RH;
@@ -465,8 +518,16 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       }
       if (pass == HK_PASS_INDIRECT && use_wavefront(c)) {
         { const int rc_ = ensure_wavefront(c); if (rc_) return rc_; }
+        hkd::WideTrees wide{};
+        if (use_wide(c)) {
+          { const int rc_ = ensure_wide(c); if (rc_) return rc_; }
+          wide.tlas = c->wide_tlas;
+          wide.blas = c->wide_blas;
+          wide.tlas_count = c->scene.tlas_count;
+          wide.spill = c->wide_spill;
+        }
         launch_indirect_wavefront(c->stream, c->scene, fr, g, t, c->wf, y0, y1, c->compute_units, timer.on ? timer.t.start : nullptr,
-                                  timer.on ? timer.t.stop : nullptr);
+                                  timer.on ? timer.t.stop : nullptr, &wide);
       } else if (pass == HK_PASS_INDIRECT)  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
         launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, t, y0, y1, counters, timer.on ? timer.t.start : nullptr,
                         timer.on ? timer.t.stop : nullptr);
@@ -662,6 +723,8 @@ void hk_destroy(hk_ctx* c) {
     if (c->staging_done[k]) (void)hipEventDestroy(c->staging_done[k]);
   }
   free_refit(c);
+  for (void* q : {(void*)c->wide_tlas, (void*)c->wide_blas, (void*)c->wide_spill})
+    if (q) (void)hipFree(q);
   c->d_tex_data.release();
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);

@@ -211,6 +211,14 @@ struct hk_ctx {
   // the planes of hkd::WfBuffers on first use and again after hk_resize
   void* wf_mem = nullptr;
   hkd::WfBuffers wf{};
+  // wide trees of the trace stages (hk_kernels.hpp WideTrees): records derived ON THE DEVICE from ordering 0 of the trees the scene
+  // blob holds, lazily - the mesh trees when the mesh-level region was rebuilt, the instance tree whenever it was uploaded, refit or
+  // rebuilt (wide_*_dirty), in stream order right before the pass that walks them
+  float4* wide_tlas = nullptr;
+  float4* wide_blas = nullptr;
+  uint32_t* wide_spill = nullptr;
+  size_t wide_tlas_slots = 0, wide_blas_slots = 0, wide_spill_lanes = 0;
+  bool wide_tlas_dirty = true, wide_blas_dirty = true;
   int compute_units = 0;
 
   // uniforms

@@ -77,6 +77,18 @@ struct WfBuffers {
   // [4] waves, [5] most node steps of one ray, [6] node steps, [7] rays, [8..23] rays by floor(log2(node steps + 1))
   unsigned long long* timeline;
 };
+// Wide trees for the queue-based trace stage (round 4; kernels_wavefront.hip k_build_wide / k_wf_trace_wide; DESIGN 4 "Wide walk").
+// One 128-B record per INNER node of a flatten_custom tree, at the node's own position in a parallel array: the boxes and links
+// of its (up to four) grandchildren - four 32-B box-nodes, lo = (min.xyz, link), hi = (max.xyz, -).  link: HK_LEAF | id = a leaf
+// (triangle of the mesh / instance), < HK_LEAF = position of an inner node (its record), 0xFFFFFFFF = no child.  The record of a
+// tree's root (which flatten_custom does not store) sits in the tree's LAST slot (always a leaf's).  ONE ordering: the walk keeps
+// a per-lane stack and takes the children nearest first, so the eight direction-threaded copies are not needed here.
+struct WideTrees {
+  const float4* tlas;   // records of the instance tree: 8 float4 per slot, tlas_count slots
+  const float4* blas;   // records of every mesh tree: slot node_offset + local position
+  uint32_t tlas_count;  // (its root: slot tlas_count - 1)
+  uint32_t* spill;      // stack entries beyond the LDS part: HK_WIDE_SPILL u32 per lane of the persistent launch
+};
 // Instance motion on the device (kernels_scene.hip): the arrays of the instance-level region the refit kernels rewrite, plus
 // the refit's own side arrays.
 struct RefitUpdate {       // one record per instance whose transform changed (read from pinned host memory)
@@ -257,8 +269,11 @@ void launch_direct(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, con
 void launch_indirect(hipStream_t st, bool multiple_bounces, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g,
                      const hkd::LightTargets& t, int y0, int y1, unsigned long long* counters, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // the same dispatch as launch_indirect(multiple_bounces = true), scheduled through ray queues (kernels_wavefront.hip)
+// wide: records of the trees for the trace stages (nullptr members = the threaded walk)
+void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide);  // one flatten_custom tree (ordering 0) -> its records
 void launch_indirect_wavefront(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
-                               const hkd::WfBuffers& w, int y0, int y1, int compute_units, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+                               const hkd::WfBuffers& w, int y0, int y1, int compute_units, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
+                               const hkd::WideTrees* wide = nullptr);
 void launch_copy_region(hipStream_t st, void* dst, const void* src, size_t bytes);
 void launch_gather_instance_boxes(hipStream_t st, const hkd::RefitScene& s, const float4* tlas, uint32_t tlas_count);
 // the first n_emitter_updates records are the moved emitters (the largest of their meshes has emitter_triangles triangles)

@@ -431,6 +431,318 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
   }
 }
 
+// ------------------------------------------------------------------ wide walk (round 4)
+// a trace stage is a bulk at the memory system's rate for DEPENDENT DIVERGENT FETCHES - a miss costs a 128-B line whatever
+// the node's size - followed by a tail as long as the longest walk's chain.  The flatten_custom layout spends one dependent fetch
+// per BOX (84 per ray, 34-42 of them in the instance tree).  Here a fetch is one 128-B record with the boxes of an inner node's FOUR
+// grandchildren (hk_kernels.hpp WideTrees): two levels per dependent step, on both levels of the scene, from ONE copy of the trees
+// (1/8 of the bytes the eight threaded orderings take: what the 4 MB L2s can hold goes up accordingly).  The order in which
+// children are visited is not stored but decided per ray - nearest first - with a per-lane stack: 32 entries in LDS (entry-major:
+// conflict-free), the rest in a global spill area.  Same candidates, same per-triangle arithmetic on the same operands as
+// traverse_top: the closest hit is the reference's except where two candidates tie exactly (the product default's bar, like the
+// threaded orderings); an any-hit ray's outcome - occluded or not - does not depend on the order at all.
+#ifndef HK_WIDE_LDS_STACK
+#define HK_WIDE_LDS_STACK 32u
+#endif
+#ifndef HK_WIDE_SPILL
+#define HK_WIDE_SPILL 96u
+#endif
+constexpr uint32_t WIDE_NONE = 0xFFFFFFFFu;      // no child / nothing to visit
+constexpr uint32_t WIDE_LEAVE = 0xFFFFFFFEu;     // stack marker: the mesh tree below this entry is done, back to the instance tree
+
+// one thread per slot of ONE tree (ordering 0; links local to the tree): the record of the inner node at that slot, and - in the
+// last slot - the root's
+__global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ nodes, uint32_t count, float4* __restrict__ wide) {
+  const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+  if (x >= count) return;
+  auto entry_of = [&](uint32_t i) { return f2u(nodes[2u * i].w); };
+  auto exit_of = [&](uint32_t i) { return f2u(nodes[2u * i + 1u].w); };
+  const bool is_root = x + 1u == count;
+  if (!is_root && entry_of(x) >= HK_LEAF) return;  // a leaf (or a leaf's unused slot) has no record
+  float4 rec[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rec[2 * k] = make_float4(HK_F32_MAX, HK_F32_MAX, HK_F32_MAX, u2f(WIDE_NONE));
+    rec[2 * k + 1] = make_float4(-HK_F32_MAX, -HK_F32_MAX, -HK_F32_MAX, 0.0f);
+  }
+  int n = 0;
+  auto add = [&](uint32_t g) {  // box-node g becomes a child of the record
+    const float4 lo = nodes[2u * g], hi = nodes[2u * g + 1u];
+    const uint32_t e = f2u(lo.w);
+    const uint32_t link = e >= HK_LEAF ? e : g;
+    for (int k = 0; k < 4; ++k)
+      if (k == n) {
+        rec[2 * k] = make_float4(lo.x, lo.y, lo.z, u2f(link));
+        rec[2 * k + 1] = make_float4(hi.x, hi.y, hi.z, 0.0f);
+      }
+    n += 1;
+  };
+  // the children of this node: the box-nodes at `first` and at first's exit, inside [first, limit)
+  uint32_t first, limit;
+  if (is_root) {  // flatten_custom stores no node for the root: its children are the box-nodes at 0 and at 0's exit
+    first = 0u;
+    limit = count;
+  } else {
+    first = x + 1u;
+    limit = exit_of(x);
+  }
+  if (is_root && count == 1u) {
+    add(0u);  // a tree of one leaf
+  } else {
+    uint32_t c = first;
+    for (int side = 0; side < 2 && c < limit; ++side) {
+      if (entry_of(c) >= HK_LEAF) {
+        add(c);
+      } else {  // an inner child: its own children take its place
+        const uint32_t cl = exit_of(c);
+        uint32_t g = c + 1u;
+        for (int gs = 0; gs < 2 && g < cl; ++gs) {
+          add(g);
+          g = exit_of(g);
+        }
+      }
+      c = exit_of(c);
+    }
+  }
+  // (the root of a tree whose last slot is an inner node does not occur: the last node of a depth-first flattening is a leaf's)
+  float4* out = wide + 8u * (size_t)x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[k] = rec[k];
+}
+
+namespace {
+struct WideWalk {
+  f3 origin, direction, inv_direction;  // the world-space ray
+  float early_distance;
+  uint32_t exclude_instance;
+  Hit hit;
+  uint32_t cur;        // record to visit next (a slot of the current level's array), or WIDE_NONE: pop
+  uint32_t sp;         // stack entries
+  uint32_t mesh_base;  // slot of the current mesh tree's first node in WideTrees::blas
+  uint32_t prim_base, cur_instance;
+  bool in_blas, intersected;
+  f3 co, cinv, ld;     // origin / inverse direction of the level being walked, local direction inside a mesh tree
+};
+__device__ __forceinline__ void wide_push(WideWalk& k, uint32_t* lds, uint32_t* spill, uint32_t e) {
+  if (k.sp < HK_WIDE_LDS_STACK) lds[k.sp * 256u + threadIdx.x] = e;
+  else if (k.sp < HK_WIDE_LDS_STACK + HK_WIDE_SPILL) spill[(size_t)(k.sp - HK_WIDE_LDS_STACK) * gridDim.x * 256u + blockIdx.x * 256u + threadIdx.x] = e;
+  k.sp += 1u;  // (beyond LDS + spill - 128 entries, a tree some 80 levels deep - the entry is lost: counted by hk_debug in the tests)
+}
+__device__ __forceinline__ uint32_t wide_pop(WideWalk& k, const uint32_t* lds, const uint32_t* spill) {
+  k.sp -= 1u;
+  if (k.sp < HK_WIDE_LDS_STACK) return lds[k.sp * 256u + threadIdx.x];
+  if (k.sp < HK_WIDE_LDS_STACK + HK_WIDE_SPILL) return spill[(size_t)(k.sp - HK_WIDE_LDS_STACK) * gridDim.x * 256u + blockIdx.x * 256u + threadIdx.x];
+  return WIDE_NONE;
+}
+__device__ __forceinline__ void wide_begin(WideWalk& k, const WideTrees& wt, f3 origin, f3 direction, float max_distance, float early_distance, uint32_t exclude) {
+  k.origin = origin;
+  k.direction = direction;
+  k.inv_direction = 1.0f / direction;
+  k.early_distance = early_distance;
+  k.exclude_instance = exclude;
+  k.hit.uv = F2(0.0f, 0.0f);
+  k.hit.distance = max_distance;
+  k.hit.instance_index = HK_U32_MAX;
+  k.hit.primitive_index = HK_U32_MAX;
+  k.cur = wt.tlas_count - 1u;  // the root's record
+  k.sp = 0u;
+  k.mesh_base = 0u;
+  k.prim_base = 0u;
+  k.cur_instance = 0u;
+  k.in_blas = false;
+  k.intersected = false;
+  k.co = origin;
+  k.cinv = k.inv_direction;
+  k.ld = direction;
+}
+// One step: pop (if there is nothing to visit) and / or visit one record.  Returns the lane's next phase; `pending` = the leaf a
+// PH_TRI / PH_ENTRY lane is parked at.
+__device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, uint32_t* lds, uint32_t* spill, uint32_t& pending) {
+  if (k.cur == WIDE_NONE) {
+    if (k.sp == 0u) return PH_IDLE;
+    const uint32_t e = wide_pop(k, lds, spill);
+    if (e == WIDE_LEAVE) {  // traverse_bottom returned, light.wgsl:465-470
+      if (k.intersected) {
+        k.hit.instance_index = k.cur_instance;
+        if (k.hit.distance < k.early_distance) return PH_IDLE;
+      }
+      k.in_blas = false;
+      k.co = k.origin;
+      k.cinv = k.inv_direction;
+      return PH_NODE;
+    }
+    if (e == WIDE_NONE) return PH_NODE;
+    if (e >= HK_LEAF) {
+      pending = e - HK_LEAF;
+      if (k.in_blas) return PH_TRI;
+      return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
+    }
+    k.cur = e;
+  }
+  const float4* __restrict__ rec = (k.in_blas ? wt.blas + 8u * (size_t)(k.mesh_base + k.cur) : wt.tlas + 8u * (size_t)k.cur);
+  float t[4];
+  uint32_t link[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 lo = rec[2 * c], hi = rec[2 * c + 1];
+    const f3 t1 = (xyz(lo) - k.co) * k.cinv;  // intersects_aabb, light.wgsl:344-362
+    const f3 t2 = (xyz(hi) - k.co) * k.cinv;
+    float t_min = fmin_(t1.x, t2.x);
+    float t_max = fmax_(t1.x, t2.x);
+    t_min = fmax_(t_min, fmin_(t1.y, t2.y));
+    t_max = fmin_(t_max, fmax_(t1.y, t2.y));
+    t_min = fmax_(t_min, fmin_(t1.z, t2.z));
+    t_max = fmin_(t_max, fmax_(t1.z, t2.z));
+    const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
+    link[c] = f2u(lo.w);
+    t[c] = (link[c] != WIDE_NONE && t_box < k.hit.distance) ? t_box : HK_F32_MAX;
+    if (t[c] == HK_F32_MAX) link[c] = WIDE_NONE;
+  }
+  // nearest first: a 5-comparator network on (t, link), then the three farther ones go to the stack, farthest first
+#define HK_WIDE_CSWAP(a, b)                                  \
+  if (t[b] < t[a]) {                                         \
+    const float tt = t[a]; t[a] = t[b]; t[b] = tt;           \
+    const uint32_t ll = link[a]; link[a] = link[b]; link[b] = ll; \
+  }
+  HK_WIDE_CSWAP(0, 1) HK_WIDE_CSWAP(2, 3) HK_WIDE_CSWAP(0, 2) HK_WIDE_CSWAP(1, 3) HK_WIDE_CSWAP(1, 2)
+#undef HK_WIDE_CSWAP
+#pragma unroll
+  for (int c = 3; c >= 1; --c)
+    if (link[c] != WIDE_NONE) wide_push(k, lds, spill, link[c]);
+  k.cur = WIDE_NONE;
+  if (link[0] == WIDE_NONE) return PH_NODE;  // nothing hit: pop next turn
+  if (link[0] >= HK_LEAF) {
+    pending = link[0] - HK_LEAF;
+    if (k.in_blas) return PH_TRI;
+    return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
+  }
+  k.cur = link[0];
+  return PH_NODE;
+}
+__device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, uint32_t pending) {
+  const uint32_t primitive_index = k.prim_base + pending;
+  Ray lr;
+  lr.origin = k.co;
+  lr.direction = k.ld;
+  lr.inv_direction = k.cinv;
+  f2 uv;
+  const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+  if (d < k.hit.distance) {
+    k.hit.uv = uv;
+    k.hit.distance = d;
+    k.hit.primitive_index = primitive_index;
+    k.intersected = true;
+    if (d < k.early_distance) {  // light.wgsl:421-423 then 466-469
+      k.hit.instance_index = k.cur_instance;
+      return PH_IDLE;
+    }
+  }
+  return PH_NODE;
+}
+__device__ __forceinline__ void wide_enter(WideWalk& k, const DScene& sc, uint32_t* lds, uint32_t* spill, uint32_t instance_index) {
+  const DInstance& in = sc.instances[instance_index];
+  k.co = world_to_local_position(in, k.origin);
+  k.ld = world_to_local_direction(in, k.direction);
+  k.cinv = 1.0f / k.ld;
+  wide_push(k, lds, spill, WIDE_LEAVE);
+  k.mesh_base = in.node_offset;
+  k.cur = in.node_count - 1u;  // the mesh tree's root record
+  k.prim_base = in.primitive;
+  k.cur_instance = instance_index;
+  k.in_blas = true;
+  k.intersected = false;
+}
+}  // namespace
+
+#ifndef HK_WF_WIDE_WAVES
+#define HK_WF_WIDE_WAVES 4   // waves per SIMD the wide trace kernel is compiled for: 4 workgroups x 32 KB of stack per CU
+#endif
+// k_wf_trace with the wide walk: the same queue, the same refill, the same three phases - a NODE step is one record
+__global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene sc, WfBuffers w, WideTrees wt, uint32_t stage) {
+  __shared__ uint32_t stack_lds[HK_WIDE_LDS_STACK * 256u];
+  const uint32_t n_alive = w.ctr[WF_ALIVE + stage], tail = n_alive + w.ctr[WF_SHADOWS + stage];
+  const uint32_t* __restrict__ alive = w.alive[stage & 1u];
+  const uint32_t* __restrict__ shadow = w.shadow[stage & 1u];
+  uint32_t* head_ptr = &w.ctr[WF_QHEAD + stage];
+  const uint32_t all_lanes = gridDim.x * 256u;
+  uint32_t res_base = 0u, res_count = 0u;
+  bool exhausted = tail == 0u;
+  uint32_t phase = PH_IDLE, pending = 0u;
+  uint32_t entry_id = 0u;
+  WideWalk k;
+  wide_begin(k, wt, F3(0, 0, 0), F3(1, 1, 1), 0.0f, 0.0f, HK_DONT_EXCLUDE);
+  auto finish = [&]() {
+    const uint32_t slot = entry_id & ~WF_SHADOW;
+    if (entry_id & WF_SHADOW) {
+      w.sh[slot] = k.hit.instance_index;
+    } else {
+      w.ch0[slot] = make_float4(k.hit.distance, k.hit.uv.x, k.hit.uv.y, u2f(k.hit.primitive_index));
+      w.ch1[slot] = k.hit.instance_index;
+    }
+  };
+  for (;;) {
+    const unsigned long long idle_mask = __ballot(phase == PH_IDLE);
+    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+    const bool dry = exhausted && res_count == 0u;
+    if (dry && n_idle == 64u) break;
+    if (!dry && (n_idle >= HK_WF_REFILL_MIN || n_idle == 64u)) {
+      const bool idle = phase == PH_IDLE;
+      const uint32_t rank = lane_rank(idle_mask);
+      uint32_t mine = HK_U32_MAX;
+      uint32_t given = 0u;
+      if (res_count < n_idle && !exhausted) {
+        given = res_count;
+        if (idle && rank < given) mine = res_base + rank;
+        const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : 64u;
+        uint32_t b = 0u;
+        if ((threadIdx.x & 63u) == 0u) b = atomicAdd(head_ptr, block);
+        b = __builtin_amdgcn_readfirstlane(b);
+        res_base = b;
+        res_count = b < tail ? min(block, tail - b) : 0u;
+        if (b + block >= tail) exhausted = true;
+      }
+      if (idle && rank >= given && rank - given < res_count) mine = res_base + (rank - given);
+      const uint32_t used = min(n_idle - given, res_count);
+      res_base += used;
+      res_count -= used;
+      if (mine != HK_U32_MAX) {
+        entry_id = mine < n_alive ? alive[mine] : (shadow[mine - n_alive] | WF_SHADOW);
+        const uint32_t slot = entry_id & ~WF_SHADOW;
+        if (entry_id & WF_SHADOW) {
+          const float4 a = w.sr0[slot], b4 = w.sr1[slot];
+          wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), a.w, b4.w, w.sr2[slot]);
+        } else {
+          const float4 a = w.cr0[slot], b4 = w.cr1[slot];
+          wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE);
+        }
+        phase = PH_NODE;
+      }
+    }
+    const uint32_t n_node = (uint32_t)__popcll(__ballot(phase == PH_NODE));
+    const uint32_t n_tri = (uint32_t)__popcll(__ballot(phase == PH_TRI));
+    const uint32_t n_entry = (uint32_t)__popcll(__ballot(phase == PH_ENTRY));
+    if (n_node >= n_tri && n_node >= n_entry && n_node != 0u) {
+#pragma unroll 1
+      for (int s = 0; s < 2; ++s) {
+        if (phase == PH_NODE) {
+          phase = wide_node(k, wt, stack_lds, wt.spill, pending);
+          if (phase == PH_IDLE) finish();
+        }
+      }
+    } else if (n_tri >= n_entry) {
+      if (phase == PH_TRI) {
+        phase = wide_triangle(k, sc, pending);
+        if (phase == PH_IDLE) finish();
+      }
+    } else {
+      if (phase == PH_ENTRY) {
+        wide_enter(k, sc, stack_lds, wt.spill, pending);
+        phase = PH_NODE;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ shade: bounce n of every live path
 #ifndef HK_WF_SHADE_WAVES
 #define HK_WF_SHADE_WAVES 4
@@ -586,8 +898,12 @@ __global__ __launch_bounds__(256, 4) void k_wf_final(DScene sc, DFrame fr, GBuff
 namespace hk {
 using namespace hkd;
 
+void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide) {
+  if (count) hipLaunchKernelGGL(k_build_wide, dim3((count + 255u) / 256u), dim3(256), 0, st, nodes, count, wide);
+}
+
 void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,
-                               int y1, int compute_units, hipEvent_t start, hipEvent_t stop) {
+                               int y1, int compute_units, hipEvent_t start, hipEvent_t stop, const WideTrees* wide) {
   if (y1 <= y0) return;
   (void)hipMemsetAsync(w.ctr, 0, 192 * sizeof(uint32_t), st);
   if (w.timeline) (void)hipMemsetAsync(w.timeline, 0, 64 * 32 * sizeof(unsigned long long), st);
@@ -601,7 +917,8 @@ void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& f
   const dim3 tracers((unsigned)(compute_units * trace_wg_per_cu));
   const uint32_t bounces = fr.indirect_bounces;
   for (uint32_t n = 0; n <= bounces; ++n) {
-    if (w.timeline && !lds) hipLaunchKernelGGL((k_wf_trace<false, true>), tracers, dim3(256), 0, st, sc, w, n);
+    if (wide && wide->tlas && !lds && !w.timeline) hipLaunchKernelGGL(k_wf_trace_wide, dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, *wide, n);
+    else if (w.timeline && !lds) hipLaunchKernelGGL((k_wf_trace<false, true>), tracers, dim3(256), 0, st, sc, w, n);
     else if (lds) hipLaunchKernelGGL((k_wf_trace<true, false>), tracers, dim3(256), lds, st, sc, w, n);
     else hipLaunchKernelGGL((k_wf_trace<false, false>), tracers, dim3(256), 0, st, sc, w, n);
     if (n == bounces) break;

@@ -618,6 +618,8 @@ int finalize_scene(hk_ctx* c) {
   c->mesh_dirty = c->dynamic_dirty = false;
   c->static_rebuilds += need_static ? 1 : 0;
   c->dynamic_rebuilds += 1;
+  c->wide_tlas_dirty = true;                       // (the wide records follow the trees: context.hip ensure_wide)
+  if (need_static) c->wide_blas_dirty = true;
   return HK_OK;
 }
 

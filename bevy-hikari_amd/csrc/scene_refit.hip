@@ -176,6 +176,7 @@ int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
     HK_REQUIRE(launch_tree_build(c->stream, build, true, r, ne, nullptr, nullptr, c->lbvh_scratch, (float4*)(base + c->dyn_off.light_lo), (float4*)(base + c->dyn_off.light_hi),
                                  1u, 1u) == 0, HK_E_HIP, "device build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
   c->mirrors_stale = true;
+  c->wide_tlas_dirty = true;
   c->device_tree_builds += 1;
   return HK_OK;
 }
@@ -322,6 +323,7 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
   c->d_prev_models = c->rf_prev_models;
   c->rf_last_moved = moved;
   c->mirrors_stale = true;
+  c->wide_tlas_dirty = true;
   c->device_refits += 1;
   if (commit) builder_commit_transforms(b);
   return HK_OK;
