@@ -375,7 +375,7 @@ bool use_wide(const hk_ctx* c) {
   return !off && c->threaded && !c->wf.timeline && !c->scene.flat_mode;
 }
 // records of the trees the next trace stages walk, (re)derived from what the scene blob holds now
-int ensure_wide(hk_ctx* c) {
+int ensure_wide(hk_ctx* c, bool with_spill) {
   const size_t tlas_slots = c->instance_nodes.size(), blas_slots = c->asset_nodes.size();
   if (tlas_slots == 0 || blas_slots == 0) return HK_OK;
   if (tlas_slots > c->wide_tlas_slots) {
@@ -395,7 +395,7 @@ int ensure_wide(hk_ctx* c) {
     HK_HIP(hipGetDeviceProperties(&prop, c->device));
     c->compute_units = prop.multiProcessorCount;
   }
-  const size_t lanes = (size_t)c->compute_units * 4 * 256;  // HK_WF_WIDE_WAVES workgroups per CU
+  const size_t lanes = with_spill ? (size_t)c->compute_units * 4 * 256 : 0;  // HK_WF_WIDE_WAVES workgroups per CU
   if (lanes > c->wide_spill_lanes) {
     if (c->wide_spill) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_spill); c->wide_spill = nullptr; }
     HK_HIP(hipMalloc((void**)&c->wide_spill, lanes * 96 * sizeof(uint32_t)));  // HK_WIDE_SPILL entries per lane
@@ -419,6 +419,19 @@ int ensure_wide(hk_ctx* c) {
     HK_HIP(hipGetLastError());
     c->wide_tlas_dirty = false;
   }
+  return HK_OK;
+}
+// the records for a fused kernel's walks (the primary rays): scenes in global memory with threaded trees, i.e. the product default
+int wide_for_fused(hk_ctx* c, hkd::WideTrees* out) {
+  static const bool off = getenv("HK_NO_WIDE_WALK") != nullptr || getenv("HK_NO_WIDE_PREPASS") != nullptr;
+  *out = hkd::WideTrees{};
+  if (off || !c->threaded || c->scene.flat_mode) return HK_OK;
+  const int rc = ensure_wide(c, false);
+  if (rc) return rc;
+  out->tlas = c->wide_tlas;
+  out->blas = c->wide_blas;
+  out->tlas_count = c->scene.tlas_count;
+  out->spill = nullptr;
   return HK_OK;
 }
 // the scratch of the queue-based schedule: allocated on first use for the current render size
@@ -498,7 +511,9 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
   switch (pass) {
     case HK_PASS_PREPASS: {
       Jitter j = prepass_jitter(c);
-      launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, y0, y1, counters);
+      hkd::WideTrees wide{};
+      { const int rc_ = wide_for_fused(c, &wide); if (rc_) return rc_; }
+      launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, y0, y1, counters, &wide);
       break;
     }
     case HK_PASS_FULL_SCREEN_ALBEDO: launch_albedo(c->stream, c->scene, fr, g, c->buf[HK_BUF_ALBEDO], y0, y1); break;
@@ -520,7 +535,7 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
         { const int rc_ = ensure_wavefront(c); if (rc_) return rc_; }
         hkd::WideTrees wide{};
         if (use_wide(c)) {
-          { const int rc_ = ensure_wide(c); if (rc_) return rc_; }
+          { const int rc_ = ensure_wide(c, true); if (rc_) return rc_; }
           wide.tlas = c->wide_tlas;
           wide.blas = c->wide_blas;
           wide.tlas_count = c->scene.tlas_count;
@@ -1050,7 +1065,9 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
         unsigned long long* counters = (c->flags & HK_CTX_COUNT_RAYS) ? c->d_counters : nullptr;
         const Jitter j = prepass_jitter(c);
         ScopedTimer timer(c, HK_PASS_PREPASS);
-        launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters);
+        hkd::WideTrees wide{};
+        if ((rc = wide_for_fused(c, &wide))) return rc;
+        launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
         HK_HIP(hipGetLastError());
         albedo_done = true;
       }

@@ -77,7 +77,8 @@ struct WfBuffers {
   // [4] waves, [5] most node steps of one ray, [6] node steps, [7] rays, [8..23] rays by floor(log2(node steps + 1))
   unsigned long long* timeline;
 };
-// Wide trees for the queue-based trace stage (round 4; kernels_wavefront.hip k_build_wide / k_wf_trace_wide; DESIGN 4 "Wide walk").
+// Wide trees for the queue-based trace stage and the primary rays of scenes in global memory (round 4; kernels_wavefront.hip
+// k_build_wide / k_wf_trace_wide, kernels.hip k_prepass<*, 4>, hk_wide.hpp; DESIGN 4 "Wide walk").
 // One 128-B record per INNER node of a flatten_custom tree, at the node's own position in a parallel array: the boxes and links
 // of its (up to four) grandchildren - four 32-B box-nodes, lo = (min.xyz, link), hi = (max.xyz, -).  link: HK_LEAF | id = a leaf
 // (triangle of the mesh / instance), < HK_LEAF = position of an inner node (its record), 0xFFFFFFFF = no child.  The record of a
@@ -87,7 +88,8 @@ struct WideTrees {
   const float4* tlas;   // records of the instance tree: 8 float4 per slot, tlas_count slots
   const float4* blas;   // records of every mesh tree: slot node_offset + local position
   uint32_t tlas_count;  // (its root: slot tlas_count - 1)
-  uint32_t* spill;      // stack entries beyond the LDS part: HK_WIDE_SPILL u32 per lane of the persistent launch
+  uint32_t* spill;      // stack entries beyond the LDS part: HK_WIDE_SPILL u32 per lane of the persistent launch (the trace stage;
+                        // nullptr where only the prepass - whose lanes keep the rest in private memory - walks them)
 };
 // Instance motion on the device (kernels_scene.hip): the arrays of the instance-level region the refit kernels rewrite, plus
 // the refit's own side arrays.
@@ -262,7 +264,7 @@ static inline dim3 grid_for(int width, int rows) {
 
 void launch_prepass(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const float* inverse_view_proj, const float* view_proj,
                     const float* prev_view_proj, const float4* prev_models, float jitter_x, float jitter_y, const hkd::GBuffer& g, int y0, int y1,
-                    unsigned long long* counters);
+                    unsigned long long* counters, const hkd::WideTrees* wide = nullptr);
 void launch_albedo(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, void* albedo, int y0, int y1);
 void launch_direct(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                    int y0, int y1, unsigned long long* counters);

@@ -19,7 +19,7 @@ namespace hkd {
 // bits).  (bool converts: true = 1, false = 0.)  The walk is a compile-time constant of the instantiation.
 template <int MODE>
 __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
-  if constexpr (MODE == 0 || MODE == 3) {
+  if constexpr (MODE == 0 || MODE == 3 || MODE == 4) {  // (4: global memory, the wide walk - a prepass instantiation of its own, so that the skip-link one carries no stack)
     DScene g = sc;
     g.flat_mode = MODE == 3 ? 1u : 0u;
     return g;

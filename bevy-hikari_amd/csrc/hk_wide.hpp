@@ -1,0 +1,226 @@
+// hk_wide.hpp - the wide walk (round 4; DESIGN 4 "Wide walk", 8.1): BVH traversal over 128-B records of an inner node's four
+// grandchildren (hk_kernels.hpp WideTrees, built by kernels_wavefront.hip k_build_wide), nearest child first, with a per-lane stack.
+// Shared by the queue-based trace stage (k_wf_trace_wide) and the fused kernels' walks of scenes in global memory
+// (traverse_top_wide).  Same candidates and the same per-triangle arithmetic on the same operands as traverse_top (hk_device.hpp):
+// the closest hit is the reference's except where two candidates tie exactly; an any-hit ray's outcome does not depend on the
+// order.  The reference's order (HK_CTX_EXACT_TRAVERSAL) never comes here.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hk_device.hpp"
+#include "hk_kernels.hpp"
+
+namespace hkd {
+
+#ifndef HK_WIDE_LDS_STACK
+#define HK_WIDE_LDS_STACK 32u
+#endif
+#ifndef HK_WIDE_SPILL
+#define HK_WIDE_SPILL 96u
+#endif
+
+constexpr uint32_t WIDE_NONE = 0xFFFFFFFFu;      // no child / nothing to visit
+constexpr uint32_t WIDE_LEAVE = 0xFFFFFFFEu;     // stack marker: the mesh tree below this entry is done, back to the instance tree
+enum : uint32_t { PH_IDLE = 0u, PH_NODE = 1u, PH_TRI = 2u, PH_ENTRY = 3u };  // what a lane of a walk waits for (kernels_wavefront.hip)
+
+struct WideWalk {
+  f3 origin, direction, inv_direction;  // the world-space ray
+  float early_distance;
+  uint32_t exclude_instance;
+  Hit hit;
+  uint32_t cur;        // record to visit next (a slot of the current level's array), or WIDE_NONE: pop
+  uint32_t sp;         // stack entries
+  uint32_t mesh_base;  // slot of the current mesh tree's first node in WideTrees::blas
+  uint32_t prim_base, cur_instance;
+  bool in_blas, intersected;
+  f3 co, cinv, ld;     // origin / inverse direction of the level being walked, local direction inside a mesh tree
+};
+// Where a lane's pending children wait.  The first HK_WIDE_LDS_STACK entries: LDS, entry-major (address = entry x 256 + thread: no bank
+// conflicts).  Beyond: a global spill area indexed by the lane of a PERSISTENT launch (the trace kernel), or a small private array
+// (the fused kernels: their grids are as large as the image).  Entries beyond both are lost - a tree some eighty levels deep.
+struct WideStackSpill {
+  uint32_t* lds;
+  uint32_t* spill;
+  size_t stride, lane;  // spill[(entry - HK_WIDE_LDS_STACK) x stride + lane]
+  __device__ __forceinline__ void put(uint32_t at, uint32_t e) {
+    if (at < HK_WIDE_LDS_STACK) lds[at * 256u + threadIdx.x] = e;
+    else if (at < HK_WIDE_LDS_STACK + HK_WIDE_SPILL) spill[(size_t)(at - HK_WIDE_LDS_STACK) * stride + lane] = e;
+  }
+  __device__ __forceinline__ uint32_t get(uint32_t at) const {
+    if (at < HK_WIDE_LDS_STACK) return lds[at * 256u + threadIdx.x];
+    if (at < HK_WIDE_LDS_STACK + HK_WIDE_SPILL) return spill[(size_t)(at - HK_WIDE_LDS_STACK) * stride + lane];
+    return WIDE_NONE;
+  }
+};
+template <uint32_t LDS_ENTRIES, uint32_t PRIVATE_ENTRIES>
+struct WideStackPrivate {
+  uint32_t* lds;
+  uint32_t priv[PRIVATE_ENTRIES];
+  __device__ __forceinline__ void put(uint32_t at, uint32_t e) {
+    if (at < LDS_ENTRIES) lds[at * 256u + threadIdx.x] = e;
+    else if (at < LDS_ENTRIES + PRIVATE_ENTRIES) priv[at - LDS_ENTRIES] = e;
+  }
+  __device__ __forceinline__ uint32_t get(uint32_t at) const {
+    if (at < LDS_ENTRIES) return lds[at * 256u + threadIdx.x];
+    if (at < LDS_ENTRIES + PRIVATE_ENTRIES) return priv[at - LDS_ENTRIES];
+    return WIDE_NONE;
+  }
+};
+template <class S>
+__device__ __forceinline__ void wide_push(WideWalk& k, S& st, uint32_t e) {
+  st.put(k.sp, e);
+  k.sp += 1u;
+}
+template <class S>
+__device__ __forceinline__ uint32_t wide_pop(WideWalk& k, S& st) {
+  k.sp -= 1u;
+  return st.get(k.sp);
+}
+__device__ __forceinline__ void wide_begin(WideWalk& k, const WideTrees& wt, f3 origin, f3 direction, float max_distance, float early_distance, uint32_t exclude) {
+  k.origin = origin;
+  k.direction = direction;
+  k.inv_direction = 1.0f / direction;
+  k.early_distance = early_distance;
+  k.exclude_instance = exclude;
+  k.hit.uv = F2(0.0f, 0.0f);
+  k.hit.distance = max_distance;
+  k.hit.instance_index = HK_U32_MAX;
+  k.hit.primitive_index = HK_U32_MAX;
+  k.cur = wt.tlas_count - 1u;  // the root's record
+  k.sp = 0u;
+  k.mesh_base = 0u;
+  k.prim_base = 0u;
+  k.cur_instance = 0u;
+  k.in_blas = false;
+  k.intersected = false;
+  k.co = origin;
+  k.cinv = k.inv_direction;
+  k.ld = direction;
+}
+// One step: pop (if there is nothing to visit) and / or visit one record.  Returns the lane's next phase; `pending` = the leaf a
+// PH_TRI / PH_ENTRY lane is parked at.
+template <class S>
+__device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, S& st, uint32_t& pending) {
+  if (k.cur == WIDE_NONE) {
+    if (k.sp == 0u) return PH_IDLE;
+    const uint32_t e = wide_pop(k, st);
+    if (e == WIDE_LEAVE) {  // traverse_bottom returned, light.wgsl:465-470
+      if (k.intersected) {
+        k.hit.instance_index = k.cur_instance;
+        if (k.hit.distance < k.early_distance) return PH_IDLE;
+      }
+      k.in_blas = false;
+      k.co = k.origin;
+      k.cinv = k.inv_direction;
+      return PH_NODE;
+    }
+    if (e == WIDE_NONE) return PH_NODE;
+    if (e >= HK_LEAF) {
+      pending = e - HK_LEAF;
+      if (k.in_blas) return PH_TRI;
+      return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
+    }
+    k.cur = e;
+  }
+  const float4* __restrict__ rec = (k.in_blas ? wt.blas + 8u * (size_t)(k.mesh_base + k.cur) : wt.tlas + 8u * (size_t)k.cur);
+  float t[4];
+  uint32_t link[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 lo = rec[2 * c], hi = rec[2 * c + 1];
+    const f3 t1 = (xyz(lo) - k.co) * k.cinv;  // intersects_aabb, light.wgsl:344-362
+    const f3 t2 = (xyz(hi) - k.co) * k.cinv;
+    float t_min = fmin_(t1.x, t2.x);
+    float t_max = fmax_(t1.x, t2.x);
+    t_min = fmax_(t_min, fmin_(t1.y, t2.y));
+    t_max = fmin_(t_max, fmax_(t1.y, t2.y));
+    t_min = fmax_(t_min, fmin_(t1.z, t2.z));
+    t_max = fmin_(t_max, fmax_(t1.z, t2.z));
+    const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
+    link[c] = f2u(lo.w);
+    t[c] = (link[c] != WIDE_NONE && t_box < k.hit.distance) ? t_box : HK_F32_MAX;
+    if (t[c] == HK_F32_MAX) link[c] = WIDE_NONE;
+  }
+  // nearest first: a 5-comparator network on (t, link), then the three farther ones go to the stack, farthest first
+#define HK_WIDE_CSWAP(a, b)                                  \
+  if (t[b] < t[a]) {                                         \
+    const float tt = t[a]; t[a] = t[b]; t[b] = tt;           \
+    const uint32_t ll = link[a]; link[a] = link[b]; link[b] = ll; \
+  }
+  HK_WIDE_CSWAP(0, 1) HK_WIDE_CSWAP(2, 3) HK_WIDE_CSWAP(0, 2) HK_WIDE_CSWAP(1, 3) HK_WIDE_CSWAP(1, 2)
+#undef HK_WIDE_CSWAP
+#pragma unroll
+  for (int c = 3; c >= 1; --c)
+    if (link[c] != WIDE_NONE) wide_push(k, st, link[c]);
+  k.cur = WIDE_NONE;
+  if (link[0] == WIDE_NONE) return PH_NODE;  // nothing hit: pop next turn
+  if (link[0] >= HK_LEAF) {
+    pending = link[0] - HK_LEAF;
+    if (k.in_blas) return PH_TRI;
+    return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
+  }
+  k.cur = link[0];
+  return PH_NODE;
+}
+__device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, uint32_t pending) {
+  const uint32_t primitive_index = k.prim_base + pending;
+  Ray lr;
+  lr.origin = k.co;
+  lr.direction = k.ld;
+  lr.inv_direction = k.cinv;
+  f2 uv;
+  const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+  if (d < k.hit.distance) {
+    k.hit.uv = uv;
+    k.hit.distance = d;
+    k.hit.primitive_index = primitive_index;
+    k.intersected = true;
+    if (d < k.early_distance) {  // light.wgsl:421-423 then 466-469
+      k.hit.instance_index = k.cur_instance;
+      return PH_IDLE;
+    }
+  }
+  return PH_NODE;
+}
+template <class S>
+__device__ __forceinline__ void wide_enter(WideWalk& k, const DScene& sc, S& st, uint32_t instance_index) {
+  const DInstance& in = sc.instances[instance_index];
+  k.co = world_to_local_position(in, k.origin);
+  k.ld = world_to_local_direction(in, k.direction);
+  k.cinv = 1.0f / k.ld;
+  wide_push(k, st, WIDE_LEAVE);
+  k.mesh_base = in.node_offset;
+  k.cur = in.node_count - 1u;  // the mesh tree's root record
+  k.prim_base = in.primitive;
+  k.cur_instance = instance_index;
+  k.in_blas = true;
+  k.intersected = false;
+}
+
+// The whole walk for one ray per lane, in lock step (the fused kernels): every turn each live lane visits one record or pops; the
+// triangle tests and instance entries of the lanes that reached a leaf follow in the same turn.
+template <class S>
+__device__ __forceinline__ Hit traverse_top_wide(const DScene& sc, const WideTrees& wt, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance,
+                                                  S& st, RayCounters& rc) {
+  rc.tlas++;
+  WideWalk k;
+  wide_begin(k, wt, ray.origin, ray.direction, max_distance, early_distance, exclude_instance);
+  uint32_t phase = PH_NODE, pending = 0u;
+  while (phase != PH_IDLE) {
+    if (phase == PH_NODE) {
+      rc.nodes++;
+      phase = wide_node(k, wt, st, pending);
+    }
+    if (phase == PH_TRI) {
+      rc.tris++;
+      phase = wide_triangle(k, sc, pending);
+    } else if (phase == PH_ENTRY) {
+      rc.entries++;
+      wide_enter(k, sc, st, pending);
+      phase = PH_NODE;
+    }
+  }
+  return k.hit;
+}
+
+}  // namespace hkd

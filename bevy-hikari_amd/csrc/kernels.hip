@@ -27,6 +27,7 @@
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 #include "hk_light.hpp"
+#include "hk_wide.hpp"
 
 namespace hkd {
 
@@ -55,6 +56,7 @@ struct PrepassParams {
   float4 pvp0, pvp1, pvp2, pvp3;  // previous view_proj columns
   float jitter_x, jitter_y;       // NDC shift of the geometry (prepass.wgsl:52-54,71)
   const float4* prev_models;      // previous model matrix (4 columns) per instance, read where DInstance::moved
+  WideTrees wide;                 // scenes in global memory, product default: the records of the wide walk (tlas == nullptr: the skip-link walk)
 };
 __device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams& pp, float px, float py) {
   const float ux = fr.uv_fast ? div_by(px + 0.5f, (float)fr.dw, fr.inv_dw) : (px + 0.5f) / (float)fr.dw;
@@ -100,10 +102,20 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
     if (px.valid) wray = primary_ray(fr, pp, (float)px.x, (float)px.y);
     whit = traverse_top_wave(sc, wray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, px.valid, rc);
   }
+  __shared__ uint32_t wide_lds[LDS == 4 ? HK_WIDE_LDS_STACK * 256u : 1u];
   if (px.valid) {
     const int idx = px.x + fr.dw * px.y;
     Ray ray = WAVE_WALK ? wray : primary_ray(fr, pp, (float)px.x, (float)px.y);
-    Hit hit = WAVE_WALK ? whit : traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+    Hit hit;
+    if (WAVE_WALK) {
+      hit = whit;
+    } else if (LDS == 4) {  // scenes in global memory, product default: the wide walk (hk_wide.hpp)
+      WideStackPrivate<HK_WIDE_LDS_STACK, 32u> stack;
+      stack.lds = wide_lds;
+      hit = traverse_top_wide(sc, pp.wide, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, stack, rc);
+    } else {
+      hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+    }
     rc.tlas = 0;  // counted as a primary ray
     primary = 1;
     rc.hits += hit.instance_index != HK_U32_MAX ? 1u : 0u;
@@ -914,10 +926,11 @@ static inline size_t lds_bytes_for(const DScene& sc) { return (size_t)sc.blob_f4
 
 void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj,
                     const float* prev_view_proj, const float4* prev_models, float jitter_x, float jitter_y, const GBuffer& g, int y0, int y1,
-                    unsigned long long* counters) {
+                    unsigned long long* counters, const WideTrees* wide) {
   if (y1 <= y0) return;
   PrepassParams pp;
   pp.prev_models = prev_models;
+  pp.wide = wide ? *wide : WideTrees{};
   auto col = [](const float* m, int c) { return make_float4(m[4 * c], m[4 * c + 1], m[4 * c + 2], m[4 * c + 3]); };
   pp.ivp0 = col(inverse_view_proj, 0); pp.ivp1 = col(inverse_view_proj, 1); pp.ivp2 = col(inverse_view_proj, 2); pp.ivp3 = col(inverse_view_proj, 3);
   pp.vp0 = col(view_proj, 0); pp.vp1 = col(view_proj, 1); pp.vp2 = col(view_proj, 2); pp.vp3 = col(view_proj, 3);
@@ -930,12 +943,16 @@ void launch_prepass(hipStream_t st, const DScene& sc, const DFrame& fr, const fl
   const bool flat = sc.flat_mode != 0u && lds;
   if (counters && flat)
     hipLaunchKernelGGL((k_prepass<true, 3>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
+  else if (counters && pp.wide.tlas)
+    hipLaunchKernelGGL((k_prepass<true, 4>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
   else if (counters)
     hipLaunchKernelGGL((k_prepass<true, 0>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
   else if (flat)
     hipLaunchKernelGGL((k_prepass<false, 2>), grid, dim3(256), lds, st, sc, fr, pp, g, y0, y1, counters);
   else if (lds)
     hipLaunchKernelGGL((k_prepass<false, 1>), grid, dim3(256), lds, st, sc, fr, pp, g, y0, y1, counters);
+  else if (pp.wide.tlas)
+    hipLaunchKernelGGL((k_prepass<false, 4>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
   else
     hipLaunchKernelGGL((k_prepass<false, 0>), grid, dim3(256), 0, st, sc, fr, pp, g, y0, y1, counters);
 }

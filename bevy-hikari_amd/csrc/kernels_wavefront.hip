@@ -36,6 +36,7 @@
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 #include "hk_light.hpp"
+#include "hk_wide.hpp"
 
 namespace hkd {
 
@@ -202,7 +203,7 @@ __device__ __forceinline__ void walk_begin(Walk& k, const DScene& sc, f3 origin,
 // so refilled lanes alone leave the wave at ~16 % lane utilisation (measured, config 3).  Here a lane that reaches a hit leaf
 // PARKS with the leaf in `pending`; the wave runs whichever of the three phases has the most lanes waiting, so triangle tests
 // and entries execute with many lanes at once.  A lane's own sequence of steps - and with it every result bit - is unchanged.
-enum : uint32_t { PH_IDLE = 0u, PH_NODE = 1u, PH_TRI = 2u, PH_ENTRY = 3u };
+// (the phases PH_IDLE / PH_NODE / PH_TRI / PH_ENTRY: hk_wide.hpp)
 // NODE step; returns the lane's next phase (PH_IDLE: the walk has ended, k.hit is the result)
 __device__ __forceinline__ uint32_t walk_node(Walk& k, const DScene& sc, uint32_t& pending) {
   if (k.index >= k.limit) {
@@ -441,15 +442,6 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
 // conflict-free), the rest in a global spill area.  Same candidates, same per-triangle arithmetic on the same operands as
 // traverse_top: the closest hit is the reference's except where two candidates tie exactly (the product default's bar, like the
 // threaded orderings); an any-hit ray's outcome - occluded or not - does not depend on the order at all.
-#ifndef HK_WIDE_LDS_STACK
-#define HK_WIDE_LDS_STACK 32u
-#endif
-#ifndef HK_WIDE_SPILL
-#define HK_WIDE_SPILL 96u
-#endif
-constexpr uint32_t WIDE_NONE = 0xFFFFFFFFu;      // no child / nothing to visit
-constexpr uint32_t WIDE_LEAVE = 0xFFFFFFFEu;     // stack marker: the mesh tree below this entry is done, back to the instance tree
-
 // one thread per slot of ONE tree (ordering 0; links local to the tree): the record of the inner node at that slot, and - in the
 // last slot - the root's
 __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ nodes, uint32_t count, float4* __restrict__ wide) {
@@ -510,156 +502,16 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
   for (int k = 0; k < 8; ++k) out[k] = rec[k];
 }
 
-namespace {
-struct WideWalk {
-  f3 origin, direction, inv_direction;  // the world-space ray
-  float early_distance;
-  uint32_t exclude_instance;
-  Hit hit;
-  uint32_t cur;        // record to visit next (a slot of the current level's array), or WIDE_NONE: pop
-  uint32_t sp;         // stack entries
-  uint32_t mesh_base;  // slot of the current mesh tree's first node in WideTrees::blas
-  uint32_t prim_base, cur_instance;
-  bool in_blas, intersected;
-  f3 co, cinv, ld;     // origin / inverse direction of the level being walked, local direction inside a mesh tree
-};
-__device__ __forceinline__ void wide_push(WideWalk& k, uint32_t* lds, uint32_t* spill, uint32_t e) {
-  if (k.sp < HK_WIDE_LDS_STACK) lds[k.sp * 256u + threadIdx.x] = e;
-  else if (k.sp < HK_WIDE_LDS_STACK + HK_WIDE_SPILL) spill[(size_t)(k.sp - HK_WIDE_LDS_STACK) * gridDim.x * 256u + blockIdx.x * 256u + threadIdx.x] = e;
-  k.sp += 1u;  // (beyond LDS + spill - 128 entries, a tree some 80 levels deep - the entry is lost: counted by hk_debug in the tests)
-}
-__device__ __forceinline__ uint32_t wide_pop(WideWalk& k, const uint32_t* lds, const uint32_t* spill) {
-  k.sp -= 1u;
-  if (k.sp < HK_WIDE_LDS_STACK) return lds[k.sp * 256u + threadIdx.x];
-  if (k.sp < HK_WIDE_LDS_STACK + HK_WIDE_SPILL) return spill[(size_t)(k.sp - HK_WIDE_LDS_STACK) * gridDim.x * 256u + blockIdx.x * 256u + threadIdx.x];
-  return WIDE_NONE;
-}
-__device__ __forceinline__ void wide_begin(WideWalk& k, const WideTrees& wt, f3 origin, f3 direction, float max_distance, float early_distance, uint32_t exclude) {
-  k.origin = origin;
-  k.direction = direction;
-  k.inv_direction = 1.0f / direction;
-  k.early_distance = early_distance;
-  k.exclude_instance = exclude;
-  k.hit.uv = F2(0.0f, 0.0f);
-  k.hit.distance = max_distance;
-  k.hit.instance_index = HK_U32_MAX;
-  k.hit.primitive_index = HK_U32_MAX;
-  k.cur = wt.tlas_count - 1u;  // the root's record
-  k.sp = 0u;
-  k.mesh_base = 0u;
-  k.prim_base = 0u;
-  k.cur_instance = 0u;
-  k.in_blas = false;
-  k.intersected = false;
-  k.co = origin;
-  k.cinv = k.inv_direction;
-  k.ld = direction;
-}
-// One step: pop (if there is nothing to visit) and / or visit one record.  Returns the lane's next phase; `pending` = the leaf a
-// PH_TRI / PH_ENTRY lane is parked at.
-__device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, uint32_t* lds, uint32_t* spill, uint32_t& pending) {
-  if (k.cur == WIDE_NONE) {
-    if (k.sp == 0u) return PH_IDLE;
-    const uint32_t e = wide_pop(k, lds, spill);
-    if (e == WIDE_LEAVE) {  // traverse_bottom returned, light.wgsl:465-470
-      if (k.intersected) {
-        k.hit.instance_index = k.cur_instance;
-        if (k.hit.distance < k.early_distance) return PH_IDLE;
-      }
-      k.in_blas = false;
-      k.co = k.origin;
-      k.cinv = k.inv_direction;
-      return PH_NODE;
-    }
-    if (e == WIDE_NONE) return PH_NODE;
-    if (e >= HK_LEAF) {
-      pending = e - HK_LEAF;
-      if (k.in_blas) return PH_TRI;
-      return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
-    }
-    k.cur = e;
-  }
-  const float4* __restrict__ rec = (k.in_blas ? wt.blas + 8u * (size_t)(k.mesh_base + k.cur) : wt.tlas + 8u * (size_t)k.cur);
-  float t[4];
-  uint32_t link[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float4 lo = rec[2 * c], hi = rec[2 * c + 1];
-    const f3 t1 = (xyz(lo) - k.co) * k.cinv;  // intersects_aabb, light.wgsl:344-362
-    const f3 t2 = (xyz(hi) - k.co) * k.cinv;
-    float t_min = fmin_(t1.x, t2.x);
-    float t_max = fmax_(t1.x, t2.x);
-    t_min = fmax_(t_min, fmin_(t1.y, t2.y));
-    t_max = fmin_(t_max, fmax_(t1.y, t2.y));
-    t_min = fmax_(t_min, fmin_(t1.z, t2.z));
-    t_max = fmin_(t_max, fmax_(t1.z, t2.z));
-    const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
-    link[c] = f2u(lo.w);
-    t[c] = (link[c] != WIDE_NONE && t_box < k.hit.distance) ? t_box : HK_F32_MAX;
-    if (t[c] == HK_F32_MAX) link[c] = WIDE_NONE;
-  }
-  // nearest first: a 5-comparator network on (t, link), then the three farther ones go to the stack, farthest first
-#define HK_WIDE_CSWAP(a, b)                                  \
-  if (t[b] < t[a]) {                                         \
-    const float tt = t[a]; t[a] = t[b]; t[b] = tt;           \
-    const uint32_t ll = link[a]; link[a] = link[b]; link[b] = ll; \
-  }
-  HK_WIDE_CSWAP(0, 1) HK_WIDE_CSWAP(2, 3) HK_WIDE_CSWAP(0, 2) HK_WIDE_CSWAP(1, 3) HK_WIDE_CSWAP(1, 2)
-#undef HK_WIDE_CSWAP
-#pragma unroll
-  for (int c = 3; c >= 1; --c)
-    if (link[c] != WIDE_NONE) wide_push(k, lds, spill, link[c]);
-  k.cur = WIDE_NONE;
-  if (link[0] == WIDE_NONE) return PH_NODE;  // nothing hit: pop next turn
-  if (link[0] >= HK_LEAF) {
-    pending = link[0] - HK_LEAF;
-    if (k.in_blas) return PH_TRI;
-    return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
-  }
-  k.cur = link[0];
-  return PH_NODE;
-}
-__device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, uint32_t pending) {
-  const uint32_t primitive_index = k.prim_base + pending;
-  Ray lr;
-  lr.origin = k.co;
-  lr.direction = k.ld;
-  lr.inv_direction = k.cinv;
-  f2 uv;
-  const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
-  if (d < k.hit.distance) {
-    k.hit.uv = uv;
-    k.hit.distance = d;
-    k.hit.primitive_index = primitive_index;
-    k.intersected = true;
-    if (d < k.early_distance) {  // light.wgsl:421-423 then 466-469
-      k.hit.instance_index = k.cur_instance;
-      return PH_IDLE;
-    }
-  }
-  return PH_NODE;
-}
-__device__ __forceinline__ void wide_enter(WideWalk& k, const DScene& sc, uint32_t* lds, uint32_t* spill, uint32_t instance_index) {
-  const DInstance& in = sc.instances[instance_index];
-  k.co = world_to_local_position(in, k.origin);
-  k.ld = world_to_local_direction(in, k.direction);
-  k.cinv = 1.0f / k.ld;
-  wide_push(k, lds, spill, WIDE_LEAVE);
-  k.mesh_base = in.node_offset;
-  k.cur = in.node_count - 1u;  // the mesh tree's root record
-  k.prim_base = in.primitive;
-  k.cur_instance = instance_index;
-  k.in_blas = true;
-  k.intersected = false;
-}
-}  // namespace
-
+#ifndef HK_WIDE_STEPS
+#define HK_WIDE_STEPS 2      // records per turn of the node phase
+#endif
 #ifndef HK_WF_WIDE_WAVES
 #define HK_WF_WIDE_WAVES 4   // waves per SIMD the wide trace kernel is compiled for: 4 workgroups x 32 KB of stack per CU
 #endif
 // k_wf_trace with the wide walk: the same queue, the same refill, the same three phases - a NODE step is one record
 __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene sc, WfBuffers w, WideTrees wt, uint32_t stage) {
   __shared__ uint32_t stack_lds[HK_WIDE_LDS_STACK * 256u];
+  WideStackSpill stack{stack_lds, wt.spill, (size_t)gridDim.x * 256u, (size_t)blockIdx.x * 256u + threadIdx.x};
   const uint32_t n_alive = w.ctr[WF_ALIVE + stage], tail = n_alive + w.ctr[WF_SHADOWS + stage];
   const uint32_t* __restrict__ alive = w.alive[stage & 1u];
   const uint32_t* __restrict__ shadow = w.shadow[stage & 1u];
@@ -723,9 +575,9 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     const uint32_t n_entry = (uint32_t)__popcll(__ballot(phase == PH_ENTRY));
     if (n_node >= n_tri && n_node >= n_entry && n_node != 0u) {
 #pragma unroll 1
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < HK_WIDE_STEPS; ++s) {
         if (phase == PH_NODE) {
-          phase = wide_node(k, wt, stack_lds, wt.spill, pending);
+          phase = wide_node(k, wt, stack, pending);
           if (phase == PH_IDLE) finish();
         }
       }
@@ -736,7 +588,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
       }
     } else {
       if (phase == PH_ENTRY) {
-        wide_enter(k, sc, stack_lds, wt.spill, pending);
+        wide_enter(k, sc, stack, pending);
         phase = PH_NODE;
       }
     }
