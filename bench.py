@@ -103,12 +103,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--ctx-flags", type=int, default=0, help="OR-ed into the flags of the timed contexts (64 = HK_CTX_WAVEFRONT, 128 = HK_CTX_FUSED_INDIRECT, 32 = HK_CTX_EXACT_TRAVERSAL)")
+    ap.add_argument("--ctx-flags", type=int, default=0, help="OR-ed into the flags of the timed contexts (64 = HK_CTX_WAVEFRONT, 128 = HK_CTX_FUSED_INDIRECT, 32 = HK_CTX_EXACT_TRAVERSAL, 256 = HK_CTX_NO_WIDE_WALK)")
+    ap.add_argument("--no-wide-walk", action="store_true", help="A/B: scenes beyond LDS keep the threaded skip-link walk for closest-hit rays too (HK_CTX_NO_WIDE_WALK)")
     ap.add_argument("--passes", action="store_true", help="also report a per-pass time breakdown (extra untimed frames)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the short config-3 / config-5 measurements of the default run")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="length of the sustained block of the default run (0 = none)")
     ap.add_argument("--sustained", dest="sustained_seconds_forced", action="store_true", help="run the sustained block for any config / rank count")
     args = ap.parse_args()
+    if args.no_wide_walk:
+        args.ctx_flags |= 256  # HK_CTX_NO_WIDE_WALK
     if args.steps is None:
         args.steps = 48 if args.config == 2 else 12
     if args.warmup is None:
@@ -232,7 +235,7 @@ def main():
         elapsed = float(np.median(blocks))
         st = eng.stats()
         schedule = eng.indirect_schedule()
-        traversal = eng.traversal_mode()
+        traversal = eng.traversal_mode() + (eng.wide_walk(),)
         ind_ms = st.pass_ms_total[F.PASS_INDIRECT] / max(1, st.pass_launches[F.PASS_INDIRECT])
         ind_launches = int(st.pass_launches[F.PASS_INDIRECT])
         eng.set_timing_mask(0)
@@ -255,7 +258,7 @@ def main():
 
         # ray count by deterministic replay (one block's worth of frames: the camera is static and the rays per frame are
         # counted over the LAST timed block)
-        ceng, crend = make_engine(F.CTX_COUNT_RAYS | (args.ctx_flags & F.CTX_EXACT_TRAVERSAL))
+        ceng, crend = make_engine(F.CTX_COUNT_RAYS | (args.ctx_flags & (F.CTX_EXACT_TRAVERSAL | F.CTX_NO_WIDE_WALK)))  # (the primary rays of the replay walk what the timed ones do)
         run_frames(ceng, crend, 1, last_frame - steps)
         ceng.wait()
         ceng.reset_stats()
@@ -364,7 +367,7 @@ def main():
             extra[str(cfg)] = {"workload": x["description"], "value": round(x["total_rays"] / x["elapsed"] / 1e6, 3), "unit": "Mray/s",
                                "ms_per_step": round(x["elapsed"] / steps_x * 1e3, 4), "steps": steps_x, "warmup": 6,
                                "blocks_ms_per_step": [round(b / steps_x * 1e3, 4) for b in x["blocks"]], "rays_per_frame": round(x["total_rays"] / steps_x, 1),
-                               "indirect_schedule": x["schedule"], "traversal": x["traversal"][0], "indirect_avg_launch_ms": round(x["ind_ms"], 5), "replay_bit_identical": x["same"]}
+                               "indirect_schedule": x["schedule"], "traversal": x["traversal"][0], "wide_walk": x["traversal"][2], "indirect_avg_launch_ms": round(x["ind_ms"], 5), "replay_bit_identical": x["same"]}
             if cfg in (3, 4) and rank == 0 and not args.no_hbm_probe:
                 extra[str(cfg)]["roofline"] = walk_roofline(x, xeng)
             del x
@@ -413,8 +416,9 @@ def main():
             **({"band_split": ("balanced" if m["band_bounds"] else "equal"), "band_bounds": m["band_bounds"],
                 "gather": "none" if args.no_gather else "rank 0 collects the tone-mapped image every frame (HK_FRAME_GATHER), inside the timed region"} if world > 1 else {}),
             # hk_traversal_mode: "one-level" = one BVH over all triangles in the instances' shared local space (the Cornell box),
-            # "threaded" = two-level walk over 8 direction-ordered flattenings (scenes beyond LDS), "reference" = the reference's order
-            "traversal": {"mode": m["traversal"][0], "orderings": m["traversal"][1]},
+            # "threaded" = two-level walk over 8 direction-ordered flattenings (scenes beyond LDS), "reference" = the reference's order;
+            # wide_walk: the closest-hit walks (primary rays, trace stages) take 128-B records of four grandchildren, nearest first
+            "traversal": {"mode": m["traversal"][0], "orderings": m["traversal"][1], "wide_walk": m["traversal"][2]},
         },
         "blocks_ms_per_step": ms_blocks,
         "min_ms_per_step": min(ms_blocks),

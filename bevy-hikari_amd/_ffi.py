@@ -43,6 +43,8 @@ DEFAULT_CTX_FLAGS = int(os.environ.get("HIKARI_HIP_DEFAULT_CTX_FLAGS", "0"))
 CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETERMINISTIC_SCATTER, CTX_EXACT_TRAVERSAL = 1, 2, 4, 8, 16, 32
 TREE_SAH, TREE_LBVH = 0, 1  # hk_rebuild_scene_trees
 CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient with >= 2 bounces (hikari_hip.h)
+CTX_NO_WIDE_WALK = 256  # closest-hit walks of scenes beyond LDS keep the threaded skip-link walk (A/B switch)
+TRAVERSAL_WIDE = 0x100
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS, FRAME_GATHER = 1, 2, 4, 8
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1

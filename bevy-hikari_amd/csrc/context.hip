@@ -368,12 +368,11 @@ bool use_wavefront(const hk_ctx* c) {
   if (c->flags & HK_CTX_WAVEFRONT) return true;
   return (size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES;
 }
-// The wide walk (kernels_wavefront.hip k_wf_trace_wide) is the trace stage of scenes beyond LDS in the product default; the
-// reference's order (HK_CTX_EXACT_TRAVERSAL) and the instrumented twin keep the skip-link walk.  HK_NO_WIDE_WALK=1: A/B switch.
-bool use_wide(const hk_ctx* c) {
-  static const bool off = getenv("HK_NO_WIDE_WALK") != nullptr;
-  return !off && c->threaded && !c->wf.timeline && !c->scene.flat_mode;
-}
+// The wide walk (hk_wide.hpp) is the closest-hit walk of scenes beyond LDS in the product default: the trace stages
+// (k_wf_trace_wide) and the primary rays (k_prepass<*, 4>).  The reference's order (HK_CTX_EXACT_TRAVERSAL) keeps the skip-link walk;
+// HK_CTX_NO_WIDE_WALK is the A/B switch.
+static bool wide_allowed(const hk_ctx* c) { return !(c->flags & HK_CTX_NO_WIDE_WALK) && c->threaded && !c->scene.flat_mode; }
+bool use_wide(const hk_ctx* c) { return wide_allowed(c) && !c->wf.timeline; }  // (the instrumented twin of the trace kernel walks skip links)
 // records of the trees the next trace stages walk, (re)derived from what the scene blob holds now
 int ensure_wide(hk_ctx* c, bool with_spill) {
   const size_t tlas_slots = c->instance_nodes.size(), blas_slots = c->asset_nodes.size();
@@ -423,9 +422,8 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
 }
 // the records for a fused kernel's walks (the primary rays): scenes in global memory with threaded trees, i.e. the product default
 int wide_for_fused(hk_ctx* c, hkd::WideTrees* out) {
-  static const bool off = getenv("HK_NO_WIDE_WALK") != nullptr || getenv("HK_NO_WIDE_PREPASS") != nullptr;
   *out = hkd::WideTrees{};
-  if (off || !c->threaded || c->scene.flat_mode) return HK_OK;
+  if (!wide_allowed(c)) return HK_OK;
   const int rc = ensure_wide(c, false);
   if (rc) return rc;
   out->tlas = c->wide_tlas;
@@ -1340,7 +1338,7 @@ int hk_traversal_mode(hk_ctx* c, uint32_t* out, uint32_t* orderings) {
   HK_HIP(hipSetDevice(c->device));
   { const int rc = finalize_scene(c); if (rc) return rc; }
   HK_REQUIRE(c->scene_mem, HK_E_NOT_READY, "no scene uploaded");
-  *out = c->scene.flat_mode ? HK_TRAVERSAL_ONE_LEVEL : c->threaded ? HK_TRAVERSAL_THREADED : HK_TRAVERSAL_REFERENCE;
+  *out = c->scene.flat_mode ? HK_TRAVERSAL_ONE_LEVEL : c->threaded ? (HK_TRAVERSAL_THREADED | (wide_allowed(c) ? HK_TRAVERSAL_WIDE : 0u)) : HK_TRAVERSAL_REFERENCE;
   if (orderings) *orderings = c->scene.flat_mode ? c->scene.flat_mask + 1u : c->threaded ? 8u : 1u;
   return HK_OK;
 }

@@ -688,7 +688,13 @@ class Engine:
         """('reference' | 'threaded' | 'one-level', stored direction orderings): hk_traversal_mode."""
         v, n = C.c_uint32(), C.c_uint32()
         self.api.call("traversal_mode", self.ctx, C.byref(v), C.byref(n))
-        return ("reference", "threaded", "one-level")[v.value], n.value
+        return ("reference", "threaded", "one-level")[v.value & 0xFF], n.value
+
+    def wide_walk(self):
+        """True when the closest-hit walks of the uploaded scene take the wide records (HK_TRAVERSAL_WIDE; HK_CTX_NO_WIDE_WALK)."""
+        v = C.c_uint32()
+        self.api.call("traversal_mode", self.ctx, C.byref(v), None)
+        return bool(v.value & 0x100)
 
     def measure_hbm(self, bytes_per_array=1 << 30, reps=8):
         """Empirical HBM ceiling: (copy GB/s, triad GB/s) of grid-stride float4 streams over arrays too big for the Infinity Cache."""

@@ -398,6 +398,14 @@ int hk_device_count(int* count);
  * where the ~0.4 KB per path and bounce of queue traffic costs more than the idle lanes).  bit6 / bit7 force one or the other. */
 #define HK_CTX_WAVEFRONT 64u
 #define HK_CTX_FUSED_INDIRECT 128u
+/* Scenes beyond the LDS copy, product default (no HK_CTX_EXACT_TRAVERSAL): the CLOSEST-HIT walks - the primary rays of the prepass and
+ * every ray of the wavefront schedule's trace stages - read 128-B records of an inner node's four grandchildren (derived on the
+ * device from ordering 0 of the trees the scene holds) and take the children nearest first with a per-lane stack: two levels of the
+ * tree per dependent fetch, on both levels of the scene.  Same candidates, same per-triangle arithmetic on the same operands: the
+ * parity bar is the threaded walk's (1e-3 relative L2; any-hit outcomes do not depend on the order).  The shadow rays of the fused
+ * direct passes keep the threaded orderings (measured: faster there).  bit8 switches the wide walk off: the A/B the tests and
+ * `bench.py --no-wide-walk` use.  hk_traversal_mode reports HK_TRAVERSAL_WIDE when it is in use. */
+#define HK_CTX_NO_WIDE_WALK 256u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);
 
@@ -770,10 +778,12 @@ int hk_indirect_schedule(hk_ctx* ctx, uint32_t* out);
  *                           instances all have the same transform, e.g. the Cornell box): the reference's per-triangle
  *                           arithmetic on the reference's operands, so the closest hit is the reference's except where a
  *                           ray grazes an instance's world box within rounding or two candidates tie exactly.
- * orderings (may be NULL): how many direction orderings of the trees are stored (1, 2, 4 or 8). */
+ * orderings (may be NULL): how many direction orderings of the trees are stored (1, 2, 4 or 8).
+ * HK_TRAVERSAL_WIDE is OR-ed into HK_TRAVERSAL_THREADED when the closest-hit walks take the wide records (HK_CTX_NO_WIDE_WALK). */
 #define HK_TRAVERSAL_REFERENCE 0u
 #define HK_TRAVERSAL_THREADED 1u
 #define HK_TRAVERSAL_ONE_LEVEL 2u
+#define HK_TRAVERSAL_WIDE 0x100u
 int hk_traversal_mode(hk_ctx* ctx, uint32_t* out, uint32_t* orderings);
 
 /* Test and measurement hooks (hk_debug_*, hk_measure_*) are declared in hikari_hip_debug.h: a host that renders binds none of them. */

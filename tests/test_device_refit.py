@@ -234,6 +234,7 @@ def test_device_rebuild_of_all_orderings_stays_within_tolerance():
                 if n == 4:
                     p.engine.rebuild_trees(F.TREE_SAH)
             p.render(cam, s, lights=lights, frame_number=n)
+        assert p.engine.wide_walk() == (not exact)  # (the wide records are derived again from the refit trees: hk_wide.hpp)
         outs.append((p.output(s), snapshot(p)))
     (a, sa), (b, sb) = outs
     assert float(np.linalg.norm(a - b) / np.linalg.norm(a)) <= 1e-3

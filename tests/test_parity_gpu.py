@@ -339,7 +339,7 @@ def test_config3_full_1080p_vs_oracle():
         assert bad == {}, (n, bad)
         # what bench.py times for this config - direction-threaded trees, the queue-based indirect pass - against the oracle directly
         worst = max(worst, assert_rendered_within(snapshot(dflt), want, f"config 3 at 1920x1080 frame {n}, product default mode"))
-    assert dflt.engine.traversal_mode()[0] == "threaded" and dflt.engine.indirect_schedule() == "wavefront"
+    assert dflt.engine.traversal_mode()[0] == "threaded" and dflt.engine.indirect_schedule() == "wavefront" and dflt.engine.wide_walk()
     report("default_mode_config3_1080p_vs_oracle", {"worst_relative_l2": worst[0], "worst_fraction_of_pixels_differing": worst[1], "frames": 2})
     sg, sc = gpu.engine.stats(), cpu.engine.stats()
     assert (sg.rays_tlas, sg.rays_blas) == (sc.rays_tlas, sc.rays_blas) and sg.rays_tlas > 1920 * 1080 * 2
@@ -366,12 +366,49 @@ def test_config4_city_class_vs_oracle():
         bad = diff_buffers(snapshot(gpu), want)
         assert bad == {}, (n, bad)
         worst = max(worst, assert_rendered_within(snapshot(dflt), want, f"config 4 (city class) frame {n}, product default mode"))
-    assert dflt.engine.traversal_mode()[0] == "threaded" and dflt.engine.indirect_schedule() == "wavefront"
+    assert dflt.engine.traversal_mode()[0] == "threaded" and dflt.engine.indirect_schedule() == "wavefront" and dflt.engine.wide_walk()
     report("default_mode_config4_city_class_vs_oracle", {"worst_relative_l2": worst[0], "worst_fraction_of_pixels_differing": worst[1], "frames": 2})
     sg, sc = gpu.engine.stats(), cpu.engine.stats()
     assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)
     out = gpu.output(s)
     assert np.isfinite(out).all() and out[..., :3].max() > 0.05
+
+def test_wide_walk_against_the_threaded_walk_and_the_oracle():
+    """Scenes beyond LDS, product default: the closest-hit walks read the wide records (HK_TRAVERSAL_WIDE; hk_wide.hpp).  The same
+    frames with HK_CTX_NO_WIDE_WALK (the threaded skip-link walk everywhere) and on the oracle: both within the north star's 1e-3
+    of the oracle in every rendered buffer, and the two G-buffers - primary rays, where a different closest hit would show first -
+    agree in all but exact ties.  (Instance motion - the records are derived again after a device refit - is
+    test_device_refit.py::test_refit_with_direction_threaded_orderings_stays_within_tolerance, which runs in this mode.)"""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+    from cases import product_default_traversal
+
+    scene, sun = synthetic_large(0x5EED0004, 60, 80, 160, 2000, 50, 1, 40.0)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = synthetic_camera(640, 360, extent=30.0)
+    lights = hk.lights_uniform(directional=dict(sun, illuminance=10000.0))
+    cpu = oracle()
+    with product_default_traversal():
+        wide, threaded, exact = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0, flags=F.CTX_NO_WIDE_WALK), hk.HikariPlugin(device=0, flags=F.CTX_EXACT_TRAVERSAL)
+    for p in (cpu, wide, threaded, exact):
+        p.set_scene(scene)
+
+    def frames(numbers):
+        for n in numbers:
+            for p in (cpu, wide, threaded):
+                p.render(cam, s, lights=lights, frame_number=n)
+        want = snapshot(cpu)
+        a = assert_rendered_within(snapshot(wide), want, f"wide walk, frame {numbers[-1]}")
+        b = assert_rendered_within(snapshot(threaded), want, f"threaded walk, frame {numbers[-1]}")
+        ia, ib = wide.engine.read(F.BUF_INSTANCE_MATERIAL), threaded.engine.read(F.BUF_INSTANCE_MATERIAL)
+        assert float((ia[..., 0] != ib[..., 0]).mean()) <= 1e-5
+        return a, b
+
+    first = frames((1, 2))
+    assert wide.engine.wide_walk() and not threaded.engine.wide_walk()
+    assert wide.engine.traversal_mode() == threaded.engine.traversal_mode() == ("threaded", 8)
+    exact.render(cam, s, lights=lights, frame_number=1)
+    assert exact.engine.traversal_mode()[0] == "reference" and not exact.engine.wide_walk()
+    report("wide_walk_vs_threaded_vs_oracle", {"wide_vs_oracle": first[0], "threaded_vs_oracle": first[1]})
 
 
 def test_config5_full_4k_8_bounces_vs_oracle():
