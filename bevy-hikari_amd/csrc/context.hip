@@ -372,7 +372,7 @@ bool use_wavefront(const hk_ctx* c) {
 // (k_wf_trace_wide) and the primary rays (k_prepass<*, 4>).  The reference's order (HK_CTX_EXACT_TRAVERSAL) keeps the skip-link walk;
 // HK_CTX_NO_WIDE_WALK is the A/B switch.
 static bool wide_allowed(const hk_ctx* c) { return !(c->flags & HK_CTX_NO_WIDE_WALK) && c->threaded && !c->scene.flat_mode; }
-bool use_wide(const hk_ctx* c) { return wide_allowed(c) && !c->wf.timeline; }  // (the instrumented twin of the trace kernel walks skip links)
+bool use_wide(const hk_ctx* c) { return wide_allowed(c); }
 // records of the trees the next trace stages walk, (re)derived from what the scene blob holds now
 int ensure_wide(hk_ctx* c, bool with_spill) {
   const size_t tlas_slots = c->instance_nodes.size(), blas_slots = c->asset_nodes.size();

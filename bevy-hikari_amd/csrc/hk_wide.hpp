@@ -28,8 +28,12 @@ struct WideWalk {
   float early_distance;
   uint32_t exclude_instance;
   Hit hit;
+  float limit;         // a distance the closest hit is known not to exceed (another lane's piece of the same ray found one there: k_wf_trace_wide)
   uint32_t cur;        // record to visit next (a slot of the current level's array), or WIDE_NONE: pop
-  uint32_t sp;         // stack entries
+  uint32_t sp;         // the stack holds entries [base, sp)
+  uint32_t base;       // (> 0 once idle lanes of the wave took pending subtrees off the BOTTOM of this stack: k_wf_trace_wide)
+  uint32_t mark;       // inside a mesh tree: where its WIDE_LEAVE marker sits - the instance-tree entries are [base, mark)
+  uint32_t blas_base;  // ... and the mesh tree's live entries are [blas_base, sp) (mark + 1 until entries were handed over)
   uint32_t mesh_base;  // slot of the current mesh tree's first node in WideTrees::blas
   uint32_t prim_base, cur_instance;
   bool in_blas, intersected;
@@ -86,8 +90,12 @@ __device__ __forceinline__ void wide_begin(WideWalk& k, const WideTrees& wt, f3 
   k.hit.distance = max_distance;
   k.hit.instance_index = HK_U32_MAX;
   k.hit.primitive_index = HK_U32_MAX;
+  k.limit = HK_F32_MAX;
   k.cur = wt.tlas_count - 1u;  // the root's record
   k.sp = 0u;
+  k.base = 0u;
+  k.mark = 0u;
+  k.blas_base = 0u;
   k.mesh_base = 0u;
   k.prim_base = 0u;
   k.cur_instance = 0u;
@@ -102,7 +110,7 @@ __device__ __forceinline__ void wide_begin(WideWalk& k, const WideTrees& wt, f3 
 template <class S>
 __device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, S& st, uint32_t& pending) {
   if (k.cur == WIDE_NONE) {
-    if (k.sp == 0u) return PH_IDLE;
+    if (k.sp == k.base) return PH_IDLE;
     const uint32_t e = wide_pop(k, st);
     if (e == WIDE_LEAVE) {  // traverse_bottom returned, light.wgsl:465-470
       if (k.intersected) {
@@ -125,6 +133,7 @@ __device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, 
   const float4* __restrict__ rec = (k.in_blas ? wt.blas + 8u * (size_t)(k.mesh_base + k.cur) : wt.tlas + 8u * (size_t)k.cur);
   float t[4];
   uint32_t link[4];
+  const float bound = fmin_(k.hit.distance, k.limit);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const float4 lo = rec[2 * c], hi = rec[2 * c + 1];
@@ -138,7 +147,9 @@ __device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, 
     t_max = fmin_(t_max, fmax_(t1.z, t2.z));
     const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
     link[c] = f2u(lo.w);
-    t[c] = (link[c] != WIDE_NONE && t_box < k.hit.distance) ? t_box : HK_F32_MAX;
+    // (<=, not the reference's <: a candidate that TIES with the closest hit so far is still tested - wide_triangle decides ties by
+    // a rule that does not depend on the order of the visits)
+    t[c] = (link[c] != WIDE_NONE && t_box <= bound) ? t_box : HK_F32_MAX;
     if (t[c] == HK_F32_MAX) link[c] = WIDE_NONE;
   }
   // nearest first: a 5-comparator network on (t, link), then the three farther ones go to the stack, farthest first
@@ -170,7 +181,15 @@ __device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc,
   lr.inv_direction = k.cinv;
   f2 uv;
   const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
-  if (d < k.hit.distance) {
+  // closest hit; of two candidates at EXACTLY the same distance the one with the smaller (instance, primitive) wins - whichever
+  // the walk met first (the reference keeps the first it meets in ITS order, which no other order reproduces; a rule of its own makes
+  // the result independent of the order, of how the walk was split among lanes, and of timing)
+  bool closer = d < k.hit.distance;
+  if (d == k.hit.distance && k.hit.primitive_index != HK_U32_MAX) {
+    const uint32_t best_instance = k.intersected ? k.cur_instance : k.hit.instance_index;
+    closer = k.cur_instance < best_instance || (k.cur_instance == best_instance && primitive_index < k.hit.primitive_index);
+  }
+  if (closer) {
     k.hit.uv = uv;
     k.hit.distance = d;
     k.hit.primitive_index = primitive_index;
@@ -188,7 +207,9 @@ __device__ __forceinline__ void wide_enter(WideWalk& k, const DScene& sc, S& st,
   k.co = world_to_local_position(in, k.origin);
   k.ld = world_to_local_direction(in, k.direction);
   k.cinv = 1.0f / k.ld;
+  k.mark = k.sp;
   wide_push(k, st, WIDE_LEAVE);
+  k.blas_base = k.sp;
   k.mesh_base = in.node_offset;
   k.cur = in.node_count - 1u;  // the mesh tree's root record
   k.prim_base = in.primitive;

@@ -509,21 +509,75 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 #define HK_WF_WIDE_WAVES 4   // waves per SIMD the wide trace kernel is compiled for: 4 workgroups x 32 KB of stack per CU
 #endif
 // k_wf_trace with the wide walk: the same queue, the same refill, the same three phases - a NODE step is one record
+// Work sharing inside a wave (round 4, HK_WF_WIDE_SHARE): tools/wf_timeline.py shows a trace stage ending with 0.5-1.1 ms in which
+// the queue is dry and a few long walks finish - 200-500 records at 3-6 us each - while the other lanes of their waves idle.  What a
+// walk still has to do sits on its stack as INDEPENDENT subtrees, and the bottom entry is the farthest (largest, last to be
+// visited) of them.  Once the wave can no longer be refilled, every idle lane takes the bottom entry of a busy lane's stack and
+// walks that subtree for it, starting from the owner's current closest distance; helpers can be helped in turn.  A helper's hit is
+// merged into the ROOT lane's (the lane that claimed the ray) when the helper's stack is empty; the root writes the result when its
+// own piece and all helpers are done.  The closest hit is the minimum over all pieces under wide_triangle's order-independent
+// tie rule, so the result depends neither on who walked what nor on timing; an any-hit ray is occluded iff any piece found an
+// occluder.  Only instance-tree entries are handed over (below a lane's WIDE_LEAVE marker, or its whole stack outside a mesh
+// tree): the helper starts like a fresh ray with one pending entry.
+#ifndef HK_WF_WIDE_SHARE
+#define HK_WF_WIDE_SHARE 1
+#endif
+#ifndef HK_WF_DRY_ALL_PHASES
+#define HK_WF_DRY_ALL_PHASES 1
+#endif
+#ifndef HK_WF_SHARE_MIN
+#define HK_WF_SHARE_MIN 16u  // idle lanes a dry wave must have before its working lanes hand entries over
+#endif
+#ifndef HK_WF_SHARE_STEPS
+#define HK_WF_SHARE_STEPS 8u  // ... and records a lane must have visited for its piece before it does: only the long walks end a stage
+#endif
+enum : uint32_t { PH_WAIT = 4u, PH_HELPED = 5u };  // a root whose helpers are still out / a helper whose piece is done (merged at the next turn)
+__device__ __forceinline__ uint32_t lane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+
+template <bool TL>  // (TL: the instrumented twin, as for k_wf_trace - tools/wf_timeline.py)
 __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene sc, WfBuffers w, WideTrees wt, uint32_t stage) {
   __shared__ uint32_t stack_lds[HK_WIDE_LDS_STACK * 256u];
+  __shared__ uint32_t tl_hist[16];
+  unsigned long long tl_start = 0ull;
+  uint32_t tl_steps = 0u, tl_max = 0u, tl_sum = 0u, tl_rays = 0u, tl_claimed = 0u;
+  bool tl_seen_dry = false;
+  if (TL) {
+    if (threadIdx.x < 16u) tl_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    tl_start = wall_clock64();
+    if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 0u], ~tl_start);
+  }
   WideStackSpill stack{stack_lds, wt.spill, (size_t)gridDim.x * 256u, (size_t)blockIdx.x * 256u + threadIdx.x};
   const uint32_t n_alive = w.ctr[WF_ALIVE + stage], tail = n_alive + w.ctr[WF_SHADOWS + stage];
   const uint32_t* __restrict__ alive = w.alive[stage & 1u];
   const uint32_t* __restrict__ shadow = w.shadow[stage & 1u];
   uint32_t* head_ptr = &w.ctr[WF_QHEAD + stage];
   const uint32_t all_lanes = gridDim.x * 256u;
+  const uint32_t lane = threadIdx.x & 63u;
   uint32_t res_base = 0u, res_count = 0u;
   bool exhausted = tail == 0u;
   uint32_t phase = PH_IDLE, pending = 0u;
   uint32_t entry_id = 0u;
+  uint32_t root = lane;  // the lane (of this wave) the ray belongs to
+  __shared__ uint32_t share_lane[4][64];  // taker rank -> thread
+  __shared__ uint32_t share_help[256];    // (per root) pieces of its ray other lanes still walk
+  __shared__ uint32_t share_best[256];    // (per root) the closest distance any piece of its ray has found, as ordered bits
+  share_help[threadIdx.x] = 0u;
+  share_best[threadIdx.x] = f2u(HK_F32_MAX);
+  uint32_t steps = 0u;  // records this lane has visited for its current piece
   WideWalk k;
   wide_begin(k, wt, F3(0, 0, 0), F3(1, 1, 1), 0.0f, 0.0f, HK_DONT_EXCLUDE);
-  auto finish = [&]() {
+  auto begin_ray = [&](uint32_t id, float bound) {  // the ray of queue entry `id`, from its planes
+    const uint32_t slot = id & ~WF_SHADOW;
+    if (id & WF_SHADOW) {
+      const float4 a = w.sr0[slot], b4 = w.sr1[slot];
+      wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), fminf(a.w, bound), b4.w, w.sr2[slot]);
+    } else {
+      const float4 a = w.cr0[slot], b4 = w.cr1[slot];
+      wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), bound, 0.0f, HK_DONT_EXCLUDE);
+    }
+  };
+  auto write_result = [&]() {  // (root) the ray is done: its result goes to the slot
     const uint32_t slot = entry_id & ~WF_SHADOW;
     if (entry_id & WF_SHADOW) {
       w.sh[slot] = k.hit.instance_index;
@@ -532,10 +586,70 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
       w.ch1[slot] = k.hit.instance_index;
     }
   };
+  auto finish = [&]() {  // the lane's piece of a walk has ended
+    if (TL) {
+      tl_max = max(tl_max, tl_steps);
+      tl_sum += tl_steps;
+      tl_rays += 1u;
+      atomicAdd(&tl_hist[min(15u, 31u - (uint32_t)__clz((int)(tl_steps + 1u)))], 1u);
+      if (tl_steps >= 128u) {  // the long walks (a record is two levels: half the skip-link kernel's threshold)
+        const uint32_t now_rel = (uint32_t)(wall_clock64() - tl_start);
+        unsigned long long* tl = w.timeline + 32u * stage;
+        atomicAdd(&tl[24], (unsigned long long)(now_rel - tl_claimed));
+        atomicAdd(&tl[25], (unsigned long long)tl_steps);
+        atomicAdd(&tl[26], 1ull);
+        atomicMax(&tl[27], ((unsigned long long)(now_rel - tl_claimed) << 32) | tl_steps);
+        atomicMax(&tl[28], ((unsigned long long)tl_claimed << 32) | tl_steps);
+      }
+      tl_steps = 0u;
+    }
+    if (root != lane) {
+      phase = PH_HELPED;
+    } else if (share_help[threadIdx.x] != 0u) {
+      phase = PH_WAIT;
+    } else {
+      write_result();
+      phase = PH_IDLE;
+    }
+  };
   for (;;) {
+#if HK_WF_WIDE_SHARE
+    // helpers whose piece ended since the last turn: their hits go to their roots (one at a time: the wave runs in lock step,
+    // so a root's registers can be written from here)
+    for (unsigned long long done = __ballot(phase == PH_HELPED); done != 0ull; done &= done - 1ull) {
+      const int h = __ffsll((long long)done) - 1;
+      const uint32_t to = lane_u32(root, h), h_prim = lane_u32(k.hit.primitive_index, h), h_inst = lane_u32(k.hit.instance_index, h);
+      const float h_d = u2f(lane_u32(f2u(k.hit.distance), h)), h_u = u2f(lane_u32(f2u(k.hit.uv.x), h)), h_v = u2f(lane_u32(f2u(k.hit.uv.y), h));
+      if (lane == to) {
+        share_help[threadIdx.x] -= 1u;
+        if (h_inst != HK_U32_MAX) {  // the helper found something below the distance it started from
+          // (the root may be inside a mesh tree with a hit of its own there: that hit's instance is cur_instance until it leaves)
+          const uint32_t mine_inst = k.intersected ? k.cur_instance : k.hit.instance_index;
+          bool closer = h_d < k.hit.distance;
+          if (h_d == k.hit.distance && k.hit.primitive_index != HK_U32_MAX) closer = h_inst < mine_inst || (h_inst == mine_inst && h_prim < k.hit.primitive_index);
+          if (closer) {
+            k.hit.distance = h_d;
+            k.hit.uv = F2(h_u, h_v);
+            k.hit.primitive_index = h_prim;
+            k.hit.instance_index = h_inst;
+            k.intersected = false;  // (what the current mesh tree contributed so far lost against it)
+          }
+        }
+      }
+    }
+    if (phase == PH_HELPED) phase = PH_IDLE;
+    if (phase == PH_WAIT && share_help[threadIdx.x] == 0u) {
+      write_result();
+      phase = PH_IDLE;
+    }
+#endif
     const unsigned long long idle_mask = __ballot(phase == PH_IDLE);
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     const bool dry = exhausted && res_count == 0u;
+    if (TL && exhausted && !tl_seen_dry) {
+      tl_seen_dry = true;
+      if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 1u], ~wall_clock64());
+    }
     if (dry && n_idle == 64u) break;
     if (!dry && (n_idle >= HK_WF_REFILL_MIN || n_idle == 64u)) {
       const bool idle = phase == PH_IDLE;
@@ -559,39 +673,156 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
       res_count -= used;
       if (mine != HK_U32_MAX) {
         entry_id = mine < n_alive ? alive[mine] : (shadow[mine - n_alive] | WF_SHADOW);
-        const uint32_t slot = entry_id & ~WF_SHADOW;
-        if (entry_id & WF_SHADOW) {
-          const float4 a = w.sr0[slot], b4 = w.sr1[slot];
-          wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), a.w, b4.w, w.sr2[slot]);
-        } else {
-          const float4 a = w.cr0[slot], b4 = w.cr1[slot];
-          wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE);
-        }
+        begin_ray(entry_id, HK_F32_MAX);
+        root = lane;
+        steps = 0u;
+        share_best[threadIdx.x] = f2u(HK_F32_MAX);
         phase = PH_NODE;
+        if (TL) tl_claimed = (uint32_t)(wall_clock64() - tl_start);
       }
     }
+#if HK_WF_WIDE_SHARE
+    if (dry && n_idle >= HK_WF_SHARE_MIN) {
+      // who can give: a lane at work with a pending entry that is nobody's current business - the bottom of its instance-tree
+      // entries (the farthest, largest subtree), else, inside a mesh tree, the bottom of that tree's entries
+      const bool working = phase == PH_NODE || phase == PH_TRI || phase == PH_ENTRY;
+      const uint32_t tlas_top = k.in_blas ? k.mark : k.sp;  // instance-tree entries: [base, tlas_top)
+      uint32_t give_at = HK_U32_MAX;
+      bool give_blas = false;
+      if (working && steps >= HK_WF_SHARE_STEPS) {
+        if (k.base < tlas_top) give_at = k.base;
+        else if (k.in_blas && k.blas_base < k.sp) { give_at = k.blas_base; give_blas = true; }
+      }
+      uint32_t link = give_at != HK_U32_MAX ? stack.get(give_at) : WIDE_NONE;
+      if (link == WIDE_NONE || link == WIDE_LEAVE) {  // (a tombstone: skip it for the next time)
+        if (give_at != HK_U32_MAX) { if (give_blas) k.blas_base += 1u; else k.base += 1u; }
+        give_at = HK_U32_MAX;
+      }
+      const unsigned long long givers = __ballot(give_at != HK_U32_MAX);
+      const uint32_t n_givers = (uint32_t)__popcll(givers);
+      if (n_givers != 0u) {
+        const uint32_t wave = threadIdx.x >> 6;
+        const bool idle = phase == PH_IDLE;
+        const uint32_t t_rank = lane_rank(idle_mask), g_rank = lane_rank(givers);
+        if (idle && t_rank < n_givers) share_lane[wave][t_rank] = threadIdx.x;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (give_at != HK_U32_MAX && g_rank < n_idle) {  // hand the entry over: the walk's context goes into the taker's (unused) stack column
+          uint32_t* col = stack_lds + share_lane[wave][g_rank];
+          const bool in_blas = give_blas;
+          const f3 co = in_blas ? k.co : k.origin, cinv = in_blas ? k.cinv : k.inv_direction, ld = in_blas ? k.ld : k.direction;
+          const uint32_t ctx[28] = {link, entry_id, root, f2u(k.hit.distance), f2u(k.origin.x), f2u(k.origin.y), f2u(k.origin.z), f2u(k.direction.x), f2u(k.direction.y),
+                                    f2u(k.direction.z), f2u(k.inv_direction.x), f2u(k.inv_direction.y), f2u(k.inv_direction.z), f2u(k.early_distance), k.exclude_instance,
+                                    in_blas ? 1u : 0u, k.mesh_base, k.prim_base, k.cur_instance, f2u(co.x), f2u(co.y), f2u(co.z), f2u(ld.x), f2u(ld.y), f2u(ld.z),
+                                    f2u(cinv.x), f2u(cinv.y), f2u(cinv.z)};
+#pragma unroll
+          for (int e = 0; e < 28; ++e) col[e * 256] = ctx[e];
+          atomicAdd(&share_help[(threadIdx.x & ~63u) + root], 1u);
+          if (give_blas) {
+            stack.put(give_at, WIDE_NONE);  // (a tombstone: popping it costs one turn)
+            k.blas_base += 1u;
+          } else {
+            k.base += 1u;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (idle && t_rank < n_givers) {  // a walk of the same ray over that one subtree, limited by the giver's closest distance so far
+          const uint32_t* col = stack_lds + threadIdx.x;
+          uint32_t ctx[28];
+#pragma unroll
+          for (int e = 0; e < 28; ++e) ctx[e] = col[e * 256];
+          entry_id = ctx[1];
+          root = ctx[2];
+          k.origin = F3(u2f(ctx[4]), u2f(ctx[5]), u2f(ctx[6]));
+          k.direction = F3(u2f(ctx[7]), u2f(ctx[8]), u2f(ctx[9]));
+          k.inv_direction = F3(u2f(ctx[10]), u2f(ctx[11]), u2f(ctx[12]));
+          k.early_distance = u2f(ctx[13]);
+          k.exclude_instance = ctx[14];
+          k.hit.uv = F2(0.0f, 0.0f);
+          k.hit.distance = u2f(ctx[3]);
+          k.limit = HK_F32_MAX;
+          k.hit.instance_index = HK_U32_MAX;
+          k.hit.primitive_index = HK_U32_MAX;
+          k.in_blas = ctx[15] != 0u;
+          k.mesh_base = ctx[16];
+          k.prim_base = ctx[17];
+          k.cur_instance = ctx[18];
+          k.co = F3(u2f(ctx[19]), u2f(ctx[20]), u2f(ctx[21]));
+          k.ld = F3(u2f(ctx[22]), u2f(ctx[23]), u2f(ctx[24]));
+          k.cinv = F3(u2f(ctx[25]), u2f(ctx[26]), u2f(ctx[27]));
+          k.intersected = false;
+          k.cur = WIDE_NONE;
+          k.sp = 0u;
+          k.base = 0u;
+          k.mark = 0u;
+          k.blas_base = 0u;
+          if (k.in_blas) {
+            wide_push(k, stack, WIDE_LEAVE);
+            k.blas_base = 1u;
+          }
+          wide_push(k, stack, ctx[0]);
+          steps = 0u;
+          phase = PH_NODE;
+          if (TL) tl_claimed = (uint32_t)(wall_clock64() - tl_start);
+        }
+      }
+    }
+#endif
     const uint32_t n_node = (uint32_t)__popcll(__ballot(phase == PH_NODE));
     const uint32_t n_tri = (uint32_t)__popcll(__ballot(phase == PH_TRI));
     const uint32_t n_entry = (uint32_t)__popcll(__ballot(phase == PH_ENTRY));
-    if (n_node >= n_tri && n_node >= n_entry && n_node != 0u) {
+    // While the queue lasts the phase with the most lanes waiting runs (lane utilisation: an idle lane is refilled).  Once the wave
+    // is dry every parked lane is served every turn: what is left are the walks that end the stage, and (HK_WF_WIDE_SHARE) the
+    // lanes that help them - a lane that waits a turn for its phase makes the stage a turn longer.
+    const bool all_phases = HK_WF_DRY_ALL_PHASES && dry;
+    if (all_phases ? n_node != 0u : (n_node >= n_tri && n_node >= n_entry && n_node != 0u)) {
+#if HK_WF_WIDE_SHARE
+      if (dry) k.limit = u2f(share_best[(threadIdx.x & ~63u) + root]);  // (what the other pieces of the ray have found meanwhile)
+#endif
 #pragma unroll 1
       for (int s = 0; s < HK_WIDE_STEPS; ++s) {
         if (phase == PH_NODE) {
+          if (TL) tl_steps += 1u;
+          steps += 1u;
           phase = wide_node(k, wt, stack, pending);
           if (phase == PH_IDLE) finish();
         }
       }
-    } else if (n_tri >= n_entry) {
+    }
+    if (all_phases ? n_tri != 0u : (!(n_node >= n_tri && n_node >= n_entry && n_node != 0u) && n_tri >= n_entry)) {
       if (phase == PH_TRI) {
+        const float before = k.hit.distance;
         phase = wide_triangle(k, sc, pending);
+#if HK_WF_WIDE_SHARE
+        if (dry && k.hit.distance < before) atomicMin(&share_best[(threadIdx.x & ~63u) + root], f2u(k.hit.distance));  // (distances are >= 0: their bits order like they do)
+#endif
         if (phase == PH_IDLE) finish();
       }
-    } else {
+    }
+    if (all_phases ? n_entry != 0u : (!(n_node >= n_tri && n_node >= n_entry && n_node != 0u) && n_tri < n_entry)) {
       if (phase == PH_ENTRY) {
         wide_enter(k, sc, stack, pending);
         phase = PH_NODE;
       }
     }
+  }
+  if (TL) {
+    const unsigned long long now = wall_clock64();
+    for (int off = 32; off > 0; off >>= 1) {
+      tl_max = max(tl_max, (uint32_t)__shfl_down(tl_max, off));
+      tl_sum += __shfl_down(tl_sum, off);
+      tl_rays += __shfl_down(tl_rays, off);
+    }
+    unsigned long long* tl = w.timeline + 32u * stage;
+    if ((threadIdx.x & 63u) == 0u) {
+      atomicMax(&tl[2], now);
+      atomicAdd(&tl[3], now - tl_start);
+      atomicAdd(&tl[4], 1ull);
+      atomicMax(&tl[5], (unsigned long long)tl_max);
+      atomicAdd(&tl[6], (unsigned long long)tl_sum);
+      atomicAdd(&tl[7], (unsigned long long)tl_rays);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16u && tl_hist[threadIdx.x]) atomicAdd(&tl[8u + threadIdx.x], (unsigned long long)tl_hist[threadIdx.x]);
   }
 }
 
@@ -769,7 +1000,8 @@ void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& f
   const dim3 tracers((unsigned)(compute_units * trace_wg_per_cu));
   const uint32_t bounces = fr.indirect_bounces;
   for (uint32_t n = 0; n <= bounces; ++n) {
-    if (wide && wide->tlas && !lds && !w.timeline) hipLaunchKernelGGL(k_wf_trace_wide, dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, *wide, n);
+    if (wide && wide->tlas && !lds && w.timeline) hipLaunchKernelGGL(k_wf_trace_wide<true>, dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, *wide, n);
+    else if (wide && wide->tlas && !lds) hipLaunchKernelGGL(k_wf_trace_wide<false>, dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, *wide, n);
     else if (w.timeline && !lds) hipLaunchKernelGGL((k_wf_trace<false, true>), tracers, dim3(256), 0, st, sc, w, n);
     else if (lds) hipLaunchKernelGGL((k_wf_trace<true, false>), tracers, dim3(256), lds, st, sc, w, n);
     else hipLaunchKernelGGL((k_wf_trace<false, false>), tracers, dim3(256), 0, st, sc, w, n);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Bulk / tail split of the trace stages of the queue-based indirect pass: with HK_WF_TIMELINE=1 the trace
 kernel's instrumented twin records per stage when the ray queue ran dry, when the last persistent wave left and how long the rays'
-walks were.  Prints one JSON object per config.    python tools/wf_timeline.py [3 4]"""
+walks were.  Prints one JSON object per config.    python tools/wf_timeline.py [--no-wide-walk] [3 4]
+(default: the wide kernel k_wf_trace_wide, whose "node steps" are 128-B records of two tree levels and whose long walks are those of
+>= 128 records; --no-wide-walk: the skip-link kernel k_wf_trace, long walks >= 256 node steps)"""
 import ctypes as C
 import json
 import os
@@ -17,11 +19,12 @@ from bench import workload  # noqa: E402
 
 
 def main():
-    configs = [int(a) for a in sys.argv[1:]] or [3, 4]
+    no_wide = "--no-wide-walk" in sys.argv
+    configs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [3, 4]
     out = {}
     for cfg in configs:
         scene, camera, settings, lights, description = workload(hk, cfg, None, None, None)
-        e = hk.Engine(device=0)
+        e = hk.Engine(device=0, flags=256 if no_wide else 0)
         e.upload_noise(); e.upload_scene(scene); e.resize(camera.width, camera.height, 1.0)
         view, pview, sc = camera.view_uniform(), camera.previous_view_uniform(), settings.to_c()
         for n in range(1, 9):
@@ -43,10 +46,10 @@ def main():
                            "tail_fraction": round((total - bulk) / total, 3), "mean_wave_residency": round(int(r[3]) / int(r[4]) / (tend - t0), 3),
                            "rays": int(r[7]), "mean_node_steps": round(int(r[6]) / max(1, int(r[7])), 1), "max_node_steps": int(r[5]),
                            "rays_by_log2_steps": [int(x) for x in r[8:24]],
-                           "long_walks_256_steps_up": {"rays": int(r[26]), "mean_us_per_node_step": round(int(r[24]) * tick_us / max(1, int(r[25])), 3),
+                           "long_walks": {"rays": int(r[26]), "mean_us_per_node_step": round(int(r[24]) * tick_us / max(1, int(r[25])), 3),
                                                        "slowest": {"us": round((int(r[27]) >> 32) * tick_us, 1), "node_steps": int(r[27]) & 0xFFFFFFFF},
                                                        "handed_out_last": {"us_after_wave_start": round((int(r[28]) >> 32) * tick_us, 1), "node_steps": int(r[28]) & 0xFFFFFFFF}}})
-        out[str(cfg)] = {"workload": description, "wall_clock_khz": int(raw[63, 31]), "trace_stages": stages}
+        out[str(cfg)] = {"workload": description, "trace_kernel": "k_wf_trace_wide" if e.wide_walk() else "k_wf_trace", "wall_clock_khz": int(raw[63, 31]), "trace_stages": stages}
         del e
     print(json.dumps(out, indent=1))
 
