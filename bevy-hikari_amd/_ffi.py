@@ -149,7 +149,8 @@ class HkStats(C.Structure):
                 ("pass_ms_total", C.c_double * TIMING_SLOTS), ("pass_launches", u64 * TIMING_SLOTS), ("last_frame_ms", f32),
                 ("_pad", u32), ("scene_mesh_builds", u64), ("scene_instance_builds", u64),
                 ("scene_async_instance_uploads", u64), ("scene_device_refits", u64), ("scene_device_tree_builds", u64),
-                ("walk_node_steps", u64), ("walk_triangle_tests", u64), ("walk_instance_entries", u64), ("walk_closest_hits", u64), ("walk_top_node_steps", u64)]
+                ("walk_node_steps", u64), ("walk_triangle_tests", u64), ("walk_instance_entries", u64), ("walk_closest_hits", u64), ("walk_top_node_steps", u64),
+                ("wide_stack_lost", u64)]
 
 
 assert C.sizeof(HkVertex) == 32 and C.sizeof(HkPrimitive) == 48 and C.sizeof(HkNode) == 32 and C.sizeof(HkInstance) == 176

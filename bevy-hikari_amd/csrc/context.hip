@@ -430,6 +430,7 @@ int wide_for_fused(hk_ctx* c, hkd::WideTrees* out) {
   out->blas = c->wide_blas;
   out->tlas_count = c->scene.tlas_count;
   out->spill = nullptr;
+  out->lost = c->d_counters + 8;
   return HK_OK;
 }
 // the scratch of the queue-based schedule: allocated on first use for the current render size
@@ -538,6 +539,7 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
           wide.blas = c->wide_blas;
           wide.tlas_count = c->scene.tlas_count;
           wide.spill = c->wide_spill;
+          wide.lost = c->d_counters + 8;
         }
         launch_indirect_wavefront(c->stream, c->scene, fr, g, t, c->wf, y0, y1, c->compute_units, timer.on ? timer.t.start : nullptr,
                                   timer.on ? timer.t.stop : nullptr, &wide);
@@ -691,8 +693,8 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   c->device = device_id;
   c->flags = flags;
   c->timing_mask = (flags & HK_CTX_TIME_PASSES) ? 0xFFFFFFFFu : 0u;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&c->frame_start) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 9 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->d_counters, 0, 9 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&c->frame_start) != hipSuccess ||
       hipEventCreate(&c->frame_stop) != hipSuccess) {
     set_error("HIP resource creation failed: %s", hipGetErrorString(hipGetLastError()));
     hk_destroy(c);
@@ -1301,7 +1303,7 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   memset(out, 0, sizeof(*out));
-  unsigned long long h[8] = {};
+  unsigned long long h[9] = {};  // ([8]: stack entries the wide walk dropped - counted by every context)
   HK_HIP(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
   out->rays_primary = h[0];
   out->rays_tlas = h[1];
@@ -1311,6 +1313,7 @@ int hk_get_stats(hk_ctx* c, HkStats* out) {
   out->walk_instance_entries = h[5];
   out->walk_closest_hits = h[6];
   out->walk_top_node_steps = h[7];
+  out->wide_stack_lost = h[8];
   out->frames = c->frames;
   out->last_frame_ms = c->last_frame_ms;
   out->scene_mesh_builds = c->static_rebuilds;
@@ -1348,7 +1351,7 @@ int hk_reset_stats(hk_ctx* c) {
   HK_HIP(hipSetDevice(c->device));
   { const int rc_ = sync_all(c); if (rc_) return rc_; }
   drain_timers(c);
-  HK_HIP(hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
+  HK_HIP(hipMemset(c->d_counters, 0, 9 * sizeof(unsigned long long)));
   c->frames = 0;
   for (int i = 0; i < HK_TIMING_SLOTS; ++i) {
     c->slot_ms[i] = 0.0;

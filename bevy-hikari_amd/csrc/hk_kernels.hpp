@@ -88,6 +88,7 @@ struct WideTrees {
   const float4* tlas;   // records of the instance tree: 8 float4 per slot, tlas_count slots
   const float4* blas;   // records of every mesh tree: slot node_offset + local position
   uint32_t tlas_count;  // (its root: slot tlas_count - 1)
+  unsigned long long* lost;  // counts stack entries that fit neither part (HkStats::wide_stack_lost)
   uint32_t* spill;      // stack entries beyond the LDS part: HK_WIDE_SPILL u32 per lane of the persistent launch (the trace stage;
                         // nullptr where only the prepass - whose lanes keep the rest in private memory - walks them)
 };

@@ -41,14 +41,17 @@ struct WideWalk {
 };
 // Where a lane's pending children wait.  The first HK_WIDE_LDS_STACK entries: LDS, entry-major (address = entry x 256 + thread: no bank
 // conflicts).  Beyond: a global spill area indexed by the lane of a PERSISTENT launch (the trace kernel), or a small private array
-// (the fused kernels: their grids are as large as the image).  Entries beyond both are lost - a tree some eighty levels deep.
+// (the fused kernels: their grids are as large as the image).  Entries beyond both are dropped and COUNTED (HkStats::wide_stack_lost):
+// 128 entries serve trees some eighty levels deep.
 struct WideStackSpill {
   uint32_t* lds;
   uint32_t* spill;
   size_t stride, lane;  // spill[(entry - HK_WIDE_LDS_STACK) x stride + lane]
+  unsigned long long* lost;
   __device__ __forceinline__ void put(uint32_t at, uint32_t e) {
     if (at < HK_WIDE_LDS_STACK) lds[at * 256u + threadIdx.x] = e;
     else if (at < HK_WIDE_LDS_STACK + HK_WIDE_SPILL) spill[(size_t)(at - HK_WIDE_LDS_STACK) * stride + lane] = e;
+    else if (e != WIDE_NONE) atomicAdd(lost, 1ull);
   }
   __device__ __forceinline__ uint32_t get(uint32_t at) const {
     if (at < HK_WIDE_LDS_STACK) return lds[at * 256u + threadIdx.x];
@@ -59,10 +62,12 @@ struct WideStackSpill {
 template <uint32_t LDS_ENTRIES, uint32_t PRIVATE_ENTRIES>
 struct WideStackPrivate {
   uint32_t* lds;
+  unsigned long long* lost;
   uint32_t priv[PRIVATE_ENTRIES];
   __device__ __forceinline__ void put(uint32_t at, uint32_t e) {
     if (at < LDS_ENTRIES) lds[at * 256u + threadIdx.x] = e;
     else if (at < LDS_ENTRIES + PRIVATE_ENTRIES) priv[at - LDS_ENTRIES] = e;
+    else if (e != WIDE_NONE) atomicAdd(lost, 1ull);
   }
   __device__ __forceinline__ uint32_t get(uint32_t at) const {
     if (at < LDS_ENTRIES) return lds[at * 256u + threadIdx.x];

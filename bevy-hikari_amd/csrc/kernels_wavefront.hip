@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     tl_start = wall_clock64();
     if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 0u], ~tl_start);
   }
-  WideStackSpill stack{stack_lds, wt.spill, (size_t)gridDim.x * 256u, (size_t)blockIdx.x * 256u + threadIdx.x};
+  WideStackSpill stack{stack_lds, wt.spill, (size_t)gridDim.x * 256u, (size_t)blockIdx.x * 256u + threadIdx.x, wt.lost};
   const uint32_t n_alive = w.ctr[WF_ALIVE + stage], tail = n_alive + w.ctr[WF_SHADOWS + stage];
   const uint32_t* __restrict__ alive = w.alive[stage & 1u];
   const uint32_t* __restrict__ shadow = w.shadow[stage & 1u];

@@ -37,7 +37,7 @@ SCRATCH_ALLOWED = {
     r"k_indirect<true, false, 0>": 32,         # fused schedule on a scene in global memory (the default there is the wavefront)
     r"k_indirect<true, true, (0|3)>": 96,      # ray-counting replays (two-level / one-level walk from global memory; + the walk counters of HkStats)
     r"k_wf_final": 16,
-    r"k_prepass<(true|false), 4>": 160,        # the wide walk's stack beyond its 32 LDS entries: a 32-entry private array (hk_wide.hpp WideStackPrivate)
+    r"k_prepass<(true|false), 4>": 416,        # the wide walk's stack beyond its 32 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks that deep
     r"k_wf_trace<false, true>": 64,            # the instrumented twin of tools/wf_timeline.py (never launched by the product)
     # scenes beyond LDS: 4 waves per SIMD with 9 / 54 spilled VGPRs beat 3 without (profiles/r03_occupancy_ab.txt); COUNT = the replays
     r"k_direct_lit<false, (true|false), 0>": 48,
