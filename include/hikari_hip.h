@@ -407,9 +407,13 @@ int hk_device_count(int* count);
  * every ray of the wavefront schedule's trace stages - read 128-B records of an inner node's four grandchildren (derived on the
  * device from ordering 0 of the trees the scene holds) and take the children nearest first with a per-lane stack: two levels of the
  * tree per dependent fetch, on both levels of the scene.  Same candidates, same per-triangle arithmetic on the same operands: the
- * parity bar is the threaded walk's (1e-3 relative L2; any-hit outcomes do not depend on the order).  The shadow rays of the fused
- * direct passes keep the threaded orderings (measured: faster there).  bit8 switches the wide walk off: the A/B the tests and
- * `bench.py --no-wide-walk` use.  hk_traversal_mode reports HK_TRAVERSAL_WIDE when it is in use. */
+ * parity bar is the threaded walk's (1e-3 relative L2; any-hit outcomes do not depend on the order).  Of two candidates at EXACTLY
+ * the same distance the one with the smaller (instance, primitive) wins - a rule of the walk's own (the reference keeps the first
+ * it meets in its order), which makes a ray's result independent of the visit order, of timing, and of how the trace stage splits
+ * a long walk among the idle lanes of its wave at the end of a stage; two runs of the same frames are equal byte for byte.  The
+ * shadow rays of the fused direct passes keep the threaded orderings (measured: faster there).  bit8 switches the wide walk off:
+ * the A/B the tests and `bench.py --no-wide-walk` use.  hk_traversal_mode reports HK_TRAVERSAL_WIDE when it is in use;
+ * HkStats.wide_stack_lost counts pending subtrees a walk had to drop (0 for trees up to ~80 levels deep). */
 #define HK_CTX_NO_WIDE_WALK 256u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);

@@ -10,6 +10,7 @@ timeout 400 python tools/band_probe.py > $OUT/${TAG}_band_probe.json 2> /dev/nul
 timeout 600 python tools/refit_probe.py 2000 20000 > $OUT/${TAG}_device_refit_probe.json 2> /dev/null
 timeout 300 python tools/gather_probe.py > $OUT/${TAG}_gather_probe.json 2> /dev/null
 timeout 300 python tools/wf_timeline.py 3 4 > $OUT/${TAG}_wf_timeline.json 2> /dev/null
+timeout 300 python tools/wf_timeline.py --no-wide-walk 3 4 > $OUT/${TAG}_wf_timeline_skip_link.json 2> /dev/null
 bash tools/pmc_calibrate.sh $TAG > /dev/null 2>&1
 # the wide walk's A/B on the scenes it serves: the same bench lines with HK_CTX_NO_WIDE_WALK (threaded skip-link walk for every ray)
 for C in 3 4; do
