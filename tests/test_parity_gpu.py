@@ -417,6 +417,31 @@ def test_wide_walk_against_the_threaded_walk_and_the_oracle():
     assert exact.engine.traversal_mode()[0] == "reference" and not exact.engine.wide_walk()
     report("wide_walk_vs_threaded_vs_oracle", {"wide_vs_oracle": first[0], "threaded_vs_oracle": first[1]})
 
+def test_wide_walk_inside_few_large_meshes():
+    """The other shape of a long walk: few instances of two 100 k-triangle meshes - the walks are long INSIDE a mesh tree (17 levels),
+    so what a dry wave of the trace stage hands to its idle lanes are mesh-tree entries (hk_wide.hpp: blas_base, tombstones), and the
+    stacks are at their deepest.  Product default against the oracle (1e-3), two contexts byte for byte, no dropped stack entry."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+    from cases import product_default_traversal
+
+    scene, sun = synthetic_large(0x5EED0007, 2, 160, 320, 6, 8, 2, 3.0)
+    s = hk.HikariSettings(indirect_bounces=3, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam = synthetic_camera(320, 180, extent=3.0)
+    lights = hk.lights_uniform(directional=sun)
+    cpu = oracle()
+    with product_default_traversal():
+        wide, again = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0)
+    for p in (cpu, wide, again):
+        p.set_scene(scene)
+    worst = (0.0, 0.0)
+    for n in (1, 2, 3):
+        for p in (cpu, wide, again):
+            p.render(cam, s, lights=lights, frame_number=n)
+        worst = max(worst, assert_rendered_within(snapshot(wide), snapshot(cpu), f"two large meshes, frame {n}, product default mode"))
+        assert diff_buffers(snapshot(again), snapshot(wide)) == {}
+    assert wide.engine.wide_walk() and wide.engine.indirect_schedule() == "wavefront" and wide.engine.stats().wide_stack_lost == 0
+    report("wide_walk_few_large_meshes_vs_oracle", {"worst_relative_l2": worst[0], "worst_fraction_of_pixels_differing": worst[1], "frames": 3})
+
 
 def test_config5_full_4k_8_bounces_vs_oracle():
     """BASELINE config 5 at its FULL size (Cornell 3840x2160, 8 bounces, emissive + indirect spatial reuse, denoise off): two
