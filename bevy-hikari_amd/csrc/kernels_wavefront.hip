@@ -441,7 +441,8 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
 // children are visited is not stored but decided per ray - nearest first - with a per-lane stack: 32 entries in LDS (entry-major:
 // conflict-free), the rest in a global spill area.  Same candidates, same per-triangle arithmetic on the same operands as
 // traverse_top: the closest hit is the reference's except where two candidates tie exactly (the product default's bar, like the
-// threaded orderings); an any-hit ray's outcome - occluded or not - does not depend on the order at all.
+// threaded orderings; hk_wide.hpp wide_triangle decides ties by a rule of its own - the smaller (instance, primitive) - so that the
+// result does not depend on the order of the visits); an any-hit ray's outcome - occluded or not - does not depend on the order at all.
 // one thread per slot of ONE tree (ordering 0; links local to the tree): the record of the inner node at that slot, and - in the
 // last slot - the root's
 __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ nodes, uint32_t count, float4* __restrict__ wide) {
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 #ifndef HK_WF_WIDE_WAVES
 #define HK_WF_WIDE_WAVES 4   // waves per SIMD the wide trace kernel is compiled for: 4 workgroups x 32 KB of stack per CU
 #endif
-// k_wf_trace with the wide walk: the same queue, the same refill, the same three phases - a NODE step is one record
+// k_wf_trace with the wide walk: the same queue, the same refill, the same three phases - a NODE step is one record.
 // Work sharing inside a wave (round 4, HK_WF_WIDE_SHARE): tools/wf_timeline.py shows a trace stage ending with 0.5-1.1 ms in which
 // the queue is dry and a few long walks finish - 200-500 records at 3-6 us each - while the other lanes of their waves idle.  What a
 // walk still has to do sits on its stack as INDEPENDENT subtrees, and the bottom entry is the farthest (largest, last to be
@@ -516,9 +517,12 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 // walks that subtree for it, starting from the owner's current closest distance; helpers can be helped in turn.  A helper's hit is
 // merged into the ROOT lane's (the lane that claimed the ray) when the helper's stack is empty; the root writes the result when its
 // own piece and all helpers are done.  The closest hit is the minimum over all pieces under wide_triangle's order-independent
-// tie rule, so the result depends neither on who walked what nor on timing; an any-hit ray is occluded iff any piece found an
-// occluder.  Only instance-tree entries are handed over (below a lane's WIDE_LEAVE marker, or its whole stack outside a mesh
-// tree): the helper starts like a fresh ray with one pending entry.
+// tie rule, and every piece prunes with the closest distance ANY piece of its ray has found (share_best, LDS): the result depends
+// neither on who walked what nor on timing; an any-hit ray is occluded iff any piece found an occluder.  Handed over: the bottom
+// of the lane's instance-tree entries (below its WIDE_LEAVE marker, or its whole stack outside a mesh tree), else the bottom entry
+// of the mesh tree it is in (a tombstone stays); the walk's context - ray, local ray, closest distance, 28 dwords - travels through
+// the TAKER's unused stack column.  A dry wave also serves every parked lane every turn (HK_WF_DRY_ALL_PHASES): with many lanes of
+// a wave at work again, waiting a turn for one's phase is what makes the stage longer.  profiles/r04_wide_share_ab.txt.
 #ifndef HK_WF_WIDE_SHARE
 #define HK_WF_WIDE_SHARE 1
 #endif
