@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Builds libhikari_hip.so for gfx950: every source to an object of its own (in parallel, only what changed), then one link - 25 s
+instead of the 3 minutes of one hipcc invocation over all sources.  Used by __graft_entry__.build() and tools/build_variant.sh.
+    python tools/build_lib.py [-o out.so] [--objdir dir] [-DFLAG ...]      (extra flags reach every compile)"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "bevy-hikari_amd", "csrc")
+# -ffp-contract=off: only the fmaf() calls written in the sources become v_fma_f32 (numeric contract).  gfx950 only.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+SOURCES = ["kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "kernels_wavefront.hip", "kernels_scene.hip", "context.hip", "scene_layout.hip", "scene_refit.hip",
+           "probes.hip", "host_logic.cpp", "scene_builder.cpp", "comm.cpp"]
+
+
+def build_library(out, objdir=None, extra=(), force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = objdir or os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [os.path.join(ROOT, "include", "hikari_hip.h"),
+                                                                                                   os.path.join(ROOT, "include", "hikari_hip_debug.h")]
+    stamp = os.path.join(objdir, "flags.txt")
+    flag_line = " ".join(list(extra))
+    if not os.path.exists(stamp) or open(stamp).read() != flag_line:
+        force = True
+    jobs = []
+    for src in SOURCES:
+        base = os.path.splitext(src)[0]
+        jobs.append((src, os.path.join(objdir, base + ".o"), []))
+
+    def stale(obj, src):
+        if force or not os.path.exists(obj):
+            return True
+        t = os.path.getmtime(obj)
+        return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, src)] + headers)
+
+    def compile_one(job):
+        src, obj, more = job
+        cmd = [hipcc] + FLAGS + list(extra) + more + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    todo = [j for j in jobs if stale(j[1], j[0])]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
+        list(pool.map(compile_one, todo))
+    open(stamp, "w").write(flag_line)
+    objs = [j[1] for j in jobs]
+    if todo or not os.path.exists(out) or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return out
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    out = os.path.join(ROOT, "bevy-hikari_amd", "libhikari_hip.so")
+    objdir = None
+    extra = []
+    while args:
+        a = args.pop(0)
+        if a == "-o":
+            out = os.path.abspath(args.pop(0))
+        elif a == "--objdir":
+            objdir = os.path.abspath(args.pop(0))
+        else:
+            extra.append(a)
+    build_library(out, objdir, extra)
