@@ -13,7 +13,7 @@
 namespace hkd {
 
 #ifndef HK_WIDE_LDS_STACK
-#define HK_WIDE_LDS_STACK 32u
+#define HK_WIDE_LDS_STACK 28u  // entries of a lane's stack that live in LDS (28 KB per workgroup: five workgroups per CU next to the sharing tables)
 #endif
 #ifndef HK_WIDE_SPILL
 #define HK_WIDE_SPILL 96u

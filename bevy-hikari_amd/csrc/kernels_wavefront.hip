@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
 // per BOX (84 per ray, 34-42 of them in the instance tree).  Here a fetch is one 128-B record with the boxes of an inner node's FOUR
 // grandchildren (hk_kernels.hpp WideTrees): two levels per dependent step, on both levels of the scene, from ONE copy of the trees
 // (1/8 of the bytes the eight threaded orderings take: what the 4 MB L2s can hold goes up accordingly).  The order in which
-// children are visited is not stored but decided per ray - nearest first - with a per-lane stack: 32 entries in LDS (entry-major:
+// children are visited is not stored but decided per ray - nearest first - with a per-lane stack: 28 entries in LDS (entry-major:
 // conflict-free), the rest in a global spill area.  Same candidates, same per-triangle arithmetic on the same operands as
 // traverse_top: the closest hit is the reference's except where two candidates tie exactly (the product default's bar, like the
 // threaded orderings; hk_wide.hpp wide_triangle decides ties by a rule of its own - the smaller (instance, primitive) - so that the
@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 #define HK_WIDE_STEPS 2      // records per turn of the node phase
 #endif
 #ifndef HK_WF_WIDE_WAVES
-#define HK_WF_WIDE_WAVES 4   // waves per SIMD the wide trace kernel is compiled for: 4 workgroups x 32 KB of stack per CU
+#define HK_WF_WIDE_WAVES 5   // waves per SIMD the wide trace kernel is compiled for (<= 96 VGPRs): 5 workgroups x 31 KB of LDS per CU
+                             // (4 x 35 KB with a 32-entry LDS stack: indirect pass +2.4 % / +6 %, profiles/r04_wide_share_ab.txt)
 #endif
 // k_wf_trace with the wide walk: the same queue, the same refill, the same three phases - a NODE step is one record.
 // Work sharing inside a wave (round 4, HK_WF_WIDE_SHARE): tools/wf_timeline.py shows a trace stage ending with 0.5-1.1 ms in which
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 // tie rule, and every piece prunes with the closest distance ANY piece of its ray has found (share_best, LDS): the result depends
 // neither on who walked what nor on timing; an any-hit ray is occluded iff any piece found an occluder.  Handed over: the bottom
 // of the lane's instance-tree entries (below its WIDE_LEAVE marker, or its whole stack outside a mesh tree), else the bottom entry
-// of the mesh tree it is in (a tombstone stays); the walk's context - ray, local ray, closest distance, 28 dwords - travels through
+// of the mesh tree it is in (a tombstone stays); the walk's context - ray, local ray, closest distance, 22 dwords - travels through
 // the TAKER's unused stack column.  A dry wave also serves every parked lane every turn (HK_WF_DRY_ALL_PHASES): with many lanes of
 // a wave at work again, waiting a turn for one's phase is what makes the stage longer.  profiles/r04_wide_share_ab.txt.
 #ifndef HK_WF_WIDE_SHARE
@@ -711,15 +712,15 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
         if (idle && t_rank < n_givers) share_lane[wave][t_rank] = threadIdx.x;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (give_at != HK_U32_MAX && g_rank < n_idle) {  // hand the entry over: the walk's context goes into the taker's (unused) stack column
+          static_assert(HK_WIDE_LDS_STACK >= 22u, "the context a lane hands over travels through 22 entries of the taker's LDS stack column");
           uint32_t* col = stack_lds + share_lane[wave][g_rank];
           const bool in_blas = give_blas;
-          const f3 co = in_blas ? k.co : k.origin, cinv = in_blas ? k.cinv : k.inv_direction, ld = in_blas ? k.ld : k.direction;
-          const uint32_t ctx[28] = {link, entry_id, root, f2u(k.hit.distance), f2u(k.origin.x), f2u(k.origin.y), f2u(k.origin.z), f2u(k.direction.x), f2u(k.direction.y),
-                                    f2u(k.direction.z), f2u(k.inv_direction.x), f2u(k.inv_direction.y), f2u(k.inv_direction.z), f2u(k.early_distance), k.exclude_instance,
-                                    in_blas ? 1u : 0u, k.mesh_base, k.prim_base, k.cur_instance, f2u(co.x), f2u(co.y), f2u(co.z), f2u(ld.x), f2u(ld.y), f2u(ld.z),
-                                    f2u(cinv.x), f2u(cinv.y), f2u(cinv.z)};
+          const f3 co = in_blas ? k.co : k.origin, ld = in_blas ? k.ld : k.direction;  // (the reciprocals are taken again by the taker: the same divisions)
+          const uint32_t ctx[22] = {link, entry_id, root, f2u(k.hit.distance), f2u(k.origin.x), f2u(k.origin.y), f2u(k.origin.z), f2u(k.direction.x), f2u(k.direction.y),
+                                    f2u(k.direction.z), f2u(k.early_distance), k.exclude_instance, in_blas ? 1u : 0u, k.mesh_base, k.prim_base, k.cur_instance,
+                                    f2u(co.x), f2u(co.y), f2u(co.z), f2u(ld.x), f2u(ld.y), f2u(ld.z)};
 #pragma unroll
-          for (int e = 0; e < 28; ++e) col[e * 256] = ctx[e];
+          for (int e = 0; e < 22; ++e) col[e * 256] = ctx[e];
           atomicAdd(&share_help[(threadIdx.x & ~63u) + root], 1u);
           if (give_blas) {
             stack.put(give_at, WIDE_NONE);  // (a tombstone: popping it costs one turn)
@@ -731,28 +732,28 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         if (idle && t_rank < n_givers) {  // a walk of the same ray over that one subtree, limited by the giver's closest distance so far
           const uint32_t* col = stack_lds + threadIdx.x;
-          uint32_t ctx[28];
+          uint32_t ctx[22];
 #pragma unroll
-          for (int e = 0; e < 28; ++e) ctx[e] = col[e * 256];
+          for (int e = 0; e < 22; ++e) ctx[e] = col[e * 256];
           entry_id = ctx[1];
           root = ctx[2];
           k.origin = F3(u2f(ctx[4]), u2f(ctx[5]), u2f(ctx[6]));
           k.direction = F3(u2f(ctx[7]), u2f(ctx[8]), u2f(ctx[9]));
-          k.inv_direction = F3(u2f(ctx[10]), u2f(ctx[11]), u2f(ctx[12]));
-          k.early_distance = u2f(ctx[13]);
-          k.exclude_instance = ctx[14];
+          k.inv_direction = 1.0f / k.direction;   // (wide_begin's division)
+          k.early_distance = u2f(ctx[10]);
+          k.exclude_instance = ctx[11];
           k.hit.uv = F2(0.0f, 0.0f);
           k.hit.distance = u2f(ctx[3]);
           k.limit = HK_F32_MAX;
           k.hit.instance_index = HK_U32_MAX;
           k.hit.primitive_index = HK_U32_MAX;
-          k.in_blas = ctx[15] != 0u;
-          k.mesh_base = ctx[16];
-          k.prim_base = ctx[17];
-          k.cur_instance = ctx[18];
-          k.co = F3(u2f(ctx[19]), u2f(ctx[20]), u2f(ctx[21]));
-          k.ld = F3(u2f(ctx[22]), u2f(ctx[23]), u2f(ctx[24]));
-          k.cinv = F3(u2f(ctx[25]), u2f(ctx[26]), u2f(ctx[27]));
+          k.in_blas = ctx[12] != 0u;
+          k.mesh_base = ctx[13];
+          k.prim_base = ctx[14];
+          k.cur_instance = ctx[15];
+          k.co = F3(u2f(ctx[16]), u2f(ctx[17]), u2f(ctx[18]));
+          k.ld = F3(u2f(ctx[19]), u2f(ctx[20]), u2f(ctx[21]));
+          k.cinv = k.in_blas ? 1.0f / k.ld : k.inv_direction;  // (wide_enter's division)
           k.intersected = false;
           k.cur = WIDE_NONE;
           k.sp = 0u;

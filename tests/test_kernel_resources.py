@@ -37,7 +37,7 @@ SCRATCH_ALLOWED = {
     r"k_indirect<true, false, 0>": 32,         # fused schedule on a scene in global memory (the default there is the wavefront)
     r"k_indirect<true, true, (0|3)>": 96,      # ray-counting replays (two-level / one-level walk from global memory; + the walk counters of HkStats)
     r"k_wf_final": 16,
-    r"k_prepass<(true|false), 4>": 416,        # the wide walk's stack beyond its 32 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks that deep
+    r"k_prepass<(true|false), 4>": 416,        # the wide walk's stack beyond its 28 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks that deep
     r"k_wf_trace<false, true>": 64,            # the instrumented twin of tools/wf_timeline.py (never launched by the product)
     # scenes beyond LDS: 4 waves per SIMD with 9 / 54 spilled VGPRs beat 3 without (profiles/r03_occupancy_ab.txt); COUNT = the replays
     r"k_direct_lit<false, (true|false), 0>": 48,
@@ -74,7 +74,10 @@ def test_lds_leaves_room_for_the_scene_copy(table):
     """The ray kernels copy scenes of up to 32 KB into dynamic LDS on top of their static LDS; with four workgroups per CU that
     has to fit the CU's 160 KB."""
     for name, r in table.items():
-        if re.search(r"k_wf_trace_wide|k_prepass<(true|false), 4>", name):   # global-memory scenes: no scene copy, a 32 KB stack instead, 4 workgroups per CU
+        if re.search(r"k_wf_trace_wide", name):   # global-memory scenes: no scene copy, a 28 KB stack + the sharing tables instead, FIVE workgroups per CU
+            assert 5 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 96 and r["vgpr_spill_count"] == 0, name
+            continue
+        if re.search(r"k_prepass<(true|false), 4>", name):   # ... the fused prepass: the stack only, 4 workgroups per CU (104 VGPRs)
             assert 4 * r["group_segment_fixed_size"] <= 160 * 1024, name
             continue
         if re.search(r"k_(direct_lit|indirect|prepass|wf_trace|wf_shade)", name):
