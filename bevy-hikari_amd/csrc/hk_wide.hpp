@@ -42,7 +42,7 @@ struct WideWalk {
 // Where a lane's pending children wait.  The first HK_WIDE_LDS_STACK entries: LDS, entry-major (address = entry x 256 + thread: no bank
 // conflicts).  Beyond: a global spill area indexed by the lane of a PERSISTENT launch (the trace kernel), or a small private array
 // (the fused kernels: their grids are as large as the image).  Entries beyond both are dropped and COUNTED (HkStats::wide_stack_lost):
-// 128 entries serve trees some eighty levels deep.
+// 124 entries serve trees some eighty levels deep.
 struct WideStackSpill {
   uint32_t* lds;
   uint32_t* spill;

@@ -349,7 +349,7 @@ typedef struct HkStats {
   uint64_t walk_instance_entries;
   uint64_t walk_closest_hits;
   uint64_t walk_top_node_steps;  /* ... of walk_node_steps, those taken in the instance tree (the rest walk mesh trees) */
-  /* The wide walk (HK_TRAVERSAL_WIDE) keeps a lane's pending subtrees on a stack of 128 entries (32 in LDS, 96 behind them): enough
+  /* The wide walk (HK_TRAVERSAL_WIDE) keeps a lane's pending subtrees on a stack of 124 entries (28 in LDS, 96 behind them): enough
    * for trees 80 levels deep.  An entry that did not fit is DROPPED - geometry behind it is not seen by that ray - and counted here
    * (every context counts, not only HK_CTX_COUNT_RAYS): a host that loads degenerate trees checks this for 0 after its first
    * frames and creates the context with HK_CTX_NO_WIDE_WALK otherwise.  0 in every test and benchmark of this repository. */

@@ -17,19 +17,18 @@ from conftest import ROOT
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    from rendezvous import new_rendezvous
+
+    return new_rendezvous()   # (not a port any more: a file:// rendezvous token)
 
 
 def _worker(rank, world, port, case_name, out_dir, transport=None, split=None, gather=False):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rendezvous import init_gloo
+
+    init_gloo(rank, world, port)   # (`port`: a file:// rendezvous token, tests/rendezvous.py)
     import bevy_hikari_amd as hk
     from bevy_hikari_amd import _ffi as F
     from bevy_hikari_amd.distributed import BandRenderer
@@ -132,8 +131,9 @@ def _motion_worker(rank, world, port, history_rows, out_dir, settings_kw):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rendezvous import init_gloo
+
+    init_gloo(rank, world, port)   # (`port`: a file:// rendezvous token, tests/rendezvous.py)
     import bevy_hikari_amd as hk
     from bevy_hikari_amd import _ffi as F
     from bevy_hikari_amd.distributed import BandRenderer
@@ -209,8 +209,9 @@ def _aa_worker(rank, world, port, case_name, out_dir):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rendezvous import init_gloo
+
+    init_gloo(rank, world, port)   # (`port`: a file:// rendezvous token, tests/rendezvous.py)
     import bevy_hikari_amd as hk
     from bevy_hikari_amd import _ffi as F
     from bevy_hikari_amd.distributed import BandRenderer

@@ -221,8 +221,9 @@ def _gpu_band_worker(rank, world, port, case_name, out_dir):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rendezvous import init_gloo
+
+    init_gloo(rank, world, port)   # (`port`: a file:// rendezvous token, tests/rendezvous.py)
     import torch
 
     import bevy_hikari_amd as hk
@@ -273,11 +274,9 @@ def test_gpu_bands_equal_single_gpu(tmp_path, world, case_name):
 
     import torch.multiprocessing as mp
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_gpu_band_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
+    from rendezvous import new_rendezvous
+
+    mp.spawn(_gpu_band_worker, args=(world, new_rendezvous(), case_name, str(tmp_path)), nprocs=world, join=True)
     from cases import random_case
 
     case = random_case(int(case_name[6:])) if case_name.startswith("random") else make_case(case_name)

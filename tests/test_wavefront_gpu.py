@@ -139,11 +139,9 @@ def test_wavefront_bands_equal_single_context(tmp_path, world, case_name, monkey
     from test_parity_gpu import _gpu_band_worker
 
     monkeypatch.setenv("HIKARI_HIP_DEFAULT_CTX_FLAGS", str(F.CTX_EXACT_TRAVERSAL | F.CTX_WAVEFRONT))  # inherited by the spawned ranks
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    mp.spawn(_gpu_band_worker, args=(world, port, case_name, str(tmp_path)), nprocs=world, join=True)
+    from rendezvous import new_rendezvous
+
+    mp.spawn(_gpu_band_worker, args=(world, new_rendezvous(), case_name, str(tmp_path)), nprocs=world, join=True)
     case = make_case(case_name)
     ref = hk.HikariPlugin(device=0, flags=F.CTX_FUSED_INDIRECT)
     run_case(ref, case)

@@ -22,8 +22,9 @@ def _worker(rank, world, port, seed, mode, out_dir):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rendezvous import init_gloo
+
+    init_gloo(rank, world, port)   # (`port`: a file:// rendezvous token, tests/rendezvous.py)
     import bevy_hikari_amd as hk
     from bevy_hikari_amd import _ffi as F
     from bevy_hikari_amd.distributed import BandRenderer, _final_buffer
@@ -78,7 +79,9 @@ def main():
         world = int(min(rng.integers(2, 7), rh))
         mode = ("equal", "uneven", "balanced")[seed % 3]
         kinds[f"{mode}x{world}"] = kinds.get(f"{mode}x{world}", 0) + 1
-        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        from rendezvous import new_rendezvous
+
+        port = new_rendezvous()
         with tempfile.TemporaryDirectory() as d:
             try:
                 mp.spawn(_worker, args=(world, port, seed, mode, d), nprocs=world, join=True)
