@@ -17,18 +17,21 @@ from conftest import ROOT
 def test_bench_band_path_runs_with_several_ranks_on_one_gpu(world, launcher):
     """launcher "torchrun": the driver's own command line.  "plain": `python bench.py --gpus N` with no launcher - bench.py
     re-launches itself under torch.distributed.run (VERDICT r02 missing 1)."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, HIKARI_BENCH_TRANSPORT="host", HIKARI_BENCH_DEVICE="0")
-    cmd = [sys.executable]
-    if launcher in ("torchrun", "balanced"):
-        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "3", "--blocks", "2", "--width", "640", "--height", "360"]
-    if launcher == "balanced":   # the split by cost, derived by every rank on frame 1 (HK_FRAME_BALANCE_BANDS / hk_balance_bands)
-        cmd += ["--band-split", "balanced"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(3):   # (the launcher needs a TCP port; one picked by bind / close can be taken before the launcher binds it)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable]
+        if launcher in ("torchrun", "balanced"):
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+        cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "3", "--blocks", "2", "--width", "640", "--height", "360"]
+        if launcher == "balanced":   # the split by cost, derived by every rank on frame 1 (HK_FRAME_BALANCE_BANDS / hk_balance_bands)
+            cmd += ["--band-split", "balanced"]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode == 0 or "address already in use" not in r.stderr.lower():
+            break
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 alone prints
