@@ -347,6 +347,18 @@ def main():
                          "instance_entries": round(ip["instance_entries"] / ip["rays"], 2), "node_steps_in_the_instance_tree": round(ip["top_node_steps"] / ip["rays"], 2), "bvh_bytes": round(bvh_bytes / ip["rays"], 1)},
              "formula": "SURVEY 8d: visited nodes x 32 + leaf (triangle) tests x 48 + 96 per closest hit; instance entries (208-B records) counted, not priced",
              "tree_bytes_walked": tree_bytes, "traffic": None}
+        # HBM-side bytes of the pass's trace stages by the PMC counters (tools/pmc_fetch.sh; not measured in this run): x 1 per 64-B request,
+        # which is what a walk's gathers issue (profiles/r04_fetch_calibration.json)
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_walk_hbm_traffic.json")) as f:
+                tw = json.load(f).get(f"config{x.get('config', 0)}_trace_stages")
+            if tw and x["schedule"] == "wavefront" and x["traversal"][2]:
+                r["traffic"] = tw["hbm_bytes_per_pass_lower"]
+                r["traffic_source"] = {"file": "profiles/r04_walk_hbm_traffic.json", "upper_bound_if_every_request_were_128_B": tw["hbm_bytes_per_pass_upper"],
+                                       "ratio_to_algorithmic": round(tw["hbm_bytes_per_pass_lower"] / bvh_bytes, 3),
+                                       "note": "FETCH_SIZE + WRITE_SIZE of the pass's k_wf_trace_wide launches (separate PMC passes of the same command, not this run)"}
+        except (OSError, ValueError, KeyError, TypeError, IndexError):
+            pass
         if probe_engine is not None:
             # 7 waves per SIMD = k_wf_trace's occupancy (HK_WF_TRACE_WAVES); 32 B per step = a node step's two 16-B loads
             gl, gb = probe_engine.measure_gather(max(tree_bytes, 1 << 20), 32, 7, 512)
