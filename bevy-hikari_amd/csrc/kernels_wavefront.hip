@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
           const bool in_blas = give_blas;
           const f3 co = in_blas ? k.co : k.origin, ld = in_blas ? k.ld : k.direction;  // (the reciprocals are taken again by the taker: the same divisions)
           const uint32_t ctx[22] = {link, entry_id, root, f2u(k.hit.distance), f2u(k.origin.x), f2u(k.origin.y), f2u(k.origin.z), f2u(k.direction.x), f2u(k.direction.y),
-                                    f2u(k.direction.z), f2u(k.early_distance), k.exclude_instance, in_blas ? 1u : 0u, k.mesh_base, k.prim_base, k.cur_instance,
+                                    f2u(k.direction.z), f2u(k.early_distance), k.exclude_instance, (in_blas ? 1u : 0u) | (k.hit.primitive_index != HK_U32_MAX ? 2u : 0u), k.mesh_base, k.prim_base, k.cur_instance,
                                     f2u(co.x), f2u(co.y), f2u(co.z), f2u(ld.x), f2u(ld.y), f2u(ld.z)};
 #pragma unroll
           for (int e = 0; e < 22; ++e) col[e * 256] = ctx[e];
@@ -743,11 +743,14 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
           k.early_distance = u2f(ctx[10]);
           k.exclude_instance = ctx[11];
           k.hit.uv = F2(0.0f, 0.0f);
-          k.hit.distance = u2f(ctx[3]);
+          // the giver's closest distance is this piece's limit.  If it is a HIT's distance, a candidate at exactly that distance must
+          // still be accepted here - it may carry the smaller (instance, primitive) and win the tie at the merge - so the piece starts
+          // from the next float above it (tests/test_wide_model.py::test_ties_do_not_depend_on_the_order is this case on the CPU)
+          k.hit.distance = (ctx[12] & 2u) ? u2f(ctx[3] + 1u) : u2f(ctx[3]);
           k.limit = HK_F32_MAX;
           k.hit.instance_index = HK_U32_MAX;
           k.hit.primitive_index = HK_U32_MAX;
-          k.in_blas = ctx[12] != 0u;
+          k.in_blas = (ctx[12] & 1u) != 0u;
           k.mesh_base = ctx[13];
           k.prim_base = ctx[14];
           k.cur_instance = ctx[15];
