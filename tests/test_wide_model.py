@@ -124,3 +124,40 @@ def test_ties_do_not_depend_on_the_order():
         for steal in (None, 0, 1):
             got = walk_wide(sc, o, d, steal_after=steal)
             assert (got[0], got[1]) == want
+
+
+@pytest.mark.parametrize("name,extent", [("cornell", 1.2), ("yard", 5.0)])
+def test_pieces_in_any_order_with_a_published_distance_give_the_same_hit(models, name, extent):
+    """The lanes of a dry wave: pieces split off at random moments, advanced in a random order, pruning with the closest distance any
+    of them has published - five different schedules per ray, all equal to brute force."""
+    from wide_model import walk_wide_concurrent
+
+    sc = models[name]
+    o, d = rays(41, 40, extent)
+    split = 0
+    for k in range(len(o)):
+        want = brute_force(sc, o[k], d[k])
+        for seed in range(5):
+            got = walk_wide_concurrent(sc, o[k], d[k], np.random.default_rng(1000 * k + seed))
+            assert (got[0], got[1]) == want, (k, seed, got, want)
+            split += got[2] > 1
+    assert split > 100
+
+
+def test_pieces_in_any_order_on_exact_ties():
+    """... and on the scene where every hit ties three ways."""
+    from wide_model import walk_wide_concurrent
+
+    b = hk.SceneBuilder()
+    quad_p = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], dtype=np.float32)
+    mesh = b.add_mesh(quad_p, np.tile(np.array([[0, 1, 0]], dtype=np.float32), (4, 1)), np.zeros((4, 2), dtype=np.float32), np.array([0, 1, 2, 0, 2, 3], dtype=np.uint32))
+    mat = b.add_material(hk.standard_material((0.8, 0.8, 0.8, 1.0), (0, 0, 0), 0.5, 0.0, 0.5))
+    for _ in range(4):
+        b.add_instance(mesh, mat, np.eye(4, dtype=np.float32))
+    sc = Scene(b.finish())
+    o, d = np.array([0.3, 2.0, 0.2]), np.array([0.0, -1.0, 0.0])
+    want = brute_force(sc, o, d)
+    assert want[1][0] == 0
+    for seed in range(60):
+        got = walk_wide_concurrent(sc, o, d, np.random.default_rng(seed), steal_probability=0.7)
+        assert (got[0], got[1]) == want, (seed, got)

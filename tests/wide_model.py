@@ -223,3 +223,65 @@ def brute_force(sc, origin, direction, t_max=np.inf):
             if t <= best[0] and BETTER(t, key, best):
                 best[0], best[1] = t, key
     return best[0], best[1]
+
+
+def walk_wide_concurrent(sc, origin, direction, rng, t_max=np.inf, steal_probability=0.5):
+    """The same walk as a set of PIECES that advance one stack entry at a time in a random order - the lanes of a dry wave - with what the
+    device shares between them: a piece is created by taking the bottom entry off another piece's stack (its limit: the giver's closest
+    distance at that moment, one float up if it is a hit's), every piece prunes with min(own closest distance, the closest distance ANY
+    piece has published) under `<=`, accepts into its OWN hit only, and the hits are merged under the tie rule when all are done."""
+    o, d = np.asarray(origin, np.float64), np.asarray(direction, np.float64)
+    with np.errstate(divide="ignore"):
+        inv = 1.0 / d
+    shared = [np.inf]   # share_best: the closest distance any piece has found
+
+    def local(inst):
+        inv_m = sc.instances[inst]["inverse"]
+        lo = inv_m @ np.append(o, 1.0)
+        ld = (inv_m @ np.append(d, 0.0))[:3]
+        with np.errstate(divide="ignore"):
+            return lo[:3] / lo[3], ld, 1.0 / ld
+
+    pieces = [{"best": [t_max, None], "stack": [("t", None, len(sc.tlas[2]) - 1)]}]
+    done = []
+    while pieces:
+        k = int(rng.integers(len(pieces)))
+        p = pieces[k]
+        if len(p["stack"]) >= 1 and rng.random() < steal_probability and len(pieces) < 64:
+            entry = p["stack"].pop(0)
+            b = p["best"]
+            pieces.append({"best": [np.nextafter(b[0], np.inf) if b[1] is not None else b[0], None], "stack": [entry]})
+        if not p["stack"]:
+            done.append(pieces.pop(k))
+            continue
+        level, inst, link = p["stack"].pop()
+        best = p["best"]
+        if link >= LEAF:
+            ident = link - LEAF
+            if level == "t":
+                p["stack"].append(("b", ident, len(sc.instances[ident]["tree"][2]) - 1))
+            else:
+                lo, ld, _ = local(inst)
+                tri = sc.prims[sc.instances[inst]["primitive"] + ident]
+                t = triangle(lo, ld, tri[0], tri[1], tri[2])
+                key = (inst, sc.instances[inst]["primitive"] + ident)
+                if t <= best[0] and BETTER(t, key, best):
+                    best[0], best[1] = t, key
+                    shared[0] = min(shared[0], t)
+            continue
+        if level == "t":
+            rec, ro, rinv = sc.tlas_wide[link], o, inv
+        else:
+            lo, _, linv = local(inst)
+            rec, ro, rinv = sc.instances[inst]["wide"][link], lo, linv
+        bound = min(best[0], shared[0])
+        hits = [(t, child) for mn, mx, child in rec for t in [slab(mn, mx, ro, rinv)] if t is not None and t <= bound]
+        hits.sort(key=lambda h: -h[0])
+        for _, child in hits:
+            p["stack"].append((level, inst, child))
+    out = [t_max, None]
+    for p in done:
+        b = p["best"]
+        if b[1] is not None and BETTER(b[0], b[1], out):
+            out[0], out[1] = b[0], b[1]
+    return out[0], out[1], len(done)
