@@ -161,3 +161,24 @@ def test_pieces_in_any_order_on_exact_ties():
     for seed in range(60):
         got = walk_wide_concurrent(sc, o, d, np.random.default_rng(seed), steal_probability=0.7)
         assert (got[0], got[1]) == want, (seed, got)
+
+
+@pytest.mark.parametrize("name,extent", [("cornell", 1.2), ("yard", 5.0)])
+def test_any_hit_rays_occluded_or_not_whatever_the_schedule(models, name, extent):
+    """A shadow ray (a limit below which anything occludes): occluded iff ANY candidate lies below the limit - the unsplit walk, split
+    walks with stale limits and pieces in random order all say what brute force says."""
+    from wide_model import walk_wide_concurrent
+
+    sc = models[name]
+    o, d = rays(53, 50, extent)
+    rng = np.random.default_rng(5)
+    n_occluded = 0
+    for k in range(len(o)):
+        t_max = float(rng.uniform(0.3, 2.5 * extent))
+        want = brute_force(sc, o[k], d[k], t_max)[1] is not None
+        assert (walk_wide(sc, o[k], d[k], t_max)[1] is not None) == want
+        assert (walk_wide(sc, o[k], d[k], t_max, steal_after=1)[1] is not None) == want
+        for seed in range(3):
+            assert (walk_wide_concurrent(sc, o[k], d[k], np.random.default_rng(77 * k + seed), t_max)[1] is not None) == want
+        n_occluded += want
+    assert 5 < n_occluded < len(o) - 5
