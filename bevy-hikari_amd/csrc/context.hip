@@ -394,10 +394,10 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
     HK_HIP(hipGetDeviceProperties(&prop, c->device));
     c->compute_units = prop.multiProcessorCount;
   }
-  const size_t lanes = with_spill ? (size_t)c->compute_units * 4 * 256 : 0;  // HK_WF_WIDE_WAVES workgroups per CU
+  const size_t lanes = with_spill ? wide_trace_lanes(c->compute_units) : 0;  // (the trace kernel's own launch size: kernels_wavefront.hip)
   if (lanes > c->wide_spill_lanes) {
     if (c->wide_spill) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_spill); c->wide_spill = nullptr; }
-    HK_HIP(hipMalloc((void**)&c->wide_spill, lanes * 96 * sizeof(uint32_t)));  // HK_WIDE_SPILL entries per lane
+    HK_HIP(hipMalloc((void**)&c->wide_spill, lanes * wide_spill_entries() * sizeof(uint32_t)));
     c->wide_spill_lanes = lanes;
   }
   if (c->wide_blas_dirty) {  // one launch per mesh tree (links are local to a tree): once per mesh-level build

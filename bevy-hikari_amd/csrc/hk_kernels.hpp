@@ -274,6 +274,10 @@ void launch_indirect(hipStream_t st, bool multiple_bounces, const hkd::DScene& s
 // the same dispatch as launch_indirect(multiple_bounces = true), scheduled through ray queues (kernels_wavefront.hip)
 // wide: records of the trees for the trace stages (nullptr members = the threaded walk)
 void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide);  // one flatten_custom tree (ordering 0) -> its records
+// what WideTrees::spill must hold: wide_trace_lanes(compute_units) x wide_spill_entries() u32 (the lanes of the persistent trace launch
+// x the stack entries a lane keeps beyond LDS) - asked of the file that launches the kernel, so that the two cannot disagree
+size_t wide_trace_lanes(int compute_units);
+size_t wide_spill_entries();
 void launch_indirect_wavefront(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                                const hkd::WfBuffers& w, int y0, int y1, int compute_units, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
                                const hkd::WideTrees* wide = nullptr);

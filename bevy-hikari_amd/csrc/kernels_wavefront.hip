@@ -989,6 +989,8 @@ __global__ __launch_bounds__(256, 4) void k_wf_final(DScene sc, DFrame fr, GBuff
 namespace hk {
 using namespace hkd;
 
+size_t wide_trace_lanes(int compute_units) { return (size_t)compute_units * HK_WF_WIDE_WAVES * 256u; }  // = the grid of k_wf_trace_wide below
+size_t wide_spill_entries() { return HK_WIDE_SPILL; }
 void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide) {
   if (count) hipLaunchKernelGGL(k_build_wide, dim3((count + 255u) / 256u), dim3(256), 0, st, nodes, count, wide);
 }
