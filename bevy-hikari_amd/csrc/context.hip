@@ -400,18 +400,24 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
     HK_HIP(hipMalloc((void**)&c->wide_spill, lanes * wide_spill_entries() * sizeof(uint32_t)));
     c->wide_spill_lanes = lanes;
   }
-  if (c->wide_blas_dirty) {  // one launch per mesh tree (links are local to a tree): once per mesh-level build
-    std::vector<uint8_t> seen;
+  if (c->wide_blas_dirty || c->wide_mesh_check) {
+    // one launch per mesh tree (links are local to a tree): all of them after a mesh-level build, and after a change of the instance
+    // SET the ones no instance used before (a mesh uploaded ahead of its first instance has no records until then)
+    if (c->wide_blas_dirty) c->wide_meshes.clear();
     std::vector<std::pair<uint32_t, uint32_t>> meshes;
     for (const HkInstance& in : c->instances) meshes.emplace_back(in.mesh.node_offset, in.mesh.node_count);
     std::sort(meshes.begin(), meshes.end());
     meshes.erase(std::unique(meshes.begin(), meshes.end()), meshes.end());
     for (const auto& m : meshes) {
+      if (std::binary_search(c->wide_meshes.begin(), c->wide_meshes.end(), m)) continue;
       HK_REQUIRE((size_t)m.first + m.second <= blas_slots, HK_E_INVALID, "an instance's mesh nodes lie outside the uploaded mesh nodes");
       launch_build_wide(c->stream, c->scene.nodes + 2u * ((size_t)c->scene.blas_base + m.first), m.second, c->wide_blas + 8u * (size_t)m.first);
     }
     HK_HIP(hipGetLastError());
-    c->wide_blas_dirty = false;
+    std::vector<std::pair<uint32_t, uint32_t>> all;
+    std::set_union(c->wide_meshes.begin(), c->wide_meshes.end(), meshes.begin(), meshes.end(), std::back_inserter(all));
+    c->wide_meshes.swap(all);
+    c->wide_blas_dirty = c->wide_mesh_check = false;
   }
   if (c->wide_tlas_dirty) {
     launch_build_wide(c->stream, c->scene.nodes, (uint32_t)tlas_slots, c->wide_tlas);

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <iterator>
 #include <chrono>
 #include <new>
 #include <thread>
@@ -219,6 +220,8 @@ struct hk_ctx {
   uint32_t* wide_spill = nullptr;
   size_t wide_tlas_slots = 0, wide_blas_slots = 0, wide_spill_lanes = 0;
   bool wide_tlas_dirty = true, wide_blas_dirty = true;
+  bool wide_mesh_check = true;                                  // the instance SET changed: a mesh no instance used before may have none yet
+  std::vector<std::pair<uint32_t, uint32_t>> wide_meshes;       // (node_offset, node_count) of the mesh trees whose records exist, sorted
   int compute_units = 0;
 
   // uniforms

@@ -619,6 +619,7 @@ int finalize_scene(hk_ctx* c) {
   c->static_rebuilds += need_static ? 1 : 0;
   c->dynamic_rebuilds += 1;
   c->wide_tlas_dirty = true;                       // (the wide records follow the trees: context.hip ensure_wide)
+  c->wide_mesh_check = true;                       // (... and the instance set may now use a mesh tree that has no records yet)
   if (need_static) c->wide_blas_dirty = true;
   return HK_OK;
 }

@@ -406,6 +406,37 @@ def test_stand_in_trees_only_reach_the_device_through_the_update_that_rebuilds_t
     assert same_links(got[0], full.instance_nodes) and same_links(got[1], full.emissive_nodes)
     e.api.call("upload_scene_instances", e.ctx, b.h)   # a fully finished builder is welcome again
 
+def test_a_mesh_first_instanced_by_a_later_edit_gets_its_wide_records():
+    """The wide walk's mesh-tree records are derived per mesh an instance uses.  A mesh that is uploaded but not instanced (the quad
+    strip of a yard without emitters) has none - until an instance edit puts one in the scene: the update must derive them then, not
+    only after a mesh-level upload.  Product default traversal (wide walk + queue-based indirect pass) against the oracle, every frame."""
+    from cases import assert_rendered_within
+
+    kw = dict(n_boxes=20, n_spheres=5, n_emitters=0, sphere_rings=12, sphere_segs=16)   # beyond the LDS copy; mesh 2 (the quad strip) unused
+    dev_scene, sun = synthetic_scene(**kw)
+    ref_scene, _ = synthetic_scene(**kw)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam, lights = synthetic_camera(160, 96), hk.lights_uniform(directional=sun)
+    with product_default_traversal():
+        gpu = hk.HikariPlugin(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)
+    cpu = oracle()
+    gpu.set_scene(dev_scene)
+    cpu.set_scene(ref_scene)
+    for n in (1, 2, 3, 4):
+        if n == 3:   # a big quad across the yard, a metre up: most rays now meet the mesh that had no instance
+            for b in (dev_scene.builder, ref_scene.builder):
+                b.add_instance(2, 3, _pose_matrix((0.0, 1.0, 0.0), 0.4, (3.0, 1.0, 3.0)))
+            gpu.engine.update_instances_on_device(dev_scene.builder, F.TREE_SAH)
+            cpu.update_instances(ref_scene.builder.finish())
+        for p in (gpu, cpu):
+            p.render(cam, s, lights=lights, frame_number=n)
+        assert_rendered_within(snapshot(gpu), snapshot(cpu), f"frame {n}")
+    assert gpu.engine.wide_walk() and gpu.engine.indirect_schedule() == "wavefront" and gpu.engine.stats().wide_stack_lost == 0
+    quad = len(ref_scene.builder.finish().instances) - 1   # (the plane holds instance + 0.5; 0 = background)
+    seen = [float((p.engine.read(F.BUF_INSTANCE_MATERIAL)[..., 0] == quad + 0.5).mean()) for p in (gpu, cpu)]
+    assert seen[0] == seen[1] and seen[1] > 0.005, seen   # ... and primary rays see it, the same pixels as the oracle's
+
+
 
 def _pose_matrix(t, yaw, scale):
     c, s = math.cos(yaw), math.sin(yaw)
