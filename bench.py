@@ -133,15 +133,12 @@ def main():
             # launcher does); the ranks' exit code and rank 0's JSON line pass straight through
             if "HIKARI_BENCH_DEVICE" not in os.environ and torch.cuda.device_count() < args.gpus:
                 sys.exit(f"bench.py --gpus {args.gpus}: this node exposes {torch.cuda.device_count()} GPU(s)")
-            import socket
             import subprocess
 
-            sock = socket.socket()
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-            sock.close()
-            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            # --standalone: the launcher binds a port of its own on 127.0.0.1 (a port picked here by bind / close can be taken before the
+            # launcher binds it)
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   os.path.abspath(__file__)] + sys.argv[1:]
             sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode)
         args.gpus = world
     # Test hooks (tests/test_bench_ranks.py): HIKARI_BENCH_TRANSPORT=host + HIKARI_BENCH_DEVICE=0 run every rank on ONE GPU with
