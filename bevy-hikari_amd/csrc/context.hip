@@ -389,6 +389,20 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
     c->wide_blas_slots = blas_slots;
     c->wide_blas_dirty = true;
   }
+  // the leaves' ranks (hk_kernels.hpp WideTrees): one u32 per instance / per primitive, written with the records
+  const size_t n_inst = c->instances.size(), n_prim = c->primitives.size();
+  if (n_inst > c->wide_rank_instances) {
+    if (c->wide_tlas_rank) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_tlas_rank); c->wide_tlas_rank = nullptr; }
+    HK_HIP(hipMalloc((void**)&c->wide_tlas_rank, (n_inst + n_inst / 2 + 16) * sizeof(uint32_t)));
+    c->wide_rank_instances = n_inst + n_inst / 2 + 16;
+    c->wide_tlas_dirty = true;
+  }
+  if (n_prim > c->wide_rank_primitives) {
+    if (c->wide_blas_rank) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_blas_rank); c->wide_blas_rank = nullptr; }
+    HK_HIP(hipMalloc((void**)&c->wide_blas_rank, std::max<size_t>(n_prim, 1) * sizeof(uint32_t)));
+    c->wide_rank_primitives = n_prim;
+    c->wide_blas_dirty = true;
+  }
   if (!c->compute_units) {
     hipDeviceProp_t prop;
     HK_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -405,13 +419,21 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
     // SET the ones no instance used before (a mesh uploaded ahead of its first instance has no records until then)
     if (c->wide_blas_dirty) c->wide_meshes.clear();
     std::vector<std::pair<uint32_t, uint32_t>> meshes;
-    for (const HkInstance& in : c->instances) meshes.emplace_back(in.mesh.node_offset, in.mesh.node_count);
+    std::vector<std::pair<uint32_t, uint32_t>> first_primitive;  // (node_offset, the mesh's first primitive): a triangle leaf's id is local to its mesh
+    for (const HkInstance& in : c->instances) {
+      meshes.emplace_back(in.mesh.node_offset, in.mesh.node_count);
+      first_primitive.emplace_back(in.mesh.node_offset, in.mesh.primitive);
+    }
     std::sort(meshes.begin(), meshes.end());
     meshes.erase(std::unique(meshes.begin(), meshes.end()), meshes.end());
+    std::sort(first_primitive.begin(), first_primitive.end());
     for (const auto& m : meshes) {
       if (std::binary_search(c->wide_meshes.begin(), c->wide_meshes.end(), m)) continue;
       HK_REQUIRE((size_t)m.first + m.second <= blas_slots, HK_E_INVALID, "an instance's mesh nodes lie outside the uploaded mesh nodes");
-      launch_build_wide(c->stream, c->scene.nodes + 2u * ((size_t)c->scene.blas_base + m.first), m.second, c->wide_blas + 8u * (size_t)m.first);
+      const uint32_t prim0 = std::lower_bound(first_primitive.begin(), first_primitive.end(), std::make_pair(m.first, 0u))->second;
+      // (a tree of L leaves has 3 L - 2 nodes: its leaf ids stay below (node_count + 2) / 3)
+      HK_REQUIRE((size_t)prim0 + (m.second + 2u) / 3u <= n_prim, HK_E_INVALID, "an instance's mesh primitives lie outside the uploaded primitives");
+      launch_build_wide(c->stream, c->scene.nodes + 2u * ((size_t)c->scene.blas_base + m.first), m.second, c->wide_blas + 8u * (size_t)m.first, c->wide_blas_rank + prim0);
     }
     HK_HIP(hipGetLastError());
     std::vector<std::pair<uint32_t, uint32_t>> all;
@@ -420,7 +442,7 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
     c->wide_blas_dirty = c->wide_mesh_check = false;
   }
   if (c->wide_tlas_dirty) {
-    launch_build_wide(c->stream, c->scene.nodes, (uint32_t)tlas_slots, c->wide_tlas);
+    launch_build_wide(c->stream, c->scene.nodes, (uint32_t)tlas_slots, c->wide_tlas, c->wide_tlas_rank);
     HK_HIP(hipGetLastError());
     c->wide_tlas_dirty = false;
   }
@@ -434,6 +456,8 @@ int wide_for_fused(hk_ctx* c, hkd::WideTrees* out) {
   if (rc) return rc;
   out->tlas = c->wide_tlas;
   out->blas = c->wide_blas;
+  out->tlas_rank = c->wide_tlas_rank;
+  out->blas_rank = c->wide_blas_rank;
   out->tlas_count = c->scene.tlas_count;
   out->spill = nullptr;
   out->lost = c->d_counters + 8;
@@ -543,6 +567,8 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
           { const int rc_ = ensure_wide(c, true); if (rc_) return rc_; }
           wide.tlas = c->wide_tlas;
           wide.blas = c->wide_blas;
+          wide.tlas_rank = c->wide_tlas_rank;
+          wide.blas_rank = c->wide_blas_rank;
           wide.tlas_count = c->scene.tlas_count;
           wide.spill = c->wide_spill;
           wide.lost = c->d_counters + 8;
@@ -744,7 +770,7 @@ void hk_destroy(hk_ctx* c) {
     if (c->staging_done[k]) (void)hipEventDestroy(c->staging_done[k]);
   }
   free_refit(c);
-  for (void* q : {(void*)c->wide_tlas, (void*)c->wide_blas, (void*)c->wide_spill})
+  for (void* q : {(void*)c->wide_tlas, (void*)c->wide_blas, (void*)c->wide_spill, (void*)c->wide_tlas_rank, (void*)c->wide_blas_rank})
     if (q) (void)hipFree(q);
   c->d_tex_data.release();
   c->d_noise.release();

@@ -218,6 +218,9 @@ struct hk_ctx {
   float4* wide_tlas = nullptr;
   float4* wide_blas = nullptr;
   uint32_t* wide_spill = nullptr;
+  uint32_t* wide_tlas_rank = nullptr;   // [instance] / [primitive]: the position of its leaf in ordering 0 (the reference's tie rule)
+  uint32_t* wide_blas_rank = nullptr;
+  size_t wide_rank_instances = 0, wide_rank_primitives = 0;
   size_t wide_tlas_slots = 0, wide_blas_slots = 0, wide_spill_lanes = 0;
   bool wide_tlas_dirty = true, wide_blas_dirty = true;
   bool wide_mesh_check = true;                                  // the instance SET changed: a mesh no instance used before may have none yet

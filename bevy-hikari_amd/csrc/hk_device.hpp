@@ -428,12 +428,19 @@ HKD f3 local_to_world_normal(const DInstance& in, f3 n) {  // light.wgsl:324-338
 // sign pattern of a ray direction: selects the flattening whose child order is the one this ray meets (strides 0: always 0)
 HKD uint32_t ray_octant(f3 d) { return (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u); }
 
-// stackless skip-link walk of one BLAS, light.wgsl:400-440
+// stackless skip-link walk of one BLAS, light.wgsl:400-440.  Its one stand-alone caller is the closest hit on the sampled EMITTER's own
+// mesh (select_light_candidate, light.wgsl:687): round 5 walks it in the reference's order (ordering 0) whatever the ray's octant -
+// two triangles of the emitter that tie exactly (a sampled point on a shared edge) then resolve as in the reference, and with the
+// wide walk's rank rule (hk_wide.hpp) and traverse_top<true> every hit of the product default is the reference's.
+// HK_EMITTER_WALK_REF_ORDER=0 is the A/B (the octant's ordering: the visits front to back).
+#ifndef HK_EMITTER_WALK_REF_ORDER
+#define HK_EMITTER_WALK_REF_ORDER 1
+#endif
 HKD bool traverse_bottom(const DScene& sc, Hit& hit, const Ray& ray, uint32_t node_offset, uint32_t node_count, uint32_t primitive_offset,
                          float early_distance, RayCounters& rc) {
   bool intersected = false;
   uint32_t index = 0u;
-  const uint32_t nbase = sc.blas_base + ray_octant(ray.direction) * sc.blas_stride + node_offset;
+  const uint32_t nbase = sc.blas_base + (HK_EMITTER_WALK_REF_ORDER ? 0u : ray_octant(ray.direction) * sc.blas_stride) + node_offset;
   while (index < node_count) {
     const float4* __restrict__ nd = sc.nodes + 2u * (nbase + index);
     const float4 lo = nd[0];
@@ -487,6 +494,7 @@ extern __device__ unsigned long long g_walk_events[8];  // wave-iterations: all,
 #ifndef HK_FLAT_CAP
 #define HK_FLAT_CAP 2
 #endif
+template <bool REF_ORDER = false>
 HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, RayCounters& rc) {
   rc.tlas++;
   Hit hit;
@@ -499,7 +507,7 @@ HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, floa
   lr.origin = world_to_local_position(in0, ray.origin);
   lr.direction = world_to_local_direction(in0, ray.direction);
   lr.inv_direction = 1.0f / lr.direction;
-  const float4* __restrict__ nodes = sc.flat + 2u * ((ray_octant(lr.direction) & sc.flat_mask) * sc.flat_count);
+  const float4* __restrict__ nodes = sc.flat + 2u * (REF_ORDER ? 0u : (ray_octant(lr.direction) & sc.flat_mask) * sc.flat_count);
 #ifdef HK_FLAT_FMA_SLAB
   const f3 noi = F3(-lr.origin.x * lr.inv_direction.x, -lr.origin.y * lr.inv_direction.y, -lr.origin.z * lr.inv_direction.z);
 #endif
@@ -599,8 +607,16 @@ HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, floa
 // same load + slab-test stream instead of serialising nested loops under partial exec masks.  Only
 // the two rare events diverge: entering an instance (ray transform) and a triangle test.  Each
 // lane's own visit order, and therefore every result bit, is that of the reference's nested loops.
+// REF_ORDER (round 5): the walk takes ordering 0 - the REFERENCE's own child order (scene_layout.hip thread_orderings) - on both
+// levels, whatever the ray's octant.  For the any-hit rays whose OCCLUDER is kept: direct_lit stores the occluder's position as the
+// reservoir's sample_position (light.wgsl:526-533, 1117-1130), and a later validation frame shoots its ray at that position
+// (light.wgsl:1156-1170).  Which occluder an any-hit walk reports - the first it meets - depends on the order of the visits; in any
+// other order than the reference's the validation rays, and through them the reservoirs, drift away from the reference's
+// (profiles/r05_default_mode_sequence_*: the emissive channel 1.6e-2 off after 30 frames).  An unoccluded ray visits the same boxes
+// in any order, so only rays that do find an occluder pay for not meeting it front to back.
+template <bool REF_ORDER = false>
 HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, RayCounters& rc) {
-  if (sc.flat_mode) return traverse_flat(sc, ray, max_distance, early_distance, exclude_instance, rc);
+  if (sc.flat_mode) return traverse_flat<REF_ORDER>(sc, ray, max_distance, early_distance, exclude_instance, rc);
   rc.tlas++;
 #ifdef HK_PROFILE_SECTIONS
   uint32_t wev_[5] = {0u, 0u, 0u, 0u, 0u};
@@ -618,7 +634,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
   hit.instance_index = HK_U32_MAX;
   hit.primitive_index = HK_U32_MAX;
   // cursor of the level being walked: node = nodes[base + index], index < limit
-  const uint32_t tlas_base = ray_octant(ray.direction) * sc.tlas_stride;
+  const uint32_t tlas_base = REF_ORDER ? 0u : ray_octant(ray.direction) * sc.tlas_stride;
   uint32_t index = 0u, limit = sc.tlas_count, base = tlas_base;
   uint32_t t_resume = 0u;  // TLAS index to continue with when the current BLAS is exhausted
   uint32_t prim_base = 0u, cur_instance = 0u;
@@ -716,7 +732,7 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
             cinv = 1.0f / ld;
           }
           t_resume = index;
-          base = sc.blas_base + ray_octant(ld) * sc.blas_stride + in.node_offset;
+          base = sc.blas_base + (REF_ORDER ? 0u : ray_octant(ld) * sc.blas_stride) + in.node_offset;
           index = 0u;
           limit = in.node_count;
           prim_base = in.primitive;

@@ -84,9 +84,15 @@ struct WfBuffers {
 // (triangle of the mesh / instance), < HK_LEAF = position of an inner node (its record), 0xFFFFFFFF = no child.  The record of a
 // tree's root (which flatten_custom does not store) sits in the tree's LAST slot (always a leaf's).  ONE ordering: the walk keeps
 // a per-lane stack and takes the children nearest first, so the eight direction-threaded copies are not needed here.
+// Ranks (round 5): the position of every leaf in the REFERENCE's own flattening (ordering 0) - the order in which the reference's
+// stackless walk meets the leaves.  Of two candidates at exactly the same distance the reference keeps the one it meets first
+// (light.wgsl:415-424: `<`), i.e. the one of smaller rank - instance leaves first, then triangle leaves inside the instance; the
+// wide walk, which meets them nearest-box first, decides the tie by the ranks and so returns the reference's hit, bit for bit.
 struct WideTrees {
   const float4* tlas;   // records of the instance tree: 8 float4 per slot, tlas_count slots
   const float4* blas;   // records of every mesh tree: slot node_offset + local position
+  const uint32_t* tlas_rank;  // [instance] position of its leaf in the instance tree (ordering 0)
+  const uint32_t* blas_rank;  // [primitive] position of its leaf in its mesh tree (ordering 0)
   uint32_t tlas_count;  // (its root: slot tlas_count - 1)
   unsigned long long* lost;  // counts stack entries that fit neither part (HkStats::wide_stack_lost)
   uint32_t* spill;      // stack entries beyond the LDS part: HK_WIDE_SPILL u32 per lane of the persistent launch (the trace stage;
@@ -273,7 +279,7 @@ void launch_indirect(hipStream_t st, bool multiple_bounces, const hkd::DScene& s
                      const hkd::LightTargets& t, int y0, int y1, unsigned long long* counters, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
 // the same dispatch as launch_indirect(multiple_bounces = true), scheduled through ray queues (kernels_wavefront.hip)
 // wide: records of the trees for the trace stages (nullptr members = the threaded walk)
-void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide);  // one flatten_custom tree (ordering 0) -> its records
+void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide, uint32_t* rank);  // one flatten_custom tree (ordering 0) -> its records; rank[leaf id] = the leaf's position
 // what WideTrees::spill must hold: wide_trace_lanes(compute_units) x wide_spill_entries() u32 (the lanes of the persistent trace launch
 // x the stack entries a lane keeps beyond LDS) - asked of the file that launches the kernel, so that the two cannot disagree
 size_t wide_trace_lanes(int compute_units);

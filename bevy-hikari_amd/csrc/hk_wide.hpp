@@ -1,9 +1,11 @@
 // hk_wide.hpp - the wide walk (round 4; DESIGN 4 "Wide walk", 8.1): BVH traversal over 128-B records of an inner node's four
 // grandchildren (hk_kernels.hpp WideTrees, built by kernels_wavefront.hip k_build_wide), nearest child first, with a per-lane stack.
 // Shared by the queue-based trace stage (k_wf_trace_wide) and the fused kernels' walks of scenes in global memory
-// (traverse_top_wide).  Same candidates and the same per-triangle arithmetic on the same operands as traverse_top (hk_device.hpp):
-// the closest hit is the reference's except where two candidates tie exactly; an any-hit ray's outcome does not depend on the
-// order.  The reference's order (HK_CTX_EXACT_TRAVERSAL) never comes here.
+// (traverse_top_wide).  Same candidates and the same per-triangle arithmetic on the same operands as traverse_top (hk_device.hpp),
+// and (round 5) the reference's own rule for two candidates at exactly the same distance (wide_tie_goes_to: the leaf the reference's
+// walk meets first): the closest hit IS the reference's; an any-hit ray's outcome - occluded or not - does not depend on the order
+// (WHICH occluder it reports does: rays whose occluder is kept walk the reference's order, hk_device.hpp traverse_top<true>).
+// The reference's order (HK_CTX_EXACT_TRAVERSAL) never comes here.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -178,7 +180,13 @@ __device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, 
   k.cur = link[0];
   return PH_NODE;
 }
-__device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, uint32_t pending) {
+// the reference's tie rule between two candidates at exactly the same distance: the one its stackless walk meets first wins, i.e. the
+// leaf of smaller position in ordering 0 - instance leaves first, triangle leaves inside one instance (hk_kernels.hpp WideTrees ranks)
+__device__ __forceinline__ bool wide_tie_goes_to(const WideTrees& wt, uint32_t instance, uint32_t primitive, uint32_t best_instance, uint32_t best_primitive) {
+  if (instance != best_instance) return wt.tlas_rank[instance] < wt.tlas_rank[best_instance];
+  return wt.blas_rank[primitive] < wt.blas_rank[best_primitive];
+}
+__device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, const WideTrees& wt, uint32_t pending) {
   const uint32_t primitive_index = k.prim_base + pending;
   Ray lr;
   lr.origin = k.co;
@@ -186,13 +194,13 @@ __device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc,
   lr.inv_direction = k.cinv;
   f2 uv;
   const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
-  // closest hit; of two candidates at EXACTLY the same distance the one with the smaller (instance, primitive) wins - whichever
-  // the walk met first (the reference keeps the first it meets in ITS order, which no other order reproduces; a rule of its own makes
-  // the result independent of the order, of how the walk was split among lanes, and of timing)
+  // closest hit; of two candidates at EXACTLY the same distance the reference keeps the first its walk meets (light.wgsl:415-424) -
+  // the leaf of smaller rank, whichever this walk met first: the result is the reference's, and it depends neither on the order of
+  // the visits, nor on how the walk was split among lanes, nor on timing
   bool closer = d < k.hit.distance;
   if (d == k.hit.distance && k.hit.primitive_index != HK_U32_MAX) {
     const uint32_t best_instance = k.intersected ? k.cur_instance : k.hit.instance_index;
-    closer = k.cur_instance < best_instance || (k.cur_instance == best_instance && primitive_index < k.hit.primitive_index);
+    closer = wide_tie_goes_to(wt, k.cur_instance, primitive_index, best_instance, k.hit.primitive_index);
   }
   if (closer) {
     k.hit.uv = uv;
@@ -239,7 +247,7 @@ __device__ __forceinline__ Hit traverse_top_wide(const DScene& sc, const WideTre
     }
     if (phase == PH_TRI) {
       rc.tris++;
-      phase = wide_triangle(k, sc, pending);
+      phase = wide_triangle(k, sc, wt, pending);
     } else if (phase == PH_ENTRY) {
       rc.entries++;
       wide_enter(k, sc, st, pending);

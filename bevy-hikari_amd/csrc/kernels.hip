@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, (LDS == 0 ? HK_DIRECT_GLOBAL_WAVES : 1)) void 
         trace_condition = trace_condition && candidate.p > 0.0f;
         if (EMISSIVE_LIT) trace_condition = trace_condition && candidate.emissive_instance != HK_DONT_SAMPLE_EMISSIVE;
         if (trace_condition) {
-          Hit hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+          Hit hit = traverse_top<true>(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);  // (the occluder is KEPT: the reference's order, hk_device.hpp)
           occlude_hit_info(ray, hit, info);
           s.radiance = EMISSIVE_LIT ? input_radiance(sc, fr, ray, info, false, candidate.emissive_instance, false)
                                     : input_radiance(sc, fr, ray, info, true, HK_DONT_SAMPLE_EMISSIVE, false);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, (LDS == 0 ? HK_DIRECT_GLOBAL_WAVES : 1)) void 
         trace_condition = trace_condition && candidate.p > 0.0f;
         if (EMISSIVE_LIT) trace_condition = trace_condition && candidate.emissive_instance != HK_DONT_SAMPLE_EMISSIVE;
         if (trace_condition) {
-          Hit hit = traverse_top(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);
+          Hit hit = traverse_top<true>(sc, ray, candidate.max_distance, candidate.min_distance, candidate.emissive_instance, rc);  // (the occluder is KEPT: the reference's order, hk_device.hpp)
           occlude_hit_info(ray, hit, info);
           validate_radiance = EMISSIVE_LIT ? input_radiance(sc, fr, ray, info, false, candidate.emissive_instance, false)
                                            : input_radiance(sc, fr, ray, info, true, HK_DONT_SAMPLE_EMISSIVE, false);

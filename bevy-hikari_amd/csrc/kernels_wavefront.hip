@@ -441,15 +441,20 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
 // children are visited is not stored but decided per ray - nearest first - with a per-lane stack: 28 entries in LDS (entry-major:
 // conflict-free), the rest in a global spill area.  Same candidates, same per-triangle arithmetic on the same operands as
 // traverse_top: the closest hit is the reference's except where two candidates tie exactly (the product default's bar, like the
-// threaded orderings; hk_wide.hpp wide_triangle decides ties by a rule of its own - the smaller (instance, primitive) - so that the
-// result does not depend on the order of the visits); an any-hit ray's outcome - occluded or not - does not depend on the order at all.
+// threaded orderings WAS; since round 5 hk_wide.hpp wide_triangle decides ties by the REFERENCE's rule - the leaf its walk meets first,
+// from the leaves' ranks in ordering 0 - so the closest hit is the reference's, whatever the order of the visits); an any-hit ray's
+// outcome - occluded or not - does not depend on the order at all.
 // one thread per slot of ONE tree (ordering 0; links local to the tree): the record of the inner node at that slot, and - in the
 // last slot - the root's
-__global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ nodes, uint32_t count, float4* __restrict__ wide) {
+__global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ nodes, uint32_t count, float4* __restrict__ wide, uint32_t* __restrict__ rank) {
   const uint32_t x = blockIdx.x * 256u + threadIdx.x;
   if (x >= count) return;
   auto entry_of = [&](uint32_t i) { return f2u(nodes[2u * i].w); };
   auto exit_of = [&](uint32_t i) { return f2u(nodes[2u * i + 1u].w); };
+  // the rank of a leaf = its position in this (the reference's) flattening: the order in which the reference's walk meets the
+  // leaves (hk_kernels.hpp WideTrees).  A folded navigator (scene_layout.hip fold_leaf_navigators) carries its leaf's id one slot
+  // ahead of the leaf's own, never visited slot: the navigator's position is the leaf's.
+  if (entry_of(x) >= HK_LEAF && !(x > 0u && entry_of(x - 1u) == entry_of(x))) rank[entry_of(x) - HK_LEAF] = x;
   const bool is_root = x + 1u == count;
   if (!is_root && entry_of(x) >= HK_LEAF) return;  // a leaf (or a leaf's unused slot) has no record
   float4 rec[8];
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
           // (the root may be inside a mesh tree with a hit of its own there: that hit's instance is cur_instance until it leaves)
           const uint32_t mine_inst = k.intersected ? k.cur_instance : k.hit.instance_index;
           bool closer = h_d < k.hit.distance;
-          if (h_d == k.hit.distance && k.hit.primitive_index != HK_U32_MAX) closer = h_inst < mine_inst || (h_inst == mine_inst && h_prim < k.hit.primitive_index);
+          if (h_d == k.hit.distance && k.hit.primitive_index != HK_U32_MAX) closer = wide_tie_goes_to(wt, h_inst, h_prim, mine_inst, k.hit.primitive_index);
           if (closer) {
             k.hit.distance = h_d;
             k.hit.uv = F2(h_u, h_v);
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     if (all_phases ? n_tri != 0u : (!(n_node >= n_tri && n_node >= n_entry && n_node != 0u) && n_tri >= n_entry)) {
       if (phase == PH_TRI) {
         const float before = k.hit.distance;
-        phase = wide_triangle(k, sc, pending);
+        phase = wide_triangle(k, sc, wt, pending);
 #if HK_WF_WIDE_SHARE
         if (dry && k.hit.distance < before) atomicMin(&share_best[(threadIdx.x & ~63u) + root], f2u(k.hit.distance));  // (distances are >= 0: their bits order like they do)
 #endif
@@ -991,8 +996,8 @@ using namespace hkd;
 
 size_t wide_trace_lanes(int compute_units) { return (size_t)compute_units * HK_WF_WIDE_WAVES * 256u; }  // = the grid of k_wf_trace_wide below
 size_t wide_spill_entries() { return HK_WIDE_SPILL; }
-void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide) {
-  if (count) hipLaunchKernelGGL(k_build_wide, dim3((count + 255u) / 256u), dim3(256), 0, st, nodes, count, wide);
+void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide, uint32_t* rank) {
+  if (count) hipLaunchKernelGGL(k_build_wide, dim3((count + 255u) / 256u), dim3(256), 0, st, nodes, count, wide, rank);
 }
 
 void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,

@@ -37,6 +37,12 @@
 extern "C" {
 #endif
 
+/* libhikari_hip.so is built with -fvisibility=hidden (tools/build_lib.py): the entry points declared between this push and the pop at
+ * the end of the header - and the hooks of hikari_hip_debug.h - are ALL it exports; a host that links it sees no internal symbol. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #define HK_ABI_VERSION 7
 
 /* ------------------------------------------------------------------ error codes */
@@ -797,6 +803,9 @@ int hk_traversal_mode(hk_ctx* ctx, uint32_t* out, uint32_t* orderings);
 
 /* Test and measurement hooks (hk_debug_*, hk_measure_*) are declared in hikari_hip_debug.h: a host that renders binds none of them. */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* (exported next to the boundary's entry points; everything else in the library is hidden) */
+#endif
 
 /* Test hook: the instance tree (ordering 0) and the light tree as the device holds them, in the reference's HkNode layout. */
 int hk_debug_read_trees(hk_ctx* ctx, HkNode* instance_nodes, uint32_t instance_cap, HkNode* emissive_nodes, uint32_t emissive_cap);
@@ -54,6 +57,9 @@ int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer
                                             frame (hk_frame_render with HK_FRAME_GATHER) - complete before the frame of the same parity begins or
                                             anybody reads a buffer */);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -464,15 +464,17 @@ def test_config5_full_4k_8_bounces_vs_oracle():
 
 
 def _threaded_vs_exact(name, scene, cam, s, lights, frames, tol_pixels):
-    """The product default for scenes beyond the LDS copy - eight direction-ordered flattenings of every TLAS / BLAS, each ray
-    walking the one of its octant - against HK_CTX_EXACT_TRAVERSAL (the reference's single order, bit-exact vs the oracle in the
-    tests above) on the same frames: the north star's 1e-3 relative L2 on the output, and the fraction of pixels whose primary
-    hit (instance id) or any G-buffer byte differs - exact ties between two candidates are the only thing the order can change."""
+    """The product default for scenes beyond the LDS copy (flags 0, NO ray counters - HK_CTX_COUNT_RAYS would switch the queue-based
+    schedule off, context.hip use_wavefront: the kernels bench.py times are the ones that run here: direction-threaded trees, the
+    wavefront schedule of the indirect pass, the wide walk) against HK_CTX_EXACT_TRAVERSAL (the reference's single order, bit-exact vs
+    the oracle in the tests above) on the same frames: the north star's 1e-3 relative L2 on the output, and the fraction of pixels
+    whose primary hit (instance id) or any G-buffer byte differs - exact ties between two candidates are the only thing the order
+    can change."""
     from cases import product_default_traversal
 
     exact = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS)
     with product_default_traversal():
-        fast = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS)
+        fast = hk.HikariPlugin(device=0)
     for p in (exact, fast):
         p.set_scene(scene)
     for n in frames:
@@ -484,10 +486,11 @@ def _threaded_vs_exact(name, scene, cam, s, lights, frames, tol_pixels):
     pa, pb = fast.engine.read(F.BUF_POSITION), exact.engine.read(F.BUF_POSITION)
     hit_diff = float((ia[..., 0] != ib[..., 0]).mean())
     pos_diff = float((pa.view(np.uint32) != pb.view(np.uint32)).any(axis=2).mean())
-    sf, se = fast.engine.stats(), exact.engine.stats()
-    report = {"case": name, "traversal": list(fast.engine.traversal_mode()), "rel_l2": rel, "primary_hit_instance_differs": hit_diff,
-              "gbuffer_position_differs": pos_diff, "rays": [int(sf.rays_tlas + sf.rays_blas), int(se.rays_tlas + se.rays_blas)]}
+    se = exact.engine.stats()
+    report = {"case": name, "traversal": list(fast.engine.traversal_mode()), "schedule": fast.engine.indirect_schedule(), "wide_walk": bool(fast.engine.wide_walk()),
+              "rel_l2": rel, "primary_hit_instance_differs": hit_diff, "gbuffer_position_differs": pos_diff, "rays_exact": int(se.rays_tlas + se.rays_blas)}
     assert fast.engine.traversal_mode()[0] == "threaded" and exact.engine.traversal_mode()[0] == "reference"
+    assert fast.engine.indirect_schedule() == "wavefront" and fast.engine.wide_walk() and fast.engine.stats().wide_stack_lost == 0
     print("threaded vs exact traversal:", report)
     out_dir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out_dir):

@@ -12,6 +12,14 @@ IDLE, NODE, TRI, ENTRY, WAIT, HELPED = 0, 1, 2, 3, 4, 5
 STACK = 124
 
 
+def tie_goes_to(sc, instance, primitive, best_instance, best_primitive):
+    """hk_wide.hpp wide_tie_goes_to: the reference's rule - the candidate its stackless walk meets first, by the leaves' ranks."""
+    if instance != best_instance:
+        return sc.tlas_rank[instance] < sc.tlas_rank[best_instance]
+    I = sc.instances[instance]
+    return I["rank"][primitive - I["primitive"]] < I["rank"][best_primitive - I["primitive"]]
+
+
 def slab_t(mn, mx, o, inv):
     with np.errstate(invalid="ignore", over="ignore"):
         t1, t2 = (mn - o) * inv, (mx - o) * inv
@@ -113,7 +121,7 @@ class Lane:
         closer = d < self.hit[0]
         if d == self.hit[0] and self.hit[2] != U32_MAX:
             best_instance = self.cur_instance if self.intersected else self.hit[1]
-            closer = self.cur_instance < best_instance or (self.cur_instance == best_instance and prim < self.hit[2])
+            closer = tie_goes_to(sc, self.cur_instance, prim, best_instance, self.hit[2])
         if closer:
             self.hit[0], self.hit[2] = d, prim
             self.intersected = True
@@ -178,7 +186,7 @@ class Wave:
                 mine_inst = r.cur_instance if r.intersected else r.hit[1]
                 closer = h.hit[0] < r.hit[0]
                 if h.hit[0] == r.hit[0] and r.hit[2] != U32_MAX:
-                    closer = h.hit[1] < mine_inst or (h.hit[1] == mine_inst and h.hit[2] < r.hit[2])
+                    closer = tie_goes_to(self.sc, h.hit[1], h.hit[2], mine_inst, r.hit[2])
                 if closer:
                     r.hit = list(h.hit)
                     r.intersected = False

@@ -104,8 +104,18 @@ class Scene:
             sl = slice(m.node_offset, m.node_offset + m.node_count)
             tree = tuple(a[sl] for a in an)
             model = np.array(list(i.model), dtype=np.float64).reshape(4, 4).T   # column-major in the struct
-            self.instances.append({"tree": tree, "wide": build_wide(*tree), "inverse": np.linalg.inv(model), "primitive": int(m.primitive)})
+            # the rank of a leaf = its position in the reference's flattening: the order in which the reference's stackless walk meets
+            # the leaves (hk_kernels.hpp WideTrees; k_build_wide writes them)
+            rank = {int(e - LEAF): pos for pos, e in enumerate(tree[2]) if e >= LEAF}
+            self.instances.append({"tree": tree, "wide": build_wide(*tree), "inverse": np.linalg.inv(model), "primitive": int(m.primitive), "rank": rank})
+        self.tlas_rank = {int(e - LEAF): pos for pos, e in enumerate(self.tlas[2]) if e >= LEAF}
         self.prims = prims
+
+    def key(self, inst, ident):
+        """What decides a tie between two candidates at exactly the same distance - the REFERENCE's rule (round 5): the leaf its walk
+        meets first, i.e. (rank of the instance's leaf, rank of the triangle's leaf inside the instance) - followed by the identity
+        (instance, primitive) the walk reports."""
+        return (self.tlas_rank[inst], self.instances[inst]["rank"][ident], inst, self.instances[inst]["primitive"] + ident)
 
 
 BETTER = lambda d, key, best: d < best[0] or (d == best[0] and best[1] is not None and key < best[1])   # wide_triangle's tie rule
@@ -145,7 +155,7 @@ def walk_wide(sc, origin, direction, t_max=np.inf, start=None, bound=None, steal
                 lo, ld, _ = local(inst)
                 p = sc.prims[sc.instances[inst]["primitive"] + ident]
                 t = triangle(lo, ld, p[0], p[1], p[2])
-                key = (inst, sc.instances[inst]["primitive"] + ident)
+                key = sc.key(inst, ident)
                 if t <= best[0] and BETTER(t, key, best):
                     best[0], best[1] = t, key
             continue
@@ -209,7 +219,7 @@ def walk_skip_link(sc, origin, direction, t_max=np.inf):
 
 
 def brute_force(sc, origin, direction, t_max=np.inf):
-    """Every triangle of every instance: the closest hit under the tie rule."""
+    """Every triangle of every instance: the closest hit under the tie rule (the reference's: Scene.key)."""
     o, d = np.asarray(origin, np.float64), np.asarray(direction, np.float64)
     best = [t_max, None]
     for inst, I in enumerate(sc.instances):
@@ -219,7 +229,7 @@ def brute_force(sc, origin, direction, t_max=np.inf):
         for k in range(n_tris):
             p = sc.prims[I["primitive"] + k]
             t = triangle(lo, ld, p[0], p[1], p[2])
-            key = (inst, I["primitive"] + k)
+            key = sc.key(inst, k)
             if t <= best[0] and BETTER(t, key, best):
                 best[0], best[1] = t, key
     return best[0], best[1]
@@ -264,7 +274,7 @@ def walk_wide_concurrent(sc, origin, direction, rng, t_max=np.inf, steal_probabi
                 lo, ld, _ = local(inst)
                 tri = sc.prims[sc.instances[inst]["primitive"] + ident]
                 t = triangle(lo, ld, tri[0], tri[1], tri[2])
-                key = (inst, sc.instances[inst]["primitive"] + ident)
+                key = sc.key(inst, ident)
                 if t <= best[0] and BETTER(t, key, best):
                     best[0], best[1] = t, key
                     shared[0] = min(shared[0], t)

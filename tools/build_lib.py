@@ -10,20 +10,32 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bevy-hikari_amd", "csrc")
 # -ffp-contract=off: only the fmaf() calls written in the sources become v_fma_f32 (numeric contract).  gfx950 only.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -fvisibility=hidden: the library exports the entry points of include/hikari_hip.h / hikari_hip_debug.h (their #pragma GCC visibility) and nothing else.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 SOURCES = ["kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "kernels_wavefront.hip", "kernels_scene.hip", "context.hip", "scene_layout.hip", "scene_refit.hip",
            "probes.hip", "host_logic.cpp", "scene_builder.cpp", "comm.cpp"]
 
 
 def build_library(out, objdir=None, extra=(), force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = objdir or os.path.join(ROOT, "build", "obj")
+    # one object directory per OUTPUT (a variant built with other flags never evicts the shipped library's objects)
+    objdir = objdir or os.path.join(ROOT, "build", "obj_" + os.path.splitext(os.path.basename(out))[0])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + [os.path.join(ROOT, "include", "hikari_hip.h"),
                                                                                                    os.path.join(ROOT, "include", "hikari_hip_debug.h")]
+    # what an object depends on besides its sources: the compiler (path + version) and EVERY flag - the numeric contract lives in
+    # -ffp-contract=off, an object compiled without it must never be linked silently
     stamp = os.path.join(objdir, "flags.txt")
-    flag_line = " ".join(list(extra))
-    if not os.path.exists(stamp) or open(stamp).read() != flag_line:
+    try:
+        version = subprocess.run([hipcc, "--version"], capture_output=True, text=True, check=True).stdout.strip().replace("\n", " | ")
+    except (OSError, subprocess.CalledProcessError):
+        version = "unknown"
+    flag_line = " ".join([hipcc, version] + FLAGS + list(extra))
+    old = None
+    if os.path.exists(stamp):
+        with open(stamp) as f:
+            old = f.read()
+    if old != flag_line:
         force = True
     jobs = []
     for src in SOURCES:
@@ -46,7 +58,8 @@ def build_library(out, objdir=None, extra=(), force=False, verbose=True):
     todo = [j for j in jobs if stale(j[1], j[0])]
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
         list(pool.map(compile_one, todo))
-    open(stamp, "w").write(flag_line)
+    with open(stamp, "w") as f:
+        f.write(flag_line)
     objs = [j[1] for j in jobs]
     if todo or not os.path.exists(out) or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
