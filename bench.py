@@ -215,7 +215,7 @@ def main():
         run_frames(eng, rend, 1, warmup)
         eng.wait()
         eng.reset_stats()
-        eng.set_timing_mask(1 << F.PASS_INDIRECT)  # HIP events around the dominant kernel only
+        eng.set_timing_mask((1 << F.PASS_INDIRECT) | (1 << F.TIMING_TRACE_STAGES))  # HIP events around the dominant pass (+ each of its trace launches: queue-based schedule)
         blocks = []
         n0 = warmup
         for _ in range(max(1, n_blocks)):
@@ -235,6 +235,8 @@ def main():
         traversal = eng.traversal_mode() + (eng.wide_walk(),)
         ind_ms = st.pass_ms_total[F.PASS_INDIRECT] / max(1, st.pass_launches[F.PASS_INDIRECT])
         ind_launches = int(st.pass_launches[F.PASS_INDIRECT])
+        trace_launches = int(st.pass_launches[F.TIMING_TRACE_STAGES])
+        trace_ms = st.pass_ms_total[F.TIMING_TRACE_STAGES] / max(1, trace_launches)   # average TRACE launch of the queue-based indirect pass (0 launches: fused schedule)
         eng.set_timing_mask(0)
         tone = eng.read(F.BUF_TONE_MAPPED)
 
@@ -280,10 +282,37 @@ def main():
             walk["indirect_pass"] = {k: float(getattr(ist, "walk_" + k)) for k in ("node_steps", "triangle_tests", "instance_entries", "closest_hits", "top_node_steps")}
             walk["indirect_pass"]["rays"] = float(ist.rays_tlas + ist.rays_blas)
         del ceng, crend
+        # Scenes beyond LDS, product default: what the TIMED trace kernel's walks do, counted by its own counting twin (HK_CTX_COUNT_WALKS:
+        # same schedule, same walks, same bytes out) - the same frames once more, then the indirect pass alone on the last frame's inputs
+        if schedule == "wavefront" and traversal[2] and rend is None:
+            import ctypes as C
+
+            weng, _ = make_engine(F.CTX_COUNT_WALKS | args.ctx_flags)
+            run_frames(weng, None, 1, last_frame)
+            weng.wait()
+            same_w = bool((weng.read(F.BUF_TONE_MAPPED) == tone).all())
+            weng.pass_run(F.PASS_INDIRECT)
+            raw = np.zeros(64 * 32, dtype=np.uint64)
+            weng.api.call("debug_read_wf_timeline", weng.ctx, raw.ctypes.data_as(C.POINTER(C.c_uint64)), raw.size)
+            raw = raw.reshape(64, 32)
+            inv = np.uint64(0xFFFFFFFFFFFFFFFF)
+            names = ("records", "records_in_the_instance_tree", "triangle_tests", "instance_entries", "rays", "any_hit_rays", "closest_hits_found", "pieces_handed_to_idle_lanes")
+            stages = []
+            for sidx in range(settings.indirect_bounces + 1):
+                r = raw[sidx]
+                if r[4] == 0:
+                    continue
+                t0, tdry, tend = int(inv - r[0]), int(inv - r[1]), int(r[2])
+                stages.append({"stage": sidx, "ticks": tend - t0, "ticks_after_the_queue_ran_dry": tend - max(t0, min(tdry, tend)),
+                               "mean_wave_residency": round(int(r[3]) / int(r[4]) / max(1, tend - t0), 3), **{k: int(r[8 + j]) for j, k in enumerate(names)}})
+            walk["trace_kernel"] = {"stages": stages, "replay_bit_identical": same_w, **{k: sum(st_[k] for st_ in stages) for k in names},
+                                    "tail_fraction_of_trace_time": round(sum(st_["ticks_after_the_queue_ran_dry"] for st_ in stages) / max(1, sum(st_["ticks"] for st_ in stages)), 4)}
+            del weng
 
         res = {"config": config, "description": description, "W": W, "H": H, "steps": steps, "warmup": warmup, "blocks": blocks, "elapsed": elapsed,
                "band_bounds": (rend.bounds if rend is not None else None),
-               "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "total_rays": total_rays, "same": same,
+               "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "trace_ms": trace_ms, "trace_launches": trace_launches,
+               "total_rays": total_rays, "same": same,
                "walk": walk, "sustained": sustained, "scene": scene, "settings": settings, "lights": lights, "view": view, "pview": pview, "sc": sc,
                "band_rows": H if rend is None else (rend.band(H)[1] - rend.band(H)[0])}
         if sustained:
@@ -323,49 +352,66 @@ def main():
 
     # ------------------------------------------------------------------ the other single-GPU configs, briefly, in the same invocation
     def walk_roofline(x, probe_engine):
-        """SURVEY 8d for scenes beyond LDS: the indirect pass priced by what its walks MUST fetch - visited nodes x 32 B + triangle
-        tests x 48 B + 96 B per closest hit (counted by the replay) - against the HBM peak (the contract's roof: a walk moves little,
-        the fraction is small by nature) and against the roof that applies, MEASURED in this run: the rate at which the chip serves
-        dependent divergent 32-B gathers over a table as large as the scene's trees, at the trace kernel's occupancy."""
-        ip = x["walk"].get("indirect_pass")
-        if not ip or x["ind_ms"] <= 0:
+        """SURVEY 8d for scenes beyond LDS.  Dominant kernel: k_wf_trace_wide, the trace launches of the queue-based indirect pass
+        (bounces + 1 per pass) - timed by HIP events around EVERY trace launch of the timed frames (HK_TIMING_TRACE_STAGES), its walks
+        counted by its own counting twin (HK_CTX_COUNT_WALKS: records of 128 B, triangle tests of 48 B, instance entries of 208 B, 96 B
+        per closest hit).  Three fractions, none of which can exceed 1: algorithmic bytes against the HBM peak (small by nature: a
+        walk moves little), record fetches against the rate at which the chip serves dependent divergent 128-B gathers out of its L2s
+        (measured in this run at the kernel's own occupancy: no chain of dependent record fetches runs faster), and the HBM-side
+        bytes of the committed counter passes against the HBM peak.  The tail fraction says how much of the trace time passes after
+        the stage's queue ran dry (the longest walks finishing): the kernel is latency- and tail-bound, not bandwidth-bound."""
+        tk = x["walk"].get("trace_kernel")
+        if not tk or x["trace_launches"] == 0 or x["trace_ms"] <= 0:
             return None
         scene = x["scene"]
-        orderings = x["traversal"][1]
-        tree_bytes = (len(scene.asset_nodes) + len(scene.instance_nodes)) * 32 * orderings + len(scene.primitives) * 48
-        bvh_bytes = ip["node_steps"] * 32 + ip["triangle_tests"] * 48 + ip["closest_hits"] * 96
-        t = x["ind_ms"] * 1e-3
-        r = {"kernel": "indirect_lit_ambient as k_wf_setup + (k_wf_trace + k_wf_shade) per bounce + k_wf_trace + k_wf_final" if x["schedule"] == "wavefront" else "k_indirect",
+        per_pass = x["settings"].indirect_bounces + 1
+        t = x["trace_ms"] * 1e-3 * per_pass                       # trace time of one pass
+        bvh_bytes = tk["records"] * 128 + tk["triangle_tests"] * 48 + tk["instance_entries"] * 208 + tk["closest_hits_found"] * 96
+        wide_bytes = (len(scene.asset_nodes) + len(scene.instance_nodes)) * 128 + len(scene.primitives) * 48
+        r = {"kernel": "k_wf_trace_wide: the %d trace launches of the queue-based indirect pass (closest-hit + any-hit rays of a bounce in one launch)" % per_pass,
              "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-             "algorithmic_bvh_bytes_per_launch": bvh_bytes, "achieved": round(bvh_bytes / t / 1e9, 2), "frac": round(bvh_bytes / t / 1e9 / HBM_PEAK_GBS, 5),
-             "avg_launch_ms": round(x["ind_ms"], 4),
-             "walk_counts_per_launch": {k: int(v) for k, v in ip.items()},
-             "per_ray": {"node_steps": round(ip["node_steps"] / ip["rays"], 2), "triangle_tests": round(ip["triangle_tests"] / ip["rays"], 2),
-                         "instance_entries": round(ip["instance_entries"] / ip["rays"], 2), "node_steps_in_the_instance_tree": round(ip["top_node_steps"] / ip["rays"], 2), "bvh_bytes": round(bvh_bytes / ip["rays"], 1)},
-             "formula": "SURVEY 8d: visited nodes x 32 + leaf (triangle) tests x 48 + 96 per closest hit; instance entries (208-B records) counted, not priced",
-             "tree_bytes_walked": tree_bytes, "traffic": None}
-        # HBM-side bytes of the pass's trace stages by the PMC counters (tools/pmc_fetch.sh; not measured in this run): x 1 per 64-B request,
-        # which is what a walk's gathers issue (profiles/r04_fetch_calibration.json)
+             "avg_launch_ms": round(x["trace_ms"], 4), "launches_per_pass": per_pass, "trace_ms_per_pass": round(t * 1e3, 4), "launches_timed": x["trace_launches"],
+             "pass_ms": round(x["ind_ms"], 4),
+             "counted_by": "HK_CTX_COUNT_WALKS: the counting twin of the timed kernel on the same frames (its frames bit-identical to the timed ones: %s)" % tk["replay_bit_identical"],
+             "walk_counts_per_pass": {k: tk[k] for k in ("records", "records_in_the_instance_tree", "triangle_tests", "instance_entries", "rays", "any_hit_rays", "closest_hits_found",
+                                                         "pieces_handed_to_idle_lanes")},
+             "per_ray": {"records": round(tk["records"] / max(1, tk["rays"]), 2), "triangle_tests": round(tk["triangle_tests"] / max(1, tk["rays"]), 2),
+                         "instance_entries": round(tk["instance_entries"] / max(1, tk["rays"]), 2), "bvh_bytes": round(bvh_bytes / max(1, tk["rays"]), 1)},
+             "algorithmic_bytes_per_pass": bvh_bytes, "achieved": round(bvh_bytes / t / 1e9, 2), "frac": round(bvh_bytes / t / 1e9 / HBM_PEAK_GBS, 5),
+             "formula": "records fetched x 128 + triangle tests x 48 + instance entries x 208 + 96 per closest hit found (SURVEY 8d's terms, in the units of THIS walk)",
+             "tail": {"fraction_of_trace_time_after_the_queue_ran_dry": tk["tail_fraction_of_trace_time"],
+                      "per_stage": [round(st_["ticks_after_the_queue_ran_dry"] / max(1, st_["ticks"]), 3) for st_ in tk["stages"]],
+                      "mean_wave_residency_per_stage": [st_["mean_wave_residency"] for st_ in tk["stages"]],
+                      "note": "from the counting twin's stamps (first wave in, queue first seen dry, last wave out)"},
+             "wide_tree_bytes": wide_bytes, "traffic": None}
+        # HBM-side bytes of the pass's trace launches by the PMC counters (tools/pmc_fetch.sh: separate FETCH_SIZE / WRITE_SIZE passes of
+        # `bench.py --config N`; not measured in this run): lower = x 1 per 64-B request (right for gathers), upper = x 2
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_walk_hbm_traffic.json")) as f:
+            tfile = next(q for q in (os.path.join(ROOT, "profiles", f"r0{k}_walk_hbm_traffic.json") for k in (5, 4)) if os.path.exists(q))
+            with open(tfile) as f:
                 tw = json.load(f).get(f"config{x.get('config', 0)}_trace_stages")
-            if tw and x["schedule"] == "wavefront" and x["traversal"][2]:
+            if tw:
                 r["traffic"] = tw["hbm_bytes_per_pass_lower"]
-                r["traffic_source"] = {"file": "profiles/r04_walk_hbm_traffic.json", "upper_bound_if_every_request_were_128_B": tw["hbm_bytes_per_pass_upper"],
-                                       "ratio_to_algorithmic": round(tw["hbm_bytes_per_pass_lower"] / bvh_bytes, 3),
-                                       "note": "FETCH_SIZE + WRITE_SIZE of the pass's k_wf_trace_wide launches (separate PMC passes of the same command, not this run)"}
-        except (OSError, ValueError, KeyError, TypeError, IndexError):
+                r["hbm_side"] = {"bytes_per_pass": tw["hbm_bytes_per_pass_lower"], "bytes_per_pass_if_every_request_were_128_B": tw["hbm_bytes_per_pass_upper"],
+                                 "frac_of_peak": round(tw["hbm_bytes_per_pass_lower"] / t / 1e9 / HBM_PEAK_GBS, 5),
+                                 "frac_of_peak_upper": round(tw["hbm_bytes_per_pass_upper"] / t / 1e9 / HBM_PEAK_GBS, 5),
+                                 "ratio_to_algorithmic": round(tw["hbm_bytes_per_pass_lower"] / bvh_bytes, 3),
+                                 "source": os.path.relpath(tfile, ROOT) + " (FETCH_SIZE + WRITE_SIZE of the pass's k_wf_trace_wide launches; separate PMC passes of the same command, not this run)"}
+        except (StopIteration, OSError, ValueError, KeyError, TypeError, IndexError):
             pass
         if probe_engine is not None:
-            # 7 waves per SIMD = k_wf_trace's occupancy (HK_WF_TRACE_WAVES); 32 B per step = a node step's two 16-B loads
-            gl, gb = probe_engine.measure_gather(max(tree_bytes, 1 << 20), 32, 7, 512)
-            steps_s = ip["node_steps"] / t / 1e9   # G node steps / s over the whole pass (trace + shade + set-up + tail launches)
-            r["gather_ceiling_measured"] = {"footprint_bytes": tree_bytes, "bytes_per_step": 32, "waves_per_simd": 7, "g_lane_steps_s": round(gl / 2 * 64, 2),
-                                            "g_wave_loads_s": round(gl, 3), "gbytes_s": round(gb, 1),
-                                            "note": "hk_measure_gather in this run: every lane its own chain of dependent 32-B loads through a random cycle over a table of "
-                                                    "the size of the scene's trees (all stored orderings): the rate no walk of that shape can exceed"}
-            r["achieved_g_node_steps_s"] = round(steps_s, 3)
-            r["frac_of_gather_ceiling"] = round(steps_s / (gl / 2 * 64), 4) if gl > 0 else None
+            # the roofs of dependent divergent 128-B record fetches, measured now, at the trace kernel's occupancy (HK_WF_WIDE_WAVES = 5):
+            # table in L1 / in the L2s / as large as the scene's wide trees (random over all of it: a walk WITHOUT locality)
+            roofs = {}
+            for name, fp in (("l1_resident_16KiB", 16 << 10), ("l2_resident_1MiB", 1 << 20), ("random_over_the_wide_trees", max(wide_bytes, 1 << 20))):
+                gl, gb = probe_engine.measure_gather(fp, 128, 5, 256)
+                roofs[name] = {"g_lane_records_s": round(gl / 8 * 64, 2), "gbytes_s": round(gb, 1), "footprint_bytes": fp}
+            rec_s = tk["records"] / t / 1e9
+            r["record_fetches"] = {"achieved_g_records_s": round(rec_s, 3), "roofs_measured": roofs,
+                                   "frac_of_l2_resident_roof": round(rec_s / roofs["l2_resident_1MiB"]["g_lane_records_s"], 4) if roofs["l2_resident_1MiB"]["g_lane_records_s"] > 0 else None,
+                                   "frac_of_random_gather_over_the_trees": round(rec_s / roofs["random_over_the_wide_trees"]["g_lane_records_s"], 4) if roofs["random_over_the_wide_trees"]["g_lane_records_s"] > 0 else None,
+                                   "note": "hk_measure_gather, 128 B per dependent step, 5 waves per SIMD, every lane its own chain: the L2-resident rate is the roof of ANY chain "
+                                           "of dependent record fetches short of L1 hits (a walk's upper levels do hit the L2s, which is why the random-over-the-trees figure is not a roof)"}
         return r
 
     extra = None
@@ -376,7 +422,8 @@ def main():
             extra[str(cfg)] = {"workload": x["description"], "value": round(x["total_rays"] / x["elapsed"] / 1e6, 3), "unit": "Mray/s",
                                "ms_per_step": round(x["elapsed"] / steps_x * 1e3, 4), "steps": steps_x, "warmup": 6,
                                "blocks_ms_per_step": [round(b / steps_x * 1e3, 4) for b in x["blocks"]], "rays_per_frame": round(x["total_rays"] / steps_x, 1),
-                               "indirect_schedule": x["schedule"], "traversal": x["traversal"][0], "wide_walk": x["traversal"][2], "indirect_avg_launch_ms": round(x["ind_ms"], 5), "replay_bit_identical": x["same"]}
+                               "indirect_schedule": x["schedule"], "traversal": x["traversal"][0], "wide_walk": x["traversal"][2], "indirect_avg_launch_ms": round(x["ind_ms"], 5),
+                               "trace_avg_launch_ms": round(x["trace_ms"], 5), "replay_bit_identical": x["same"]}
             if cfg in (3, 4) and rank == 0 and not args.no_hbm_probe:
                 extra[str(cfg)]["roofline"] = walk_roofline(x, xeng)
             del x

@@ -44,6 +44,8 @@ CTX_COUNT_RAYS, CTX_TIME_PASSES, CTX_PLAIN_DIVISION, CTX_SINGLE_STREAM, CTX_DETE
 TREE_SAH, TREE_LBVH = 0, 1  # hk_rebuild_scene_trees
 CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient with >= 2 bounces (hikari_hip.h)
 CTX_NO_WIDE_WALK = 256  # closest-hit walks of scenes beyond LDS keep the threaded skip-link walk (A/B switch)
+CTX_COUNT_WALKS = 512   # the trace stages run the counting twin of their kernel (same schedule, same walks): hk_debug_read_wf_timeline
+TIMING_TRACE_STAGES = 18  # hk_set_timing_mask bit / HkStats slot: every trace launch of the queue-based indirect pass
 TRAVERSAL_WIDE = 0x100
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS, FRAME_GATHER = 1, 2, 4, 8
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
@@ -202,6 +204,7 @@ _DEBUG = {
     "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
     "debug_comm_loopback": [_vp, u32, u32, u32, u32, u32],
     "debug_read_wf_timeline": [_vp, P(C.c_uint64), u32],
+    "debug_prepasses_pipelined": [_vp, P(C.c_uint64)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],
     "measure_gather": [_vp, C.c_size_t, u32, u32, u32, u32, P(C.c_double), P(C.c_double)],

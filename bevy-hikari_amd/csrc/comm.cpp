@@ -230,6 +230,9 @@ int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root, bool overlap) {
   // overlap: nobody waits - the next frame writes the OTHER parity's plane, and the frame after it (or whoever reads the image
   // first) joins.  Only for a plane that is double-buffered by frame parity and that the next frame does not read.
   overlap = overlap && buffer == HK_BUF_TONE_MAPPED;
+  // (one pending gather is tracked: an older one still in flight - of either parity - is joined before its record is overwritten;
+  // hk_frame_render joins everything before it gathers, a caller of hk_comm_gather alone need not have)
+  if (overlap && (rc = comm_join(c, -1))) return rc;
   if ((rc = run_ordered(c, cm, R, tr.data(), tr.size(), (hipStream_t)ci.stream, !overlap))) return rc;
   if (overlap) {
     cm->gather_pending = true;
@@ -603,6 +606,7 @@ int hk_debug_comm_loopback(hk_ctx* c, uint32_t src_buffer, uint32_t dst_buffer, 
   tr[1].buffer = dst_buffer; tr[1].is_recv = 1;
   HK_HIP(hipSetDevice(ci.device));
   const bool overlap = mode == 1u;  // 1: like the gather of a finished frame - nobody waits, comm_join does (hk_frame_begin of the same parity, any read)
+  if (overlap && (rc = comm_join(c, -1))) return rc;  // (as comm_gather: never two overlapped transfers behind one record)
   if ((rc = run_ordered(c, cm, R, tr, 2, (hipStream_t)ci.stream, !overlap))) return rc;
   if (overlap) {
     cm->gather_pending = true;

@@ -66,11 +66,13 @@ int free_screen(hk_ctx* c) {
   if (c->dn_g) (void)hipFree(c->dn_g);
   c->depth_plane = nullptr;
   c->dn_g = nullptr;
-  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin}) {
+  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin, &c->normal_twin, &c->instance_material_twin}) {
     if (*q) (void)hipFree(*q);
     *q = nullptr;
   }
   c->post_pending = false;
+  c->pre_chain_ok = false;
+  c->post_recorded[0] = c->post_recorded[1] = false;
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
       if (c->dn_extra[k][l]) (void)hipFree(c->dn_extra[k][l]);
@@ -183,14 +185,36 @@ bool parks_across_bands(const hk_ctx* c) { return c->band_count > 1 && c->histor
 // the parked planes, on first use (3 x 72 B per render pixel)
 int ensure_parked(hk_ctx* c) {
   if (c->det_winner[0]) return HK_OK;
+  // all nine planes or none: they are allocated into locals and committed together, so that a failure half way leaves the
+  // context as it was (det_winner[0] is what says "the planes exist")
   const size_t nr = (size_t)c->RW * c->RH;
+  int* winner[3] = {nullptr, nullptr, nullptr};
+  void* plane[6] = {};
+  size_t plane_bytes[6] = {};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+    e = hipMalloc((void**)&winner[k], nr * sizeof(int));
+    for (int j = 0; j < 2 && e == hipSuccess; ++j) {
+      const uint32_t b = (j == 0 ? (uint32_t)HK_BUF_PARKED_TO0 : (uint32_t)HK_BUF_PARKED_RECORD0) + (uint32_t)k;
+      plane_bytes[2 * k + j] = nr * buffer_bpp(b);
+      e = hipMalloc(&plane[2 * k + j], plane_bytes[2 * k + j]);
+      if (e == hipSuccess) e = hipMemsetAsync(plane[2 * k + j], j == 0 ? 0xFF : 0, plane_bytes[2 * k + j], c->stream);  // nothing parked
+    }
+  }
+  if (e != hipSuccess) {
+    for (int k = 0; k < 3; ++k)
+      if (winner[k]) (void)hipFree(winner[k]);
+    for (void* q : plane)
+      if (q) (void)hipFree(q);
+    set_error("allocating the parked-store planes failed: %s", hipGetErrorString(e));
+    return HK_E_HIP;
+  }
   for (int k = 0; k < 3; ++k) {
-    HK_HIP(hipMalloc((void**)&c->det_winner[k], nr * sizeof(int)));
-    for (uint32_t b : {(uint32_t)HK_BUF_PARKED_TO0 + k, (uint32_t)HK_BUF_PARKED_RECORD0 + k}) {
-      const size_t bytes = nr * buffer_bpp(b);
-      HK_HIP(hipMalloc(&c->buf[b], bytes));
-      HK_HIP(hipMemsetAsync(c->buf[b], b < HK_BUF_PARKED_RECORD0 ? 0xFF : 0, bytes, c->stream));  // nothing parked
-      c->buf_bytes[b] = bytes;
+    c->det_winner[k] = winner[k];
+    for (int j = 0; j < 2; ++j) {
+      const uint32_t b = (j == 0 ? (uint32_t)HK_BUF_PARKED_TO0 : (uint32_t)HK_BUF_PARKED_RECORD0) + (uint32_t)k;
+      c->buf[b] = plane[2 * k + j];
+      c->buf_bytes[b] = plane_bytes[2 * k + j];
     }
   }
   return HK_OK;
@@ -371,7 +395,10 @@ bool use_wavefront(const hk_ctx* c) {
 // The wide walk (hk_wide.hpp) is the closest-hit walk of scenes beyond LDS in the product default: the trace stages
 // (k_wf_trace_wide) and the primary rays (k_prepass<*, 4>).  The reference's order (HK_CTX_EXACT_TRAVERSAL) keeps the skip-link walk;
 // HK_CTX_NO_WIDE_WALK is the A/B switch.
-static bool wide_allowed(const hk_ctx* c) { return !(c->flags & HK_CTX_NO_WIDE_WALK) && c->threaded && !c->scene.flat_mode; }
+// (a scene that fits the LDS copy is walked from LDS by every kernel: no records are built for it)
+static bool wide_allowed(const hk_ctx* c) {
+  return !(c->flags & HK_CTX_NO_WIDE_WALK) && c->threaded && !c->scene.flat_mode && (size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES;
+}
 bool use_wide(const hk_ctx* c) { return wide_allowed(c); }
 // records of the trees the next trace stages walk, (re)derived from what the scene blob holds now
 int ensure_wide(hk_ctx* c, bool with_spill) {
@@ -493,7 +520,9 @@ int ensure_wavefront(hk_ctx* c) {
   w.alive[0] = u32(1); w.alive[1] = u32(1);
   w.shadow[0] = u32(1); w.shadow[1] = u32(1);
   w.cap = (uint32_t)n;
-  if (getenv("HK_WF_TIMELINE") && !w.timeline) HK_HIP(hipMalloc((void**)&w.timeline, 64 * 32 * sizeof(unsigned long long)));  // tools/wf_timeline.py
+  const bool tl_twin = getenv("HK_WF_TIMELINE") != nullptr, count_twin = (c->flags & HK_CTX_COUNT_WALKS) != 0u;
+  if ((tl_twin || count_twin) && !w.timeline) HK_HIP(hipMalloc((void**)&w.timeline, 64 * 32 * sizeof(unsigned long long)));  // tools/wf_timeline.py, bench.py
+  w.timeline_mode = count_twin ? 2u : (tl_twin ? 1u : 0u);
   return HK_OK;
 }
 
@@ -573,8 +602,13 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
           wide.spill = c->wide_spill;
           wide.lost = c->d_counters + 8;
         }
+        // (HK_TIMING_TRACE_STAGES: every trace launch of the pass between its own pair of events)
+        std::vector<hipEvent_t> trace_events;
+        if ((c->timing_mask >> HK_TIMING_TRACE_STAGES) & 1u)
+          for (uint32_t k = 0; k < 2u * (c->frame.indirect_bounces + 1u); ++k) trace_events.push_back(get_event(c));
         launch_indirect_wavefront(c->stream, c->scene, fr, g, t, c->wf, y0, y1, c->compute_units, timer.on ? timer.t.start : nullptr,
-                                  timer.on ? timer.t.stop : nullptr, &wide);
+                                  timer.on ? timer.t.stop : nullptr, &wide, trace_events.empty() ? nullptr : trace_events.data());
+        for (size_t k = 0; k + 1 < trace_events.size(); k += 2) c->pending.push_back(TimedLaunch{HK_TIMING_TRACE_STAGES, trace_events[k], trace_events[k + 1]});
       } else if (pass == HK_PASS_INDIRECT)  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
         launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, t, y0, y1, counters, timer.on ? timer.t.start : nullptr,
                         timer.on ? timer.t.stop : nullptr);
@@ -747,6 +781,20 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
         hk_destroy(c);
         return HK_E_HIP;
       }
+      {
+        const char* e = getenv("HK_PREPASS_PIPELINE");
+        c->pre_mode = !e ? 0 : (!strcmp(e, "all") ? 2 : (!strcmp(e, "lds") ? 1 : 0));  // default: off (measured, see hk_frame_stage)
+      }
+      if (c->pre_mode != 0) {
+        bool ok = hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < 2 && ok; ++k)
+          ok = hipEventCreateWithFlags(&c->frame_mark[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->post_done_parity[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+          set_error("cannot create the primary-ray stream");
+          hk_destroy(c);
+          return HK_E_HIP;
+        }
+      }
     }
   }
   *out = c;
@@ -776,6 +824,12 @@ void hk_destroy(hk_ctx* c) {
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+  if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); }
+  if (c->pre_done) (void)hipEventDestroy(c->pre_done);
+  for (int k = 0; k < 2; ++k) {
+    if (c->frame_mark[k]) (void)hipEventDestroy(c->frame_mark[k]);
+    if (c->post_done_parity[k]) (void)hipEventDestroy(c->post_done_parity[k]);
+  }
   if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
   if (c->post_fork) (void)hipEventDestroy(c->post_fork);
   if (c->post_done) (void)hipEventDestroy(c->post_done);
@@ -787,13 +841,19 @@ void hk_destroy(hk_ctx* c) {
 // tools/wf_timeline.py: the 64 x 32 u64 the instrumented trace kernel left for the frame most recently rendered (HK_WF_TIMELINE=1)
 int hk_debug_read_wf_timeline(hk_ctx* c, unsigned long long* out, uint32_t n) {
   HK_REQUIRE(c && out && n == 64u * 32u, HK_E_INVALID, "bad argument");
-  HK_REQUIRE(c->wf.timeline, HK_E_NOT_READY, "no timeline: set HK_WF_TIMELINE=1 before the first frame of a scene beyond the LDS copy");
+  HK_REQUIRE(c->wf.timeline, HK_E_NOT_READY, "no timeline: set HK_WF_TIMELINE=1 (or create the context with HK_CTX_COUNT_WALKS) before the first frame of a scene beyond the LDS copy");
   HK_HIP(hipSetDevice(c->device));
   { const int rc = sync_all(c); if (rc) return rc; }
   HK_HIP(hipMemcpy(out, c->wf.timeline, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   int khz = 0;
   HK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
   out[n - 1] = (unsigned long long)khz;  // (slot 31 of stage 63 - never a real stage: the rate of wall_clock64, kHz)
+  return HK_OK;
+}
+
+int hk_debug_prepasses_pipelined(hk_ctx* c, uint64_t* out) {
+  HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
+  *out = c->prepasses_pipelined;
   return HK_OK;
 }
 
@@ -861,6 +921,12 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     HK_HIP(hipMemset(c->depth_gradient_twin, 0, c->buf_bytes[HK_BUF_DEPTH_GRADIENT]));
     HK_HIP(hipMalloc(&c->dn_g_twin, nf * 16));
     HK_HIP(hipMemset(c->dn_g_twin, 0, nf * 16));
+    if (c->pre_stream) {  // primary-ray pipelining: the two G-buffer planes that had no previous-frame twin
+      HK_HIP(hipMalloc(&c->normal_twin, c->buf_bytes[HK_BUF_NORMAL]));
+      HK_HIP(hipMemset(c->normal_twin, 0, c->buf_bytes[HK_BUF_NORMAL]));
+      HK_HIP(hipMalloc(&c->instance_material_twin, c->buf_bytes[HK_BUF_INSTANCE_MATERIAL]));
+      HK_HIP(hipMemset(c->instance_material_twin, 0, c->buf_bytes[HK_BUF_INSTANCE_MATERIAL]));
+    }
   }
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
@@ -905,6 +971,10 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
       std::swap(c->buf[HK_BUF_DEPTH_GRADIENT], c->depth_gradient_twin);
       std::swap(c->dn_g, c->dn_g_twin);
     }
+    if (c->normal_twin) {  // (primary-ray pipelining: the next frame's prepass may write while this frame's passes still read)
+      std::swap(c->buf[HK_BUF_NORMAL], c->normal_twin);
+      std::swap(c->buf[HK_BUF_INSTANCE_MATERIAL], c->instance_material_twin);
+    }
     c->mapped_parity = f->number & 1u;
   }
   if (c->comm) { const int rc = comm_join(c, (int)(f->number & 1u)); if (rc) return rc; }  // a gather still reading the plane this frame writes
@@ -943,6 +1013,7 @@ int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint
   int rc = ready(c);
   if (rc) return rc;
   if ((rc = join_all(c))) return rc;
+  c->pre_chain_ok = false;  // (a host that dispatches passes itself: the next frame's primary rays take the serial order)
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
   int rows = full_grid ? c->H : c->RH;
   if (pass == HK_PASS_TAA_JASMINE) { int w; buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &rows); }
@@ -1083,12 +1154,25 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     // what they read - provided the double-buffered planes really flipped (a host that renders two frames of the same parity in a
     // row, or shards the frame into bands, or timed passes, gets the serial order)
     if (c->post_pending && (c->mapped_parity == c->post_parity || (flags & HK_FRAME_EXTERNAL_GBUFFER)) && (rc = join_post(c))) return rc;
-    if (c->timing_mask) {
-      (void)hipEventRecord(c->frame_start, c->stream);
-    }
     int f0, f1;
     full_rows_for(c, clampr(b0 - den - sp), clampr(b1 + den + sp), &f0, &f1);
     bool albedo_done = false;
+    // primary-ray pipelining (hk_context.hpp): this frame's prepass goes to its own stream, ordered only against what last touched the
+    // planes of ITS parity, when the previous frame came through here with the other parity over the same scene
+    const uint32_t parity = c->mapped_parity;
+    // HK_PREPASS_PIPELINE (read by hk_create) = "none" (DEFAULT), "lds" (scenes every kernel walks from its LDS copy), "all".  Built,
+    // bit-exact (test_primary_ray_pipelining_changes_no_bit) and MEASURED SLOWER everywhere (round 5, profiles/r05_prepass_pipeline_ab.txt):
+    // Cornell 1080p 0.969 -> 1.046 ms per frame (the three cross-stream waits per frame cost more than the 0.065 ms of primary rays
+    // they hide), configs 3 / 4 7.28 -> 7.39 / 16.52 -> 16.60 ms (the tails of the trace stages are not idle capacity: the long walks
+    // that end them crawl behind whatever else uses the memory system).  Kept behind the switch as the A/B.
+    const int pre_mode = c->pre_mode;  // (read from the environment by hk_create)
+    const bool in_lds = (size_t)c->scene.blob_f4 * 16 <= HK_LDS_SCENE_BYTES;
+    const bool wide_clean = !wide_allowed(c) || (!c->wide_tlas_dirty && !c->wide_blas_dirty && !c->wide_mesh_check);  // (else k_build_wide runs first, on the main stream)
+    const bool pre_pipelined = c->pre_stream && c->normal_twin && c->pre_chain_ok && c->pre_last_parity != parity && !(flags & HK_FRAME_EXTERNAL_GBUFFER) &&
+                               c->band_count == 1 && !(c->timing_mask & (1u << HK_PASS_PREPASS)) && wide_clean && !c->derived_dirty &&
+                               (pre_mode == 2 || (pre_mode == 1 && in_lds));
+    if (c->pre_stream) HK_HIP(hipEventRecord(c->frame_mark[parity], c->stream));  // everything enqueued before this frame (main; the side stream was joined)
+    if (c->timing_mask && !(pre_pipelined && !(flags & HK_FRAME_EXTERNAL_GBUFFER) && f1 > f0)) (void)hipEventRecord(c->frame_start, c->stream);
     if (!(flags & HK_FRAME_EXTERNAL_GBUFFER)) {
       if (f1 > f0) {  // the prepass also fills the albedo of every pixel it covers (a superset of the rows albedo needs)
         const DFrame fr = make_dframe(c);
@@ -1096,11 +1180,28 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
         g.albedo_out = (uint2*)c->buf[HK_BUF_ALBEDO];
         unsigned long long* counters = (c->flags & HK_CTX_COUNT_RAYS) ? c->d_counters : nullptr;
         const Jitter j = prepass_jitter(c);
-        ScopedTimer timer(c, HK_PASS_PREPASS);
         hkd::WideTrees wide{};
         if ((rc = wide_for_fused(c, &wide))) return rc;
-        launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
+        hipStream_t main_stream = c->stream;
+        if (pre_pipelined) {
+          // the last writers / readers of this parity's planes: frame n - 2 (everything it had on the main and side streams is behind
+          // frame n - 1's mark) and its a-trous levels on the post stream
+          HK_HIP(hipStreamWaitEvent(c->pre_stream, c->frame_mark[parity ^ 1u], 0));
+          if (c->post_recorded[parity]) HK_HIP(hipStreamWaitEvent(c->pre_stream, c->post_done_parity[parity], 0));
+          c->stream = c->pre_stream;
+          c->prepasses_pipelined += 1;
+          if (c->timing_mask) (void)hipEventRecord(c->frame_start, c->pre_stream);  // (HkStats.last_frame_ms: first dispatch of the frame)
+        }
+        {
+          ScopedTimer timer(c, HK_PASS_PREPASS);
+          launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
+        }
+        c->stream = main_stream;
         HK_HIP(hipGetLastError());
+        if (pre_pipelined) {
+          HK_HIP(hipEventRecord(c->pre_done, c->pre_stream));
+          HK_HIP(hipStreamWaitEvent(c->stream, c->pre_done, 0));
+        }
         albedo_done = true;
       }
     } else if (f1 > f0) {  // host-rasterised G-buffer: only the derived planes are ours to fill
@@ -1126,6 +1227,8 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       HK_RUN(HK_PASS_DIRECT_EMISSIVE, 0, b0, b1);
       HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
     }
+    c->pre_chain_ok = !(flags & HK_FRAME_EXTERNAL_GBUFFER);  // (the next frame's primary rays may overlap what follows of this one)
+    c->pre_last_parity = parity;
   } else if (stage == HK_STAGE_SPATIAL) {            // light.rs:689-697
     if (parks_across_bands(c) && c->det_winner[0]) {
       // exchange A delivered the parked stores of the pixels up to 2 x history rows outside the band.  Per
@@ -1186,6 +1289,10 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
         HK_HIP(hipEventRecord(c->post_done, c->post_stream));
         c->post_pending = true;
         c->post_parity = c->mapped_parity;
+        if (c->pre_stream) {  // (what the prepass of the frame after next - the next writer of this parity's planes - waits for)
+          HK_HIP(hipEventRecord(c->post_done_parity[c->mapped_parity], c->post_stream));
+          c->post_recorded[c->mapped_parity] = true;
+        }
       }
       if (c->timing_mask) {
         (void)hipEventRecord(c->frame_stop, pipelined ? c->post_stream : c->stream);
@@ -1201,6 +1308,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     c->frames += 1;
   } else if (stage == HK_STAGE_ANTIALIAS) {            // post_process.rs:1236-1272
     if ((rc = join_post(c))) return rc;                // (reads the tone-mapped image)
+    c->pre_chain_ok = false;                           // (... and the PREVIOUS frame's G-buffer planes: the next prepass writes them only after this)
     // band: TAA on the band's output rows; its input row beyond the border comes from the extrapolation of the
     // neighbouring quad row, which needs the SMAA samples one more row out (footprints: hk_band_plan_for, exchange D)
     const bool smaa = st->upscale_kind == HK_UPSCALE_SMAA_TU4X;
@@ -1216,6 +1324,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     }
   } else if (stage == HK_STAGE_UPSCALE) {              // post_process.rs:1277-1308
     if ((rc = join_post(c))) return rc;
+    c->pre_chain_ok = false;
     if (st->upscale_kind == HK_UPSCALE_FSR1) {
       uint32_t w0, w1;
       band_rows_in(bounds, (uint32_t)c->RH, (uint32_t)c->H, c->band_index, c->band_count, &w0, &w1);
@@ -1295,6 +1404,7 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
   { int rc_ = join_all(c); if (rc_) return rc_; }
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
+  c->pre_chain_ok = false;
   if (buffer >= HK_BUF_RESERVOIR0 && buffer < HK_BUF_RESERVOIR0 + 10 && c->tile_meta[buffer - HK_BUF_RESERVOIR0]) {  // host-written reservoirs: tiles unknown
     const uint32_t k = buffer - HK_BUF_RESERVOIR0;
     HK_HIP(hipMemset(c->tile_meta[k], 0, (size_t)c->tiles_x * c->tiles_y * sizeof(TileMeta)));
@@ -1316,6 +1426,7 @@ int hk_set_stream(hk_ctx* c, void* s) {
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->pre_chain_ok = false;
   return HK_OK;
 }
 int hk_stream(hk_ctx* c, void** s) {

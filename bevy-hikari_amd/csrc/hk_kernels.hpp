@@ -75,7 +75,11 @@ struct WfBuffers {
   // u64 per trace stage, zeroed per dispatch - [0] ~first wave start, [1] ~first time a wave found the queue exhausted, [2] last
   // wave exit (wall_clock64 ticks; ~x = UINT64_MAX - x so that atomicMax keeps the minimum), [3] sum of the waves' resident ticks,
   // [4] waves, [5] most node steps of one ray, [6] node steps, [7] rays, [8..23] rays by floor(log2(node steps + 1))
+  // HK_CTX_COUNT_WALKS (round 5): the COUNTING twin of k_wf_trace_wide writes [0..4] as above and [8] records fetched, [9] of them in
+  // the instance tree, [10] triangle tests, [11] instance entries, [12] rays claimed, [13] of them any-hit, [14] closest hits found,
+  // [15] pieces of walks handed to idle lanes
   unsigned long long* timeline;
+  uint32_t timeline_mode;  // 0: none (the product), 1: the timeline twin, 2: the counting twin
 };
 // Wide trees for the queue-based trace stage and the primary rays of scenes in global memory (round 4; kernels_wavefront.hip
 // k_build_wide / k_wf_trace_wide, kernels.hip k_prepass<*, 4>, hk_wide.hpp; DESIGN 4 "Wide walk").
@@ -284,9 +288,10 @@ void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, floa
 // x the stack entries a lane keeps beyond LDS) - asked of the file that launches the kernel, so that the two cannot disagree
 size_t wide_trace_lanes(int compute_units);
 size_t wide_spill_entries();
+// trace_events: nullptr, or 2 x (bounces + 1) events - start / stop of every trace launch (HK_TIMING_TRACE_STAGES)
 void launch_indirect_wavefront(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                                const hkd::WfBuffers& w, int y0, int y1, int compute_units, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
-                               const hkd::WideTrees* wide = nullptr);
+                               const hkd::WideTrees* wide = nullptr, hipEvent_t* trace_events = nullptr);
 void launch_copy_region(hipStream_t st, void* dst, const void* src, size_t bytes);
 void launch_gather_instance_boxes(hipStream_t st, const hkd::RefitScene& s, const float4* tlas, uint32_t tlas_count);
 // the first n_emitter_updates records are the moved emitters (the largest of their meshes has emitter_triangles triangles)

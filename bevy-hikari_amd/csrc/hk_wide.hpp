@@ -114,8 +114,9 @@ __device__ __forceinline__ void wide_begin(WideWalk& k, const WideTrees& wt, f3 
 }
 // One step: pop (if there is nothing to visit) and / or visit one record.  Returns the lane's next phase; `pending` = the leaf a
 // PH_TRI / PH_ENTRY lane is parked at.
-template <class S>
-__device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, S& st, uint32_t& pending) {
+// (COUNT: rc->nodes / rc->top_nodes count the records actually FETCHED - a turn that only pops fetches nothing)
+template <class S, bool COUNT = false>
+__device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, S& st, uint32_t& pending, RayCounters* rc = nullptr) {
   if (k.cur == WIDE_NONE) {
     if (k.sp == k.base) return PH_IDLE;
     const uint32_t e = wide_pop(k, st);
@@ -138,12 +139,24 @@ __device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, 
     k.cur = e;
   }
   const float4* __restrict__ rec = (k.in_blas ? wt.blas + 8u * (size_t)(k.mesh_base + k.cur) : wt.tlas + 8u * (size_t)k.cur);
+  if (COUNT) {
+    rc->nodes++;
+    rc->top_nodes += k.in_blas ? 0u : 1u;
+  }
+  // The eight 16-B loads of the record are ISSUED TOGETHER - one round trip to the memory system per record, not four.  Left to
+  // itself the scheduler sometimes sinks each pair next to its slab test to save registers (round 5: the build with the rank
+  // loads of wide_tie_goes_to did, and the trace stages of configs 3 / 4 got 11 % / 18 % slower - profiles/r05_rank_rule_ab.txt);
+  // the barrier keeps the batch whatever else changes in the kernel.
+  float4 r8[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) r8[c] = rec[c];
+  __builtin_amdgcn_sched_barrier(0);
   float t[4];
   uint32_t link[4];
   const float bound = fmin_(k.hit.distance, k.limit);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float4 lo = rec[2 * c], hi = rec[2 * c + 1];
+    const float4 lo = r8[2 * c], hi = r8[2 * c + 1];
     const f3 t1 = (xyz(lo) - k.co) * k.cinv;  // intersects_aabb, light.wgsl:344-362
     const f3 t2 = (xyz(hi) - k.co) * k.cinv;
     float t_min = fmin_(t1.x, t2.x);
@@ -182,9 +195,16 @@ __device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, 
 }
 // the reference's tie rule between two candidates at exactly the same distance: the one its stackless walk meets first wins, i.e. the
 // leaf of smaller position in ordering 0 - instance leaves first, triangle leaves inside one instance (hk_kernels.hpp WideTrees ranks)
+#ifndef HK_WIDE_TIE_BY_RANK
+#define HK_WIDE_TIE_BY_RANK 1  // (0: round 4's rule - the smaller (instance, primitive); the A/B of what the rank loads cost)
+#endif
 __device__ __forceinline__ bool wide_tie_goes_to(const WideTrees& wt, uint32_t instance, uint32_t primitive, uint32_t best_instance, uint32_t best_primitive) {
+#if HK_WIDE_TIE_BY_RANK
   if (instance != best_instance) return wt.tlas_rank[instance] < wt.tlas_rank[best_instance];
   return wt.blas_rank[primitive] < wt.blas_rank[best_primitive];
+#else
+  return instance < best_instance || (instance == best_instance && primitive < best_primitive);
+#endif
 }
 __device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, const WideTrees& wt, uint32_t pending) {
   const uint32_t primitive_index = k.prim_base + pending;
@@ -241,10 +261,7 @@ __device__ __forceinline__ Hit traverse_top_wide(const DScene& sc, const WideTre
   wide_begin(k, wt, ray.origin, ray.direction, max_distance, early_distance, exclude_instance);
   uint32_t phase = PH_NODE, pending = 0u;
   while (phase != PH_IDLE) {
-    if (phase == PH_NODE) {
-      rc.nodes++;
-      phase = wide_node(k, wt, st, pending);
-    }
+    if (phase == PH_NODE) phase = wide_node<S, true>(k, wt, st, pending, &rc);  // (rc.nodes: records fetched)
     if (phase == PH_TRI) {
       rc.tris++;
       phase = wide_triangle(k, sc, wt, pending);

@@ -544,16 +544,25 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 enum : uint32_t { PH_WAIT = 4u, PH_HELPED = 5u };  // a root whose helpers are still out / a helper whose piece is done (merged at the next turn)
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
-template <bool TL>  // (TL: the instrumented twin, as for k_wf_trace - tools/wf_timeline.py)
+// TL: the instrumented twin, as for k_wf_trace - tools/wf_timeline.py.  COUNT (round 5; HK_CTX_COUNT_WALKS): the COUNTING twin of
+// THIS walk - records fetched (of them in the instance tree), triangle tests, instance entries, rays claimed (of them any-hit),
+// closest hits found, pieces handed to idle lanes - per stage into WfBuffers::timeline[32 stage + 8 ..], next to three stamps (first
+// wave in, queue first seen dry, last wave out) from which bench.py takes the stage's tail fraction.  The product launches
+// <false, false>; the three differ in bookkeeping only: a ray's walk and result are the same.
+template <bool TL, bool COUNT>
 __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene sc, WfBuffers w, WideTrees wt, uint32_t stage) {
   __shared__ uint32_t stack_lds[HK_WIDE_LDS_STACK * 256u];
   __shared__ uint32_t tl_hist[16];
   unsigned long long tl_start = 0ull;
   uint32_t tl_steps = 0u, tl_max = 0u, tl_sum = 0u, tl_rays = 0u, tl_claimed = 0u;
   bool tl_seen_dry = false;
+  RayCounters cn{0, 0};  // COUNT: tlas = rays claimed, blas = of them any-hit, nodes / top_nodes / tris / entries / hits; pieces below
+  uint32_t cn_pieces = 0u;
   if (TL) {
     if (threadIdx.x < 16u) tl_hist[threadIdx.x] = 0u;
     __syncthreads();
+  }
+  if (TL || COUNT) {
     tl_start = wall_clock64();
     if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 0u], ~tl_start);
   }
@@ -594,6 +603,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     } else {
       w.ch0[slot] = make_float4(k.hit.distance, k.hit.uv.x, k.hit.uv.y, u2f(k.hit.primitive_index));
       w.ch1[slot] = k.hit.instance_index;
+      if (COUNT) cn.hits += k.hit.instance_index != HK_U32_MAX ? 1u : 0u;
     }
   };
   auto finish = [&]() {  // the lane's piece of a walk has ended
@@ -656,7 +666,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     const unsigned long long idle_mask = __ballot(phase == PH_IDLE);
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     const bool dry = exhausted && res_count == 0u;
-    if (TL && exhausted && !tl_seen_dry) {
+    if ((TL || COUNT) && exhausted && !tl_seen_dry) {
       tl_seen_dry = true;
       if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 1u], ~wall_clock64());
     }
@@ -684,6 +694,10 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
       if (mine != HK_U32_MAX) {
         entry_id = mine < n_alive ? alive[mine] : (shadow[mine - n_alive] | WF_SHADOW);
         begin_ray(entry_id, HK_F32_MAX);
+        if (COUNT) {
+          cn.tlas += 1u;
+          cn.blas += (entry_id & WF_SHADOW) ? 1u : 0u;
+        }
         root = lane;
         steps = 0u;
         share_best[threadIdx.x] = f2u(HK_F32_MAX);
@@ -775,6 +789,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
           wide_push(k, stack, ctx[0]);
           steps = 0u;
           phase = PH_NODE;
+          if (COUNT) cn_pieces += 1u;
           if (TL) tl_claimed = (uint32_t)(wall_clock64() - tl_start);
         }
       }
@@ -796,7 +811,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
         if (phase == PH_NODE) {
           if (TL) tl_steps += 1u;
           steps += 1u;
-          phase = wide_node(k, wt, stack, pending);
+          phase = wide_node<WideStackSpill, COUNT>(k, wt, stack, pending, &cn);
           if (phase == PH_IDLE) finish();
         }
       }
@@ -804,6 +819,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     if (all_phases ? n_tri != 0u : (!(n_node >= n_tri && n_node >= n_entry && n_node != 0u) && n_tri >= n_entry)) {
       if (phase == PH_TRI) {
         const float before = k.hit.distance;
+        if (COUNT) cn.tris += 1u;
         phase = wide_triangle(k, sc, wt, pending);
 #if HK_WF_WIDE_SHARE
         if (dry && k.hit.distance < before) atomicMin(&share_best[(threadIdx.x & ~63u) + root], f2u(k.hit.distance));  // (distances are >= 0: their bits order like they do)
@@ -813,9 +829,24 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     }
     if (all_phases ? n_entry != 0u : (!(n_node >= n_tri && n_node >= n_entry && n_node != 0u) && n_tri < n_entry)) {
       if (phase == PH_ENTRY) {
+        if (COUNT) cn.entries += 1u;
         wide_enter(k, sc, stack, pending);
         phase = PH_NODE;
       }
+    }
+  }
+  if (COUNT) {
+    const unsigned long long now = wall_clock64();
+    uint32_t v[8] = {cn.nodes, cn.top_nodes, cn.tris, cn.entries, cn.tlas, cn.blas, cn.hits, cn_pieces};
+    for (int off = 32; off > 0; off >>= 1)
+      for (int j = 0; j < 8; ++j) v[j] += __shfl_down(v[j], off);
+    unsigned long long* tl = w.timeline + 32u * stage;
+    if ((threadIdx.x & 63u) == 0u) {
+      atomicMax(&tl[2], now);
+      atomicAdd(&tl[3], now - tl_start);
+      atomicAdd(&tl[4], 1ull);
+      for (int j = 0; j < 8; ++j)
+        if (v[j]) atomicAdd(&tl[8 + j], (unsigned long long)v[j]);
     }
   }
   if (TL) {
@@ -1001,7 +1032,7 @@ void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, floa
 }
 
 void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,
-                               int y1, int compute_units, hipEvent_t start, hipEvent_t stop, const WideTrees* wide) {
+                               int y1, int compute_units, hipEvent_t start, hipEvent_t stop, const WideTrees* wide, hipEvent_t* trace_events) {
   if (y1 <= y0) return;
   (void)hipMemsetAsync(w.ctr, 0, 192 * sizeof(uint32_t), st);
   if (w.timeline) (void)hipMemsetAsync(w.timeline, 0, 64 * 32 * sizeof(unsigned long long), st);
@@ -1013,13 +1044,18 @@ void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& f
   // its longest walk (tools/wf_timeline.py; HK_WF_TRACE_WG_PER_CU for the A/B)
   static const int trace_wg_per_cu = getenv("HK_WF_TRACE_WG_PER_CU") ? std::max(1, atoi(getenv("HK_WF_TRACE_WG_PER_CU"))) : HK_WF_TRACE_WG_PER_CU;
   const dim3 tracers((unsigned)(compute_units * trace_wg_per_cu));
+  const dim3 wide_tracers((unsigned)(compute_units * HK_WF_WIDE_WAVES));
   const uint32_t bounces = fr.indirect_bounces;
+  const bool use_wide = wide && wide->tlas && !lds;
+  const uint32_t twin = w.timeline ? w.timeline_mode : 0u;
   for (uint32_t n = 0; n <= bounces; ++n) {
-    if (wide && wide->tlas && !lds && w.timeline) hipLaunchKernelGGL(k_wf_trace_wide<true>, dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, *wide, n);
-    else if (wide && wide->tlas && !lds) hipLaunchKernelGGL(k_wf_trace_wide<false>, dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, *wide, n);
-    else if (w.timeline && !lds) hipLaunchKernelGGL((k_wf_trace<false, true>), tracers, dim3(256), 0, st, sc, w, n);
-    else if (lds) hipLaunchKernelGGL((k_wf_trace<true, false>), tracers, dim3(256), lds, st, sc, w, n);
-    else hipLaunchKernelGGL((k_wf_trace<false, false>), tracers, dim3(256), 0, st, sc, w, n);
+    hipEvent_t e0 = trace_events ? trace_events[2u * n] : nullptr, e1 = trace_events ? trace_events[2u * n + 1u] : nullptr;
+    if (use_wide && twin == 1u) hipExtLaunchKernelGGL((k_wf_trace_wide<true, false>), wide_tracers, dim3(256), 0, st, e0, e1, 0, sc, w, *wide, n);
+    else if (use_wide && twin == 2u) hipExtLaunchKernelGGL((k_wf_trace_wide<false, true>), wide_tracers, dim3(256), 0, st, e0, e1, 0, sc, w, *wide, n);
+    else if (use_wide) hipExtLaunchKernelGGL((k_wf_trace_wide<false, false>), wide_tracers, dim3(256), 0, st, e0, e1, 0, sc, w, *wide, n);
+    else if (twin == 1u && !lds) hipExtLaunchKernelGGL((k_wf_trace<false, true>), tracers, dim3(256), 0, st, e0, e1, 0, sc, w, n);
+    else if (lds) hipExtLaunchKernelGGL((k_wf_trace<true, false>), tracers, dim3(256), lds, st, e0, e1, 0, sc, w, n);
+    else hipExtLaunchKernelGGL((k_wf_trace<false, false>), tracers, dim3(256), 0, st, e0, e1, 0, sc, w, n);
     if (n == bounces) break;
     if (lds) hipLaunchKernelGGL((k_wf_shade<true>), persistent, dim3(256), lds, st, sc, fr, w, n);
     else hipLaunchKernelGGL((k_wf_shade<false>), persistent, dim3(256), 0, st, sc, fr, w, n);

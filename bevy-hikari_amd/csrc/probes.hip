@@ -2,7 +2,8 @@
 // in the same run on the same device ("measure the empirical HBM ceiling with a device copy/triad kernel in the same run").
 //   hk_measure_hbm     streaming copy / triad                       - the HBM roof of the screen-space kernels
 //   hk_measure_valu    register-only v_fma_f32 chains                - the issue roof of the ray kernels of LDS-resident scenes
-//   hk_measure_gather  dependent, divergent 16-B / 32-B gathers      - the roof of the BVH walks of scenes beyond LDS (round 4)
+//   hk_measure_gather  dependent, divergent 16-B .. 128-B gathers    - the roof of the BVH walks of scenes beyond LDS (round 4; 128 B = a
+//                                                                     record of the wide walk: round 5)
 // None of them touches a context's buffers; they run on its stream between frames.
 #include <hip/hip_runtime.h>
 
@@ -213,7 +214,7 @@ int hk_measure_valu(hk_ctx* c, uint32_t iters, double ginstr_s[4]) {
 // hikari_hip_debug.h
 int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps, uint32_t workgroups, double* gloads_s,
                       double* gbytes_s) {
-  HK_REQUIRE(c && gloads_s && gbytes_s && (bytes_per_step == 16u || bytes_per_step == 32u || bytes_per_step == 64u) && waves_per_simd >= 1u && waves_per_simd <= 8u && steps >= 16u &&
+  HK_REQUIRE(c && gloads_s && gbytes_s && (bytes_per_step == 16u || bytes_per_step == 32u || bytes_per_step == 64u || bytes_per_step == 128u) && waves_per_simd >= 1u && waves_per_simd <= 8u && steps >= 16u &&
                  footprint_bytes >= 4096u && footprint_bytes <= ((size_t)32 << 30), HK_E_INVALID, "bad argument");
   PROBE_BEGIN(c);
   uint32_t n_records = 1u;
@@ -239,7 +240,8 @@ int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step
       (void)hipEventRecord(e0, stream);
       if (loads == 1u) hipLaunchKernelGGL(k_gather_chase<1>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
       else if (loads == 2u) hipLaunchKernelGGL(k_gather_chase<2>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
-      else hipLaunchKernelGGL(k_gather_chase<4>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
+      else if (loads == 4u) hipLaunchKernelGGL(k_gather_chase<4>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
+      else hipLaunchKernelGGL(k_gather_chase<8>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);  // 128 B: a record of the wide walk (hk_wide.hpp)
       (void)hipEventRecord(e1, stream);
     }
     float ms = 0.0f;

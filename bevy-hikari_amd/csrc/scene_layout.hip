@@ -513,6 +513,7 @@ void point_scene_at_slot(hk_ctx* c) {
 
 int finalize_scene(hk_ctx* c) {
   if (!c->mesh_dirty && !c->dynamic_dirty && !c->textures_dirty) return HK_OK;
+  c->pre_chain_ok = false;  // (the scene changes in the main stream's order: the next frame's primary rays follow it there)
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
   const size_t n_nodes = c->asset_nodes.size();
   bool need_static = c->mesh_dirty || !c->scene_mem || c->node_prim_offset.size() != n_nodes;

@@ -177,6 +177,7 @@ int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
                                  1u, 1u) == 0, HK_E_HIP, "device build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
   c->mirrors_stale = true;
   c->wide_tlas_dirty = true;
+  c->pre_chain_ok = false;
   c->device_tree_builds += 1;
   return HK_OK;
 }
@@ -324,6 +325,7 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
   c->rf_last_moved = moved;
   c->mirrors_stale = true;
   c->wide_tlas_dirty = true;
+  c->pre_chain_ok = false;
   c->device_refits += 1;
   if (commit) builder_commit_transforms(b);
   return HK_OK;

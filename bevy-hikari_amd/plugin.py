@@ -696,6 +696,12 @@ class Engine:
         self.api.call("traversal_mode", self.ctx, C.byref(v), None)
         return bool(v.value & 0x100)
 
+    def prepasses_pipelined(self):
+        """Frames whose primary rays ran on the context's fourth stream next to the previous frame's light passes (hikari_hip_debug.h)."""
+        n = C.c_uint64()
+        self.api.call("debug_prepasses_pipelined", self.ctx, C.byref(n))
+        return int(n.value)
+
     def measure_hbm(self, bytes_per_array=1 << 30, reps=8):
         """Empirical HBM ceiling: (copy GB/s, triad GB/s) of grid-stride float4 streams over arrays too big for the Infinity Cache."""
         cp, tr = C.c_double(), C.c_double()

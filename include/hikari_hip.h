@@ -324,6 +324,9 @@ typedef struct HkHaloOp {
 } HkHaloOp;
 
 #define HK_TIMING_SLOTS 24
+/* slot 18 (beyond the HkPass ids): every TRACE launch of the queue-based indirect pass on its own (bounces + 1 launches per pass);
+ * selected like a pass, by bit 18 of hk_set_timing_mask */
+#define HK_TIMING_TRACE_STAGES 18u
 typedef struct HkStats {
   uint64_t rays_primary;      /* G-buffer rays */
   uint64_t rays_tlas;         /* traverse_top invocations (light.wgsl:442) */
@@ -421,6 +424,13 @@ int hk_device_count(int* count);
  * the A/B the tests and `bench.py --no-wide-walk` use.  hk_traversal_mode reports HK_TRAVERSAL_WIDE when it is in use;
  * HkStats.wide_stack_lost counts pending subtrees a walk had to drop (0 for trees up to ~80 levels deep). */
 #define HK_CTX_NO_WIDE_WALK 256u
+/* Measurement (round 5): the frame takes exactly the schedule and walks it takes without the flag - unlike HK_CTX_COUNT_RAYS, whose
+ * counting kernels exist in the fused form only and switch the queue-based schedule off - but the trace stages of the queue-based
+ * indirect pass run the COUNTING twin of their kernel: per stage, records fetched (of them in the instance tree), triangle tests,
+ * instance entries, rays, closest hits, pieces of long walks handed to idle lanes, and the moments the stage's queue ran dry and its
+ * last wave left (hikari_hip_debug.h hk_debug_read_wf_timeline).  bench.py prices the trace kernel of configs 3 / 4 with these - the
+ * walk that is TIMED, not a replay in another form. */
+#define HK_CTX_COUNT_WALKS 512u
 int hk_create(int device_id, uint32_t flags, hk_ctx** out);
 void hk_destroy(hk_ctx* ctx);
 
