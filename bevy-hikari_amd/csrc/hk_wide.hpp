@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 
@@ -112,45 +114,38 @@ __device__ __forceinline__ void wide_begin(WideWalk& k, const WideTrees& wt, f3 
   k.cinv = k.inv_direction;
   k.ld = direction;
 }
-// One step: pop (if there is nothing to visit) and / or visit one record.  Returns the lane's next phase; `pending` = the leaf a
-// PH_TRI / PH_ENTRY lane is parked at.
-// (COUNT: rc->nodes / rc->top_nodes count the records actually FETCHED - a turn that only pops fetches nothing)
-template <class S, bool COUNT = false>
-__device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, S& st, uint32_t& pending, RayCounters* rc = nullptr) {
-  if (k.cur == WIDE_NONE) {
-    if (k.sp == k.base) return PH_IDLE;
-    const uint32_t e = wide_pop(k, st);
-    if (e == WIDE_LEAVE) {  // traverse_bottom returned, light.wgsl:465-470
-      if (k.intersected) {
-        k.hit.instance_index = k.cur_instance;
-        if (k.hit.distance < k.early_distance) return PH_IDLE;
-      }
-      k.in_blas = false;
-      k.co = k.origin;
-      k.cinv = k.inv_direction;
-      return PH_NODE;
+// A NODE lane with nothing to visit takes the next entry off its stack.  Returns the lane's phase: PH_IDLE (the walk has ended),
+// PH_TRI / PH_ENTRY (a leaf: parked at `pending`), PH_NODE - with k.cur set (a record to fetch) or still WIDE_NONE (the entry only
+// changed the walk's state: the mesh tree's end marker, a tombstone, the excluded instance).
+template <class S>
+__device__ __forceinline__ uint32_t wide_pop_next(WideWalk& k, S& st, uint32_t& pending) {
+  if (k.sp == k.base) return PH_IDLE;
+  const uint32_t e = wide_pop(k, st);
+  if (e == WIDE_LEAVE) {  // traverse_bottom returned, light.wgsl:465-470
+    if (k.intersected) {
+      k.hit.instance_index = k.cur_instance;
+      if (k.hit.distance < k.early_distance) return PH_IDLE;
     }
-    if (e == WIDE_NONE) return PH_NODE;
-    if (e >= HK_LEAF) {
-      pending = e - HK_LEAF;
-      if (k.in_blas) return PH_TRI;
-      return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
-    }
-    k.cur = e;
+    k.in_blas = false;
+    k.co = k.origin;
+    k.cinv = k.inv_direction;
+    return PH_NODE;
   }
-  const float4* __restrict__ rec = (k.in_blas ? wt.blas + 8u * (size_t)(k.mesh_base + k.cur) : wt.tlas + 8u * (size_t)k.cur);
-  if (COUNT) {
-    rc->nodes++;
-    rc->top_nodes += k.in_blas ? 0u : 1u;
+  if (e == WIDE_NONE) return PH_NODE;
+  if (e >= HK_LEAF) {
+    pending = e - HK_LEAF;
+    if (k.in_blas) return PH_TRI;
+    return pending != k.exclude_instance ? PH_ENTRY : PH_NODE;
   }
-  // The eight 16-B loads of the record are ISSUED TOGETHER - one round trip to the memory system per record, not four.  Left to
-  // itself the scheduler sometimes sinks each pair next to its slab test to save registers (round 5: the build with the rank
-  // loads of wide_tie_goes_to did, and the trace stages of configs 3 / 4 got 11 % / 18 % slower - profiles/r05_rank_rule_ab.txt);
-  // the barrier keeps the batch whatever else changes in the kernel.
-  float4 r8[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) r8[c] = rec[c];
-  __builtin_amdgcn_sched_barrier(0);
+  k.cur = e;
+  return PH_NODE;
+}
+__device__ __forceinline__ const float4* wide_record(const WideWalk& k, const WideTrees& wt) {  // the record k.cur names
+  return k.in_blas ? wt.blas + 8u * (size_t)(k.mesh_base + k.cur) : wt.tlas + 8u * (size_t)k.cur;
+}
+// the record's four boxes against the ray: nearest child next, the others onto the stack (farthest first)
+template <class S>
+__device__ __forceinline__ uint32_t wide_node_test(WideWalk& k, const float4 (&r8)[8], S& st, uint32_t& pending) {
   float t[4];
   uint32_t link[4];
   const float bound = fmin_(k.hit.distance, k.limit);
@@ -193,6 +188,30 @@ __device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, 
   k.cur = link[0];
   return PH_NODE;
 }
+// One step: pop (if there is nothing to visit) and / or visit one record.  Returns the lane's next phase; `pending` = the leaf a
+// PH_TRI / PH_ENTRY lane is parked at.
+// (COUNT: rc->nodes / rc->top_nodes count the records actually FETCHED - a turn that only pops fetches nothing)
+template <class S, bool COUNT = false>
+__device__ __forceinline__ uint32_t wide_node(WideWalk& k, const WideTrees& wt, S& st, uint32_t& pending, RayCounters* rc = nullptr) {
+  if (k.cur == WIDE_NONE) {
+    const uint32_t ph = wide_pop_next(k, st, pending);
+    if (ph != PH_NODE || k.cur == WIDE_NONE) return ph;
+  }
+  const float4* __restrict__ rec = wide_record(k, wt);
+  if (COUNT) {
+    rc->nodes++;
+    rc->top_nodes += k.in_blas ? 0u : 1u;
+  }
+  // The eight 16-B loads of the record are ISSUED TOGETHER - one round trip to the memory system per record, not four.  Left to
+  // itself the scheduler sometimes sinks each pair next to its slab test to save registers (round 5: the build with the rank
+  // loads of wide_tie_goes_to did, and the trace stages of configs 3 / 4 got 11 % / 18 % slower - profiles/r05_rank_rule_ab.txt);
+  // the barrier keeps the batch whatever else changes in the kernel.
+  float4 r8[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) r8[c] = rec[c];
+  __builtin_amdgcn_sched_barrier(0);
+  return wide_node_test(k, r8, st, pending);
+}
 // the reference's tie rule between two candidates at exactly the same distance: the one its stackless walk meets first wins, i.e. the
 // leaf of smaller position in ordering 0 - instance leaves first, triangle leaves inside one instance (hk_kernels.hpp WideTrees ranks)
 #ifndef HK_WIDE_TIE_BY_RANK
@@ -206,14 +225,13 @@ __device__ __forceinline__ bool wide_tie_goes_to(const WideTrees& wt, uint32_t i
   return instance < best_instance || (instance == best_instance && primitive < best_primitive);
 #endif
 }
-__device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, const WideTrees& wt, uint32_t pending) {
-  const uint32_t primitive_index = k.prim_base + pending;
+__device__ __forceinline__ uint32_t wide_triangle_test(WideWalk& k, const WideTrees& wt, uint32_t primitive_index, f3 v0, f3 v1, f3 v2) {
   Ray lr;
   lr.origin = k.co;
   lr.direction = k.ld;
   lr.inv_direction = k.cinv;
   f2 uv;
-  const float d = intersects_triangle(lr, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]), &uv);
+  const float d = intersects_triangle(lr, v0, v1, v2, &uv);
   // closest hit; of two candidates at EXACTLY the same distance the reference keeps the first its walk meets (light.wgsl:415-424) -
   // the leaf of smaller rank, whichever this walk met first: the result is the reference's, and it depends neither on the order of
   // the visits, nor on how the walk was split among lanes, nor on timing
@@ -234,43 +252,125 @@ __device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc,
   }
   return PH_NODE;
 }
+__device__ __forceinline__ uint32_t wide_triangle(WideWalk& k, const DScene& sc, const WideTrees& wt, uint32_t pending) {
+  const uint32_t primitive_index = k.prim_base + pending;
+  return wide_triangle_test(k, wt, primitive_index, xyz(sc.tri_v0[primitive_index]), xyz(sc.tri_v1[primitive_index]), xyz(sc.tri_v2[primitive_index]));
+}
+// entering an instance (light.wgsl:458-464) from the pieces of its record the walk needs: the inverse model's columns, the mesh's
+// (material, vertex, primitive, node_offset) and its node count
 template <class S>
-__device__ __forceinline__ void wide_enter(WideWalk& k, const DScene& sc, S& st, uint32_t instance_index) {
-  const DInstance& in = sc.instances[instance_index];
-  k.co = world_to_local_position(in, k.origin);
-  k.ld = world_to_local_direction(in, k.direction);
+__device__ __forceinline__ void wide_enter_apply(WideWalk& k, S& st, uint32_t instance_index, float4 im0, float4 im1, float4 im2, float4 im3, uint32_t primitive,
+                                                  uint32_t node_offset, uint32_t node_count) {
+  const f4 q = mul(im0, im1, im2, im3, F4(k.origin, 1.0f));  // world_to_local_position / _direction (hk_device.hpp), on the loaded columns
+  k.co = xyz(q) / q.w;
+  k.ld = xyz(mul(im0, im1, im2, im3, F4(k.direction, 0.0f)));
   k.cinv = 1.0f / k.ld;
   k.mark = k.sp;
   wide_push(k, st, WIDE_LEAVE);
   k.blas_base = k.sp;
-  k.mesh_base = in.node_offset;
-  k.cur = in.node_count - 1u;  // the mesh tree's root record
-  k.prim_base = in.primitive;
+  k.mesh_base = node_offset;
+  k.cur = node_count - 1u;  // the mesh tree's root record
+  k.prim_base = primitive;
   k.cur_instance = instance_index;
   k.in_blas = true;
   k.intersected = false;
 }
+template <class S>
+__device__ __forceinline__ void wide_enter(WideWalk& k, const DScene& sc, S& st, uint32_t instance_index) {
+  const DInstance& in = sc.instances[instance_index];
+  wide_enter_apply(k, st, instance_index, in.im0, in.im1, in.im2, in.im3, in.primitive, in.node_offset, in.node_count);
+}
+
+// ONE MEMORY ROUND TRIP PER TURN (round 5 EXPERIMENT - measured slower, off: HK_WIDE_OVERLAPPED_TURNS / HK_WF_DRY_OVERLAPPED below and
+// in kernels_wavefront.hip).  A step of a walk is a dependent fetch followed by arithmetic: a record (8 x 16 B), a
+// triangle's vertices (3 x 16 B) or an instance's record (6 x 16 B of it).  Served phase after phase - the record fetches of the NODE
+// lanes, then the vertex fetches of the TRI lanes, then the instance fetches of the ENTRY lanes - a turn of the wave costs three
+// round trips to the memory system, and where the walks are latency-bound (the tails of the trace stages: 43 % / 77 % of their time
+// on configs 4 / 3; the fused primary rays) that is what a step costs.  Here every lane first decides what it fetches this turn
+// (a NODE lane with nothing to visit pops its stack - which may park it at a leaf it can serve right away), then ALL fetches are
+// issued from one block into the same eight landing registers, then each lane does its arithmetic.  A lane's own sequence of
+// records, triangle tests and instance entries - and with it every bit of its result - is that of wide_node / wide_triangle /
+// wide_enter called one after the other.
+struct WideFetch {
+  const char* p;   // first piece
+  uint32_t n;      // pieces to fetch (0: nothing this turn)
+  uint32_t kind;   // PH_NODE / PH_TRI / PH_ENTRY
+};
+template <class S, bool COUNT>
+__device__ __forceinline__ void wide_step(WideWalk& k, const DScene& sc, const WideTrees& wt, S& st, uint32_t& phase, uint32_t& pending, RayCounters* rc) {
+  if (phase == PH_NODE && k.cur == WIDE_NONE) phase = wide_pop_next(k, st, pending);
+  WideFetch f{nullptr, 0u, PH_IDLE};
+  uint32_t primitive_index = 0u;
+  if (phase == PH_NODE && k.cur != WIDE_NONE) {
+    f = WideFetch{(const char*)wide_record(k, wt), 8u, PH_NODE};
+    if (COUNT) {
+      rc->nodes++;
+      rc->top_nodes += k.in_blas ? 0u : 1u;
+    }
+  } else if (phase == PH_TRI) {
+    primitive_index = k.prim_base + pending;
+    f = WideFetch{(const char*)(sc.tri_v0 + primitive_index), 3u, PH_TRI};
+    if (COUNT) rc->tris++;
+  } else if (phase == PH_ENTRY) {
+    f = WideFetch{(const char*)(sc.instances + pending), 6u, PH_ENTRY};
+    if (COUNT) rc->entries++;
+  }
+  // where piece i lies behind f.p: a record's pieces are adjacent; a triangle's vertices sit in three planes; of an instance's record
+  // the inverse model (4 x 16 B at 0) and the two 16-B rows of indices behind its eleven matrix columns
+  const uint32_t tri1 = (uint32_t)((const char*)sc.tri_v1 - (const char*)sc.tri_v0), tri2 = (uint32_t)((const char*)sc.tri_v2 - (const char*)sc.tri_v0);
+  float4 b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t off_tri = i == 1 ? tri1 : (i == 2 ? tri2 : 0u);
+    const uint32_t off_entry = i < 4 ? 16u * (uint32_t)i : (i == 4 ? (uint32_t)offsetof(DInstance, material) : (uint32_t)offsetof(DInstance, node_count));
+    const uint32_t off = f.kind == PH_NODE ? 16u * (uint32_t)i : (f.kind == PH_TRI ? off_tri : off_entry);
+    b[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if ((uint32_t)i < f.n) b[i] = *(const float4*)(f.p + off);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (f.kind == PH_NODE) {
+    phase = wide_node_test(k, b, st, pending);
+  } else if (f.kind == PH_TRI) {
+    phase = wide_triangle_test(k, wt, primitive_index, xyz(b[0]), xyz(b[1]), xyz(b[2]));
+  } else if (f.kind == PH_ENTRY) {
+    wide_enter_apply(k, st, pending, b[0], b[1], b[2], b[3], f2u(b[4].z), f2u(b[4].w), f2u(b[5].x));
+    phase = PH_NODE;
+  }
+}
 
 // The whole walk for one ray per lane, in lock step (the fused kernels): every turn each live lane visits one record or pops; the
 // triangle tests and instance entries of the lanes that reached a leaf follow in the same turn.
-template <class S>
+// HK_WIDE_OVERLAPPED_TURNS = 1: every turn is ONE wide_step.  Built, bit-exact, measured SLOWER (round 5, profiles/r05_overlapped_turns_ab.txt):
+// the primary rays of configs 3 / 4 0.91 -> 1.03 / 2.79 -> 2.94 ms - they are bound by the bytes their record fetches move from the
+// L1 / L2 (the 128-B gather roof of bench.py: 16 B per clock and CU whatever the access shape, tools/coop_probe.py), not by the
+// latency of a turn, and the predicated fetch block costs more instructions than the three it replaces.
+#ifndef HK_WIDE_OVERLAPPED_TURNS
+#define HK_WIDE_OVERLAPPED_TURNS 0
+#endif
+// (COUNT: the kernel's counting instantiation - the product's carries no counter at all; left to the optimiser, the counters of a
+// RayCounters whose address is taken stayed in scratch memory, a load / add / store per record in the walk's loop)
+template <bool COUNT, class S>
 __device__ __forceinline__ Hit traverse_top_wide(const DScene& sc, const WideTrees& wt, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance,
                                                   S& st, RayCounters& rc) {
-  rc.tlas++;
+  if (COUNT) rc.tlas++;
   WideWalk k;
   wide_begin(k, wt, ray.origin, ray.direction, max_distance, early_distance, exclude_instance);
   uint32_t phase = PH_NODE, pending = 0u;
+#if HK_WIDE_OVERLAPPED_TURNS
+  while (phase != PH_IDLE) wide_step<S, COUNT>(k, sc, wt, st, phase, pending, &rc);
+#else
   while (phase != PH_IDLE) {
-    if (phase == PH_NODE) phase = wide_node<S, true>(k, wt, st, pending, &rc);  // (rc.nodes: records fetched)
+    if (phase == PH_NODE) phase = wide_node<S, COUNT>(k, wt, st, pending, &rc);  // (rc.nodes: records fetched)
     if (phase == PH_TRI) {
-      rc.tris++;
+      if (COUNT) rc.tris++;
       phase = wide_triangle(k, sc, wt, pending);
     } else if (phase == PH_ENTRY) {
-      rc.entries++;
+      if (COUNT) rc.entries++;
       wide_enter(k, sc, st, pending);
       phase = PH_NODE;
     }
   }
+#endif
   return k.hit;
 }
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassP
       WideStackPrivate<HK_WIDE_LDS_STACK, 96u> stack;
       stack.lds = wide_lds;
       stack.lost = pp.wide.lost;
-      hit = traverse_top_wide(sc, pp.wide, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, stack, rc);
+      hit = traverse_top_wide<COUNT>(sc, pp.wide, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, stack, rc);
     } else {
       hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
     }

@@ -535,6 +535,14 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 #ifndef HK_WF_DRY_ALL_PHASES
 #define HK_WF_DRY_ALL_PHASES 1
 #endif
+// HK_WF_DRY_OVERLAPPED = 1: a dry wave's turn is ONE memory round trip (hk_wide.hpp wide_step) instead of the three phases one after the
+// other.  Built, bit-exact (the suite ran with it), measured SLOWER - the indirect pass of configs 3 / 4 3.67 -> 4.50 / 6.47 -> 7.91 ms
+// (profiles/r05_overlapped_turns_ab.txt): after the queue runs dry a wave is not a few lanes waiting for memory - work sharing keeps most
+// of its lanes walking small pieces, and a turn that serves one step per lane pays the turn's bookkeeping (merge, ballots, hand-over)
+// once per step instead of once per two records.
+#ifndef HK_WF_DRY_OVERLAPPED
+#define HK_WF_DRY_OVERLAPPED 0
+#endif
 #ifndef HK_WF_SHARE_MIN
 #define HK_WF_SHARE_MIN 16u  // idle lanes a dry wave must have before its working lanes hand entries over
 #endif
@@ -802,6 +810,28 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     // is dry every parked lane is served every turn: what is left are the walks that end the stage, and (HK_WF_WIDE_SHARE) the
     // lanes that help them - a lane that waits a turn for its phase makes the stage a turn longer.
     const bool all_phases = HK_WF_DRY_ALL_PHASES && dry;
+#if HK_WF_DRY_OVERLAPPED
+    if (all_phases) {
+      // the dry wave's turn: ONE round trip to the memory system - every working lane takes one step of its walk, the fetches of
+      // the records, the triangles and the instances issued together (hk_wide.hpp wide_step)
+      if (phase == PH_NODE || phase == PH_TRI || phase == PH_ENTRY) {
+#if HK_WF_WIDE_SHARE
+        k.limit = u2f(share_best[(threadIdx.x & ~63u) + root]);  // (what the other pieces of the ray have found meanwhile)
+#endif
+        const float before = k.hit.distance;
+        if (phase == PH_NODE) {
+          if (TL) tl_steps += 1u;
+          steps += 1u;
+        }
+        wide_step<WideStackSpill, COUNT>(k, sc, wt, stack, phase, pending, &cn);
+#if HK_WF_WIDE_SHARE
+        if (k.hit.distance < before) atomicMin(&share_best[(threadIdx.x & ~63u) + root], f2u(k.hit.distance));  // (distances are >= 0: their bits order like they do)
+#endif
+        if (phase == PH_IDLE) finish();
+      }
+      continue;
+    }
+#endif
     if (all_phases ? n_node != 0u : (n_node >= n_tri && n_node >= n_entry && n_node != 0u)) {
 #if HK_WF_WIDE_SHARE
       if (dry) k.limit = u2f(share_best[(threadIdx.x & ~63u) + root]);  // (what the other pieces of the ray have found meanwhile)

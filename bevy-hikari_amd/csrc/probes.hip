@@ -116,6 +116,37 @@ __global__ __launch_bounds__(256) void k_gather_chase(const uint4* __restrict__ 
   }
   if (acc == 0x12345678u) sink[0] = at;  // (keeps the chain alive)
 }
+// Round 5 experiment: the same chains of 128-B records, fetched COOPERATIVELY - in instruction i the eight lanes 8a .. 8a + 7 load the
+// eight 16-B pieces of the record that lane 8i + a wants: every wave-level load touches 8 lines (each covered by 8 consecutive lanes)
+// instead of 64.  Lane b = 0 of a group holds the record's first piece, with the chain's next pointer: it goes back to its owner
+// through LDS.  What it measures: whether the rate of divergent record fetches - 1 lane-load per clock and CU when every lane loads
+// its own record (the roofs of bench.py) - is a matter of LINES per instruction (then this runs several times faster) or of lanes.
+__global__ __launch_bounds__(256) void k_gather_chase_coop(const uint4* __restrict__ table, uint32_t n_records, uint32_t steps, uint32_t* __restrict__ sink) {
+  __shared__ uint32_t next_of[256];
+  const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u, wave_base = threadIdx.x & ~63u;
+  const uint32_t a = lane >> 3, b = lane & 7u;
+  uint32_t at = (tid * 2654435761u + 12345u) % n_records;
+  uint32_t acc = 0u;
+  for (uint32_t k = 0; k < steps; ++k) {
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t want = (uint32_t)__shfl((int)at, (int)(8u * (uint32_t)i + a));  // the record lane 8 i + a is at
+      v[i] = table[(size_t)want * 8u + b];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      acc += v[i].w;
+      if (b == 0u) next_of[wave_base + 8u * (uint32_t)i + a] = v[i].x;  // piece 0 of the record of lane 8 i + a: its next pointer
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    at = next_of[threadIdx.x];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (acc == 0x12345678u) sink[0] = at;
+}
 __global__ __launch_bounds__(256) void k_gather_fill(uint4* __restrict__ table, uint32_t n_records, uint32_t loads, uint32_t mult, uint32_t add) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n_records) return;
@@ -214,9 +245,11 @@ int hk_measure_valu(hk_ctx* c, uint32_t iters, double ginstr_s[4]) {
 // hikari_hip_debug.h
 int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps, uint32_t workgroups, double* gloads_s,
                       double* gbytes_s) {
-  HK_REQUIRE(c && gloads_s && gbytes_s && (bytes_per_step == 16u || bytes_per_step == 32u || bytes_per_step == 64u || bytes_per_step == 128u) && waves_per_simd >= 1u && waves_per_simd <= 8u && steps >= 16u &&
+  HK_REQUIRE(c && gloads_s && gbytes_s && (bytes_per_step == 16u || bytes_per_step == 32u || bytes_per_step == 64u || bytes_per_step == 128u || bytes_per_step == 129u) && waves_per_simd >= 1u && waves_per_simd <= 8u && steps >= 16u &&
                  footprint_bytes >= 4096u && footprint_bytes <= ((size_t)32 << 30), HK_E_INVALID, "bad argument");
   PROBE_BEGIN(c);
+  const bool coop = bytes_per_step == 129u;  // 128-B records fetched cooperatively (k_gather_chase_coop)
+  if (coop) bytes_per_step = 128u;
   uint32_t n_records = 1u;
   while ((size_t)n_records * 2u * bytes_per_step <= footprint_bytes && n_records < (1u << 30)) n_records *= 2u;  // a power of two: the LCG's period
   const uint32_t loads = bytes_per_step / 16u;
@@ -238,7 +271,8 @@ int hk_measure_gather(hk_ctx* c, size_t footprint_bytes, uint32_t bytes_per_step
     const dim3 grid(workgroups ? workgroups : (unsigned)prop.multiProcessorCount * waves_per_simd);
     for (int pass = 0; pass < 2; ++pass) {  // (pass 0 warms up: page tables, clocks)
       (void)hipEventRecord(e0, stream);
-      if (loads == 1u) hipLaunchKernelGGL(k_gather_chase<1>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
+      if (coop) hipLaunchKernelGGL(k_gather_chase_coop, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
+      else if (loads == 1u) hipLaunchKernelGGL(k_gather_chase<1>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
       else if (loads == 2u) hipLaunchKernelGGL(k_gather_chase<2>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
       else if (loads == 4u) hipLaunchKernelGGL(k_gather_chase<4>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);
       else hipLaunchKernelGGL(k_gather_chase<8>, grid, dim3(256), 0, stream, (const uint4*)table, n_records, steps, sink);  // 128 B: a record of the wide walk (hk_wide.hpp)

@@ -35,7 +35,7 @@ int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, floa
 
 /* Measurement hook for the roof of the BVH walks of scenes beyond the LDS copy (round 4): every lane of
  * `waves_per_simd` resident waves per SIMD follows its own chain of `steps` DEPENDENT loads through a random permutation cycle over
- * `footprint_bytes` of records - `bytes_per_step` = 16 (one 16-B load per step), 32 (the two adjacent 16-B loads of a node step), 64 (a reservoir record) or 128 (a record of the wide walk: eight adjacent 16-B loads, one 128-B line) -
+ * `footprint_bytes` of records - `bytes_per_step` = 16 (one 16-B load per step), 32 (the two adjacent 16-B loads of a node step), 64 (a reservoir record) 128 (a record of the wide walk: eight adjacent 16-B loads, one 128-B line) or 129 (the same 128-B records fetched COOPERATIVELY: eight consecutive lanes load the eight pieces of one lane's record - round 5 experiment) -
  * i.e. 64 unrelated addresses per wave-level load instruction and no reuse.  Returns the rate of wave-level load instructions
  * (1e9 / s) and of loaded bytes (lanes x bytes_per_step per step; GB/s).  No walk of that shape runs faster on the chip: the
  * trace kernels of configs 3 / 4 are priced against it in bench.py (the HBM roof is meaningless for them - they move little). */

@@ -69,11 +69,15 @@ def _sequence(name, scene, cam, s, lights, n_frames, flags_fast=0):
                       "per_buffer_rel_l2": {k: v[0] for k, v in per.items()}})
     assert exact.engine.traversal_mode()[0] == "reference" and fast.engine.traversal_mode()[0] == "threaded"
     assert fast.engine.indirect_schedule() == "wavefront" and fast.engine.wide_walk() and fast.engine.stats().wide_stack_lost == 0
-    data = {"case": name, "frames": n_frames, "bar": 1e-3, "fast": "flags 0 (threaded trees + queue-based indirect pass + wide walk: what bench.py times)",
+    data = {"case": name, "frames": n_frames, "bar": 1e-3, "held_to": 2e-4, "fast": "flags 0 (threaded trees + queue-based indirect pass + wide walk: what bench.py times)",
             "against": "HK_CTX_EXACT_TRAVERSAL (bit-exact vs the oracle)", "max_worst_rel_l2": max(c["worst_rel_l2"] for c in curve),
             "max_output_rel_l2": max(c["output_rel_l2"] for c in curve), "curve": curve}
     _report(f"default_mode_sequence_{name}", data)
-    over = [(c["frame"], c["worst_buffer"], c["worst_rel_l2"]) for c in curve if not c["worst_rel_l2"] <= 1e-3]
+    # The north star's bar is 1e-3.  Since round 5 the default mode's hits ARE the reference's (ties by the leaves' ranks, kept occluders
+    # in the reference's order): what is left is a pixel or two per 8 M and frame (6e-5 at most over these sequences,
+    # profiles/r05_default_mode_sequence_*.json) - the test holds the curve to 2e-4, so that a return of either order dependence
+    # (8.6e-4 after two frames, 1.6e-2 after thirty: round 4's state) fails it long before the bar is in sight.
+    over = [(c["frame"], c["worst_buffer"], c["worst_rel_l2"]) for c in curve if not c["worst_rel_l2"] <= 2e-4]
     assert not over, over
     return data
 
