@@ -39,6 +39,8 @@ SCRATCH_ALLOWED = {
     r"k_wf_final": 16,
     r"k_prepass<(true|false), 4>": 416,        # the wide walk's stack beyond its 28 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks that deep
     r"k_wf_trace<false, true>": 64,            # the instrumented twin of tools/wf_timeline.py (never launched by the product)
+    r"k_wf_trace_wide<(true, false|false, true)>": 64,   # ... and the wide kernel's two twins (timeline / HK_CTX_COUNT_WALKS): their bookkeeping
+                                                         # spills a few VGPRs at the 96 the five-waves bound leaves; the product <false, false> must not
     # scenes beyond LDS: 4 waves per SIMD with 9 / 54 spilled VGPRs beat 3 without (profiles/r03_occupancy_ab.txt); COUNT = the replays
     r"k_direct_lit<false, (true|false), 0>": 48,
     r"k_direct_lit<true, (true|false), 0>": 112,
@@ -75,7 +77,8 @@ def test_lds_leaves_room_for_the_scene_copy(table):
     has to fit the CU's 160 KB."""
     for name, r in table.items():
         if re.search(r"k_wf_trace_wide", name):   # global-memory scenes: no scene copy, a 28 KB stack + the sharing tables instead, FIVE workgroups per CU
-            assert 5 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 96 and r["vgpr_spill_count"] == 0, name
+            assert 5 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 96, name
+            assert r["vgpr_spill_count"] == 0 or not re.search(r"<false, false>", name), name   # (the product instantiation; its measurement twins may spill)
             continue
         if re.search(r"k_prepass<(true|false), 4>", name):   # ... the fused prepass: the stack only, 4 workgroups per CU (104 VGPRs)
             assert 4 * r["group_segment_fixed_size"] <= 160 * 1024, name
