@@ -616,7 +616,13 @@ HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, floa
 // in any order, so only rays that do find an occluder pay for not meeting it front to back.
 template <bool REF_ORDER = false>
 HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, RayCounters& rc) {
-  if (sc.flat_mode) return traverse_flat<REF_ORDER>(sc, ray, max_distance, early_distance, exclude_instance, rc);
+  // (a ray whose occluder is kept does not take the one-level walk either: that is ANOTHER tree - whichever of its orderings is
+  // walked, the first occluder it meets need not be the reference's; the two-level walk below in ordering 0 is the reference's walk.
+  // HK_FLAT_KEPT_OCCLUDERS = 1 is the A/B: round 3-4's behaviour, the one-level walk for these rays too.)
+#ifndef HK_FLAT_KEPT_OCCLUDERS
+#define HK_FLAT_KEPT_OCCLUDERS 0
+#endif
+  if (sc.flat_mode && (!REF_ORDER || HK_FLAT_KEPT_OCCLUDERS)) return traverse_flat<REF_ORDER>(sc, ray, max_distance, early_distance, exclude_instance, rc);
   rc.tlas++;
 #ifdef HK_PROFILE_SECTIONS
   uint32_t wev_[5] = {0u, 0u, 0u, 0u, 0u};

@@ -210,8 +210,15 @@ __global__ __launch_bounds__(256) void k_full_screen_albedo(DScene sc, DFrame fr
 #ifndef HK_DIRECT_GLOBAL_WAVES
 #define HK_DIRECT_GLOBAL_WAVES 4
 #endif
+// (LDS == 2, the one-level mode: since round 5 both walks of this kernel keep their occluder and take the reference's two-level walk from
+// the LDS copy - hk_device.hpp traverse_top<true> - which wants 129 / 142 VGPRs where the one-level walk had 104 / 118.  Capped at
+// 128 (4 waves per SIMD; 4 / 56 spilled) the Cornell frame is where it was - 0.981 / 0.984 ms against 0.986 / 0.983 with the
+// one-level walk for these rays and 0.986 / 0.990 uncapped at 3 waves: profiles/r05_flat_kept_occluders_ab.txt)
+#ifndef HK_DIRECT_FLAT_WAVES
+#define HK_DIRECT_FLAT_WAVES 4
+#endif
 template <bool EMISSIVE_LIT, bool COUNT, int LDS>
-__global__ __launch_bounds__(256, (LDS == 0 ? HK_DIRECT_GLOBAL_WAVES : 1)) void k_direct_lit(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+__global__ __launch_bounds__(256, (LDS == 0 ? HK_DIRECT_GLOBAL_WAVES : (LDS == 2 ? HK_DIRECT_FLAT_WAVES : 1))) void k_direct_lit(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                      unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);

@@ -415,13 +415,14 @@ int hk_device_count(int* count);
 /* Scenes beyond the LDS copy, product default (no HK_CTX_EXACT_TRAVERSAL): the CLOSEST-HIT walks - the primary rays of the prepass and
  * every ray of the wavefront schedule's trace stages - read 128-B records of an inner node's four grandchildren (derived on the
  * device from ordering 0 of the trees the scene holds) and take the children nearest first with a per-lane stack: two levels of the
- * tree per dependent fetch, on both levels of the scene.  Same candidates, same per-triangle arithmetic on the same operands: the
- * parity bar is the threaded walk's (1e-3 relative L2; any-hit outcomes do not depend on the order).  Of two candidates at EXACTLY
- * the same distance the one with the smaller (instance, primitive) wins - a rule of the walk's own (the reference keeps the first
- * it meets in its order), which makes a ray's result independent of the visit order, of timing, and of how the trace stage splits
- * a long walk among the idle lanes of its wave at the end of a stage; two runs of the same frames are equal byte for byte.  The
- * shadow rays of the fused direct passes keep the threaded orderings (measured: faster there).  bit8 switches the wide walk off:
- * the A/B the tests and `bench.py --no-wide-walk` use.  hk_traversal_mode reports HK_TRAVERSAL_WIDE when it is in use;
+ * tree per dependent fetch, on both levels of the scene.  Same candidates, same per-triangle arithmetic on the same operands, and of
+ * two candidates at EXACTLY the same distance the one the reference's own walk meets first (decided from the leaves' positions in
+ * the reference's flattening, kept next to the records): the closest hit is the reference's, independent of the visit order, of
+ * timing, and of how the trace stage splits a long walk among the idle lanes of its wave at the end of a stage; two runs of the
+ * same frames are equal byte for byte.  Any-hit rays: whether a ray is occluded does not depend on the order; the rays whose
+ * OCCLUDER is kept (the direct-light passes store its position in the reservoir) walk the reference's own order.  bit8 switches the
+ * wide walk off (the closest-hit walks then take the direction-threaded skip-link walk, whose exact ties may fall differently): the
+ * A/B the tests and `bench.py --no-wide-walk` use.  hk_traversal_mode reports HK_TRAVERSAL_WIDE when it is in use;
  * HkStats.wide_stack_lost counts pending subtrees a walk had to drop (0 for trees up to ~80 levels deep). */
 #define HK_CTX_NO_WIDE_WALK 256u
 /* Measurement (round 5): the frame takes exactly the schedule and walks it takes without the flag - unlike HK_CTX_COUNT_RAYS, whose

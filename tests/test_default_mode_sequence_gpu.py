@@ -82,6 +82,30 @@ def _sequence(name, scene, cam, s, lights, n_frames, flags_fast=0):
     return data
 
 
+def test_config2_default_mode_every_buffer_of_24_frames_1080p():
+    """BASELINE config 2 (the configuration the metric is quoted on) at 1920x1080 in the product default - the one-level walk from the
+    LDS copy, frame pipelining - against HK_CTX_EXACT_TRAVERSAL (bit-exact against the oracle): EVERY buffer, the ten reservoir
+    buffers included, byte for byte, every fourth frame of 24.  (Round 3-4 excepted the reservoir records: the one-level walk kept
+    whichever occluder it met first.  Since round 5 a ray whose occluder is kept takes the reference's own walk -
+    hk_device.hpp traverse_top<true> - and nothing is excepted.)"""
+    from cases import diff_buffers, snapshot
+
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    scene, cam = hk.load_cornell(), hk.cornell_camera(1920, 1080)
+    exact = hk.HikariPlugin(device=0, flags=F.CTX_EXACT_TRAVERSAL)
+    with product_default_traversal():
+        fast = hk.HikariPlugin(device=0)
+    for p in (exact, fast):
+        p.set_scene(scene)
+    for n in range(1, 25):
+        for p in (exact, fast):
+            p.render(cam, s, frame_number=n)
+        if n % 4 == 0:
+            bad = diff_buffers(snapshot(fast), snapshot(exact))
+            assert bad == {}, (n, bad)
+    assert fast.engine.traversal_mode()[0] == "one-level" and exact.engine.traversal_mode()[0] == "reference"
+
+
 def test_config3_default_mode_32_frames_1080p():
     from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
 

@@ -1154,7 +1154,6 @@ def test_primary_ray_pipelining_changes_no_bit():
             snaps.append(snapshot(p))
             assert p.engine.prepasses_pipelined() == (0 if single else frames - 1)
         assert diff_buffers(snaps[0], snaps[1]) == {}
-    del os.environ["HK_PREPASS_PIPELINE"]
     # (b) Cornell with the anti-aliasing tail on some frames, by_nodes on others, repeated parities: against the oracle, frame by frame
     gpu, cpu = hk.HikariPlugin(device=0), oracle()
     aa_case = make_case("cornell_aa_default")
@@ -1167,6 +1166,7 @@ def test_primary_ray_pipelining_changes_no_bit():
             p.render(aa_case.camera, aa_case.settings, lights=aa_case.lights, frame_number=n, antialias=aa, by_nodes=by_nodes)
         bad = diff_buffers(snapshot(gpu), snapshot(cpu))
         assert bad == {}, (n, bad)
+    del os.environ["HK_PREPASS_PIPELINE"]
     assert 0 < gpu.engine.prepasses_pipelined() < len(plan) - 1
 
 
