@@ -85,8 +85,14 @@ __device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams
 #ifndef HK_PREPASS_WAVE_WALK
 #define HK_PREPASS_WAVE_WALK 0
 #endif
+// waves per SIMD the wide-walk prepass is compiled for.  Its walk is a chain of dependent fetches: one more resident wave hides more
+// of them than the 8 VGPRs it spills cost - 5 waves (95 VGPRs; 5 x 28 KB of LDS stacks fit the CU) against the compiler's own 103
+// VGPRs / 4 waves: primary rays of configs 3 / 4 0.905 -> 0.858 / 2.748 -> 2.544 ms (profiles/r05_sweep_ab.txt)
+#ifndef HK_PREPASS_WIDE_WAVES
+#define HK_PREPASS_WIDE_WAVES 5
+#endif
 template <bool COUNT, int LDS>
-__global__ __launch_bounds__(256) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
+__global__ __launch_bounds__(256, (LDS == 4 ? HK_PREPASS_WIDE_WAVES : 1)) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
                                                   unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);

@@ -177,8 +177,9 @@ def _as_float(x):
 def rendered_deviation(a, b):
     """{name: (relative L2, fraction of pixels with any differing byte)} over every RENDERED buffer of two snapshots - everything a
     frame's consumers see: the G-buffer, albedo, render / variance, the denoiser's planes, the tone-mapped image and the
-    anti-aliasing tail.  (Not the reservoir records: an any-hit walk in another order may report another occluder in the
-    sample_position of an occluded shadow sample, which nothing rendered reads - DESIGN 0.)"""
+    anti-aliasing tail.  (The reservoir records are compared where the claim is bit equality - test_default_mode_sequence_gpu.py
+    holds config 2's default mode to the exact walk in EVERY buffer; until round 5 an any-hit walk in another order could keep another
+    occluder in an occluded sample's sample_position - since then the rays whose occluder is kept walk the reference's order)"""
     out = {}
     for name in a:
         if name.startswith("reservoir"):

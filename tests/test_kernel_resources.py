@@ -36,7 +36,8 @@ SCRATCH_ALLOWED = {
     r"k_indirect<true, false, 0>": 32,         # fused schedule on a scene in global memory (the default there is the wavefront)
     r"k_indirect<true, true, (0|3)>": 96,      # ray-counting replays (two-level / one-level walk from global memory; + the walk counters of HkStats)
     r"k_wf_final": 16,
-    r"k_prepass<(true|false), 4>": 416,        # the wide walk's stack beyond its 28 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks that deep
+    r"k_prepass<(true|false), 4>": 480,        # the wide walk's stack beyond its 28 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks
+                                               # that deep (384 B) + the few VGPRs the five-waves bound spills (HK_PREPASS_WIDE_WAVES; the counting instantiation a few more)
     r"k_wf_trace<false, true>": 64,            # the instrumented twin of tools/wf_timeline.py (never launched by the product)
     r"k_wf_trace_wide<(true, false|false, true)>": 64,   # ... and the wide kernel's two twins (timeline / HK_CTX_COUNT_WALKS): their bookkeeping
                                                          # spills a few VGPRs at the 96 the five-waves bound leaves; the product <false, false> must not
@@ -89,8 +90,8 @@ def test_lds_leaves_room_for_the_scene_copy(table):
             assert 5 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 96, name
             assert r["vgpr_spill_count"] == 0 or not re.search(r"<false, false>", name), name   # (the product instantiation; its measurement twins may spill)
             continue
-        if re.search(r"k_prepass<(true|false), 4>", name):   # ... the fused prepass: the stack only, 4 workgroups per CU (104 VGPRs)
-            assert 4 * r["group_segment_fixed_size"] <= 160 * 1024, name
+        if re.search(r"k_prepass<(true|false), 4>", name):   # ... the fused prepass: the stack only, FIVE workgroups per CU (<= 96 VGPRs: HK_PREPASS_WIDE_WAVES)
+            assert 5 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 96, name
             continue
         if re.search(r"k_(direct_lit|indirect|prepass|wf_trace|wf_shade)", name):
             assert 4 * (r["group_segment_fixed_size"] + 32768) <= 160 * 1024 + 4 * 16640, name  # (k_direct_lit: its 16.6 KB store tile)
