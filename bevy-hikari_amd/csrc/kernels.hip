@@ -516,11 +516,15 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
 }
 
 // ------------------------------------------------------------------ indirect_lit_ambient
+// Waves per SIMD of the headline's dominant kernel (LDS scene, one-level walk).  The kernel issues VALU instructions at 44 % lane
+// utilisation and waits on LDS / memory in between: a FIFTH resident wave (96 VGPRs instead of 114, 35 spilled to scratch) hides
+// more than the spills cost - Cornell 1080p: the kernel 0.408 -> 0.383 ms in the frame (0.271 -> 0.262 alone), the frame
+// 0.974 / 0.977 -> 0.958 / 0.958 ms, every byte unchanged (round 5, profiles/r05_indirect_waves_ab.txt; round 3 had seen -0.5 % and left it).
 #ifndef HK_INDIRECT_FLAT_WAVES
-#define HK_INDIRECT_FLAT_WAVES 4
+#define HK_INDIRECT_FLAT_WAVES 5
 #endif
 template <bool MULTIPLE_BOUNCES, bool COUNT, int LDS>
-__global__ __launch_bounds__(256, (LDS == 2 ? HK_INDIRECT_FLAT_WAVES : 4)) void k_indirect(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
+__global__ __launch_bounds__(256, (LDS == 2 && MULTIPLE_BOUNCES ? HK_INDIRECT_FLAT_WAVES : 4)) void k_indirect(DScene gsc, DFrame fr, GBuffer g, LightTargets t, int row_begin, int row_end,
                                                    unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);

@@ -17,7 +17,6 @@ LIB = os.path.join(ROOT, "bevy-hikari_amd", "libhikari_hip.so")
 # kernel (regex on the demangled name) -> most VGPRs it may use (512 / waves per SIMD, in the allocation granule of 8)
 BUDGETS = {
     r"k_indirect<true, false, 1>": 128,        # the dominant ray kernel, LDS scene, reference walk: 4 waves per SIMD
-    r"k_indirect<true, false, 2>": 120,        # ... one-level walk (the product default on the Cornell box): 114 VGPRs
     r"k_spatial_reuse<false>": 128,
     r"k_spatial_reuse<true>": 128,
     r"k_prepass<false, (1|2)>": 128,
@@ -34,6 +33,7 @@ BUDGETS = {
 # default path of an LDS-resident scene
 SCRATCH_ALLOWED = {
     r"k_indirect<true, false, 0>": 32,         # fused schedule on a scene in global memory (the default there is the wavefront)
+    r"k_indirect<true, false, 2>": 96,         # the headline kernel at FIVE waves per SIMD (HK_INDIRECT_FLAT_WAVES): 96 VGPRs, 35 spilled - measured faster than 114 / 4 waves
     r"k_indirect<true, true, (0|3)>": 96,      # ray-counting replays (two-level / one-level walk from global memory; + the walk counters of HkStats)
     r"k_wf_final": 16,
     r"k_prepass<(true|false), 4>": 480,        # the wide walk's stack beyond its 28 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks
@@ -63,6 +63,8 @@ def test_direct_passes_of_lds_scenes_stay_at_four_waves(table):
     for name, r in table.items():
         if re.search(r"k_direct_lit<(true|false), false, 2>", name):
             assert r["vgpr_count"] <= 128, name
+        if re.search(r"k_indirect<true, false, 2>", name):   # ... and the headline kernel at five
+            assert r["vgpr_count"] <= 96, name
 
 
 def test_hot_kernels_stay_inside_their_occupancy_budget(table):
