@@ -305,6 +305,11 @@ def main():
                 t0, tdry, tend = int(inv - r[0]), int(inv - r[1]), int(r[2])
                 stages.append({"stage": sidx, "ticks": tend - t0, "ticks_after_the_queue_ran_dry": tend - max(t0, min(tdry, tend)),
                                "mean_wave_residency": round(int(r[3]) / int(r[4]) / max(1, tend - t0), 3), **{k: int(r[8 + j]) for j, k in enumerate(names)}})
+            # the counting twin runs the timed kernels themselves: ITS frames are what "the replay reproduces the timed frames" is asked of
+            # (the ray-counting replay above walks the fused, direction-threaded kernels - the only form HK_CTX_COUNT_RAYS exists in -
+            # whose closest hits may fall differently where two candidates tie exactly: a pixel or two per 4K frame)
+            same_rays, same = same, same_w
+            walk["ray_count_replay_bit_identical"] = same_rays
             walk["trace_kernel"] = {"stages": stages, "replay_bit_identical": same_w, **{k: sum(st_[k] for st_ in stages) for k in names},
                                     "tail_fraction_of_trace_time": round(sum(st_["ticks_after_the_queue_ran_dry"] for st_ in stages) / max(1, sum(st_["ticks"] for st_ in stages)), 4)}
             del weng
@@ -424,6 +429,8 @@ def main():
                                "blocks_ms_per_step": [round(b / steps_x * 1e3, 4) for b in x["blocks"]], "rays_per_frame": round(x["total_rays"] / steps_x, 1),
                                "indirect_schedule": x["schedule"], "traversal": x["traversal"][0], "wide_walk": x["traversal"][2], "indirect_avg_launch_ms": round(x["ind_ms"], 5),
                                "trace_avg_launch_ms": round(x["trace_ms"], 5), "replay_bit_identical": x["same"]}
+            if "ray_count_replay_bit_identical" in x["walk"]:   # (scenes beyond LDS: `replay_bit_identical` is the counting twin of the timed kernels; this is the fused ray-counting replay)
+                extra[str(cfg)]["ray_count_replay_bit_identical"] = x["walk"]["ray_count_replay_bit_identical"]
             if cfg in (3, 4) and rank == 0 and not args.no_hbm_probe:
                 extra[str(cfg)]["roofline"] = walk_roofline(x, xeng)
             del x
@@ -481,6 +488,7 @@ def main():
         "mray_per_s_per_gpu": round(total_rays / elapsed / 1e6 / world, 3),
         "rays_per_frame": round(total_rays / args.steps, 1),
         "replay_bit_identical": same,
+        **({"ray_count_replay_bit_identical": m["walk"]["ray_count_replay_bit_identical"]} if "ray_count_replay_bit_identical" in m["walk"] else {}),
         "roofline": {
             "kernel": "k_indirect (indirect_lit_ambient, light.wgsl:1263-1498)" if schedule == "fused" else
                       "indirect_lit_ambient (light.wgsl:1263-1498) as k_wf_setup + k_wf_trace / k_wf_shade per bounce + k_wf_final: first dispatch start to last dispatch end",
@@ -504,7 +512,7 @@ def main():
                       "frac": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ind_ms_alone > 0 else 0.0},
         },
     }
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_indirect_hbm_traffic.json") for k in (4, 3, 2)) if os.path.exists(q)), "")
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_indirect_hbm_traffic.json") for k in (5, 4, 3, 2)) if os.path.exists(q)), "")
     if m.get("spatial_ms_alone"):
         # the second large kernel of the frame (by now as long as the first): spatial_reuse, light.wgsl:1503-1684 - SURVEY 8d: reads
         # G-buffer 40 + own reservoir 64 + previous spatial 64, writes reservoir 64 + render 8 (the 16 neighbour records it gathers,
