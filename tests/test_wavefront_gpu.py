@@ -153,3 +153,64 @@ def test_wavefront_bands_equal_single_context(tmp_path, world, case_name, monkey
             if key in ("b0", "b1") or key.endswith("_rows"):
                 continue
             assert (d[key].view(np.uint8) == full[key][b0:b1].view(np.uint8)).all(), f"rank {rank} [{b0},{b1}) differs in {key}"
+
+
+def _read_wf_timeline(engine):
+    import ctypes as C
+
+    raw = np.zeros(64 * 32, dtype=np.uint64)
+    engine.api.call("debug_read_wf_timeline", engine.ctx, raw.ctypes.data_as(C.POINTER(C.c_uint64)), raw.size)
+    return raw.reshape(64, 32)
+
+
+def test_counting_twin_of_the_wide_trace_kernel_changes_no_byte_and_counts_what_ran():
+    """Round 5: HK_CTX_COUNT_WALKS runs the COUNTING twin of k_wf_trace_wide - the schedule and the walks bench.py
+    times, unlike HK_CTX_COUNT_RAYS (fused replay).  Its frames equal the product's byte for byte; what it counts is consistent with the
+    frame: per stage as many rays as the stage's queue held (paths alive + shadow rays), fewer rays from bounce to bounce, at least one
+    record per ray, closest hits <= closest-hit rays; and the stamps are ordered (first wave in <= queue dry <= last wave out).
+    HK_TIMING_TRACE_STAGES: every trace launch between its own pair of events - bounces + 1 launches per pass."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0007, 8, 24, 48, 60, 8, 2, 6.0)
+    s = hk.HikariSettings(indirect_bounces=3, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam, lights = synthetic_camera(320, 180, extent=6.0), hk.lights_uniform(directional=sun)
+    with product_default_traversal():
+        plain, twin = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0, flags=F.CTX_COUNT_WALKS)
+    for p in (plain, twin):
+        p.set_scene(scene)
+    twin.engine.set_timing_mask(1 << F.TIMING_TRACE_STAGES)
+    frames = 4
+    for n in range(1, frames + 1):
+        for p in (plain, twin):
+            p.render(cam, s, lights=lights, frame_number=n)
+    assert diff_buffers(snapshot(twin), snapshot(plain)) == {}
+    assert twin.engine.indirect_schedule() == "wavefront" and twin.engine.wide_walk()
+    twin.engine.wait()
+    st = twin.engine.stats()
+    assert st.pass_launches[F.TIMING_TRACE_STAGES] == frames * (s.indirect_bounces + 1) and st.pass_ms_total[F.TIMING_TRACE_STAGES] > 0.0
+    tl = _read_wf_timeline(twin.engine)     # the last frame's pass
+    inv = np.uint64(0xFFFFFFFFFFFFFFFF)
+    rays_before = None
+    for stage in range(s.indirect_bounces + 1):
+        r = tl[stage]
+        records, top, tris, entries, rays, any_hit, hits, pieces = (int(v) for v in r[8:16])
+        assert int(r[4]) > 0 and rays > 0, stage
+        t0, tdry, tend = int(inv - r[0]), int(inv - r[1]), int(r[2])
+        assert t0 <= tdry <= tend, (stage, t0, tdry, tend)
+        assert records >= rays and top <= records and hits <= rays - any_hit and any_hit <= rays and entries <= records * 4
+        if stage == 0:
+            assert any_hit == 0 and rays <= 320 * 180          # bounce 0: one closest-hit ray per geometry pixel, no shadow rays yet
+        else:
+            assert rays - any_hit <= rays_before               # paths only ever end
+        rays_before = rays - any_hit
+    assert (tl[s.indirect_bounces + 1:63] == 0).all()          # (row 63 carries the clock rate)
+
+
+def test_gather_roofs_of_128_byte_records():
+    """hk_measure_gather with 128-B steps (a record of the wide walk) and the cooperative variant (mode 129): positive, finite, and the
+    64-B rate above the 128-B rate for an L2-resident table (the roof is bytes: DESIGN 8.1b)."""
+    e = hk.Engine(device=0)
+    r64 = e.measure_gather(1 << 20, 64, 5, 128)[0] / 4 * 64
+    r128 = e.measure_gather(1 << 20, 128, 5, 128)[0] / 8 * 64
+    coop = e.measure_gather(1 << 20, 129, 5, 128)[0] / 8 * 64
+    assert 1.0 < r128 < r64 < 2000.0 and 1.0 < coop < 2000.0, (r64, r128, coop)
