@@ -1139,7 +1139,16 @@ def test_primary_ray_pipelining_changes_no_bit():
     big, sun = synthetic_large(0x5EED0007, 8, 24, 48, 60, 8, 2, 6.0)
     runs = [(case.scene, case.camera, case.settings, case.lights, 0, 24),
             (big, synthetic_camera(320, 180, extent=6.0), hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0), hk.lights_uniform(directional=sun), None, 12)]
-    os.environ["HK_PREPASS_PIPELINE"] = "all"   # (read by hk_create; the default pipelines LDS-resident scenes only: measured)
+    os.environ["HK_PREPASS_PIPELINE"] = "all"   # (read by hk_create; off by default: measured slower)
+    try:
+        _pipelining_body(make_case, runs, oracle)
+    finally:
+        del os.environ["HK_PREPASS_PIPELINE"]
+
+
+def _pipelining_body(make_case, runs, oracle):
+    from cases import product_default_traversal
+
     for scene, cam, s, lights, flags, frames in runs:   # (a)
         snaps = []
         for single in (False, True):
@@ -1166,7 +1175,6 @@ def test_primary_ray_pipelining_changes_no_bit():
             p.render(aa_case.camera, aa_case.settings, lights=aa_case.lights, frame_number=n, antialias=aa, by_nodes=by_nodes)
         bad = diff_buffers(snapshot(gpu), snapshot(cpu))
         assert bad == {}, (n, bad)
-    del os.environ["HK_PREPASS_PIPELINE"]
     assert 0 < gpu.engine.prepasses_pipelined() < len(plan) - 1
 
 
