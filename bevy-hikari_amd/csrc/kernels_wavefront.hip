@@ -47,6 +47,9 @@ constexpr uint32_t WF_ALIVE = 0u;    // [s] paths alive at bounce s (s = 0: all 
 constexpr uint32_t WF_SHADOWS = 64u;  // [s] shadow rays trace stage s walks (emitted by the shade stage of bounce s - 1)
 constexpr uint32_t WF_QHEAD = 128u;   // [s] rays of trace stage s claimed so far (its queue = the alive list, then the shadow list)
 
+#ifndef HK_WF_BLOCK_SMALL
+#define HK_WF_BLOCK_SMALL 64u  // rays a wave reserves at a time once the queue is within four rounds of its end (256 before)
+#endif
 #ifndef HK_WF_REFILL_MIN
 #define HK_WF_REFILL_MIN 8u   // a wave fetches new rays once this many lanes are idle (or all of them)
 #endif
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256, HK_WF_TRACE_WAVES) void k_wf_trace(DScene gsc,
         // lanes busy with long walks.  Guided self-scheduling - a wave takes 1/4 of an even share of what is left, at least its idle
         // lanes - hands the last ray out right when the queue empties, as intended, and makes the frames 2-8 % SLOWER: twice the
         // atomics on one hot counter, and the stage's end is set by its longest walks either way - see DESIGN 8.1.)
-        const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : 64u;
+        const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : HK_WF_BLOCK_SMALL;
         uint32_t b = 0u;
         if ((threadIdx.x & 63u) == 0u) b = atomicAdd(head_ptr, block);
         b = __builtin_amdgcn_readfirstlane(b);
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
       if (res_count < n_idle && !exhausted) {
         given = res_count;
         if (idle && rank < given) mine = res_base + rank;
-        const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : 64u;
+        const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : HK_WF_BLOCK_SMALL;
         uint32_t b = 0u;
         if ((threadIdx.x & 63u) == 0u) b = atomicAdd(head_ptr, block);
         b = __builtin_amdgcn_readfirstlane(b);
