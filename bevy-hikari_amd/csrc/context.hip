@@ -767,6 +767,7 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
     return HK_E_HIP;
   }
   c->stream = c->own_stream;
+  c->prepass_queue = getenv("HK_PREPASS_QUEUE") != nullptr && atoi(getenv("HK_PREPASS_QUEUE")) != 0;
   if (!(flags & HK_CTX_SINGLE_STREAM)) {
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming) != hipSuccess) {
@@ -1194,7 +1195,18 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
         }
         {
           ScopedTimer timer(c, HK_PASS_PREPASS);
-          launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
+          // HK_PREPASS_QUEUE (round 5 experiment): the primary rays through the trace kernel's queue - scenes beyond LDS with the wide walk,
+          // a G-buffer no larger than the queue scratch (upscale ratio 1), no counters
+          bool queued = false;
+          if (c->prepass_queue && wide.tlas && !counters && use_wide(c) && (size_t)c->W * c->H <= (size_t)c->RW * c->RH) {
+            if ((rc = ensure_wavefront(c)) || (rc = ensure_wide(c, true))) return rc;
+            wide.spill = c->wide_spill;
+            launch_prepass_queue(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, c->wf, wide, f0, f1,
+                                 c->compute_units);
+            queued = true;
+          }
+          if (!queued)
+            launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
         }
         c->stream = main_stream;
         HK_HIP(hipGetLastError());

@@ -132,6 +132,7 @@ struct hk_ctx {
   // hk_create) = none (default: measured slower everywhere, context.hip hk_frame_stage), lds, all.
   hipStream_t pre_stream = nullptr;
   int pre_mode = 0;
+  bool prepass_queue = false;           // HK_PREPASS_QUEUE=1 (read by hk_create): the primary rays of scenes beyond LDS through the trace kernel's queue (experiment)
   hipEvent_t pre_done = nullptr;
   hipEvent_t frame_mark[2] = {nullptr, nullptr};        // main stream, start of the TEMPORAL stage of the last frame of that parity
   hipEvent_t post_done_parity[2] = {nullptr, nullptr};  // post stream, end of the a-trous levels of the last frame of that parity

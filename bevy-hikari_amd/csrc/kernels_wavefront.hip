@@ -36,6 +36,7 @@
 #include "hk_device.hpp"
 #include "hk_kernels.hpp"
 #include "hk_light.hpp"
+#include "hk_prepass.hpp"
 #include "hk_wide.hpp"
 
 namespace hkd {
@@ -930,6 +931,36 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
   }
 }
 
+// ------------------------------------------------------------------ primary rays through the queue (round 5 experiment, HK_PREPASS_QUEUE)
+// "the primary rays of scenes beyond LDS keep one pixel per lane to the end of its walk - emit them into the trace
+// kernel's queue and finish the pixel in a tail kernel".  k_primary_emit writes every pixel's ray into the closest-hit ray planes
+// (slot = pixel) and the pixel into the stage-0 queue, in tile order; k_wf_trace_wide walks them with lane refill, work sharing and the
+// permuted queue; k_prepass_finish forms the ray again (the same operations: the same bits) and writes the G-buffer record from the hit.
+__global__ __launch_bounds__(256) void k_primary_emit(DFrame fr, PrepassParams pp, WfBuffers w, int row_begin, int row_end) {
+  const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
+  __shared__ uint32_t push_lds[6];
+  const uint32_t q = block_push(&w.ctr[WF_ALIVE], px.valid, push_lds);
+  if (!px.valid) return;
+  const uint32_t slot = (uint32_t)(px.x + fr.dw * px.y);
+  const Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
+  w.cr0[slot] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, 0.0f);
+  w.cr1[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, 0.0f);
+  w.alive[0][q] = slot;
+}
+__global__ __launch_bounds__(256) void k_prepass_finish(DScene sc, DFrame fr, PrepassParams pp, GBuffer g, WfBuffers w, int row_begin, int row_end) {
+  const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
+  if (!px.valid) return;
+  const uint32_t slot = (uint32_t)(px.x + fr.dw * px.y);
+  const Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
+  const float4 h0 = w.ch0[slot];
+  Hit hit;
+  hit.distance = h0.x;
+  hit.uv = F2(h0.y, h0.z);
+  hit.primitive_index = f2u(h0.w);
+  hit.instance_index = w.ch1[slot];
+  prepass_store(sc, fr, pp, g, px.x, px.y, ray, hit);
+}
+
 // ------------------------------------------------------------------ shade: bounce n of every live path
 #ifndef HK_WF_SHADE_WAVES
 #define HK_WF_SHADE_WAVES 4
@@ -1089,6 +1120,20 @@ size_t wide_trace_lanes(int compute_units) { return (size_t)compute_units * HK_W
 size_t wide_spill_entries() { return HK_WIDE_SPILL; }
 void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, float4* wide, uint32_t* rank) {
   if (count) hipLaunchKernelGGL(k_build_wide, dim3((count + 255u) / 256u), dim3(256), 0, st, nodes, count, wide, rank);
+}
+
+// the prepass of rows [y0, y1) with its primary rays walked by the trace kernel (w: the queue-based schedule's scratch, free between
+// frames' indirect passes; wide: the records with their spill area)
+void launch_prepass_queue(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj, const float* prev_view_proj,
+                          const float4* prev_models, float jitter_x, float jitter_y, const GBuffer& g, const WfBuffers& w, const WideTrees& wide, int y0, int y1,
+                          int compute_units) {
+  if (y1 <= y0) return;
+  const PrepassParams pp = make_prepass_params(inverse_view_proj, view_proj, prev_view_proj, prev_models, jitter_x, jitter_y, &wide);
+  (void)hipMemsetAsync(w.ctr, 0, 192 * sizeof(uint32_t), st);
+  const dim3 grid = grid_for(fr.dw, y1 - y0);
+  hipLaunchKernelGGL(k_primary_emit, grid, dim3(256), 0, st, fr, pp, w, y0, y1);
+  hipLaunchKernelGGL((k_wf_trace_wide<false, false>), dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, wide, 0u);
+  hipLaunchKernelGGL(k_prepass_finish, grid, dim3(256), 0, st, sc, fr, pp, g, w, y0, y1);
 }
 
 void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,

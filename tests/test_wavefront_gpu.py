@@ -214,3 +214,29 @@ def test_gather_roofs_of_128_byte_records():
     r128 = e.measure_gather(1 << 20, 128, 5, 128)[0] / 8 * 64
     coop = e.measure_gather(1 << 20, 129, 5, 128)[0] / 8 * 64
     assert 1.0 < r128 < r64 < 2000.0 and 1.0 < coop < 2000.0, (r64, r128, coop)
+
+
+def test_primary_rays_through_the_queue_change_no_byte():
+    """HK_PREPASS_QUEUE=1 (round 5 experiment, measured slower and off: profiles/r05_prepass_queue_ab.txt): the primary rays of a scene beyond
+    LDS walked by the trace kernel (k_primary_emit + k_wf_trace_wide + k_prepass_finish) - every buffer of every frame equal to the fused prepass."""
+    import os
+
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0007, 8, 24, 48, 60, 8, 2, 6.0)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    cam, lights = synthetic_camera(333, 187, extent=6.0), hk.lights_uniform(directional=sun)   # (odd sizes: partial tiles on both edges)
+    with product_default_traversal():
+        fused = hk.HikariPlugin(device=0)
+        os.environ["HK_PREPASS_QUEUE"] = "1"   # (read by hk_create)
+        try:
+            queued = hk.HikariPlugin(device=0)
+        finally:
+            del os.environ["HK_PREPASS_QUEUE"]
+    for p in (fused, queued):
+        p.set_scene(scene)
+    for n in range(1, 5):
+        for p in (fused, queued):
+            p.render(cam, s, lights=lights, frame_number=n)
+        assert diff_buffers(snapshot(queued), snapshot(fused)) == {}, n
+    assert queued.engine.wide_walk() and queued.engine.stats().wide_stack_lost == 0
