@@ -1198,7 +1198,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
           // HK_PREPASS_QUEUE (round 5 experiment): the primary rays through the trace kernel's queue - scenes beyond LDS with the wide walk,
           // a G-buffer no larger than the queue scratch (upscale ratio 1), no counters
           bool queued = false;
-          if (c->prepass_queue && wide.tlas && !counters && use_wide(c) && (size_t)c->W * c->H <= (size_t)c->RW * c->RH) {
+          if (c->prepass_queue && !pre_pipelined && wide.tlas && !counters && use_wide(c) && (size_t)c->W * c->H <= (size_t)c->RW * c->RH) {  // (not beside the previous frame's indirect pass: they share the queue scratch)
             if ((rc = ensure_wavefront(c)) || (rc = ensure_wide(c, true))) return rc;
             wide.spill = c->wide_spill;
             launch_prepass_queue(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, c->wf, wide, f0, f1,
