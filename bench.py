@@ -19,6 +19,13 @@ traverse_bottom invocations.  They are counted by replaying the same
 context created with HK_CTX_COUNT_RAYS (the path is deterministic, so the replay traces exactly the
 rays of the timed run) - the timed region itself carries no counters.
 
+Scenes beyond LDS (configs 3, 4; also measured briefly inside the default run: `extra_configs`): `roofline` is the TIMED trace kernel's
+(k_wf_trace_wide) - every trace launch between its own HIP events (HK_TIMING_TRACE_STAGES), its walks counted by its own counting twin
+on a third context (HK_CTX_COUNT_WALKS: same schedule, same walks, same bytes out - `replay_bit_identical` refers to it; the fused
+ray-counting replay, which may resolve an exact tie differently, is `ray_count_replay_bit_identical`) - as algorithmic bytes / HBM
+peak, record fetches / the 128-B gather roof measured in the same run, HBM-side counter bytes / HBM peak, and the fraction of the
+trace time after a stage's queue first runs dry.
+
 --config selects the other BASELINE.json configs on ONE GPU (3: Sponza-class stand-in 1080p 3 bounces;
 4: city-class stand-in 4K 2 bounces; 5: Cornell 4K 8 bounces, both spatial passes, denoise off).  The
 default (2) is the configuration the metric is quoted on; the default single-GPU invocation also measures configs 3 and 5
