@@ -90,6 +90,69 @@ def workload(hk, config, width, height, bounces):
     raise SystemExit(f"unknown --config {config}")
 
 
+def pmc_traffic_in_run(timeout_s=150):
+    """HBM-side bytes per launch of every production kernel of a config-2 frame, measured now: two child runs of this script (short,
+    no probes) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` - one counter per pass.  Bytes = 2 x FETCH_SIZE +
+    WRITE_SIZE in KB (MI355X_MICROARCH.md, HBM section: gfx950 tallies a 128-B read request as 64 B).  None on any failure."""
+    import glob
+    import shutil
+    import signal
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--config", "2", "--steps", "6", "--warmup", "4", "--blocks", "1", "--no-cpu-baseline", "--no-hbm-probe",
+             "--no-extra-configs", "--sustained-seconds", "0", "--no-pmc"]
+    per = {}
+    try:
+        for counters in (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")):   # (memory counters one per pass; three of the SQ block's)
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                p = subprocess.Popen([rocprof, "--kernel-trace", "--pmc"] + list(counters) + ["-d", d, "--"] + child, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    p.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    os.killpg(p.pid, signal.SIGKILL)   # (the group this call started: rocprofv3 and its child)
+                    p.wait()
+                    return None
+                dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+                if not dbs:
+                    return None
+                db = sqlite3.connect(dbs[0])
+                rows = db.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+                db.close()
+                acc = {}
+                for name, counter, value in rows:
+                    if counter in counters:
+                        acc.setdefault((name, counter), []).append(float(value))
+                for (name, counter), vals in acc.items():
+                    short = name.replace("void hkd::", "").replace("hkd::", "").split("(")[0]
+                    per.setdefault(short, {})[counter] = sum(vals) / len(vals)
+    except Exception:
+        return None
+    import re
+
+    out, frame = {}, 0
+    for short, v in per.items():
+        if not short.startswith("k_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+            continue
+        out[short] = int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+        # (the frame's production kernels: the ray-counting replay's instantiations and the probes excluded, as tools/make_traffic_profile.py does)
+        if not re.search(r"<(true|false), true, \d>|k_prepass<true|k_stream|k_valu|k_gather|k_copy|k_resolve|k_join|k_count", short):
+            frame += out[short]
+    if not out:
+        return None
+    sq = {short: {"valu_wave_instructions": v["SQ_INSTS_VALU"], "lane_utilisation": round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)}
+          for short, v in per.items() if short.startswith("k_") and all(k in v for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU")) and v["SQ_ACTIVE_INST_VALU"] > 0}
+    return {"per_kernel": out, "frame_bytes": frame, "sq": sq,
+            "source": "measured in this invocation: rocprofv3 --kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE, then SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU, on "
+                      "three child runs of `bench.py --config 2 --steps 6 --warmup 4`; bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: a 128-B read request is tallied as 64 B), "
+                      "lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); per-launch averages"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +172,9 @@ def main():
                     "collects them every frame, HK_FRAME_GATHER - SURVEY 8e step 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-probe", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not collect the HBM-side bytes of the headline's kernels in this invocation (two child runs of a short config-2 bench "
+                    "under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE after the timed region; default for the plain single-GPU config-2 run); the committed profile "
+                    "under profiles/ is used instead")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ctx-flags", type=int, default=0, help="OR-ed into the flags of the timed contexts (64 = HK_CTX_WAVEFRONT, 128 = HK_CTX_FUSED_INDIRECT, 32 = HK_CTX_EXACT_TRAVERSAL, 256 = HK_CTX_NO_WIDE_WALK)")
     ap.add_argument("--no-wide-walk", action="store_true", help="A/B: scenes beyond LDS keep the threaded skip-link walk for closest-hit rays too (HK_CTX_NO_WIDE_WALK)")
@@ -587,6 +653,38 @@ def main():
             out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
         except Exception:
             pass
+    if default_run and not args.no_pmc and not args.no_extra_configs and not args.no_hbm_probe:   # (the full default invocation only: every tool that profiles a short run passes one of these)
+        # ... and MEASURED IN THIS INVOCATION where rocprofv3 is at hand: after the timed region, two child runs of a
+        # short config-2 bench under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (one counter per pass, as the micro-arch
+        # guide prescribes; every failure falls back to the committed profile above)
+        live = pmc_traffic_in_run()
+        if live:
+            k1 = next((v for k, v in live["per_kernel"].items() if k.startswith("k_indirect<true, false, 2>")), None)
+            k2 = next((v for k, v in live["per_kernel"].items() if k.startswith("k_spatial_reuse<false>")), None)
+            if k1:
+                out["roofline"]["traffic"] = k1
+                out["roofline"]["traffic_source"] = live["source"]
+                out["roofline"]["traffic_ratio_to_algorithmic"] = round(k1 / algo_bytes, 3)
+            if k2 and "second_kernel" in out["roofline"]:
+                out["roofline"]["second_kernel"]["traffic"] = k2
+                out["roofline"]["second_kernel"]["traffic_ratio_to_algorithmic"] = round(k2 / (240.0 * W * band_rows), 3)
+                out["roofline"]["second_kernel"]["traffic_source"] = live["source"]
+            if "frame_roofline" in out and live["frame_bytes"] > 0:
+                cb = float(live["frame_bytes"])
+                out["frame_roofline"]["counter"] = {"hbm_bytes_per_frame": cb, "achieved_gbs": round(cb / (elapsed / args.steps) / 1e9, 1),
+                                                    "frac_of_peak": round(cb / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                                    "frac_of_measured_copy": round(cb / (elapsed / args.steps) / 1e9 / hbm["copy_gbs"], 4) if hbm and hbm["copy_gbs"] > 0 else None,
+                                                    "per_kernel": live["per_kernel"], "source": live["source"]}
+            out["traffic_profile"] = {"source": live["source"]}
+            q1 = next((v for k, v in live["sq"].items() if k.startswith("k_indirect<true, false, 2>")), None)
+            if q1 and valu and "valu_issue" in out["roofline"]:   # the kernel's VALU wave-instructions and lane utilisation, of this invocation too
+                alone_ms = ind_ms_alone or ind_ms
+                rate = q1["valu_wave_instructions"] / (alone_ms * 1e-3) / 1e9
+                out["roofline"]["valu_issue"].update({"wave_instructions_per_launch": q1["valu_wave_instructions"], "achieved_ginstr_s": round(rate, 1),
+                                                      "frac_of_measured_peak_8_waves": round(rate / valu["8_waves_per_simd"], 4),
+                                                      "frac_of_measured_peak_4_waves": round(rate / valu["4_waves_per_simd"], 4),
+                                                      "frac_of_nominal": round(rate / (256 * 4 * 2.4 / 2), 4), "lane_utilisation": q1["lane_utilisation"],
+                                                      "source": live["source"] + "; launch time of this run, kernel alone"})
     if args.config in (3, 4) and world == 1 and not args.no_hbm_probe:
         out["roofline"]["bvh_walk"] = walk_roofline(m, xeng)
     if m["sustained"]:
