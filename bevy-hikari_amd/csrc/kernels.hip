@@ -595,6 +595,101 @@ struct SpatialTaps {
   uint32_t tap_count[16];
   float march_frac[16][6];  // f32(j) / f32(tap_count + 1), j = 1..tap_count (light.wgsl:1619)
 };
+// One neighbour of spatial_reuse's loop (light.wgsl:1565-1660) in two halves.  spatial_tap_reaches: everything that needs no record
+// of the neighbour - where the tap lands, its depth against the pixel's, the screen-space depth march; 0 if the tap is still a
+// candidate, else the HK_TAP statistic it ends in.  spatial_tap_merge: the neighbour's record, its own tests, the merge.
+struct SpatialPixel {
+  int x, y;
+  f2 uv;
+  float depth, rot;
+};
+HKD uint32_t spatial_tap_reaches(const DFrame& fr, const GBuffer& g, const SpatialTaps& taps, const SpatialPixel& me, uint32_t i, int* out_x, int* out_y) {
+  const float angle = HK_TAU * fract((float)i * HK_GOLDEN_RATIO + me.rot + fr.random_float_number);
+  const float radius = taps.radius[i - 1u];
+  float sn, cs;
+  sincos_(angle, &sn, &cs);
+  const f2 offset = radius * F2(cs, sn);
+
+  const int scx = f32_to_i32(offset.x + (float)me.x), scy = f32_to_i32(offset.y + (float)me.y);
+  *out_x = scx;
+  *out_y = scy;
+  const f2 sample_uv = coords_to_uv(fr, scx, scy);
+  if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) return 1u;
+  int sdx, sdy;
+  jittered_deferred_coords(fr, sample_uv, &sdx, &sdy);
+  const float sample_depth = in_bounds(sdx, sdy, fr.dw, fr.dh) ? g.depth[sdx + fr.dw * sdy] : 0.0f;
+
+  const float depth_ratio = me.depth / sample_depth;
+  if (depth_ratio < 0.9f || depth_ratio > 1.1f) return 2u;
+
+  // The tap is merged iff it passes the neighbour's own tests (non-empty, normal within 30 degrees, sample in front of the pixel)
+  // AND the screen-space depth march finds the segment unoccluded (light.wgsl:1593-1631).  All of them are pure predicates, so
+  // their order is free: the march - which needs nothing of the neighbour's record, only depths - goes FIRST.  On the Cornell
+  // frame it rejects 36 % of the taps (the record tests: 5 %), and those no longer fetch and unpack a 64-B record
+  // (tools/section_profile.py "spatial_reuse_taps").
+  const float tap_interval = taps.tap_interval[i - 1u];
+  const uint32_t tap_count = taps.tap_count[i - 1u];
+  bool occluded = false;
+  const f2 dir = normalize(offset);
+  // The march's depth taps (at most 6, a wave-uniform count): all loads first, then the comparisons.  `occluded` is the OR of
+  // the steps' tests, so stopping at the first hit or looking at every step gives the same answer; the wave waits for memory
+  // once per neighbour instead of once per step and the data-dependent loop (a branch and a wait per step) is gone:
+  // 0.353 -> 0.318 ms.  Two more steps in the same direction changed nothing and are not done: the sixteen neighbours' own
+  // depths fetched eight at a time (parked in LDS), and the neighbour's record requested together with its march taps.
+  // tap_offset / (width, height) goes through the frame's f64 reciprocals (quotient_by_reciprocal: the IEEE quotient unless that
+  // is subnormal, which it cannot be here - a non-zero component of `dir` is >= 1e-9: the polynomial of an angle that is at
+  // least 2^-25 away from the multiples of pi/2, over a tap radius of a few hundred pixels at most).
+  float march_depth[6];
+#pragma unroll
+  for (uint32_t j = 1u; j <= 6u; j += 1u) {
+    march_depth[j - 1u] = 0.0f;
+    if (j <= tap_count) {
+      const float tap_dist = (float)j * tap_interval;
+      const f2 tap_offset = tap_dist * dir;
+      const f2 tap_uv = me.uv + F2(quotient_by_reciprocal(tap_offset.x, fr.rcp_rw), quotient_by_reciprocal(tap_offset.y, fr.rcp_rh));
+      int tdx, tdy;
+      jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
+      march_depth[j - 1u] = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.depth[tdx + fr.dw * tdy] : 0.0f;
+    }
+  }
+#pragma unroll
+  for (uint32_t j = 1u; j <= 6u; j += 1u) {
+    if (j <= tap_count) {
+      const float ref_depth = mix(me.depth, sample_depth, taps.march_frac[i - 1u][j - 1u]);
+      if (march_depth[j - 1u] > ref_depth + 0.00001f) occluded = true;
+    }
+  }
+  return occluded ? 5u : 0u;
+}
+template <bool EMISSIVE_LIT>
+HKD uint32_t spatial_tap_merge(const ShadingSite& site, const Sample& s, Reservoir& r, const PackedReservoir& record) {
+  const Reservoir q = unpack_reservoir(record);
+  const bool normal_miss = dot(s.visible_normal, q.s.visible_normal) < 0.866f;
+  if (q.count < HK_F32_EPSILON || normal_miss) return 3u;
+
+  // normalize(q.s.sample_position - s.visible_position), keeping the length for the Jacobian below (compute_jacobian_shared)
+  const f3 to_sample = xyz(q.s.sample_position) - xyz(s.visible_position);
+  const float to_sample_length = sqrtf(dot(to_sample, to_sample));
+  const f3 sample_direction = to_sample * (1.0f / to_sample_length);
+  if (dot(sample_direction, s.visible_normal) < 0.0f) return 4u;
+
+  const float jacobian = (q.s.sample_position.w > 0.5f) ? compute_jacobian_shared(q.s, sample_direction, to_sample_length) : 1.0f;
+  if (EMISSIVE_LIT) {
+    merge_reservoir(r, q, luminance(xyz(q.s.radiance)) / jacobian);
+  } else {
+    f3 out_radiance = shade(site, sample_direction, q.s.radiance);
+    merge_reservoir(r, q, luminance(out_radiance) / jacobian);
+  }
+  return 0u;
+}
+// HK_SPATIAL_COMPACT_TAPS: the loop over the neighbours as two loops.  In the one loop a lane whose tap ended early (out of the image,
+// another depth, occluded: half of the taps of a Cornell frame) sits masked while the rest of its wave unpacks, shades and merges - the
+// kernel is bound by VALU issue at 0.71 lane utilisation.  The first loop now only notes the taps that reach their record (its index
+// in LDS, 16 x 256 words per workgroup), the second walks each lane's list: a wave runs it as often as its BUSIEST lane
+// has survivors instead of 16 times.  Same taps, same order of merges: the same bits.
+#ifndef HK_SPATIAL_COMPACT_TAPS
+#define HK_SPATIAL_COMPACT_TAPS 0
+#endif
 #ifndef HK_SPATIAL_WGS
 #define HK_SPATIAL_WGS 4  // workgroups per CU = waves per SIMD: 128 VGPRs (5 -> 102 VGPRs spills: measured slower)
 #endif
@@ -680,81 +775,43 @@ __global__ __launch_bounds__(256, HK_SPATIAL_WGS) void k_spatial_reuse(DScene sc
 #else
 #define HK_TAP(k) ((void)0)
 #endif
+  const SpatialPixel me{x, y, uv, depth, rot};
+#if HK_SPATIAL_COMPACT_TAPS
+  // Two loops instead of one (HK_SPATIAL_COMPACT_TAPS above): which taps survive the tests that need no record, then the survivors.
+  __shared__ uint32_t kept[16u * 256u];
+  uint32_t n_kept = 0u;
   for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
     HK_TAP(0);
-    const float angle = HK_TAU * fract((float)i * HK_GOLDEN_RATIO + rot + fr.random_float_number);
-    const float radius = taps.radius[i - 1u];
-    float sn, cs;
-    sincos_(angle, &sn, &cs);
-    const f2 offset = radius * F2(cs, sn);
-
-    const int scx = f32_to_i32(offset.x + (float)x), scy = f32_to_i32(offset.y + (float)y);
-    const f2 sample_uv = coords_to_uv(fr, scx, scy);
-    if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) { HK_TAP(1); continue; }
-    int sdx, sdy;
-    jittered_deferred_coords(fr, sample_uv, &sdx, &sdy);
-    const float sample_depth = in_bounds(sdx, sdy, fr.dw, fr.dh) ? g.depth[sdx + fr.dw * sdy] : 0.0f;
-
-    const float depth_ratio = depth / sample_depth;
-    if (depth_ratio < 0.9f || depth_ratio > 1.1f) { HK_TAP(2); continue; }
-
-    // The tap is merged iff it passes the neighbour's own tests (non-empty, normal within 30 degrees, sample in front of the pixel)
-    // AND the screen-space depth march finds the segment unoccluded (light.wgsl:1593-1631).  All of them are pure predicates, so
-    // their order is free: the march - which needs nothing of the neighbour's record, only depths - goes FIRST.  On the Cornell
-    // frame it rejects 36 % of the taps (the record tests: 5 %), and those no longer fetch and unpack a 64-B record
-    // (tools/section_profile.py "spatial_reuse_taps").
-    const float tap_interval = taps.tap_interval[i - 1u];
-    const uint32_t tap_count = taps.tap_count[i - 1u];
-    bool occluded = false;
-    const f2 dir = normalize(offset);
-    // The march's depth taps (at most 6, a wave-uniform count): all loads first, then the comparisons.  `occluded` is the OR of
-    // the steps' tests, so stopping at the first hit or looking at every step gives the same answer; the wave waits for memory
-    // once per neighbour instead of once per step and the data-dependent loop (a branch and a wait per step) is gone:
-    // 0.353 -> 0.318 ms.  Two more steps in the same direction changed nothing and are not done: the sixteen neighbours' own
-    // depths fetched eight at a time (parked in LDS), and the neighbour's record requested together with its march taps.
-    // tap_offset / (width, height) goes through the frame's f64 reciprocals (quotient_by_reciprocal: the IEEE quotient unless that
-    // is subnormal, which it cannot be here - a non-zero component of `dir` is >= 1e-9: the polynomial of an angle that is at
-    // least 2^-25 away from the multiples of pi/2, over a tap radius of a few hundred pixels at most).
-    float march_depth[6];
-#pragma unroll
-    for (uint32_t j = 1u; j <= 6u; j += 1u) {
-      march_depth[j - 1u] = 0.0f;
-      if (j <= tap_count) {
-        const float tap_dist = (float)j * tap_interval;
-        const f2 tap_offset = tap_dist * dir;
-        const f2 tap_uv = uv + F2(quotient_by_reciprocal(tap_offset.x, fr.rcp_rw), quotient_by_reciprocal(tap_offset.y, fr.rcp_rh));
-        int tdx, tdy;
-        jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
-        march_depth[j - 1u] = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.depth[tdx + fr.dw * tdy] : 0.0f;
-      }
-    }
-#pragma unroll
-    for (uint32_t j = 1u; j <= 6u; j += 1u) {
-      if (j <= tap_count) {
-        const float ref_depth = mix(depth, sample_depth, taps.march_frac[i - 1u][j - 1u]);
-        if (march_depth[j - 1u] > ref_depth + 0.00001f) occluded = true;
-      }
-    }
-    if (occluded) { HK_TAP(5); continue; }
-    q = unpack_reservoir(load_packed(t.current, scx + fr.rw * scy));
-    const bool normal_miss = dot(s.visible_normal, q.s.visible_normal) < 0.866f;
-    if (q.count < HK_F32_EPSILON || normal_miss) { HK_TAP(3); continue; }
-
-    // normalize(q.s.sample_position - s.visible_position), keeping the length for the Jacobian below (compute_jacobian_shared)
-    const f3 to_sample = xyz(q.s.sample_position) - xyz(s.visible_position);
-    const float to_sample_length = sqrtf(dot(to_sample, to_sample));
-    const f3 sample_direction = to_sample * (1.0f / to_sample_length);
-    if (dot(sample_direction, s.visible_normal) < 0.0f) { HK_TAP(4); continue; }
-
-
-    const float jacobian = (q.s.sample_position.w > 0.5f) ? compute_jacobian_shared(q.s, sample_direction, to_sample_length) : 1.0f;
-    if (EMISSIVE_LIT) {
-      merge_reservoir(r, q, luminance(xyz(q.s.radiance)) / jacobian);
-    } else {
-      f3 out_radiance = shade(site, sample_direction, q.s.radiance);
-      merge_reservoir(r, q, luminance(out_radiance) / jacobian);
-    }
+    int scx, scy;
+    const uint32_t why = spatial_tap_reaches(fr, g, taps, me, i, &scx, &scy);
+    if (why) { HK_TAP(why); continue; }
+    kept[n_kept * 256u + threadIdx.x] = (uint32_t)(scx + fr.rw * scy);
+    n_kept += 1u;
   }
+#if HK_SPATIAL_COMPACT_TAPS == 2  // the next survivor's record requested before this one is shaded
+  PackedReservoir ahead = load_packed(t.current, n_kept ? (int)kept[threadIdx.x] : index);
+  for (uint32_t k = 0u; k < n_kept; k += 1u) {
+    const PackedReservoir record = ahead;
+    if (k + 1u < n_kept) ahead = load_packed(t.current, (int)kept[(k + 1u) * 256u + threadIdx.x]);
+    const uint32_t why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, record);
+    if (why) HK_TAP(why);
+  }
+#else
+  for (uint32_t k = 0u; k < n_kept; k += 1u) {
+    const uint32_t why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, load_packed(t.current, (int)kept[k * 256u + threadIdx.x]));
+    if (why) HK_TAP(why);
+  }
+#endif
+#else
+  for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
+    HK_TAP(0);
+    int scx, scy;
+    uint32_t why = spatial_tap_reaches(fr, g, taps, me, i, &scx, &scy);
+    if (why) { HK_TAP(why); continue; }
+    why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, load_packed(t.current, scx + fr.rw * scy));
+    if (why) HK_TAP(why);
+  }
+#endif
 
   const float m = (float)fr.max_spatial_reuse_count;
   if (r.count > m) {
