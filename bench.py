@@ -104,6 +104,9 @@ def pmc_traffic_in_run(timeout_s=150):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None
+    # this process is itself being profiled (rocprofv3 exports these to its application): no profiler inside a profiler
+    if any(k.startswith(("ROCPROF_", "ROCP_TOOL_", "ROCPROFILER_")) for k in os.environ):
+        return None
     child = [sys.executable, os.path.abspath(__file__), "--config", "2", "--steps", "6", "--warmup", "4", "--blocks", "1", "--no-cpu-baseline", "--no-hbm-probe",
              "--no-extra-configs", "--sustained-seconds", "0", "--no-pmc"]
     per = {}
