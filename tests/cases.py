@@ -24,6 +24,26 @@ ALL_BUFFERS.update({F.BUF_PREVIOUS_POSITION: "previous_position", F.BUF_PREVIOUS
 
 
 import contextlib
+import json
+import os
+
+
+def oracle():
+    """The CPU oracle behind the plugin interface (test infrastructure: tests/oracle_lib.py)."""
+    from oracle_lib import oracle_plugin
+
+    return oracle_plugin()
+
+
+def report(name, data):
+    """Printed, and kept under gpurun_out/ when the suite runs on the GPU box (copied to profiles/ by the round's scripts)."""
+    from conftest import ROOT
+
+    print(name, data)
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, name + ".json"), "w") as f:
+            json.dump(data, f, indent=1)
 
 
 @contextlib.contextmanager
@@ -203,6 +223,7 @@ def assert_rendered_within(a, b, what, tol=1e-3):
     return max(v[0] for v in dev.values()), max(v[1] for v in dev.values())
 
 
+GBUFFER = ("position", "normal", "depth_gradient", "instance_material", "velocity_uv", "albedo")   # names, as diff_buffers reports them
 GBUFFER_IDS = (F.BUF_POSITION, F.BUF_NORMAL, F.BUF_DEPTH_GRADIENT, F.BUF_INSTANCE_MATERIAL, F.BUF_VELOCITY_UV)
 
 

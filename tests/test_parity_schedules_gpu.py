@@ -1,0 +1,216 @@
+"""Every schedule and every cheaper route renders the SAME BYTES: second stream, frame pipelining, primary-ray pipelining, the
+certified division route, uniform-tile store elision.  Split from test_parity_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+
+import bevy_hikari_amd as hk
+from bevy_hikari_amd import _ffi as F
+from cases import diff_buffers, make_case, oracle, run_case, snapshot
+
+pytestmark = pytest.mark.gpu
+
+
+def test_certified_division_route_changes_no_bit():
+    """(k + 0.5) / size goes through a multiply + exact-residual correction that hk_resize certifies against
+    the IEEE quotient for every coordinate; HK_CTX_PLAIN_DIVISION forces the IEEE sequence.  Same frames."""
+    case = make_case("cornell_upscale2")
+    snaps = []
+    for flags in (0, F.CTX_PLAIN_DIVISION):
+        p = hk.HikariPlugin(device=0, flags=flags)
+        run_case(p, case)
+        snaps.append(snapshot(p))
+    assert diff_buffers(snaps[0], snaps[1]) == {}
+    odd = hk.HikariPlugin(device=0)          # sizes that are not powers of two or multiples of eight
+    odd.set_scene(case.scene)
+    plain = hk.HikariPlugin(device=0, flags=F.CTX_PLAIN_DIVISION)
+    plain.set_scene(case.scene)
+    s = hk.HikariSettings(indirect_bounces=1, upscale=hk.Upscale.Fsr1(1.3, 0.2))
+    for n in (1, 2, 3):
+        for p in (odd, plain):
+            p.render(hk.cornell_camera(117, 83), s, frame_number=n)
+    assert diff_buffers(snapshot(odd), snapshot(plain)) == {}
+
+
+def test_second_stream_overlap_changes_no_bit_and_joins_on_reads():
+    """The frame path runs the two direct-light dispatches on a second stream (joined before demodulation);
+    HK_CTX_SINGLE_STREAM keeps one stream.  Same frames; and a host that stops after the temporal stage and
+    reads the sun / emissive outputs must see them complete (hk_read_buffer joins)."""
+    case = make_case("yard_sun")      # both direct channels carry light, emissive spatial reuse on
+    snaps = []
+    for flags in (0, F.CTX_SINGLE_STREAM):
+        p = hk.HikariPlugin(device=0, flags=flags)
+        run_case(p, case)
+        snaps.append(snapshot(p))
+    assert diff_buffers(snaps[0], snaps[1]) == {}
+    s = case.settings
+    outs = []
+    for flags in (0, F.CTX_SINGLE_STREAM):
+        e = hk.Engine(device=0, flags=flags)
+        e.upload_noise()
+        e.upload_scene(case.scene)
+        e.resize(case.camera.width, case.camera.height, s.upscale.ratio())
+        for n in (1, 2, 3):
+            e.frame_begin(hk.frame_uniform(s, n), case.camera.view_uniform(), case.camera.previous_view_uniform(), case.lights)
+            e.frame_stage(F.STAGE_TEMPORAL, s.to_c())
+            got = [e.read(b) for b in (F.BUF_RENDER0, F.BUF_RENDER0 + 1, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0 + 1)]   # straight after the fork
+            e.frame_stage(F.STAGE_SPATIAL, s.to_c())
+            e.frame_stage(F.STAGE_POST_PROCESS, s.to_c())
+        outs.append(got)
+    for a, b in zip(*outs):
+        assert (a.view(np.uint8) == b.view(np.uint8)).all()
+    assert outs[0][1].view(np.float16).astype(np.float32)[..., :3].max() > 0
+
+
+def test_frame_pipelining_changes_no_bit_in_any_frame_order():
+    """Round 3: the a-trous levels of frame n run on a third stream beside frame n + 1's primary rays and light passes, the G-buffer
+    planes both touch double-buffered by frame parity.  (a) The pipelined context equals the single-stream one in every buffer after a
+    long back-to-back sequence; (b) frames of the SAME parity in a row (1, 3, 5 ...: the planes do not flip) and an arbitrary order of
+    frame numbers take the serial order and still equal the oracle bit for bit; (c) switching a context to bands and back in the
+    middle of a sequence (bands never pipeline) changes nothing."""
+    case = make_case("cornell_b2")
+    s, cam = case.settings, case.camera
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    snaps = []
+    for flags in (0, F.CTX_SINGLE_STREAM):   # (a)
+        p = hk.HikariPlugin(device=0, flags=flags)
+        p.set_scene(case.scene)
+        for n in range(1, 41):
+            p.render(cam, s, lights=case.lights, frame_number=n)
+        snaps.append(snapshot(p))
+    assert diff_buffers(snaps[0], snaps[1]) == {}
+    for numbers in ((1, 3, 5, 7, 9), (2, 2, 7, 4, 4, 11, 12)):   # (b)
+        gpu, cpu = hk.HikariPlugin(device=0), oracle()
+        for p in (gpu, cpu):
+            p.set_scene(case.scene)
+        for n in numbers:
+            for p in (gpu, cpu):
+                p.render(cam, s, lights=case.lights, frame_number=n)
+        assert diff_buffers(snapshot(gpu), snapshot(cpu)) == {}, numbers
+    e, ref = hk.Engine(device=0), hk.Engine(device=0, flags=F.CTX_SINGLE_STREAM)   # (c)
+    for x in (e, ref):
+        x.upload_noise(); x.upload_scene(case.scene); x.resize(cam.width, cam.height, s.upscale.ratio())
+    for n in range(1, 13):
+        f = hk.frame_uniform(s, n)
+        ref.frame_render(f, view, pview, case.lights, s.to_c())
+        if n in (5, 6, 9):   # two bands, both rendered by this context: together they are the whole frame
+            e.frame_begin(f, view, pview, case.lights)
+            for stage in (F.STAGE_TEMPORAL, F.STAGE_SPATIAL, F.STAGE_POST_PROCESS):
+                for band in (0, 1):
+                    e.set_band(band, 2)
+                    e.frame_stage(stage, s.to_c())
+            e.set_band(0, 1)
+        else:
+            e.frame_render(f, view, pview, case.lights, s.to_c())
+    for b in (F.BUF_TONE_MAPPED, F.BUF_DENOISE_RENDER0 + 2, F.BUF_RENDER0 + 2, F.BUF_ALBEDO, F.BUF_DEPTH_GRADIENT, F.BUF_RESERVOIR0 + 6, F.BUF_RESERVOIR0 + 7):
+        assert (e.read(b).view(np.uint8) == ref.read(b).view(np.uint8)).all(), b
+
+
+def test_primary_ray_pipelining_changes_no_bit():
+    """Round 5: the primary rays of frame n + 1 run on a fourth stream beside frame n's light passes (every plane the prepass writes
+    is double-buffered by frame parity).  (a) A pipelined context equals a single-stream one in every buffer after a long back-to-back
+    sequence - on Cornell (scene in LDS) and on a scene beyond LDS in the product default (the queue-based indirect pass, whose
+    trace stages' tails the primary rays fill) - and the pipelined path really ran; (b) what breaks the chain takes the serial order
+    and changes nothing: the anti-aliasing tail (reads the previous frame's planes), an instance update between frames, a host that
+    dispatches passes itself, frames of one parity in a row."""
+    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
+    from cases import product_default_traversal
+
+    case = make_case("cornell_b2")
+    big, sun = synthetic_large(0x5EED0007, 8, 24, 48, 60, 8, 2, 6.0)
+    runs = [(case.scene, case.camera, case.settings, case.lights, 0, 24),
+            (big, synthetic_camera(320, 180, extent=6.0), hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0), hk.lights_uniform(directional=sun), None, 12)]
+    os.environ["HK_PREPASS_PIPELINE"] = "all"   # (read by hk_create; off by default: measured slower)
+    try:
+        _pipelining_body(make_case, runs, oracle)
+    finally:
+        del os.environ["HK_PREPASS_PIPELINE"]
+
+
+def _pipelining_body(make_case, runs, oracle):
+    from cases import product_default_traversal
+
+    for scene, cam, s, lights, flags, frames in runs:   # (a)
+        snaps = []
+        for single in (False, True):
+            if flags is None:
+                with product_default_traversal():
+                    p = hk.HikariPlugin(device=0, flags=F.CTX_SINGLE_STREAM if single else 0)
+            else:
+                p = hk.HikariPlugin(device=0, flags=F.CTX_SINGLE_STREAM if single else 0)
+            p.set_scene(scene)
+            for n in range(1, frames + 1):
+                p.render(cam, s, lights=lights, frame_number=n)
+            snaps.append(snapshot(p))
+            assert p.engine.prepasses_pipelined() == (0 if single else frames - 1)
+        assert diff_buffers(snaps[0], snaps[1]) == {}
+    # (b) Cornell with the anti-aliasing tail on some frames, by_nodes on others, repeated parities: against the oracle, frame by frame
+    gpu, cpu = hk.HikariPlugin(device=0), oracle()
+    aa_case = make_case("cornell_aa_default")
+    for p in (gpu, cpu):
+        p.set_scene(aa_case.scene)
+    plan = [(1, False, False), (2, False, False), (3, True, False), (4, False, False), (5, False, True), (6, False, False), (7, False, False), (9, False, False), (10, True, False),
+            (11, False, False), (12, False, False)]
+    for n, aa, by_nodes in plan:
+        for p in (gpu, cpu):
+            p.render(aa_case.camera, aa_case.settings, lights=aa_case.lights, frame_number=n, antialias=aa, by_nodes=by_nodes)
+        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+        assert bad == {}, (n, bad)
+    assert 0 < gpu.engine.prepasses_pipelined() < len(plan) - 1
+
+
+def test_uniform_tile_store_elision_changes_no_bit():
+    """Uniform-tile store elision (hk_kernels.hpp TileMeta): waves whose 64 pixels are background skip reservoir stores that
+    would rewrite the record the tile already holds.  Every buffer must stay bit-identical to the oracle through the situations
+    that invalidate a tile record: background turning into geometry and back (camera pans across the box), scatter stores into
+    background tiles under motion, a host write into a reservoir buffer, partial-row dispatches, a resize."""
+    s = hk.HikariSettings(indirect_bounces=2, emissive_spatial_reuse=True, upscale=hk.Upscale.SMAA_TU_1_0)
+    scene = hk.load_cornell()
+    gpu, cpu = hk.HikariPlugin(device=0, flags=F.CTX_COUNT_RAYS), oracle()
+    for p in (gpu, cpu):
+        p.set_scene(scene)
+    w, h = 160, 96
+    # static frames first (records settle), then the camera jumps sideways so that tiles change between sky and box, then back
+    eyes = [(0.0, 1.0, 4.0)] * 4 + [(1.6, 1.0, 4.0)] * 3 + [(0.0, 1.0, 4.0)] * 3 + [(-1.2, 1.4, 5.0)] * 2
+    n = 0
+    prev_cam = None
+    for eye in eyes:
+        n += 1
+        cam = hk.Camera(hk.look_at_transform(eye, (eye[0], 1.0, 0.0)), w, h)
+        static = prev_cam is not None and eye == prev_eye
+        for p in (gpu, cpu):
+            p.render(cam, s, frame_number=n)
+        prev_cam, prev_eye = cam, eye
+        if static or n == 1:  # (a jump frame reprojects: the reference's scatter race is visible there, covered by the motion tests;
+            # the previous_* planes of the frame after a jump ARE that jump frame)
+            bad = {k: v for k, v in diff_buffers(snapshot(gpu), snapshot(cpu)).items() if not k.startswith("previous_")}
+            assert bad == {}, (n, bad)
+    # a host write into a reservoir buffer (what the fixture replays do) must drop the tile records of that buffer
+    for p in (gpu, cpu):
+        e = p.engine
+        r = e.read(F.BUF_RESERVOIR0 + 8)
+        r[:8, :16] = 0x3C003C00
+        e.write(F.BUF_RESERVOIR0 + 8, r)
+        e.write(F.BUF_RESERVOIR0 + 9, r)
+    for it in range(3):
+        n += 1
+        for p in (gpu, cpu):
+            p.render(prev_cam, s, frame_number=n)
+        bad = {name: v for name, v in diff_buffers(snapshot(gpu), snapshot(cpu)).items() if not name.startswith("previous_") or it > 0}
+        assert bad == {}, (n, bad)
+    # partial-row dispatches that do not end on a tile row, then whole-frame dispatches again
+    e = gpu.engine
+    before = snapshot(gpu)
+    e.pass_run(F.PASS_INDIRECT, 0, 0, 37)
+    e.pass_run(F.PASS_INDIRECT, 0, 37, h)
+    e.pass_run(F.PASS_INDIRECT_SPATIAL_REUSE, 0, 16, 61)
+    e.pass_run(F.PASS_INDIRECT_SPATIAL_REUSE, 0, 0, 16)
+    e.pass_run(F.PASS_INDIRECT_SPATIAL_REUSE, 0, 61, h)
+    assert diff_buffers(snapshot(gpu), before) == {}
+    for k in range(3):
+        n += 1
+        for p in (gpu, cpu):
+            p.render(prev_cam, s, frame_number=n)
+    bad = diff_buffers(snapshot(gpu), snapshot(cpu))
+    assert bad == {}, bad
