@@ -594,7 +594,7 @@ def main():
         # G-buffer 40 + own reservoir 64 + previous spatial 64, writes reservoir 64 + render 8 (the 16 neighbour records it gathers,
         # ~1 KB per pixel, are re-reads of lines other pixels own and do not count as compulsory traffic)
         sp_bytes = 240 * W * band_rows
-        out["roofline"]["second_kernel"] = {"kernel": "k_spatial_reuse<false> (spatial_reuse, light.wgsl:1503-1684)", "algorithmic_bytes_per_launch": sp_bytes,
+        out["roofline"]["second_kernel"] = {"kernel": "k_spatial_reuse<false, false> (spatial_reuse, light.wgsl:1503-1684; plain form)", "algorithmic_bytes_per_launch": sp_bytes,
                                             "alone": {"avg_launch_ms": round(m["spatial_ms_alone"], 5), "achieved": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9, 3),
                                                       "frac": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
         if tpath:   # its counter traffic (same committed PMC passes as roofline.traffic; round 2: 1.8x the algorithmic bytes)
@@ -663,7 +663,7 @@ def main():
         live = pmc_traffic_in_run()
         if live:
             k1 = next((v for k, v in live["per_kernel"].items() if k.startswith("k_indirect<true, false, 2>")), None)
-            k2 = next((v for k, v in live["per_kernel"].items() if k.startswith("k_spatial_reuse<false>")), None)
+            k2 = next((v for k, v in live["per_kernel"].items() if k.startswith("k_spatial_reuse<false, false>")), None)
             if k1:
                 out["roofline"]["traffic"] = k1
                 out["roofline"]["traffic_source"] = live["source"]

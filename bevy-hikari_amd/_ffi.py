@@ -205,6 +205,7 @@ _DEBUG = {
     "debug_comm_loopback": [_vp, u32, u32, u32, u32, u32],
     "debug_read_wf_timeline": [_vp, P(C.c_uint64), u32],
     "debug_prepasses_pipelined": [_vp, P(C.c_uint64)],
+    "debug_spatial_windowed_launches": [_vp, P(C.c_uint64)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],
     "measure_gather": [_vp, C.c_size_t, u32, u32, u32, u32, P(C.c_double), P(C.c_double)],

@@ -623,7 +623,7 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       const int channel = pass == HK_PASS_EMISSIVE_SPATIAL_REUSE ? 1 : 2;
       LightTargets t = make_light_targets(c, channel);
       { const int rc_ = attach_tile_meta(c, t, channel, true, y0, y1); if (rc_) return rc_; }
-      launch_spatial(c->stream, channel == 1, c->scene, fr, g, t, y0, y1);
+      if (launch_spatial(c->stream, channel == 1, c->scene, fr, g, t, y0, y1, c->spatial_window)) c->spatial_windowed_launches += 1;
       break;
     }
     case HK_PASS_DEMODULATION: {
@@ -768,6 +768,10 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   }
   c->stream = c->own_stream;
   c->prepass_queue = getenv("HK_PREPASS_QUEUE") != nullptr && atoi(getenv("HK_PREPASS_QUEUE")) != 0;
+  {
+    const char* e = getenv("HK_SPATIAL_WINDOW");
+    c->spatial_window = !e ? -1 : (!strcmp(e, "on") ? 1 : (!strcmp(e, "off") ? 0 : -1));
+  }
   if (!(flags & HK_CTX_SINGLE_STREAM)) {
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming) != hipSuccess) {
@@ -849,6 +853,12 @@ int hk_debug_read_wf_timeline(hk_ctx* c, unsigned long long* out, uint32_t n) {
   int khz = 0;
   HK_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
   out[n - 1] = (unsigned long long)khz;  // (slot 31 of stage 63 - never a real stage: the rate of wall_clock64, kHz)
+  return HK_OK;
+}
+
+int hk_debug_spatial_windowed_launches(hk_ctx* c, uint64_t* out) {
+  HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
+  *out = c->spatial_windowed_launches;
   return HK_OK;
 }
 

@@ -132,6 +132,8 @@ struct hk_ctx {
   // hk_create) = none (default: measured slower everywhere, context.hip hk_frame_stage), lds, all.
   hipStream_t pre_stream = nullptr;
   int pre_mode = 0;
+  int spatial_window = -1;               // HK_SPATIAL_WINDOW=auto|on|off (read by hk_create): which form of k_spatial_reuse a launch takes (kernels.hip launch_spatial)
+  uint64_t spatial_windowed_launches = 0;
   bool prepass_queue = false;           // HK_PREPASS_QUEUE=1 (read by hk_create): the primary rays of scenes beyond LDS through the trace kernel's queue (experiment)
   hipEvent_t pre_done = nullptr;
   hipEvent_t frame_mark[2] = {nullptr, nullptr};        // main stream, start of the TEMPORAL stage of the last frame of that parity

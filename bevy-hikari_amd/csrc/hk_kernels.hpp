@@ -306,8 +306,10 @@ void launch_refit(hipStream_t st, const hkd::RefitScene& s, const hkd::RefitUpda
 size_t lbvh_scratch_bytes(uint32_t n, size_t* sort_temp_bytes);
 int launch_tree_build(hipStream_t st, int mode /* 0 LBVH, 1 the reference's binned SAH */, bool light, const hkd::RefitScene& s, uint32_t n, const float4* box_lo,
                       const float4* box_hi, void* scratch, float4* lo, float4* hi, uint32_t stride, uint32_t orderings);
-void launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
-                    int y0, int y1);
+// windowed: 0 the plain form, 1 the windowed form (depth window + tap lists in LDS: kernels.hip), -1 by the size of the launch; returns
+// whether the windowed form was launched
+bool launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
+                    int y0, int y1, int windowed);
 void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);
 void launch_count_geometry_rows(hipStream_t st, const float* depth, int width, int height, uint32_t* out);
 void launch_demodulation(hipStream_t st, int nch, const hkd::DFrame& fr, const hkd::DemodTargets& d, int y0, int y1);

@@ -603,7 +603,35 @@ struct SpatialPixel {
   f2 uv;
   float depth, rot;
 };
-HKD uint32_t spatial_tap_reaches(const DFrame& fr, const GBuffer& g, const SpatialTaps& taps, const SpatialPixel& me, uint32_t i, int* out_x, int* out_y) {
+// The WINDOWED form of the kernel (template parameter; launch_spatial picks it for frames of many rounds of workgroups):
+//  * the depths a workgroup's taps can reach, in LDS.  A pixel reads ~85 depths around itself (16 neighbours and up to five march
+//    steps towards each, within 20 pixels: light.wgsl:1570,1609).  The workgroup's 16 x 16 pixels + 22 around them are a 60 x 60
+//    window of the depth plane (at upscale ratio 1; fewer texels otherwise): 14 KB, filled with coalesced row loads, read with
+//    ds_read_b32.  A coordinate outside the window (never, at the reference's radii) falls through to the plane: the same value.
+//  * the loop over the neighbours as two loops.  In the one loop a lane whose tap ended early (out of the image, another depth,
+//    occluded: half of the taps of a Cornell frame) sits masked while the rest of its wave unpacks, shades and merges.  The first loop
+//    only notes the taps that reach their record (its index in LDS, 16 x 256 words per workgroup), the second walks each lane's list:
+//    a wave runs it as often as its BUSIEST lane has survivors.  Same taps, same order of merges: the same bits.
+// Measured (profiles/r05_spatial_reuse_ab.txt): 15 % fewer VALU wave-instructions at lane utilisation 0.84 instead of 0.71 - worth
+// -7 % / -18 % on the two spatial passes of a 4K Cornell frame (config 5: the frame 4.44 -> 4.25 ms), and NOTHING at 1080p, where the
+// launch is three rounds of workgroups and ends in a tail as long as a wave lives: there the plain form stays.
+constexpr int HK_SPATIAL_TILE_W = 60, HK_SPATIAL_TILE_REACH = 22;
+template <bool WINDOWED>
+struct DepthWindow {
+  const float* __restrict__ plane;
+  const float* tile;
+  int x0, y0, dw, dh;
+  HKD float at(int x, int y) const {  // in_bounds(x, y) ? depth[x + dw * y] : 0
+    if (!in_bounds(x, y, dw, dh)) return 0.0f;
+    if constexpr (WINDOWED) {
+      const unsigned lx = (unsigned)(x - x0), ly = (unsigned)(y - y0);
+      if (lx < (unsigned)HK_SPATIAL_TILE_W && ly < (unsigned)HK_SPATIAL_TILE_W) return tile[ly * (unsigned)HK_SPATIAL_TILE_W + lx];
+    }
+    return plane[x + dw * y];
+  }
+};
+template <bool WINDOWED>
+HKD uint32_t spatial_tap_reaches(const DFrame& fr, const DepthWindow<WINDOWED>& g, const SpatialTaps& taps, const SpatialPixel& me, uint32_t i, int* out_x, int* out_y) {
   const float angle = HK_TAU * fract((float)i * HK_GOLDEN_RATIO + me.rot + fr.random_float_number);
   const float radius = taps.radius[i - 1u];
   float sn, cs;
@@ -617,7 +645,7 @@ HKD uint32_t spatial_tap_reaches(const DFrame& fr, const GBuffer& g, const Spati
   if (sample_uv.x < 0.0f || sample_uv.y < 0.0f || sample_uv.x > 1.0f || sample_uv.y > 1.0f) return 1u;
   int sdx, sdy;
   jittered_deferred_coords(fr, sample_uv, &sdx, &sdy);
-  const float sample_depth = in_bounds(sdx, sdy, fr.dw, fr.dh) ? g.depth[sdx + fr.dw * sdy] : 0.0f;
+  const float sample_depth = g.at(sdx, sdy);
 
   const float depth_ratio = me.depth / sample_depth;
   if (depth_ratio < 0.9f || depth_ratio > 1.1f) return 2u;
@@ -649,7 +677,7 @@ HKD uint32_t spatial_tap_reaches(const DFrame& fr, const GBuffer& g, const Spati
       const f2 tap_uv = me.uv + F2(quotient_by_reciprocal(tap_offset.x, fr.rcp_rw), quotient_by_reciprocal(tap_offset.y, fr.rcp_rh));
       int tdx, tdy;
       jittered_deferred_coords(fr, tap_uv, &tdx, &tdy);
-      march_depth[j - 1u] = in_bounds(tdx, tdy, fr.dw, fr.dh) ? g.depth[tdx + fr.dw * tdy] : 0.0f;
+      march_depth[j - 1u] = g.at(tdx, tdy);
     }
   }
 #pragma unroll
@@ -682,32 +710,42 @@ HKD uint32_t spatial_tap_merge(const ShadingSite& site, const Sample& s, Reservo
   }
   return 0u;
 }
-// HK_SPATIAL_COMPACT_TAPS: the loop over the neighbours as two loops.  In the one loop a lane whose tap ended early (out of the image,
-// another depth, occluded: half of the taps of a Cornell frame) sits masked while the rest of its wave unpacks, shades and merges - the
-// kernel is bound by VALU issue at 0.71 lane utilisation.  The first loop now only notes the taps that reach their record (its index
-// in LDS, 16 x 256 words per workgroup), the second walks each lane's list: a wave runs it as often as its BUSIEST lane
-// has survivors instead of 16 times.  Same taps, same order of merges: the same bits.
-#ifndef HK_SPATIAL_COMPACT_TAPS
-#define HK_SPATIAL_COMPACT_TAPS 0
-#endif
 #ifndef HK_SPATIAL_WGS
 #define HK_SPATIAL_WGS 4  // workgroups per CU = waves per SIMD: 128 VGPRs (5 -> 102 VGPRs spills: measured slower)
 #endif
-template <bool EMISSIVE_LIT>
+template <bool EMISSIVE_LIT, bool WINDOWED>
 __global__ __launch_bounds__(256, HK_SPATIAL_WGS) void k_spatial_reuse(DScene sc, DFrame fr, GBuffer g, LightTargets t, SpatialTaps taps, int row_begin, int row_end) {
   const Pixel px = pixel_of_thread<false>(fr.rw, row_begin, row_end);
-  if (!px.valid) return;
+  if (!WINDOWED && !px.valid) return;  // (the windowed form has a workgroup barrier ahead: its invalid lanes leave after it)
   constexpr uint32_t SPATIAL_REUSE_COUNT = EMISSIVE_LIT ? 8u : 16u;
   const int x = px.x, y = px.y;
   const int index = x + fr.rw * y;
   const f2 uv = coords_to_uv(fr, x, y);
   int dcx, dcy;
   jittered_deferred_coords(fr, uv, &dcx, &dcy);
-  const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh);
+  const bool din = in_bounds(dcx, dcy, fr.dw, fr.dh) && px.valid;  // (px.valid: always, in the plain form)
   const int didx = dcx + fr.dw * dcy;
   const float4 position_depth = din ? g.position[didx] : make_float4(0, 0, 0, 0);
   const f3 position = xyz(position_depth);
   const float depth = position_depth.w;
+  // the window of the depth plane this workgroup's taps reach (every thread arrives here; a workgroup of background pixels skips the fill)
+  __shared__ float depth_tile[WINDOWED ? HK_SPATIAL_TILE_W * HK_SPATIAL_TILE_W : 1];
+  DepthWindow<WINDOWED> window{g.depth, depth_tile, 0, 0, fr.dw, fr.dh};
+  if constexpr (WINDOWED) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int block_x0 = x - (lane & 7) - (wave & 1) * 8, block_y0 = y - (lane >> 3) - (wave >> 1) * 8;
+    window.x0 = (int)floorf((float)(block_x0 - HK_SPATIAL_TILE_REACH) * (float)fr.dw / (float)fr.rw);
+    window.y0 = (int)floorf((float)(block_y0 - HK_SPATIAL_TILE_REACH) * (float)fr.dh / (float)fr.rh);
+    if (__syncthreads_or(px.valid && !(depth < HK_F32_EPSILON))) {
+      for (int k = (int)threadIdx.x; k < HK_SPATIAL_TILE_W * HK_SPATIAL_TILE_W; k += 256) {
+        const int ly = k / HK_SPATIAL_TILE_W, lx = k - ly * HK_SPATIAL_TILE_W;
+        const int gx = window.x0 + lx, gy = window.y0 + ly;
+        depth_tile[k] = in_bounds(gx, gy, fr.dw, fr.dh) ? g.depth[gx + fr.dw * gy] : 0.0f;
+      }
+      __syncthreads();
+    }
+    if (!px.valid) return;
+  }
 
   // background pixels re-pack their temporal reservoir into the spatial buffer (light.wgsl:1527-1532).  Uniform-tile store
   // elision (hk_kernels.hpp TileMeta): a wave of background pixels whose input tile holds ONE record everywhere, and whose
@@ -776,42 +814,31 @@ __global__ __launch_bounds__(256, HK_SPATIAL_WGS) void k_spatial_reuse(DScene sc
 #define HK_TAP(k) ((void)0)
 #endif
   const SpatialPixel me{x, y, uv, depth, rot};
-#if HK_SPATIAL_COMPACT_TAPS
-  // Two loops instead of one (HK_SPATIAL_COMPACT_TAPS above): which taps survive the tests that need no record, then the survivors.
-  __shared__ uint32_t kept[16u * 256u];
-  uint32_t n_kept = 0u;
-  for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
-    HK_TAP(0);
-    int scx, scy;
-    const uint32_t why = spatial_tap_reaches(fr, g, taps, me, i, &scx, &scy);
-    if (why) { HK_TAP(why); continue; }
-    kept[n_kept * 256u + threadIdx.x] = (uint32_t)(scx + fr.rw * scy);
-    n_kept += 1u;
+  __shared__ uint32_t kept[WINDOWED ? 16u * 256u : 1u];
+  if constexpr (WINDOWED) {  // which taps reach their record, then the survivors (the comment above DepthWindow)
+    uint32_t n_kept = 0u;
+    for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
+      HK_TAP(0);
+      int scx, scy;
+      const uint32_t why = spatial_tap_reaches(fr, window, taps, me, i, &scx, &scy);
+      if (why) { HK_TAP(why); continue; }
+      kept[n_kept * 256u + threadIdx.x] = (uint32_t)(scx + fr.rw * scy);
+      n_kept += 1u;
+    }
+    for (uint32_t k = 0u; k < n_kept; k += 1u) {
+      const uint32_t why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, load_packed(t.current, (int)kept[k * 256u + threadIdx.x]));
+      if (why) HK_TAP(why);
+    }
+  } else {
+    for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
+      HK_TAP(0);
+      int scx, scy;
+      uint32_t why = spatial_tap_reaches(fr, window, taps, me, i, &scx, &scy);
+      if (why) { HK_TAP(why); continue; }
+      why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, load_packed(t.current, scx + fr.rw * scy));
+      if (why) HK_TAP(why);
+    }
   }
-#if HK_SPATIAL_COMPACT_TAPS == 2  // the next survivor's record requested before this one is shaded
-  PackedReservoir ahead = load_packed(t.current, n_kept ? (int)kept[threadIdx.x] : index);
-  for (uint32_t k = 0u; k < n_kept; k += 1u) {
-    const PackedReservoir record = ahead;
-    if (k + 1u < n_kept) ahead = load_packed(t.current, (int)kept[(k + 1u) * 256u + threadIdx.x]);
-    const uint32_t why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, record);
-    if (why) HK_TAP(why);
-  }
-#else
-  for (uint32_t k = 0u; k < n_kept; k += 1u) {
-    const uint32_t why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, load_packed(t.current, (int)kept[k * 256u + threadIdx.x]));
-    if (why) HK_TAP(why);
-  }
-#endif
-#else
-  for (uint32_t i = 1u; i <= SPATIAL_REUSE_COUNT; i += 1u) {
-    HK_TAP(0);
-    int scx, scy;
-    uint32_t why = spatial_tap_reaches(fr, g, taps, me, i, &scx, &scy);
-    if (why) { HK_TAP(why); continue; }
-    why = spatial_tap_merge<EMISSIVE_LIT>(site, s, r, load_packed(t.current, scx + fr.rw * scy));
-    if (why) HK_TAP(why);
-  }
-#endif
 
   const float m = (float)fr.max_spatial_reuse_count;
   if (r.count > m) {
@@ -978,8 +1005,13 @@ void launch_resolve_scatter(hipStream_t st, const LightTargets& t, int p0, int p
   if (own1 > own0 && (p0 < own0 || p1 > own1)) hipLaunchKernelGGL(k_join_winners, grid, dim3(256), 0, st, t, p0, p1, own0, own1);
   hipLaunchKernelGGL(k_resolve_scatter, grid, dim3(256), 0, st, t, p0, p1);
 }
-void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1) {
-  if (y1 <= y0) return;
+// windowed: 0 never, 1 always, -1 by the size of the launch - the windowed form pays where the launch is many rounds of workgroups
+// (HK_SPATIAL_WINDOWED_MIN_TILES: sixteen rounds of 4 workgroups on 256 CUs); a 1080p frame (8 160 tiles) keeps the plain one
+#ifndef HK_SPATIAL_WINDOWED_MIN_TILES
+#define HK_SPATIAL_WINDOWED_MIN_TILES 16384u
+#endif
+bool launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1, int windowed) {
+  if (y1 <= y0) return false;
   dim3 grid = grid_for(fr.rw, y1 - y0);
   SpatialTaps taps{};
   const uint32_t count = emissive_lit ? 8u : 16u;           // light.wgsl:246-252
@@ -992,8 +1024,12 @@ void launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const D
     taps.tap_count[i - 1] = (uint32_t)(radius / interval);                 // light.wgsl:1610
     for (uint32_t j = 1; j <= taps.tap_count[i - 1] && j <= 6u; ++j) taps.march_frac[i - 1][j - 1] = (float)j / (float)(taps.tap_count[i - 1] + 1u);
   }
-  if (emissive_lit) hipLaunchKernelGGL(k_spatial_reuse<true>, grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
-  else hipLaunchKernelGGL(k_spatial_reuse<false>, grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
+  const bool window = windowed > 0 || (windowed < 0 && grid.x >= HK_SPATIAL_WINDOWED_MIN_TILES);
+  if (emissive_lit && window) hipLaunchKernelGGL((k_spatial_reuse<true, true>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
+  else if (emissive_lit) hipLaunchKernelGGL((k_spatial_reuse<true, false>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
+  else if (window) hipLaunchKernelGGL((k_spatial_reuse<false, true>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
+  else hipLaunchKernelGGL((k_spatial_reuse<false, false>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
+  return window;
 }
 void launch_tone_mapping(hipStream_t st, const DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1) {
   if (y1 <= y0) return;

@@ -702,6 +702,12 @@ class Engine:
         self.api.call("debug_prepasses_pipelined", self.ctx, C.byref(n))
         return int(n.value)
 
+    def spatial_windowed_launches(self):
+        """spatial_reuse launches that took the windowed form of the kernel (hikari_hip_debug.h; HK_SPATIAL_WINDOW=auto|on|off at creation)."""
+        n = C.c_uint64()
+        self.api.call("debug_spatial_windowed_launches", self.ctx, C.byref(n))
+        return int(n.value)
+
     def measure_hbm(self, bytes_per_array=1 << 30, reps=8):
         """Empirical HBM ceiling: (copy GB/s, triad GB/s) of grid-stride float4 streams over arrays too big for the Infinity Cache."""
         cp, tr = C.c_double(), C.c_double()

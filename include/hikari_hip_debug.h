@@ -61,6 +61,11 @@ int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer
  * stream, next to the previous frame's light passes (hk_frame_stage(TEMPORAL); DESIGN 4 "Primary-ray pipelining") - since hk_create. */
 int hk_debug_prepasses_pipelined(hk_ctx* ctx, uint64_t* out);
 
+/* Test hook (round 5): how many spatial_reuse launches of this context took the WINDOWED form of the kernel (the depths its taps reach
+ * and the lists of surviving taps in LDS: kernels.hip) since hk_create.  Which form a launch takes: by its size, or HK_SPATIAL_WINDOW =
+ * auto | on | off in the environment of hk_create. */
+int hk_debug_spatial_windowed_launches(hk_ctx* ctx, uint64_t* out);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

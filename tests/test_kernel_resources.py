@@ -17,8 +17,8 @@ LIB = os.path.join(ROOT, "bevy-hikari_amd", "libhikari_hip.so")
 # kernel (regex on the demangled name) -> most VGPRs it may use (512 / waves per SIMD, in the allocation granule of 8)
 BUDGETS = {
     r"k_indirect<true, false, 1>": 128,        # the dominant ray kernel, LDS scene, reference walk: 4 waves per SIMD
-    r"k_spatial_reuse<false>": 128,
-    r"k_spatial_reuse<true>": 128,
+    r"k_spatial_reuse<false, (true|false)>": 128,   # (second parameter: the windowed form, 31 KB of LDS - four workgroups per CU either way)
+    r"k_spatial_reuse<true, (true|false)>": 128,
     r"k_prepass<false, (1|2)>": 128,
     r"k_wf_trace<(true|false), false>": 72,          # HK_WF_TRACE_WAVES = 7
     r"k_wf_shade<(true|false)>": 128,
@@ -106,7 +106,7 @@ VALU_BUDGETS = {
     r"k_denoise<0, 3, 6>": 2111,
     r"k_denoise<3, 3, 6>": 2207,
     r"k_demodulation<3>": 514,
-    r"k_spatial_reuse<false>": 3770,
+    r"k_spatial_reuse<false, false>": 3770,
     r"k_indirect<true, false, 1>": 7941,
     r"k_indirect<true, false, 2>": 7751,
     r"k_prepass<false, 1>": 3274,

@@ -180,6 +180,8 @@ def test_config5_full_4k_8_bounces_vs_oracle():
     assert bad == {}, bad
     rel, frac = assert_rendered_within(snapshot(dflt), want, "config 5 at 3840x2160 x 8 bounces, product default mode")
     assert dflt.engine.traversal_mode()[0] == "one-level"
+    # a 4K launch is many rounds of workgroups: both spatial passes of both frames took the WINDOWED form of k_spatial_reuse (kernels.hip)
+    assert gpu.engine.spatial_windowed_launches() == 4 and dflt.engine.spatial_windowed_launches() == 4
     report("default_mode_config5_4k_vs_oracle", {"worst_relative_l2": rel, "worst_fraction_of_pixels_differing": frac, "frames": 2})
     sg, sc = gpu.engine.stats(), cpu.engine.stats()
     assert (sg.rays_primary, sg.rays_tlas, sg.rays_blas) == (sc.rays_primary, sc.rays_tlas, sc.rays_blas)

@@ -214,3 +214,33 @@ def test_uniform_tile_store_elision_changes_no_bit():
             p.render(prev_cam, s, frame_number=n)
     bad = diff_buffers(snapshot(gpu), snapshot(cpu))
     assert bad == {}, bad
+
+
+@pytest.mark.parametrize("name", ["cornell_b2", "cornell_upscale2", "cornell_ratio15_fsr", "cornell_b8", "yard_sun", "yard_textured", "yard_ortho", "background_only", "tiny_3x5"])
+def test_windowed_spatial_reuse_changes_no_byte(name):
+    """k_spatial_reuse has two forms (kernels.hip): the plain one and the WINDOWED one - the depths a workgroup's taps reach in an LDS
+    window, the taps that reach their record in per-lane lists - which launch_spatial takes for launches of many rounds of workgroups
+    (4K frames; the full-size tests of configs 4 / 5 run it).  Here it is FORCED on small cases - upscale ratios 1, 1.5 and 2 (the window
+    is in deferred texels), both spatial passes, an orthographic camera, images smaller than a window, no geometry at all: every buffer
+    of every frame equals the oracle's, and the windowed form really ran (light.wgsl:1503-1684)."""
+    case = make_case(name)
+    cpu = oracle()
+    os.environ["HK_SPATIAL_WINDOW"] = "on"   # (read by hk_create)
+    try:
+        forced = hk.HikariPlugin(device=0)
+    finally:
+        del os.environ["HK_SPATIAL_WINDOW"]
+    plain = hk.HikariPlugin(device=0)
+
+    for p in (forced, plain, cpu):
+        p.set_scene(case.scene)
+    for n in case.frames:
+        for p in (forced, plain, cpu):
+            p.render(case.camera, case.settings, lights=case.lights, frame_number=n, antialias=case.antialias)
+        want = snapshot(cpu)
+        for what, p in (("windowed", forced), ("plain", plain)):
+            bad = diff_buffers(snapshot(p), want)
+            assert bad == {}, (what, n, bad)
+    spatial_passes = int(bool(case.settings.emissive_spatial_reuse)) + int(bool(case.settings.indirect_spatial_reuse))
+    assert plain.engine.spatial_windowed_launches() == 0
+    assert forced.engine.spatial_windowed_launches() == (spatial_passes * len(case.frames) if spatial_passes else 0)

@@ -33,6 +33,6 @@ for d in sq fetch write; do
   [ -z "$DB" ] && { echo "no db for $d"; continue; }
   python tools/pmc_summary.py $DB > $OUT/${TAG}_pmc_$d.txt
 done
-grep -A9 "k_spatial_reuse<false>\|k_indirect<true" $OUT/${TAG}_pmc_sq.txt | head -40
+grep -A9 "k_spatial_reuse<false, false>\|k_indirect<true" $OUT/${TAG}_pmc_sq.txt | head -40
 grep -A2 "k_indirect<true" $OUT/${TAG}_pmc_fetch.txt $OUT/${TAG}_pmc_write.txt
 rm -rf $OUT/prof_trace_c* $OUT/prof_sq $OUT/prof_fetch $OUT/prof_write

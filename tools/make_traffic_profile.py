@@ -55,13 +55,13 @@ def main():
             "source": "SQ_INSTS_VALU; SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)",
         },
     }
-    # the second kernel of the frame (bench.py roofline.second_kernel): k_spatial_reuse<false>, 240 B/px algorithmic
+    # the second kernel of the frame (bench.py roofline.second_kernel): k_spatial_reuse<false, false>, 240 B/px algorithmic
     try:
-        n2, s2 = pick(sq, "k_spatial_reuse<false>")
-        _, f2 = pick(fetch, "k_spatial_reuse<false>")
-        _, w2 = pick(write, "k_spatial_reuse<false>")
+        n2, s2 = pick(sq, "k_spatial_reuse<false, false>")
+        _, f2 = pick(fetch, "k_spatial_reuse<false, false>")
+        _, w2 = pick(write, "k_spatial_reuse<false, false>")
         hbm2, algo2 = int(2 * f2["FETCH_SIZE"][0] * 1024 + w2["WRITE_SIZE"][0] * 1024), 240 * 1920 * 1080
-        out["second_kernel"] = {"kernel": "k_spatial_reuse<false> (spatial_reuse, light.wgsl:1503-1684)", "FETCH_SIZE_KB_raw": round(f2["FETCH_SIZE"][0], 1),
+        out["second_kernel"] = {"kernel": "k_spatial_reuse<false, false> (spatial_reuse, light.wgsl:1503-1684; plain form)", "FETCH_SIZE_KB_raw": round(f2["FETCH_SIZE"][0], 1),
                                 "WRITE_SIZE_KB": round(w2["WRITE_SIZE"][0], 1), "hbm_bytes_per_launch": hbm2, "algorithmic_bytes_per_launch": algo2,
                                 "ratio_to_algorithmic": round(hbm2 / algo2, 3),
                                 # profiles/r04_fetch_calibration.json: FETCH_SIZE tallies 64 B per memory-side read request; a coalesced stream issues 128-B

@@ -19,5 +19,5 @@ for d in trace sq fetch write; do
   if [ $d = trace ]; then python tools/rocpd_summary.py $DB > $OUT/${TAG}_kernel_stats.txt; else python tools/pmc_summary.py $DB > $OUT/${TAG}_pmc_$d.txt; fi
 done
 head -14 $OUT/${TAG}_kernel_stats.txt | cut -c1-200
-grep -A9 "k_spatial_reuse<false>\|k_indirect<true" $OUT/${TAG}_pmc_sq.txt | head -40
+grep -A9 "k_spatial_reuse<false, false>\|k_indirect<true" $OUT/${TAG}_pmc_sq.txt | head -40
 grep -A2 "k_indirect<true" $OUT/${TAG}_pmc_fetch.txt $OUT/${TAG}_pmc_write.txt
