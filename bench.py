@@ -291,7 +291,12 @@ def main():
         run_frames(eng, rend, 1, warmup)
         eng.wait()
         eng.reset_stats()
-        eng.set_timing_mask((1 << F.PASS_INDIRECT) | (1 << F.TIMING_TRACE_STAGES))  # HIP events around the dominant pass (+ each of its trace launches: queue-based schedule)
+        # HIP events ON the two long dispatches of the frame (hipExtLaunchKernelGGL: no extra stream operation) + each trace launch of the
+        # queue-based schedule; scenes beyond LDS (configs 3 / 4) also bracket their two direct-light dispatches on the side stream
+        mask = (1 << F.PASS_INDIRECT) | (1 << F.PASS_INDIRECT_SPATIAL_REUSE) | (1 << F.TIMING_TRACE_STAGES)
+        if config in (3, 4):
+            mask |= (1 << F.PASS_DIRECT_LIT) | (1 << F.PASS_DIRECT_EMISSIVE)
+        eng.set_timing_mask(mask)
         blocks = []
         n0 = warmup
         for _ in range(max(1, n_blocks)):
@@ -311,6 +316,8 @@ def main():
         traversal = eng.traversal_mode() + (eng.wide_walk(),)
         ind_ms = st.pass_ms_total[F.PASS_INDIRECT] / max(1, st.pass_launches[F.PASS_INDIRECT])
         ind_launches = int(st.pass_launches[F.PASS_INDIRECT])
+        sp_ms = st.pass_ms_total[F.PASS_INDIRECT_SPATIAL_REUSE] / max(1, st.pass_launches[F.PASS_INDIRECT_SPATIAL_REUSE])
+        direct_ms = {F.PASS_NAMES[k]: round(st.pass_ms_total[k] / max(1, st.pass_launches[k]), 5) for k in (F.PASS_DIRECT_LIT, F.PASS_DIRECT_EMISSIVE) if st.pass_launches[k]}
         trace_launches = int(st.pass_launches[F.TIMING_TRACE_STAGES])
         trace_ms = st.pass_ms_total[F.TIMING_TRACE_STAGES] / max(1, trace_launches)   # average TRACE launch of the queue-based indirect pass (0 launches: fused schedule)
         eng.set_timing_mask(0)
@@ -330,6 +337,19 @@ def main():
             barrier()
             sustained = {"frames": n_frames, "seconds": round(max_over_ranks(t1 - t0), 3)}
             sustained["ms_per_step"] = round(sustained["seconds"] / n_frames * 1e3, 4)
+
+        # frame LATENCY: one frame, wait, repeat (the timed blocks keep three streams full - frame n's a-trous levels run beside frame
+        # n + 1's light passes - so ms_per_step is a THROUGHPUT figure; this is what one frame takes from its first dispatch to its image).
+        # After everything that is compared with the replay: these frames are not part of any count.
+        lat, nl = [], last_frame + (sustained["frames"] if sustained else 0)
+        for k in range(min(steps, 16)):
+            barrier()
+            t0 = time.perf_counter()
+            run_frames(eng, rend, nl + 1, nl + 1)
+            eng.wait()
+            lat.append(max_over_ranks(time.perf_counter() - t0))
+            nl += 1
+        frame_latency_ms = float(np.median(lat)) * 1e3
 
         # ray count by deterministic replay (one block's worth of frames: the camera is static and the rays per frame are
         # counted over the LAST timed block)
@@ -392,7 +412,8 @@ def main():
 
         res = {"config": config, "description": description, "W": W, "H": H, "steps": steps, "warmup": warmup, "blocks": blocks, "elapsed": elapsed,
                "band_bounds": (rend.bounds if rend is not None else None),
-               "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "trace_ms": trace_ms, "trace_launches": trace_launches,
+               "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "sp_ms": sp_ms, "direct_ms": direct_ms,
+               "frame_latency_ms": frame_latency_ms, "trace_ms": trace_ms, "trace_launches": trace_launches,
                "total_rays": total_rays, "same": same,
                "walk": walk, "sustained": sustained, "scene": scene, "settings": settings, "lights": lights, "view": view, "pview": pview, "sc": sc,
                "band_rows": H if rend is None else (rend.band(H)[1] - rend.band(H)[0])}
@@ -458,7 +479,9 @@ def main():
                                                          "pieces_handed_to_idle_lanes")},
              "per_ray": {"records": round(tk["records"] / max(1, tk["rays"]), 2), "triangle_tests": round(tk["triangle_tests"] / max(1, tk["rays"]), 2),
                          "instance_entries": round(tk["instance_entries"] / max(1, tk["rays"]), 2), "bvh_bytes": round(bvh_bytes / max(1, tk["rays"]), 1)},
-             "algorithmic_bytes_per_pass": bvh_bytes, "achieved": round(bvh_bytes / t / 1e9, 2), "frac": round(bvh_bytes / t / 1e9 / HBM_PEAK_GBS, 5),
+             # (cache-served: the walk's algorithmic bytes mostly never reach HBM - so their ratio to the HBM peak is NOT an HBM roofline fraction;
+             # `frac` below is the HBM-side counter bytes over the peak, when the committed counter passes exist)
+             "algorithmic_bytes_per_pass": bvh_bytes, "achieved": round(bvh_bytes / t / 1e9, 2), "algorithmic_bytes_over_hbm_peak": round(bvh_bytes / t / 1e9 / HBM_PEAK_GBS, 5), "frac": None,
              "formula": "records fetched x 128 + triangle tests x 48 + instance entries x 208 + 96 per closest hit found (SURVEY 8d's terms, in the units of THIS walk)",
              "tail": {"fraction_of_trace_time_after_the_queue_ran_dry": tk["tail_fraction_of_trace_time"],
                       "per_stage": [round(st_["ticks_after_the_queue_ran_dry"] / max(1, st_["ticks"]), 3) for st_ in tk["stages"]],
@@ -468,11 +491,13 @@ def main():
         # HBM-side bytes of the pass's trace launches by the PMC counters (tools/pmc_fetch.sh: separate FETCH_SIZE / WRITE_SIZE passes of
         # `bench.py --config N`; not measured in this run): lower = x 1 per 64-B request (right for gathers), upper = x 2
         try:
-            tfile = next(q for q in (os.path.join(ROOT, "profiles", f"r0{k}_walk_hbm_traffic.json") for k in (5, 4)) if os.path.exists(q))
+            tfile = next(q for q in (os.path.join(ROOT, "profiles", f"r0{k}_walk_hbm_traffic.json") for k in (6, 5, 4)) if os.path.exists(q))
             with open(tfile) as f:
                 tw = json.load(f).get(f"config{x.get('config', 0)}_trace_stages")
             if tw:
                 r["traffic"] = tw["hbm_bytes_per_pass_lower"]
+                r["frac"] = round(tw["hbm_bytes_per_pass_lower"] / t / 1e9 / HBM_PEAK_GBS, 5)
+                r["frac_is"] = "HBM-side bytes of the pass's trace launches (FETCH_SIZE + WRITE_SIZE, committed counter passes) / trace time / HBM peak"
                 r["hbm_side"] = {"bytes_per_pass": tw["hbm_bytes_per_pass_lower"], "bytes_per_pass_if_every_request_were_128_B": tw["hbm_bytes_per_pass_upper"],
                                  "frac_of_peak": round(tw["hbm_bytes_per_pass_lower"] / t / 1e9 / HBM_PEAK_GBS, 5),
                                  "frac_of_peak_upper": round(tw["hbm_bytes_per_pass_upper"] / t / 1e9 / HBM_PEAK_GBS, 5),
@@ -509,6 +534,21 @@ def main():
                 extra[str(cfg)]["ray_count_replay_bit_identical"] = x["walk"]["ray_count_replay_bit_identical"]
             if cfg in (3, 4) and rank == 0 and not args.no_hbm_probe:
                 extra[str(cfg)]["roofline"] = walk_roofline(x, xeng)
+            if cfg in (3, 4) and x["direct_ms"]:
+                # the two direct-light dispatches (side stream, beside the trace stages; HIP events around them in the timed frames).  Config 4's
+                # sun pass is as heavy as all trace launches of the frame together; its lanes: profiles/*_lanes_config4.txt
+                lanes = {}
+                try:
+                    lf = next(q for q in (os.path.join(ROOT, "profiles", f"r0{k}_final_lanes_config{cfg}.txt") for k in (6, 5)) if os.path.exists(q))
+                    for line in open(lf):   # "<kernel signature, cut>  util 0.500 valu  593.7 M  waves 129600" (tools/pmc_lanes.sh)
+                        if "k_direct_lit<" in line and ", false, 0>" in line and " util " in line:
+                            lanes[line.split("hkd::")[1].split("(")[0]] = float(line.split(" util ")[1].split()[0])
+                    lanes["source"] = os.path.relpath(lf, ROOT) + " (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU), committed counter pass)"
+                except (StopIteration, OSError, ValueError, IndexError):
+                    pass
+                extra[str(cfg)]["direct_passes"] = {"avg_launch_ms_in_run": x["direct_ms"], "lane_utilisation": lanes or None,
+                                                    "note": "k_direct_lit<false, false, 0> (sun) / <true, false, 0> (emissive): any-hit shadow rays that keep their occluder - the "
+                                                            "reference's own visit order, skip-link walk per lane"}
             del x
 
     # ------------------------------------------------------------------ empirical HBM ceiling, same run
@@ -565,45 +605,46 @@ def main():
         "rays_per_frame": round(total_rays / args.steps, 1),
         "replay_bit_identical": same,
         **({"ray_count_replay_bit_identical": m["walk"]["ray_count_replay_bit_identical"]} if "ray_count_replay_bit_identical" in m["walk"] else {}),
-        "roofline": {
-            "kernel": "k_indirect (indirect_lit_ambient, light.wgsl:1263-1498)" if schedule == "fused" else
-                      "indirect_lit_ambient (light.wgsl:1263-1498) as k_wf_setup + k_wf_trace / k_wf_shade per bounce + k_wf_final: first dispatch start to last dispatch end",
-            "schedule": schedule,
-            "bound": "hbm",
-            "achieved": round(achieved, 3),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6),
-            # HBM bytes per launch from PMC counters cannot be collected inside this process; filled in below from the committed
-            # rocprofv3 --pmc passes of this very command (profiles/, see "traffic_source") when they exist for this config
-            "traffic": None,
-            "algorithmic_bytes_per_launch": algo_bytes,
-            "avg_launch_ms": round(ind_ms, 5),
-            "launches": m["ind_launches"],
-            # the same kernel with nothing else on the GPU (HK_CTX_SINGLE_STREAM replay of the same frames).  In the timed run the
-            # direct-light dispatches (second stream) and the previous frame's a-trous levels (third stream) share the GPU with
-            # it: the frame gets shorter, this dispatch's own duration longer - `frac` above is the contract's in-run figure, this
-            # one is the kernel's.
-            "alone": {"avg_launch_ms": round(ind_ms_alone, 5), "achieved": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9, 3) if ind_ms_alone > 0 else 0.0,
-                      "frac": round(algo_bytes / (ind_ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ind_ms_alone > 0 else 0.0},
-        },
+        "frame_latency_ms": round(m["frame_latency_ms"], 4),
+        "ms_per_step_is": "throughput: frames enqueued back to back, frame n's a-trous levels (third stream) beside frame n + 1's light passes; frame_latency_ms = one frame, wait, repeat",
+        "roofline": None,
     }
-    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_indirect_hbm_traffic.json") for k in (5, 4, 3, 2)) if os.path.exists(q)), "")
-    if m.get("spatial_ms_alone"):
-        # the second large kernel of the frame (by now as long as the first): spatial_reuse, light.wgsl:1503-1684 - SURVEY 8d: reads
-        # G-buffer 40 + own reservoir 64 + previous spatial 64, writes reservoir 64 + render 8 (the 16 neighbour records it gathers,
-        # ~1 KB per pixel, are re-reads of lines other pixels own and do not count as compulsory traffic)
-        sp_bytes = 240 * W * band_rows
-        out["roofline"]["second_kernel"] = {"kernel": "k_spatial_reuse<false, false> (spatial_reuse, light.wgsl:1503-1684; plain form)", "algorithmic_bytes_per_launch": sp_bytes,
-                                            "alone": {"avg_launch_ms": round(m["spatial_ms_alone"], 5), "achieved": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9, 3),
-                                                      "frac": round(sp_bytes / (m["spatial_ms_alone"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)}}
-        if tpath:   # its counter traffic (same committed PMC passes as roofline.traffic; round 2: 1.8x the algorithmic bytes)
-            t2 = json.load(open(tpath)).get("second_kernel")
-            if t2:
-                out["roofline"]["second_kernel"]["traffic"] = t2["hbm_bytes_per_launch"]
-                out["roofline"]["second_kernel"]["traffic_ratio_to_algorithmic"] = t2["ratio_to_algorithmic"]
-                if "ratio_to_algorithmic_lower_bound" in t2:   # FETCH_SIZE x 1 (right for 64-B record gathers) .. x 2 (right for coalesced streams): profiles/r04_fetch_calibration.json
-                    out["roofline"]["second_kernel"]["traffic_ratio_bounds"] = [t2["ratio_to_algorithmic_lower_bound"], t2["ratio_to_algorithmic"]]
+    # The dominant kernel is the LONGER of the frame's two long dispatches AS TIMED IN THIS RUN (HIP events on both dispatches inside the
+    # timed region: in the pipelined frame their durations stretch differently - rocprofv3 of round 5: k_spatial_reuse 521 us against
+    # k_indirect 331 us - while alone on the GPU they tie).  `second_kernel` is the other one, same arithmetic.
+    sp_ms, sp_ms_alone = m["sp_ms"], m.get("spatial_ms_alone") or 0.0
+    sp_bytes = 240 * W * band_rows   # G-buffer 40 + own reservoir 64 + previous spatial 64 read, reservoir 64 + render 8 written (the gathered neighbour records are re-reads)
+
+    def kernel_roofline(name, ms, ms_alone, bytes_per_launch, launches):
+        ach = bytes_per_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": round(ms, 5), "launches": launches,
+                # the same kernel with nothing else on the GPU (HK_CTX_SINGLE_STREAM replay of the same frames): in the timed run the other
+                # streams' dispatches share the GPU with it - the frame gets shorter, this dispatch's own duration longer
+                "alone": {"avg_launch_ms": round(ms_alone, 5), "achieved": round(bytes_per_launch / (ms_alone * 1e-3) / 1e9, 3) if ms_alone > 0 else 0.0,
+                          "frac": round(bytes_per_launch / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ms_alone > 0 else 0.0}}
+
+    k_ind = kernel_roofline("k_indirect<true, false, 2> (indirect_lit_ambient, light.wgsl:1263-1498)" if schedule == "fused" else
+                            "indirect_lit_ambient (light.wgsl:1263-1498) as k_wf_setup + k_wf_trace / k_wf_shade per bounce + k_wf_final: first dispatch start to last dispatch end",
+                            ind_ms, ind_ms_alone, algo_bytes, m["ind_launches"])
+    k_ind["schedule"] = schedule
+    k_sp = kernel_roofline("k_spatial_reuse<false, %s> (spatial_reuse, light.wgsl:1503-1684)" % ("true" if ((W + 15) // 16) * ((band_rows + 15) // 16) >= 16384 else "false"), sp_ms, sp_ms_alone, sp_bytes, m["ind_launches"]) if sp_ms > 0 else None
+    spatial_dominant = bool(k_sp and schedule == "fused" and sp_ms > ind_ms)
+    out["roofline"] = dict(k_sp if spatial_dominant else k_ind)
+    out["roofline"]["dominant_by"] = "the longer average launch of the two long dispatches, HIP events in the timed region: k_indirect %.4f ms, k_spatial_reuse %.4f ms" % (ind_ms, sp_ms)
+    if k_sp:
+        out["roofline"]["second_kernel"] = k_ind if spatial_dominant else k_sp
+    achieved = out["roofline"]["achieved"]
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r0{k}_indirect_hbm_traffic.json") for k in (6, 5, 4, 3, 2)) if os.path.exists(q)), "")
+    rf_ind = out["roofline"]["second_kernel"] if spatial_dominant else out["roofline"]              # where k_indirect's / k_spatial_reuse's figures live in the line
+    rf_sp = out["roofline"] if spatial_dominant else out["roofline"].get("second_kernel")
+    if tpath and rf_sp is not None and world == 1 and args.config == 2:   # counter traffic from the committed PMC passes (replaced below by this invocation's own when it measures them)
+        t2 = json.load(open(tpath)).get("second_kernel")
+        if t2:
+            rf_sp["traffic"] = t2["hbm_bytes_per_launch"]
+            rf_sp["traffic_ratio_to_algorithmic"] = t2["ratio_to_algorithmic"]
+            if "ratio_to_algorithmic_lower_bound" in t2:   # FETCH_SIZE x 1 (right for 64-B record gathers) .. x 2 (right for coalesced streams): profiles/r04_fetch_calibration.json
+                rf_sp["traffic_ratio_bounds"] = [t2["ratio_to_algorithmic_lower_bound"], t2["ratio_to_algorithmic"]]
     if hbm:
         out["roofline"]["hbm_ceiling_measured"] = hbm
         out["roofline"]["frac_of_measured_copy"] = round(achieved / hbm["copy_gbs"], 6) if hbm["copy_gbs"] > 0 else None
@@ -648,12 +689,12 @@ def main():
                                      " (not measured in this run); launch time of this run, kernel alone"})
             except Exception:
                 pass
-        out["roofline"]["valu_issue"] = vi
+        rf_ind["valu_issue"] = vi   # (k_indirect's: its VALU wave-instructions against the issue ceiling measured in this run)
     if tpath and world == 1 and args.config == 2:
         out["traffic_profile"] = {"source": os.path.relpath(tpath, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)"}
         try:  # separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction (MI355X_MICROARCH.md, HBM section), per launch
-            out["roofline"]["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            out["roofline"]["traffic_source"] = os.path.relpath(tpath, ROOT)
+            rf_ind["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            rf_ind["traffic_source"] = os.path.relpath(tpath, ROOT)
         except Exception:
             pass
     if default_run and not args.no_pmc and not args.no_extra_configs and not args.no_hbm_probe:   # (the full default invocation only: every tool that profiles a short run passes one of these)
@@ -665,13 +706,14 @@ def main():
             k1 = next((v for k, v in live["per_kernel"].items() if k.startswith("k_indirect<true, false, 2>")), None)
             k2 = next((v for k, v in live["per_kernel"].items() if k.startswith("k_spatial_reuse<false, false>")), None)
             if k1:
-                out["roofline"]["traffic"] = k1
-                out["roofline"]["traffic_source"] = live["source"]
-                out["roofline"]["traffic_ratio_to_algorithmic"] = round(k1 / algo_bytes, 3)
-            if k2 and "second_kernel" in out["roofline"]:
-                out["roofline"]["second_kernel"]["traffic"] = k2
-                out["roofline"]["second_kernel"]["traffic_ratio_to_algorithmic"] = round(k2 / (240.0 * W * band_rows), 3)
-                out["roofline"]["second_kernel"]["traffic_source"] = live["source"]
+                rf_ind["traffic"] = k1
+                rf_ind["traffic_source"] = live["source"]
+                rf_ind["traffic_ratio_to_algorithmic"] = round(k1 / algo_bytes, 3)
+            if k2 and rf_sp is not None:
+                rf_sp["traffic"] = k2
+                rf_sp["traffic_ratio_to_algorithmic"] = round(k2 / (240.0 * W * band_rows), 3)
+                rf_sp["traffic_source"] = live["source"]
+                rf_sp.pop("traffic_ratio_bounds", None)
             if "frame_roofline" in out and live["frame_bytes"] > 0:
                 cb = float(live["frame_bytes"])
                 out["frame_roofline"]["counter"] = {"hbm_bytes_per_frame": cb, "achieved_gbs": round(cb / (elapsed / args.steps) / 1e9, 1),
@@ -680,16 +722,25 @@ def main():
                                                     "per_kernel": live["per_kernel"], "source": live["source"]}
             out["traffic_profile"] = {"source": live["source"]}
             q1 = next((v for k, v in live["sq"].items() if k.startswith("k_indirect<true, false, 2>")), None)
-            if q1 and valu and "valu_issue" in out["roofline"]:   # the kernel's VALU wave-instructions and lane utilisation, of this invocation too
+            if q1 and valu and "valu_issue" in rf_ind:   # the kernel's VALU wave-instructions and lane utilisation, of this invocation too
                 alone_ms = ind_ms_alone or ind_ms
                 rate = q1["valu_wave_instructions"] / (alone_ms * 1e-3) / 1e9
-                out["roofline"]["valu_issue"].update({"wave_instructions_per_launch": q1["valu_wave_instructions"], "achieved_ginstr_s": round(rate, 1),
+                rf_ind["valu_issue"].update({"wave_instructions_per_launch": q1["valu_wave_instructions"], "achieved_ginstr_s": round(rate, 1),
                                                       "frac_of_measured_peak_8_waves": round(rate / valu["8_waves_per_simd"], 4),
                                                       "frac_of_measured_peak_4_waves": round(rate / valu["4_waves_per_simd"], 4),
                                                       "frac_of_nominal": round(rate / (256 * 4 * 2.4 / 2), 4), "lane_utilisation": q1["lane_utilisation"],
                                                       "source": live["source"] + "; launch time of this run, kernel alone"})
+            q2 = next((v for k, v in live["sq"].items() if k.startswith("k_spatial_reuse<false, false>")), None)
+            if q2 and valu and rf_sp is not None:
+                alone_ms = sp_ms_alone or sp_ms
+                rate = q2["valu_wave_instructions"] / (alone_ms * 1e-3) / 1e9
+                rf_sp["valu_issue"] = {"wave_instructions_per_launch": q2["valu_wave_instructions"], "achieved_ginstr_s": round(rate, 1),
+                                       "frac_of_measured_peak_4_waves": round(rate / valu["4_waves_per_simd"], 4), "lane_utilisation": q2["lane_utilisation"],
+                                       "source": live["source"] + "; launch time of this run, kernel alone"}
     if args.config in (3, 4) and world == 1 and not args.no_hbm_probe:
         out["roofline"]["bvh_walk"] = walk_roofline(m, xeng)
+    if m.get("direct_ms"):
+        out["direct_passes_in_run_ms"] = m["direct_ms"]
     if m["sustained"]:
         out["sustained"] = m["sustained"]
     if extra:

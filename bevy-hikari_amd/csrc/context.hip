@@ -565,7 +565,9 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     launch_derive_planes(c->stream, g, c->depth_plane, c->dn_g, c->W, 0, c->H);
     c->derived_dirty = false;
   }
-  ScopedTimer timer(c, pass, pass == HK_PASS_INDIRECT);
+  // (the two long dispatches of a frame carry their events ON the dispatch - hipExtLaunchKernelGGL - so that timing them inside a
+  // pipelined frame adds no stream operation; every other pass is bracketed by two records)
+  ScopedTimer timer(c, pass, pass == HK_PASS_INDIRECT || pass == HK_PASS_INDIRECT_SPATIAL_REUSE || pass == HK_PASS_EMISSIVE_SPATIAL_REUSE);
   switch (pass) {
     case HK_PASS_PREPASS: {
       Jitter j = prepass_jitter(c);
@@ -623,7 +625,8 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       const int channel = pass == HK_PASS_EMISSIVE_SPATIAL_REUSE ? 1 : 2;
       LightTargets t = make_light_targets(c, channel);
       { const int rc_ = attach_tile_meta(c, t, channel, true, y0, y1); if (rc_) return rc_; }
-      if (launch_spatial(c->stream, channel == 1, c->scene, fr, g, t, y0, y1, c->spatial_window)) c->spatial_windowed_launches += 1;
+      if (launch_spatial(c->stream, channel == 1, c->scene, fr, g, t, y0, y1, c->spatial_window, timer.on ? timer.t.start : nullptr, timer.on ? timer.t.stop : nullptr))
+        c->spatial_windowed_launches += 1;
       break;
     }
     case HK_PASS_DEMODULATION: {
@@ -758,7 +761,7 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   HK_REQUIRE(c, HK_E_NOMEM, "allocation failed");
   c->device = device_id;
   c->flags = flags;
-  c->timing_mask = (flags & HK_CTX_TIME_PASSES) ? 0xFFFFFFFFu : 0u;
+  c->timing_mask = (flags & HK_CTX_TIME_PASSES) ? ((1u << HK_PASS_COUNT) - 1u) : 0u;  // (HK_TIMING_TRACE_STAGES, events around every trace launch, only through hk_set_timing_mask)
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, 9 * sizeof(unsigned long long)) != hipSuccess ||
       hipMemset(c->d_counters, 0, 9 * sizeof(unsigned long long)) != hipSuccess || hipEventCreate(&c->frame_start) != hipSuccess ||
       hipEventCreate(&c->frame_stop) != hipSuccess) {

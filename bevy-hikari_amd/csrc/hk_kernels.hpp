@@ -309,7 +309,7 @@ int launch_tree_build(hipStream_t st, int mode /* 0 LBVH, 1 the reference's binn
 // windowed: 0 the plain form, 1 the windowed form (depth window + tap lists in LDS: kernels.hip), -1 by the size of the launch; returns
 // whether the windowed form was launched
 bool launch_spatial(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
-                    int y0, int y1, int windowed);
+                    int y0, int y1, int windowed, hipEvent_t start = nullptr, hipEvent_t stop = nullptr);  // (events attached to the dispatch: HkStats timing)
 void launch_derive_planes(hipStream_t st, const hkd::GBuffer& g, float* depth_plane, void* dn_g, int width, int y0, int y1);
 void launch_count_geometry_rows(hipStream_t st, const float* depth, int width, int height, uint32_t* out);
 void launch_demodulation(hipStream_t st, int nch, const hkd::DFrame& fr, const hkd::DemodTargets& d, int y0, int y1);

@@ -1010,7 +1010,8 @@ void launch_resolve_scatter(hipStream_t st, const LightTargets& t, int p0, int p
 #ifndef HK_SPATIAL_WINDOWED_MIN_TILES
 #define HK_SPATIAL_WINDOWED_MIN_TILES 16384u
 #endif
-bool launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1, int windowed) {
+bool launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, int y0, int y1, int windowed,
+                    hipEvent_t start, hipEvent_t stop) {
   if (y1 <= y0) return false;
   dim3 grid = grid_for(fr.rw, y1 - y0);
   SpatialTaps taps{};
@@ -1025,10 +1026,10 @@ bool launch_spatial(hipStream_t st, bool emissive_lit, const DScene& sc, const D
     for (uint32_t j = 1; j <= taps.tap_count[i - 1] && j <= 6u; ++j) taps.march_frac[i - 1][j - 1] = (float)j / (float)(taps.tap_count[i - 1] + 1u);
   }
   const bool window = windowed > 0 || (windowed < 0 && grid.x >= HK_SPATIAL_WINDOWED_MIN_TILES);
-  if (emissive_lit && window) hipLaunchKernelGGL((k_spatial_reuse<true, true>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
-  else if (emissive_lit) hipLaunchKernelGGL((k_spatial_reuse<true, false>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
-  else if (window) hipLaunchKernelGGL((k_spatial_reuse<false, true>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
-  else hipLaunchKernelGGL((k_spatial_reuse<false, false>), grid, dim3(256), 0, st, sc, fr, g, t, taps, y0, y1);
+  if (emissive_lit && window) hipExtLaunchKernelGGL((k_spatial_reuse<true, true>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, taps, y0, y1);
+  else if (emissive_lit) hipExtLaunchKernelGGL((k_spatial_reuse<true, false>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, taps, y0, y1);
+  else if (window) hipExtLaunchKernelGGL((k_spatial_reuse<false, true>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, taps, y0, y1);
+  else hipExtLaunchKernelGGL((k_spatial_reuse<false, false>), grid, dim3(256), 0, st, start, stop, 0, sc, fr, g, t, taps, y0, y1);
   return window;
 }
 void launch_tone_mapping(hipStream_t st, const DFrame& fr, const void* direct, const void* emissive, const void* indirect, void* out, int y0, int y1) {

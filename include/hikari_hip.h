@@ -325,7 +325,7 @@ typedef struct HkHaloOp {
 
 #define HK_TIMING_SLOTS 24
 /* slot 18 (beyond the HkPass ids): every TRACE launch of the queue-based indirect pass on its own (bounces + 1 launches per pass);
- * selected like a pass, by bit 18 of hk_set_timing_mask */
+ * selected like a pass, by bit 18 of hk_set_timing_mask - and only so: HK_CTX_TIME_PASSES selects the HkPass slots 0 .. HK_PASS_COUNT - 1 */
 #define HK_TIMING_TRACE_STAGES 18u
 typedef struct HkStats {
   uint64_t rays_primary;      /* G-buffer rays */
@@ -333,7 +333,7 @@ typedef struct HkStats {
   uint64_t rays_blas;         /* stand-alone traverse_bottom invocations (light.wgsl:687) */
   uint64_t frames;
   /* HIP-event timing on the context's stream.  Slot = HkPass id.  Only passes selected by
-   * hk_set_timing_mask() (all, with HK_CTX_TIME_PASSES) are bracketed by events. */
+   * hk_set_timing_mask() (every HkPass, with HK_CTX_TIME_PASSES) are bracketed by events. */
   double pass_ms_total[HK_TIMING_SLOTS];
   uint64_t pass_launches[HK_TIMING_SLOTS];
   float last_frame_ms;        /* first dispatch of TEMPORAL .. last dispatch of POST_PROCESS */
