@@ -45,6 +45,7 @@ TREE_SAH, TREE_LBVH = 0, 1  # hk_rebuild_scene_trees
 CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient with >= 2 bounces (hikari_hip.h)
 CTX_NO_WIDE_WALK = 256  # closest-hit walks of scenes beyond LDS keep the threaded skip-link walk (A/B switch)
 CTX_COUNT_WALKS = 512   # the trace stages run the counting twin of their kernel (same schedule, same walks): hk_debug_read_wf_timeline
+(DEBUG_OPT_SPATIAL_WINDOW, DEBUG_OPT_FRAME_PIPELINE, DEBUG_OPT_WF_TIMELINE, DEBUG_OPT_FLAT_WALK, DEBUG_OPT_FLAT_ORDERINGS, DEBUG_OPT_TRACE_UPDATE) = range(6)  # hikari_hip_debug.h hk_debug_set_option
 TIMING_TRACE_STAGES = 18  # hk_set_timing_mask bit / HkStats slot: every trace launch of the queue-based indirect pass
 TRAVERSAL_WIDE = 0x100
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS, FRAME_GATHER = 1, 2, 4, 8
@@ -204,7 +205,8 @@ _DEBUG = {
     "debug_read_trees": [_vp, P(HkNode), u32, P(HkNode), u32],
     "debug_comm_loopback": [_vp, u32, u32, u32, u32, u32],
     "debug_read_wf_timeline": [_vp, P(C.c_uint64), u32],
-    "debug_prepasses_pipelined": [_vp, P(C.c_uint64)],
+    "debug_set_option": [_vp, u32, C.c_int64],
+    "debug_multi_serial": [C.c_int],
     "debug_spatial_windowed_launches": [_vp, P(C.c_uint64)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],
@@ -285,7 +287,7 @@ _PRODUCT_ONLY = {
 _VOID = {"destroy": [_vp], "scene_builder_destroy": [_vp], "multi_destroy": [_vp]}
 
 #: every symbol include/hikari_hip.h declares / include/hikari_hip_debug.h declares (checked by tests/test_abi.py)
-DECLARED_SYMBOLS = sorted(["hk_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY) + list(_VOID)] + ["hk_abi_version", "hk_last_error", "hk_final_buffer"])
+DECLARED_SYMBOLS = sorted(["hk_" + n for n in list(_SIGNATURES) + list(_PRODUCT_ONLY) + list(_VOID)] + ["hk_abi_version", "hk_last_error", "hk_final_buffer", "hk_build_info"])
 DECLARED_DEBUG_SYMBOLS = sorted("hk_" + n for n in _DEBUG)
 
 
@@ -311,6 +313,8 @@ class Api:
         self._last_error.restype = C.c_char_p
         self._abi = self.dll.hk_abi_version
         self._abi.restype = u32
+        self._build_info = self.dll.hk_build_info
+        self._build_info.restype = C.c_char_p
         self._final_buffer = self.dll.hk_final_buffer
         self._final_buffer.argtypes, self._final_buffer.restype = [P(HkSettings), u32], u32
 
@@ -320,6 +324,10 @@ class Api:
 
     def abi_version(self):
         return int(self._abi())
+
+    def build_info(self):
+        """hk_build_info: the hash of the sources, the compiler and flags this binary was built with, and when."""
+        return self._build_info().decode()
 
     def last_error(self):
         msg = self._last_error()

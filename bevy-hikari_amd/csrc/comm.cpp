@@ -259,6 +259,7 @@ void comm_release(hk_ctx* c) {
 
 // ------------------------------------------------------------------ hk_multi
 struct MultiPool;
+static std::atomic<int> g_multi_serial{0};  // hk_debug_multi_serial: the calling thread enqueues every band (the A/B of the enqueue threads)
 struct hk_multi {
   std::vector<hk_ctx*> ctx;
   std::vector<int> device;
@@ -790,6 +791,10 @@ int hk_multi_set_history_rows(hk_multi* m, uint32_t rows) {
 }
 
 static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags);
+int hk_debug_multi_serial(int on) {
+  g_multi_serial.store(on ? 1 : 0);
+  return HK_OK;
+}
 int hk_multi_frame_render(hk_multi* m, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l, const HkSettings* st, uint32_t flags) {
   HK_REQUIRE(m && st, HK_E_INVALID, "bad argument");
   const int rc = multi_frame_render_bands(m, f, v, pv, l, st, flags);
@@ -800,8 +805,7 @@ static int multi_frame_render_bands(hk_multi* m, const HkFrame* f, const HkView*
   int rc;
   {
     // every band's enqueue work on its own thread (the frame that re-splits the bands sets state on every context: serial)
-    static const bool serial_env = getenv("HK_MULTI_SERIAL") != nullptr;
-    if (m->ctx.size() > 1 && !serial_env && !(flags & HK_FRAME_BALANCE_BANDS)) {
+    if (m->ctx.size() > 1 && !g_multi_serial.load() && !(flags & HK_FRAME_BALANCE_BANDS)) {
       if ((rc = pool_start(m))) return rc;
       MultiPool* P = m->pool;
       HK_REQUIRE(P->threads.size() == m->ctx.size(), HK_E_NOMEM, "the enqueue threads did not start");

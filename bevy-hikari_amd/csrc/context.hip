@@ -66,13 +66,11 @@ int free_screen(hk_ctx* c) {
   if (c->dn_g) (void)hipFree(c->dn_g);
   c->depth_plane = nullptr;
   c->dn_g = nullptr;
-  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin, &c->normal_twin, &c->instance_material_twin}) {
+  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin}) {
     if (*q) (void)hipFree(*q);
     *q = nullptr;
   }
   c->post_pending = false;
-  c->pre_chain_ok = false;
-  c->post_recorded[0] = c->post_recorded[1] = false;
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
       if (c->dn_extra[k][l]) (void)hipFree(c->dn_extra[k][l]);
@@ -520,7 +518,7 @@ int ensure_wavefront(hk_ctx* c) {
   w.alive[0] = u32(1); w.alive[1] = u32(1);
   w.shadow[0] = u32(1); w.shadow[1] = u32(1);
   w.cap = (uint32_t)n;
-  const bool tl_twin = getenv("HK_WF_TIMELINE") != nullptr, count_twin = (c->flags & HK_CTX_COUNT_WALKS) != 0u;
+  const bool tl_twin = c->wf_timeline, count_twin = (c->flags & HK_CTX_COUNT_WALKS) != 0u;
   if ((tl_twin || count_twin) && !w.timeline) HK_HIP(hipMalloc((void**)&w.timeline, 64 * 32 * sizeof(unsigned long long)));  // tools/wf_timeline.py, bench.py
   w.timeline_mode = count_twin ? 2u : (tl_twin ? 1u : 0u);
   return HK_OK;
@@ -770,11 +768,6 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
     return HK_E_HIP;
   }
   c->stream = c->own_stream;
-  c->prepass_queue = getenv("HK_PREPASS_QUEUE") != nullptr && atoi(getenv("HK_PREPASS_QUEUE")) != 0;
-  {
-    const char* e = getenv("HK_SPATIAL_WINDOW");
-    c->spatial_window = !e ? -1 : (!strcmp(e, "on") ? 1 : (!strcmp(e, "off") ? 0 : -1));
-  }
   if (!(flags & HK_CTX_SINGLE_STREAM)) {
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming) != hipSuccess) {
@@ -782,26 +775,12 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
       hk_destroy(c);
       return HK_E_HIP;
     }
-    if (!getenv("HK_NO_FRAME_PIPELINE") && !(flags & (HK_CTX_DETERMINISTIC_SCATTER | HK_CTX_COUNT_RAYS | HK_CTX_TIME_PASSES))) {
+    if (!(flags & (HK_CTX_DETERMINISTIC_SCATTER | HK_CTX_COUNT_RAYS | HK_CTX_TIME_PASSES))) {
       if (hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->post_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->post_done, hipEventDisableTiming) != hipSuccess) {
         set_error("cannot create the post-process stream");
         hk_destroy(c);
         return HK_E_HIP;
-      }
-      {
-        const char* e = getenv("HK_PREPASS_PIPELINE");
-        c->pre_mode = !e ? 0 : (!strcmp(e, "all") ? 2 : (!strcmp(e, "lds") ? 1 : 0));  // default: off (measured, see hk_frame_stage)
-      }
-      if (c->pre_mode != 0) {
-        bool ok = hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < 2 && ok; ++k)
-          ok = hipEventCreateWithFlags(&c->frame_mark[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->post_done_parity[k], hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-          set_error("cannot create the primary-ray stream");
-          hk_destroy(c);
-          return HK_E_HIP;
-        }
       }
     }
   }
@@ -832,12 +811,6 @@ void hk_destroy(hk_ctx* c) {
   c->d_noise.release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
-  if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); }
-  if (c->pre_done) (void)hipEventDestroy(c->pre_done);
-  for (int k = 0; k < 2; ++k) {
-    if (c->frame_mark[k]) (void)hipEventDestroy(c->frame_mark[k]);
-    if (c->post_done_parity[k]) (void)hipEventDestroy(c->post_done_parity[k]);
-  }
   if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
   if (c->post_fork) (void)hipEventDestroy(c->post_fork);
   if (c->post_done) (void)hipEventDestroy(c->post_done);
@@ -859,15 +832,29 @@ int hk_debug_read_wf_timeline(hk_ctx* c, unsigned long long* out, uint32_t n) {
   return HK_OK;
 }
 
-int hk_debug_spatial_windowed_launches(hk_ctx* c, uint64_t* out) {
-  HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
-  *out = c->spatial_windowed_launches;
+// hikari_hip_debug.h: the switches tests and A/B tools used to pass through the environment
+int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
+  HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
+  HK_HIP(hipSetDevice(c->device));
+  { const int rc = sync_all(c); if (rc) return rc; }
+  switch (option) {
+    case HK_DEBUG_OPT_SPATIAL_WINDOW: c->spatial_window = value < 0 ? -1 : (value ? 1 : 0); break;
+    case HK_DEBUG_OPT_FRAME_PIPELINE: c->frame_pipeline = value != 0; break;
+    case HK_DEBUG_OPT_WF_TIMELINE:
+      c->wf_timeline = value != 0;
+      if (c->wf_mem) { (void)hipFree(c->wf_mem); c->wf_mem = nullptr; }  // (re-carved on the next queue-based pass, with or without the timeline)
+      break;
+    case HK_DEBUG_OPT_FLAT_WALK: c->flat_walk = value != 0; c->dynamic_dirty = true; break;
+    case HK_DEBUG_OPT_FLAT_ORDERINGS: c->flat_orderings = (int)std::max<int64_t>(0, std::min<int64_t>(8, value)); c->dynamic_dirty = true; break;
+    case HK_DEBUG_OPT_TRACE_UPDATE: c->trace_update = value != 0; break;
+    default: HK_REQUIRE(false, HK_E_INVALID, "unknown option %u", option);
+  }
   return HK_OK;
 }
 
-int hk_debug_prepasses_pipelined(hk_ctx* c, uint64_t* out) {
+int hk_debug_spatial_windowed_launches(hk_ctx* c, uint64_t* out) {
   HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
-  *out = c->prepasses_pipelined;
+  *out = c->spatial_windowed_launches;
   return HK_OK;
 }
 
@@ -935,12 +922,6 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     HK_HIP(hipMemset(c->depth_gradient_twin, 0, c->buf_bytes[HK_BUF_DEPTH_GRADIENT]));
     HK_HIP(hipMalloc(&c->dn_g_twin, nf * 16));
     HK_HIP(hipMemset(c->dn_g_twin, 0, nf * 16));
-    if (c->pre_stream) {  // primary-ray pipelining: the two G-buffer planes that had no previous-frame twin
-      HK_HIP(hipMalloc(&c->normal_twin, c->buf_bytes[HK_BUF_NORMAL]));
-      HK_HIP(hipMemset(c->normal_twin, 0, c->buf_bytes[HK_BUF_NORMAL]));
-      HK_HIP(hipMalloc(&c->instance_material_twin, c->buf_bytes[HK_BUF_INSTANCE_MATERIAL]));
-      HK_HIP(hipMemset(c->instance_material_twin, 0, c->buf_bytes[HK_BUF_INSTANCE_MATERIAL]));
-    }
   }
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
@@ -985,10 +966,6 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
       std::swap(c->buf[HK_BUF_DEPTH_GRADIENT], c->depth_gradient_twin);
       std::swap(c->dn_g, c->dn_g_twin);
     }
-    if (c->normal_twin) {  // (primary-ray pipelining: the next frame's prepass may write while this frame's passes still read)
-      std::swap(c->buf[HK_BUF_NORMAL], c->normal_twin);
-      std::swap(c->buf[HK_BUF_INSTANCE_MATERIAL], c->instance_material_twin);
-    }
     c->mapped_parity = f->number & 1u;
   }
   if (c->comm) { const int rc = comm_join(c, (int)(f->number & 1u)); if (rc) return rc; }  // a gather still reading the plane this frame writes
@@ -1027,7 +1004,6 @@ int hk_pass_run(hk_ctx* c, uint32_t pass, uint32_t arg, uint32_t row_begin, uint
   int rc = ready(c);
   if (rc) return rc;
   if ((rc = join_all(c))) return rc;
-  c->pre_chain_ok = false;  // (a host that dispatches passes itself: the next frame's primary rays take the serial order)
   const bool full_grid = pass == HK_PASS_PREPASS || pass == HK_PASS_FULL_SCREEN_ALBEDO;
   int rows = full_grid ? c->H : c->RH;
   if (pass == HK_PASS_TAA_JASMINE) { int w; buffer_dims(c, HK_BUF_TAA_OUTPUT, &w, &rows); }
@@ -1171,22 +1147,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     int f0, f1;
     full_rows_for(c, clampr(b0 - den - sp), clampr(b1 + den + sp), &f0, &f1);
     bool albedo_done = false;
-    // primary-ray pipelining (hk_context.hpp): this frame's prepass goes to its own stream, ordered only against what last touched the
-    // planes of ITS parity, when the previous frame came through here with the other parity over the same scene
-    const uint32_t parity = c->mapped_parity;
-    // HK_PREPASS_PIPELINE (read by hk_create) = "none" (DEFAULT), "lds" (scenes every kernel walks from its LDS copy), "all".  Built,
-    // bit-exact (test_primary_ray_pipelining_changes_no_bit) and MEASURED SLOWER everywhere (round 5, profiles/r05_prepass_pipeline_ab.txt):
-    // Cornell 1080p 0.969 -> 1.046 ms per frame (the three cross-stream waits per frame cost more than the 0.065 ms of primary rays
-    // they hide), configs 3 / 4 7.28 -> 7.39 / 16.52 -> 16.60 ms (the tails of the trace stages are not idle capacity: the long walks
-    // that end them crawl behind whatever else uses the memory system).  Kept behind the switch as the A/B.
-    const int pre_mode = c->pre_mode;  // (read from the environment by hk_create)
-    const bool in_lds = (size_t)c->scene.blob_f4 * 16 <= HK_LDS_SCENE_BYTES;
-    const bool wide_clean = !wide_allowed(c) || (!c->wide_tlas_dirty && !c->wide_blas_dirty && !c->wide_mesh_check);  // (else k_build_wide runs first, on the main stream)
-    const bool pre_pipelined = c->pre_stream && c->normal_twin && c->pre_chain_ok && c->pre_last_parity != parity && !(flags & HK_FRAME_EXTERNAL_GBUFFER) &&
-                               c->band_count == 1 && !(c->timing_mask & (1u << HK_PASS_PREPASS)) && wide_clean && !c->derived_dirty &&
-                               (pre_mode == 2 || (pre_mode == 1 && in_lds));
-    if (c->pre_stream) HK_HIP(hipEventRecord(c->frame_mark[parity], c->stream));  // everything enqueued before this frame (main; the side stream was joined)
-    if (c->timing_mask && !(pre_pipelined && !(flags & HK_FRAME_EXTERNAL_GBUFFER) && f1 > f0)) (void)hipEventRecord(c->frame_start, c->stream);
+    if (c->timing_mask) (void)hipEventRecord(c->frame_start, c->stream);
     if (!(flags & HK_FRAME_EXTERNAL_GBUFFER)) {
       if (f1 > f0) {  // the prepass also fills the albedo of every pixel it covers (a superset of the rows albedo needs)
         const DFrame fr = make_dframe(c);
@@ -1196,37 +1157,11 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
         const Jitter j = prepass_jitter(c);
         hkd::WideTrees wide{};
         if ((rc = wide_for_fused(c, &wide))) return rc;
-        hipStream_t main_stream = c->stream;
-        if (pre_pipelined) {
-          // the last writers / readers of this parity's planes: frame n - 2 (everything it had on the main and side streams is behind
-          // frame n - 1's mark) and its a-trous levels on the post stream
-          HK_HIP(hipStreamWaitEvent(c->pre_stream, c->frame_mark[parity ^ 1u], 0));
-          if (c->post_recorded[parity]) HK_HIP(hipStreamWaitEvent(c->pre_stream, c->post_done_parity[parity], 0));
-          c->stream = c->pre_stream;
-          c->prepasses_pipelined += 1;
-          if (c->timing_mask) (void)hipEventRecord(c->frame_start, c->pre_stream);  // (HkStats.last_frame_ms: first dispatch of the frame)
-        }
         {
           ScopedTimer timer(c, HK_PASS_PREPASS);
-          // HK_PREPASS_QUEUE (round 5 experiment): the primary rays through the trace kernel's queue - scenes beyond LDS with the wide walk,
-          // a G-buffer no larger than the queue scratch (upscale ratio 1), no counters
-          bool queued = false;
-          if (c->prepass_queue && !pre_pipelined && wide.tlas && !counters && use_wide(c) && (size_t)c->W * c->H <= (size_t)c->RW * c->RH) {  // (not beside the previous frame's indirect pass: they share the queue scratch)
-            if ((rc = ensure_wavefront(c)) || (rc = ensure_wide(c, true))) return rc;
-            wide.spill = c->wide_spill;
-            launch_prepass_queue(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, c->wf, wide, f0, f1,
-                                 c->compute_units);
-            queued = true;
-          }
-          if (!queued)
-            launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
+          launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
         }
-        c->stream = main_stream;
         HK_HIP(hipGetLastError());
-        if (pre_pipelined) {
-          HK_HIP(hipEventRecord(c->pre_done, c->pre_stream));
-          HK_HIP(hipStreamWaitEvent(c->stream, c->pre_done, 0));
-        }
         albedo_done = true;
       }
     } else if (f1 > f0) {  // host-rasterised G-buffer: only the derived planes are ours to fill
@@ -1252,8 +1187,6 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       HK_RUN(HK_PASS_DIRECT_EMISSIVE, 0, b0, b1);
       HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
     }
-    c->pre_chain_ok = !(flags & HK_FRAME_EXTERNAL_GBUFFER);  // (the next frame's primary rays may overlap what follows of this one)
-    c->pre_last_parity = parity;
   } else if (stage == HK_STAGE_SPATIAL) {            // light.rs:689-697
     if (parks_across_bands(c) && c->det_winner[0]) {
       // exchange A delivered the parked stores of the pixels up to 2 x history rows outside the band.  Per
@@ -1297,7 +1230,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       const uint32_t level_bits = (1u << HK_PASS_DENOISE_L0) | (1u << HK_PASS_DENOISE_L1) | (1u << HK_PASS_DENOISE_L2) | (1u << HK_PASS_DENOISE_L3);
       // (round 4: bands too - a 135-row band leaves most of the chip idle, the next frame's light passes fit beside its a-trous levels;
       // whoever reads the frame's output - exchange D, the gather, a host - joins the post stream first)
-      const bool pipelined = c->post_stream && !(c->timing_mask & level_bits) && c->albedo_twin;
+      const bool pipelined = c->post_stream && c->frame_pipeline && !(c->timing_mask & level_bits) && c->albedo_twin;
       hipStream_t main_stream = c->stream;
       if (pipelined) {
         HK_HIP(hipEventRecord(c->post_fork, c->stream));
@@ -1314,10 +1247,6 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
         HK_HIP(hipEventRecord(c->post_done, c->post_stream));
         c->post_pending = true;
         c->post_parity = c->mapped_parity;
-        if (c->pre_stream) {  // (what the prepass of the frame after next - the next writer of this parity's planes - waits for)
-          HK_HIP(hipEventRecord(c->post_done_parity[c->mapped_parity], c->post_stream));
-          c->post_recorded[c->mapped_parity] = true;
-        }
       }
       if (c->timing_mask) {
         (void)hipEventRecord(c->frame_stop, pipelined ? c->post_stream : c->stream);
@@ -1333,7 +1262,6 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     c->frames += 1;
   } else if (stage == HK_STAGE_ANTIALIAS) {            // post_process.rs:1236-1272
     if ((rc = join_post(c))) return rc;                // (reads the tone-mapped image)
-    c->pre_chain_ok = false;                           // (... and the PREVIOUS frame's G-buffer planes: the next prepass writes them only after this)
     // band: TAA on the band's output rows; its input row beyond the border comes from the extrapolation of the
     // neighbouring quad row, which needs the SMAA samples one more row out (footprints: hk_band_plan_for, exchange D)
     const bool smaa = st->upscale_kind == HK_UPSCALE_SMAA_TU4X;
@@ -1349,7 +1277,6 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     }
   } else if (stage == HK_STAGE_UPSCALE) {              // post_process.rs:1277-1308
     if ((rc = join_post(c))) return rc;
-    c->pre_chain_ok = false;
     if (st->upscale_kind == HK_UPSCALE_FSR1) {
       uint32_t w0, w1;
       band_rows_in(bounds, (uint32_t)c->RH, (uint32_t)c->H, c->band_index, c->band_count, &w0, &w1);
@@ -1429,7 +1356,6 @@ int hk_write_buffer(hk_ctx* c, uint32_t buffer, const void* src, size_t bytes) {
   { int rc_ = join_all(c); if (rc_) return rc_; }
   HK_HIP(hipStreamSynchronize(c->stream));
   HK_HIP(hipMemcpy(c->buf[buffer], src, bytes, hipMemcpyHostToDevice));
-  c->pre_chain_ok = false;
   if (buffer >= HK_BUF_RESERVOIR0 && buffer < HK_BUF_RESERVOIR0 + 10 && c->tile_meta[buffer - HK_BUF_RESERVOIR0]) {  // host-written reservoirs: tiles unknown
     const uint32_t k = buffer - HK_BUF_RESERVOIR0;
     HK_HIP(hipMemset(c->tile_meta[k], 0, (size_t)c->tiles_x * c->tiles_y * sizeof(TileMeta)));
@@ -1451,7 +1377,6 @@ int hk_set_stream(hk_ctx* c, void* s) {
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   c->stream = s ? (hipStream_t)s : c->own_stream;
-  c->pre_chain_ok = false;
   return HK_OK;
 }
 int hk_stream(hk_ctx* c, void** s) {

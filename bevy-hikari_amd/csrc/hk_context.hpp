@@ -120,30 +120,14 @@ struct hk_ctx {
   void* albedo_twin = nullptr;         // the planes of the OTHER frame parity (swapped with buf[HK_BUF_ALBEDO] ... in hk_frame_begin)
   void* depth_gradient_twin = nullptr;
   void* dn_g_twin = nullptr;
-  // Primary-ray pipelining (round 5): the primary rays of frame n + 1 depend on nothing frame n computes - only on the camera and
-  // the scene - so they run on a fourth stream next to frame n's light passes, whose trace stages end in tails that leave most of
-  // the chip idle.  Every plane the prepass writes is double-buffered by frame parity (position / velocity / depth were
-  // already: the reference's own previous-frame bindings; normal and instance_material get twins here); the prepass of frame n + 1
-  // waits for what last touched ITS parity's planes - the main stream's position at the start of frame n (frame_mark: everything of
-  // frame n - 1 on the main and side streams) and frame n - 1's a-trous levels (post_done_parity) - and the main stream waits for it
-  // (pre_done) before frame n + 1's first light pass.  Only a chain of hk_frame_stage(TEMPORAL) frames of alternating parity over an
-  // unchanged scene pipelines (pre_chain_ok); anything else - a scene update, hk_pass_run, host-written buffers, the anti-aliasing
-  // tail (which reads the previous frame's planes), a timed prepass, bands - takes the serial order.  HK_PREPASS_PIPELINE (read by
-  // hk_create) = none (default: measured slower everywhere, context.hip hk_frame_stage), lds, all.
-  hipStream_t pre_stream = nullptr;
-  int pre_mode = 0;
-  int spatial_window = -1;               // HK_SPATIAL_WINDOW=auto|on|off (read by hk_create): which form of k_spatial_reuse a launch takes (kernels.hip launch_spatial)
+  // test / measurement switches (hikari_hip_debug.h hk_debug_set_option; the library reads no environment variable)
+  int spatial_window = -1;               // which form of k_spatial_reuse a launch takes: -1 by its size, 0 plain, 1 windowed (kernels.hip launch_spatial)
   uint64_t spatial_windowed_launches = 0;
-  bool prepass_queue = false;           // HK_PREPASS_QUEUE=1 (read by hk_create): the primary rays of scenes beyond LDS through the trace kernel's queue (experiment)
-  hipEvent_t pre_done = nullptr;
-  hipEvent_t frame_mark[2] = {nullptr, nullptr};        // main stream, start of the TEMPORAL stage of the last frame of that parity
-  hipEvent_t post_done_parity[2] = {nullptr, nullptr};  // post stream, end of the a-trous levels of the last frame of that parity
-  bool post_recorded[2] = {false, false};
-  void* normal_twin = nullptr;
-  void* instance_material_twin = nullptr;
-  bool pre_chain_ok = false;           // the frame before this one went through hk_frame_stage(TEMPORAL) and nothing has broken the chain since
-  uint32_t pre_last_parity = 0;        // its parity
-  uint64_t prepasses_pipelined = 0;
+  bool frame_pipeline = true;            // the a-trous levels of frame n beside frame n + 1's light passes (post_stream)
+  bool wf_timeline = false;              // the instrumented twin of the trace kernels (tools/wf_timeline.py)
+  bool flat_walk = true;                 // the one-level tree for scenes under one transform (scene_layout.hip)
+  int flat_orderings = 0;                // ... with this many direction orderings (0: as many as fit 4 KB)
+  bool trace_update = false;             // timings of scene updates on stderr
 
   // host copies of the reference-layout scene (kept for the layout conversion)
   std::vector<HkVertex> vertices;

@@ -508,9 +508,6 @@ HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, floa
   lr.direction = world_to_local_direction(in0, ray.direction);
   lr.inv_direction = 1.0f / lr.direction;
   const float4* __restrict__ nodes = sc.flat + 2u * (REF_ORDER ? 0u : (ray_octant(lr.direction) & sc.flat_mask) * sc.flat_count);
-#ifdef HK_FLAT_FMA_SLAB
-  const f3 noi = F3(-lr.origin.x * lr.inv_direction.x, -lr.origin.y * lr.inv_direction.y, -lr.origin.z * lr.inv_direction.z);
-#endif
   const uint32_t count = sc.flat_count;
   uint32_t index = 0u, npend = 0u;
   uint32_t pend[HK_FLAT_CAP];  // queued candidates, oldest first: primitive index | instance << 16
@@ -545,13 +542,8 @@ HKD Hit traverse_flat(const DScene& sc, const Ray& ray, float max_distance, floa
       const float4 hi = nodes[2u * index + 1u];
       rc.nodes++;
       const uint32_t entry = f2u(lo.w), link = f2u(hi.w);
-#ifdef HK_FLAT_FMA_SLAB
-      const f3 t1 = F3(fmaf(lo.x, lr.inv_direction.x, noi.x), fmaf(lo.y, lr.inv_direction.y, noi.y), fmaf(lo.z, lr.inv_direction.z, noi.z));
-      const f3 t2 = F3(fmaf(hi.x, lr.inv_direction.x, noi.x), fmaf(hi.y, lr.inv_direction.y, noi.y), fmaf(hi.z, lr.inv_direction.z, noi.z));
-#else
       const f3 t1 = (xyz(lo) - lr.origin) * lr.inv_direction;  // intersects_aabb, light.wgsl:344-362
       const f3 t2 = (xyz(hi) - lr.origin) * lr.inv_direction;
-#endif
       float t_min = fmin_(t1.x, t2.x);
       float t_max = fmax_(t1.x, t2.x);
       t_min = fmax_(t_min, fmin_(t1.y, t2.y));
@@ -748,151 +740,6 @@ HKD Hit traverse_top(const DScene& sc, const Ray& ray, float max_distance, float
         }
       }
     }
-  }
-  return hit;
-}
-
-// Wave-coherent walk (round 4): traverse_top for rays that travel TOGETHER - the 64 primary rays of an 8x8 pixel tile, the
-// sun's shadow rays of a tile.  In traverse_top every lane follows its own node sequence: 64 unrelated addresses per load
-// instruction (tools/gather_probe.py: 142 ns per dependent step even when every line sits in the L1, the address unit serialises
-// the lanes) and a loop that runs as long as the slowest lane.  Here the WAVE walks the union of its lanes' node sequences in array
-// order with ONE wave-uniform cursor: the node is fetched once for everybody (a scalar load), every lane that would visit it in
-// its own walk tests it, and the cursor moves on to the smallest index any lane still wants.  A lane's own walk is a subsequence of
-// that - `next` is the node it would visit next; nodes the cursor passes before are ones it skips - so each lane performs exactly
-// the box and triangle tests of its own walk, in its own order, on its own operands: every result bit is traverse_top's when the
-// scene stores one ordering (HK_CTX_EXACT_TRAVERSAL), and with direction-threaded trees the wave takes the ordering of its first
-// live lane for everybody (any ordering visits the same candidates; only ties may fall differently - the product default's bar).
-// Why the cursor needs no reduction: the flattening is depth-first (a navigator's subtree starts right behind it, `entry` =
-// index + 1, and ends before `exit`), every lane that is not at the cursor waits at the exit of a node whose subtree contains
-// the cursor, i.e. at or beyond this node's exit - so the next cursor is `entry` if any lane descends and `exit` otherwise.  Only a
-// lane LEAVING the walk early (an any-hit ray that found its occluder) can make the others' minimum jump: then it is recomputed.
-// All 64 lanes call this together; `alive` = the lane has a ray.
-HKD uint32_t wave_min_u32(uint32_t v) {
-  for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off));
-  return v;
-}
-HKD Hit traverse_top_wave(const DScene& sc, const Ray& ray, float max_distance, float early_distance, uint32_t exclude_instance, bool alive, RayCounters& rc) {
-  Hit hit;
-  hit.uv = F2(0.0f, 0.0f);
-  hit.distance = max_distance;
-  hit.instance_index = HK_U32_MAX;
-  hit.primitive_index = HK_U32_MAX;
-  const unsigned long long live = __ballot(alive);
-  if (live == 0ull) return hit;
-  if (alive) rc.tlas++;
-  const int first = __builtin_ctzll(live);
-  const uint32_t tlas_base = (uint32_t)__builtin_amdgcn_readlane((int)ray_octant(ray.direction), first) * sc.tlas_stride;
-  const uint32_t DONE = HK_U32_MAX;
-  uint32_t next = alive ? 0u : DONE;  // the TLAS node this lane visits next in its OWN walk
-  uint32_t index = 0u;                // the wave's cursor
-  const uint32_t limit = sc.tlas_count;
-  while (index < limit) {
-    const float4* __restrict__ nd = sc.nodes + 2u * (tlas_base + index);
-    const float4 lo = nd[0];
-    const float4 hi = nd[1];
-    const uint32_t entry = f2u(lo.w), exit_ = f2u(hi.w);
-    const bool active = next == index;
-    if (active) rc.nodes++;
-    const f3 t1 = (xyz(lo) - ray.origin) * ray.inv_direction;  // intersects_aabb, light.wgsl:344-362
-    const f3 t2 = (xyz(hi) - ray.origin) * ray.inv_direction;
-    float t_min = fmin_(t1.x, t2.x);
-    float t_max = fmax_(t1.x, t2.x);
-    t_min = fmax_(t_min, fmin_(t1.y, t2.y));
-    t_max = fmin_(t_max, fmax_(t1.y, t2.y));
-    t_min = fmax_(t_min, fmin_(t1.z, t2.z));
-    t_max = fmin_(t_max, fmax_(t1.z, t2.z));
-    const float t_box = (t_max >= t_min && t_max >= 0.0f) ? t_min : HK_F32_MAX;
-    const bool box_hit = active && t_box < hit.distance;
-    if (entry < HK_LEAF) {  // a navigator: descend on a hit, skip its subtree otherwise
-      if (active) next = box_hit ? entry : exit_;
-      index = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__ballot(box_hit) != 0ull ? entry : exit_));
-      continue;
-    }
-    // a leaf of the instance tree: the lanes whose ray hits its box walk the instance's mesh tree together
-    if (active) next = exit_;
-    const uint32_t instance_index = entry - HK_LEAF;
-    const bool enter = box_hit && instance_index != exclude_instance;
-    bool left = false;  // some lane left the whole walk inside this instance (any-hit early out)
-    if (__ballot(enter) != 0ull) {
-      const DInstance& in = sc.instances[instance_index];
-      f3 co = ray.origin, ld = ray.direction, cinv = ray.inv_direction;
-      if (enter) {
-        rc.entries++;
-        co = world_to_local_position(in, ray.origin);
-        ld = world_to_local_direction(in, ray.direction);
-        cinv = 1.0f / ld;
-      }
-      const int bfirst = __builtin_ctzll(__ballot(enter));
-      const uint32_t bbase = sc.blas_base + (uint32_t)__builtin_amdgcn_readlane((int)ray_octant(ld), bfirst) * sc.blas_stride + in.node_offset;
-      const uint32_t blimit = in.node_count, prim_base = in.primitive;
-      uint32_t bnext = enter ? 0u : DONE, bindex = 0u;
-      bool intersected = false;
-      while (bindex < blimit) {
-        const float4* __restrict__ bd = sc.nodes + 2u * (bbase + bindex);
-        const float4 blo = bd[0];
-        const float4 bhi = bd[1];
-        const uint32_t bentry = f2u(blo.w), bexit = f2u(bhi.w);
-        const bool bactive = bnext == bindex;
-        if (bactive) rc.nodes++;
-        const f3 u1 = (xyz(blo) - co) * cinv;
-        const f3 u2 = (xyz(bhi) - co) * cinv;
-        float b_min = fmin_(u1.x, u2.x);
-        float b_max = fmax_(u1.x, u2.x);
-        b_min = fmax_(b_min, fmin_(u1.y, u2.y));
-        b_max = fmin_(b_max, fmax_(u1.y, u2.y));
-        b_min = fmax_(b_min, fmin_(u1.z, u2.z));
-        b_max = fmin_(b_max, fmax_(u1.z, u2.z));
-        const float b_box = (b_max >= b_min && b_max >= 0.0f) ? b_min : HK_F32_MAX;
-        const bool bhit = bactive && b_box < hit.distance;
-        if (bentry < HK_LEAF) {
-          if (bactive) bnext = bhit ? bentry : bexit;
-          bindex = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__ballot(bhit) != 0ull ? bentry : bexit));
-          continue;
-        }
-        if (bactive) bnext = bexit;
-        bool gone = false;
-        if (__ballot(bhit) != 0ull) {
-          const uint32_t primitive_index = prim_base + bentry - HK_LEAF;
-          const float4 q0 = sc.tri_v0[primitive_index], q1 = sc.tri_v1[primitive_index], q2 = sc.tri_v2[primitive_index];
-          if (bhit) {
-            rc.tris++;
-            Ray lr;
-            lr.origin = co;
-            lr.direction = ld;
-            lr.inv_direction = cinv;
-            f2 uv;
-            const float d = intersects_triangle(lr, xyz(q0), xyz(q1), xyz(q2), &uv);
-            if (d < hit.distance) {
-              hit.uv = uv;
-              hit.distance = d;
-              hit.primitive_index = primitive_index;
-              intersected = true;
-              if (d < early_distance) {  // light.wgsl:421-423 then 466-469: this lane's walk is over
-                hit.instance_index = instance_index;
-                intersected = false;
-                bnext = DONE;
-                next = DONE;
-                gone = true;
-              }
-            }
-          }
-        }
-        if (__ballot(gone) != 0ull) {
-          left = true;
-          bindex = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_min_u32(bnext));
-        } else {
-          bindex = (uint32_t)__builtin_amdgcn_readfirstlane((int)bexit);
-        }
-      }
-      if (intersected) {  // traverse_bottom returned, light.wgsl:465-470
-        hit.instance_index = instance_index;
-        if (hit.distance < early_distance) {
-          next = DONE;
-          left = true;
-        }
-      }
-    }
-    index = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__ballot(left) != 0ull ? wave_min_u32(next) : exit_));
   }
   return hit;
 }

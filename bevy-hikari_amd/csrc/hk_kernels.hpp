@@ -276,9 +276,6 @@ static inline dim3 grid_for(int width, int rows) {
 void launch_prepass(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const float* inverse_view_proj, const float* view_proj,
                     const float* prev_view_proj, const float4* prev_models, float jitter_x, float jitter_y, const hkd::GBuffer& g, int y0, int y1,
                     unsigned long long* counters, const hkd::WideTrees* wide = nullptr);
-void launch_prepass_queue(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const float* inverse_view_proj, const float* view_proj, const float* prev_view_proj,
-                          const float4* prev_models, float jitter_x, float jitter_y, const hkd::GBuffer& g, const hkd::WfBuffers& w, const hkd::WideTrees& wide, int y0,
-                          int y1, int compute_units);  // (kernels_wavefront.hip: the primary rays through the trace kernel's queue - HK_PREPASS_QUEUE)
 void launch_albedo(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, void* albedo, int y0, int y1);
 void launch_direct(hipStream_t st, bool emissive_lit, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                    int y0, int y1, unsigned long long* counters);

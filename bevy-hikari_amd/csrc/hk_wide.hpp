@@ -281,72 +281,10 @@ __device__ __forceinline__ void wide_enter(WideWalk& k, const DScene& sc, S& st,
   wide_enter_apply(k, st, instance_index, in.im0, in.im1, in.im2, in.im3, in.primitive, in.node_offset, in.node_count);
 }
 
-// ONE MEMORY ROUND TRIP PER TURN (round 5 EXPERIMENT - measured slower, off: HK_WIDE_OVERLAPPED_TURNS / HK_WF_DRY_OVERLAPPED below and
-// in kernels_wavefront.hip).  A step of a walk is a dependent fetch followed by arithmetic: a record (8 x 16 B), a
-// triangle's vertices (3 x 16 B) or an instance's record (6 x 16 B of it).  Served phase after phase - the record fetches of the NODE
-// lanes, then the vertex fetches of the TRI lanes, then the instance fetches of the ENTRY lanes - a turn of the wave costs three
-// round trips to the memory system, and where the walks are latency-bound (the tails of the trace stages: 43 % / 77 % of their time
-// on configs 4 / 3; the fused primary rays) that is what a step costs.  Here every lane first decides what it fetches this turn
-// (a NODE lane with nothing to visit pops its stack - which may park it at a leaf it can serve right away), then ALL fetches are
-// issued from one block into the same eight landing registers, then each lane does its arithmetic.  A lane's own sequence of
-// records, triangle tests and instance entries - and with it every bit of its result - is that of wide_node / wide_triangle /
-// wide_enter called one after the other.
-struct WideFetch {
-  const char* p;   // first piece
-  uint32_t n;      // pieces to fetch (0: nothing this turn)
-  uint32_t kind;   // PH_NODE / PH_TRI / PH_ENTRY
-};
-template <class S, bool COUNT>
-__device__ __forceinline__ void wide_step(WideWalk& k, const DScene& sc, const WideTrees& wt, S& st, uint32_t& phase, uint32_t& pending, RayCounters* rc) {
-  if (phase == PH_NODE && k.cur == WIDE_NONE) phase = wide_pop_next(k, st, pending);
-  WideFetch f{nullptr, 0u, PH_IDLE};
-  uint32_t primitive_index = 0u;
-  if (phase == PH_NODE && k.cur != WIDE_NONE) {
-    f = WideFetch{(const char*)wide_record(k, wt), 8u, PH_NODE};
-    if (COUNT) {
-      rc->nodes++;
-      rc->top_nodes += k.in_blas ? 0u : 1u;
-    }
-  } else if (phase == PH_TRI) {
-    primitive_index = k.prim_base + pending;
-    f = WideFetch{(const char*)(sc.tri_v0 + primitive_index), 3u, PH_TRI};
-    if (COUNT) rc->tris++;
-  } else if (phase == PH_ENTRY) {
-    f = WideFetch{(const char*)(sc.instances + pending), 6u, PH_ENTRY};
-    if (COUNT) rc->entries++;
-  }
-  // where piece i lies behind f.p: a record's pieces are adjacent; a triangle's vertices sit in three planes; of an instance's record
-  // the inverse model (4 x 16 B at 0) and the two 16-B rows of indices behind its eleven matrix columns
-  const uint32_t tri1 = (uint32_t)((const char*)sc.tri_v1 - (const char*)sc.tri_v0), tri2 = (uint32_t)((const char*)sc.tri_v2 - (const char*)sc.tri_v0);
-  float4 b[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t off_tri = i == 1 ? tri1 : (i == 2 ? tri2 : 0u);
-    const uint32_t off_entry = i < 4 ? 16u * (uint32_t)i : (i == 4 ? (uint32_t)offsetof(DInstance, material) : (uint32_t)offsetof(DInstance, node_count));
-    const uint32_t off = f.kind == PH_NODE ? 16u * (uint32_t)i : (f.kind == PH_TRI ? off_tri : off_entry);
-    b[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if ((uint32_t)i < f.n) b[i] = *(const float4*)(f.p + off);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if (f.kind == PH_NODE) {
-    phase = wide_node_test(k, b, st, pending);
-  } else if (f.kind == PH_TRI) {
-    phase = wide_triangle_test(k, wt, primitive_index, xyz(b[0]), xyz(b[1]), xyz(b[2]));
-  } else if (f.kind == PH_ENTRY) {
-    wide_enter_apply(k, st, pending, b[0], b[1], b[2], b[3], f2u(b[4].z), f2u(b[4].w), f2u(b[5].x));
-    phase = PH_NODE;
-  }
-}
-
 // The whole walk for one ray per lane, in lock step (the fused kernels): every turn each live lane visits one record or pops; the
 // triangle tests and instance entries of the lanes that reached a leaf follow in the same turn.
-// HK_WIDE_OVERLAPPED_TURNS = 1: every turn is ONE wide_step.  Built, bit-exact, measured SLOWER (round 5, profiles/r05_overlapped_turns_ab.txt):
-// the primary rays of configs 3 / 4 0.91 -> 1.03 / 2.79 -> 2.94 ms - they are bound by the bytes their record fetches move from the
-// L1 / L2 (the 128-B gather roof of bench.py: 16 B per clock and CU whatever the access shape, tools/coop_probe.py), not by the
-// latency of a turn, and the predicated fetch block costs more instructions than the three it replaces.
-#ifndef HK_WIDE_OVERLAPPED_TURNS
-#define HK_WIDE_OVERLAPPED_TURNS 0
-#endif
+// (one memory round trip per turn - all three fetch kinds issued from one block - was built, bit-exact and slower:
+// profiles/r05_overlapped_turns_ab.txt, profiles/r06_removed_wide_overlapped_turns.patch)
 // (COUNT: the kernel's counting instantiation - the product's carries no counter at all; left to the optimiser, the counters of a
 // RayCounters whose address is taken stayed in scratch memory, a load / add / store per record in the walk's loop)
 template <bool COUNT, class S>
@@ -356,9 +294,6 @@ __device__ __forceinline__ Hit traverse_top_wide(const DScene& sc, const WideTre
   WideWalk k;
   wide_begin(k, wt, ray.origin, ray.direction, max_distance, early_distance, exclude_instance);
   uint32_t phase = PH_NODE, pending = 0u;
-#if HK_WIDE_OVERLAPPED_TURNS
-  while (phase != PH_IDLE) wide_step<S, COUNT>(k, sc, wt, st, phase, pending, &rc);
-#else
   while (phase != PH_IDLE) {
     if (phase == PH_NODE) phase = wide_node<S, COUNT>(k, wt, st, pending, &rc);  // (rc.nodes: records fetched)
     if (phase == PH_TRI) {
@@ -370,7 +305,6 @@ __device__ __forceinline__ Hit traverse_top_wide(const DScene& sc, const WideTre
       phase = PH_NODE;
     }
   }
-#endif
   return k.hit;
 }
 

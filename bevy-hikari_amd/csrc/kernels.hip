@@ -51,14 +51,6 @@ __global__ __launch_bounds__(256) void k_resolve_scatter(LightTargets t, int p0,
 }
 
 // ------------------------------------------------------------------ prepass by primary rays (PrepassParams, primary_ray, prepass_store: hk_prepass.hpp)
-// Round 4 experiment, OFF: the wave-coherent walk of hk_device.hpp (traverse_top_wave) for the primary rays of scenes in global
-// memory.  Bit-exact in the reference order, inside the default mode's bars with threaded trees (the parity tests of configs 3 / 4
-// pass with it), scalar node loads as intended - and config 3's prepass goes 1.04 -> 0.99 ms, config 4's (4K, distant small
-// instances: the UNION of 64 neighbouring rays' node sequences is several times one ray's) 4.1 -> 6.7 ms
-// (profiles/r04_wave_walk_ab.txt).  Kept behind the switch for coherent rays over coarser geometry.
-#ifndef HK_PREPASS_WAVE_WALK
-#define HK_PREPASS_WAVE_WALK 0
-#endif
 // waves per SIMD the wide-walk prepass is compiled for.  Its walk is a chain of dependent fetches: one more resident wave hides more
 // of them than the 8 VGPRs it spills cost - 5 waves (95 VGPRs; 5 x 28 KB of LDS stacks fit the CU) against the compiler's own 103
 // VGPRs / 4 waves: primary rays of configs 3 / 4 0.905 -> 0.858 / 2.748 -> 2.544 ms (profiles/r05_sweep_ab.txt)
@@ -72,23 +64,11 @@ __global__ __launch_bounds__(256, (LDS == 4 ? HK_PREPASS_WIDE_WAVES : 1)) void k
   const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
   RayCounters rc{0, 0};
   uint32_t primary = 0;
-  // scenes walked from global memory: the 64 primary rays of the wave's 8x8 tile travel together - one wave-uniform cursor, the
-  // node fetched once for everybody (hk_device.hpp traverse_top_wave); scenes in LDS keep one walk per lane
-  constexpr bool WAVE_WALK = LDS == 0 && HK_PREPASS_WAVE_WALK;
-  Ray wray;
-  wray.origin = wray.direction = wray.inv_direction = F3(0, 0, 0);
-  Hit whit;
-  if (WAVE_WALK) {
-    if (px.valid) wray = primary_ray(fr, pp, (float)px.x, (float)px.y);
-    whit = traverse_top_wave(sc, wray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, px.valid, rc);
-  }
   __shared__ uint32_t wide_lds[LDS == 4 ? HK_WIDE_LDS_STACK * 256u : 1u];
   if (px.valid) {
-    Ray ray = WAVE_WALK ? wray : primary_ray(fr, pp, (float)px.x, (float)px.y);
+    Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
     Hit hit;
-    if (WAVE_WALK) {
-      hit = whit;
-    } else if (LDS == 4) {  // scenes in global memory, product default: the wide walk (hk_wide.hpp)
+    if (LDS == 4) {  // scenes in global memory, product default: the wide walk (hk_wide.hpp)
       WideStackPrivate<HK_WIDE_LDS_STACK, 96u> stack;
       stack.lds = wide_lds;
       stack.lost = pp.wide.lost;

@@ -539,14 +539,6 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 #ifndef HK_WF_DRY_ALL_PHASES
 #define HK_WF_DRY_ALL_PHASES 1
 #endif
-// HK_WF_DRY_OVERLAPPED = 1: a dry wave's turn is ONE memory round trip (hk_wide.hpp wide_step) instead of the three phases one after the
-// other.  Built, bit-exact (the suite ran with it), measured SLOWER - the indirect pass of configs 3 / 4 3.67 -> 4.50 / 6.47 -> 7.91 ms
-// (profiles/r05_overlapped_turns_ab.txt): after the queue runs dry a wave is not a few lanes waiting for memory - work sharing keeps most
-// of its lanes walking small pieces, and a turn that serves one step per lane pays the turn's bookkeeping (merge, ballots, hand-over)
-// once per step instead of once per two records.
-#ifndef HK_WF_DRY_OVERLAPPED
-#define HK_WF_DRY_OVERLAPPED 0
-#endif
 // The wide trace kernel hands its queue out in a permuted order (round 5): what ends a stage is the waves whose blocks of 64 rays
 // happened to be expensive, and a block of consecutive entries is one small region of the image.  Runs of 2^HK_WF_QUEUE_RUN
 // consecutive entries stay together (neighbouring pixels: coherent rays).  Config 3 (4 stages of 0.2-1.4 M rays: four blocks per
@@ -841,28 +833,6 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     // is dry every parked lane is served every turn: what is left are the walks that end the stage, and (HK_WF_WIDE_SHARE) the
     // lanes that help them - a lane that waits a turn for its phase makes the stage a turn longer.
     const bool all_phases = HK_WF_DRY_ALL_PHASES && dry;
-#if HK_WF_DRY_OVERLAPPED
-    if (all_phases) {
-      // the dry wave's turn: ONE round trip to the memory system - every working lane takes one step of its walk, the fetches of
-      // the records, the triangles and the instances issued together (hk_wide.hpp wide_step)
-      if (phase == PH_NODE || phase == PH_TRI || phase == PH_ENTRY) {
-#if HK_WF_WIDE_SHARE
-        k.limit = u2f(share_best[(threadIdx.x & ~63u) + root]);  // (what the other pieces of the ray have found meanwhile)
-#endif
-        const float before = k.hit.distance;
-        if (phase == PH_NODE) {
-          if (TL) tl_steps += 1u;
-          steps += 1u;
-        }
-        wide_step<WideStackSpill, COUNT>(k, sc, wt, stack, phase, pending, &cn);
-#if HK_WF_WIDE_SHARE
-        if (k.hit.distance < before) atomicMin(&share_best[(threadIdx.x & ~63u) + root], f2u(k.hit.distance));  // (distances are >= 0: their bits order like they do)
-#endif
-        if (phase == PH_IDLE) finish();
-      }
-      continue;
-    }
-#endif
     if (all_phases ? n_node != 0u : (n_node >= n_tri && n_node >= n_entry && n_node != 0u)) {
 #if HK_WF_WIDE_SHARE
       if (dry) k.limit = u2f(share_best[(threadIdx.x & ~63u) + root]);  // (what the other pieces of the ray have found meanwhile)
@@ -929,36 +899,6 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     __syncthreads();
     if (threadIdx.x < 16u && tl_hist[threadIdx.x]) atomicAdd(&tl[8u + threadIdx.x], (unsigned long long)tl_hist[threadIdx.x]);
   }
-}
-
-// ------------------------------------------------------------------ primary rays through the queue (round 5 experiment, HK_PREPASS_QUEUE)
-// "the primary rays of scenes beyond LDS keep one pixel per lane to the end of its walk - emit them into the trace
-// kernel's queue and finish the pixel in a tail kernel".  k_primary_emit writes every pixel's ray into the closest-hit ray planes
-// (slot = pixel) and the pixel into the stage-0 queue, in tile order; k_wf_trace_wide walks them with lane refill, work sharing and the
-// permuted queue; k_prepass_finish forms the ray again (the same operations: the same bits) and writes the G-buffer record from the hit.
-__global__ __launch_bounds__(256) void k_primary_emit(DFrame fr, PrepassParams pp, WfBuffers w, int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
-  __shared__ uint32_t push_lds[6];
-  const uint32_t q = block_push(&w.ctr[WF_ALIVE], px.valid, push_lds);
-  if (!px.valid) return;
-  const uint32_t slot = (uint32_t)(px.x + fr.dw * px.y);
-  const Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
-  w.cr0[slot] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, 0.0f);
-  w.cr1[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, 0.0f);
-  w.alive[0][q] = slot;
-}
-__global__ __launch_bounds__(256) void k_prepass_finish(DScene sc, DFrame fr, PrepassParams pp, GBuffer g, WfBuffers w, int row_begin, int row_end) {
-  const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
-  if (!px.valid) return;
-  const uint32_t slot = (uint32_t)(px.x + fr.dw * px.y);
-  const Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
-  const float4 h0 = w.ch0[slot];
-  Hit hit;
-  hit.distance = h0.x;
-  hit.uv = F2(h0.y, h0.z);
-  hit.primitive_index = f2u(h0.w);
-  hit.instance_index = w.ch1[slot];
-  prepass_store(sc, fr, pp, g, px.x, px.y, ray, hit);
 }
 
 // ------------------------------------------------------------------ shade: bounce n of every live path
@@ -1122,20 +1062,6 @@ void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, floa
   if (count) hipLaunchKernelGGL(k_build_wide, dim3((count + 255u) / 256u), dim3(256), 0, st, nodes, count, wide, rank);
 }
 
-// the prepass of rows [y0, y1) with its primary rays walked by the trace kernel (w: the queue-based schedule's scratch, free between
-// frames' indirect passes; wide: the records with their spill area)
-void launch_prepass_queue(hipStream_t st, const DScene& sc, const DFrame& fr, const float* inverse_view_proj, const float* view_proj, const float* prev_view_proj,
-                          const float4* prev_models, float jitter_x, float jitter_y, const GBuffer& g, const WfBuffers& w, const WideTrees& wide, int y0, int y1,
-                          int compute_units) {
-  if (y1 <= y0) return;
-  const PrepassParams pp = make_prepass_params(inverse_view_proj, view_proj, prev_view_proj, prev_models, jitter_x, jitter_y, &wide);
-  (void)hipMemsetAsync(w.ctr, 0, 192 * sizeof(uint32_t), st);
-  const dim3 grid = grid_for(fr.dw, y1 - y0);
-  hipLaunchKernelGGL(k_primary_emit, grid, dim3(256), 0, st, fr, pp, w, y0, y1);
-  hipLaunchKernelGGL((k_wf_trace_wide<false, false>), dim3((unsigned)(compute_units * HK_WF_WIDE_WAVES)), dim3(256), 0, st, sc, w, wide, 0u);
-  hipLaunchKernelGGL(k_prepass_finish, grid, dim3(256), 0, st, sc, fr, pp, g, w, y0, y1);
-}
-
 void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,
                                int y1, int compute_units, hipEvent_t start, hipEvent_t stop, const WideTrees* wide, hipEvent_t* trace_events) {
   if (y1 <= y0) return;
@@ -1146,9 +1072,8 @@ void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& f
   const dim3 persistent((unsigned)(compute_units * 8));  // 8 workgroups of 4 waves per CU: what 64 VGPRs leave resident
   // rays in flight = lanes of the trace launch.  Little's law: with R node steps per second served by the memory system, a step of
   // one ray takes (rays in flight) / R - every ray beyond what saturates R only makes all of them slower, and the launch ends with
-  // its longest walk (tools/wf_timeline.py; HK_WF_TRACE_WG_PER_CU for the A/B)
-  static const int trace_wg_per_cu = getenv("HK_WF_TRACE_WG_PER_CU") ? std::max(1, atoi(getenv("HK_WF_TRACE_WG_PER_CU"))) : HK_WF_TRACE_WG_PER_CU;
-  const dim3 tracers((unsigned)(compute_units * trace_wg_per_cu));
+  // its longest walk (tools/wf_timeline.py; -DHK_WF_TRACE_WG_PER_CU=n for the A/B)
+  const dim3 tracers((unsigned)(compute_units * HK_WF_TRACE_WG_PER_CU));
   const dim3 wide_tracers((unsigned)(compute_units * HK_WF_WIDE_WAVES));
   const uint32_t bounces = fr.indirect_bounces;
   const bool use_wide = wide && wide->tlas && !lds;

@@ -426,7 +426,7 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_byt
   // transform, outside the bit-exact verification mode; as many direction orderings (8, 4, 2, 1) as fit
   o.flat = 0;
   o.flat_count = o.flat_orderings = 0;
-  if (!(c->flags & HK_CTX_EXACT_TRAVERSAL) && !c->threaded && !c->instances.empty() && c->instances.size() <= 0xFFFFu && !getenv("HK_FLAT_DISABLE")) {
+  if (!(c->flags & HK_CTX_EXACT_TRAVERSAL) && !c->threaded && !c->instances.empty() && c->instances.size() <= 0xFFFFu && c->flat_walk) {
     bool shared = true;
     for (const HkInstance& in : c->instances)
       if (memcmp(in.inverse_transpose_model, c->instances[0].inverse_transpose_model, 64) != 0) shared = false;
@@ -434,7 +434,7 @@ int build_dynamic_region(hk_ctx* c, Blob& blob, DynOffsets& o, size_t static_byt
     // the LDS a workgroup holds bounds the workgroups per CU; measured on the Cornell box (71 nodes, tools/ab_flat.sh): 1 / 2 / 4 / 8
     // orderings walk equally fast (0.27 ms k_indirect) and the direct-light kernels lose 13 % with the 18 KB of eight
     uint32_t want = 8, budget = 4096;
-    if (const char* e = getenv("HK_FLAT_ORDERINGS")) { want = (uint32_t)std::max(1, std::min(8, atoi(e))); budget = HK_LDS_SCENE_BYTES; }
+    if (c->flat_orderings > 0) { want = (uint32_t)c->flat_orderings; budget = HK_LDS_SCENE_BYTES; }  // (hk_debug_set_option: the A/B of the orderings)
     while (want & (want - 1)) want &= want - 1;  // a power of two
     std::vector<float4> flat;
     uint32_t count = 0;
@@ -513,7 +513,6 @@ void point_scene_at_slot(hk_ctx* c) {
 
 int finalize_scene(hk_ctx* c) {
   if (!c->mesh_dirty && !c->dynamic_dirty && !c->textures_dirty) return HK_OK;
-  c->pre_chain_ok = false;  // (the scene changes in the main stream's order: the next frame's primary rays follow it there)
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
   const size_t n_nodes = c->asset_nodes.size();
   bool need_static = c->mesh_dirty || !c->scene_mem || c->node_prim_offset.size() != n_nodes;
@@ -553,7 +552,7 @@ int finalize_scene(hk_ctx* c) {
   DynOffsets o{};
   const double tb0_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   if ((rc = build_dynamic_region(c, dyn, o, need_static ? st.bytes.size() : c->static_bytes))) return rc;
-  if (getenv("HK_TRACE_UPDATE")) fprintf(stderr, "  build_dynamic_region %.2f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tb0_, dyn.bytes.size());
+  if (c->trace_update) fprintf(stderr, "  build_dynamic_region %.2f ms (%zu bytes)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tb0_, dyn.bytes.size());
   c->dyn_off = o;
   c->rf_ready = false;
   c->rf_last_moved.clear();

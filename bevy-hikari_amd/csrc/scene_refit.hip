@@ -17,7 +17,7 @@ int hk_update_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t tree_mode
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
   HK_REQUIRE(tree_mode == HK_TREE_SAH || tree_mode == HK_TREE_LBVH, HK_E_INVALID, "unknown tree build mode %u", tree_mode);
   int rc;
-  const bool trace = getenv("HK_TRACE_UPDATE") != nullptr;
+  const bool trace = c->trace_update;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   if ((rc = hk_scene_builder_finish_instances(b))) return rc;
@@ -177,7 +177,6 @@ int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
                                  1u, 1u) == 0, HK_E_HIP, "device build of the light tree failed: %s", hipGetErrorString(hipGetLastError()));
   c->mirrors_stale = true;
   c->wide_tlas_dirty = true;
-  c->pre_chain_ok = false;
   c->device_tree_builds += 1;
   return HK_OK;
 }
@@ -325,7 +324,6 @@ static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool 
   c->rf_last_moved = moved;
   c->mirrors_stale = true;
   c->wide_tlas_dirty = true;
-  c->pre_chain_ok = false;
   c->device_refits += 1;
   if (commit) builder_commit_transforms(b);
   return HK_OK;

@@ -696,14 +696,12 @@ class Engine:
         self.api.call("traversal_mode", self.ctx, C.byref(v), None)
         return bool(v.value & 0x100)
 
-    def prepasses_pipelined(self):
-        """Frames whose primary rays ran on the context's fourth stream next to the previous frame's light passes (hikari_hip_debug.h)."""
-        n = C.c_uint64()
-        self.api.call("debug_prepasses_pipelined", self.ctx, C.byref(n))
-        return int(n.value)
+    def set_debug_option(self, option, value):
+        """hikari_hip_debug.h hk_debug_set_option (F.DEBUG_OPT_*): the switches of tests and A/B tools - the library reads no environment variable."""
+        self.api.call("debug_set_option", self.ctx, option, int(value))
 
     def spatial_windowed_launches(self):
-        """spatial_reuse launches that took the windowed form of the kernel (hikari_hip_debug.h; HK_SPATIAL_WINDOW=auto|on|off at creation)."""
+        """spatial_reuse launches that took the windowed form of the kernel (hikari_hip_debug.h; F.DEBUG_OPT_SPATIAL_WINDOW)."""
         n = C.c_uint64()
         self.api.call("debug_spatial_windowed_launches", self.ctx, C.byref(n))
         return int(n.value)

@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define HK_ABI_VERSION 7
+#define HK_ABI_VERSION 8
 
 /* ------------------------------------------------------------------ error codes */
 #define HK_OK 0
@@ -370,6 +370,9 @@ typedef struct hk_ctx hk_ctx;
 /* ------------------------------------------------------------------ lifetime */
 uint32_t hk_abi_version(void);
 const char* hk_last_error(void); /* thread-local description of the last failure */
+/* What this binary was built from (tools/build_lib.py): "sources <sha256[:16] of csrc/ + include/> | <hipcc, its version, every flag> |
+ * built <UTC time>".  A host (and __graft_entry__.smoke()) can tell a stale library from the tree it sits in. */
+const char* hk_build_info(void);
 int hk_device_count(int* count);
 /* Creates a context on HIP device `device_id`; flags: bit0 = count rays (HK_CTX_COUNT_RAYS),
  * bit1 = time every dispatch with HIP events (HK_CTX_TIME_PASSES), bit2 = take every (k + 0.5) / size through

@@ -42,7 +42,7 @@ int hk_debug_math(hk_ctx* ctx, uint32_t op, const float* x, const float* y, floa
 int hk_measure_gather(hk_ctx* ctx, size_t footprint_bytes, uint32_t bytes_per_step, uint32_t waves_per_simd, uint32_t steps,
                       uint32_t workgroups /* 0 = CUs x waves_per_simd (the whole chip); else that many 256-thread workgroups */, double* gloads_s, double* gbytes_s);
 
-/* Profiling hook (tools/wf_timeline.py): with HK_WF_TIMELINE=1 in the environment the trace stages of the queue-based indirect pass
+/* Profiling hook (tools/wf_timeline.py): with HK_DEBUG_OPT_WF_TIMELINE set the trace stages of the queue-based indirect pass
  * run an instrumented twin that records, per stage, when the ray queue ran dry, when the last persistent wave left and how long
  * the rays' walks were (hk_kernels.hpp WfBuffers::timeline: 64 stages x 32 u64, wall_clock64 ticks of 10 ns). */
 int hk_debug_read_wf_timeline(hk_ctx* ctx, unsigned long long* out, uint32_t n /* 64 * 32 */);
@@ -57,14 +57,22 @@ int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer
                                             frame (hk_frame_render with HK_FRAME_GATHER) - complete before the frame of the same parity begins or
                                             anybody reads a buffer */);
 
-/* Test hook (round 5): how many frames of this context ran their primary rays on the pipelined path - on the context's fourth
- * stream, next to the previous frame's light passes (hk_frame_stage(TEMPORAL); DESIGN 4 "Primary-ray pipelining") - since hk_create. */
-int hk_debug_prepasses_pipelined(hk_ctx* ctx, uint64_t* out);
-
 /* Test hook (round 5): how many spatial_reuse launches of this context took the WINDOWED form of the kernel (the depths its taps reach
- * and the lists of surviving taps in LDS: kernels.hip) since hk_create.  Which form a launch takes: by its size, or HK_SPATIAL_WINDOW =
- * auto | on | off in the environment of hk_create. */
+ * and the lists of surviving taps in LDS: kernels.hip) since hk_create.  Which form a launch takes: by its size, or what
+ * hk_debug_set_option(HK_DEBUG_OPT_SPATIAL_WINDOW) says. */
 int hk_debug_spatial_windowed_launches(hk_ctx* ctx, uint64_t* out);
+
+/* Switches for tests and A/B tools (round 6: the library itself reads NO environment variable).  Waits for the context's work, sets
+ * the option, returns; options that change the scene layout take effect with the next frame. */
+#define HK_DEBUG_OPT_SPATIAL_WINDOW 0u  /* which form of k_spatial_reuse a launch takes: -1 by its size (default), 0 plain, 1 windowed */
+#define HK_DEBUG_OPT_FRAME_PIPELINE 1u  /* 0: the a-trous levels of frame n are NOT run beside frame n + 1's light passes (default 1) */
+#define HK_DEBUG_OPT_WF_TIMELINE 2u     /* 1: the instrumented twin of the trace kernels (hk_debug_read_wf_timeline) */
+#define HK_DEBUG_OPT_FLAT_WALK 3u       /* 0: no one-level tree for LDS scenes under one transform - they keep the reference's two-level walk (default 1) */
+#define HK_DEBUG_OPT_FLAT_ORDERINGS 4u  /* 1..8 direction orderings of that tree (default 0: as many as keep it within 4 KB) */
+#define HK_DEBUG_OPT_TRACE_UPDATE 5u    /* 1: timings of scene updates on stderr */
+int hk_debug_set_option(hk_ctx* ctx, uint32_t option, int64_t value);
+/* hk_multi_*: 1 = the calling thread enqueues every band's launches one after another instead of one thread per band (process-wide) */
+int hk_debug_multi_serial(int on);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

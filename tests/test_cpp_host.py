@@ -21,7 +21,7 @@ def test_describe_matches_reference_constants():
     r = run("--describe")
     assert r.returncode == 0, r.stderr
     assert "graph=hikari nodes=hikari_prepass,hikari_light,hikari_post_process,hikari_overlay workgroup=8 noise=16" in r.stdout
-    assert "defaults_match_library=1 ratio=2.0 abi=7" in r.stdout      # C++ HikariSettings{} == hk_settings_default (lib.rs:435-455)
+    assert "defaults_match_library=1 ratio=2.0 abi=8" in r.stdout      # C++ HikariSettings{} == hk_settings_default (lib.rs:435-455)
     assert "tlas_nodes=22 emissives=1" in r.stdout                      # same builder result as the Python path
 
 

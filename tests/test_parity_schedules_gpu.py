@@ -107,59 +107,6 @@ def test_frame_pipelining_changes_no_bit_in_any_frame_order():
         assert (e.read(b).view(np.uint8) == ref.read(b).view(np.uint8)).all(), b
 
 
-def test_primary_ray_pipelining_changes_no_bit():
-    """Round 5: the primary rays of frame n + 1 run on a fourth stream beside frame n's light passes (every plane the prepass writes
-    is double-buffered by frame parity).  (a) A pipelined context equals a single-stream one in every buffer after a long back-to-back
-    sequence - on Cornell (scene in LDS) and on a scene beyond LDS in the product default (the queue-based indirect pass, whose
-    trace stages' tails the primary rays fill) - and the pipelined path really ran; (b) what breaks the chain takes the serial order
-    and changes nothing: the anti-aliasing tail (reads the previous frame's planes), an instance update between frames, a host that
-    dispatches passes itself, frames of one parity in a row."""
-    from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
-    from cases import product_default_traversal
-
-    case = make_case("cornell_b2")
-    big, sun = synthetic_large(0x5EED0007, 8, 24, 48, 60, 8, 2, 6.0)
-    runs = [(case.scene, case.camera, case.settings, case.lights, 0, 24),
-            (big, synthetic_camera(320, 180, extent=6.0), hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0), hk.lights_uniform(directional=sun), None, 12)]
-    os.environ["HK_PREPASS_PIPELINE"] = "all"   # (read by hk_create; off by default: measured slower, DESIGN 8.1b)
-    try:
-        _pipelining_body(make_case, runs, oracle)
-    finally:
-        del os.environ["HK_PREPASS_PIPELINE"]
-
-
-def _pipelining_body(make_case, runs, oracle):
-    from cases import product_default_traversal
-
-    for scene, cam, s, lights, flags, frames in runs:   # (a)
-        snaps = []
-        for single in (False, True):
-            if flags is None:
-                with product_default_traversal():
-                    p = hk.HikariPlugin(device=0, flags=F.CTX_SINGLE_STREAM if single else 0)
-            else:
-                p = hk.HikariPlugin(device=0, flags=F.CTX_SINGLE_STREAM if single else 0)
-            p.set_scene(scene)
-            for n in range(1, frames + 1):
-                p.render(cam, s, lights=lights, frame_number=n)
-            snaps.append(snapshot(p))
-            assert p.engine.prepasses_pipelined() == (0 if single else frames - 1)
-        assert diff_buffers(snaps[0], snaps[1]) == {}
-    # (b) Cornell with the anti-aliasing tail on some frames, by_nodes on others, repeated parities: against the oracle, frame by frame
-    gpu, cpu = hk.HikariPlugin(device=0), oracle()
-    aa_case = make_case("cornell_aa_default")
-    for p in (gpu, cpu):
-        p.set_scene(aa_case.scene)
-    plan = [(1, False, False), (2, False, False), (3, True, False), (4, False, False), (5, False, True), (6, False, False), (7, False, False), (9, False, False), (10, True, False),
-            (11, False, False), (12, False, False)]
-    for n, aa, by_nodes in plan:
-        for p in (gpu, cpu):
-            p.render(aa_case.camera, aa_case.settings, lights=aa_case.lights, frame_number=n, antialias=aa, by_nodes=by_nodes)
-        bad = diff_buffers(snapshot(gpu), snapshot(cpu))
-        assert bad == {}, (n, bad)
-    assert 0 < gpu.engine.prepasses_pipelined() < len(plan) - 1
-
-
 def test_uniform_tile_store_elision_changes_no_bit():
     """Uniform-tile store elision (hk_kernels.hpp TileMeta): waves whose 64 pixels are background skip reservoir stores that
     would rewrite the record the tile already holds.  Every buffer must stay bit-identical to the oracle through the situations
@@ -225,11 +172,8 @@ def test_windowed_spatial_reuse_changes_no_byte(name):
     of every frame equals the oracle's, and the windowed form really ran (light.wgsl:1503-1684)."""
     case = make_case(name)
     cpu = oracle()
-    os.environ["HK_SPATIAL_WINDOW"] = "on"   # (read by hk_create)
-    try:
-        forced = hk.HikariPlugin(device=0)
-    finally:
-        del os.environ["HK_SPATIAL_WINDOW"]
+    forced = hk.HikariPlugin(device=0)
+    forced.engine.set_debug_option(F.DEBUG_OPT_SPATIAL_WINDOW, 1)
     plain = hk.HikariPlugin(device=0)
 
     for p in (forced, plain, cpu):

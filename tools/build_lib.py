@@ -16,6 +16,21 @@ SOURCES = ["kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "kernels_wave
            "probes.hip", "host_logic.cpp", "scene_builder.cpp", "comm.cpp"]
 
 
+def source_hash():
+    """sha256 over every source the library is built from (csrc/*, include/*.h), names included: what hk_build_info() reports and
+    __graft_entry__ compares with the tree, so that a stale binary is visible (and rebuilt) wherever the tree travels."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".hpp", ".h", ".cpp"))]
+    files += [os.path.join(ROOT, "include", f) for f in ("hikari_hip.h", "hikari_hip_debug.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_library(out, objdir=None, extra=(), force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # one object directory per OUTPUT (a variant built with other flags never evicts the shipped library's objects)
@@ -61,11 +76,26 @@ def build_library(out, objdir=None, extra=(), force=False, verbose=True):
     with open(stamp, "w") as f:
         f.write(flag_line)
     objs = [j[1] for j in jobs]
+    # the build stamp (hk_build_info, include/hikari_hip.h): sources' hash, compiler, every flag, when - compiled into the library
+    import time
+
+    src_hash = source_hash()
+    stamp_text = "sources %s | %s | built %s" % (src_hash, flag_line, time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()))
+    stamp_cpp, stamp_obj = os.path.join(objdir, "build_stamp.cpp"), os.path.join(objdir, "build_stamp.o")
+    old_stamp = open(stamp_cpp).read() if os.path.exists(stamp_cpp) else ""
+    if todo or force or ("sources %s |" % src_hash) not in old_stamp or not os.path.exists(stamp_obj):
+        with open(stamp_cpp, "w") as f:
+            f.write('extern "C" __attribute__((visibility("default"))) const char* hk_build_info(void) { return "%s"; }\n' % stamp_text.replace("\\", "/").replace('"', "'"))
+        subprocess.run(["g++", "-O1", "-fPIC", "-c", stamp_cpp, "-o", stamp_obj], check=True)
+        todo = todo or [None]
+    objs.append(stamp_obj)
     if todo or not os.path.exists(out) or any(os.path.getmtime(o) > os.path.getmtime(out) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", out] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        with open(out + ".stamp", "w") as f:   # (sidecar: what __graft_entry__.build() compares with the tree BEFORE loading the library)
+            f.write(src_hash + "\n")
     return out
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Host time of hk_multi_frame_render (one process driving n bands; here all on device 0): the call's return-to-return
-time with nothing waited for, serial enqueue (HK_MULTI_SERIAL=1, one thread walks the bands) against one enqueue thread per
+time with nothing waited for, serial enqueue (hk_debug_multi_serial, one thread walks the bands) against one enqueue thread per
 band.  A band's GPU time at 8 GPUs is ~0.3 ms (profiles/r03_final_band_probe.json): the host must stay below that.
 
     python tools/multi_host_overhead.py [bands ...]      -> JSON
@@ -46,11 +46,14 @@ def measure(bands):
 
 if __name__ == "__main__":
     if os.environ.get("HK_MULTI_PROBE_CHILD"):
+        if os.environ.get("HK_MULTI_PROBE_SERIAL"):
+            import bevy_hikari_amd as _hk
+            _hk.api().call("debug_multi_serial", 1)   # hikari_hip_debug.h
         print(json.dumps(measure([int(a) for a in sys.argv[1:]])))
         sys.exit(0)
     bands = sys.argv[1:] or ["2", "4", "8"]
     res = {}
-    for label, env in (("one_thread_per_band", {}), ("serial", {"HK_MULTI_SERIAL": "1"})):
+    for label, env in (("one_thread_per_band", {}), ("serial", {"HK_MULTI_PROBE_SERIAL": "1"})):
         r = subprocess.run([sys.executable, __file__] + bands, env=dict(os.environ, HK_MULTI_PROBE_CHILD="1", **env), capture_output=True, text=True)
         if r.returncode:
             sys.stderr.write(r.stderr[-2000:])

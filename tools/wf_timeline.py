@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Bulk / tail split of the trace stages of the queue-based indirect pass: with HK_WF_TIMELINE=1 the trace
+"""Bulk / tail split of the trace stages of the queue-based indirect pass: with HK_DEBUG_OPT_WF_TIMELINE the trace
 kernel's instrumented twin records per stage when the ray queue ran dry, when the last persistent wave left and how long the rays'
 walks were.  Prints one JSON object per config.    python tools/wf_timeline.py [--no-wide-walk] [3 4]
 (default: the wide kernel k_wf_trace_wide, whose "node steps" are 128-B records of two tree levels and whose long walks are those of
@@ -9,7 +9,6 @@ import json
 import os
 import sys
 
-os.environ["HK_WF_TIMELINE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
@@ -25,6 +24,7 @@ def main():
     for cfg in configs:
         scene, camera, settings, lights, description = workload(hk, cfg, None, None, None)
         e = hk.Engine(device=0, flags=256 if no_wide else 0)
+        e.set_debug_option(2, 1)   # HK_DEBUG_OPT_WF_TIMELINE
         e.upload_noise(); e.upload_scene(scene); e.resize(camera.width, camera.height, 1.0)
         view, pview, sc = camera.view_uniform(), camera.previous_view_uniform(), settings.to_c()
         for n in range(1, 9):
