@@ -419,12 +419,14 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
   if (n_inst > c->wide_rank_instances) {
     if (c->wide_tlas_rank) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_tlas_rank); c->wide_tlas_rank = nullptr; }
     HK_HIP(hipMalloc((void**)&c->wide_tlas_rank, (n_inst + n_inst / 2 + 16) * sizeof(uint32_t)));
+    HK_HIP(hipMemsetAsync(c->wide_tlas_rank, 0xFF, (n_inst + n_inst / 2 + 16) * sizeof(uint32_t), c->stream));
     c->wide_rank_instances = n_inst + n_inst / 2 + 16;
     c->wide_tlas_dirty = true;
   }
   if (n_prim > c->wide_rank_primitives) {
     if (c->wide_blas_rank) { HK_HIP(hipStreamSynchronize(c->stream)); (void)hipFree(c->wide_blas_rank); c->wide_blas_rank = nullptr; }
     HK_HIP(hipMalloc((void**)&c->wide_blas_rank, std::max<size_t>(n_prim, 1) * sizeof(uint32_t)));
+    HK_HIP(hipMemsetAsync(c->wide_blas_rank, 0xFF, std::max<size_t>(n_prim, 1) * sizeof(uint32_t), c->stream));  // (a primitive no mesh tree names: a rank that is at least deterministic)
     c->wide_rank_primitives = n_prim;
     c->wide_blas_dirty = true;
   }
@@ -444,18 +446,24 @@ int ensure_wide(hk_ctx* c, bool with_spill) {
     // SET the ones no instance used before (a mesh uploaded ahead of its first instance has no records until then)
     if (c->wide_blas_dirty) c->wide_meshes.clear();
     std::vector<std::pair<uint32_t, uint32_t>> meshes;
-    std::vector<std::pair<uint32_t, uint32_t>> first_primitive;  // (node_offset, the mesh's first primitive): a triangle leaf's id is local to its mesh
+    // (node_offset, node_count) -> the mesh's first primitive: a triangle leaf's id is local to its mesh.  Two instances that name the
+    // same tree must name the same primitives - otherwise the second mesh's ranks would land at the wrong base
+    std::vector<std::pair<std::pair<uint32_t, uint32_t>, uint32_t>> first_primitive;
     for (const HkInstance& in : c->instances) {
       meshes.emplace_back(in.mesh.node_offset, in.mesh.node_count);
-      first_primitive.emplace_back(in.mesh.node_offset, in.mesh.primitive);
+      first_primitive.emplace_back(std::make_pair(in.mesh.node_offset, in.mesh.node_count), in.mesh.primitive);
     }
     std::sort(meshes.begin(), meshes.end());
     meshes.erase(std::unique(meshes.begin(), meshes.end()), meshes.end());
     std::sort(first_primitive.begin(), first_primitive.end());
+    first_primitive.erase(std::unique(first_primitive.begin(), first_primitive.end()), first_primitive.end());
+    for (size_t k = 0; k + 1 < first_primitive.size(); ++k)
+      HK_REQUIRE(first_primitive[k].first != first_primitive[k + 1].first, HK_E_INVALID, "two instances share the mesh nodes [%u, +%u) but not the mesh primitives (%u / %u)",
+                 first_primitive[k].first.first, first_primitive[k].first.second, first_primitive[k].second, first_primitive[k + 1].second);
     for (const auto& m : meshes) {
       if (std::binary_search(c->wide_meshes.begin(), c->wide_meshes.end(), m)) continue;
       HK_REQUIRE((size_t)m.first + m.second <= blas_slots, HK_E_INVALID, "an instance's mesh nodes lie outside the uploaded mesh nodes");
-      const uint32_t prim0 = std::lower_bound(first_primitive.begin(), first_primitive.end(), std::make_pair(m.first, 0u))->second;
+      const uint32_t prim0 = std::lower_bound(first_primitive.begin(), first_primitive.end(), std::make_pair(m, 0u))->second;
       // (a tree of L leaves has 3 L - 2 nodes: its leaf ids stay below (node_count + 2) / 3)
       HK_REQUIRE((size_t)prim0 + (m.second + 2u) / 3u <= n_prim, HK_E_INVALID, "an instance's mesh primitives lie outside the uploaded primitives");
       launch_build_wide(c->stream, c->scene.nodes + 2u * ((size_t)c->scene.blas_base + m.first), m.second, c->wide_blas + 8u * (size_t)m.first, c->wide_blas_rank + prim0);

@@ -413,6 +413,8 @@ __device__ __forceinline__ bool bounce_step(const DScene& sc, const DFrame& fr, 
 // utilisation and waits on LDS / memory in between: a FIFTH resident wave (96 VGPRs instead of 114, 35 spilled to scratch) hides
 // more than the spills cost - Cornell 1080p: the kernel 0.408 -> 0.383 ms in the frame (0.271 -> 0.262 alone), the frame
 // 0.974 / 0.977 -> 0.958 / 0.958 ms, every byte unchanged (round 5, profiles/r05_indirect_waves_ab.txt; round 3 had seen -0.5 % and left it).
+// (no static LDS in this kernel: five workgroups x the largest scene copy, HK_LDS_SCENE_BYTES = 32 KB, are exactly the CU's 160 KB - the
+// fifth wave is resident for every scene the one-level mode accepts; tests/test_kernel_resources.py holds both facts)
 #ifndef HK_INDIRECT_FLAT_WAVES
 #define HK_INDIRECT_FLAT_WAVES 5
 #endif
