@@ -1,6 +1,5 @@
-// hk_prepass.hpp - what the two forms of the prepass share (kernels.hip k_prepass: one fused kernel; kernels_wavefront.hip: the primary
-// rays through the trace kernel's queue, round 5 experiment): the parameters, the primary ray of a pixel (prepass.wgsl:40-100 semantics by
-// ray casting) and the G-buffer record of a pixel from its closest hit.
+// hk_prepass.hpp - the prepass by primary rays (kernels.hip k_prepass): the parameters, the primary ray of a pixel (prepass.wgsl:40-100
+// semantics by ray casting), the near-plane clip of the rasteriser it replaces, and the G-buffer record of a pixel from its closest hit.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,13 +16,30 @@ struct PrepassParams {
   const float4* prev_models;      // previous model matrix (4 columns) per instance, read where DInstance::moved
   WideTrees wide;                 // scenes in global memory, product default: the records of the wide walk (tlas == nullptr: the skip-link walk)
 };
-__device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams& pp, float px, float py) {
+// the point of the NEAR PLANE under the pixel's centre (reverse-Z: NDC z = 1), minus the geometry's jitter shift
+__device__ __forceinline__ f3 primary_near_point(const DFrame& fr, const PrepassParams& pp, float px, float py) {
   const float ux = fr.uv_fast ? div_by(px + 0.5f, (float)fr.dw, fr.inv_dw) : (px + 0.5f) / (float)fr.dw;
   const float uy = fr.uv_fast ? div_by(py + 0.5f, (float)fr.dh, fr.inv_dh) : (py + 0.5f) / (float)fr.dh;
   float ndc_x = ux * 2.0f - 1.0f - pp.jitter_x;
   float ndc_y = 1.0f - uy * 2.0f - pp.jitter_y;
   f4 pn = mul(pp.ivp0, pp.ivp1, pp.ivp2, pp.ivp3, F4(ndc_x, ndc_y, 1.0f, 1.0f));
-  f3 near_point = xyz(pn) / pn.w;
+  return xyz(pn) / pn.w;
+}
+// Near-plane clip (round 6; prepass.rs:242-266: the reference's raster pipeline has `unclipped_depth: false`, so geometry in front
+// of the camera's near plane - 0.1 by default - never reaches the G-buffer).  A perspective primary ray starts at the EYE (every
+// stored bit of a frame without such geometry depends on that origin); when its closest hit lies in front of the near plane the
+// pixel is traced once more from the near plane itself: what the rasteriser would have drawn there - the nearest surface BEYOND the
+// plane, a triangle that straddles it cut exactly at it.  Returns whether `ray` was moved (the caller traces again).  Orthographic
+// rays start on the near plane already.
+__device__ __forceinline__ bool clip_at_near_plane(const DFrame& fr, const PrepassParams& pp, float px, float py, Ray& ray, const Hit& hit) {
+  if (fr.is_ortho || hit.instance_index == HK_U32_MAX) return false;
+  const f3 near_point = primary_near_point(fr, pp, px, py);
+  if (!(hit.distance < length(near_point - ray.origin))) return false;
+  ray.origin = near_point;
+  return true;
+}
+__device__ __forceinline__ Ray primary_ray(const DFrame& fr, const PrepassParams& pp, float px, float py) {
+  const f3 near_point = primary_near_point(fr, pp, px, py);
   Ray ray;
   if (fr.is_ortho) {
     ray.origin = near_point;

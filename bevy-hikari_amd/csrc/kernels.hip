@@ -68,13 +68,17 @@ __global__ __launch_bounds__(256, (LDS == 4 ? HK_PREPASS_WIDE_WAVES : 1)) void k
   if (px.valid) {
     Ray ray = primary_ray(fr, pp, (float)px.x, (float)px.y);
     Hit hit;
-    if (LDS == 4) {  // scenes in global memory, product default: the wide walk (hk_wide.hpp)
-      WideStackPrivate<HK_WIDE_LDS_STACK, 96u> stack;
-      stack.lds = wide_lds;
-      stack.lost = pp.wide.lost;
-      hit = traverse_top_wide<COUNT>(sc, pp.wide, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, stack, rc);
-    } else {
-      hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+#pragma unroll 1
+    for (int attempt = 0;; ++attempt) {  // (one call site for the walk: a second trip only for a pixel whose nearest surface lies in front of the near plane)
+      if (LDS == 4) {  // scenes in global memory, product default: the wide walk (hk_wide.hpp)
+        WideStackPrivate<HK_WIDE_LDS_STACK, 96u> stack;
+        stack.lds = wide_lds;
+        stack.lost = pp.wide.lost;
+        hit = traverse_top_wide<COUNT>(sc, pp.wide, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, stack, rc);
+      } else {
+        hit = traverse_top(sc, ray, HK_F32_MAX, 0.0f, HK_DONT_EXCLUDE, rc);
+      }
+      if (attempt != 0 || !clip_at_near_plane(fr, pp, (float)px.x, (float)px.y, ray, hit)) break;
     }
     rc.tlas = 0;  // counted as a primary ray
     primary = 1;

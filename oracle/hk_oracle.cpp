@@ -1084,13 +1084,15 @@ static v2 frame_jitter(Ctx* c) {  // prepass.wgsl:30-38
   const float* h = c->frame.halton[index >> 1u];
   return ((index & 1u) == 0u) ? V2(h[0], h[1]) : V2(h[2], h[3]);
 }
-static Ray primary_ray(Ctx* c, float px, float py, v2 jitter_ndc) {
-  // pixel centre (px+0.5, py+0.5) in NDC, minus the geometry shift
+static v3 primary_near_point(Ctx* c, float px, float py, v2 jitter_ndc) {
   float ndc_x = (px + 0.5f) / (float)c->W * 2.0f - 1.0f - jitter_ndc.x;
   float ndc_y = 1.0f - (py + 0.5f) / (float)c->H * 2.0f - jitter_ndc.y;
-  m4 ivp = load_m4(c->view.inverse_view_proj);
-  v4 pn = mul(ivp, V4(ndc_x, ndc_y, 1.0f, 1.0f));  // reverse-Z: z = 1 is the near plane
-  v3 near_point = xyz(pn) / pn.w;
+  v4 pn = mul(load_m4(c->view.inverse_view_proj), V4(ndc_x, ndc_y, 1.0f, 1.0f));  // reverse-Z: z = 1 is the near plane
+  return xyz(pn) / pn.w;
+}
+static Ray primary_ray(Ctx* c, float px, float py, v2 jitter_ndc) {
+  // pixel centre (px+0.5, py+0.5) in NDC, minus the geometry shift
+  v3 near_point = primary_near_point(c, px, py, jitter_ndc);
   Ray ray;
   if (c->view.projection[15] == 1.0f) {  // orthographic (light.wgsl:1040 test)
     const float* vp = c->view.view_proj;
@@ -1119,6 +1121,17 @@ static void pass_prepass(Ctx* c, int y0, int y1) {
     for (int x = 0; x < c->W; ++x) {
       Ray ray = primary_ray(c, (float)x, (float)y, jitter_ndc);
       Hit hit = traverse_top(sc, ray, F32_MAX, 0.0f, DONT_EXCLUDE);
+      // Near-plane clip (prepass.rs:242-266: the raster pipeline the primary rays stand in for has `unclipped_depth: false` - geometry
+      // in front of the near plane never reaches the G-buffer).  A perspective ray starts at the eye; if its closest hit lies in
+      // front of the near plane the pixel is traced again from the near plane: the nearest surface BEYOND it, a triangle that
+      // straddles it cut at it.  (Orthographic rays start on the near plane.)
+      if (c->view.projection[15] != 1.0f && hit.instance_index != U32_MAX) {
+        const v3 near_point = primary_near_point(c, (float)x, (float)y, jitter_ndc);
+        if (hit.intersection.distance < length(near_point - ray.origin)) {
+          ray.origin = near_point;
+          hit = traverse_top(sc, ray, F32_MAX, 0.0f, DONT_EXCLUDE);
+        }
+      }
       n_primary++;
       if (hit.instance_index == U32_MAX) {  // LoadOp::Clear(Color::NONE), prepass.rs:792
         position.store_f32x4(x, y, V4(0, 0, 0, 0));
