@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--no-wide-walk", action="store_true", help="A/B: scenes beyond LDS keep the threaded skip-link walk for closest-hit rays too (HK_CTX_NO_WIDE_WALK)")
     ap.add_argument("--passes", action="store_true", help="also report a per-pass time breakdown (extra untimed frames)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the short config-3 / config-5 measurements of the default run")
+    ap.add_argument("--motion", action="store_true", help="ONLY the frames under motion (tools/motion_bench.py): config 2 with an orbiting camera (two speeds), config 3 with the orbit + "
+                    "instances moving through hk_refit_scene_instances - ms per frame in the racing default and with HK_CTX_DETERMINISTIC_SCATTER, their deviation from each other "
+                    "and from the CPU oracle per frame; the default run carries a shorter version of the same in extra_configs['motion']")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="length of the sustained block of the default run (0 = none)")
     ap.add_argument("--sustained", dest="sustained_seconds_forced", action="store_true", help="run the sustained block for any config / rank count")
     args = ap.parse_args()
@@ -442,6 +445,27 @@ def main():
             res["_probe_engine"] = xeng
         res["_engines"] = (eng, rend)
         return res
+
+    def motion_lines(short):
+        """frames under motion + the price of determinism: tools/motion_bench.py"""
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import motion_bench
+        from oracle_lib import oracle_engine   # (the checker, compared against - never timed)
+
+        res = {"orbit_radians_per_frame": motion_bench.ORBIT_RAD_PER_FRAME, "note": motion_bench.__doc__.split("\n\n")[1].replace("\n", " ")}
+        kw = dict(device=local_rank, blocks=3, warmup=16 if short else 24, compare_frames=6 if short else 12, oracle_engine=oracle_engine)
+        res["2"] = motion_bench.run(hk, F, 2, frames=24 if short else 48, oracle_frames=2 if short else 6, **kw)
+        if not short:
+            res["2_fast_orbit"] = motion_bench.run(hk, F, 2, frames=48, oracle_frames=6, orbit=10.0 * motion_bench.ORBIT_RAD_PER_FRAME, **kw)
+        res["3"] = motion_bench.run(hk, F, 3, frames=6 if short else 12, oracle_frames=0, **kw)
+        return res
+
+    if args.motion:
+        if world != 1:
+            sys.exit("bench.py --motion is a single-GPU measurement")
+        print(json.dumps({"metric": "frame ms under motion: racing default vs HK_CTX_DETERMINISTIC_SCATTER", "unit": "ms", "n_gpus": 1, "higher_is_better": False, "motion": motion_lines(False)}), flush=True)
+        return
 
     # ------------------------------------------------------------------ timed run (headline)
     default_run = world == 1 and args.config == 2 and args.width is None and args.height is None and args.bounces is None and not args.ctx_flags
@@ -743,6 +767,11 @@ def main():
         out["direct_passes_in_run_ms"] = m["direct_ms"]
     if m["sustained"]:
         out["sustained"] = m["sustained"]
+    if extra is not None and rank == 0:
+        try:
+            extra["motion"] = motion_lines(True)
+        except Exception as e:   # (a measurement beside the headline: never the reason the line is missing)
+            extra["motion"] = {"error": repr(e)}
     if extra:
         out["extra_configs"] = extra
     if transport_used[0]:
