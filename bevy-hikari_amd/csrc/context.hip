@@ -66,11 +66,12 @@ int free_screen(hk_ctx* c) {
   if (c->dn_g) (void)hipFree(c->dn_g);
   c->depth_plane = nullptr;
   c->dn_g = nullptr;
-  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin}) {
+  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin, &c->render_twin[0], &c->render_twin[1], &c->render_twin[2], &c->variance_twin[0],
+                   &c->variance_twin[1], &c->variance_twin[2]}) {
     if (*q) (void)hipFree(*q);
     *q = nullptr;
   }
-  c->post_pending = false;
+  c->post_pending[0] = c->post_pending[1] = false;
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
       if (c->dn_extra[k][l]) (void)hipFree(c->dn_extra[k][l]);
@@ -542,9 +543,18 @@ int join_side(hk_ctx* c) {
 }
 // make the main stream wait for the a-trous levels of the last frame (post_stream)
 int join_post(hk_ctx* c) {
-  if (!c->post_pending) return HK_OK;
-  HK_HIP(hipStreamWaitEvent(c->stream, c->post_done, 0));
-  c->post_pending = false;
+  for (int k = 0; k < 2; ++k)
+    if (c->post_pending[k]) {
+      HK_HIP(hipStreamWaitEvent(c->stream, c->post_done[k], 0));
+      c->post_pending[k] = false;
+    }
+  return HK_OK;
+}
+// ... for the post-processing of the last frame of one parity only: whoever is about to write that parity's planes
+int join_post_parity(hk_ctx* c, uint32_t parity) {
+  if (!c->post_pending[parity & 1u]) return HK_OK;
+  HK_HIP(hipStreamWaitEvent(c->stream, c->post_done[parity & 1u], 0));
+  c->post_pending[parity & 1u] = false;
   return HK_OK;
 }
 int join_all(hk_ctx* c) {
@@ -552,6 +562,43 @@ int join_all(hk_ctx* c) {
   if (!rc) rc = join_post(c);
   if (!rc && c->comm) rc = comm_join(c, -1);  // a gather of the last frame still collecting rows on the communicator's stream
   return rc;
+}
+#ifndef HK_POST_DEMODULATION_RULE
+#define HK_POST_DEMODULATION_RULE true
+#endif
+// Stage POST_PROCESS on the post stream (hk_context.hpp "Frame pipelining"): the main stream waits for the side stream, then the post
+// stream takes over behind everything the main stream holds - demodulation, the a-trous levels and tone mapping of this frame (on a
+// band with a communicator also exchange B) run there while the main stream goes on to the next frame.  `pipelined` = false: the frame
+// stays on the main stream, which then waits for what the post stream still holds (timed passes, no denoiser, verification contexts).
+// whether demodulation goes to the post stream with the levels (hk_debug_set_option(HK_DEBUG_OPT_POST_DEMODULATION): -1 = the rule)
+static bool demod_on_post(const hk_ctx* c) { return c->post_demodulation < 0 ? HK_POST_DEMODULATION_RULE : c->post_demodulation != 0; }
+int post_begin(hk_ctx* c, const HkSettings* st, bool* pipelined) {
+  *pipelined = false;
+  int rc = join_side(c);
+  if (rc) return rc;
+  if (st->denoise && c->derived_dirty) {
+    launch_derive_planes(c->stream, make_gbuffer(c), c->depth_plane, c->dn_g, c->W, 0, c->H);
+    c->derived_dirty = false;
+  }
+  const uint32_t post_bits = (1u << HK_PASS_DEMODULATION) | (1u << HK_PASS_DENOISE_L0) | (1u << HK_PASS_DENOISE_L1) | (1u << HK_PASS_DENOISE_L2) | (1u << HK_PASS_DENOISE_L3);
+  if (!(st->denoise && c->post_stream && c->frame_pipeline && !(c->timing_mask & post_bits) && c->albedo_twin && c->render_twin[0]))
+    return join_post(c);  // the denoiser's internal planes: last frame's levels come first
+  HK_HIP(hipEventRecord(c->post_fork, c->stream));
+  HK_HIP(hipStreamWaitEvent(c->post_stream, c->post_fork, 0));
+  c->post_saved_main = c->stream;
+  c->stream = c->post_stream;
+  *pipelined = true;
+  return HK_OK;
+}
+int post_end(hk_ctx* c, bool pipelined) {
+  c->post_forked = false;
+  if (!pipelined) return HK_OK;
+  const uint32_t parity = c->mapped_parity & 1u;
+  const hipError_t e = hipEventRecord(c->post_done[parity], c->post_stream);
+  c->stream = c->post_saved_main;
+  HK_REQUIRE(e == hipSuccess, HK_E_HIP, "hipEventRecord failed: %s", hipGetErrorString(e));
+  c->post_pending[parity] = true;
+  return HK_OK;
 }
 // run one dispatch on the side stream (timers record there too)
 int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1);
@@ -785,7 +832,7 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
     }
     if (!(flags & (HK_CTX_DETERMINISTIC_SCATTER | HK_CTX_COUNT_RAYS | HK_CTX_TIME_PASSES))) {
       if (hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->post_fork, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&c->post_done, hipEventDisableTiming) != hipSuccess) {
+          hipEventCreateWithFlags(&c->post_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->post_done[1], hipEventDisableTiming) != hipSuccess) {
         set_error("cannot create the post-process stream");
         hk_destroy(c);
         return HK_E_HIP;
@@ -821,7 +868,8 @@ void hk_destroy(hk_ctx* c) {
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
   if (c->post_stream) (void)hipStreamDestroy(c->post_stream);
   if (c->post_fork) (void)hipEventDestroy(c->post_fork);
-  if (c->post_done) (void)hipEventDestroy(c->post_done);
+  for (int k = 0; k < 2; ++k)
+    if (c->post_done[k]) (void)hipEventDestroy(c->post_done[k]);
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->join_event) (void)hipEventDestroy(c->join_event);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -855,6 +903,7 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
     case HK_DEBUG_OPT_FLAT_WALK: c->flat_walk = value != 0; c->dynamic_dirty = true; break;
     case HK_DEBUG_OPT_FLAT_ORDERINGS: c->flat_orderings = (int)std::max<int64_t>(0, std::min<int64_t>(8, value)); c->dynamic_dirty = true; break;
     case HK_DEBUG_OPT_TRACE_UPDATE: c->trace_update = value != 0; break;
+    case HK_DEBUG_OPT_POST_DEMODULATION: c->post_demodulation = value < 0 ? -1 : (value ? 1 : 0); break;
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown option %u", option);
   }
   return HK_OK;
@@ -930,6 +979,12 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     HK_HIP(hipMemset(c->depth_gradient_twin, 0, c->buf_bytes[HK_BUF_DEPTH_GRADIENT]));
     HK_HIP(hipMalloc(&c->dn_g_twin, nf * 16));
     HK_HIP(hipMemset(c->dn_g_twin, 0, nf * 16));
+    for (int ch = 0; ch < 3; ++ch) {  // (round 6: what demodulation reads of the light passes' outputs - it runs beside the next frame's light passes too)
+      HK_HIP(hipMalloc(&c->render_twin[ch], c->buf_bytes[HK_BUF_RENDER0 + ch]));
+      HK_HIP(hipMemset(c->render_twin[ch], 0, c->buf_bytes[HK_BUF_RENDER0 + ch]));
+      HK_HIP(hipMalloc(&c->variance_twin[ch], c->buf_bytes[HK_BUF_VARIANCE0 + ch]));
+      HK_HIP(hipMemset(c->variance_twin[ch], 0, c->buf_bytes[HK_BUF_VARIANCE0 + ch]));
+    }
   }
   for (int k = 0; k < 2; ++k) {
     for (int l = 0; l < 4; ++l) {
@@ -973,6 +1028,10 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
       std::swap(c->buf[HK_BUF_ALBEDO], c->albedo_twin);
       std::swap(c->buf[HK_BUF_DEPTH_GRADIENT], c->depth_gradient_twin);
       std::swap(c->dn_g, c->dn_g_twin);
+      for (int ch = 0; ch < 3; ++ch) {
+        std::swap(c->buf[HK_BUF_RENDER0 + ch], c->render_twin[ch]);
+        std::swap(c->buf[HK_BUF_VARIANCE0 + ch], c->variance_twin[ch]);
+      }
     }
     c->mapped_parity = f->number & 1u;
   }
@@ -1148,10 +1207,11 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
   } while (0)
   if (stage == HK_STAGE_TEMPORAL) {
     if ((rc = join_side(c))) return rc;
-    // last frame's a-trous levels may still be running on post_stream: this frame's primary rays and light passes do not touch
-    // what they read - provided the double-buffered planes really flipped (a host that renders two frames of the same parity in a
-    // row, or shards the frame into bands, or timed passes, gets the serial order)
-    if (c->post_pending && (c->mapped_parity == c->post_parity || (flags & HK_FRAME_EXTERNAL_GBUFFER)) && (rc = join_post(c))) return rc;
+    // last frame's post-processing may still be running on post_stream: this frame's primary rays and light passes do not touch what
+    // it reads - the planes both touch are double-buffered by frame parity.  What this frame does write again is what the last frame
+    // OF ITS OWN PARITY read (normally two frames back and long done; the last frame itself when a host renders two frames of one
+    // parity in a row); a host-rasterised G-buffer was written into whichever planes were mapped: everything first
+    if ((flags & HK_FRAME_EXTERNAL_GBUFFER) ? (rc = join_post(c)) : (rc = join_post_parity(c, c->mapped_parity))) return rc;
     int f0, f1;
     full_rows_for(c, clampr(b0 - den - sp), clampr(b1 + den + sp), &f0, &f1);
     bool albedo_done = false;
@@ -1223,43 +1283,36 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     if (st->indirect_spatial_reuse) HK_RUN(HK_PASS_INDIRECT_SPATIAL_REUSE, 0, b0, b1);
     if ((rc = join_side(c))) return rc;              // exchange B / demodulation read all three channels
   } else if (stage == HK_STAGE_POST_PROCESS) {
-    if ((rc = join_side(c))) return rc;
-    if ((rc = join_post(c))) return rc;              // the denoiser's internal planes: last frame's levels come first
+    // (hk_frame_render on a band with a communicator has moved to the post stream already: exchange B belongs in front of demodulation)
+    bool pipelined = c->post_forked;
+    if (!pipelined && (rc = post_begin(c, st, &pipelined))) return rc;
     if (st->denoise) {                               // post_process.rs:1190-1224
       const uint32_t nch = st->indirect_bounces == 0 ? 2u : 3u;  // post_process.rs:949-954
-      if (c->derived_dirty) {
-        launch_derive_planes(c->stream, make_gbuffer(c), c->depth_plane, c->dn_g, c->W, 0, c->H);
-        c->derived_dirty = false;
+      // the reference's per-channel loop, with the channels of each step fused into one launch.  Round 6: demodulation too runs on
+      // the post stream - the render / variance planes it reads are double-buffered by frame parity, the next frame's light passes
+      // write the other set - so a frame's main stream ends with its spatial pass (a band: with exchange A and its spatial pass)
+      if (pipelined && !demod_on_post(c)) {  // (demodulation stays on the main stream, the levels follow it on the post stream)
+        hipStream_t post = c->stream;
+        c->stream = c->post_saved_main;
+        rc = join_post(c);  // the denoiser's internal planes: last frame's levels come first
+        if (!rc) rc = run_demodulation_fused(c, nch, clampr(b0 - 15), clampr(b1 + 15));
+        if (!rc && hipEventRecord(c->post_fork, c->stream) != hipSuccess) rc = HK_E_HIP;
+        if (!rc && hipStreamWaitEvent(post, c->post_fork, 0) != hipSuccess) rc = HK_E_HIP;
+        c->stream = post;
+      } else {
+        rc = run_demodulation_fused(c, nch, clampr(b0 - 15), clampr(b1 + 15));
       }
-      // the reference's per-channel loop, with the channels of each step fused into one launch
-      if ((rc = run_demodulation_fused(c, nch, clampr(b0 - 15), clampr(b1 + 15)))) return rc;
-      // demodulation was the last reader of the light passes' render / variance planes: from here on nothing this frame still
-      // does is touched by the next frame's light passes - the four levels go to post_stream (a single-band, untimed frame)
-      const uint32_t level_bits = (1u << HK_PASS_DENOISE_L0) | (1u << HK_PASS_DENOISE_L1) | (1u << HK_PASS_DENOISE_L2) | (1u << HK_PASS_DENOISE_L3);
-      // (round 4: bands too - a 135-row band leaves most of the chip idle, the next frame's light passes fit beside its a-trous levels;
-      // whoever reads the frame's output - exchange D, the gather, a host - joins the post stream first)
-      const bool pipelined = c->post_stream && c->frame_pipeline && !(c->timing_mask & level_bits) && c->albedo_twin;
-      hipStream_t main_stream = c->stream;
-      if (pipelined) {
-        HK_HIP(hipEventRecord(c->post_fork, c->stream));
-        HK_HIP(hipStreamWaitEvent(c->post_stream, c->post_fork, 0));
-        c->stream = c->post_stream;
-      }
-      rc = run_denoise_fused(c, nch, 0, clampr(b0 - 7), clampr(b1 + 7));
+      if (!rc) rc = run_denoise_fused(c, nch, 0, clampr(b0 - 7), clampr(b1 + 7));
       if (!rc) rc = run_denoise_fused(c, nch, 1, clampr(b0 - 3), clampr(b1 + 3));
       if (!rc) rc = run_denoise_fused(c, nch, 2, clampr(b0 - 1), clampr(b1 + 1));
       if (!rc) rc = run_denoise_fused(c, nch, 3, b0, b1, true);  // + tone mapping (post_process.rs:1226-1234) in the same launch
-      c->stream = main_stream;
-      if (rc) return rc;
-      if (pipelined) {
-        HK_HIP(hipEventRecord(c->post_done, c->post_stream));
-        c->post_pending = true;
-        c->post_parity = c->mapped_parity;
-      }
       if (c->timing_mask) {
-        (void)hipEventRecord(c->frame_stop, pipelined ? c->post_stream : c->stream);
+        (void)hipEventRecord(c->frame_stop, c->stream);
         c->frame_timed = true;
       }
+      const int rc2 = post_end(c, pipelined);
+      if (rc) return rc;
+      if (rc2) return rc2;
     } else {
       HK_RUN(HK_PASS_TONE_MAPPING, 0u, b0, b1);                   // post_process.rs:1226-1234
       if (c->timing_mask) {
@@ -1311,8 +1364,22 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
   const bool ex = c->comm != nullptr && c->band_count > 1;
   const uint32_t hist = c->history_now << 8;
   for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) {
-    if (ex && (s != HK_STAGE_TEMPORAL || hist) && (rc = comm_exchange(c, s <= HK_STAGE_SPATIAL ? (s | hist) : s, st))) return rc;
-    if ((rc = hk_frame_stage(c, s, st, flags))) return rc;
+    if (ex && s == HK_STAGE_POST_PROCESS) {
+      // exchange B feeds demodulation only: both leave the main stream (round 6) - the band's next frame does not wait for either
+      bool pipelined = false;
+      if ((rc = ready(c)) || (rc = post_begin(c, st, &pipelined))) return rc;
+      c->post_forked = pipelined;
+      if ((rc = comm_exchange(c, s, st))) {
+        (void)post_end(c, pipelined);
+        return rc;
+      }
+    } else if (ex && (s != HK_STAGE_TEMPORAL || hist) && (rc = comm_exchange(c, s <= HK_STAGE_SPATIAL ? (s | hist) : s, st))) {
+      return rc;
+    }
+    if ((rc = hk_frame_stage(c, s, st, flags))) {
+      if (c->post_forked) (void)post_end(c, true);
+      return rc;
+    }
   }
   if (flags & HK_FRAME_ANTIALIAS) {
     if (ex && (rc = comm_exchange(c, HK_STAGE_ANTIALIAS | hist, st))) return rc;

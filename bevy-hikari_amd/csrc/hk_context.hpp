@@ -110,16 +110,23 @@ struct hk_ctx {
   hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
   hipEvent_t fork_event = nullptr, join_event = nullptr;
   bool forked = false;                 // side_stream holds work the main stream has not waited for yet
-  // Frame pipelining (round 3): the a-trous levels + tone mapping of frame n run on a third stream, so that the main stream goes
-  // straight on to frame n + 1's primary rays and light passes (which read none of the denoiser's buffers).  What both touch is
-  // double-buffered by frame parity: albedo, depth gradient and the derived planes (dn_g, depth) the a-trous taps read.
+  // Frame pipelining (round 3; round 6: the whole post-processing).  Demodulation, the a-trous levels and tone mapping of frame n - and,
+  // on a band with a communicator, the halo exchange B in front of them - run on a third stream, so that the main stream goes straight
+  // on to frame n + 1's primary rays and light passes.  What both touch is double-buffered by frame parity: albedo, depth gradient, the
+  // derived planes (dn_g, depth) the a-trous taps read, and (round 6) the render / variance planes the light passes write and
+  // demodulation reads.  Stream order keeps the denoiser's own planes safe (post-processing n + 1 follows post-processing n); the main
+  // stream waits for the post-processing of the LAST FRAME OF THE SAME PARITY before it writes that parity's planes again.
   hipStream_t post_stream = nullptr;
-  hipEvent_t post_fork = nullptr, post_done = nullptr;
-  bool post_pending = false;           // post_stream holds work the main stream has not waited for yet
-  uint32_t post_parity = 0;            // mapped_parity of the frame whose a-trous levels are (were last) on post_stream
+  hipEvent_t post_fork = nullptr;
+  hipEvent_t post_done[2] = {nullptr, nullptr};  // post stream: end of the post-processing of the last frame of that parity
+  bool post_pending[2] = {false, false};        // ... which the main stream has not waited for yet
+  bool post_forked = false;                     // hk_frame_render moved the context to the post stream ahead of stage POST_PROCESS (exchange B goes there too)
+  hipStream_t post_saved_main = nullptr;
   void* albedo_twin = nullptr;         // the planes of the OTHER frame parity (swapped with buf[HK_BUF_ALBEDO] ... in hk_frame_begin)
   void* depth_gradient_twin = nullptr;
   void* dn_g_twin = nullptr;
+  void* render_twin[3] = {nullptr, nullptr, nullptr};
+  void* variance_twin[3] = {nullptr, nullptr, nullptr};
   // test / measurement switches (hikari_hip_debug.h hk_debug_set_option; the library reads no environment variable)
   int spatial_window = -1;               // which form of k_spatial_reuse a launch takes: -1 by its size, 0 plain, 1 windowed (kernels.hip launch_spatial)
   uint64_t spatial_windowed_launches = 0;
@@ -128,6 +135,7 @@ struct hk_ctx {
   bool flat_walk = true;                 // the one-level tree for scenes under one transform (scene_layout.hip)
   int flat_orderings = 0;                // ... with this many direction orderings (0: as many as fit 4 KB)
   bool trace_update = false;             // timings of scene updates on stderr
+  int post_demodulation = -1;            // demodulation on the post stream with the levels: -1 by the rule (context.hip demod_on_post), 0 no, 1 yes
 
   // host copies of the reference-layout scene (kept for the layout conversion)
   std::vector<HkVertex> vertices;
