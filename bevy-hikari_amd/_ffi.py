@@ -48,7 +48,7 @@ CTX_COUNT_WALKS = 512   # the trace stages run the counting twin of their kernel
 (DEBUG_OPT_SPATIAL_WINDOW, DEBUG_OPT_FRAME_PIPELINE, DEBUG_OPT_WF_TIMELINE, DEBUG_OPT_FLAT_WALK, DEBUG_OPT_FLAT_ORDERINGS, DEBUG_OPT_TRACE_UPDATE, DEBUG_OPT_POST_DEMODULATION) = range(7)  # hikari_hip_debug.h hk_debug_set_option
 TIMING_TRACE_STAGES = 18  # hk_set_timing_mask bit / HkStats slot: every trace launch of the queue-based indirect pass
 TRAVERSAL_WIDE = 0x100
-FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS, FRAME_GATHER = 1, 2, 4, 8
+FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS, FRAME_GATHER, FRAME_TIME_BAND = 1, 2, 4, 8, 16
 TOPOLOGY_TRIANGLE_LIST, TOPOLOGY_TRIANGLE_STRIP = 0, 1
 TAA_JASMINE, TAA_NONE = 0, 1
 UPSCALE_FSR1, UPSCALE_SMAA_TU4X = 0, 1
@@ -245,6 +245,12 @@ _PRODUCT_ONLY = {
     "band_rows": [u32, u32, u32, P(u32), P(u32)],
     "balanced_band_bounds": [P(u32), u32, u32, u32, u32, u32, f32, P(u32)],
     "balance_bands": [_vp, u32, P(u32), u32],
+    "rebalanced_band_bounds": [P(u32), P(f32), u32, u32, P(f32), u32, u32, f32, P(u32)],
+    "band_migration_plan": [u32, u32, f32, P(u32), P(u32), u32, u32, u32, P(HkSettings), P(HkHaloOp), P(u32)],
+    "band_migration_schedule": [u32, u32, f32, P(u32), P(u32), u32, u32, u32, P(HkSettings), P(HkTransfer), P(u32)],
+    "migrate_bands": [_vp, P(u32), u32, u32, P(HkSettings)],
+    "band_time_ms": [_vp, P(f32)],
+    "multi_migrate_bands": [_vp, P(u32), u32, u32, P(HkSettings)],
     "band_gather_schedule": [u32, u32, f32, u32, P(u32), u32, u32, u32, u32, P(HkTransfer), P(u32)],
     "comm_gather": [_vp, u32, u32],
     "multi_gather": [_vp, u32, u32],

@@ -209,6 +209,26 @@ int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
   return HK_OK;
 }
 
+// hk_migrate_bands: the rows of the history reservoirs that change owner between two splits, as one exchange in stream order
+int comm_migrate(hk_ctx* c, const uint32_t* old_bounds, const uint32_t* new_bounds, uint32_t next_frame_number, const HkSettings* st) {
+  Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
+  HK_REQUIRE(cm && cm->comm, HK_E_NOT_READY, "no communicator attached (hk_comm_init): a host with its own transport moves hk_band_migration_schedule's rows itself");
+  Rccl* R = rccl();
+  HK_REQUIRE(R, HK_E_UNSUPPORTED, "librccl could not be loaded");
+  CtxInfo ci;
+  int rc = ctx_info(c, &ci);
+  if (rc) return rc;
+  uint32_t n = 0;
+  if ((rc = hk_band_migration_schedule(ci.width, ci.height, ci.ratio, old_bounds, new_bounds, cm->rank, cm->n_ranks, next_frame_number, st, nullptr, &n))) return rc;
+  std::vector<HkTransfer> tr(n);
+  if (n && (rc = hk_band_migration_schedule(ci.width, ci.height, ci.ratio, old_bounds, new_bounds, cm->rank, cm->n_ranks, next_frame_number, st, tr.data(), &n))) return rc;
+  if (tr.empty()) return HK_OK;
+  HK_HIP(hipSetDevice(ci.device));
+  if ((rc = run_ordered(c, cm, R, tr.data(), tr.size(), (hipStream_t)ci.stream, true))) return rc;
+  cm->exchanges += 1;
+  return HK_OK;
+}
+
 // the root collects every other band's rows of `buffer` (ncclSend / ncclRecv pairs in one group, on the stream)
 int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root, bool overlap) {
   Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
@@ -316,27 +336,9 @@ struct MultiPool {
 
 namespace {
 
-// everything band i receives before `stage_arg`, as peer copies on i's stream; events order them against the owners' streams
-int multi_exchange(hk_multi* m, uint32_t stage_arg, const HkSettings* st) {
+// the receive side of one transfer list per band as peer copies on the receiver's stream, ordered by events against the owners' streams
+int multi_run_plans(hk_multi* m, const std::vector<const std::vector<HkTransfer>*>& plans, const std::vector<CtxInfo>& ci) {
   const uint32_t n = (uint32_t)m->ctx.size();
-  if (n < 2) return HK_OK;
-  std::vector<const std::vector<HkTransfer>*> plans(n, nullptr);
-  std::vector<CtxInfo> ci(n);
-  bool any = false;
-  if (m->cache.size() > 1024) m->cache.clear();
-  for (uint32_t i = 0; i < n; ++i) {
-    int rc = ctx_info(m->ctx[i], &ci[i]);
-    if (rc) return rc;
-    HK_REQUIRE(ci[i].width > 0, HK_E_NOT_READY, "hk_multi_resize has not been called");
-    if ((rc = schedule_for(m->cache, ci[i], i, n, stage_arg, st, &plans[i]))) return rc;
-    any = any || !plans[i]->empty();
-  }
-  if (!any) return HK_OK;
-  if ((stage_arg & 0xffu) >= HK_STAGE_ANTIALIAS)  // exchanges D / E read what the post stream wrote (frame pipelining)
-    for (uint32_t i = 0; i < n; ++i) {
-      const int rj = ctx_join_side(m->ctx[i]);
-      if (rj) return rj;
-    }
   // 1. every band: "produced" recorded on its stream (hk_frame_stage has joined the side stream wherever an exchange reads
   //    what the direct-light dispatches wrote; exchange A therefore overlaps them)
   for (uint32_t i = 0; i < n; ++i) {
@@ -378,6 +380,30 @@ int multi_exchange(hk_multi* m, uint32_t stage_arg, const HkSettings* st) {
       if (read_by[p * n + i]) HK_HIP(hipStreamWaitEvent((hipStream_t)ci[p].stream, m->copied[i], 0));
   }
   return HK_OK;
+}
+
+// everything band i receives before `stage_arg`, as peer copies on i's stream; events order them against the owners' streams
+int multi_exchange(hk_multi* m, uint32_t stage_arg, const HkSettings* st) {
+  const uint32_t n = (uint32_t)m->ctx.size();
+  if (n < 2) return HK_OK;
+  std::vector<const std::vector<HkTransfer>*> plans(n, nullptr);
+  std::vector<CtxInfo> ci(n);
+  bool any = false;
+  if (m->cache.size() > 1024) m->cache.clear();
+  for (uint32_t i = 0; i < n; ++i) {
+    int rc = ctx_info(m->ctx[i], &ci[i]);
+    if (rc) return rc;
+    HK_REQUIRE(ci[i].width > 0, HK_E_NOT_READY, "hk_multi_resize has not been called");
+    if ((rc = schedule_for(m->cache, ci[i], i, n, stage_arg, st, &plans[i]))) return rc;
+    any = any || !plans[i]->empty();
+  }
+  if (!any) return HK_OK;
+  if ((stage_arg & 0xffu) >= HK_STAGE_ANTIALIAS)  // exchanges D / E read what the post stream wrote (frame pipelining)
+    for (uint32_t i = 0; i < n; ++i) {
+      const int rj = ctx_join_side(m->ctx[i]);
+      if (rj) return rj;
+    }
+  return multi_run_plans(m, plans, ci);
 }
 
 // band i's side of multi_exchange, on band i's thread.  Returns HK_OK or the error; false from a barrier = some other band failed.
@@ -745,6 +771,29 @@ int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b) { HK
 int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode) { HK_EACH(hk_rebuild_scene_trees(c, mode)); }
 // the same explicit split on every band's context (all of them must agree: the schedules are derived per context)
 int hk_multi_set_band_bounds(hk_multi* m, const uint32_t* bounds, uint32_t n_bounds) { HK_EACH(hk_set_band_bounds(c, bounds, n_bounds)); }
+// the rows of the history reservoirs that change owner travel between the bands' contexts, then every band takes the new split
+int hk_multi_migrate_bands(hk_multi* m, const uint32_t* new_bounds, uint32_t n_bounds, uint32_t next_frame_number, const HkSettings* st) {
+  HK_REQUIRE(m && st, HK_E_INVALID, "NULL argument");
+  const uint32_t n = (uint32_t)m->ctx.size();
+  HK_REQUIRE(!new_bounds || n_bounds == n + 1, HK_E_INVALID, "need band_count + 1 = %u boundaries", n + 1);
+  int rc;
+  if (n > 1) {
+    std::vector<CtxInfo> ci(n);
+    std::vector<std::vector<HkTransfer>> lists(n);
+    std::vector<const std::vector<HkTransfer>*> plans(n, nullptr);
+    for (uint32_t i = 0; i < n; ++i) {
+      if ((rc = ctx_join_side(m->ctx[i])) || (rc = ctx_info(m->ctx[i], &ci[i]))) return rc;
+      HK_REQUIRE(ci[i].width > 0, HK_E_NOT_READY, "hk_multi_resize has not been called");
+      uint32_t k = 0;
+      if ((rc = hk_band_migration_schedule(ci[i].width, ci[i].height, ci[i].ratio, ci[i].band_bounds, new_bounds, i, n, next_frame_number, st, nullptr, &k))) return rc;
+      lists[i].resize(k);
+      if (k && (rc = hk_band_migration_schedule(ci[i].width, ci[i].height, ci[i].ratio, ci[i].band_bounds, new_bounds, i, n, next_frame_number, st, lists[i].data(), &k))) return rc;
+      plans[i] = &lists[i];
+    }
+    if ((rc = multi_run_plans(m, plans, ci))) return rc;
+  }
+  return hk_multi_set_band_bounds(m, new_bounds, new_bounds ? n_bounds : 0u);
+}
 // the builder is finished ONCE (its transform bookkeeping advances once), every band's replica takes the records and builds its trees
 int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t tree_mode) {
   HK_REQUIRE(m && b, HK_E_INVALID, "NULL argument");

@@ -851,6 +851,8 @@ void hk_destroy(hk_ctx* c) {
   comm_release(c);
   drain_timers(c);
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->band_ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->frame_start) (void)hipEventDestroy(c->frame_start);
   if (c->frame_stop) (void)hipEventDestroy(c->frame_stop);
   free_screen(c);
@@ -1171,6 +1173,31 @@ int hk_balance_bands(hk_ctx* c, uint32_t min_rows, uint32_t* bounds_out, uint32_
   return HK_OK;
 }
 
+int hk_band_time_ms(hk_ctx* c, float* ms) {
+  HK_REQUIRE(c && ms, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(c->band_timed, HK_E_NOT_READY, "no frame has been rendered with HK_FRAME_TIME_BAND");
+  HK_HIP(hipSetDevice(c->device));
+  HK_HIP(hipEventSynchronize(c->band_ev[3]));
+  float a = 0.0f, b = 0.0f;
+  HK_HIP(hipEventElapsedTime(&a, c->band_ev[0], c->band_ev[1]));
+  HK_HIP(hipEventElapsedTime(&b, c->band_ev[2], c->band_ev[3]));
+  *ms = a + b;
+  return HK_OK;
+}
+
+int hk_migrate_bands(hk_ctx* c, const uint32_t* new_bounds, uint32_t n_bounds, uint32_t next_frame_number, const HkSettings* st) {
+  HK_REQUIRE(c && st, HK_E_INVALID, "NULL argument");
+  HK_REQUIRE(c->RH > 0, HK_E_NOT_READY, "hk_resize has not been called");
+  HK_REQUIRE(!new_bounds || n_bounds == c->band_count + 1, HK_E_INVALID, "need band_count + 1 = %u boundaries", c->band_count + 1);
+  HK_REQUIRE(band_bounds_valid(new_bounds, c->band_count, (uint32_t)c->RH), HK_E_INVALID, "band bounds must run 0 = b[0] < b[1] < ... < b[%u] = %d", c->band_count, c->RH);
+  HK_HIP(hipSetDevice(c->device));
+  int rc = join_all(c);
+  if (rc) return rc;
+  const uint32_t* old_bounds = c->band_bounds.size() == (size_t)c->band_count + 1 ? c->band_bounds.data() : nullptr;
+  if (c->band_count > 1 && (rc = comm_migrate(c, old_bounds, new_bounds, next_frame_number, st))) return rc;
+  return hk_set_band_bounds(c, new_bounds, new_bounds ? n_bounds : 0u);
+}
+
 int hk_band_plan(hk_ctx* c, uint32_t stage, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
   HK_REQUIRE(c && c->W > 0, HK_E_NOT_READY, "hk_resize has not been called");
   HK_REQUIRE(c->have_frame, HK_E_NOT_READY, "hk_frame_begin has not been called");
@@ -1376,9 +1403,20 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
     } else if (ex && (s != HK_STAGE_TEMPORAL || hist) && (rc = comm_exchange(c, s <= HK_STAGE_SPATIAL ? (s | hist) : s, st))) {
       return rc;
     }
+    const bool timed = (flags & HK_FRAME_TIME_BAND) && s <= HK_STAGE_SPATIAL;  // (behind the exchange: the wait for the neighbours is not the band's time)
+    if (timed) {
+      for (int k = 0; k < 4; ++k)
+        if (!c->band_ev[k]) HK_HIP(hipEventCreate(&c->band_ev[k]));
+      HK_HIP(hipEventRecord(c->band_ev[2 * s], c->stream));
+    }
     if ((rc = hk_frame_stage(c, s, st, flags))) {
       if (c->post_forked) (void)post_end(c, true);
       return rc;
+    }
+    if (timed) {
+      if (s == HK_STAGE_TEMPORAL && (rc = join_side(c))) return rc;  // (the direct-light dispatches are the band's work too)
+      HK_HIP(hipEventRecord(c->band_ev[2 * s + 1], c->stream));
+      if (s == HK_STAGE_SPATIAL) c->band_timed = true;
     }
   }
   if (flags & HK_FRAME_ANTIALIAS) {

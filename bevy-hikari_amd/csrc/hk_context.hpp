@@ -258,6 +258,8 @@ struct hk_ctx {
   void* comm = nullptr;        // RCCL communicator state, owned by comm.cpp (hk_comm_init)
   uint32_t history_rows = HK_HISTORY_AUTO;  // exchange C rows asked for (hk_set_history_rows): a count, or derived per frame
   uint32_t history_now = 0;    // ... in force for the frame most recently begun (0 for a single band)
+  hipEvent_t band_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // HK_FRAME_TIME_BAND: around stage TEMPORAL, around stage SPATIAL (main stream)
+  bool band_timed = false;
 
   // statistics
   unsigned long long* d_counters = nullptr;  // primary, tlas, blas, node steps, triangle tests, instance entries, closest hits (hk_light.hpp flush_counters)

@@ -89,6 +89,7 @@ void** ctx_comm_slot(hk_ctx* c);       // owned by comm.cpp (NULL = no communica
 int ctx_join_side(hk_ctx* c);          // main stream waits for the side stream
 // run before `stage` by hk_frame_render when a communicator is attached
 int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st);
+int comm_migrate(hk_ctx* c, const uint32_t* old_bounds, const uint32_t* new_bounds, uint32_t next_frame_number, const HkSettings* st);  // hk_migrate_bands
 void comm_release(hk_ctx* c);          // hk_destroy
 
 }  // namespace hk

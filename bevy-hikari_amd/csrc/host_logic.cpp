@@ -683,4 +683,152 @@ int hk_balanced_band_bounds(const uint32_t* row_cost, uint32_t cost_rows, uint32
   return HK_OK;
 }
 
+// ---- bands of equal MEASURED time (round 6) -----------------------------------------------------------------
+// The split by geometry pixels (hk_balanced_band_bounds) prices every geometry pixel alike; rows of a city-class frame differ three
+// times in walk length, and a band's fixed cost does not shrink with its rows.  The controller below needs no model: after some
+// frames every rank contributes ONE number - the time its band took - and the boundaries move towards equal times.
+//   bounds[band_count + 1]   the split in force (0 = b0 < ... < bN = render_rows)
+//   band_ms[band_count]      what each band took (any unit; <= 0 or non-finite entries: no information - the split stays)
+//   row_weight[render_rows]  optional prior of how cost is spread INSIDE a band (e.g. geometry pixels per row + a floor): a band's
+//                            measured time is distributed over its rows in proportion; NULL = evenly
+//   damping in (0, 1]        the fraction of the way to the predicted optimum a boundary moves per call (cost per row is not constant
+//                            and part of a band's time is fixed cost: the prediction overshoots; 0.5 converges in 3-5 calls)
+//   max_shift                rows a boundary may move per call (0 = no limit): the rows that change owner travel as one migration
+//                            (hk_band_migration_plan) and every moved row costs W x 64 B per history buffer
+// Deterministic, pure: every rank that evaluates it on the same numbers gets the same boundaries.
+int hk_rebalanced_band_bounds(const uint32_t* bounds, const float* band_ms, uint32_t band_count, uint32_t render_rows, const float* row_weight, uint32_t min_rows,
+                              uint32_t max_shift, float damping, uint32_t* out) {
+  HK_REQUIRE(bounds && band_ms && out && band_count > 0 && render_rows >= band_count, HK_E_INVALID, "bad argument");
+  HK_REQUIRE(band_bounds_valid(bounds, band_count, render_rows), HK_E_INVALID, "band bounds must run 0 = b[0] < b[1] < ... < b[%u] = %u", band_count, render_rows);
+  min_rows = std::max(min_rows, 1u);
+  HK_REQUIRE((uint64_t)min_rows * band_count <= render_rows, HK_E_INVALID, "min_rows x band_count exceeds the %u render rows", render_rows);
+  HK_REQUIRE(std::isfinite(damping) && damping > 0.0f && damping <= 1.0f, HK_E_INVALID, "damping must lie in (0, 1]");
+  std::copy(bounds, bounds + band_count + 1, out);
+  double total = 0.0;
+  for (uint32_t i = 0; i < band_count; ++i) {
+    if (!(std::isfinite(band_ms[i]) && band_ms[i] > 0.0f)) return HK_OK;  // no information from some band: keep the split
+    total += (double)band_ms[i];
+  }
+  // cumulative cost over the rows: band i's time spread over its rows by the prior
+  std::vector<double> prefix(render_rows + 1, 0.0);
+  for (uint32_t i = 0; i < band_count; ++i) {
+    double wsum = 0.0;
+    for (uint32_t y = bounds[i]; y < bounds[i + 1]; ++y) {
+      const double w = row_weight ? (double)row_weight[y] : 1.0;
+      wsum += (std::isfinite(w) && w > 0.0) ? w : 0.0;
+    }
+    const uint32_t rows = bounds[i + 1] - bounds[i];
+    for (uint32_t y = bounds[i]; y < bounds[i + 1]; ++y) {
+      double w = row_weight ? (double)row_weight[y] : 1.0;
+      w = (std::isfinite(w) && w > 0.0) ? w : 0.0;
+      const double share = wsum > 0.0 ? w / wsum : 1.0 / (double)rows;
+      prefix[y + 1] = prefix[y] + (double)band_ms[i] * share;
+    }
+  }
+  for (uint32_t k = 1; k < band_count; ++k) {
+    const double target = total * (double)k / (double)band_count;
+    // the row position (fractional) where the cumulative cost reaches the target
+    uint32_t y = (uint32_t)(std::upper_bound(prefix.begin(), prefix.end(), target) - prefix.begin());  // first prefix > target
+    y = std::min(std::max(y, 1u), render_rows);
+    const double seg = prefix[y] - prefix[y - 1];
+    const double pos = (double)(y - 1) + (seg > 0.0 ? (target - prefix[y - 1]) / seg : 0.0);
+    double moved = (double)bounds[k] + (double)damping * (pos - (double)bounds[k]);
+    if (max_shift > 0u) moved = std::min(std::max(moved, (double)bounds[k] - (double)max_shift), (double)bounds[k] + (double)max_shift);
+    long r = std::lround(moved);
+    r = std::max<long>(r, (long)out[k - 1] + (long)min_rows);                              // at least min_rows in the band before
+    r = std::min<long>(r, (long)render_rows - (long)(band_count - k) * (long)min_rows);   // ... and in every band after
+    out[k] = (uint32_t)r;
+  }
+  out[band_count] = render_rows;
+  return HK_OK;
+}
+
+// What travels when the split changes between two frames (round 6).  A band keeps per-pixel state from frame to frame - the
+// reservoirs the next frame reads as history (light.rs:518-546: the three temporal outputs, and the spatial outputs whose pass is on) -
+// for the rows it OWNS; rows that change owner must reach the new owner before it renders them, or it would find its own stale
+// records there.  (With the history halo of a moving camera, exchange C then delivers the rows around the NEW borders from their new
+// owners, as always.)  The anti-aliasing tail keeps more state (previous tone-mapped / TAA planes, previous G-buffer planes): a host
+// that runs it keeps the split fixed or treats a re-split as a cut.
+//   `next_frame_number` = the frame that will be rendered with `new_bounds` (the ping-pong parity of the buffers it reads).
+// ops (capacity *n_ops in, count out): rows [row_begin, row_end) of `buffer` that band `band_index` receives from `peer`, the band
+// that owned them under `old_bounds`.  NULL bounds = the equal split.
+int hk_band_migration_plan(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* old_bounds, const uint32_t* new_bounds, uint32_t band_index,
+                           uint32_t band_count, uint32_t next_frame_number, const HkSettings* st, HkHaloOp* ops, uint32_t* n_ops) {
+  HK_REQUIRE(st && n_ops && band_count > 0 && band_index < band_count, HK_E_INVALID, "bad argument");
+  uint32_t rw, rh;
+  int rc = hk_scaled_size(width, height, upscale_ratio, &rw, &rh);
+  if (rc) return rc;
+  HK_REQUIRE(rh >= band_count, HK_E_INVALID, "more bands than rows");
+  HK_REQUIRE(band_bounds_valid(old_bounds, band_count, rh) && band_bounds_valid(new_bounds, band_count, rh), HK_E_INVALID, "band bounds do not fit the render size");
+  const uint32_t cap = ops ? *n_ops : 0;
+  uint32_t n = 0;
+  uint32_t n0, n1, o0, o1;
+  band_rows_in(new_bounds, rh, rh, band_index, band_count, &n0, &n1);
+  band_rows_in(old_bounds, rh, rh, band_index, band_count, &o0, &o1);
+  const uint32_t current = next_frame_number % 2u;  // as exchange C: previous = buf[current + T], previous_spatial = buf[current + S]
+  std::vector<uint32_t> buffers = {HK_BUF_RESERVOIR0 + current + 0u, HK_BUF_RESERVOIR0 + current + 2u, HK_BUF_RESERVOIR0 + current + 6u};
+  if (st->emissive_spatial_reuse) buffers.push_back(HK_BUF_RESERVOIR0 + current + 4u);
+  if (st->indirect_spatial_reuse) buffers.push_back(HK_BUF_RESERVOIR0 + current + 8u);
+  for (uint32_t buffer : buffers)
+    for (uint32_t j = 0; j < band_count; ++j) {
+      if (j == band_index) continue;
+      uint32_t p0, p1;
+      band_rows_in(old_bounds, rh, rh, j, band_count, &p0, &p1);
+      const uint32_t a = std::max(n0, p0), b = std::min(n1, p1);   // rows this band owns now and band j owned before
+      if (a >= b) continue;
+      if (ops && n < cap) {
+        ops[n].buffer = buffer;
+        ops[n].peer = j;
+        ops[n].row_begin = a;
+        ops[n].row_end = b;
+        ops[n].row_bytes = (uint64_t)rw * buffer_bpp(buffer);
+      }
+      n += 1;
+    }
+  (void)o0;
+  (void)o1;
+  if (ops && n > cap) {
+    *n_ops = n;
+    HK_REQUIRE(false, HK_E_INVALID, "ops array too small: need %u", n);
+  }
+  *n_ops = n;
+  return HK_OK;
+}
+
+// ... as ONE global order of sends and receives that every rank derives identically (hk_band_schedule's contract)
+int hk_band_migration_schedule(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* old_bounds, const uint32_t* new_bounds, uint32_t rank,
+                               uint32_t n_ranks, uint32_t next_frame_number, const HkSettings* st, HkTransfer* out, uint32_t* n_out) {
+  HK_REQUIRE(st && n_out && n_ranks > 0 && rank < n_ranks, HK_E_INVALID, "bad argument");
+  const uint32_t cap = out ? *n_out : 0;
+  uint32_t n = 0;
+  std::vector<HkHaloOp> ops;
+  for (uint32_t r = 0; r < n_ranks; ++r) {
+    uint32_t k = 0;
+    int rc = hk_band_migration_plan(width, height, upscale_ratio, old_bounds, new_bounds, r, n_ranks, next_frame_number, st, nullptr, &k);
+    if (rc) return rc;
+    ops.resize(k);
+    if (k && (rc = hk_band_migration_plan(width, height, upscale_ratio, old_bounds, new_bounds, r, n_ranks, next_frame_number, st, ops.data(), &k))) return rc;
+    for (uint32_t i = 0; i < k; ++i) {
+      const HkHaloOp& op = ops[i];
+      const bool recv = r == rank, send = op.peer == rank;
+      if (!recv && !send) continue;
+      if (out && n < cap) {
+        out[n].buffer = op.buffer;
+        out[n].peer = recv ? op.peer : r;
+        out[n].is_recv = recv ? 1u : 0u;
+        out[n]._pad = 0;
+        out[n].offset = (uint64_t)op.row_begin * op.row_bytes;
+        out[n].bytes = (uint64_t)(op.row_end - op.row_begin) * op.row_bytes;
+      }
+      n += 1;
+    }
+  }
+  if (out && n > cap) {
+    *n_out = n;
+    HK_REQUIRE(false, HK_E_INVALID, "transfer array too small: need %u", n);
+  }
+  *n_out = n;
+  return HK_OK;
+}
+
 }  // extern "C"

@@ -105,6 +105,41 @@ def balanced_band_bounds(row_costs, width, render_rows, band_count, min_rows=8, 
     return [int(x) for x in out]
 
 
+def rebalanced_band_bounds(bounds, band_ms, render_rows, row_weight=None, min_rows=8, max_shift=0, damping=0.5):
+    """hk_rebalanced_band_bounds (pure host logic): the split `bounds` moved `damping` of the way towards equal MEASURED band times
+    `band_ms` (one number per band; a band's time spread over its rows evenly or by the prior row_weight[render_rows]), at most
+    max_shift rows per boundary (0: no limit), at least min_rows per band.  bounds None = the equal split."""
+    n = len(band_ms)
+    if bounds is None:
+        base, rem = divmod(int(render_rows), n)
+        bounds = [i * base + min(i, rem) for i in range(n)] + [int(render_rows)]
+    b = (C.c_uint32 * (n + 1))(*[int(x) for x in bounds])
+    ms = (C.c_float * n)(*[float(x) for x in band_ms])
+    w = None
+    if row_weight is not None:
+        rw = np.ascontiguousarray(row_weight, dtype=np.float32)
+        assert len(rw) == int(render_rows)
+        w = rw.ctypes.data_as(C.POINTER(C.c_float))
+    out = (C.c_uint32 * (n + 1))()
+    F.api().call("rebalanced_band_bounds", b, ms, n, int(render_rows), w, int(min(min_rows, max(1, int(render_rows) // n))), int(max_shift), float(damping), out)
+    return [int(x) for x in out]
+
+
+def band_migration_schedule(width, height, upscale_ratio, old_bounds, new_bounds, rank, n_ranks, next_frame_number, settings_c):
+    """hk_band_migration_schedule: the transfers of `rank` when the split changes from old_bounds to new_bounds before frame
+    `next_frame_number` - the rows of the history reservoirs that change owner (list of HkTransfer; None = the equal split)."""
+    api = F.api()
+    arr = lambda b: None if b is None else (C.c_uint32 * len(b))(*[int(x) for x in b])
+    ob, nb = arr(old_bounds), arr(new_bounds)
+    n = F.u32(0)
+    api.call("band_migration_schedule", width, height, upscale_ratio, ob, nb, rank, n_ranks, int(next_frame_number), C.byref(settings_c), None, C.byref(n))
+    tr = (F.HkTransfer * max(n.value, 1))()
+    n2 = F.u32(n.value)
+    if n.value:
+        api.call("band_migration_schedule", width, height, upscale_ratio, ob, nb, rank, n_ranks, int(next_frame_number), C.byref(settings_c), tr, C.byref(n2))
+    return [tr[i] for i in range(n2.value)]
+
+
 class BandRenderer:
     """Drives one rank's band of the frame; `engine` is a bevy_hikari_amd.Engine (or, in the CPU tests, the oracle behind
     the same class).  transport: "rccl" (the product: exchanges inside the library) or "host" (tests, see the module text)."""
@@ -124,6 +159,7 @@ class BandRenderer:
         self._generation = getattr(engine, "generation", 0)
         self.rccl_error = None
         self.bounds = None
+        self._band_ms = 0.0
         engine.set_band(rank, world_size)
         if bounds is not None:
             self.set_bounds(bounds)
@@ -249,6 +285,60 @@ class BandRenderer:
             self.torch.cuda.synchronize()  # the halo rows are in place before the next stage is enqueued on the engine's stream
         return nbytes
 
+    def rebalance(self, my_band_ms, next_frame_number, settings, width, height, damping=0.5, max_shift=0, min_rows=8, row_weight=None):
+        """Bands of equal MEASURED time (round 6): every rank contributes the time its band took (`band_time_ms()` after a frame rendered
+        with time_band=True, or any per-band figure), ONE all-gather of world_size floats over the process group, every rank evaluates
+        hk_rebalanced_band_bounds on the same numbers, the rows of the history reservoirs that change owner travel (RCCL inside the
+        library, or the host transport in the tests), and the new split is in force for frame `next_frame_number`.  Returns the new
+        boundaries (unchanged boundaries: nothing moves).  Call it between two frames, on every rank."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return self.bounds
+        self._follow_resize()
+        t = self.torch.zeros(self.world, dtype=self.torch.float32)
+        t[self.rank] = float(my_band_ms)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)   # (an all-gather of one float per rank)
+        sc = settings.to_c()
+        _w, rh, _b = self.engine.buffer_info(F.BUF_TONE_MAPPED)
+        new = rebalanced_band_bounds(self.bounds, [float(x) for x in t], rh, row_weight, min_rows, max_shift, damping)
+        old = self.bounds
+        if old is not None and new == [int(b) for b in old]:
+            return self.bounds
+        if self.transport == "rccl":
+            self.engine.migrate_bands(new, next_frame_number, sc)
+            self.bounds = new
+            self._plans = {}
+            return new
+        # host transport (tests): the migration's transfers through host memory, then the new split
+        self.engine.wait()
+        ops, landing = [], []
+        for tr in band_migration_schedule(width, height, settings.upscale.ratio(), old, new, self.rank, self.world, next_frame_number, sc):
+            view = self._view(tr.buffer, next_frame_number & 1)[tr.offset:tr.offset + tr.bytes]
+            if tr.is_recv:
+                if self.device == "cuda":
+                    tmp = self.torch.empty(view.numel(), dtype=self.torch.uint8)
+                    landing.append((view, tmp))
+                    view = tmp
+                ops.append(dist.P2POp(dist.irecv, view, tr.peer))
+            else:
+                ops.append(dist.P2POp(dist.isend, view.cpu() if self.device == "cuda" else view.clone(), tr.peer))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for view, tmp in landing:
+            view.copy_(tmp)
+        if landing:
+            self.torch.cuda.synchronize()
+        self.set_bounds(new)
+        return new
+
+    def band_time_ms(self):
+        """the band's own time in the last frame rendered with time_band=True (without the waits for the neighbours' halos)"""
+        if self.transport == "rccl":
+            return self.engine.band_time_ms()
+        return self._band_ms
+
     def gather(self, buffer, settings, width, height, frame_number, root=0):
         """SURVEY 8e step 7 through the host transport (tests): band `root` collects every band's rows of `buffer`."""
         import torch.distributed as dist
@@ -275,7 +365,7 @@ class BandRenderer:
         if landing:
             self.torch.cuda.synchronize()
 
-    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=None, antialias=False, balance=False, gather=False):
+    def render(self, frame, view, previous_view, lights, settings, width, height, history_rows=None, antialias=False, balance=False, gather=False, time_band=False):
         """One frame of this rank's band.  history_rows: rows of last frame's reservoirs fetched from the neighbouring bands before
         stage TEMPORAL (exchange C; the bands then also hand each other the scatter stores that cross a border, with exchange A).
         None = derived per frame by the library from the frame's own uniforms (hk_history_rows_bound: 0 for a static view), a
@@ -294,7 +384,8 @@ class BandRenderer:
             e.set_history_rows(F.HISTORY_AUTO if history_rows is None else int(history_rows))
         if self.transport == "rccl":
             e.frame_render(frame, view, previous_view, lights, sc,
-                           (F.FRAME_ANTIALIAS if antialias else 0) | (F.FRAME_BALANCE_BANDS if balance else 0) | (F.FRAME_GATHER if gather else 0))
+                           (F.FRAME_ANTIALIAS if antialias else 0) | (F.FRAME_BALANCE_BANDS if balance else 0) | (F.FRAME_GATHER if gather else 0) |
+                           (F.FRAME_TIME_BAND if time_band else 0))
             if balance:
                 self.bounds = e.band_bounds()
             return
@@ -308,11 +399,17 @@ class BandRenderer:
         if history_rows > 0:
             e.wait()
             self.exchange(F.STAGE_TEMPORAL | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
+        import time as _time
+
+        t0 = _time.perf_counter()
         e.frame_stage(F.STAGE_TEMPORAL, sc)
         e.wait()
+        t1 = _time.perf_counter()
         self.exchange(F.STAGE_SPATIAL | (int(history_rows) << 8), frame.number, sc, width, height, ratio)
+        t2 = _time.perf_counter()
         e.frame_stage(F.STAGE_SPATIAL, sc)
         e.wait()
+        self._band_ms = ((t1 - t0) + (_time.perf_counter() - t2)) * 1e3   # (the host transport's band time: the two stages, not the exchanges)
         self.exchange(F.STAGE_POST_PROCESS, frame.number, sc, width, height, ratio)
         e.frame_stage(F.STAGE_POST_PROCESS, sc)
         if antialias:  # SMAA Tu4x / TAA on the band: exchange D = tone-mapped rows + last frame's TAA rows
@@ -391,6 +488,15 @@ class MultiEngine:
     def gather(self, buffer, root=0):
         """hk_multi_gather: band `root`'s context collects every band's rows of `buffer` on its own device."""
         self.api.call("multi_gather", self.h, buffer, root)
+
+    def migrate_bands(self, new_bounds, next_frame_number, settings_c):
+        """hk_multi_migrate_bands: the history rows that change owner travel between the bands' contexts (peer copies), then every
+        band takes the new split (None = equal)."""
+        if new_bounds is None:
+            self.api.call("multi_migrate_bands", self.h, None, 0, int(next_frame_number), C.byref(settings_c))
+        else:
+            arr = (C.c_uint32 * len(new_bounds))(*[int(b) for b in new_bounds])
+            self.api.call("multi_migrate_bands", self.h, arr, len(new_bounds), int(next_frame_number), C.byref(settings_c))
 
     def set_band_bounds(self, bounds=None):
         """hk_multi_set_band_bounds: bands of unequal height, the same split on every context (None = equal)."""

@@ -558,6 +558,22 @@ class Engine:
         self.set_band_bounds(bounds)
         return bounds
 
+    def migrate_bands(self, new_bounds, next_frame_number, settings_c):
+        """hk_migrate_bands (needs a communicator): the history rows that change owner travel as one RCCL exchange, then the new split is
+        set.  Every rank calls it with the same arguments between two frames.  new_bounds None = the equal split."""
+        if new_bounds is None:
+            self.api.call("migrate_bands", self.ctx, None, 0, int(next_frame_number), C.byref(settings_c))
+        else:
+            arr = (C.c_uint32 * len(new_bounds))(*[int(b) for b in new_bounds])
+            self.api.call("migrate_bands", self.ctx, arr, len(new_bounds), int(next_frame_number), C.byref(settings_c))
+
+    def band_time_ms(self):
+        """hk_band_time_ms: the band's own GPU time (stage TEMPORAL + stage SPATIAL, without the waits for its neighbours' halos) in the
+        last frame rendered with F.FRAME_TIME_BAND."""
+        ms = C.c_float()
+        self.api.call("band_time_ms", self.ctx, C.byref(ms))
+        return float(ms.value)
+
     def row_costs(self):
         """hk_row_costs: geometry pixels per full-size row of the frame most recently begun (numpy uint32[height])."""
         _w, h, _b = self.buffer_info(F.BUF_POSITION)

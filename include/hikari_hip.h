@@ -604,6 +604,10 @@ int hk_pass_run(hk_ctx* ctx, uint32_t pass, uint32_t arg, uint32_t row_begin, ui
  * ordered against the context's stream by events; the tone-mapped image is double-buffered by frame parity): the image on band 0 is
  * complete once hk_frame_wait, any buffer access, or the hk_frame_begin of the frame after next has been passed. */
 #define HK_FRAME_GATHER 8u
+/* flags bit4 (hk_frame_render; round 6): take THIS frame's band time - HIP events on the context's stream around stage TEMPORAL and
+ * around stage SPATIAL, i.e. the band's own work on the critical cycle of a sharded frame WITHOUT the waits for its neighbours' halos
+ * in between (with a communicator every band's wall clock shows the slowest band's time; this does not) - for hk_band_time_ms. */
+#define HK_FRAME_TIME_BAND 16u
 int hk_frame_stage(hk_ctx* ctx, uint32_t stage, const HkSettings* settings, uint32_t flags);
 /* hk_frame_begin + TEMPORAL, SPATIAL, POST_PROCESS (+ ANTIALIAS with HK_FRAME_ANTIALIAS): single GPU, no halo exchange */
 int hk_frame_render(hk_ctx* ctx, const HkFrame* frame, const HkView* view, const HkPreviousView* previous_view,
@@ -636,6 +640,33 @@ int hk_balance_bands(hk_ctx* ctx, uint32_t min_rows, uint32_t* bounds_out, uint3
 int hk_row_costs(hk_ctx* ctx, uint32_t* geometry_pixels_per_row, uint32_t n_rows /* = the full-size height */);
 int hk_balanced_band_bounds(const uint32_t* row_cost, uint32_t cost_rows, uint32_t width, uint32_t render_rows, uint32_t band_count,
                             uint32_t min_rows, float background_cost /* of a background pixel, geometry pixel = 1; <= 0: 1/16 */, uint32_t* bounds);
+/* Bands of equal MEASURED time (round 6).  The split by geometry pixels prices every geometry pixel alike; the rows of a city-class
+ * frame differ three times in walk length, and part of a band's time is fixed cost.  So: every M frames each rank takes its band's
+ * GPU time (hk_frame_render(.., HK_FRAME_TIME_BAND), hk_band_time_ms), the ranks all-gather these N floats over the host's channel,
+ * and every rank evaluates the same pure function on them:
+ *   hk_rebalanced_band_bounds  bounds[band_count + 1] in force + band_ms[band_count] -> out[band_count + 1]: the boundaries moved
+ *                          `damping` (0..1] of the way towards equal times (a band's time spread over its rows evenly, or by the
+ *                          optional prior row_weight[render_rows], e.g. geometry pixels per row), at most max_shift rows per call
+ *                          (0: no limit), at least min_rows per band.  A band without a usable time keeps the split as it is.
+ *   hk_band_migration_plan / _schedule  what must travel when the split changes between two frames: the rows of the history
+ *                          reservoirs (the three temporal outputs + the spatial outputs whose pass is on: what frame
+ *                          `next_frame_number` reads as history) that change owner, from the band that owned them under old_bounds to
+ *                          the band that owns them under new_bounds (NULL = the equal split) - the same row plan / one global order
+ *                          of sends and receives as hk_band_plan / hk_band_schedule.  After it every band holds, for the rows it now
+ *                          owns, exactly what their previous owner held: the sharded frames that follow equal the single context bit
+ *                          for bit as before.  (The anti-aliasing tail keeps more per-pixel state - previous tone-mapped / TAA /
+ *                          G-buffer planes: with it keep the split, or treat a re-split as a cut.)
+ *   hk_migrate_bands       with a communicator: the migration as one RCCL exchange on the communicator's stream, ordered behind
+ *                          everything the context has enqueued, then hk_set_band_bounds(new_bounds).  Every rank calls it with
+ *                          the same arguments, between two frames.  (A host with its own transport moves hk_band_migration_schedule's
+ *                          rows and calls hk_set_band_bounds itself; hk_multi_migrate_bands is the one-process form.) */
+int hk_rebalanced_band_bounds(const uint32_t* bounds, const float* band_ms, uint32_t band_count, uint32_t render_rows, const float* row_weight /* or NULL */,
+                              uint32_t min_rows, uint32_t max_shift, float damping, uint32_t* out);
+int hk_band_migration_plan(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* old_bounds, const uint32_t* new_bounds, uint32_t band_index,
+                           uint32_t band_count, uint32_t next_frame_number, const HkSettings* settings, HkHaloOp* ops, uint32_t* n_ops);
+int hk_migrate_bands(hk_ctx* ctx, const uint32_t* new_bounds, uint32_t n_bounds /* band_count + 1 */, uint32_t next_frame_number, const HkSettings* settings);
+/* the band time of the last frame rendered with HK_FRAME_TIME_BAND, in ms (waits for that frame's spatial stage; HK_E_NOT_READY if none) */
+int hk_band_time_ms(hk_ctx* ctx, float* ms);
 /* Halo transfers that must complete before `stage` runs on this context.  Pure host logic.
  * ops may be NULL to query the count.
  * Moving cameras / objects: the temporal and spatial dispatches read LAST frame's reservoirs at reprojected
@@ -706,6 +737,9 @@ int hk_band_schedule(uint32_t width, uint32_t height, float upscale_ratio, uint3
 int hk_band_schedule_bounds(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* bounds, uint32_t rank,
                             uint32_t n_ranks, uint32_t stage, uint32_t frame_number, const HkSettings* settings, HkTransfer* out,
                             uint32_t* n_out);
+/* the schedule of hk_band_migration_plan (above: "Bands of equal MEASURED time") */
+int hk_band_migration_schedule(uint32_t width, uint32_t height, float upscale_ratio, const uint32_t* old_bounds, const uint32_t* new_bounds, uint32_t rank,
+                               uint32_t n_ranks, uint32_t next_frame_number, const HkSettings* settings, HkTransfer* out, uint32_t* n_out);
 /* SURVEY 8e step 7, the gather of a finished image: the transfers of `rank` when band `root` collects every band's rows of
  * `buffer` (the root: one receive per other band, in band order; band r: one send).  Which rows of a buffer a band owns follows
  * the buffer's kind: render rows, two rows per render row for the SMAA Tu4x outputs, window rows for the FSR1 outputs.
@@ -765,6 +799,8 @@ int hk_multi_upload_scene_instances(hk_multi* m, const hk_scene_builder* b);
 int hk_multi_refit_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t* moved); /* hk_refit_scene_instances on every band's replica */
 int hk_multi_rebuild_scene_trees(hk_multi* m, uint32_t mode);
 int hk_multi_set_band_bounds(hk_multi* m, const uint32_t* bounds, uint32_t n_bounds);
+/* hk_migrate_bands for the one-process form: the rows that change owner travel as peer copies, then every band takes the new split */
+int hk_multi_migrate_bands(hk_multi* m, const uint32_t* new_bounds, uint32_t n_bounds, uint32_t next_frame_number, const HkSettings* settings);
 /* the root band's context collects every other band's rows of `buffer` on its own device (peer copies ordered by events, no host wait) */
 int hk_multi_gather(hk_multi* m, uint32_t buffer, uint32_t root);  /* hk_set_band_bounds on every band's context */
 int hk_multi_update_scene_instances(hk_multi* m, hk_scene_builder* b, uint32_t tree_mode);  /* hk_update_scene_instances on every band's replica */

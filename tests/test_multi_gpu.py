@@ -250,6 +250,70 @@ def test_multi_engine_history_rows_under_camera_motion(bands, emissive_spatial):
     assert float(np.linalg.norm(got - want) / np.linalg.norm(want)) > 1e-3   # without the halo the bands drift
 
 
+@pytest.mark.parametrize("bands,emissive_spatial", [(3, False), (5, True), (8, False)])
+def test_multi_engine_rebalances_by_measured_time_under_camera_motion(bands, emissive_spatial):
+    """Round 6, on the GPU: the split follows band times - hk_rebalanced_band_bounds on one number per band,
+    hk_multi_migrate_bands moves the history rows that change owner (peer copies), the new split is in force from the next frame -
+    while the camera moves vertically (exchange C + the parked scatter stores).  EVERY frame of the union equals the single context
+    with HK_CTX_DETERMINISTIC_SCATTER bit for bit, every buffer and reservoir; the boundaries really move (by up to 6 rows, four
+    times); the same boundaries set WITHOUT the migration leave stale history in the rows that changed owner."""
+    from bevy_hikari_amd.distributed import rebalanced_band_bounds
+
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0, emissive_spatial_reuse=emissive_spatial)
+    w, h, frames = 96, 64, 9
+    cams = [hk.Camera(hk.look_at_transform((0.0, 0.4 + 0.16 * n, 4.0), (0.0, 0.4 + 0.16 * n, 0.0)), w, h) for n in range(1, frames + 1)]
+    scene = hk.load_cornell()
+    ref = hk.Engine(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)
+    m = MultiEngine([0] * bands)
+    cut = MultiEngine([0] * bands)           # the same boundaries, set like a cut: no migration
+    for t in (ref, m, cut):
+        t.upload_noise(); t.upload_scene(scene); t.resize(w, h, 1.0)
+    seen = set()
+    for n in range(1, frames + 1):
+        cam, prev = cams[n - 1], cams[max(n - 2, 0)]
+        args = (hk.frame_uniform(s, n), cam.view_uniform(), cam.previous_view_uniform(prev), hk.lights_uniform(), s.to_c())
+        for t in (ref, m, cut):
+            t.frame_render(*args)
+        _same_buffers(m, ref, n, s, f"rebalanced x{bands} ")
+        if n in (2, 4, 5, 7):
+            ms = [float(1 + i) if n in (2, 7) else float(bands - i) for i in range(bands)]
+            new = rebalanced_band_bounds(m.contexts[0].band_bounds(), ms, h, None, min_rows=3, max_shift=6, damping=0.6)
+            m.migrate_bands(new, n + 1, s.to_c())
+            cut.set_band_bounds(new)
+            assert all(e.band_bounds() == new for e in m.contexts)
+            seen.add(tuple(new))
+    assert len(seen) >= 3, seen
+    got = np.stack([cut.read(F.BUF_DENOISE_RENDER0 + i).view(np.float16).astype(np.float32) for i in range(3)])
+    want = np.stack([ref.read_f16(F.BUF_DENOISE_RENDER0 + i) for i in range(3)])
+    assert float(np.linalg.norm(got - want) / np.linalg.norm(want)) > 0.0   # (the migration is what keeps the bands exact)
+
+
+def test_band_time_is_measured_on_the_stream():
+    """HK_FRAME_TIME_BAND / hk_band_time_ms: events around stage TEMPORAL and stage SPATIAL on the context's stream - a positive time
+    below the frame's wall clock, NOT READY before any timed frame, and no change to any byte."""
+    import time
+
+    case = case_of("cornell_b2")
+    s = case.settings
+    a, b = hk.Engine(device=0), hk.Engine(device=0)
+    for e in (a, b):
+        e.upload_noise(); e.upload_scene(case.scene); e.resize(256, 256, 1.0)
+        e.set_band(1, 3)
+    cam = hk.cornell_camera(256, 256)
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    with pytest.raises(F.HikariError):
+        a.band_time_ms()
+    for n in range(1, 5):
+        t0 = time.perf_counter()
+        a.frame_render(hk.frame_uniform(s, n), view, pview, case.lights, s.to_c(), F.FRAME_TIME_BAND)
+        ms = a.band_time_ms()
+        wall = (time.perf_counter() - t0) * 1e3
+        b.frame_render(hk.frame_uniform(s, n), view, pview, case.lights, s.to_c())
+        assert 0.0 < ms < wall + 0.05, (ms, wall)
+    for buf in (F.BUF_TONE_MAPPED, F.BUF_RESERVOIR0 + 6, F.BUF_RESERVOIR0 + 8, F.BUF_DENOISE_RENDER0 + 2):
+        assert (a.read(buf).view(np.uint8) == b.read(buf).view(np.uint8)).all()
+
+
 @pytest.mark.parametrize("bands", [5, 8])
 def test_multi_engine_camera_and_instance_motion_equals_single_context(bands):
     """camera AND instances move (device refit on every band's replica of the scene), 5 and 8 bands of unequal
