@@ -171,6 +171,9 @@ def main():
                     help="--gpus N: bands of equal cost (geometry pixels per row, counted on frame 1 by every rank: HK_FRAME_BALANCE_BANDS) or of equal height; "
                          "auto = balanced for scenes beyond LDS (configs 3, 4: sky rows cost nothing, city rows everything - predicted 3.2x instead of 2.75x at 8 GPUs), "
                          "equal for the Cornell configs (every row costs about the same: 1.97x against 2.01x, profiles/r03_band_balance_probe.json)")
+    ap.add_argument("--band-rebalance-rounds", type=int, default=6, help="--gpus N: during the warm-up the split follows MEASURED band times - this many times a frame is rendered "
+                    "with HK_FRAME_TIME_BAND, the ranks all-gather their band's time (N floats) and move the boundaries with hk_rebalanced_band_bounds, the history rows that "
+                    "change owner travel (hk_migrate_bands); the split then stays fixed through the timed blocks.  0 = off")
     ap.add_argument("--no-gather", action="store_true", help="--gpus N: leave every band's rows of the tone-mapped image on the GPU that rendered them (default: rank 0 "
                     "collects them every frame, HK_FRAME_GATHER - SURVEY 8e step 7)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -274,14 +277,25 @@ def main():
                 transport_used[0] = r.transport
             return e, r
 
-        def run_frames(e, r, first, last):
+        bounds_log = {}   # frame number -> the split in force FROM that frame on (the timed engine's; the replays follow it)
+
+        def run_frames(e, r, first, last, rebalance_at=(), follow=None):
             for n in range(first, last + 1):
                 frame = hk.frame_uniform(settings, n)
                 if r is None:
                     e.frame_render(frame, view, pview, lights, sc)
-                else:   # frame 1 splits the rows by cost (hk_balance_bands: every rank derives the same boundaries), the rest keep them
-                    r.render(frame, view, pview, lights, settings, W, H, balance=(n == 1 and (args.band_split == "balanced" or (args.band_split == "auto" and config in (3, 4)))),
-                             gather=not args.no_gather)   # rank 0 collects the finished image, every frame, inside the timed region
+                    continue
+                if follow is not None and n in follow:   # a replay: the split the timed engine took before this frame
+                    r.migrate(follow[n], n, settings, W, H)
+                # frame 1 splits the rows by cost (hk_balance_bands: every rank derives the same boundaries), the rest keep them
+                r.render(frame, view, pview, lights, settings, W, H, balance=(n == 1 and (args.band_split == "balanced" or (args.band_split == "auto" and config in (3, 4)))),
+                         gather=not args.no_gather,   # rank 0 collects the finished image, every frame, inside the timed region
+                         time_band=n in rebalance_at)
+                if n in rebalance_at:   # (warm-up only) one all-gather of N floats, the same controller on every rank, the moved rows migrate
+                    before = list(r.bounds) if r.bounds is not None else None
+                    after = r.rebalance(r.band_time_ms(), n + 1, settings, W, H, damping=0.6 if len(bounds_log) < 3 else 0.35)
+                    if after is not None and after != before:
+                        bounds_log[n + 1] = list(after)
 
         eng, rend = make_engine(args.ctx_flags)
         if warmup < 256 and config == args.config:
@@ -291,7 +305,9 @@ def main():
             t_spin = time.perf_counter()
             while time.perf_counter() - t_spin < 0.4:
                 eng.measure_valu(4096)
-        run_frames(eng, rend, 1, warmup)
+        rounds = args.band_rebalance_rounds if (rend is not None and warmup >= 16) else 0
+        rebalance_at = tuple(sorted({max(2, (k + 1) * (warmup - 4) // (rounds + 1)) for k in range(rounds)})) if rounds > 0 else ()
+        run_frames(eng, rend, 1, warmup, rebalance_at=rebalance_at)
         eng.wait()
         eng.reset_stats()
         # HIP events ON the two long dispatches of the frame (hipExtLaunchKernelGGL: no extra stream operation) + each trace launch of the
@@ -357,10 +373,10 @@ def main():
         # ray count by deterministic replay (one block's worth of frames: the camera is static and the rays per frame are
         # counted over the LAST timed block)
         ceng, crend = make_engine(F.CTX_COUNT_RAYS | (args.ctx_flags & (F.CTX_EXACT_TRAVERSAL | F.CTX_NO_WIDE_WALK)))  # (the primary rays of the replay walk what the timed ones do)
-        run_frames(ceng, crend, 1, last_frame - steps)
+        run_frames(ceng, crend, 1, last_frame - steps, follow=bounds_log)
         ceng.wait()
         ceng.reset_stats()
-        run_frames(ceng, crend, last_frame - steps + 1, last_frame)
+        run_frames(ceng, crend, last_frame - steps + 1, last_frame, follow=bounds_log)
         cst = ceng.stats()
         traced = float(cst.rays_tlas + cst.rays_blas)
         if dist is not None:
@@ -414,7 +430,7 @@ def main():
             del weng
 
         res = {"config": config, "description": description, "W": W, "H": H, "steps": steps, "warmup": warmup, "blocks": blocks, "elapsed": elapsed,
-               "band_bounds": (rend.bounds if rend is not None else None),
+               "band_bounds": (rend.bounds if rend is not None else None), "band_bounds_history": {str(k): v for k, v in bounds_log.items()},
                "last_frame": last_frame, "schedule": schedule, "traversal": traversal, "ind_ms": ind_ms, "ind_launches": ind_launches, "sp_ms": sp_ms, "direct_ms": direct_ms,
                "frame_latency_ms": frame_latency_ms, "trace_ms": trace_ms, "trace_launches": trace_launches,
                "total_rays": total_rays, "same": same,
@@ -427,7 +443,7 @@ def main():
             # the dominant kernel ALONE on the GPU: same frames on a single-stream context (in the timed run the two
             # direct-light dispatches share the GPU with it from a second stream, which stretches its own duration)
             xeng, xrend = make_engine(F.CTX_SINGLE_STREAM | args.ctx_flags)
-            run_frames(xeng, xrend, 1, warmup)
+            run_frames(xeng, xrend, 1, warmup, follow=bounds_log)
             xeng.wait()
             xeng.reset_stats()
             xeng.set_timing_mask((1 << F.PASS_INDIRECT) | (1 << F.PASS_INDIRECT_SPATIAL_REUSE))
@@ -616,7 +632,9 @@ def main():
             "baseline_config": args.config,
             "frames": f"warmup 1..{args.warmup}, then {len(blocks)} timed blocks of {args.steps} frames ({args.warmup + 1}..{last_frame}); value = median block",
             "parallelism": f"band{world}" if world > 1 else "single",
-            **({"band_split": ("balanced" if m["band_bounds"] else "equal"), "band_bounds": m["band_bounds"],
+            **({"band_split": ("measured" if m["band_bounds_history"] else ("balanced" if m["band_bounds"] else "equal")), "band_bounds": m["band_bounds"],
+                "band_rebalancing": {"rounds_during_warmup": args.band_rebalance_rounds, "splits_taken": m["band_bounds_history"],
+                                     "how": "HK_FRAME_TIME_BAND frame -> all-gather of N floats -> hk_rebalanced_band_bounds -> hk_migrate_bands; fixed through the timed blocks"},
                 "gather": "none" if args.no_gather else "rank 0 collects the tone-mapped image every frame (HK_FRAME_GATHER), inside the timed region"} if world > 1 else {}),
             # hk_traversal_mode: "one-level" = one BVH over all triangles in the instances' shared local space (the Cornell box),
             # "threaded" = two-level walk over 8 direction-ordered flattenings (scenes beyond LDS), "reference" = the reference's order;

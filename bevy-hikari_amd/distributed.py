@@ -299,12 +299,22 @@ class BandRenderer:
         t = self.torch.zeros(self.world, dtype=self.torch.float32)
         t[self.rank] = float(my_band_ms)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)   # (an all-gather of one float per rank)
-        sc = settings.to_c()
         _w, rh, _b = self.engine.buffer_info(F.BUF_TONE_MAPPED)
         new = rebalanced_band_bounds(self.bounds, [float(x) for x in t], rh, row_weight, min_rows, max_shift, damping)
+        return self.migrate(new, next_frame_number, settings, width, height)
+
+    def migrate(self, new_bounds, next_frame_number, settings, width, height):
+        """The split changes to `new_bounds` (the same on every rank) before frame `next_frame_number`: the rows of the history
+        reservoirs that change owner travel to their new owners (hk_migrate_bands over RCCL, or the host transport in the tests), then
+        the new split is in force.  Returns the boundaries."""
+        import torch.distributed as dist
+
+        self._follow_resize()
+        new = [int(b) for b in new_bounds]
         old = self.bounds
-        if old is not None and new == [int(b) for b in old]:
+        if self.world == 1 or (old is not None and new == [int(b) for b in old]):
             return self.bounds
+        sc = settings.to_c()
         if self.transport == "rccl":
             self.engine.migrate_bands(new, next_frame_number, sc)
             self.bounds = new
