@@ -66,7 +66,7 @@ int free_screen(hk_ctx* c) {
   if (c->dn_g) (void)hipFree(c->dn_g);
   c->depth_plane = nullptr;
   c->dn_g = nullptr;
-  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin, &c->render_twin[0], &c->render_twin[1], &c->render_twin[2], &c->variance_twin[0],
+  for (void** q : {&c->albedo_twin, &c->depth_gradient_twin, &c->dn_g_twin, &c->normal_twin, &c->instance_material_twin, &c->render_twin[0], &c->render_twin[1], &c->render_twin[2], &c->variance_twin[0],
                    &c->variance_twin[1], &c->variance_twin[2]}) {
     if (*q) (void)hipFree(*q);
     *q = nullptr;
@@ -539,6 +539,7 @@ int join_side(hk_ctx* c) {
   HK_HIP(hipEventRecord(c->join_event, c->side_stream));
   HK_HIP(hipStreamWaitEvent(c->stream, c->join_event, 0));
   c->forked = false;
+  c->side_state[0] = c->side_state[1] = 0;
   return HK_OK;
 }
 // make the main stream wait for the a-trous levels of the last frame (post_stream)
@@ -563,6 +564,7 @@ int join_all(hk_ctx* c) {
   if (!rc && c->comm) rc = comm_join(c, -1);  // a gather of the last frame still collecting rows on the communicator's stream
   return rc;
 }
+#define HK_FRAME_INTERNAL_LATE_JOIN 0x80000000u   // hk_frame_render -> hk_frame_stage: the caller puts exchange B behind the side stream itself (post_begin)
 #ifndef HK_POST_DEMODULATION_RULE
 #define HK_POST_DEMODULATION_RULE true
 #endif
@@ -574,15 +576,28 @@ int join_all(hk_ctx* c) {
 static bool demod_on_post(const hk_ctx* c) { return c->post_demodulation < 0 ? HK_POST_DEMODULATION_RULE : c->post_demodulation != 0; }
 int post_begin(hk_ctx* c, const HkSettings* st, bool* pipelined) {
   *pipelined = false;
-  int rc = join_side(c);
-  if (rc) return rc;
+  int rc;
   if (st->denoise && c->derived_dirty) {
     launch_derive_planes(c->stream, make_gbuffer(c), c->depth_plane, c->dn_g, c->W, 0, c->H);
     c->derived_dirty = false;
   }
   const uint32_t post_bits = (1u << HK_PASS_DEMODULATION) | (1u << HK_PASS_DENOISE_L0) | (1u << HK_PASS_DENOISE_L1) | (1u << HK_PASS_DENOISE_L2) | (1u << HK_PASS_DENOISE_L3);
-  if (!(st->denoise && c->post_stream && c->frame_pipeline && !(c->timing_mask & post_bits) && c->albedo_twin && c->render_twin[0]))
+  if (!(st->denoise && c->post_stream && c->frame_pipeline && !(c->timing_mask & post_bits) && c->albedo_twin && c->render_twin[0])) {
+    if ((rc = join_side(c))) return rc;
     return join_post(c);  // the denoiser's internal planes: last frame's levels come first
+  }
+  if (c->side_join_each_frame && (rc = join_side(c))) return rc;   // (hk_debug_set_option: the order of rounds 1-5, for the A/B)
+  // the post stream waits for the main stream AND (round 6) for the side stream itself: the main stream goes on to the next frame without
+  // either wait (the direct-light dispatches stay "not joined": c->forked)
+  if (c->forked) {
+    HK_HIP(hipEventRecord(c->side_done, c->side_stream));
+    HK_HIP(hipStreamWaitEvent(c->post_stream, c->side_done, 0));
+    for (int k = 0; k < 2; ++k)   // (everything the side stream holds now - of either parity - is behind this frame's post-processing)
+      if (c->side_state[k] == 1) {
+        c->side_state[k] = 2;
+        c->side_cover[k] = (uint8_t)(c->mapped_parity & 1u);
+      }
+  }
   HK_HIP(hipEventRecord(c->post_fork, c->stream));
   HK_HIP(hipStreamWaitEvent(c->post_stream, c->post_fork, 0));
   c->post_saved_main = c->stream;
@@ -825,7 +840,7 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
   c->stream = c->own_stream;
   if (!(flags & HK_CTX_SINGLE_STREAM)) {
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming) != hipSuccess) {
       set_error("cannot create the side stream");
       hk_destroy(c);
       return HK_E_HIP;
@@ -874,6 +889,7 @@ void hk_destroy(hk_ctx* c) {
     if (c->post_done[k]) (void)hipEventDestroy(c->post_done[k]);
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->join_event) (void)hipEventDestroy(c->join_event);
+  if (c->side_done) (void)hipEventDestroy(c->side_done);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -905,6 +921,7 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
     case HK_DEBUG_OPT_FLAT_WALK: c->flat_walk = value != 0; c->dynamic_dirty = true; break;
     case HK_DEBUG_OPT_FLAT_ORDERINGS: c->flat_orderings = (int)std::max<int64_t>(0, std::min<int64_t>(8, value)); c->dynamic_dirty = true; break;
     case HK_DEBUG_OPT_TRACE_UPDATE: c->trace_update = value != 0; break;
+    case HK_DEBUG_OPT_SIDE_JOIN: c->side_join_each_frame = value != 0; break;
     case HK_DEBUG_OPT_POST_DEMODULATION: c->post_demodulation = value < 0 ? -1 : (value ? 1 : 0); break;
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown option %u", option);
   }
@@ -981,6 +998,11 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     HK_HIP(hipMemset(c->depth_gradient_twin, 0, c->buf_bytes[HK_BUF_DEPTH_GRADIENT]));
     HK_HIP(hipMalloc(&c->dn_g_twin, nf * 16));
     HK_HIP(hipMemset(c->dn_g_twin, 0, nf * 16));
+    // (round 6: the two G-buffer planes that had no twin - the direct-light dispatches of frame n may still read them while frame n + 1's primary rays write)
+    HK_HIP(hipMalloc(&c->normal_twin, c->buf_bytes[HK_BUF_NORMAL]));
+    HK_HIP(hipMemset(c->normal_twin, 0, c->buf_bytes[HK_BUF_NORMAL]));
+    HK_HIP(hipMalloc(&c->instance_material_twin, c->buf_bytes[HK_BUF_INSTANCE_MATERIAL]));
+    HK_HIP(hipMemset(c->instance_material_twin, 0, c->buf_bytes[HK_BUF_INSTANCE_MATERIAL]));
     for (int ch = 0; ch < 3; ++ch) {  // (round 6: what demodulation reads of the light passes' outputs - it runs beside the next frame's light passes too)
       HK_HIP(hipMalloc(&c->render_twin[ch], c->buf_bytes[HK_BUF_RENDER0 + ch]));
       HK_HIP(hipMemset(c->render_twin[ch], 0, c->buf_bytes[HK_BUF_RENDER0 + ch]));
@@ -1030,6 +1052,8 @@ int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviou
       std::swap(c->buf[HK_BUF_ALBEDO], c->albedo_twin);
       std::swap(c->buf[HK_BUF_DEPTH_GRADIENT], c->depth_gradient_twin);
       std::swap(c->dn_g, c->dn_g_twin);
+      std::swap(c->buf[HK_BUF_NORMAL], c->normal_twin);
+      std::swap(c->buf[HK_BUF_INSTANCE_MATERIAL], c->instance_material_twin);
       for (int ch = 0; ch < 3; ++ch) {
         std::swap(c->buf[HK_BUF_RENDER0 + ch], c->render_twin[ch]);
         std::swap(c->buf[HK_BUF_VARIANCE0 + ch], c->variance_twin[ch]);
@@ -1211,6 +1235,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
   HK_REQUIRE(st, HK_E_INVALID, "settings is NULL");
   HK_REQUIRE(c->band_count <= (uint32_t)c->RH, HK_E_INVALID, "more bands than rows");
   HK_REQUIRE(st->taa <= HK_TAA_NONE && st->upscale_kind <= HK_UPSCALE_SMAA_TU4X, HK_E_INVALID, "bad taa / upscale_kind in settings");
+  HK_REQUIRE(!(flags & HK_FRAME_INTERNAL_LATE_JOIN) || c->in_frame_render, HK_E_INVALID, "unknown frame flag");
   // HkSettings and the HkFrame of hk_frame_begin describe the same HikariSettings (view.rs:141-193): the fields both carry must agree
   HK_REQUIRE(st->indirect_bounces == c->frame.indirect_bounces && (st->temporal_reuse != 0u) == (c->frame.temporal_reuse != 0u) &&
                  (st->emissive_spatial_reuse != 0u) == (c->frame.emissive_spatial_reuse != 0u) &&
@@ -1233,7 +1258,14 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     if (b_ > a_ && (rc = run_pass(c, pass, arg, a_, b_))) return rc; \
   } while (0)
   if (stage == HK_STAGE_TEMPORAL) {
-    if ((rc = join_side(c))) return rc;
+    // the side stream may still hold the previous frame's direct-light dispatches (hk_context.hpp side_done): this frame touches nothing
+    // of theirs as long as the double-buffered planes flipped - a frame of the same parity, a host-written G-buffer, a context without
+    // the twins (no post stream) waits for them
+    {
+      const uint32_t p_ = c->mapped_parity & 1u;
+      const bool covered = c->side_state[p_] == 2 && c->side_cover[p_] == p_;   // (join_post_parity below then orders this frame behind that side work)
+      if (c->forked && (!c->normal_twin || (flags & HK_FRAME_EXTERNAL_GBUFFER) || (c->side_state[p_] != 0 && !covered)) && (rc = join_side(c))) return rc;
+    }
     // last frame's post-processing may still be running on post_stream: this frame's primary rays and light passes do not touch what
     // it reads - the planes both touch are double-buffered by frame parity.  What this frame does write again is what the last frame
     // OF ITS OWN PARITY read (normally two frames back and long done; the last frame itself when a host renders two frames of one
@@ -1272,6 +1304,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       HK_HIP(hipEventRecord(c->fork_event, c->stream));
       HK_HIP(hipStreamWaitEvent(c->side_stream, c->fork_event, 0));
       c->forked = true;
+      c->side_state[c->mapped_parity & 1u] = 1;
       if ((rc = run_pass_on_side(c, HK_PASS_DIRECT_LIT, 0, b0, b1))) return rc;
       if ((rc = run_pass_on_side(c, HK_PASS_DIRECT_EMISSIVE, 0, b0, b1))) return rc;
       HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
@@ -1308,7 +1341,10 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       }
     }
     if (st->indirect_spatial_reuse) HK_RUN(HK_PASS_INDIRECT_SPATIAL_REUSE, 0, b0, b1);
-    if ((rc = join_side(c))) return rc;              // exchange B / demodulation read all three channels
+    // exchange B / demodulation read all three channels.  A single band's post-processing waits for the side stream ITSELF (post_begin);
+    // a band's exchange B is enqueued by whoever drives the stages - on this stream, behind this join - unless hk_frame_render drives
+    // them (HK_FRAME_INTERNAL_LATE_JOIN: its exchange B goes to the post stream with the rest)
+    if ((c->band_count > 1 && !(flags & HK_FRAME_INTERNAL_LATE_JOIN)) && (rc = join_side(c))) return rc;
   } else if (stage == HK_STAGE_POST_PROCESS) {
     // (hk_frame_render on a band with a communicator has moved to the post stream already: exchange B belongs in front of demodulation)
     bool pipelined = c->post_forked;
@@ -1321,7 +1357,8 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       if (pipelined && !demod_on_post(c)) {  // (demodulation stays on the main stream, the levels follow it on the post stream)
         hipStream_t post = c->stream;
         c->stream = c->post_saved_main;
-        rc = join_post(c);  // the denoiser's internal planes: last frame's levels come first
+        rc = join_side(c);  // (demodulation on the main stream reads the direct-light channels)
+        if (!rc) rc = join_post(c);  // the denoiser's internal planes: last frame's levels come first
         if (!rc) rc = run_demodulation_fused(c, nch, clampr(b0 - 15), clampr(b1 + 15));
         if (!rc && hipEventRecord(c->post_fork, c->stream) != hipSuccess) rc = HK_E_HIP;
         if (!rc && hipStreamWaitEvent(post, c->post_fork, 0) != hipSuccess) rc = HK_E_HIP;
@@ -1341,6 +1378,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       if (rc) return rc;
       if (rc2) return rc2;
     } else {
+      if ((rc = join_side(c))) return rc;                         // (tone mapping reads all three channels)
       HK_RUN(HK_PASS_TONE_MAPPING, 0u, b0, b1);                   // post_process.rs:1226-1234
       if (c->timing_mask) {
         (void)hipEventRecord(c->frame_stop, c->stream);
@@ -1389,6 +1427,8 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
   }
   // with a communicator attached (hk_comm_init) the halo exchanges of the band plan run here, on the context's stream
   const bool ex = c->comm != nullptr && c->band_count > 1;
+  struct InRender { hk_ctx* c; ~InRender() { c->in_frame_render = false; } } in_render_{c};
+  c->in_frame_render = true;
   const uint32_t hist = c->history_now << 8;
   for (uint32_t s = 0; s <= HK_STAGE_POST_PROCESS; ++s) {
     if (ex && s == HK_STAGE_POST_PROCESS) {
@@ -1409,7 +1449,8 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
         if (!c->band_ev[k]) HK_HIP(hipEventCreate(&c->band_ev[k]));
       HK_HIP(hipEventRecord(c->band_ev[2 * s], c->stream));
     }
-    if ((rc = hk_frame_stage(c, s, st, flags))) {
+    // (whoever calls hk_frame_render cannot put an exchange of its own between two stages: the side stream is joined where something reads it)
+    if ((rc = hk_frame_stage(c, s, st, flags | HK_FRAME_INTERNAL_LATE_JOIN))) {
       if (c->post_forked) (void)post_end(c, true);
       return rc;
     }

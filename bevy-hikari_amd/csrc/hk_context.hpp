@@ -110,6 +110,18 @@ struct hk_ctx {
   hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
   hipEvent_t fork_event = nullptr, join_event = nullptr;
   bool forked = false;                 // side_stream holds work the main stream has not waited for yet
+  // Round 6: the main stream no longer waits for the side stream at the end of a frame.  What reads the direct-light dispatches'
+  // outputs is the post-processing (post stream: it waits for side_done itself); the NEXT frame's primary rays and indirect pass touch
+  // nothing the direct-light dispatches of this frame read or write - the G-buffer planes are double-buffered by frame parity (normal
+  // and instance_material included, below), the sun / emissive reservoirs are the side stream's own - so the side stream may run up
+  // to the post-processing behind.  side_parity = the frame parity of the work it was last given (a frame of the SAME parity joins).
+  hipEvent_t side_done = nullptr;
+  // per frame parity: 0 = the side stream holds nothing of that parity the main stream has not been ordered behind, 1 = it does,
+  // 2 = it does, and the post-processing of parity side_cover[.] waits for it (so waiting for THAT post-processing is enough)
+  uint8_t side_state[2] = {0, 0};
+  uint8_t side_cover[2] = {0, 0};
+  void* normal_twin = nullptr;
+  void* instance_material_twin = nullptr;
   // Frame pipelining (round 3; round 6: the whole post-processing).  Demodulation, the a-trous levels and tone mapping of frame n - and,
   // on a band with a communicator, the halo exchange B in front of them - run on a third stream, so that the main stream goes straight
   // on to frame n + 1's primary rays and light passes.  What both touch is double-buffered by frame parity: albedo, depth gradient, the
@@ -135,6 +147,8 @@ struct hk_ctx {
   bool flat_walk = true;                 // the one-level tree for scenes under one transform (scene_layout.hip)
   int flat_orderings = 0;                // ... with this many direction orderings (0: as many as fit 4 KB)
   bool trace_update = false;             // timings of scene updates on stderr
+  bool in_frame_render = false;          // hk_frame_render is driving the stages (its internal frame flag is only valid then)
+  bool side_join_each_frame = false;     // the main stream waits for the side stream before the post-processing of every frame (rounds 1-5)
   int post_demodulation = -1;            // demodulation on the post stream with the levels: -1 by the rule (context.hip demod_on_post), 0 no, 1 yes
 
   // host copies of the reference-layout scene (kept for the layout conversion)

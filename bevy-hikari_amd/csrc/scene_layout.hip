@@ -586,6 +586,9 @@ int finalize_scene(hk_ctx* c) {
   }
   uint8_t* const slot_mem = c->scene_mem + (size_t)c->slot * c->dyn_capacity;
   if (in_place && c->two_slots) {
+    // (the slot written now was read by the frame before last: its direct-light dispatches may still sit on the side stream - round 6,
+    // hk_context.hpp side_done - so the copy goes behind them)
+    if ((rc = join_side(c))) return rc;
     const int k = c->slot;
     if (c->staging_pending[k]) {  // the copy that last read this staging buffer (two updates ago)
       HK_HIP(hipEventSynchronize(c->staging_done[k]));

@@ -188,3 +188,61 @@ def test_windowed_spatial_reuse_changes_no_byte(name):
     spatial_passes = int(bool(case.settings.emissive_spatial_reuse)) + int(bool(case.settings.indirect_spatial_reuse))
     assert plain.engine.spatial_windowed_launches() == 0
     assert forced.engine.spatial_windowed_launches() == (spatial_passes * len(case.frames) if spatial_passes else 0)
+
+
+def test_the_side_stream_may_lag_a_frame_behind_and_no_bit_changes():
+    """Round 6: the main stream no longer waits for the direct-light dispatches (side stream) at the end of a frame - the post-processing
+    does, on its own stream; the next frame's primary rays and indirect pass touch nothing they read or write (normal / instance_material
+    planes double-buffered like the rest of the G-buffer).  Against HK_DEBUG_OPT_SIDE_JOIN = 1 (the order of rounds 1-5) and against the
+    single-stream context: Cornell back to back, frames of one parity in a row, stages driven by hand without a post-processing stage, a
+    scene beyond LDS whose instances move through the two-slot upload AND the device refit between frames."""
+    from bevy_hikari_amd.scenes import animate, synthetic_camera, synthetic_scene
+
+    case = make_case("cornell_b2")
+    s, cam = case.settings, case.camera
+    view, pview = cam.view_uniform(), cam.previous_view_uniform()
+    engines = []
+    for flags, join in ((0, 0), (0, 1), (F.CTX_SINGLE_STREAM, 0)):
+        e = hk.Engine(device=0, flags=flags)
+        e.upload_noise(); e.upload_scene(case.scene); e.resize(cam.width, cam.height, s.upscale.ratio())
+        e.set_debug_option(F.DEBUG_OPT_SIDE_JOIN, join)
+        engines.append(e)
+    n = 0
+    for step in [1] * 9 + [2, 2, 2] + ["temporal_only"] * 4 + [1, 1, 2, 1]:
+        n += step if isinstance(step, int) else 1
+        for e in engines:
+            if step == "temporal_only":   # a host that drives the stages itself and skips the post-processing of some frames
+                e.frame_begin(hk.frame_uniform(s, n), view, pview, case.lights)
+                e.frame_stage(F.STAGE_TEMPORAL, s.to_c())
+                e.frame_stage(F.STAGE_SPATIAL, s.to_c())
+            else:
+                e.frame_render(hk.frame_uniform(s, n), view, pview, case.lights, s.to_c())
+    for b in (F.BUF_TONE_MAPPED, F.BUF_RENDER0, F.BUF_RENDER0 + 1, F.BUF_RENDER0 + 2, F.BUF_VARIANCE0, F.BUF_NORMAL, F.BUF_INSTANCE_MATERIAL, F.BUF_RESERVOIR0, F.BUF_RESERVOIR0 + 1,
+              F.BUF_RESERVOIR0 + 2, F.BUF_RESERVOIR0 + 3, F.BUF_RESERVOIR0 + 4, F.BUF_RESERVOIR0 + 5, F.BUF_RESERVOIR0 + 6, F.BUF_RESERVOIR0 + 8):
+        a = engines[0].read(b)
+        for other in engines[1:]:
+            assert (a.view(np.uint8) == other.read(b).view(np.uint8)).all(), b
+    del engines
+    # a scene beyond LDS, instances moving: the host-side re-finish + two-slot upload on odd frames, the device refit on even ones
+    scenes = [synthetic_scene(n_boxes=20, n_spheres=5, n_emitters=3, sphere_rings=12, sphere_segs=16, seed=77)[0] for _ in range(2)]
+    sun = synthetic_scene(n_boxes=1, n_spheres=1, n_emitters=1, seed=77)[1]
+    cam = synthetic_camera(160, 96)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0, emissive_spatial_reuse=True)
+    lights = hk.lights_uniform(directional=sun)
+    plugins = []
+    for join in (0, 1):
+        p = hk.HikariPlugin(device=0, flags=F.CTX_DETERMINISTIC_SCATTER if False else 0)
+        p.engine.set_debug_option(F.DEBUG_OPT_SIDE_JOIN, join)
+        p.set_scene(scenes[join])
+        plugins.append(p)
+    cur = list(scenes)
+    for n in range(1, 11):
+        for k, p in enumerate(plugins):
+            if n > 1:
+                cur[k] = animate(cur[k], n - 1)
+                p.update_instances(cur[k])
+            p.render(cam, s, lights=lights, frame_number=n)
+    # (the racing default: the two contexts run the SAME kernels in the same order per stream - what is compared is every rendered plane)
+    a, b = snapshot(plugins[0]), snapshot(plugins[1])
+    bad = {k: v for k, v in diff_buffers(a, b).items() if not k.startswith("reservoir")}
+    assert bad == {}, bad
