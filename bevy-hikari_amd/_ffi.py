@@ -206,6 +206,7 @@ _DEBUG = {
     "debug_comm_loopback": [_vp, u32, u32, u32, u32, u32],
     "debug_read_wf_timeline": [_vp, P(C.c_uint64), u32],
     "debug_set_option": [_vp, u32, C.c_int64],
+    "debug_comm_lanes": [_vp, P(u32)],
     "debug_multi_serial": [C.c_int],
     "debug_spatial_windowed_launches": [_vp, P(C.c_uint64)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],

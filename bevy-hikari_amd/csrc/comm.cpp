@@ -48,6 +48,7 @@ struct Rccl {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommSplit) CommSplit = nullptr;   // optional (RCCL >= 2.18): the second communicator of a context
 };
 
 Rccl* rccl() {
@@ -61,6 +62,7 @@ Rccl* rccl() {
     if (r.lib) {
 #define HK_SYM(name) r.name = reinterpret_cast<decltype(r.name)>(dlsym(r.lib, "nccl" #name))
       HK_SYM(GetUniqueId); HK_SYM(CommInitRank); HK_SYM(CommDestroy); HK_SYM(GroupStart); HK_SYM(GroupEnd); HK_SYM(Send); HK_SYM(Recv); HK_SYM(GetErrorString);
+      HK_SYM(CommSplit);
 #undef HK_SYM
       if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.GetErrorString) {
         dlclose(r.lib);
@@ -97,8 +99,17 @@ struct Comm {
   // waits for what the context has enqueued (`ready`) and the context's stream waits for the exchange (`done`) - the order a
   // single stream would give - while the GATHER of a finished frame makes nobody wait: the next frame renders while rank 0
   // collects the rows (`gather_done`; comm_join before the plane is written again, or before anybody reads the image).
+  // Round 6: TWO lanes.  Lane 0 carries what a band's main stream waits for - exchanges C and A, a migration; lane 1 what its
+  // post-processing and the overlay wait for - exchange B, the gather, exchanges D / E.  Operations on one communicator execute in
+  // issue order: on a single lane frame n's exchange B and gather (which wait for frame n's post-processing) would sit in front of
+  // frame n + 1's exchange A, and the main stream would wait for the post stream after all.  Lane 1 is a communicator of its own
+  // (ncclCommSplit of the first, the same ranks) on a stream of its own; where the library cannot split, lane 1 IS lane 0 (correct,
+  // only serialised as before).  All ranks issue the same sequence of calls per lane.
   hipStream_t stream = nullptr;
   hipEvent_t ready = nullptr, done = nullptr, gather_done = nullptr;
+  ncclComm_t comm2 = nullptr;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ready2 = nullptr, done2 = nullptr;
   bool gather_pending = false;
   uint32_t gather_parity = 0;  // frame parity of the plane a pending gather reads / fills
 };
@@ -133,7 +144,7 @@ int schedule_for(std::deque<Comm::Cached>& cache, const CtxInfo& ci, uint32_t ra
 
 // One exchange: every transfer of the list as an ncclSend / ncclRecv on `stream`, inside ONE group (the sends and receives of a
 // rank pair up across ranks by issue order; inside a group nothing blocks before ncclGroupEnd).
-int run_transfers(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, hipStream_t stream) {
+int run_transfers(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, hipStream_t stream, ncclComm_t comm) {
   HK_NCCL(R, R->GroupStart());
   for (size_t k = 0; k < n; ++k) {
     const HkTransfer& t = tr[k];
@@ -143,8 +154,8 @@ int run_transfers(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, 
       (void)R->GroupEnd();
       HK_REQUIRE(false, HK_E_INVALID, "halo transfer outside buffer %u", t.buffer);
     }
-    ncclResult_t e = t.is_recv ? R->Recv(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream)
-                               : R->Send(base + t.offset, t.bytes, ncclUint8, (int)t.peer, cm->comm, stream);
+    ncclResult_t e = t.is_recv ? R->Recv(base + t.offset, t.bytes, ncclUint8, (int)t.peer, comm, stream)
+                               : R->Send(base + t.offset, t.bytes, ncclUint8, (int)t.peer, comm, stream);
     if (e != ncclSuccess) {
       (void)R->GroupEnd();
       set_error("ncclSend/ncclRecv failed: %s", R->GetErrorString(e));
@@ -157,13 +168,18 @@ int run_transfers(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, 
 }
 
 // the transfers on the communicator's stream, behind everything `main` holds; wait = `main` continues only after them
-int run_ordered(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, hipStream_t main, bool wait) {
-  HK_HIP(hipEventRecord(cm->ready, main));
-  HK_HIP(hipStreamWaitEvent(cm->stream, cm->ready, 0));
-  const int rc = run_transfers(c, cm, R, tr, n, cm->stream);
+// lane 0: the communicator's first stream (exchanges the band's main stream waits for); lane 1: the second communicator and stream
+// (exchange B, the gather, exchanges D / E) where the library could split, else lane 0
+int run_ordered(hk_ctx* c, Comm* cm, Rccl* R, const HkTransfer* tr, size_t n, hipStream_t main, bool wait, int lane = 0) {
+  const bool second = lane == 1 && cm->comm2 && cm->stream2;
+  hipStream_t stream = second ? cm->stream2 : cm->stream;
+  hipEvent_t ready = second ? cm->ready2 : cm->ready, done = second ? cm->done2 : cm->done;
+  HK_HIP(hipEventRecord(ready, main));
+  HK_HIP(hipStreamWaitEvent(stream, ready, 0));
+  const int rc = run_transfers(c, cm, R, tr, n, stream, second ? cm->comm2 : cm->comm);
   if (rc) return rc;
-  HK_HIP(hipEventRecord(wait ? cm->done : cm->gather_done, cm->stream));
-  if (wait) HK_HIP(hipStreamWaitEvent(main, cm->done, 0));
+  HK_HIP(hipEventRecord(wait ? done : cm->gather_done, stream));
+  if (wait) HK_HIP(hipStreamWaitEvent(main, done, 0));
   return HK_OK;
 }
 
@@ -204,7 +220,7 @@ int comm_exchange(hk_ctx* c, uint32_t stage_arg, const HkSettings* st) {
   // No join with the side stream here: hk_frame_stage joins it exactly where an exchange reads what the direct-light
   // dispatches wrote (end of TEMPORAL when the emissive channel has a spatial pass, end of SPATIAL before exchange B), so
   // exchange A (indirect reservoirs, main stream) overlaps the direct-light kernels still running on the side stream.
-  if ((rc = run_ordered(c, cm, R, tr->data(), tr->size(), (hipStream_t)ci.stream, true))) return rc;
+  if ((rc = run_ordered(c, cm, R, tr->data(), tr->size(), (hipStream_t)ci.stream, true, (stage_arg & 0xffu) >= HK_STAGE_POST_PROCESS ? 1 : 0))) return rc;
   cm->exchanges += 1;
   return HK_OK;
 }
@@ -253,7 +269,7 @@ int comm_gather(hk_ctx* c, uint32_t buffer, uint32_t root, bool overlap) {
   // (one pending gather is tracked: an older one still in flight - of either parity - is joined before its record is overwritten;
   // hk_frame_render joins everything before it gathers, a caller of hk_comm_gather alone need not have)
   if (overlap && (rc = comm_join(c, -1))) return rc;
-  if ((rc = run_ordered(c, cm, R, tr.data(), tr.size(), (hipStream_t)ci.stream, !overlap))) return rc;
+  if ((rc = run_ordered(c, cm, R, tr.data(), tr.size(), (hipStream_t)ci.stream, !overlap, 1))) return rc;
   if (overlap) {
     cm->gather_pending = true;
     cm->gather_parity = ci.frame_number & 1u;
@@ -267,10 +283,13 @@ void comm_release(hk_ctx* c) {
   if (!cm) return;
   Rccl* R = rccl();
   if (cm->stream) (void)hipStreamSynchronize(cm->stream);
+  if (cm->stream2) (void)hipStreamSynchronize(cm->stream2);
+  if (R && cm->comm2) (void)R->CommDestroy(cm->comm2);
   if (R && cm->comm) (void)R->CommDestroy(cm->comm);
-  for (hipEvent_t e : {cm->ready, cm->done, cm->gather_done})
+  for (hipEvent_t e : {cm->ready, cm->done, cm->gather_done, cm->ready2, cm->done2})
     if (e) (void)hipEventDestroy(e);
   if (cm->stream) (void)hipStreamDestroy(cm->stream);
+  if (cm->stream2) (void)hipStreamDestroy(cm->stream2);
   delete cm;
   *slot = nullptr;
 }
@@ -593,6 +612,20 @@ int hk_comm_init(hk_ctx* c, uint32_t rank, uint32_t n_ranks, const uint8_t id[HK
     comm_release(c);
     return HK_E_HIP;
   }
+  // lane 1 (Comm): a second communicator over the same ranks, if this RCCL can split one; every rank takes the same branch (the symbol
+  // is there or not in the one library a job runs), and a split that fails leaves lane 1 on lane 0
+  if (R->CommSplit) {
+    e = R->CommSplit(cm->comm, 0, (int)rank, &cm->comm2, nullptr);
+    if (e != ncclSuccess || !cm->comm2) {
+      cm->comm2 = nullptr;
+    } else if (hipStreamCreateWithFlags(&cm->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&cm->ready2, hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&cm->done2, hipEventDisableTiming) != hipSuccess) {
+      set_error("cannot create the second communicator's stream / events: %s", hipGetErrorString(hipGetLastError()));
+      *ctx_comm_slot(c) = cm;
+      comm_release(c);
+      return HK_E_HIP;
+    }
+  }
   *ctx_comm_slot(c) = cm;
   return hk_set_band(c, rank, n_ranks);
 }
@@ -632,14 +665,25 @@ int hk_debug_comm_loopback(hk_ctx* c, uint32_t src_buffer, uint32_t dst_buffer, 
   tr[1] = tr[0];
   tr[1].buffer = dst_buffer; tr[1].is_recv = 1;
   HK_HIP(hipSetDevice(ci.device));
+  HK_REQUIRE(mode <= 2u, HK_E_INVALID, "mode 0, 1 or 2");
   const bool overlap = mode == 1u;  // 1: like the gather of a finished frame - nobody waits, comm_join does (hk_frame_begin of the same parity, any read)
   if (overlap && (rc = comm_join(c, -1))) return rc;  // (as comm_gather: never two overlapped transfers behind one record)
-  if ((rc = run_ordered(c, cm, R, tr, 2, (hipStream_t)ci.stream, !overlap))) return rc;
+  if ((rc = run_ordered(c, cm, R, tr, 2, (hipStream_t)ci.stream, !overlap, (mode == 1u || mode == 2u) ? 1 : 0))) return rc;   // (mode 1 / 2: the gather's lane)
   if (overlap) {
     cm->gather_pending = true;
     cm->gather_parity = ci.frame_number & 1u;
   }
   cm->exchanges += 1;
+  return HK_OK;
+}
+
+// hikari_hip_debug.h: 2 when the context's communicator has its second lane (a communicator and stream of its own for exchange B, the
+// gather and exchanges D / E), 1 when the library could not split one off and those share the first lane
+int hk_debug_comm_lanes(hk_ctx* c, uint32_t* lanes) {
+  HK_REQUIRE(c && lanes, HK_E_INVALID, "bad argument");
+  Comm* cm = static_cast<Comm*>(*ctx_comm_slot(c));
+  HK_REQUIRE(cm && cm->comm, HK_E_NOT_READY, "no communicator attached (hk_comm_init)");
+  *lanes = cm->comm2 && cm->stream2 ? 2u : 1u;
   return HK_OK;
 }
 

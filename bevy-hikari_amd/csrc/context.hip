@@ -1468,9 +1468,18 @@ int hk_frame_render(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPrevio
   }
   // rank 0 collects the finished image (the post stream's tone mapping has to be in before the rows leave)
   if (ex && (flags & HK_FRAME_GATHER)) {
+    // (round 4: rank 0 collects the rows WHILE the next frame renders - the tone-mapped image is double-buffered by frame parity; with the
+    // anti-aliasing tail, whose next frame reads this frame's outputs, the gather completes in stream order as before.  Round 6: the
+    // rows leave behind the POST stream, where this frame's tone mapping was enqueued - the main stream waits for neither)
+    const uint32_t parity = c->mapped_parity & 1u;
+    if (!(flags & HK_FRAME_ANTIALIAS) && c->post_stream && c->post_pending[parity]) {
+      hipStream_t main_stream = c->stream;
+      c->stream = c->post_stream;
+      rc = comm_gather(c, hk_final_buffer(st, flags), 0u, true);
+      c->stream = main_stream;
+      return rc;
+    }
     if ((rc = join_all(c))) return rc;
-    // (round 4: rank 0 collects the rows WHILE the next frame renders - the tone-mapped image is double-buffered by frame parity;
-    // with the anti-aliasing tail, whose next frame reads this frame's outputs, the gather completes in stream order as before)
     return comm_gather(c, hk_final_buffer(st, flags), 0u, !(flags & HK_FRAME_ANTIALIAS));
   }
   return HK_OK;

@@ -53,7 +53,7 @@ int hk_debug_read_wf_timeline(hk_ctx* ctx, unsigned long long* out, uint32_t n /
  * ordered against the context's stream - the very function (comm.cpp run_transfers) hk_frame_render's exchanges and hk_comm_gather go
  * through.  Needs hk_comm_init (a communicator of any size; 1 rank on a one-GPU box). */
 int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer, uint32_t row_begin, uint32_t row_end,
-                           uint32_t mode /* 0: in stream order, like a halo exchange; 1: overlapped with what follows, like the gather of a finished
+                           uint32_t mode /* 0: in stream order, like a halo exchange (lane 0); 2: the same on lane 1 (exchange B's); 1: overlapped with what follows, like the gather of a finished
                                             frame (hk_frame_render with HK_FRAME_GATHER) - complete before the frame of the same parity begins or
                                             anybody reads a buffer */);
 
@@ -61,6 +61,11 @@ int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer
  * and the lists of surviving taps in LDS: kernels.hip) since hk_create.  Which form a launch takes: by its size, or what
  * hk_debug_set_option(HK_DEBUG_OPT_SPATIAL_WINDOW) says. */
 int hk_debug_spatial_windowed_launches(hk_ctx* ctx, uint64_t* out);
+
+/* Test hook (round 6): 2 when the context's communicator has its second lane - a communicator (ncclCommSplit of the first) and a stream of
+ * its own for what a band's POST-PROCESSING and the overlay wait for (exchange B, the gather, exchanges D / E), so that frame n's
+ * exchange B and gather do not sit in front of frame n + 1's exchange A on one in-order queue - 1 when the library could not split. */
+int hk_debug_comm_lanes(hk_ctx* ctx, uint32_t* lanes);
 
 /* Switches for tests and A/B tools (round 6: the library itself reads NO environment variable).  Waits for the context's work, sets
  * the option, returns; options that change the scene layout take effect with the next frame. */

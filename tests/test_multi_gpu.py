@@ -5,6 +5,8 @@ whole code path - per-band stages, hk_band_schedule, peer copies on the receiver
 bands' streams, the gather - runs exactly as on n GPUs, and the union of the bands must equal the single-context frame bit
 for bit.  hk_comm_*: RCCL refuses two ranks on one device, so what can run here is the one-rank communicator (dlopen of
 librccl, ncclGetUniqueId, ncclCommInitRank, hk_frame_render's exchange hooks with an empty schedule)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -384,6 +386,9 @@ def test_rccl_send_and_receive_execute_on_the_stream():
     for t in (e, ref):
         t.upload_noise(); t.upload_scene(hk.load_cornell()); t.resize(w, h, 1.0)
     e.comm_init(0, 1, e.comm_unique_id())
+    lanes = C.c_uint32()
+    e.api.call("debug_comm_lanes", e.ctx, C.byref(lanes))
+    assert lanes.value == 2   # round 6: exchange B / the gather travel on a communicator and stream of their own (ncclCommSplit came up)
     src, dst, rows = F.BUF_RENDER0 + 2, F.BUF_DENOISE_RENDER0 + 2, (37, 101)
     ref.frame_render(hk.frame_uniform(s, 1), view, pview, lights, s.to_c())
     first = ref.read(src)
@@ -398,6 +403,10 @@ def test_rccl_send_and_receive_execute_on_the_stream():
     assert (got[rows[0]:rows[1]] == first[rows[0]:rows[1]]).all(), "the rows RCCL delivered are not what the frame before the exchange wrote"
     assert not got[:rows[0]].any() and not got[rows[1]:].any()
     assert (e.read(src) == second).all()
+    # ... the same on the communicator's SECOND lane (exchange B's: its own communicator and stream, behind whichever stream the context is on)
+    e.api.call("debug_comm_loopback", e.ctx, src, F.BUF_DENOISE_RENDER0 + 1, rows[0], rows[1], 2)
+    e.wait()
+    assert (e.read(F.BUF_DENOISE_RENDER0 + 1)[rows[0]:rows[1]] == second[rows[0]:rows[1]]).all()
     # ... and the way the GATHER of a finished frame runs (hk_frame_render with HK_FRAME_GATHER): on the communicator's stream, nobody
     # waits - frame 4 (the other parity's planes) renders meanwhile; frame 5 writes the plane the transfer reads and therefore joins
     # first (hk_frame_begin), as does anybody who reads a buffer.  What arrives is frame 3's tone-mapped image.
