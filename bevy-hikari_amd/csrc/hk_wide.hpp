@@ -3,7 +3,8 @@
 // Shared by the queue-based trace stage (k_wf_trace_wide) and the fused kernels' walks of scenes in global memory
 // (traverse_top_wide).  Same candidates and the same per-triangle arithmetic on the same operands as traverse_top (hk_device.hpp),
 // and (round 5) the reference's own rule for two candidates at exactly the same distance (wide_tie_goes_to: the leaf the reference's
-// walk meets first): the closest hit IS the reference's; an any-hit ray's outcome - occluded or not - does not depend on the order
+// walk meets first): the closest hit is the reference's except for box culls that depend on the visit order (a leaf box grazed within rounding is tested against an
+// older, larger bound here than in the reference's walk: measured <= 1 primary hit per 8.3 M pixels, 6.3e-5 relative L2 over 32 frames); an any-hit ray's outcome - occluded or not - does not depend on the order
 // (WHICH occluder it reports does: rays whose occluder is kept walk the reference's order, hk_device.hpp traverse_top<true>).
 // The reference's order (HK_CTX_EXACT_TRAVERSAL) never comes here.
 #pragma once

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Copy what tools/r05_final.sh left under gpurun_out/ into profiles/ (tracked).   Usage: tools/copy_evidence.sh [tag]
+# Copy what tools/r06_final.sh left under gpurun_out/ into profiles/ (tracked).   Usage: tools/copy_evidence.sh [tag]
 # bench lines: the LAST stdout line of each run, pretty-printed; the traffic profiles bench.py reads also under their fixed names.
-TAG=${1:-r05_final}
+TAG=${1:-r06_final}
 G=gpurun_out
 P=profiles
 for C in 2 3 4 5; do
