@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--passes", action="store_true", help="also report a per-pass time breakdown (extra untimed frames)")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the short config-3 / config-5 measurements of the default run")
     ap.add_argument("--motion", action="store_true", help="ONLY the frames under motion (tools/motion_bench.py): config 2 with an orbiting camera (two speeds), config 3 with the orbit + "
-                    "instances moving through hk_refit_scene_instances - ms per frame in the racing default and with HK_CTX_DETERMINISTIC_SCATTER, their deviation from each other "
+                    "instances moving through hk_refit_scene_instances - ms per frame with HK_CTX_RACING_SCATTER, in the default (race resolved) and with HK_CTX_DETERMINISTIC_SCATTER, their deviation from each other "
                     "and from the CPU oracle per frame; the default run carries a shorter version of the same in extra_configs['motion']")
     ap.add_argument("--sustained-seconds", type=float, default=3.0, help="length of the sustained block of the default run (0 = none)")
     ap.add_argument("--sustained", dest="sustained_seconds_forced", action="store_true", help="run the sustained block for any config / rank count")
@@ -485,7 +485,7 @@ def main():
     if args.motion:
         if world != 1:
             sys.exit("bench.py --motion is a single-GPU measurement")
-        print(json.dumps({"metric": "frame ms under motion: racing default vs HK_CTX_DETERMINISTIC_SCATTER", "unit": "ms", "n_gpus": 1, "higher_is_better": False, "motion": motion_lines(False)}), flush=True)
+        print(json.dumps({"metric": "frame ms under motion: HK_CTX_RACING_SCATTER vs the default (race resolved, light form) vs HK_CTX_DETERMINISTIC_SCATTER", "unit": "ms", "n_gpus": 1, "higher_is_better": False, "motion": motion_lines(False)}), flush=True)
         return
 
     # ------------------------------------------------------------------ timed run (headline)

@@ -45,6 +45,7 @@ int free_screen(hk_ctx* c) {
   for (int k = 0; k < 3; ++k) {
     if (c->det_winner[k]) (void)hipFree(c->det_winner[k]);
     c->det_winner[k] = nullptr;
+    c->det_lite_clean[k] = false;
   }
   for (uint32_t b = 0; b < HK_BUF_COUNT; ++b) {
     if (c->buf[b]) (void)hipFree(c->buf[b]);
@@ -181,6 +182,14 @@ GBuffer make_gbuffer(const hk_ctx* c) {
 // A band of a sharded frame whose history halo is not empty parks the scatter stores of its temporal dispatches instead of
 // racing them into its local copy of previous_spatial: the neighbours need them (and this band theirs) before spatial_reuse
 bool parks_across_bands(const hk_ctx* c) { return c->band_count > 1 && c->history_now > 0; }
+// the light deterministic form (hk_kernels.hpp LightTargets::det_lite) for this channel's temporal dispatch: a single context, by default
+// where the channel's previous_spatial buffer has a reader, for every channel with HK_CTX_DETERMINISTIC_SCATTER, never with
+// HK_CTX_RACING_SCATTER.  (A band with a history halo parks in the full form; a band without one - static view - has nothing to resolve.)
+bool scatter_lite(const hk_ctx* c, int channel) {
+  if (c->band_count > 1 || (c->flags & HK_CTX_RACING_SCATTER)) return false;
+  if (c->flags & HK_CTX_DETERMINISTIC_SCATTER) return true;
+  return channel == 2 ? c->frame.indirect_spatial_reuse != 0u : c->frame.emissive_spatial_reuse != 0u;
+}
 // the parked planes, on first use (3 x 72 B per render pixel)
 int ensure_parked(hk_ctx* c) {
   if (c->det_winner[0]) return HK_OK;
@@ -197,7 +206,9 @@ int ensure_parked(hk_ctx* c) {
       const uint32_t b = (j == 0 ? (uint32_t)HK_BUF_PARKED_TO0 : (uint32_t)HK_BUF_PARKED_RECORD0) + (uint32_t)k;
       plane_bytes[2 * k + j] = nr * buffer_bpp(b);
       e = hipMalloc(&plane[2 * k + j], plane_bytes[2 * k + j]);
-      if (e == hipSuccess) e = hipMemsetAsync(plane[2 * k + j], j == 0 ? 0xFF : 0, plane_bytes[2 * k + j], c->stream);  // nothing parked
+      // nothing parked.  (Blocking, once: the first use may come from any of the context's streams - the side stream's direct-light
+      // dispatch - while another stream is about to use ITS channel's planes)
+      if (e == hipSuccess) e = hipMemset(plane[2 * k + j], j == 0 ? 0xFF : 0, plane_bytes[2 * k + j]);
     }
   }
   if (e != hipSuccess) {
@@ -267,7 +278,8 @@ LightTargets make_light_targets(const hk_ctx* c, int channel) {
   t.variance = (float*)c->buf[HK_BUF_VARIANCE0 + channel];
   t.render = (uint2*)c->buf[HK_BUF_RENDER0 + channel];
   // parked scatter stores: the verification mode, and a band of a sharded frame with a history halo
-  const bool parked = c->det_winner[channel] && ((c->flags & HK_CTX_DETERMINISTIC_SCATTER) || parks_across_bands(c));
+  const bool parked = c->det_winner[channel] && (scatter_lite(c, channel) || parks_across_bands(c));
+  t.det_lite = parked && !parks_across_bands(c) ? 1 : 0;
   t.det_winner = parked ? c->det_winner[channel] : nullptr;
   t.det_to = parked ? (int*)c->buf[HK_BUF_PARKED_TO0 + channel] : nullptr;
   t.det_pending = parked ? (PackedReservoir*)c->buf[HK_BUF_PARKED_RECORD0 + channel] : nullptr;
@@ -650,14 +662,25 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
     case HK_PASS_INDIRECT: {
       const int channel = pass == HK_PASS_DIRECT_LIT ? 0 : (pass == HK_PASS_DIRECT_EMISSIVE ? 1 : 2);
       const bool across = parks_across_bands(c);
-      if (across || (c->flags & HK_CTX_DETERMINISTIC_SCATTER)) { const int rc_ = ensure_parked(c); if (rc_) return rc_; }
+      if (across || scatter_lite(c, channel)) { const int rc_ = ensure_parked(c); if (rc_) return rc_; }
       LightTargets t = make_light_targets(c, channel);
       { const int rc_ = attach_tile_meta(c, t, channel, false, y0, y1); if (rc_) return rc_; }
       const size_t px = (size_t)c->RW * c->RH;
-      if (t.det_winner) {  // nothing parked, no winner: -1 everywhere (a band: in the rows it dispatches - the others arrive with exchange A)
-        HK_HIP(hipMemsetAsync(t.det_winner, 0xFF, px * sizeof(int), c->stream));
-        if (across) HK_HIP(hipMemsetAsync(t.det_to + (size_t)y0 * c->RW, 0xFF, (size_t)(y1 - y0) * c->RW * sizeof(int), c->stream));
-        else HK_HIP(hipMemsetAsync(t.det_to, 0xFF, px * sizeof(int), c->stream));
+      if (t.det_winner && t.det_lite) {  // the light form: the winner plane is handed back clean by every resolve pass; nothing else to prepare
+        if (!c->det_lite_clean[channel]) {
+          // first use, or the channel's last dispatch was not in the light form (a band's full form, the spatial pass switched off): no
+          // winners, no notes
+          HK_HIP(hipMemsetAsync(t.det_winner, 0xFF, px * sizeof(int), c->stream));
+          HK_HIP(hipMemsetAsync(t.det_to, 0xFF, px * sizeof(int), c->stream));
+          c->det_lite_clean[channel] = true;
+        }
+      } else {
+        c->det_lite_clean[channel] = false;
+        if (t.det_winner) {  // nothing parked, no winner: -1 everywhere (a band: in the rows it dispatches - the others arrive with exchange A)
+          HK_HIP(hipMemsetAsync(t.det_winner, 0xFF, px * sizeof(int), c->stream));
+          if (across) HK_HIP(hipMemsetAsync(t.det_to + (size_t)y0 * c->RW, 0xFF, (size_t)(y1 - y0) * c->RW * sizeof(int), c->stream));
+          else HK_HIP(hipMemsetAsync(t.det_to, 0xFF, px * sizeof(int), c->stream));
+        }
       }
       if (pass == HK_PASS_INDIRECT && use_wavefront(c)) {
         { const int rc_ = ensure_wavefront(c); if (rc_) return rc_; }
@@ -685,7 +708,8 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
       else
         launch_direct(c->stream, pass == HK_PASS_DIRECT_EMISSIVE, c->scene, fr, g, t, y0, y1, counters);
       // (a band with a history halo resolves at the start of stage SPATIAL, once the neighbours' parked rows are in)
-      if (t.det_winner && !across) launch_resolve_scatter(c->stream, t, 0, (int)px, 0, 0);
+      if (t.det_winner && t.det_lite) launch_resolve_scatter_lite(c->stream, t, fr, c->depth_plane, pass == HK_PASS_INDIRECT, y0, y1);
+      else if (t.det_winner && !across) launch_resolve_scatter(c->stream, t, 0, (int)px, 0, 0);
       break;
     }
     case HK_PASS_EMISSIVE_SPATIAL_REUSE:
@@ -845,6 +869,8 @@ int hk_create(int device_id, uint32_t flags, hk_ctx** out) {
       hk_destroy(c);
       return HK_E_HIP;
     }
+    // (the verification mode keeps ONE set of planes: a host that looks at a buffer between two dispatches - the fixture replays of
+    // tests/test_wgsl_pin.py - finds in it what the last frame left, as in the reference)
     if (!(flags & (HK_CTX_DETERMINISTIC_SCATTER | HK_CTX_COUNT_RAYS | HK_CTX_TIME_PASSES))) {
       if (hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->post_fork, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&c->post_done[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->post_done[1], hipEventDisableTiming) != hipSuccess) {
@@ -974,8 +1000,7 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     c->buf_bytes[b] = bytes;
   }
   const size_t nf = (size_t)c->W * c->H, nr = (size_t)c->RW * c->RH;
-  if (c->flags & HK_CTX_DETERMINISTIC_SCATTER) { const int rc_ = ensure_parked(c); if (rc_) return rc_; }
-  if (!(c->flags & HK_CTX_DETERMINISTIC_SCATTER)) {  // (the verification mode parks its scatter stores: no elision there)
+  {  // (round 6: the verification mode parks only what crosses pixels - the light form - and keeps the elision)
     c->tiles_x = (c->RW + 7) / 8;
     c->tiles_y = (c->RH + 7) / 8;
     const size_t mb = (size_t)c->tiles_x * c->tiles_y * sizeof(TileMeta);

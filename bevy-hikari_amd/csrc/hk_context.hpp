@@ -193,6 +193,11 @@ struct hk_ctx {
   // step 6), one set per light channel.  `to` and the records are the HK_BUF_PARKED_* planes (c->buf: bands exchange their rows),
   // the winners are private.  Allocated on first use (ensure_parked).
   int* det_winner[3] = {nullptr, nullptr, nullptr};
+  // Round 6: a single context resolves the reference's scatter race deterministically BY DEFAULT, in the light form (hk_kernels.hpp
+  // LightTargets::det_lite) - for the channels whose previous_spatial buffer has a reader (the spatial pass that is on); with
+  // HK_CTX_DETERMINISTIC_SCATTER for all three; HK_CTX_RACING_SCATTER restores the reference's race.  det_lite_clean[k]: channel k's
+  // winner plane holds -1 everywhere (the light form hands it back that way; the full form of a band does not).
+  bool det_lite_clean[3] = {false, false, false};
   // uniform-tile store elision (hk_kernels.hpp TileMeta): one record per 8x8 tile per reservoir buffer; tile_meta_zero[k] = the
   // device array of buffer k is known to be all zero ("contents unknown" everywhere)
   TileMeta* tile_meta[10] = {};

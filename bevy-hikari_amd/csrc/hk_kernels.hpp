@@ -47,6 +47,12 @@ struct LightTargets {
   int* det_winner;               // per previous_spatial slot: highest pixel index that stores to it (-1: none)
   int* det_to;                   // per pixel: the slot its parked store goes to (-1: none)
   PackedReservoir* det_pending;  // per pixel: the parked value
+  // Round 6, single contexts: the LIGHT form of the same rule (hk_light.hpp store_previous_spatial, kernels.hip k_resolve_scatter_lite).
+  // A store to the pixel's OWN slot goes straight to previous_spatial - one pixel owns a slot, such stores do not race with each other -
+  // and only a store to ANOTHER pixel's slot is parked and competes in det_winner.  The resolve pass applies the highest such store
+  // unless the slot's owner stored to it too and has the higher index: the same winner as the full rule, without 68 B per pixel of
+  // parked traffic, with the uniform-tile store elision and the frame pipelining left on.
+  int det_lite;
   // uniform-tile store elision (TileMeta above); all null when it is off (verification mode, band-sharded or row-unaligned dispatches)
   TileMeta* m_current;
   TileMeta* m_spatial;
@@ -332,5 +338,8 @@ void launch_fsr_rcas(hipStream_t st, const void* input, void* output, int w, int
 // apply the parked scatter stores of pixels [p0, p1); [own0, own1) = the pixels this context dispatched itself (their winners are
 // in), empty = all of them
 void launch_resolve_scatter(hipStream_t st, const hkd::LightTargets& t, int p0, int p1, int own0, int own1);
+// the light form (LightTargets::det_lite): rows [y0, y1) of the pass that just ran; `indirect`: the pass was indirect_lit_ambient (whose
+// pixels are background also when the frame has no bounces, light.wgsl:1279)
+void launch_resolve_scatter_lite(hipStream_t st, const hkd::LightTargets& t, const hkd::DFrame& fr, const float* depth_plane, bool indirect, int y0, int y1);
 void launch_debug_math(hipStream_t st, uint32_t op, const float* x, const float* y, float* out, size_t n);
 }  // namespace hk

@@ -45,10 +45,13 @@ __device__ __forceinline__ DScene stage_scene(const DScene& sc) {
 
 // every store to previous_spatial goes through here: the reference lets them race; the verification mode parks them
 __device__ __forceinline__ void store_previous_spatial(const LightTargets& t, int from, int to, const PackedReservoir& v) {
-  if (t.det_winner) {
+  if (t.det_winner && (!t.det_lite || to != from)) {
     store_packed(t.det_pending, from, v);
     t.det_to[from] = to;
     atomicMax(&t.det_winner[to], from);
+  } else if (t.det_lite) {  // the pixel's own slot: nobody else's own store goes there; k_resolve_scatter_lite weighs it against the parked ones
+    store_packed(t.previous_spatial, to, v);
+    t.det_to[from] = from;
   } else {
     store_packed(t.previous_spatial, to, v);
     // a store into a slot some other wave's tile owns: whatever that tile's record says, it no longer holds (TileMeta::poison)
@@ -78,6 +81,7 @@ __device__ __forceinline__ void indirect_temporal_tail(const DScene& sc, const D
                                                        float4 velocity_uv, uint32_t im_y, const Sample& s, float pdf) {
   const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
   Reservoir r = load_reservoir_uv(t.previous, previous_uv, fr.rw, fr.rh);
+  if (t.det_lite) t.det_to[index] = -1;  // (every geometry pixel says each frame whether and where it stores: no memset of the plane)
   if (!check_previous_reservoir(r, s) && fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f) {
     const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
     store_previous_spatial(t, index, previous_index, pack_reservoir(r));

@@ -50,6 +50,38 @@ __global__ __launch_bounds__(256) void k_resolve_scatter(LightTargets t, int p0,
   if (to >= 0 && t.det_winner[to] == i) store_packed(t.previous_spatial, to, load_packed(t.det_pending, i));
 }
 
+// The light form (LightTargets::det_lite, single contexts).  Pixel p parked a store iff it went to ANOTHER pixel's slot: det_to[p] =
+// that slot, det_winner[slot] = the highest such p.  The slot's owner may have stored to it as well - directly: a background pixel
+// always does (light.wgsl:1058-1069, 1279-1287; the uniform-tile elision may have left the identical record in place) - the pass
+// decides "background" from the depth plane exactly as the dispatch did -, a geometry pixel whose rejected history reprojects onto
+// itself says so in det_to[owner] == owner.  Highest index wins (the oracle's apply_scatter): the parked store lands iff it is the
+// highest parked one AND beats the owner.  Geometry pixels rewrite their det_to entry every frame and background pixels never park,
+// so nothing is memset per frame; the winning thread hands the slot's det_winner back as -1.  (A note per background pixel instead of
+// the depth test was tried: no faster, and wrong where a dispatch covers part of the rows.)
+__device__ __forceinline__ bool lite_is_background(const DFrame& fr, const float* __restrict__ depth_plane, int pixel, bool indirect) {
+  if (indirect && fr.indirect_bounces == 0u) return true;
+  const int y = pixel / fr.rw, x = pixel - y * fr.rw;
+  int dcx, dcy;
+  jittered_deferred_coords(fr, coords_to_uv(fr, x, y), &dcx, &dcy);
+  const float depth = in_bounds(dcx, dcy, fr.dw, fr.dh) ? depth_plane[dcx + fr.dw * dcy] : 0.0f;
+  return depth < HK_F32_EPSILON;
+}
+__global__ __launch_bounds__(256) void k_resolve_scatter_lite(LightTargets t, DFrame fr, const float* __restrict__ depth_plane, int indirect, int p0, int p1) {
+  const int p = p0 + (int)(blockIdx.x * 256u + threadIdx.x);
+  if (p >= p1) return;
+  const int to = t.det_to[p];   // (one 4-byte read is all that nearly every thread does)
+  if (to < 0 || to == p || t.det_winner[to] != p) return;
+  if (lite_is_background(fr, depth_plane, p, indirect != 0)) return;  // (background pixels store to their own slot only: this entry is a stale one)
+  t.det_winner[to] = -1;
+  const bool owner_stored = lite_is_background(fr, depth_plane, to, indirect != 0) || t.det_to[to] == to;
+  if (owner_stored && to > p) return;
+  store_packed(t.previous_spatial, to, load_packed(t.det_pending, p));
+  if (t.m_previous_spatial) {  // (as the racing store into another tile's slot: whatever that tile's record says, it no longer holds)
+    const int ty = to / t.rw, tx = to - ty * t.rw;
+    atomicMax(&t.m_previous_spatial[(ty >> 3) * t.tiles_x + (tx >> 3)].poison, t.serial);
+  }
+}
+
 // ------------------------------------------------------------------ prepass by primary rays (PrepassParams, primary_ray, prepass_store: hk_prepass.hpp)
 // waves per SIMD the wide-walk prepass is compiled for.  Its walk is a chain of dependent fetches: one more resident wave hides more
 // of them than the 8 VGPRs it spills cost - 5 waves (95 VGPRs; 5 x 28 KB of LDS stacks fit the CU) against the compiler's own 103
@@ -169,6 +201,7 @@ __global__ __launch_bounds__(256, (LDS == 0 ? HK_DIRECT_GLOBAL_WAVES : (LDS == 2
 
       const f2 previous_uv = jittered_deferred_uv(fr, uv, 0.25f) - F2(velocity_uv.x, velocity_uv.y);
       Reservoir r = load_reservoir_uv(t.previous, previous_uv, fr.rw, fr.rh);
+      if (t.det_lite) t.det_to[index] = -1;  // (every geometry pixel says each frame whether and where it stores: hk_light.hpp store_previous_spatial)
       const bool prev_on_screen = fabsf(previous_uv.x - 0.5f) <= 0.5f && fabsf(previous_uv.y - 0.5f) <= 0.5f;
       const int previous_index = f32_to_i32(previous_uv.x * (float)fr.rw) + fr.rw * f32_to_i32(previous_uv.y * (float)fr.rh);
 
@@ -277,8 +310,10 @@ __global__ __launch_bounds__(256, (LDS == 0 ? HK_DIRECT_GLOBAL_WAVES : (LDS == 2
   }
   if (!skip_current) store_packed_tile(lds, t.current, fr.rw, px, out, write_current);
   if (!skip_spatial) store_packed_tile(lds, t.spatial, fr.rw, px, out, background);
-  if (!skip_previous_spatial) store_packed_tile(lds, t.previous_spatial, fr.rw, px, out, background && !t.det_winner);
-  if (t.det_winner && background) store_previous_spatial(t, px.x + fr.rw * px.y, px.x + fr.rw * px.y, out);
+  // (background pixels store to their OWN slot: direct in the racing and in the light deterministic form, parked in the full one)
+  const bool park_background = t.det_winner && !t.det_lite;
+  if (!skip_previous_spatial) store_packed_tile(lds, t.previous_spatial, fr.rw, px, out, background && !park_background);
+  if (park_background && background) store_previous_spatial(t, px.x + fr.rw * px.y, px.x + fr.rw * px.y, out);
   flush_counters<COUNT>(rc, 0, counters);
 }
 
@@ -990,6 +1025,11 @@ void launch_resolve_scatter(hipStream_t st, const LightTargets& t, int p0, int p
   const dim3 grid((unsigned)((p1 - p0 + 255) / 256));
   if (own1 > own0 && (p0 < own0 || p1 > own1)) hipLaunchKernelGGL(k_join_winners, grid, dim3(256), 0, st, t, p0, p1, own0, own1);
   hipLaunchKernelGGL(k_resolve_scatter, grid, dim3(256), 0, st, t, p0, p1);
+}
+void launch_resolve_scatter_lite(hipStream_t st, const LightTargets& t, const DFrame& fr, const float* depth_plane, bool indirect, int y0, int y1) {
+  if (y1 <= y0) return;
+  const int p0 = y0 * fr.rw, p1 = y1 * fr.rw;
+  hipLaunchKernelGGL(k_resolve_scatter_lite, dim3((unsigned)((p1 - p0 + 255) / 256)), dim3(256), 0, st, t, fr, depth_plane, indirect ? 1 : 0, p0, p1);
 }
 // windowed: 0 never, 1 always, -1 by the size of the launch - the windowed form pays where the launch is many rounds of workgroups
 // (HK_SPATIAL_WINDOWED_MIN_TILES: sixteen rounds of 4 workgroups on 256 CUs); a 1080p frame (8 160 tiles) keeps the plain one

@@ -394,6 +394,14 @@ int hk_device_count(int* count);
  * resolves the race: with it a moving camera and moving objects are bit-exact against the oracle too.  Costs three
  * extra launches and 72 B per pixel of scratch per light dispatch; not meant for production frames. */
 #define HK_CTX_DETERMINISTIC_SCATTER 16u
+/* Round 6.  The rule above costs little in its light form - a store to the pixel's own slot goes straight to the buffer, only a store
+ * to another pixel's slot is parked and weighed against the slot's owner afterwards (one small launch per channel; the uniform-tile
+ * store elision and the frame pipelining stay on) - so a single context now applies it BY DEFAULT to the channels whose
+ * previous_spatial buffer has a reader (the indirect channel when indirect_spatial_reuse is on, sun + emissive when
+ * emissive_spatial_reuse is on): what is rendered no longer depends on which store lands last, and equals the oracle's frames under
+ * motion.  HK_CTX_DETERMINISTIC_SCATTER extends it to all three channels (every reservoir byte reproducible);
+ * HK_CTX_RACING_SCATTER (bit10) restores the reference's own race - the A/B of bench.py --motion. */
+#define HK_CTX_RACING_SCATTER 1024u
 /* Traversal order.  The reference walks its flat BVHs in ONE fixed depth-first order (`bvh` 0.7.1 flatten_custom: left child
  * first, light.wgsl:400-486), which for a closest-hit ray coming "from the right" means visiting most of the tree before the
  * near hit that would have pruned it.  For scenes too large for the LDS copy the library therefore keeps EIGHT flattenings of

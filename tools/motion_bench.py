@@ -6,11 +6,13 @@ Every other timed frame of bench.py is a static-camera steady state.  Here:
     with the mouse held: a fixed angle per frame around (0, 1, 0) at the example's radius;
   * config 3 (Sponza-class stand-in) with the same orbit AND instances moving on their own, poses pushed through
     hk_refit_scene_instances every frame (device refit of both trees).
-Each in two modes: the product default - the reference's own write-write race on previous_spatial_reservoir_buffer
-(light.wgsl:1092-1095,1199-1202,1456-1459), whichever store lands last stays - and HK_CTX_DETERMINISTIC_SCATTER (parked stores, highest
-invocation index wins: the oracle's rule).  Reported: ms per frame of both, their ratio, the relative L2 of the racing frames against the
-deterministic ones per frame (GPU against GPU, full size) and - `oracle_frames` > 0 - of BOTH against the CPU oracle on the first frames
-of the same sequence.
+Each in three modes: HK_CTX_RACING_SCATTER - the reference's own write-write race on previous_spatial_reservoir_buffer
+(light.wgsl:1092-1095,1199-1202,1456-1459), whichever store lands last stays: the product default through round 5 -, the product
+default since round 6 - the race resolved by highest invocation index (the oracle's rule) in the LIGHT form, for the channels whose
+buffer has a reader -, and HK_CTX_DETERMINISTIC_SCATTER, the verification mode (all three channels, one set of planes, no frame
+pipelining).  Reported: ms per frame of each, what the default costs over the racing mode, the relative L2 of the racing frames against
+the default's per frame (GPU against GPU, full size) and - `oracle_frames` > 0 - of all three against the CPU oracle on the first
+frames of the same sequence.
 
     python tools/motion_bench.py [--configs 2 3] [--oracle-frames 6] > profiles/r06_motion.json        (bench.py --motion prints the same)
 """
@@ -92,7 +94,7 @@ def run(hk, F, config, device=0, frames=48, blocks=3, warmup=24, compare_frames=
            (", %d of %d instances moving every frame through hk_refit_scene_instances" % (len(movers), len(rest)) if moving_instances else ""),
            "frames_per_block": frames, "blocks": blocks, "warmup_frames": warmup}
     engines = {}
-    for mode, flags in (("racing_default", 0), ("deterministic_scatter", F.CTX_DETERMINISTIC_SCATTER)):
+    for mode, flags in (("racing", F.CTX_RACING_SCATTER), ("default", 0), ("verification_mode", F.CTX_DETERMINISTIC_SCATTER)):
         e = make(flags)
         n = 0
         for _ in range(warmup):
@@ -109,10 +111,11 @@ def run(hk, F, config, device=0, frames=48, blocks=3, warmup=24, compare_frames=
             ms.append((time.perf_counter() - t0) / frames * 1e3)
         out[mode] = {"ms_per_frame": round(float(np.median(ms)), 4), "blocks_ms_per_frame": [round(x, 4) for x in ms]}
         engines[mode] = e
-    out["determinism_costs"] = round(out["deterministic_scatter"]["ms_per_frame"] / out["racing_default"]["ms_per_frame"] - 1.0, 4)
-    # the racing frames against the deterministic ones, frame by frame over a fresh sequence (both from zeroed reservoirs)
+    out["default_costs_over_racing"] = round(out["default"]["ms_per_frame"] / out["racing"]["ms_per_frame"] - 1.0, 4)
+    out["verification_mode_costs_over_racing"] = round(out["verification_mode"]["ms_per_frame"] / out["racing"]["ms_per_frame"] - 1.0, 4)
+    # the racing frames against the default's, frame by frame over a fresh sequence (both from zeroed reservoirs)
     del engines
-    a, b = make(0), make(F.CTX_DETERMINISTIC_SCATTER)
+    a, b = make(F.CTX_RACING_SCATTER), make(0)
     o = None
     if oracle_frames > 0 and oracle_engine is not None:
         o = oracle_engine()
@@ -130,10 +133,10 @@ def run(hk, F, config, device=0, frames=48, blocks=3, warmup=24, compare_frames=
             to = o.read_f16(F.BUF_TONE_MAPPED)
             dev_o_racing.append(rel_l2(ta, to))
             dev_o_det.append(rel_l2(tb, to))
-    out["racing_vs_deterministic_rel_l2_per_frame"] = [float("%.3e" % x) for x in dev]
-    out["racing_vs_deterministic_rel_l2_max"] = float("%.3e" % max(dev))
+    out["racing_vs_default_rel_l2_per_frame"] = [float("%.3e" % x) for x in dev]
+    out["racing_vs_default_rel_l2_max"] = float("%.3e" % max(dev))
     if o is not None:
-        out["vs_oracle_rel_l2_per_frame"] = {"racing_default": [float("%.3e" % x) for x in dev_o_racing], "deterministic_scatter": [float("%.3e" % x) for x in dev_o_det]}
+        out["vs_oracle_rel_l2_per_frame"] = {"racing": [float("%.3e" % x) for x in dev_o_racing], "default": [float("%.3e" % x) for x in dev_o_det]}
     return out
 
 
