@@ -59,6 +59,8 @@ int free_screen(hk_ctx* c) {
   }
   if (c->wf_mem) (void)hipFree(c->wf_mem);
   c->wf_mem = nullptr;
+  if (c->wf_paths_mem) (void)hipFree(c->wf_paths_mem);
+  c->wf_paths_mem = nullptr;
   if (c->wf.timeline) (void)hipFree(c->wf.timeline);
   c->wf = hkd::WfBuffers{};
   if (c->depth_plane) (void)hipFree(c->depth_plane);
@@ -542,6 +544,38 @@ int ensure_wavefront(hk_ctx* c) {
   const bool tl_twin = c->wf_timeline, count_twin = (c->flags & HK_CTX_COUNT_WALKS) != 0u;
   if ((tl_twin || count_twin) && !w.timeline) HK_HIP(hipMalloc((void**)&w.timeline, 64 * 32 * sizeof(unsigned long long)));  // tools/wf_timeline.py, bench.py
   w.timeline_mode = count_twin ? 2u : (tl_twin ? 1u : 0u);
+  w.pb_add = nullptr; w.pb_sh = nullptr; w.local = nullptr; w.pb_bounces = 0u;   // (re-carved below for the new size)
+  if (c->wf_paths_mem) { HK_HIP(hipFree(c->wf_paths_mem)); c->wf_paths_mem = nullptr; }
+  return HK_OK;
+}
+// whether the queue-based schedule runs every bounce in one launch (kernels_wavefront.hip k_wf_trace_wide<.., PATHS>):
+// hk_debug_set_option(HK_DEBUG_OPT_PERSISTENT_PATHS), -1 = the rule
+#ifndef HK_PERSISTENT_PATHS_RULE
+#define HK_PERSISTENT_PATHS_RULE false   // (measured: no faster than the stages on a full frame or a band - DESIGN 8.1c, profiles/r06_persistent_paths_ab.json)
+#endif
+static bool persistent_paths(const hk_ctx* c) {
+  if (!(c->persistent_paths < 0 ? HK_PERSISTENT_PATHS_RULE : c->persistent_paths != 0)) return false;
+  return use_wide(c) && !(c->flags & HK_CTX_COUNT_WALKS) && c->frame.indirect_bounces >= 1u && c->frame.indirect_bounces <= 16u &&
+         (size_t)c->RW * c->RH <= ((size_t)1 << 26);
+}
+// ... its planes per bounce (36 B per path and bounce) and the waves' own lists (4 KB per wave of the launch), for at least `bounces`
+int ensure_wavefront_paths(hk_ctx* c, uint32_t bounces) {
+  hkd::WfBuffers& w = c->wf;
+  if (c->wf_paths_mem && w.pb_bounces >= bounces) return HK_OK;
+  if (c->wf_paths_mem) {
+    HK_HIP(hipStreamSynchronize(c->stream));
+    HK_HIP(hipFree(c->wf_paths_mem));
+    c->wf_paths_mem = nullptr;
+    w.pb_bounces = 0u;
+  }
+  const size_t n = w.cap, waves = hk::wide_trace_lanes(c->compute_units) / 64u;
+  const size_t bytes = (size_t)bounces * n * (2 * 16 + 4) + waves * 1024 * sizeof(uint32_t);
+  HK_HIP(hipMalloc(&c->wf_paths_mem, bytes));
+  uint8_t* p = (uint8_t*)c->wf_paths_mem;
+  w.pb_add = (float4*)p; p += (size_t)bounces * n * 32;
+  w.pb_sh = (uint32_t*)p; p += (size_t)bounces * n * 4;
+  w.local = (uint32_t*)p;
+  w.pb_bounces = bounces;
   return HK_OK;
 }
 
@@ -695,12 +729,14 @@ int run_pass(hk_ctx* c, uint32_t pass, uint32_t arg, int y0, int y1) {
           wide.spill = c->wide_spill;
           wide.lost = c->d_counters + 8;
         }
-        // (HK_TIMING_TRACE_STAGES: every trace launch of the pass between its own pair of events)
+        const bool persistent = persistent_paths(c);
+        if (persistent) { const int rc_ = ensure_wavefront_paths(c, c->frame.indirect_bounces); if (rc_) return rc_; }
+        // (HK_TIMING_TRACE_STAGES: every trace launch of the pass between its own pair of events; the persistent schedule has one)
         std::vector<hipEvent_t> trace_events;
         if ((c->timing_mask >> HK_TIMING_TRACE_STAGES) & 1u)
-          for (uint32_t k = 0; k < 2u * (c->frame.indirect_bounces + 1u); ++k) trace_events.push_back(get_event(c));
+          for (uint32_t k = 0; k < (persistent ? 2u : 2u * (c->frame.indirect_bounces + 1u)); ++k) trace_events.push_back(get_event(c));
         launch_indirect_wavefront(c->stream, c->scene, fr, g, t, c->wf, y0, y1, c->compute_units, timer.on ? timer.t.start : nullptr,
-                                  timer.on ? timer.t.stop : nullptr, &wide, trace_events.empty() ? nullptr : trace_events.data());
+                                  timer.on ? timer.t.stop : nullptr, &wide, trace_events.empty() ? nullptr : trace_events.data(), persistent);
         for (size_t k = 0; k + 1 < trace_events.size(); k += 2) c->pending.push_back(TimedLaunch{HK_TIMING_TRACE_STAGES, trace_events[k], trace_events[k + 1]});
       } else if (pass == HK_PASS_INDIRECT)  // MULTIPLE_BOUNCES pipeline iff bounces >= 2, light.rs:663-666
         launch_indirect(c->stream, c->frame.indirect_bounces >= 2u, c->scene, fr, g, t, y0, y1, counters, timer.on ? timer.t.start : nullptr,
@@ -949,6 +985,7 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
     case HK_DEBUG_OPT_TRACE_UPDATE: c->trace_update = value != 0; break;
     case HK_DEBUG_OPT_SIDE_JOIN: c->side_join_each_frame = value != 0; break;
     case HK_DEBUG_OPT_POST_DEMODULATION: c->post_demodulation = value < 0 ? -1 : (value ? 1 : 0); break;
+    case HK_DEBUG_OPT_PERSISTENT_PATHS: c->persistent_paths = value < 0 ? -1 : (value ? 1 : 0); break;
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown option %u", option);
   }
   return HK_OK;

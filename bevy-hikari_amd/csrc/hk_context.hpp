@@ -143,6 +143,7 @@ struct hk_ctx {
   int spatial_window = -1;               // which form of k_spatial_reuse a launch takes: -1 by its size, 0 plain, 1 windowed (kernels.hip launch_spatial)
   uint64_t spatial_windowed_launches = 0;
   bool frame_pipeline = true;            // the a-trous levels of frame n beside frame n + 1's light passes (post_stream)
+  int persistent_paths = -1;             // HK_DEBUG_OPT_PERSISTENT_PATHS: every bounce of the queue-based indirect pass in one launch (-1: the rule)
   bool wf_timeline = false;              // the instrumented twin of the trace kernels (tools/wf_timeline.py)
   bool flat_walk = true;                 // the one-level tree for scenes under one transform (scene_layout.hip)
   int flat_orderings = 0;                // ... with this many direction orderings (0: as many as fit 4 KB)
@@ -246,6 +247,7 @@ struct hk_ctx {
   // scratch of the queue-based schedule of indirect_lit_ambient (hikari_hip.h HK_CTX_WAVEFRONT): ONE allocation, carved into
   // the planes of hkd::WfBuffers on first use and again after hk_resize
   void* wf_mem = nullptr;
+  void* wf_paths_mem = nullptr;          // the persistent schedule's planes per bounce + the waves' own lists (context.hip ensure_wavefront_paths)
   hkd::WfBuffers wf{};
   // wide trees of the trace stages (hk_kernels.hpp WideTrees): records derived ON THE DEVICE from ordering 0 of the trees the scene
   // blob holds, lazily - the mesh trees when the mesh-level region was rebuilt, the instance tree whenever it was uploaded, refit or

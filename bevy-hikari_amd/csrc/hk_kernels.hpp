@@ -77,6 +77,14 @@ struct WfBuffers {
   uint32_t* alive[2];  // slots alive at a bounce (= the closest-hit rays of that bounce's trace stage), ping-pong
   uint32_t* shadow[2]; // slots whose shadow ray the trace stage walks, ping-pong
   uint32_t cap;
+  // The persistent schedule (round 6; kernels_wavefront.hip k_wf_trace_wide<.., PATHS = true>): every bounce in ONE launch, a path stays
+  // with the wave that claimed it.  Per bounce n: the two outcomes of its shadow ray (planes 2n, 2n + 1 of pb_add) and the instance that
+  // ray hit (plane n of pb_sh) - a shadow ray is off the path's critical chain, nothing waits for it before k_wf_final.  `local`: 512
+  // u32 per wave of the launch - a ring of 256 rays its own shading emitted and a ring of 256 paths whose closest hit waits for shading.
+  float4* pb_add;
+  uint32_t* pb_sh;
+  uint32_t* local;
+  uint32_t pb_bounces;  // bounces the per-bounce planes were allocated for (0: none - the staged schedule)
   // HK_WF_TIMELINE=1 (tools/wf_timeline.py; null otherwise, and then the instrumented instantiation of k_wf_trace never runs): 32
   // u64 per trace stage, zeroed per dispatch - [0] ~first wave start, [1] ~first time a wave found the queue exhausted, [2] last
   // wave exit (wall_clock64 ticks; ~x = UINT64_MAX - x so that atomicMax keeps the minimum), [3] sum of the waves' resident ticks,
@@ -294,10 +302,11 @@ void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, floa
 // x the stack entries a lane keeps beyond LDS) - asked of the file that launches the kernel, so that the two cannot disagree
 size_t wide_trace_lanes(int compute_units);
 size_t wide_spill_entries();
-// trace_events: nullptr, or 2 x (bounces + 1) events - start / stop of every trace launch (HK_TIMING_TRACE_STAGES)
+// trace_events: nullptr, or 2 x (bounces + 1) events - start / stop of every trace launch (HK_TIMING_TRACE_STAGES).  persistent: every
+// bounce in ONE launch (k_wf_trace_wide<.., PATHS>; needs the wide trees and WfBuffers::pb_* for the frame's bounces, else the stages run)
 void launch_indirect_wavefront(hipStream_t st, const hkd::DScene& sc, const hkd::DFrame& fr, const hkd::GBuffer& g, const hkd::LightTargets& t,
                                const hkd::WfBuffers& w, int y0, int y1, int compute_units, hipEvent_t start = nullptr, hipEvent_t stop = nullptr,
-                               const hkd::WideTrees* wide = nullptr, hipEvent_t* trace_events = nullptr);
+                               const hkd::WideTrees* wide = nullptr, hipEvent_t* trace_events = nullptr, bool persistent = false);
 void launch_copy_region(hipStream_t st, void* dst, const void* src, size_t bytes);
 void launch_gather_instance_boxes(hipStream_t st, const hkd::RefitScene& s, const float4* tlas, uint32_t tlas_count);
 // the first n_emitter_updates records are the moved emitters (the largest of their meshes has emitter_triangles triangles)

@@ -556,7 +556,22 @@ __global__ __launch_bounds__(256) void k_build_wide(const float4* __restrict__ n
 #ifndef HK_WF_SHARE_STEPS
 #define HK_WF_SHARE_STEPS 8u  // ... and records a lane must have visited for its piece before it does: only the long walks end a stage
 #endif
-enum : uint32_t { PH_WAIT = 4u, PH_HELPED = 5u };  // a root whose helpers are still out / a helper whose piece is done (merged at the next turn)
+namespace {
+template <bool PATHS>
+__device__ __forceinline__ void shade_bounce(const DScene& sc, const DFrame& fr, const WfBuffers& w, uint32_t slot, uint32_t n, bool& want_shadow, bool& want_next);  // (below, with k_wf_shade)
+}
+enum : uint32_t { PH_WAIT = 4u, PH_HELPED = 5u, PH_READY = 6u };  // a root whose helpers are still out / a helper whose piece is done (merged at the next turn) / PATHS: a closest hit found, the path goes to the wave's shading list at the next turn
+// PATHS: a queue entry = slot | bounce << 26 | WF_SHADOW
+constexpr uint32_t WF_SLOT_BITS = 26u, WF_SLOT_MASK = (1u << WF_SLOT_BITS) - 1u, WF_BOUNCE_MASK = 31u;
+#ifndef HK_WF_PATHS_SHADE_EARLY
+#define HK_WF_PATHS_SHADE_EARLY 48u  // PATHS: paths waiting for shading from which on a wave shades them rather than take new paths from the global queue
+#endif
+#ifndef HK_WF_PATHS_BLOCK
+#define HK_WF_PATHS_BLOCK 64u       // PATHS: paths a wave reserves at a time (the staged stages reserve 256 rays until near the end)
+#endif
+#ifndef HK_WF_PATHS_SHADE_MIN
+#define HK_WF_PATHS_SHADE_MIN 16u  // PATHS, a dry wave: paths that must wait for shading before the wave shades them (or as many as half its working lanes)
+#endif
 __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
 // TL: the instrumented twin, as for k_wf_trace - tools/wf_timeline.py.  COUNT (round 5; HK_CTX_COUNT_WALKS): the COUNTING twin of
@@ -564,8 +579,40 @@ __device__ __forceinline__ uint32_t lane_u32(uint32_t v, int lane) { return (uin
 // closest hits found, pieces handed to idle lanes - per stage into WfBuffers::timeline[32 stage + 8 ..], next to three stamps (first
 // wave in, queue first seen dry, last wave out) from which bench.py takes the stage's tail fraction.  The product launches
 // <false, false>; the three differ in bookkeeping only: a ray's walk and result are the same.
-template <bool TL, bool COUNT>
-__global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene sc, WfBuffers w, WideTrees wt, uint32_t stage) {
+//
+// PATHS (round 6): EVERY bounce of the dispatch in this one launch - `stage` is not read.  The global
+// queue holds the paths themselves (bounce 0's closest-hit rays, k_wf_setup's slots); a wave that claims a path keeps it to its end:
+// when the closest hit of bounce n is found the path goes to the wave's own SHADING list, the wave shades 64 of them at a time with all
+// its lanes (shade_bounce<true>: the same code the staged schedule's k_wf_shade runs), and the rays that emits - the shadow ray of
+// bounce n, the closest-hit ray of bounce n + 1 - go to the wave's own RAY list, which idle lanes are refilled from before they take
+// new paths.  Both lists are the wave's private memory (WfBuffers::local), every plane of a path is written and read by ONE wave, in
+// program order: no hand-off between workgroups, no flag, no fence, nothing to wait for - and so nothing that could hang.  What this
+// buys: a stage's end (the queue dry, a few long walks left: 42-70 % of a stage's time on configs 3 / 4) exists once per
+// dispatch instead of once per bounce, the walks of bounce n + 1 start while those of bounce n are still out, a shadow ray is off
+// its path's chain (nothing waits for its outcome before k_wf_final), and the dispatch is three launches instead of 2 x bounces + 3.
+// A ray's walk, a bounce's arithmetic and the order of a path's additions are the staged schedule's: the same bytes in every buffer
+// (tests/test_parity_schedules_gpu.py).  The shadow ray's RECORD (sr0 / sr1 / sr2) stays one per path: the ray list is first in,
+// first out and bounce n's shadow ray enters it before bounce n + 1's closest-hit ray, so its walk has begun (the record is in
+// registers) before bounce n + 1 can be shaded; its RESULT has a plane per bounce.
+#ifndef HK_WF_PATHS_WAVES
+#define HK_WF_PATHS_WAVES 4  // waves per SIMD the PATHS instantiation is compiled for: the shading needs 116 VGPRs on its own, the walk 93 - at five waves
+                             // (96) 113 are spilled and the dispatch is 1.33x the staged one; the shading as a CALL (the walk saved around it, the kernel's
+                             // arguments read from its argument segment by the callee) 1.17-1.20x; four waves (128, 22 spilled) 1.04-1.10x (profiles/r06_persistent_paths_ab.json)
+#endif
+struct WideTraceArgs {
+  DScene sc;
+  DFrame fr;
+  WfBuffers w;
+  WideTrees wt;
+  uint32_t stage;
+};
+template <bool TL, bool COUNT, bool PATHS>
+__global__ __launch_bounds__(256, (PATHS ? HK_WF_PATHS_WAVES : HK_WF_WIDE_WAVES)) void k_wf_trace_wide(const WideTraceArgs args) {
+  const DScene& sc = args.sc;
+  const DFrame& fr = args.fr;
+  const WfBuffers& w = args.w;
+  const WideTrees& wt = args.wt;
+  uint32_t stage = args.stage;
   __shared__ uint32_t stack_lds[HK_WIDE_LDS_STACK * 256u];
   __shared__ uint32_t tl_hist[16];
   unsigned long long tl_start = 0ull;
@@ -582,7 +629,13 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 0u], ~tl_start);
   }
   WideStackSpill stack{stack_lds, wt.spill, (size_t)gridDim.x * 256u, (size_t)blockIdx.x * 256u + threadIdx.x, wt.lost};
-  const uint32_t n_alive = w.ctr[WF_ALIVE + stage], q_count = n_alive + w.ctr[WF_SHADOWS + stage];
+  if (PATHS) stage = 0u;
+  const uint32_t n_alive = w.ctr[WF_ALIVE + stage], q_count = PATHS ? n_alive : n_alive + w.ctr[WF_SHADOWS + stage];
+  // PATHS: the wave's own lists, rings of 512 (positions count up, taken mod 512).  The ray list holds at most 256 (shading needs room
+  // for 128), the shading list at most 63 + the 192 closest hits that can come in while the ray list drains from 256 to 128
+  uint32_t* const rayq = PATHS ? w.local + ((size_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 1024u : nullptr;
+  uint32_t* const shadeq = PATHS ? rayq + 512u : nullptr;
+  uint32_t rq_head = 0u, rq_count = 0u, sq_head = 0u, sq_count = 0u;
 #if HK_WF_QUEUE_INTERLEAVE
   // the queue is handed out in a PERMUTED order: runs of 8 consecutive entries (neighbouring pixels: coherent rays) from places a
   // large odd stride apart, so that a wave's block of 64 samples eight regions of the image instead of one - the cost of a block
@@ -611,7 +664,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
   WideWalk k;
   wide_begin(k, wt, F3(0, 0, 0), F3(1, 1, 1), 0.0f, 0.0f, HK_DONT_EXCLUDE);
   auto begin_ray = [&](uint32_t id, float bound) {  // the ray of queue entry `id`, from its planes
-    const uint32_t slot = id & ~WF_SHADOW;
+    const uint32_t slot = PATHS ? id & WF_SLOT_MASK : id & ~WF_SHADOW;
     if (id & WF_SHADOW) {
       const float4 a = w.sr0[slot], b4 = w.sr1[slot];
       wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), fminf(a.w, bound), b4.w, w.sr2[slot]);
@@ -620,15 +673,18 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
       wide_begin(k, wt, F3(a.x, a.y, a.z), F3(b4.x, b4.y, b4.z), bound, 0.0f, HK_DONT_EXCLUDE);
     }
   };
-  auto write_result = [&]() {  // (root) the ray is done: its result goes to the slot
-    const uint32_t slot = entry_id & ~WF_SHADOW;
+  auto write_result = [&]() -> uint32_t {  // (root) the ray is done: its result goes to the slot; returns the lane's next phase
+    const uint32_t slot = PATHS ? entry_id & WF_SLOT_MASK : entry_id & ~WF_SHADOW;
     if (entry_id & WF_SHADOW) {
-      w.sh[slot] = k.hit.instance_index;
+      if (PATHS) w.pb_sh[(size_t)((entry_id >> WF_SLOT_BITS) & WF_BOUNCE_MASK) * w.cap + slot] = k.hit.instance_index;
+      else w.sh[slot] = k.hit.instance_index;
     } else {
       w.ch0[slot] = make_float4(k.hit.distance, k.hit.uv.x, k.hit.uv.y, u2f(k.hit.primitive_index));
       w.ch1[slot] = k.hit.instance_index;
       if (COUNT) cn.hits += k.hit.instance_index != HK_U32_MAX ? 1u : 0u;
+      if (PATHS) return PH_READY;
     }
+    return PH_IDLE;
   };
   auto finish = [&]() {  // the lane's piece of a walk has ended
     if (TL) {
@@ -652,8 +708,7 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
     } else if (share_help[threadIdx.x] != 0u) {
       phase = PH_WAIT;
     } else {
-      write_result();
-      phase = PH_IDLE;
+      phase = write_result();
     }
   };
   for (;;) {
@@ -682,28 +737,78 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
       }
     }
     if (phase == PH_HELPED) phase = PH_IDLE;
-    if (phase == PH_WAIT && share_help[threadIdx.x] == 0u) {
-      write_result();
-      phase = PH_IDLE;
-    }
+    if (phase == PH_WAIT && share_help[threadIdx.x] == 0u) phase = write_result();
 #endif
+    if (PATHS) {  // closest hits found since the last turn: their paths wait for shading
+      const unsigned long long ready = __ballot(phase == PH_READY);
+      if (ready != 0ull) {
+        if (phase == PH_READY) {
+          shadeq[(sq_head + sq_count + lane_rank(ready)) & 511u] = entry_id;
+          phase = PH_IDLE;
+        }
+        sq_count += (uint32_t)__popcll(ready);
+      }
+      // Shade: 64 paths with all 64 lanes (a lane in the middle of a walk keeps its walk in its registers and takes a turn at shading
+      // like the others) as soon as 64 wait and the ray list has room for what they may emit; a wave with no other source of rays left
+      // shades what it has once that is worth stopping its working lanes for.
+      const uint32_t n_working = 64u - (uint32_t)__popcll(__ballot(phase == PH_IDLE));
+      const bool starving = exhausted && res_count == 0u && rq_count == 0u;
+      // (... and BEFORE it takes new paths from the global queue for its idle lanes: a wave that hoards paths - 64 walking, 63 waiting for
+      // shading, 128 rays listed - leaves nothing for the queue to balance: 5 120 waves x 250 paths is a whole 1080p frame)
+      const uint32_t n_idle_now = 64u - n_working;
+      const bool would_claim = n_idle_now >= HK_WF_REFILL_MIN && rq_count < n_idle_now;
+      const bool shade_now = sq_count >= 64u ? rq_count <= 128u
+                                             : ((would_claim && sq_count >= HK_WF_PATHS_SHADE_EARLY) ||
+                                                (starving && sq_count != 0u && (sq_count >= HK_WF_PATHS_SHADE_MIN || n_working <= 2u * sq_count)));
+      if (shade_now) {
+        const uint32_t batch = min(sq_count, 64u);
+        bool want_shadow = false, want_next = false;
+        uint32_t e = 0u;
+        if (lane < batch) {
+          e = shadeq[(sq_head + lane) & 511u];
+          shade_bounce<true>(sc, fr, w, e & WF_SLOT_MASK, (e >> WF_SLOT_BITS) & WF_BOUNCE_MASK, want_shadow, want_next);
+        }
+        sq_head += batch;
+        sq_count -= batch;
+        // (first in, first out, and a bounce's shadow ray ahead of the next bounce's closest-hit ray: see the header)
+        const unsigned long long ms = __ballot(want_shadow), mn = __ballot(want_next);
+        if (want_shadow) rayq[(rq_head + rq_count + lane_rank(ms)) & 511u] = e | WF_SHADOW;
+        rq_count += (uint32_t)__popcll(ms);
+        if (want_next) rayq[(rq_head + rq_count + lane_rank(mn)) & 511u] = e + (1u << WF_SLOT_BITS);
+        rq_count += (uint32_t)__popcll(mn);
+      }
+    }
     const unsigned long long idle_mask = __ballot(phase == PH_IDLE);
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-    const bool dry = exhausted && res_count == 0u;
+    const bool dry = exhausted && res_count == 0u && (!PATHS || rq_count == 0u);
     if ((TL || COUNT) && exhausted && !tl_seen_dry) {
       tl_seen_dry = true;
       if ((threadIdx.x & 63u) == 0u) atomicMax(&w.timeline[32u * stage + 1u], ~wall_clock64());
     }
-    if (dry && n_idle == 64u) break;
+    if (dry && n_idle == 64u && (!PATHS || sq_count == 0u)) break;
     if (!dry && (n_idle >= HK_WF_REFILL_MIN || n_idle == 64u)) {
       const bool idle = phase == PH_IDLE;
-      const uint32_t rank = lane_rank(idle_mask);
+      uint32_t rank = lane_rank(idle_mask);
       uint32_t mine = HK_U32_MAX;
       uint32_t given = 0u;
-      if (res_count < n_idle && !exhausted) {
+      uint32_t n_idle_q = n_idle;  // idle lanes the global queue is asked for
+      bool local_ray = false;
+      if (PATHS) {  // the wave's own rays first
+        const uint32_t take = min(n_idle, rq_count);
+        if (idle && rank < take) {
+          entry_id = rayq[(rq_head + rank) & 511u];
+          local_ray = true;
+        }
+        rq_head += take;
+        rq_count -= take;
+        n_idle_q = n_idle - take;
+        rank -= take;  // (wraps for the lanes served above: they ask the global queue for nothing)
+      }
+      const bool ask = idle && !local_ray;
+      if (res_count < n_idle_q && !exhausted) {
         given = res_count;
-        if (idle && rank < given) mine = res_base + rank;
-        const uint32_t block = (res_base + given + 4u * all_lanes < tail) ? 256u : HK_WF_BLOCK_SMALL;
+        if (ask && rank < given) mine = res_base + rank;
+        const uint32_t block = PATHS ? HK_WF_PATHS_BLOCK : ((res_base + given + 4u * all_lanes < tail) ? 256u : HK_WF_BLOCK_SMALL);
         uint32_t b = 0u;
         if ((threadIdx.x & 63u) == 0u) b = atomicAdd(head_ptr, block);
         b = __builtin_amdgcn_readfirstlane(b);
@@ -711,8 +816,8 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
         res_count = b < tail ? min(block, tail - b) : 0u;
         if (b + block >= tail) exhausted = true;
       }
-      if (idle && rank >= given && rank - given < res_count) mine = res_base + (rank - given);
-      const uint32_t used = min(n_idle - given, res_count);
+      if (ask && rank >= given && rank - given < res_count) mine = res_base + (rank - given);
+      const uint32_t used = min(n_idle_q - given, res_count);
       res_base += used;
       res_count -= used;
 #if HK_WF_QUEUE_INTERLEAVE
@@ -722,8 +827,8 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
         if (mine >= q_count) mine = HK_U32_MAX;  // (the padding of the last run)
       }
 #endif
-      if (mine != HK_U32_MAX) {
-        entry_id = mine < n_alive ? alive[mine] : (shadow[mine - n_alive] | WF_SHADOW);
+      if (mine != HK_U32_MAX || local_ray) {
+        if (!local_ray) entry_id = PATHS ? mine : (mine < n_alive ? alive[mine] : (shadow[mine - n_alive] | WF_SHADOW));  // (PATHS: bounce 0 of path `mine`, k_wf_setup's slots are their own list)
         begin_ray(entry_id, HK_F32_MAX);
         if (COUNT) {
           cn.tlas += 1u;
@@ -905,6 +1010,109 @@ __global__ __launch_bounds__(256, HK_WF_WIDE_WAVES) void k_wf_trace_wide(DScene 
 #ifndef HK_WF_SHADE_WAVES
 #define HK_WF_SHADE_WAVES 4
 #endif
+namespace {
+// Bounce `n` of the path in `slot`, from its closest hit on: light.wgsl:1313-1394, one iteration (bounce_step of kernels.hip).
+// PATHS = false, the staged schedule: the shadow ray of bounce n - 1 has been traced by the stage before, its outcome is added first.
+// PATHS = true, k_wf_paths: nothing here waits for a shadow ray - the two outcomes of bounce n's go to the planes OF THAT BOUNCE
+// (WfBuffers::pb_add), the bounce's bit to the path's pending mask, and k_wf_final<true> adds what the walks selected, in bounce order.
+template <bool PATHS>
+__device__ __forceinline__ void shade_bounce(const DScene& sc, const DFrame& fr, const WfBuffers& w, uint32_t slot, uint32_t n, bool& want_shadow, bool& want_next) {
+  RayCounters rc{0, 0};
+  f4 random = F4(plane(w, PL_RANDOM)[slot]);
+  const float4 pp = plane(w, PL_POSITION_PDF)[slot];
+  const float4 np = plane(w, PL_NORMAL_PENDING)[slot];
+  f3 position = F3(pp.x, pp.y, pp.z), normal = F3(np.x, np.y, np.z);
+  float pdf = pp.w;
+  f3 transport = F3(1.0f, 1.0f, 1.0f);  // light.wgsl:1310-1311
+  f4 radiance = F4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (n != 0u) {
+    transport = xyz(F4(plane(w, PL_TRANSPORT)[slot]));
+    if (!PATHS) radiance = F4(plane(w, PL_RADIANCE)[slot]);
+  }
+  uint32_t mask = PATHS ? f2u(np.w) : 0u;  // PATHS: bit k = bounce k has a shadow ray out, bit 31 = the path left the scene (its sky term: PL_RADIANCE)
+  if (!PATHS && np.w != 0.0f) {  // the shadow ray of bounce n - 1 has been traced by now: add the outcome it selected
+    const float4 add = (w.sh[slot] != HK_U32_MAX) ? plane(w, PL_ADD_OCCLUDED)[slot] : plane(w, PL_ADD_CLEAR)[slot];
+    radiance = radiance + F4(add.x, add.y, add.z, 1.0f);
+  }
+  const float4 ro = w.cr0[slot], rd = w.cr1[slot], h0 = w.ch0[slot];
+  Ray ray;
+  ray.origin = F3(ro.x, ro.y, ro.z);
+  ray.direction = F3(rd.x, rd.y, rd.z);
+  ray.inv_direction = F3(0, 0, 0);  // not read below
+  const float rand_sample_w = rd.w;
+  Hit hit;
+  hit.distance = h0.x;
+  hit.uv = F2(h0.y, h0.z);
+  hit.primitive_index = f2u(h0.w);
+  hit.instance_index = w.ch1[slot];
+  HitInfo info = hit_info(sc, ray, hit);
+  if (n == 0u) {
+    plane(w, PL_FIRST_POSITION)[slot] = to_float4(info.position);
+    plane(w, PL_FIRST_NORMAL)[slot] = make_float4(info.normal.x, info.normal.y, info.normal.z, 0.0f);
+    pdf = rand_sample_w;
+  }
+  const f3 sample_position = xyz(info.position);
+  const f3 sample_normal = info.normal;
+  float pending = 0.0f;
+  if (hit.instance_index != HK_U32_MAX) {
+    Surface surface = retreive_surface(sc, info.material_index, info.uv);
+    surface.roughness = 1.0f;
+    const uint32_t info_instance = info.instance_index;
+    LightCandidate candidate = select_light_candidate(sc, fr, random, sample_position, sample_normal, info_instance, info, rc);
+    const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
+    const f3 bounce_view_direction = normalize(position - sample_position);
+    if (dot(candidate.direction, sample_normal) > 0.0f && candidate.p > 0.0f) {
+      Ray sray;
+      sray.origin = sample_position + sample_normal * HK_RAY_BIAS;
+      sray.direction = candidate.direction;
+      sray.inv_direction = F3(0, 0, 0);
+      w.sr0[slot] = make_float4(sray.origin.x, sray.origin.y, sray.origin.z, candidate.max_distance);
+      w.sr1[slot] = make_float4(sray.direction.x, sray.direction.y, sray.direction.z, candidate.min_distance);
+      w.sr2[slot] = candidate.emissive_instance;
+      // both outcomes of the walk (see the header): unoccluded = the candidate's own hit info, occluded = (0,0,0,1)
+      const f4 in_clear = input_radiance(sc, fr, sray, info, sample_directional, candidate.emissive_instance, false);
+      f3 add[2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const f4 in_radiance = o == 0 ? in_clear : F4(0.0f, 0.0f, 0.0f, 1.0f);
+        f3 out_radiance = shading(fr, bounce_view_direction, sample_normal, sray.direction, surface, in_radiance);
+        out_radiance = out_radiance / candidate.p;
+        if (n > 0u) out_radiance = (rand_sample_w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample_w;
+        const float out_luminance = luminance(out_radiance);
+        if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
+        add[o] = transport * out_radiance;
+      }
+      float4* add_clear = PATHS ? w.pb_add + (size_t)(2u * n) * w.cap : plane(w, PL_ADD_CLEAR);
+      float4* add_occluded = PATHS ? w.pb_add + (size_t)(2u * n + 1u) * w.cap : plane(w, PL_ADD_OCCLUDED);
+      add_clear[slot] = make_float4(add[0].x, add[0].y, add[0].z, 0.0f);
+      add_occluded[slot] = make_float4(add[1].x, add[1].y, add[1].z, 0.0f);
+      pending = 1.0f;
+      mask |= 1u << n;
+      want_shadow = true;
+    }
+    transport = transport * env_brdf(bounce_view_direction, sample_normal, surface);
+    random = fract(random + fr.number_golden);
+    position = sample_position;
+    normal = sample_normal;
+    // the loop condition of light.wgsl:1313 for bounce n + 1
+    want_next = n + 1u < fr.indirect_bounces && (transport.x > 0.01f || transport.y > 0.01f || transport.z > 0.01f);
+    if (want_next) emit_bounce_ray(w, slot, random, position, normal);
+  } else {
+    const f3 out_radiance = xyz(input_radiance(sc, fr, ray, info, false, HK_DONT_SAMPLE_EMISSIVE, true));
+    if (PATHS) {  // (the last addition of the path: after every shadow ray's outcome - k_wf_final<true>)
+      radiance = F4(transport * out_radiance, 0.0f);
+      mask |= 0x80000000u;
+    } else {
+      radiance = radiance + F4(transport * out_radiance, 0.0f);
+    }
+  }
+  plane(w, PL_RANDOM)[slot] = to_float4(random);
+  plane(w, PL_POSITION_PDF)[slot] = make_float4(position.x, position.y, position.z, pdf);
+  plane(w, PL_NORMAL_PENDING)[slot] = make_float4(normal.x, normal.y, normal.z, PATHS ? u2f(mask) : pending);
+  plane(w, PL_TRANSPORT)[slot] = make_float4(transport.x, transport.y, transport.z, 0.0f);
+  if (!PATHS || (mask & 0x80000000u)) plane(w, PL_RADIANCE)[slot] = to_float4(radiance);
+}
+}  // namespace
 template <bool LDS>
 __global__ __launch_bounds__(256, HK_WF_SHADE_WAVES) void k_wf_shade(DScene gsc, DFrame fr, WfBuffers w, uint32_t n) {
   const DScene sc = stage_scene<LDS>(gsc);
@@ -913,7 +1121,6 @@ __global__ __launch_bounds__(256, HK_WF_SHADE_WAVES) void k_wf_shade(DScene gsc,
   uint32_t* alive_out = w.alive[(n + 1u) & 1u];
   uint32_t* shadow_out = w.shadow[(n + 1u) & 1u];
   __shared__ uint32_t push_lds[6];
-  RayCounters rc{0, 0};
   for (uint32_t first = blockIdx.x * 256u; first < count; first += gridDim.x * 256u) {  // workgroup-uniform trip count
     const uint32_t i = first + threadIdx.x;
     const bool valid = i < count;
@@ -921,91 +1128,7 @@ __global__ __launch_bounds__(256, HK_WF_SHADE_WAVES) void k_wf_shade(DScene gsc,
     uint32_t slot = 0u;
     if (valid) {
       slot = alive_in[i];
-      f4 random = F4(plane(w, PL_RANDOM)[slot]);
-      const float4 pp = plane(w, PL_POSITION_PDF)[slot];
-      const float4 np = plane(w, PL_NORMAL_PENDING)[slot];
-      f3 position = F3(pp.x, pp.y, pp.z), normal = F3(np.x, np.y, np.z);
-      float pdf = pp.w;
-      f3 transport = F3(1.0f, 1.0f, 1.0f);  // light.wgsl:1310-1311
-      f4 radiance = F4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (n != 0u) {
-        transport = xyz(F4(plane(w, PL_TRANSPORT)[slot]));
-        radiance = F4(plane(w, PL_RADIANCE)[slot]);
-      }
-      if (np.w != 0.0f) {  // the shadow ray of bounce n - 1 has been traced by now: add the outcome it selected
-        const float4 add = (w.sh[slot] != HK_U32_MAX) ? plane(w, PL_ADD_OCCLUDED)[slot] : plane(w, PL_ADD_CLEAR)[slot];
-        radiance = radiance + F4(add.x, add.y, add.z, 1.0f);
-      }
-      // light.wgsl:1313-1394, one iteration (bounce_step of kernels.hip) from the hit on
-      const float4 ro = w.cr0[slot], rd = w.cr1[slot], h0 = w.ch0[slot];
-      Ray ray;
-      ray.origin = F3(ro.x, ro.y, ro.z);
-      ray.direction = F3(rd.x, rd.y, rd.z);
-      ray.inv_direction = F3(0, 0, 0);  // not read below
-      const float rand_sample_w = rd.w;
-      Hit hit;
-      hit.distance = h0.x;
-      hit.uv = F2(h0.y, h0.z);
-      hit.primitive_index = f2u(h0.w);
-      hit.instance_index = w.ch1[slot];
-      HitInfo info = hit_info(sc, ray, hit);
-      if (n == 0u) {
-        plane(w, PL_FIRST_POSITION)[slot] = to_float4(info.position);
-        plane(w, PL_FIRST_NORMAL)[slot] = make_float4(info.normal.x, info.normal.y, info.normal.z, 0.0f);
-        pdf = rand_sample_w;
-      }
-      const f3 sample_position = xyz(info.position);
-      const f3 sample_normal = info.normal;
-      float pending = 0.0f;
-      if (hit.instance_index != HK_U32_MAX) {
-        Surface surface = retreive_surface(sc, info.material_index, info.uv);
-        surface.roughness = 1.0f;
-        const uint32_t info_instance = info.instance_index;
-        LightCandidate candidate = select_light_candidate(sc, fr, random, sample_position, sample_normal, info_instance, info, rc);
-        const bool sample_directional = (candidate.emissive_instance == HK_DONT_SAMPLE_EMISSIVE);
-        const f3 bounce_view_direction = normalize(position - sample_position);
-        if (dot(candidate.direction, sample_normal) > 0.0f && candidate.p > 0.0f) {
-          Ray sray;
-          sray.origin = sample_position + sample_normal * HK_RAY_BIAS;
-          sray.direction = candidate.direction;
-          sray.inv_direction = F3(0, 0, 0);
-          w.sr0[slot] = make_float4(sray.origin.x, sray.origin.y, sray.origin.z, candidate.max_distance);
-          w.sr1[slot] = make_float4(sray.direction.x, sray.direction.y, sray.direction.z, candidate.min_distance);
-          w.sr2[slot] = candidate.emissive_instance;
-          // both outcomes of the walk (see the header): unoccluded = the candidate's own hit info, occluded = (0,0,0,1)
-          const f4 in_clear = input_radiance(sc, fr, sray, info, sample_directional, candidate.emissive_instance, false);
-          f3 add[2];
-#pragma unroll
-          for (int o = 0; o < 2; ++o) {
-            const f4 in_radiance = o == 0 ? in_clear : F4(0.0f, 0.0f, 0.0f, 1.0f);
-            f3 out_radiance = shading(fr, bounce_view_direction, sample_normal, sray.direction, surface, in_radiance);
-            out_radiance = out_radiance / candidate.p;
-            if (n > 0u) out_radiance = (rand_sample_w < 0.01f) ? F3(0, 0, 0) : out_radiance / rand_sample_w;
-            const float out_luminance = luminance(out_radiance);
-            if (out_luminance > fr.max_indirect_luminance) out_radiance = out_radiance * fr.max_indirect_luminance / out_luminance;
-            add[o] = transport * out_radiance;
-          }
-          plane(w, PL_ADD_CLEAR)[slot] = make_float4(add[0].x, add[0].y, add[0].z, 0.0f);
-          plane(w, PL_ADD_OCCLUDED)[slot] = make_float4(add[1].x, add[1].y, add[1].z, 0.0f);
-          pending = 1.0f;
-          want_shadow = true;
-        }
-        transport = transport * env_brdf(bounce_view_direction, sample_normal, surface);
-        random = fract(random + fr.number_golden);
-        position = sample_position;
-        normal = sample_normal;
-        // the loop condition of light.wgsl:1313 for bounce n + 1
-        want_next = n + 1u < fr.indirect_bounces && (transport.x > 0.01f || transport.y > 0.01f || transport.z > 0.01f);
-        if (want_next) emit_bounce_ray(w, slot, random, position, normal);
-      } else {
-        const f3 out_radiance = xyz(input_radiance(sc, fr, ray, info, false, HK_DONT_SAMPLE_EMISSIVE, true));
-        radiance = radiance + F4(transport * out_radiance, 0.0f);
-      }
-      plane(w, PL_RANDOM)[slot] = to_float4(random);
-      plane(w, PL_POSITION_PDF)[slot] = make_float4(position.x, position.y, position.z, pdf);
-      plane(w, PL_NORMAL_PENDING)[slot] = make_float4(normal.x, normal.y, normal.z, pending);
-      plane(w, PL_TRANSPORT)[slot] = make_float4(transport.x, transport.y, transport.z, 0.0f);
-      plane(w, PL_RADIANCE)[slot] = to_float4(radiance);
+      shade_bounce<false>(sc, fr, w, slot, n, want_shadow, want_next);
     }
     // survivors and shadow rays of the next trace stage: one atomic per workgroup and list
     const uint32_t a = block_push(&w.ctr[WF_ALIVE + n + 1u], want_next, push_lds);
@@ -1016,6 +1139,7 @@ __global__ __launch_bounds__(256, HK_WF_SHADE_WAVES) void k_wf_shade(DScene gsc,
 }
 
 // ------------------------------------------------------------------ final: last shadow result + the temporal-reuse tail
+template <bool PATHS>
 __global__ __launch_bounds__(256, 4) void k_wf_final(DScene sc, DFrame fr, GBuffer g, LightTargets t, WfBuffers w) {
   const uint32_t count = w.ctr[WF_ALIVE];
   for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < count; slot += gridDim.x * 256u) {
@@ -1037,10 +1161,21 @@ __global__ __launch_bounds__(256, 4) void k_wf_final(DScene sc, DFrame fr, GBuff
     s.visible_position = F4(position, position_depth.w);
     s.visible_normal = normalize(xyz(unpack4x8snorm(g.normal[didx])));
     s.visible_instance = im_x;
-    f4 radiance = F4(plane(w, PL_RADIANCE)[slot]);
-    if (plane(w, PL_NORMAL_PENDING)[slot].w != 0.0f) {
-      const float4 add = (w.sh[slot] != HK_U32_MAX) ? plane(w, PL_ADD_OCCLUDED)[slot] : plane(w, PL_ADD_CLEAR)[slot];
-      radiance = radiance + F4(add.x, add.y, add.z, 1.0f);
+    f4 radiance = F4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (PATHS) {  // the path's additions in bounce order (shade_bounce<true>): what each bounce's shadow ray selected, then the sky term if it left the scene
+      const uint32_t mask = f2u(plane(w, PL_NORMAL_PENDING)[slot].w);
+      for (uint32_t m = mask & 0x7FFFFFFFu; m != 0u; m &= m - 1u) {
+        const uint32_t n = (uint32_t)__ffs((int)m) - 1u;
+        const float4 add = w.pb_add[(size_t)(2u * n + (w.pb_sh[(size_t)n * w.cap + slot] != HK_U32_MAX ? 1u : 0u)) * w.cap + slot];
+        radiance = radiance + F4(add.x, add.y, add.z, 1.0f);
+      }
+      if (mask & 0x80000000u) radiance = radiance + F4(plane(w, PL_RADIANCE)[slot]);
+    } else {
+      radiance = F4(plane(w, PL_RADIANCE)[slot]);
+      if (plane(w, PL_NORMAL_PENDING)[slot].w != 0.0f) {
+        const float4 add = (w.sh[slot] != HK_U32_MAX) ? plane(w, PL_ADD_OCCLUDED)[slot] : plane(w, PL_ADD_CLEAR)[slot];
+        radiance = radiance + F4(add.x, add.y, add.z, 1.0f);
+      }
     }
     s.radiance = radiance;
     s.sample_position = F4(plane(w, PL_FIRST_POSITION)[slot]);
@@ -1063,13 +1198,13 @@ void launch_build_wide(hipStream_t st, const float4* nodes, uint32_t count, floa
 }
 
 void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& fr, const GBuffer& g, const LightTargets& t, const WfBuffers& w, int y0,
-                               int y1, int compute_units, hipEvent_t start, hipEvent_t stop, const WideTrees* wide, hipEvent_t* trace_events) {
+                               int y1, int compute_units, hipEvent_t start, hipEvent_t stop, const WideTrees* wide, hipEvent_t* trace_events, bool persistent) {
   if (y1 <= y0) return;
   (void)hipMemsetAsync(w.ctr, 0, 192 * sizeof(uint32_t), st);
   if (w.timeline) (void)hipMemsetAsync(w.timeline, 0, 64 * 32 * sizeof(unsigned long long), st);
   hipExtLaunchKernelGGL(k_wf_setup, grid_for(fr.rw, y1 - y0), dim3(256), 0, st, start, nullptr, 0, sc, fr, g, t, w, y0, y1);
   const size_t lds = (size_t)sc.blob_f4 * 16 <= HK_LDS_SCENE_BYTES ? (size_t)sc.blob_f4 * 16 : 0;
-  const dim3 persistent((unsigned)(compute_units * 8));  // 8 workgroups of 4 waves per CU: what 64 VGPRs leave resident
+  const dim3 persistent_grid((unsigned)(compute_units * 8));  // 8 workgroups of 4 waves per CU: what 64 VGPRs leave resident
   // rays in flight = lanes of the trace launch.  Little's law: with R node steps per second served by the memory system, a step of
   // one ray takes (rays in flight) / R - every ray beyond what saturates R only makes all of them slower, and the launch ends with
   // its longest walk (tools/wf_timeline.py; -DHK_WF_TRACE_WG_PER_CU=n for the A/B)
@@ -1078,19 +1213,27 @@ void launch_indirect_wavefront(hipStream_t st, const DScene& sc, const DFrame& f
   const uint32_t bounces = fr.indirect_bounces;
   const bool use_wide = wide && wide->tlas && !lds;
   const uint32_t twin = w.timeline ? w.timeline_mode : 0u;
+  // every bounce in one launch (k_wf_trace_wide<.., PATHS>): the wide walk's scenes, no instrumented twin, the per-bounce planes in place
+  if (persistent && use_wide && twin <= 1u && w.local && bounces >= 1u && w.pb_bounces >= bounces && w.cap <= (1u << 26)) {
+    hipEvent_t e0 = trace_events ? trace_events[0] : nullptr, e1 = trace_events ? trace_events[1] : nullptr;
+    if (twin == 1u) hipExtLaunchKernelGGL((k_wf_trace_wide<true, false, true>), dim3((unsigned)(compute_units * HK_WF_PATHS_WAVES)), dim3(256), 0, st, e0, e1, 0, WideTraceArgs{sc, fr, w, *wide, 0u});
+    else hipExtLaunchKernelGGL((k_wf_trace_wide<false, false, true>), dim3((unsigned)(compute_units * HK_WF_PATHS_WAVES)), dim3(256), 0, st, e0, e1, 0, WideTraceArgs{sc, fr, w, *wide, 0u});
+    hipExtLaunchKernelGGL(k_wf_final<true>, persistent_grid, dim3(256), 0, st, nullptr, stop, 0, sc, fr, g, t, w);
+    return;
+  }
   for (uint32_t n = 0; n <= bounces; ++n) {
     hipEvent_t e0 = trace_events ? trace_events[2u * n] : nullptr, e1 = trace_events ? trace_events[2u * n + 1u] : nullptr;
-    if (use_wide && twin == 1u) hipExtLaunchKernelGGL((k_wf_trace_wide<true, false>), wide_tracers, dim3(256), 0, st, e0, e1, 0, sc, w, *wide, n);
-    else if (use_wide && twin == 2u) hipExtLaunchKernelGGL((k_wf_trace_wide<false, true>), wide_tracers, dim3(256), 0, st, e0, e1, 0, sc, w, *wide, n);
-    else if (use_wide) hipExtLaunchKernelGGL((k_wf_trace_wide<false, false>), wide_tracers, dim3(256), 0, st, e0, e1, 0, sc, w, *wide, n);
+    if (use_wide && twin == 1u) hipExtLaunchKernelGGL((k_wf_trace_wide<true, false, false>), wide_tracers, dim3(256), 0, st, e0, e1, 0, WideTraceArgs{sc, fr, w, *wide, n});
+    else if (use_wide && twin == 2u) hipExtLaunchKernelGGL((k_wf_trace_wide<false, true, false>), wide_tracers, dim3(256), 0, st, e0, e1, 0, WideTraceArgs{sc, fr, w, *wide, n});
+    else if (use_wide) hipExtLaunchKernelGGL((k_wf_trace_wide<false, false, false>), wide_tracers, dim3(256), 0, st, e0, e1, 0, WideTraceArgs{sc, fr, w, *wide, n});
     else if (twin == 1u && !lds) hipExtLaunchKernelGGL((k_wf_trace<false, true>), tracers, dim3(256), 0, st, e0, e1, 0, sc, w, n);
     else if (lds) hipExtLaunchKernelGGL((k_wf_trace<true, false>), tracers, dim3(256), lds, st, e0, e1, 0, sc, w, n);
     else hipExtLaunchKernelGGL((k_wf_trace<false, false>), tracers, dim3(256), 0, st, e0, e1, 0, sc, w, n);
     if (n == bounces) break;
-    if (lds) hipLaunchKernelGGL((k_wf_shade<true>), persistent, dim3(256), lds, st, sc, fr, w, n);
-    else hipLaunchKernelGGL((k_wf_shade<false>), persistent, dim3(256), 0, st, sc, fr, w, n);
+    if (lds) hipLaunchKernelGGL((k_wf_shade<true>), persistent_grid, dim3(256), lds, st, sc, fr, w, n);
+    else hipLaunchKernelGGL((k_wf_shade<false>), persistent_grid, dim3(256), 0, st, sc, fr, w, n);
   }
-  hipExtLaunchKernelGGL(k_wf_final, persistent, dim3(256), 0, st, nullptr, stop, 0, sc, fr, g, t, w);
+  hipExtLaunchKernelGGL(k_wf_final<false>, persistent_grid, dim3(256), 0, st, nullptr, stop, 0, sc, fr, g, t, w);
 }
 
 }  // namespace hk

@@ -35,12 +35,15 @@ SCRATCH_ALLOWED = {
     r"k_indirect<true, false, 0>": 32,         # fused schedule on a scene in global memory (the default there is the wavefront)
     r"k_indirect<true, false, 2>": 96,         # the headline kernel at FIVE waves per SIMD (HK_INDIRECT_FLAT_WAVES): 96 VGPRs, 35 spilled - measured faster than 114 / 4 waves
     r"k_indirect<true, true, (0|3)>": 96,      # ray-counting replays (two-level / one-level walk from global memory; + the walk counters of HkStats)
-    r"k_wf_final": 16,
+    r"k_wf_final<false>": 16,
+    r"k_wf_final<true>": 32,                   # (the persistent schedule's: the loop over the path's bounces)
     r"k_prepass<(true|false), 4>": 480,        # the wide walk's stack beyond its 28 LDS entries: a 96-entry private array (hk_wide.hpp WideStackPrivate), touched only by walks
                                                # that deep (384 B) + the few VGPRs the five-waves bound spills (HK_PREPASS_WIDE_WAVES; the counting instantiation a few more)
     r"k_wf_trace<false, true>": 64,            # the instrumented twin of tools/wf_timeline.py (never launched by the product)
-    r"k_wf_trace_wide<(true, false|false, true)>": 64,   # ... and the wide kernel's two twins (timeline / HK_CTX_COUNT_WALKS): their bookkeeping
+    r"k_wf_trace_wide<(true, false|false, true), false>": 64,   # ... and the wide kernel's two twins (timeline / HK_CTX_COUNT_WALKS): their bookkeeping
                                                          # spills a few VGPRs at the 96 the five-waves bound leaves; the product <false, false> must not
+    r"k_wf_trace_wide<false, false, true>": 128,   # every bounce in one launch (HK_DEBUG_OPT_PERSISTENT_PATHS, off by default): the shading inside the walk's kernel, four waves
+    r"k_wf_trace_wide<true, false, true>": 192,    # ... and its timeline twin
     # scenes beyond LDS: 4 waves per SIMD with 9 / 54 spilled VGPRs beat 3 without (profiles/r03_occupancy_ab.txt); COUNT = the replays
     # LDS-resident scenes under one transform (Cornell): both rays of the direct passes keep their occluder and walk the reference's
     # two-level tree (round 5) - capped at 4 waves per SIMD, 4 / 56 VGPRs spilled; measured equal to the uncapped one-level kernel
@@ -88,9 +91,12 @@ def test_lds_leaves_room_for_the_scene_copy(table):
     """The ray kernels copy scenes of up to 32 KB into dynamic LDS on top of their static LDS; with four workgroups per CU that
     has to fit the CU's 160 KB."""
     for name, r in table.items():
+        if re.search(r"k_wf_trace_wide<(true|false), (true|false), true>", name):   # every bounce in one launch (off by default): FOUR workgroups per CU
+            assert 4 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 128, name
+            continue
         if re.search(r"k_wf_trace_wide", name):   # global-memory scenes: no scene copy, a 28 KB stack + the sharing tables instead, FIVE workgroups per CU
             assert 5 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 96, name
-            assert r["vgpr_spill_count"] == 0 or not re.search(r"<false, false>", name), name   # (the product instantiation; its measurement twins may spill)
+            assert r["vgpr_spill_count"] == 0 or not re.search(r"<false, false, false>", name), name   # (the product instantiation; its measurement twins may spill)
             continue
         if re.search(r"k_prepass<(true|false), 4>", name):   # ... the fused prepass: the stack only, FIVE workgroups per CU (<= 96 VGPRs: HK_PREPASS_WIDE_WAVES)
             assert 5 * r["group_segment_fixed_size"] <= 160 * 1024 and r["vgpr_count"] <= 96, name

@@ -20,11 +20,13 @@ from bench import workload  # noqa: E402
 def main():
     no_wide = "--no-wide-walk" in sys.argv
     configs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [3, 4]
+    persistent = 0 if "--staged" in sys.argv else (1 if "--one-launch" in sys.argv else -1)   # HK_DEBUG_OPT_PERSISTENT_PATHS (-1: the library's rule)
     out = {}
     for cfg in configs:
         scene, camera, settings, lights, description = workload(hk, cfg, None, None, None)
         e = hk.Engine(device=0, flags=256 if no_wide else 0)
         e.set_debug_option(2, 1)   # HK_DEBUG_OPT_WF_TIMELINE
+        e.set_debug_option(8, persistent)
         e.upload_noise(); e.upload_scene(scene); e.resize(camera.width, camera.height, 1.0)
         view, pview, sc = camera.view_uniform(), camera.previous_view_uniform(), settings.to_c()
         for n in range(1, 9):
