@@ -150,79 +150,102 @@ __global__ __launch_bounds__(256, HK_DENOISE_WAVES) void k_denoise(DFrame fr, De
   const f3 normal = F3(gc.x, gc.y, gc.z);
   const float instance = gc.w;
 
-  f3 sum_irradiance[NCH];
-#ifndef HK_DN_F32_DIV
-  double inv_lum_denominator[NCH];  // the eight taps of a channel divide by the same number: see quotient_by_reciprocal
-#endif
-  float sum_w[NCH], lum[NCH], lum_denominator[NCH], ff_moment_1[NCH], ff_moment_2[NCH], ff_count[NCH];
-#pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
-    const float variance = d.internal_variance[ch][index];
-    f3 irradiance = xyz(unpack_f16x4(d.input[ch][index]));
-    sum_irradiance[ch] = irradiance * fr.kernel[4];
-    sum_w[ch] = fr.kernel[4];
-    if (nan_or_above_max(irradiance)) {  // any_is_nan(irradiance) || any(irradiance > F32_MAX), denoise.wgsl:201-205
-      irradiance = F3(0, 0, 0);
-      sum_irradiance[ch] = F3(0, 0, 0);
-      sum_w[ch] = 0.0f;
-    }
-    lum[ch] = luminance(irradiance);
-    lum_denominator[ch] = 4.0f * pow_quarter_(variance) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
-#ifndef HK_DN_F32_DIV
-    inv_lum_denominator[ch] = 1.0 / (double)lum_denominator[ch];
-#endif
-    ff_moment_1[ch] = 0.0f;
-    ff_moment_2[ch] = 0.0f;
-    ff_count[ch] = 0.0f;
-  }
-
+  // The eight taps' channel-independent part first - where the tap lies, whether it is inside the image, its geometric weight
+  // w_normal * w_depth * w_instance - then channel by channel (the reference runs the channels as separate dispatches: per channel
+  // the taps are visited in its order, so every sum is formed in its order).
+  constexpr int OX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+  constexpr int OY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+  bool tap_inside[8];
+  float w_geometry[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    constexpr int OX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
-    constexpr int OY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
     const int ox = OX[k], oy = OY[k];
-    const int sx = x + ox * STEP, sy = y + oy * STEP;
-    if (!(col_inside[ox + 1] && row_inside[oy + 1])) continue;  // sample_uv outside [0, 1]^2 (denoise.wgsl:232-234)
-    const int gx = col_texel[ox + 1], gy = row_texel[oy + 1];
-    const float4 gs = d.dn_g[gx + fr.dw * gy];
-    const float sample_depth = d.depth[gx + fr.dw * gy];
-    const f3 sample_normal = F3(gs.x, gs.y, gs.z);
-    // channel-independent part of the weight, evaluated once
-    const float w_normal = pow16_(fmax_(0.0f, dot(normal, sample_normal)));
-    const float w_depth = exp_nonpositive_((-fabsf(depth - sample_depth)) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
-    const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - gs.w));
-    const float w_geometry = w_normal * w_depth * w_instance;
-    const float kernel_w = fr.kernel[(oy + 1) * 3 + (ox + 1)];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-      const f3 irr = xyz(unpack_f16x4(d.input[ch][sx + fr.rw * sy]));
-      if (nan_or_above_max(irr)) continue;  // any_is_nan(irr) || any(irr > F32_MAX)
-      const float sample_luminance = luminance(irr);
-#ifdef HK_DN_F32_DIV
-      const float w_luminance = exp_nonpositive_((-fabsf(lum[ch] - sample_luminance)) / lum_denominator[ch]);
-#else
-      const float w_luminance = exp_nonpositive_(quotient_by_reciprocal(-fabsf(lum[ch] - sample_luminance), inv_lum_denominator[ch]));
-#endif
-      const float w = clamp_(w_geometry * w_luminance, 0.0f, 1.0f) * kernel_w;
-      sum_irradiance[ch] = sum_irradiance[ch] + irr * w;
-      sum_w[ch] += w;
-      if ((FFMASK >> ch) & 1) {
-        ff_moment_1[ch] += sample_luminance;
-        ff_moment_2[ch] += sample_luminance * sample_luminance;
-        ff_count[ch] += 1.0f;
-      }
+    tap_inside[k] = col_inside[ox + 1] && row_inside[oy + 1];  // sample_uv inside [0, 1]^2 (denoise.wgsl:232-234)
+    w_geometry[k] = 0.0f;
+    if (tap_inside[k]) {
+      const int gx = col_texel[ox + 1], gy = row_texel[oy + 1];
+      const float4 gs = d.dn_g[gx + fr.dw * gy];
+      const float sample_depth = d.depth[gx + fr.dw * gy];
+      const f3 sample_normal = F3(gs.x, gs.y, gs.z);
+      const float w_normal = pow16_(fmax_(0.0f, dot(normal, sample_normal)));
+      const float w_depth = exp_nonpositive_((-fabsf(depth - sample_depth)) / (fabsf(dot(depth_gradient, F2((float)ox, (float)oy))) + 0.01f));
+      const float w_instance = fmax_(0.0f, 1.0f - fabsf(instance - gs.w));
+      w_geometry[k] = w_normal * w_depth * w_instance;
     }
   }
   f4 albedo = F4(0, 0, 0, 0), tone_sum = F4(0, 0, 0, 0);
   if (LEVEL == 3) albedo = unpack_f16x4(d.albedo[didx]);  // nearest texel under jittered_deferred_uv(uv, 0.5): the centre's
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
-    const f3 qd = sum_irradiance[ch] / sum_w[ch];
-    f3 irradiance = (sum_w[ch] < 0.0001f) ? F3(0, 0, 0) : qd;
-    if ((FFMASK >> ch) & 1) {
-      const float ff_mean = ff_moment_1[ch] / ff_count[ch];
-      const float ff_var = ff_moment_2[ch] / ff_count[ch] - ff_mean * ff_mean;
-      if (lum[ch] > ff_mean + 3.0f * sqrtf(ff_var)) irradiance = ff_mean / lum[ch] * irradiance;
+    const float variance = d.internal_variance[ch][index];
+    const uint2 centre = d.input[ch][index];
+    f3 irradiance = xyz(unpack_f16x4(centre));
+    f3 sum_irradiance = irradiance * fr.kernel[4];
+    float sum_w = fr.kernel[4];
+    if (nan_or_above_max(irradiance)) {  // any_is_nan(irradiance) || any(irradiance > F32_MAX), denoise.wgsl:201-205
+      irradiance = F3(0, 0, 0);
+      sum_irradiance = F3(0, 0, 0);
+      sum_w = 0.0f;
+    }
+    const float lum = luminance(irradiance);
+    const float lum_denominator = 4.0f * pow_quarter_(variance) + 0.001f;  // luminance_weight, denoise.wgsl:56-61
+#ifndef HK_DN_F32_DIV
+    const double inv_lum_denominator = 1.0 / (double)lum_denominator;  // the eight taps of a channel divide by the same number: see quotient_by_reciprocal
+#endif
+    uint2 tap[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tap[k] = tap_inside[k] ? d.input[ch][index + OX[k] * STEP + fr.rw * (OY[k] * STEP)] : make_uint2(0u, 0u);
+    float ff_moment_1 = 0.0f, ff_moment_2 = 0.0f, ff_count = 0.0f;
+    // A channel that is BLACK under the whole stencil of every pixel of the wave (the sun's channel of a scene without a sun, of
+    // pixels in its shadow; the emitters' far from any) needs none of the per-tap luminance arithmetic: with the centre and the tap
+    // at +0 the luminance weight is exp(-|0 - 0| / denominator) = exp(-0) = 1 exactly (exp_nonpositive_: z = 0, r = +0, y = 1) for
+    // every denominator that is not NaN, the tap adds (+0 * w) to the sum of irradiance and w = clamp(w_geometry) * kernel to the sum
+    // of weights, and the firefly test (0 > ...) never fires.  Those additions are still made - a NaN weight must poison the sums as
+    // it does on the long way - the 45 instructions per tap in front of them are not.  The rgb halves of the packed texel are tested
+    // as bits: +0 only.  Wave-uniform by ballot.
+    bool black = (centre.x | (centre.y & 0xFFFFu)) == 0u && lum_denominator == lum_denominator;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) black = black && (tap[k].x | (tap[k].y & 0xFFFFu)) == 0u;
+#if defined(HK_DN_F32_DIV) || defined(HK_DN_NO_BLACK)
+    black = false;
+#endif
+    if (__ballot(!black) == 0ull) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (!tap_inside[k]) continue;
+        const float w = clamp_(w_geometry[k] * 1.0f, 0.0f, 1.0f) * fr.kernel[(OY[k] + 1) * 3 + (OX[k] + 1)];
+        const float zw = 0.0f * w;
+        sum_irradiance = sum_irradiance + F3(zw, zw, zw);
+        sum_w += w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (!tap_inside[k]) continue;
+        const f3 irr = xyz(unpack_f16x4(tap[k]));
+        if (nan_or_above_max(irr)) continue;  // any_is_nan(irr) || any(irr > F32_MAX)
+        const float sample_luminance = luminance(irr);
+#ifdef HK_DN_F32_DIV
+        const float w_luminance = exp_nonpositive_((-fabsf(lum - sample_luminance)) / lum_denominator);
+#else
+        const float w_luminance = exp_nonpositive_(quotient_by_reciprocal(-fabsf(lum - sample_luminance), inv_lum_denominator));
+#endif
+        const float w = clamp_(w_geometry[k] * w_luminance, 0.0f, 1.0f) * fr.kernel[(OY[k] + 1) * 3 + (OX[k] + 1)];
+        sum_irradiance = sum_irradiance + irr * w;
+        sum_w += w;
+        if ((FFMASK >> ch) & 1) {
+          ff_moment_1 += sample_luminance;
+          ff_moment_2 += sample_luminance * sample_luminance;
+          ff_count += 1.0f;
+        }
+      }
+    }
+    const f3 qd = sum_irradiance / sum_w;
+    irradiance = (sum_w < 0.0001f) ? F3(0, 0, 0) : qd;
+    if ((FFMASK >> ch) & 1) {  // (a black channel: ff_count = 0, the mean is NaN and the comparison false - as 0 > mean + 3 sigma is on the long way)
+      const float ff_mean = ff_moment_1 / ff_count;
+      const float ff_var = ff_moment_2 / ff_count - ff_mean * ff_mean;
+      if (lum > ff_mean + 3.0f * sqrtf(ff_var)) irradiance = ff_mean / lum * irradiance;
     }
     f4 color = F4(irradiance, 1.0f);
     if (LEVEL == 3) color = color * albedo;

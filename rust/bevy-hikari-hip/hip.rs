@@ -10,7 +10,7 @@ use std::ffi::CStr;
 use std::ptr;
 
 use bevy::{
-    pbr::{ExtractedDirectionalLight, GlobalLightMeta},
+    pbr::ExtractedDirectionalLight,
     prelude::*,
     render::{
         camera::ExtractedCamera,
@@ -370,16 +370,18 @@ impl Node for HipFrameNode {
         // GpuLights.directional_lights[0] and ambient_color (light.wgsl:611,832,847-855)
         let mut lights: hk::HkLights = unsafe { std::mem::zeroed() };
         if let Some(light) = self.lights.iter_manual(world).next() {
+            // bevy_pbr 0.9.1 prepare_lights: colour x illuminance x the default camera's exposure, 1 / (2^ev100 x 1.2) with
+            // ev100 = log2(4.0^2 x 250 x 100 / 100) - i.e. 1 / 4800 (bevy-hikari_amd/plugin.py lights_uniform does the same)
             let color = light.color.as_linear_rgba_f32();
-            lights.directional_color = [color[0] * light.illuminance, color[1] * light.illuminance, color[2] * light.illuminance, color[3]];
+            let intensity = light.illuminance / 4800.0;
+            lights.directional_color = [color[0] * intensity, color[1] * intensity, color[2] * intensity, color[3] * intensity];
             lights.direction_to_light = light.transform.back().to_array();
             lights.n_directional_lights = 1;
         }
         if let Some(ambient) = world.get_resource::<AmbientLight>() {
             let color = ambient.color.as_linear_rgba_f32();
-            lights.ambient_color = [color[0] * ambient.brightness, color[1] * ambient.brightness, color[2] * ambient.brightness, color[3]];
+            lights.ambient_color = [color[0] * ambient.brightness, color[1] * ambient.brightness, color[2] * ambient.brightness, color[3] * ambient.brightness];
         }
-        let _ = world.get_resource::<GlobalLightMeta>();
         let (view, previous_view) = views_to_hk(view, previous);
         let code = unsafe { hk::hk_frame_render(context.ctx, &frame_to_hk(frame), &view, &previous_view, &lights, &settings_to_hk(settings), hk::HK_FRAME_ANTIALIAS) };
         match check(code) {

@@ -12,9 +12,9 @@ from cases import diff_buffers, product_default_traversal, snapshot
 pytestmark = pytest.mark.gpu
 
 
-def pair():
+def pair(flags=0):
     with product_default_traversal():
-        one, staged = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0)
+        one, staged = hk.HikariPlugin(device=0, flags=flags), hk.HikariPlugin(device=0, flags=flags)
     one.engine.set_debug_option(F.DEBUG_OPT_PERSISTENT_PATHS, 1)
     staged.engine.set_debug_option(F.DEBUG_OPT_PERSISTENT_PATHS, 0)
     return one, staged
@@ -61,12 +61,13 @@ def test_long_walks_inside_few_large_meshes_every_byte():
 def test_config3_class_scene_with_emitters_and_a_moving_camera():
     """emitters (the shading samples their meshes: the light tree's walk and the emitter's mesh tree inside the trace kernel's waves),
     the camera moving from frame to frame (reprojection, scatter stores), settings changing between frames (the planes per bounce are
-    carved again for more bounces)"""
+    carved again for more bounces).  HK_CTX_DETERMINISTIC_SCATTER: under motion the default resolves the reference's scatter race only in the
+    buffers that are read - the sun / emitter channels' previous_spatial records race on, in both contexts, each its own way."""
     from bevy_hikari_amd.scenes import synthetic_camera, synthetic_large
 
     scene, sun = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
     lights = hk.lights_uniform(directional=sun)
-    one, staged = pair()
+    one, staged = pair(F.CTX_DETERMINISTIC_SCATTER)
     for p in (one, staged):
         p.set_scene(scene)
     for n, (bounces, dx) in enumerate([(2, 0.0), (2, 0.05), (4, 0.1), (1, 0.15), (3, 0.2)], start=1):
