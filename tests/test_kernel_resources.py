@@ -114,9 +114,11 @@ def test_lds_leaves_room_for_the_scene_copy(table):
 # static VALU instruction counts of the kernels that are bound by VALU issue, as built at the end of round 2, + 4 % head room: the
 # counts move with every edit of the shared device headers, and on these kernels a few per cent of instructions are a few per
 # cent of time (k_denoise<0,3,6>: 2 937 -> 2 155 instructions was 0.072 -> 0.060 ms).  Raise a budget knowingly, with a measurement.
+# (Round 6: k_denoise 2 111 -> 2 385 STATIC instructions - the kernel now holds a short way for a channel that is black under the wave's whole
+# stencil next to the long one; what a wave EXECUTES fell - an a-trous level of the Cornell frame 0.058 -> 0.050 ms, DESIGN 4 "Denoiser".)
 VALU_BUDGETS = {
-    r"k_denoise<0, 3, 6>": 2111,
-    r"k_denoise<3, 3, 6>": 2207,
+    r"k_denoise<0, 3, 6>": 2385,
+    r"k_denoise<3, 3, 6>": 2455,
     r"k_demodulation<3>": 514,
     r"k_spatial_reuse<false, false>": 3770,
     r"k_indirect<true, false, 1>": 7941,
