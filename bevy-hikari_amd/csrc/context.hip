@@ -41,6 +41,36 @@ bool certify_uv_division(int size) {
   return true;
 }
 
+// The main stream - primary rays, the indirect pass, spatial reuse: the frame's dependent chain - runs at the device's highest stream
+// priority while the context dispatches few pixels per frame, at the default priority otherwise (round 6; measured on three scenes x
+// four sizes and on bands, profiles/r06_stream_priority_ab.txt): with the chain ahead of the side stream's direct-light dispatches
+// and the post stream's a-trous levels whenever both have workgroups waiting, frames of up to 2560 x 1440 are 1-6 % shorter (Cornell
+// 1080p -1.3 %, config 3 -3.5 %, bands of any frame 0 ... -4 %); a whole 3840 x 2160 frame is 0.3-1.3 % LONGER that way, so it keeps
+// the default.  A stream's priority is fixed when it is created and a context must not hold more streams than the device has
+// hardware queues for (a second main stream beside the first cost config 4 2 %: two of the context's streams then share a queue), so
+// the stream is created again when the rule changes its mind - at hk_resize / hk_set_band, after what it held has drained.
+// hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) overrides the rule.
+#ifndef HK_MAIN_HIGH_PRIORITY_PIXELS
+#define HK_MAIN_HIGH_PRIORITY_PIXELS ((size_t)6 << 20)
+#endif
+int pick_main_stream(hk_ctx* c) {
+  if (!c->own_stream || c->in_frame_render || c->post_forked) return HK_OK;
+  const size_t px = (size_t)c->RW * (size_t)c->RH / (size_t)(c->band_count > 0 ? c->band_count : 1);
+  const bool high = c->main_priority < 0 ? (px != 0 && px <= HK_MAIN_HIGH_PRIORITY_PIXELS) : c->main_priority != 0;
+  if (high == c->own_stream_high) return HK_OK;
+  const bool in_use = c->stream == c->own_stream;   // (else the caller's own stream is: hk_set_stream)
+  { const int rc = sync_all(c); if (rc) return rc; }
+  HK_HIP(hipStreamSynchronize(c->own_stream));
+  int least = 0, greatest = 0;
+  HK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  hipStream_t fresh = nullptr;
+  HK_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, high ? greatest : least));
+  (void)hipStreamDestroy(c->own_stream);
+  c->own_stream = fresh;
+  c->own_stream_high = high;
+  if (in_use) c->stream = fresh;
+  return HK_OK;
+}
 int free_screen(hk_ctx* c) {
   for (int k = 0; k < 3; ++k) {
     if (c->det_winner[k]) (void)hipFree(c->det_winner[k]);
@@ -984,6 +1014,7 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
     case HK_DEBUG_OPT_SIDE_JOIN: c->side_join_each_frame = value != 0; break;
     case HK_DEBUG_OPT_POST_DEMODULATION: c->post_demodulation = value < 0 ? -1 : (value ? 1 : 0); break;
     case HK_DEBUG_OPT_PERSISTENT_PATHS: c->persistent_paths = value < 0 ? -1 : (value ? 1 : 0); break;
+    case HK_DEBUG_OPT_MAIN_PRIORITY: c->main_priority = value < 0 ? -1 : (value ? 1 : 0); return pick_main_stream(c);
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown option %u", option);
   }
   return HK_OK;
@@ -1081,7 +1112,7 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
   c->derived_dirty = false;
   c->uv_fast = !(c->flags & HK_CTX_PLAIN_DIVISION) && certify_uv_division(c->W) && certify_uv_division(c->H) && certify_uv_division(c->RW) && certify_uv_division(c->RH);
   HK_HIP(hipDeviceSynchronize());
-  return HK_OK;
+  return pick_main_stream(c);  // (the priority of the main stream follows the size)
 }
 
 int hk_set_view_options(hk_ctx* c, uint32_t taa, uint32_t upscale_kind, float upscale_sharpness) {
@@ -1174,7 +1205,7 @@ int hk_set_band(hk_ctx* c, uint32_t band_index, uint32_t band_count) {
   }
   c->band_index = band_index;
   c->band_count = band_count;
-  return HK_OK;
+  return pick_main_stream(c);
 }
 
 int hk_set_band_bounds(hk_ctx* c, const uint32_t* bounds, uint32_t n_bounds) {
@@ -1600,7 +1631,7 @@ int hk_set_stream(hk_ctx* c, void* s) {
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   c->stream = s ? (hipStream_t)s : c->own_stream;
-  return HK_OK;
+  return pick_main_stream(c);
 }
 int hk_stream(hk_ctx* c, void** s) {
   HK_REQUIRE(c && s, HK_E_INVALID, "bad argument");

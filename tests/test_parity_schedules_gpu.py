@@ -246,3 +246,28 @@ def test_the_side_stream_may_lag_a_frame_behind_and_no_bit_changes():
     a, b = snapshot(plugins[0]), snapshot(plugins[1])
     bad = {k: v for k, v in diff_buffers(a, b).items() if not k.startswith("reservoir")}
     assert bad == {}, bad
+
+
+def test_the_main_streams_priority_changes_no_bit_and_may_change_between_frames():
+    """Round 6: the context's main stream is created at the device's highest stream priority while the context dispatches few pixels per
+    frame (context.hip pick_main_stream) and created again at the other priority when that changes - here forced back and forth
+    between frames (HK_DEBUG_OPT_MAIN_PRIORITY), with the side stream's direct-light dispatches and the post stream's a-trous levels of
+    the frames before still in flight when the change is asked for.  Every buffer of every frame equals a context that never changed."""
+    case = make_case("cornell_b2")
+    a, b = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0)
+    for p in (a, b):
+        p.set_scene(case.scene)
+    b.engine.set_debug_option(F.DEBUG_OPT_MAIN_PRIORITY, 0)
+    for n in range(1, 13):
+        if n % 3 == 0:
+            a.engine.set_debug_option(F.DEBUG_OPT_MAIN_PRIORITY, (n // 3) % 2)
+        if n == 8:   # ... and the rule's own two triggers: a band of the frame, the whole frame again
+            a.engine.set_band(0, 2)
+            a.engine.set_band(0, 1)
+        for p in (a, b):
+            p.render(case.camera, case.settings, lights=case.lights, frame_number=n)
+        assert diff_buffers(snapshot(a), snapshot(b)) == {}, n
+    a.engine.set_debug_option(F.DEBUG_OPT_MAIN_PRIORITY, -1)
+    a.render(case.camera, case.settings, lights=case.lights, frame_number=13)
+    b.render(case.camera, case.settings, lights=case.lights, frame_number=13)
+    assert diff_buffers(snapshot(a), snapshot(b)) == {}
