@@ -42,21 +42,26 @@ bool certify_uv_division(int size) {
 }
 
 // The main stream - primary rays, the indirect pass, spatial reuse: the frame's dependent chain - runs at the device's highest stream
-// priority while the context dispatches few pixels per frame, at the default priority otherwise (round 6; measured on three scenes x
-// four sizes and on bands, profiles/r06_stream_priority_ab.txt): with the chain ahead of the side stream's direct-light dispatches
-// and the post stream's a-trous levels whenever both have workgroups waiting, frames of up to 2560 x 1440 are 1-6 % shorter (Cornell
-// 1080p -1.3 %, config 3 -3.5 %, bands of any frame 0 ... -4 %); a whole 3840 x 2160 frame is 0.3-1.3 % LONGER that way, so it keeps
-// the default.  A stream's priority is fixed when it is created and a context must not hold more streams than the device has
-// hardware queues for (a second main stream beside the first cost config 4 2 %: two of the context's streams then share a queue), so
-// the stream is created again when the rule changes its mind - at hk_resize / hk_set_band, after what it held has drained.
-// hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) overrides the rule.
+// priority when the context's frames are small, at the default priority otherwise (round 6; measured on three scenes x four sizes and
+// on bands, profiles/r06_stream_priority_ab.txt): with the chain ahead of the side stream's direct-light dispatches and the post
+// stream's a-trous levels whenever both have workgroups waiting, frames of up to 2560 x 1440 are 1-6 % shorter (Cornell 1080p -1.1 %,
+// config 3 -4.0 %, bands of any frame 0 ... -4 %); a whole 3840 x 2160 frame is 0.3-1.3 % LONGER that way, so it keeps the default.
+// A stream's priority is fixed when it is created, so the choice is made ONCE, at the context's first frame - from the pixels it
+// dispatches per frame: its size and its band are known by then; its stream, created with the context for the uploads that come
+// before, is created again at the other priority if need be - and kept: a second main
+// stream beside the first cost config 4 2.5 % (five streams per context: two share a hardware queue), and a stream created again
+// and again ends up on a queue it shares too (the same file: 0.92 -> 1.09 ms after three changes) - so later resizes and hk_set_band do
+// not revisit it.  (The device has few high-priority queues: the first contexts of a process get the benefit, a fifth one measured none.)  hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) forces a change (A/B and tests).
 #ifndef HK_MAIN_HIGH_PRIORITY_PIXELS
 #define HK_MAIN_HIGH_PRIORITY_PIXELS ((size_t)6 << 20)
 #endif
-int pick_main_stream(hk_ctx* c) {
-  if (!c->own_stream || c->in_frame_render || c->post_forked) return HK_OK;
+int pick_main_stream(hk_ctx* c, bool forced) {
+  if (!c->own_stream || c->post_forked) return HK_OK;
+  if (!forced && c->main_priority_decided) return HK_OK;
   const size_t px = (size_t)c->RW * (size_t)c->RH / (size_t)(c->band_count > 0 ? c->band_count : 1);
-  const bool high = c->main_priority < 0 ? (px != 0 && px <= HK_MAIN_HIGH_PRIORITY_PIXELS) : c->main_priority != 0;
+  if (px == 0) return HK_OK;
+  c->main_priority_decided = true;
+  const bool high = c->main_priority < 0 ? px <= HK_MAIN_HIGH_PRIORITY_PIXELS : c->main_priority != 0;
   if (high == c->own_stream_high) return HK_OK;
   const bool in_use = c->stream == c->own_stream;   // (else the caller's own stream is: hk_set_stream)
   { const int rc = sync_all(c); if (rc) return rc; }
@@ -1014,7 +1019,7 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
     case HK_DEBUG_OPT_SIDE_JOIN: c->side_join_each_frame = value != 0; break;
     case HK_DEBUG_OPT_POST_DEMODULATION: c->post_demodulation = value < 0 ? -1 : (value ? 1 : 0); break;
     case HK_DEBUG_OPT_PERSISTENT_PATHS: c->persistent_paths = value < 0 ? -1 : (value ? 1 : 0); break;
-    case HK_DEBUG_OPT_MAIN_PRIORITY: c->main_priority = value < 0 ? -1 : (value ? 1 : 0); return pick_main_stream(c);
+    case HK_DEBUG_OPT_MAIN_PRIORITY: c->main_priority = value < 0 ? -1 : (value ? 1 : 0); return pick_main_stream(c, true);
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown option %u", option);
   }
   return HK_OK;
@@ -1112,7 +1117,7 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
   c->derived_dirty = false;
   c->uv_fast = !(c->flags & HK_CTX_PLAIN_DIVISION) && certify_uv_division(c->W) && certify_uv_division(c->H) && certify_uv_division(c->RW) && certify_uv_division(c->RH);
   HK_HIP(hipDeviceSynchronize());
-  return pick_main_stream(c);  // (the priority of the main stream follows the size)
+  return HK_OK;
 }
 
 int hk_set_view_options(hk_ctx* c, uint32_t taa, uint32_t upscale_kind, float upscale_sharpness) {
@@ -1126,6 +1131,7 @@ int hk_set_view_options(hk_ctx* c, uint32_t taa, uint32_t upscale_kind, float up
 int hk_frame_begin(hk_ctx* c, const HkFrame* f, const HkView* v, const HkPreviousView* pv, const HkLights* l) {
   HK_REQUIRE(c && f && v && pv && l, HK_E_INVALID, "NULL argument");
   HK_REQUIRE(f->direct_validate_interval > 0 && f->emissive_validate_interval > 0, HK_E_INVALID, "validate intervals must be > 0");
+  if (!c->main_priority_decided) { const int rc = pick_main_stream(c, false); if (rc) return rc; }  // (the context's first frame: its size and its band are known)
   c->frame = *f;
   c->view = *v;
   c->pview = *pv;
@@ -1205,7 +1211,7 @@ int hk_set_band(hk_ctx* c, uint32_t band_index, uint32_t band_count) {
   }
   c->band_index = band_index;
   c->band_count = band_count;
-  return pick_main_stream(c);
+  return HK_OK;
 }
 
 int hk_set_band_bounds(hk_ctx* c, const uint32_t* bounds, uint32_t n_bounds) {
@@ -1631,7 +1637,7 @@ int hk_set_stream(hk_ctx* c, void* s) {
   HK_HIP(hipStreamSynchronize(c->stream));
   drain_timers(c);
   c->stream = s ? (hipStream_t)s : c->own_stream;
-  return pick_main_stream(c);
+  return HK_OK;
 }
 int hk_stream(hk_ctx* c, void** s) {
   HK_REQUIRE(c && s, HK_E_INVALID, "bad argument");

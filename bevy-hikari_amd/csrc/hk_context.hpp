@@ -108,6 +108,7 @@ struct hk_ctx {
   hipStream_t stream = nullptr;      // stream all work is enqueued on (own_stream unless hk_set_stream)
   hipStream_t own_stream = nullptr;
   bool own_stream_high = false;      // ... created at the device's highest stream priority (context.hip pick_main_stream)
+  bool main_priority_decided = false; // ... by the rule, at the first hk_resize
   int main_priority = -1;            // HK_DEBUG_OPT_MAIN_PRIORITY: -1 the rule, 0 default priority, 1 highest
   hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
   hipEvent_t fork_event = nullptr, join_event = nullptr;

@@ -836,10 +836,10 @@ int hk_write_buffer(hk_ctx* ctx, uint32_t buffer, const void* src, size_t bytes)
  * ALLOCATION, which does not depend on the upscale kind in effect (hk_buffer_info gives the logical size); the pointer is
  * valid until the next hk_resize (and, for the double-buffered ids, names another plane after the next hk_frame_begin). */
 int hk_device_ptr(hk_ctx* ctx, uint32_t buffer, void** ptr, size_t* bytes);
-/* the HIP stream the context enqueues its frames on.  Without hk_set_stream it is the context's own, created at the default or at the
- * device's highest priority from the pixels the context dispatches per frame (round 6: the frame's dependent chain ahead of the
- * direct-light and a-trous dispatches of the other streams while frames are small) and created AGAIN when that changes - so ask again
- * after hk_resize / hk_set_band: a handle kept from before may name a stream that no longer exists. */
+/* the HIP stream the context enqueues its frames on.  Without hk_set_stream it is the context's own; the context's FIRST frame may
+ * create it again at the device's highest priority (round 6: the frame's dependent chain ahead of the direct-light and a-trous
+ * dispatches of the other streams when frames are small) - so ask after that frame: a handle taken before it may name a stream that
+ * no longer exists. */
 int hk_stream(hk_ctx* ctx, void** hip_stream);
 /* Enqueue all subsequent work on a HIP stream owned by the host (e.g. the stream its RCCL calls
  * are ordered against) instead of the context's own stream; NULL restores the context's stream. */

@@ -77,7 +77,7 @@ int hk_debug_comm_lanes(hk_ctx* ctx, uint32_t* lanes);
 #define HK_DEBUG_OPT_TRACE_UPDATE 5u    /* 1: timings of scene updates on stderr */
 #define HK_DEBUG_OPT_POST_DEMODULATION 6u /* demodulation on the post stream with the a-trous levels: -1 by the library's rule (default), 0 on the main stream, 1 on the post stream */
 #define HK_DEBUG_OPT_PERSISTENT_PATHS 8u /* the queue-based indirect pass runs every bounce in ONE launch, a path staying with the wave that claimed it (kernels_wavefront.hip k_wf_trace_wide<.., PATHS>): -1 by the library's rule (default), 0 one trace + one shade launch per bounce, 1 one launch */
-#define HK_DEBUG_OPT_MAIN_PRIORITY 9u /* the priority of the context's own main stream: -1 by the library's rule (default: the highest while the context dispatches at most 6 Mi pixels per frame), 0 the default priority, 1 the highest */
+#define HK_DEBUG_OPT_MAIN_PRIORITY 9u /* the priority of the context's own main stream, created again at once: -1 by the library's rule (the highest if the context dispatches at most 6 Mi pixels per frame; what the context's first frame decides by itself), 0 the default priority, 1 the highest.  A/B and tests: a stream created again several times ends up sharing a hardware queue */
 #define HK_DEBUG_OPT_SIDE_JOIN 7u /* 1: the main stream waits for the direct-light dispatches (side stream) at the end of every frame, as it did through round 5; 0 (default): only the post-processing does */
 int hk_debug_set_option(hk_ctx* ctx, uint32_t option, int64_t value);
 /* hk_multi_*: 1 = the calling thread enqueues every band's launches one after another instead of one thread per band (process-wide) */
