@@ -945,7 +945,7 @@ using namespace hkd;
 
 // LDS staging is used when the whole scene blob fits comfortably (4 workgroups per CU stay resident)
 #ifdef HK_PROFILE_SECTIONS
-extern "C" int hk_debug_read_sections(unsigned long long* out16 /* 24 values */, int reset) {
+extern "C" __attribute__((visibility("default"))) int hk_debug_read_sections(unsigned long long* out16 /* 24 values */, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hkd::g_sections), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(hkd::g_walk_events), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;

@@ -14,12 +14,10 @@ VARIANT = os.path.join(ROOT, "build_ab", "libhikari_hip_walk_twice.so" if TWICE 
 NAMES = ["prologue+idle", "sample+ray setup", "closest-hit traversal", "hit_info+surface", "light candidate", "shadow ray setup",
          "shadow traversal", "radiance+shading+throughput", "ReSTIR temporal", "stores"]
 
-if "--build" in sys.argv:
+if "--build" in sys.argv:   # (through tools/build_lib.py, like every variant: the same sources, flags and build stamp as the shipped library)
     os.makedirs(os.path.dirname(VARIANT), exist_ok=True)
-    csrc = os.path.join(ROOT, "bevy-hikari_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("kernels.hip", "kernels_denoise.hip", "kernels_aa.hip", "kernels_wavefront.hip", "kernels_scene.hip", "context.hip", "scene_layout.hip", "scene_refit.hip", "probes.hip", "host_logic.cpp", "scene_builder.cpp", "comm.cpp")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DHK_ABLATE_WALK_TWICE" if TWICE else "-DHK_PROFILE_SECTIONS",
-                    "-o", VARIANT] + srcs, check=True, cwd=csrc)
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_lib.py"), "-o", VARIANT, "--objdir", os.path.join(ROOT, "build", "obj_" + os.path.basename(VARIANT)[:-3]),
+                    "-DHK_ABLATE_WALK_TWICE" if TWICE else "-DHK_PROFILE_SECTIONS"], check=True)
     print("built", VARIANT)
     sys.exit(0)
 
