@@ -301,7 +301,11 @@ def main():
         if warmup < 256 and config == args.config:
             # A caller that asks for few warm-up FRAMES still gets settled clocks: ~0.4 s of the VALU issue probe (register-only FMA
             # chains, hk_measure_valu) before the first frame.  No frame is added, removed or cached; with 3 warm-up frames and none of
-            # this the headline reads 3 % low (1.017 instead of 0.98 ms per frame).
+            # this the headline reads 3 % low (1.017 instead of 0.98 ms per frame).  (What the probe cannot settle is the HISTORY: the
+            # frames themselves get cheaper while the reservoirs age - frames 6-25 of the Cornell run cost 0.96 ms, 25-85 0.92, a spike when
+            # every reservoir reaches max_reservoir_lifetime = 100 together, 0.90 from frame 200 on; the spatial pass alone 0.299 -> 0.265 ms:
+            # old reservoirs skip their history merge - profiles/r06_history_age.txt.  --warmup 5 --steps 20 therefore reads 0.925 ms where
+            # --warmup 512 reads 0.900 on the same box: both are the workload, at different ages.)
             t_spin = time.perf_counter()
             while time.perf_counter() - t_spin < 0.4:
                 eng.measure_valu(4096)
