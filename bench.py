@@ -162,7 +162,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="frames per timed block (default 48; 12 for --config 3/4/5)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up frames (default 512 for the headline config: half a second, enough for the clocks to settle "
                     "- with 16 the five timed blocks of a run still drifted 2.5 %% downwards; 16 for --config 3/4/5)")
-    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps frames each; the median is reported")
+    ap.add_argument("--blocks", type=int, default=None, help="timed blocks of --steps frames each; the median is reported (default: 5, and as many more as it "
+                    "takes to time 240 frames in all - the default run's 5 x 48 - when --steps is smaller: the figure is then the median over the same "
+                    "number of frames whatever --steps is)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -198,6 +200,11 @@ def main():
         args.steps = 48 if args.config == 2 else 12
     if args.warmup is None:
         args.warmup = 512 if args.config == 2 else 16
+    if args.blocks is None:
+        # the default run of the headline config times 5 blocks of 48 frames; a caller that asks for shorter blocks gets as many as time the
+        # same 240 frames (each block still EXACTLY --steps frames between a barrier + device synchronisation on both sides): the frames of a
+        # young history are dearer (profiles/r06_history_age.txt), and five short blocks would be a median over the first hundred of them
+        args.blocks = max(5, -(-240 // max(1, args.steps))) if args.config == 2 else 5
 
     import numpy as np
     import torch
@@ -652,6 +659,10 @@ def main():
             "traversal": {"mode": m["traversal"][0], "orderings": m["traversal"][1], "wide_walk": m["traversal"][2]},
         },
         "blocks_ms_per_step": ms_blocks,
+        "blocks": {"count": len(ms_blocks), "frames_each": args.steps, "first_timed_frame": args.warmup + 1, "last_timed_frame": args.warmup + len(ms_blocks) * args.steps,
+                   "note": "every block is EXACTLY --steps frames between a barrier + device synchronisation on both sides; ms_per_step / value = the MEDIAN block.  Without "
+                           "--blocks the run times 240 frames in all whatever --steps is (5 x 48 by default): the workload gets cheaper while its reservoirs age "
+                           "(frames 6-25 of a fresh context 0.96 ms, 0.90 from frame 200 on; profiles/r06_history_age.txt), so the blocks are listed in frame order"},
         "instrumented_block": {"index": 0, "ms_per_step": ms_blocks[0], "note": "the HIP events of `roofline` (on the two long dispatches; configs 3 / 4: + every trace launch and the "
                                "direct-light dispatches) ride on this timed block only - they cost the frames that carry them 2-4 %; `value` is the median block"},
         "min_ms_per_step": min(ms_blocks),
