@@ -210,6 +210,7 @@ _DEBUG = {
     "debug_comm_lanes": [_vp, P(u32)],
     "debug_multi_serial": [C.c_int],
     "debug_spatial_windowed_launches": [_vp, P(C.c_uint64)],
+    "debug_main_stream_priority": [_vp, P(u32)],
     "measure_hbm": [_vp, C.c_size_t, u32, P(C.c_double), P(C.c_double)],
     "measure_valu": [_vp, u32, P(C.c_double)],
     "measure_gather": [_vp, C.c_size_t, u32, u32, u32, u32, P(C.c_double), P(C.c_double)],

@@ -1025,6 +1025,12 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
   return HK_OK;
 }
 
+int hk_debug_main_stream_priority(hk_ctx* c, uint32_t* out) {
+  HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
+  *out = (c->own_stream_high ? 1u : 0u) | (c->main_priority_decided ? 2u : 0u);
+  return HK_OK;
+}
+
 int hk_debug_spatial_windowed_launches(hk_ctx* c, uint64_t* out) {
   HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
   *out = c->spatial_windowed_launches;

@@ -716,6 +716,13 @@ class Engine:
         """hikari_hip_debug.h hk_debug_set_option (F.DEBUG_OPT_*): the switches of tests and A/B tools - the library reads no environment variable."""
         self.api.call("debug_set_option", self.ctx, option, int(value))
 
+    def main_stream_priority(self):
+        """(high, decided): whether the context's own main stream was created at the device's highest priority, and whether the rule has
+        decided yet - it does at the context's first frame (hikari_hip_debug.h hk_debug_main_stream_priority)."""
+        v = F.u32()
+        self.api.call("debug_main_stream_priority", self.ctx, C.byref(v))
+        return bool(v.value & 1), bool(v.value & 2)
+
     def spatial_windowed_launches(self):
         """spatial_reuse launches that took the windowed form of the kernel (hikari_hip_debug.h; F.DEBUG_OPT_SPATIAL_WINDOW)."""
         n = C.c_uint64()

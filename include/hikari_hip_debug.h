@@ -62,6 +62,10 @@ int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer
  * hk_debug_set_option(HK_DEBUG_OPT_SPATIAL_WINDOW) says. */
 int hk_debug_spatial_windowed_launches(hk_ctx* ctx, uint64_t* out);
 
+/* Test hook (round 6): the priority the context's own main stream was created at - 0 the default, 1 the device's highest, and whether the
+ * rule has decided yet (bit 1: it decides at the context's first frame; hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) decides at once). */
+int hk_debug_main_stream_priority(hk_ctx* ctx, uint32_t* out);
+
 /* Test hook (round 6): 2 when the context's communicator has its second lane - a communicator (ncclCommSplit of the first) and a stream of
  * its own for what a band's POST-PROCESSING and the overlay wait for (exchange B, the gather, exchanges D / E), so that frame n's
  * exchange B and gather do not sit in front of frame n + 1's exchange A on one in-order queue - 1 when the library could not split. */

@@ -271,3 +271,34 @@ def test_the_main_streams_priority_changes_no_bit_and_may_change_between_frames(
     a.render(case.camera, case.settings, lights=case.lights, frame_number=13)
     b.render(case.camera, case.settings, lights=case.lights, frame_number=13)
     assert diff_buffers(snapshot(a), snapshot(b)) == {}
+
+
+def test_the_main_streams_priority_follows_the_pixels_of_the_contexts_first_frame():
+    """context.hip pick_main_stream: decided once, at the first frame - the highest priority for a context that dispatches at most 6 Mi
+    pixels per frame (a small frame, or a band of a large one), the default for a whole 3840 x 2160 frame - and not revisited by later
+    resizes or bands."""
+    case = make_case("cornell_b2")
+    s = case.settings
+
+    def engine(width, height, band=None):
+        e = hk.Engine(device=0)
+        e.upload_noise()
+        e.upload_scene(case.scene)
+        e.resize(width, height, 1.0)
+        if band:
+            e.set_band(*band)
+        assert e.main_stream_priority() == (False, False)       # created with the context at the default priority; nothing decided yet
+        cam = hk.cornell_camera(width, height)
+        e.frame_render(hk.frame_uniform(s, 1), cam.view_uniform(), cam.previous_view_uniform(), case.lights, s.to_c())
+        e.wait()
+        return e
+
+    assert engine(640, 360).main_stream_priority() == (True, True)
+    big = engine(3840, 2160)
+    assert big.main_stream_priority() == (False, True)
+    big.resize(640, 360, 1.0)                                   # (decided: a later size does not revisit it)
+    cam = hk.cornell_camera(640, 360)
+    big.frame_render(hk.frame_uniform(s, 1), cam.view_uniform(), cam.previous_view_uniform(), case.lights, s.to_c())
+    big.wait()
+    assert big.main_stream_priority() == (False, True)
+    assert engine(3840, 2160, band=(1, 4)).main_stream_priority() == (True, True)   # a quarter of it: 2 Mi pixels per frame
