@@ -66,10 +66,14 @@ int pick_main_stream(hk_ctx* c, bool forced) {
   const bool in_use = c->stream == c->own_stream;   // (else the caller's own stream is: hk_set_stream)
   { const int rc = sync_all(c); if (rc) return rc; }
   HK_HIP(hipStreamSynchronize(c->own_stream));
+  // (a device or runtime without stream priorities keeps the stream it has: the priority is an optimisation, not a requirement)
   int least = 0, greatest = 0;
-  HK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
   hipStream_t fresh = nullptr;
-  HK_HIP(hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, high ? greatest : least));
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
+      hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, high ? greatest : least) != hipSuccess || !fresh) {
+    (void)hipGetLastError();
+    return HK_OK;
+  }
   (void)hipStreamDestroy(c->own_stream);
   c->own_stream = fresh;
   c->own_stream_high = high;
