@@ -89,8 +89,13 @@ __global__ __launch_bounds__(256) void k_resolve_scatter_lite(LightTargets t, DF
 #ifndef HK_PREPASS_WIDE_WAVES
 #define HK_PREPASS_WIDE_WAVES 5
 #endif
+#ifndef HK_PREPASS_FLAT_WAVES
+#define HK_PREPASS_FLAT_WAVES 5   // (the one-level walk from the LDS copy, round 6: the compiler's own choice is 103 VGPRs = four waves per SIMD; capped at
+                                  // 96 - two spilled - the Cornell primary rays take 0.069 -> 0.0655 ms and the frame -0.5 % over three interleaved rounds; six
+                                  // waves (79 VGPRs, 20 spilled): 0.072 - profiles/r06_prepass_flat_waves_ab.txt)
+#endif
 template <bool COUNT, int LDS>
-__global__ __launch_bounds__(256, (LDS == 4 ? HK_PREPASS_WIDE_WAVES : 1)) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
+__global__ __launch_bounds__(256, (LDS == 4 ? HK_PREPASS_WIDE_WAVES : (LDS == 2 ? HK_PREPASS_FLAT_WAVES : 1))) void k_prepass(DScene gsc, DFrame fr, PrepassParams pp, GBuffer g, int row_begin, int row_end,
                                                   unsigned long long* counters) {
   const DScene sc = stage_scene<LDS>(gsc);
   const Pixel px = pixel_of_thread<false>(fr.dw, row_begin, row_end);
