@@ -46,7 +46,7 @@ CTX_WAVEFRONT, CTX_FUSED_INDIRECT = 64, 128  # schedule of indirect_lit_ambient 
 CTX_NO_WIDE_WALK = 256  # closest-hit walks of scenes beyond LDS keep the threaded skip-link walk (A/B switch)
 CTX_COUNT_WALKS = 512   # the trace stages run the counting twin of their kernel (same schedule, same walks): hk_debug_read_wf_timeline
 CTX_RACING_SCATTER = 1024   # hikari_hip.h HK_CTX_RACING_SCATTER: the reference's own race on previous_spatial (round 6: the default resolves it)
-(DEBUG_OPT_SPATIAL_WINDOW, DEBUG_OPT_FRAME_PIPELINE, DEBUG_OPT_WF_TIMELINE, DEBUG_OPT_FLAT_WALK, DEBUG_OPT_FLAT_ORDERINGS, DEBUG_OPT_TRACE_UPDATE, DEBUG_OPT_POST_DEMODULATION, DEBUG_OPT_SIDE_JOIN, DEBUG_OPT_PERSISTENT_PATHS, DEBUG_OPT_MAIN_PRIORITY) = range(10)  # hikari_hip_debug.h hk_debug_set_option
+(DEBUG_OPT_SPATIAL_WINDOW, DEBUG_OPT_FRAME_PIPELINE, DEBUG_OPT_WF_TIMELINE, DEBUG_OPT_FLAT_WALK, DEBUG_OPT_FLAT_ORDERINGS, DEBUG_OPT_TRACE_UPDATE, DEBUG_OPT_POST_DEMODULATION, DEBUG_OPT_SIDE_JOIN, DEBUG_OPT_PERSISTENT_PATHS, DEBUG_OPT_MAIN_PRIORITY, DEBUG_OPT_PREPASS_PIPELINE) = range(11)  # hikari_hip_debug.h hk_debug_set_option
 TIMING_TRACE_STAGES = 18  # hk_set_timing_mask bit / HkStats slot: every trace launch of the queue-based indirect pass
 TRAVERSAL_WIDE = 0x100
 FRAME_EXTERNAL_GBUFFER, FRAME_ANTIALIAS, FRAME_BALANCE_BANDS, FRAME_GATHER, FRAME_TIME_BAND = 1, 2, 4, 8, 16

@@ -52,6 +52,9 @@ bool certify_uv_division(int size) {
 // stream beside the first cost config 4 2.5 % (five streams per context: two share a hardware queue), and a stream created again
 // and again ends up on a queue it shares too (the same file: 0.92 -> 1.09 ms after three changes) - so later resizes and hk_set_band do
 // not revisit it.  (The device has few high-priority queues: the first contexts of a process get the benefit, a fifth one measured none.)  hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) forces a change (A/B and tests).
+#ifndef HK_PRE_STREAM_HIGH
+#define HK_PRE_STREAM_HIGH 0   // the primary rays' own stream: the default priority (at the chain's: config 3 -1.8 % instead of -2.9 %, profiles/r06_prepass_pipeline_ab.txt)
+#endif
 #ifndef HK_MAIN_HIGH_PRIORITY_PIXELS
 #define HK_MAIN_HIGH_PRIORITY_PIXELS ((size_t)6 << 20)
 #endif
@@ -78,8 +81,23 @@ int pick_main_stream(hk_ctx* c, bool forced) {
   c->own_stream = fresh;
   c->own_stream_high = high;
   if (in_use) c->stream = fresh;
+  // (with the chain in the high-priority pool a fourth default-priority stream has a hardware queue of its own: the primary rays')
+  if (high && c->side_stream && c->post_stream && !c->pre_stream) {
+    if (hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, HK_PRE_STREAM_HIGH ? greatest : least) != hipSuccess || hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pre_scene_mark, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (c->pre_stream) (void)hipStreamDestroy(c->pre_stream);
+      c->pre_stream = nullptr;
+    }
+  }
   return HK_OK;
 }
+#ifndef HK_PREPASS_PIPELINE_RULE
+// scenes beyond the LDS copy (long primary rays, trace stages with ends to fill) in frames of up to 3 Mi pixels: measured on configs 3 / 4
+// at 720p / 1080p -7.5 / -3.9 / -9.0 % per frame, at 2560 x 1440 0 / +1.4 %; the Cornell frame (its primary rays: 0.066 of 0.88 ms, walked
+// from LDS) +5 % with the stream at the default priority and 0 at the chain's - profiles/r06_prepass_pipeline_ab.txt
+#define HK_PREPASS_PIPELINE_RULE ((size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES && (size_t)c->RW * (size_t)c->RH <= ((size_t)3 << 20))
+#endif
 int free_screen(hk_ctx* c) {
   for (int k = 0; k < 3; ++k) {
     if (c->det_winner[k]) (void)hipFree(c->det_winner[k]);
@@ -989,6 +1007,9 @@ void hk_destroy(hk_ctx* c) {
   if (c->fork_event) (void)hipEventDestroy(c->fork_event);
   if (c->join_event) (void)hipEventDestroy(c->join_event);
   if (c->side_done) (void)hipEventDestroy(c->side_done);
+  if (c->pre_stream) { (void)hipStreamSynchronize(c->pre_stream); (void)hipStreamDestroy(c->pre_stream); }
+  if (c->pre_done) (void)hipEventDestroy(c->pre_done);
+  if (c->pre_scene_mark) (void)hipEventDestroy(c->pre_scene_mark);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1023,6 +1044,7 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
     case HK_DEBUG_OPT_SIDE_JOIN: c->side_join_each_frame = value != 0; break;
     case HK_DEBUG_OPT_POST_DEMODULATION: c->post_demodulation = value < 0 ? -1 : (value ? 1 : 0); break;
     case HK_DEBUG_OPT_PERSISTENT_PATHS: c->persistent_paths = value < 0 ? -1 : (value ? 1 : 0); break;
+    case HK_DEBUG_OPT_PREPASS_PIPELINE: c->prepass_pipeline = value < 0 ? -1 : (value ? 1 : 0); break;
     case HK_DEBUG_OPT_MAIN_PRIORITY: c->main_priority = value < 0 ? -1 : (value ? 1 : 0); return pick_main_stream(c, true);
     default: HK_REQUIRE(false, HK_E_INVALID, "unknown option %u", option);
   }
@@ -1031,7 +1053,7 @@ int hk_debug_set_option(hk_ctx* c, uint32_t option, int64_t value) {
 
 int hk_debug_main_stream_priority(hk_ctx* c, uint32_t* out) {
   HK_REQUIRE(c && out, HK_E_INVALID, "bad argument");
-  *out = (c->own_stream_high ? 1u : 0u) | (c->main_priority_decided ? 2u : 0u);
+  *out = (c->own_stream_high ? 1u : 0u) | (c->main_priority_decided ? 2u : 0u) | (c->pre_stream ? 4u : 0u) | ((uint32_t)std::min<uint64_t>(c->prepasses_pipelined, 0xFFFFFu) << 8);
   return HK_OK;
 }
 
@@ -1072,6 +1094,7 @@ static int resize_resources(hk_ctx* c, uint32_t width, uint32_t height, float up
     c->UW = (int)ceilf((float)width * scale2);
     c->UH = (int)ceilf((float)height * scale2);
     c->mapped_parity = 0;
+    c->pre_chain_ok = false;
   }
   for (uint32_t b = 0; b < HK_BUF_PARKED_TO0; ++b) {  // (the parked-store planes beyond: on first use, ensure_parked)
     size_t n = buffer_is_full_size(b) ? (size_t)c->W * c->H : (buffer_is_upscaled(b) ? (size_t)c->UW * c->UH : (size_t)c->RW * c->RH);
@@ -1377,9 +1400,29 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     // it reads - the planes both touch are double-buffered by frame parity.  What this frame does write again is what the last frame
     // OF ITS OWN PARITY read (normally two frames back and long done; the last frame itself when a host renders two frames of one
     // parity in a row); a host-rasterised G-buffer was written into whichever planes were mapped: everything first
-    if ((flags & HK_FRAME_EXTERNAL_GBUFFER) ? (rc = join_post(c)) : (rc = join_post_parity(c, c->mapped_parity))) return rc;
     int f0, f1;
     full_rows_for(c, clampr(b0 - den - sp), clampr(b1 + den + sp), &f0, &f1);
+    // Primary-ray pipelining (hk_context.hpp): what these rays write - the G-buffer planes of this frame's parity - was last read by frame
+    // n - 2 (every plane has its twin; only the anti-aliasing tail reads the other parity's), and that frame's post-processing event
+    // (post_done[parity]: the post stream waited for the main AND the side stream before it) closes all of it.  What they read - scene
+    // memory - must not have been written since the last frame (those writes are behind the previous frame's spatial pass on the main
+    // stream), and the wide trees must be current (k_build_wide would run on the main stream).
+    const uint32_t parity = c->mapped_parity & 1u;
+    const bool wide_clean = !wide_allowed(c) || (!c->wide_tlas_dirty && !c->wide_blas_dirty && !c->wide_mesh_check);
+    const bool pre_wanted = c->prepass_pipeline < 0 ? HK_PREPASS_PIPELINE_RULE : c->prepass_pipeline != 0;
+    const bool pre_pipelined = pre_wanted && c->pre_stream && c->stream == c->own_stream && c->normal_twin && c->pre_chain_ok && c->pre_last_parity != parity &&
+                               !(flags & (HK_FRAME_EXTERNAL_GBUFFER | HK_FRAME_ANTIALIAS)) && c->band_count == 1 && !c->timing_mask && !(c->flags & HK_CTX_COUNT_RAYS) &&
+                               wide_clean && !c->derived_dirty && c->scene_epoch == c->pre_seen_epoch && c->post_pending[parity] && f1 > f0 &&
+                               (c->side_state[parity] == 0 || (c->side_state[parity] == 2 && c->side_cover[parity] == parity));   // (the side stream's readers of these planes are behind that event too)
+    const bool scene_written = c->scene_epoch != c->pre_seen_epoch || !wide_clean;
+    c->pre_seen_epoch = c->scene_epoch;
+    if (pre_pipelined) {
+      if (c->pre_scene_marked) HK_HIP(hipStreamWaitEvent(c->pre_stream, c->pre_scene_mark, 0));
+      HK_HIP(hipStreamWaitEvent(c->pre_stream, c->post_done[parity], 0));   // (the main stream gets behind it through pre_done below)
+      c->post_pending[parity] = false;
+    } else if ((flags & HK_FRAME_EXTERNAL_GBUFFER) ? (rc = join_post(c)) : (rc = join_post_parity(c, c->mapped_parity))) {
+      return rc;
+    }
     bool albedo_done = false;
     if (c->timing_mask) (void)hipEventRecord(c->frame_start, c->stream);
     if (!(flags & HK_FRAME_EXTERNAL_GBUFFER)) {
@@ -1393,9 +1436,21 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
         if ((rc = wide_for_fused(c, &wide))) return rc;
         {
           ScopedTimer timer(c, HK_PASS_PREPASS);
-          launch_prepass(c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1, counters, &wide);
+          launch_prepass(pre_pipelined ? c->pre_stream : c->stream, c->scene, fr, c->view.inverse_view_proj, c->view.view_proj, c->pview.view_proj, c->d_prev_models, j.x, j.y, g, f0, f1,
+                         counters, &wide);
         }
         HK_HIP(hipGetLastError());
+        if (pre_pipelined) {
+          HK_HIP(hipEventRecord(c->pre_done, c->pre_stream));
+          HK_HIP(hipStreamWaitEvent(c->stream, c->pre_done, 0));
+          c->prepasses_pipelined += 1;
+        } else if (c->pre_stream && scene_written) {
+          // scene memory was written since the last frame - uploads and refits on the main stream behind the previous frame's spatial pass,
+          // the wide records derived again just above: whichever later frame pipelines its primary rays (they may start as early as this
+          // frame's own) must find all of it done
+          HK_HIP(hipEventRecord(c->pre_scene_mark, c->stream));
+          c->pre_scene_marked = true;
+        }
         albedo_done = true;
       }
     } else if (f1 > f0) {  // host-rasterised G-buffer: only the derived planes are ours to fill
@@ -1422,6 +1477,8 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
       HK_RUN(HK_PASS_DIRECT_EMISSIVE, 0, b0, b1);
       HK_RUN(HK_PASS_INDIRECT, 0, b0, b1);
     }
+    c->pre_chain_ok = !(flags & (HK_FRAME_EXTERNAL_GBUFFER | HK_FRAME_ANTIALIAS));   // (the next frame's primary rays may run beside what follows of this one)
+    c->pre_last_parity = parity;
   } else if (stage == HK_STAGE_SPATIAL) {            // light.rs:689-697
     if (parks_across_bands(c) && c->det_winner[0]) {
       // exchange A delivered the parked stores of the pixels up to 2 x history rows outside the band.  Per

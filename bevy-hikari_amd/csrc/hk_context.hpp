@@ -109,6 +109,20 @@ struct hk_ctx {
   hipStream_t own_stream = nullptr;
   bool own_stream_high = false;      // ... created at the device's highest stream priority (context.hip pick_main_stream)
   bool main_priority_decided = false; // ... by the rule, at the first hk_resize
+  // Primary-ray pipelining (round 6; context.hip stage TEMPORAL): frame n's primary rays on a stream of their own, ordered only behind
+  // what last touched the G-buffer planes of ITS parity - frame n - 2, whose post-processing event covers all three of that frame's
+  // streams - so that they run beside frame n - 1's spatial pass instead of behind it.  The stream exists only where the main stream
+  // sits in the high-priority queue pool (a fourth stream of the default priority then has a hardware queue to itself).  scene_epoch
+  // counts every write to scene memory (uploads, refits, rebuilds: scene_layout.hip / scene_refit.hip); a frame whose scene was
+  // written since the last one takes the serial order - those writes sit behind the previous frame's spatial pass on the main stream.
+  hipStream_t pre_stream = nullptr;
+  hipEvent_t pre_done = nullptr, pre_scene_mark = nullptr;   // pre_scene_mark: the main stream behind the latest writes to scene memory
+  bool pre_scene_marked = false;
+  int prepass_pipeline = -1;          // HK_DEBUG_OPT_PREPASS_PIPELINE: -1 the rule, 0 never, 1 whenever the order allows
+  uint64_t scene_epoch = 0, pre_seen_epoch = 0;
+  bool pre_chain_ok = false;          // the previous frame went through stage TEMPORAL with the other parity, without the AA tail
+  uint32_t pre_last_parity = 0;
+  uint64_t prepasses_pipelined = 0;
   int main_priority = -1;            // HK_DEBUG_OPT_MAIN_PRIORITY: -1 the rule, 0 default priority, 1 highest
   hipStream_t side_stream = nullptr;   // the direct-light dispatches of the frame path run here (unless HK_CTX_SINGLE_STREAM)
   hipEvent_t fork_event = nullptr, join_event = nullptr;

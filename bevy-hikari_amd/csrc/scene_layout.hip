@@ -513,6 +513,7 @@ void point_scene_at_slot(hk_ctx* c) {
 
 int finalize_scene(hk_ctx* c) {
   if (!c->mesh_dirty && !c->dynamic_dirty && !c->textures_dirty) return HK_OK;
+  c->scene_epoch += 1;   // (scene memory is about to be written on the main stream: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "meshes, materials and instances must be uploaded first");
   const size_t n_nodes = c->asset_nodes.size();
   bool need_static = c->mesh_dirty || !c->scene_mem || c->node_prim_offset.size() != n_nodes;
@@ -632,6 +633,7 @@ int finalize_scene(hk_ctx* c) {
 extern "C" {
 
 int hk_upload_meshes(hk_ctx* c, const HkVertex* v, uint32_t nv, const HkPrimitive* p, uint32_t np, const HkNode* n, uint32_t nn) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && v && p && n && nv && np && nn, HK_E_INVALID, "NULL or empty mesh buffers");
   c->vertices.assign(v, v + nv);
   c->primitives.assign(p, p + np);
@@ -641,6 +643,7 @@ int hk_upload_meshes(hk_ctx* c, const HkVertex* v, uint32_t nv, const HkPrimitiv
   return HK_OK;
 }
 int hk_upload_materials(hk_ctx* c, const HkMaterial* m, uint32_t n) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && m && n, HK_E_INVALID, "NULL or empty material buffer");
   c->materials.assign(m, m + n);
   c->have_materials = true;
@@ -649,6 +652,7 @@ int hk_upload_materials(hk_ctx* c, const HkMaterial* m, uint32_t n) {
 }
 int hk_upload_instances(hk_ctx* c, const HkInstance* inst, uint32_t ni, const HkNode* inodes, uint32_t nin, const HkEmissive* em, uint32_t ne,
                         const HkNode* enodes, uint32_t nen, const HkAliasEntry* alias, uint32_t na) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && inst && inodes && ni && nin, HK_E_INVALID, "NULL or empty instance buffers");
   HK_REQUIRE((em || !ne) && (enodes || !nen) && (alias || !na), HK_E_INVALID, "NULL emissive buffers");
   c->instances.assign(inst, inst + ni);
@@ -663,6 +667,7 @@ int hk_upload_instances(hk_ctx* c, const HkInstance* inst, uint32_t ni, const Hk
   return HK_OK;
 }
 int hk_upload_previous_transforms(hk_ctx* c, const float* models, uint32_t n) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && (models || !n), HK_E_INVALID, "NULL argument");
   HK_REQUIRE(c->have_instances && n == c->instances.size(), HK_E_INVALID, "previous transforms must match the %zu uploaded instances", c->instances.size());
   c->prev_models.assign(models, models + 16 * (size_t)n);
@@ -674,6 +679,7 @@ int hk_upload_previous_transforms(hk_ctx* c, const float* models, uint32_t n) {
              "the builder holds stand-in trees (hk_scene_builder_finish_instances): finish it with hk_scene_builder_finish, or use " \
              "hk_update_scene_instances, which builds the trees on the device")
 int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
   HK_NO_STANDINS(b);  // (frames from stand-in trees would differ silently in tie-breaks and visit order)
   const HkVertex* v; const HkPrimitive* p; const HkNode *an, *in_, *en; const HkMaterial* m; const HkInstance* inst; const HkEmissive* em; const HkAliasEntry* al;
@@ -696,6 +702,7 @@ int hk_upload_scene(hk_ctx* c, const hk_scene_builder* b) {
   return hk_upload_previous_transforms(c, pm, npm);
 }
 int hk_upload_scene_instances(hk_ctx* c, const hk_scene_builder* b) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
   HK_NO_STANDINS(b);
   return hk::upload_scene_instances_unchecked(c, b);
@@ -718,6 +725,7 @@ int hk::upload_scene_instances_unchecked(hk_ctx* c, const hk_scene_builder* b) {
 }
 extern "C" {
 int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && (images || !n), HK_E_INVALID, "NULL argument");
   std::vector<hk_ctx::HostTexture> tex(n);
   for (uint32_t i = 0; i < n; ++i) {
@@ -736,6 +744,7 @@ int hk_upload_textures(hk_ctx* c, const HkImageDesc* images, uint32_t n) {
   return HK_OK;
 }
 int hk_upload_noise(hk_ctx* c, const uint8_t* rgba, size_t bytes) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && rgba && bytes == 16u * 64u * 64u * 4u, HK_E_INVALID, "noise must be 16 tiles of 64x64 RGBA8 (262144 bytes)");
   HK_HIP(hipSetDevice(c->device));
   std::vector<uint32_t> words(16u * 64u * 64u);

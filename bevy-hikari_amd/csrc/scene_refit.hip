@@ -14,6 +14,7 @@ extern "C" {
 // tree, link for link).  What the host no longer does is the two `BVH::build` calls: 1.1 ms of 1.7 ms at 2 000 instances, 30 of
 // 32 ms at 20 000.
 int hk_update_scene_instances(hk_ctx* c, hk_scene_builder* b, uint32_t tree_mode) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
   HK_REQUIRE(tree_mode == HK_TREE_SAH || tree_mode == HK_TREE_LBVH, HK_E_INVALID, "unknown tree build mode %u", tree_mode);
   int rc;
@@ -146,6 +147,7 @@ int begin_device_update(hk_ctx* c) {
 }  // namespace
 
 int hk_rebuild_scene_trees(hk_ctx* c, uint32_t mode) {
+  if (c) c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c, HK_E_INVALID, "ctx is NULL");
   HK_REQUIRE(mode == HK_TREE_SAH || mode == HK_TREE_LBVH, HK_E_INVALID, "unknown tree build mode %u", mode);
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
@@ -221,6 +223,7 @@ int hk_debug_read_trees(hk_ctx* c, HkNode* tlas, uint32_t tlas_cap, HkNode* ligh
 // `commit`: advance the builder's previous-transform bookkeeping (once per update, whichever context sees it last)
 static int refit_impl(hk_ctx* c, hk_scene_builder* b, uint32_t* moved_out, bool commit) {
   HK_REQUIRE(c && b, HK_E_INVALID, "NULL argument");
+  c->scene_epoch += 1;   // (scene memory is written: hk_context.hpp, primary-ray pipelining)
   HK_REQUIRE(c->have_meshes && c->have_materials && c->have_instances, HK_E_NOT_READY, "hk_upload_scene must come first");
   HK_HIP(hipSetDevice(c->device));
   int rc;

@@ -723,6 +723,12 @@ class Engine:
         self.api.call("debug_main_stream_priority", self.ctx, C.byref(v))
         return bool(v.value & 1), bool(v.value & 2)
 
+    def prepasses_pipelined(self):
+        """frames whose primary rays ran on their own stream beside the previous frame's spatial pass (hk_debug_main_stream_priority, bits 8..27)"""
+        v = F.u32()
+        self.api.call("debug_main_stream_priority", self.ctx, C.byref(v))
+        return int(v.value >> 8)
+
     def spatial_windowed_launches(self):
         """spatial_reuse launches that took the windowed form of the kernel (hikari_hip_debug.h; F.DEBUG_OPT_SPATIAL_WINDOW)."""
         n = C.c_uint64()

@@ -63,7 +63,8 @@ int hk_debug_comm_loopback(hk_ctx* ctx, uint32_t src_buffer, uint32_t dst_buffer
 int hk_debug_spatial_windowed_launches(hk_ctx* ctx, uint64_t* out);
 
 /* Test hook (round 6): the priority the context's own main stream was created at - 0 the default, 1 the device's highest, and whether the
- * rule has decided yet (bit 1: it decides at the context's first frame; hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) decides at once). */
+ * rule has decided yet (bit 1: it decides at the context's first frame; hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) decides at once);
+ * bit 2: the context has its fourth stream (the primary rays'), bits 8..27: frames whose primary rays were pipelined so far. */
 int hk_debug_main_stream_priority(hk_ctx* ctx, uint32_t* out);
 
 /* Test hook (round 6): 2 when the context's communicator has its second lane - a communicator (ncclCommSplit of the first) and a stream of
@@ -82,6 +83,7 @@ int hk_debug_comm_lanes(hk_ctx* ctx, uint32_t* lanes);
 #define HK_DEBUG_OPT_POST_DEMODULATION 6u /* demodulation on the post stream with the a-trous levels: -1 by the library's rule (default), 0 on the main stream, 1 on the post stream */
 #define HK_DEBUG_OPT_PERSISTENT_PATHS 8u /* the queue-based indirect pass runs every bounce in ONE launch, a path staying with the wave that claimed it (kernels_wavefront.hip k_wf_trace_wide<.., PATHS>): -1 by the library's rule (default), 0 one trace + one shade launch per bounce, 1 one launch */
 #define HK_DEBUG_OPT_MAIN_PRIORITY 9u /* the priority of the context's own main stream, created again at once: -1 by the library's rule (the highest if the context dispatches at most 6 Mi pixels per frame; what the context's first frame decides by itself), 0 the default priority, 1 the highest.  A/B and tests: a stream created again several times ends up sharing a hardware queue */
+#define HK_DEBUG_OPT_PREPASS_PIPELINE 10u /* a frame's primary rays on a stream of their own beside the previous frame's spatial pass, where the order allows (context.hip stage TEMPORAL): -1 by the library's rule (default: scenes beyond the LDS copy in frames of up to 3 Mi pixels, on a context whose chain runs at the highest priority), 0 never, 1 whenever the order allows */
 #define HK_DEBUG_OPT_SIDE_JOIN 7u /* 1: the main stream waits for the direct-light dispatches (side stream) at the end of every frame, as it did through round 5; 0 (default): only the post-processing does */
 int hk_debug_set_option(hk_ctx* ctx, uint32_t option, int64_t value);
 /* hk_multi_*: 1 = the calling thread enqueues every band's launches one after another instead of one thread per band (process-wide) */

@@ -302,3 +302,44 @@ def test_the_main_streams_priority_follows_the_pixels_of_the_contexts_first_fram
     big.wait()
     assert big.main_stream_priority() == (False, True)
     assert engine(3840, 2160, band=(1, 4)).main_stream_priority() == (True, True)   # a quarter of it: 2 Mi pixels per frame
+
+
+def test_primary_ray_pipelining_changes_no_bit_and_stands_down_when_the_scene_is_written():
+    """Round 6 (context.hip stage TEMPORAL): on a context whose chain runs in the high-priority queue pool, a frame's primary rays go to a
+    stream of their own - ordered only behind the frame two back - and run beside the previous frame's spatial pass.  A frame whose scene
+    memory was written since the last one (a refit, an upload), a frame behind the anti-aliasing tail, a timed frame take the serial order.
+    Every buffer of every frame equals a context that never pipelines; the camera moves every frame."""
+    from bevy_hikari_amd.scenes import synthetic_large
+
+    scene, sun = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
+    lights = hk.lights_uniform(directional=sun)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    from cases import product_default_traversal
+    with product_default_traversal():
+        a, b = hk.HikariPlugin(device=0), hk.HikariPlugin(device=0)   # (the product default: the verification contexts have no post stream, hence no fourth)
+    a.engine.set_debug_option(F.DEBUG_OPT_PREPASS_PIPELINE, 1)
+    b.engine.set_debug_option(F.DEBUG_OPT_PREPASS_PIPELINE, 0)
+    for p in (a, b):
+        p.set_scene(scene)
+    rest = [np.ctypeslib.as_array(i.model).copy() for i in scene.instances]
+    setter = scene.builder.api.raw("scene_builder_set_instance_transform")
+    import ctypes as C
+    for n in range(1, 25):
+        cam = hk.Camera(hk.look_at_transform((1.6 * 9.0 + 0.03 * n, 1.1 * 9.0, 2.0 * 9.0), (0.0, 0.6, 0.0)), 320, 180)
+        if n in (6, 7, 14):   # instances move: a device refit of both contexts' scenes between two frames
+            for k in range(0, len(rest), 37):
+                m = rest[k].reshape(4, 4).T.copy()
+                m[0, 3] += 0.02 * n
+                t = m.T.astype(np.float32).reshape(-1)
+                setter(scene.builder.h, k, t.ctypes.data_as(C.POINTER(F.f32)))
+            for p in (a, b):
+                p.engine.refit_instances(scene.builder)
+        for p in (a, b):
+            p.render(cam, s, lights=lights, frame_number=n, antialias=(n == 10))
+        if n % 4:   # (reading a buffer waits for the post stream, after which the next frame has nothing to pipeline behind: frames run in bursts)
+            continue
+        # (the camera moves: the default resolves the scatter race in the buffers that are read - the sun / emitter channels' previous_spatial
+        # records, reservoir4 / reservoir5, race on in both contexts, each its own way)
+        bad = {k: v for k, v in diff_buffers(snapshot(a), snapshot(b)).items() if k not in ("reservoir4", "reservoir5")}
+        assert bad == {}, n
+    assert a.engine.main_stream_priority()[0] and a.engine.prepasses_pipelined() >= 6 and b.engine.prepasses_pipelined() == 0
