@@ -52,6 +52,9 @@ bool certify_uv_division(int size) {
 // stream beside the first cost config 4 2.5 % (five streams per context: two share a hardware queue), and a stream created again
 // and again ends up on a queue it shares too (the same file: 0.92 -> 1.09 ms after three changes) - so later resizes and hk_set_band do
 // not revisit it.  (The device has few high-priority queues: the first contexts of a process get the benefit, a fifth one measured none.)  hk_debug_set_option(HK_DEBUG_OPT_MAIN_PRIORITY) forces a change (A/B and tests).
+#ifndef HK_PRE_BANDS
+#define HK_PRE_BANDS 1   // bands pipeline their primary rays too: a band of config 3 / 4 (an eighth of the frame) -11.5 % / -8.7 ... -12.4 % (profiles/r06_prepass_pipeline_ab.txt)
+#endif
 #ifndef HK_PRE_STREAM_HIGH
 #define HK_PRE_STREAM_HIGH 0   // the primary rays' own stream: the default priority (at the chain's: config 3 -1.8 % instead of -2.9 %, profiles/r06_prepass_pipeline_ab.txt)
 #endif
@@ -83,7 +86,8 @@ int pick_main_stream(hk_ctx* c, bool forced) {
   if (in_use) c->stream = fresh;
   // (with the chain in the high-priority pool a fourth default-priority stream has a hardware queue of its own: the primary rays')
   if (high && c->side_stream && c->post_stream && !c->pre_stream) {
-    if (hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, HK_PRE_STREAM_HIGH ? greatest : least) != hipSuccess || hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess ||
+    // (a band's context also holds the two communicator lanes: the default-priority pool is full, the primary rays join the chain's pool)
+    if (hipStreamCreateWithPriority(&c->pre_stream, hipStreamNonBlocking, (HK_PRE_STREAM_HIGH || c->band_count > 1) ? greatest : least) != hipSuccess || hipEventCreateWithFlags(&c->pre_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->pre_scene_mark, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       if (c->pre_stream) (void)hipStreamDestroy(c->pre_stream);
@@ -96,7 +100,7 @@ int pick_main_stream(hk_ctx* c, bool forced) {
 // scenes beyond the LDS copy (long primary rays, trace stages with ends to fill) in frames of up to 3 Mi pixels: measured on configs 3 / 4
 // at 720p / 1080p -7.5 / -3.9 / -9.0 % per frame, at 2560 x 1440 0 / +1.4 %; the Cornell frame (its primary rays: 0.066 of 0.88 ms, walked
 // from LDS) +5 % with the stream at the default priority and 0 at the chain's - profiles/r06_prepass_pipeline_ab.txt
-#define HK_PREPASS_PIPELINE_RULE ((size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES && (size_t)c->RW * (size_t)c->RH <= ((size_t)3 << 20))
+#define HK_PREPASS_PIPELINE_RULE ((size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES && (size_t)c->RW * (size_t)c->RH / (size_t)(c->band_count > 0 ? c->band_count : 1) <= ((size_t)3 << 20))
 #endif
 int free_screen(hk_ctx* c) {
   for (int k = 0; k < 3; ++k) {
@@ -1411,7 +1415,7 @@ int hk_frame_stage(hk_ctx* c, uint32_t stage, const HkSettings* st, uint32_t fla
     const bool wide_clean = !wide_allowed(c) || (!c->wide_tlas_dirty && !c->wide_blas_dirty && !c->wide_mesh_check);
     const bool pre_wanted = c->prepass_pipeline < 0 ? HK_PREPASS_PIPELINE_RULE : c->prepass_pipeline != 0;
     const bool pre_pipelined = pre_wanted && c->pre_stream && c->stream == c->own_stream && c->normal_twin && c->pre_chain_ok && c->pre_last_parity != parity &&
-                               !(flags & (HK_FRAME_EXTERNAL_GBUFFER | HK_FRAME_ANTIALIAS)) && c->band_count == 1 && !c->timing_mask && !(c->flags & HK_CTX_COUNT_RAYS) &&
+                               !(flags & (HK_FRAME_EXTERNAL_GBUFFER | HK_FRAME_ANTIALIAS | HK_FRAME_TIME_BAND)) && (c->band_count == 1 || HK_PRE_BANDS) && !c->timing_mask && !(c->flags & HK_CTX_COUNT_RAYS) &&
                                wide_clean && !c->derived_dirty && c->scene_epoch == c->pre_seen_epoch && c->post_pending[parity] && f1 > f0 &&
                                (c->side_state[parity] == 0 || (c->side_state[parity] == 2 && c->side_cover[parity] == parity));   // (the side stream's readers of these planes are behind that event too)
     const bool scene_written = c->scene_epoch != c->pre_seen_epoch || !wide_clean;

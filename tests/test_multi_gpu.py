@@ -480,3 +480,42 @@ def test_multi_engine_device_motion_reaches_every_band():
     for e in m.contexts:
         st = e.stats()
         assert st.scene_device_refits == 5 and st.scene_device_tree_builds == 1
+
+
+@pytest.mark.parametrize("bands", [3, 8])
+def test_bands_with_pipelined_primary_rays_equal_the_single_context(bands):
+    """Round 6: a band's context pipelines its primary rays like a single one (context.hip stage TEMPORAL; its fourth stream in the chain's
+    queue pool, the default pool being full with the communicator lanes).  A scene beyond the LDS copy, camera AND instances moving
+    (device refits between frames: those frames take the serial order), frames enqueued in bursts - a read waits for the post stream,
+    after which the next frame has nothing to pipeline behind.  The bands' union == a single context that never pipelines
+    (HK_CTX_DETERMINISTIC_SCATTER: it has no post stream), every buffer that has a reader, bit for bit."""
+    from bevy_hikari_amd.scenes import synthetic_large
+    from cases import product_default_traversal
+
+    multi_scene, sun = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
+    single_scene, _ = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
+    s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
+    w, h, frames = 256, 144, 18
+    lights = hk.lights_uniform(directional=sun)
+    cams = [hk.Camera(hk.look_at_transform((1.6 * 9.0 + 0.04 * n, 1.1 * 9.0 + 0.03 * n, 2.0 * 9.0), (0.0, 0.6, 0.0)), w, h) for n in range(frames + 1)]
+    with product_default_traversal():
+        m = MultiEngine([0] * bands)
+        ref = hk.Engine(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)
+    for t, scene in ((m, multi_scene), (ref, single_scene)):
+        t.upload_noise(); t.upload_scene(scene); t.resize(w, h, 1.0)
+    m.set_band_bounds(_uneven(h, bands, 17 * bands))
+    rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in single_scene.instances], dtype=np.float32)
+    for n in range(1, frames + 1):
+        if n in (5, 6, 13):
+            for k in range(0, len(rest), 41):
+                mm = rest[k].reshape(4, 4).T.copy()
+                mm[0, 3] += 0.02 * n
+                for scene in (multi_scene, single_scene):
+                    scene.builder.set_instance_transform(k, mm.T.astype(np.float32).reshape(-1))
+            assert m.refit_instances(multi_scene.builder) == ref.refit_instances(single_scene.builder) > 0
+        args = (hk.frame_uniform(s, n), cams[n].view_uniform(), cams[n].previous_view_uniform(cams[n - 1]), lights, s.to_c())
+        m.frame_render(*args)
+        ref.frame_render(*args)
+        if n % 3 == 0:
+            _same_buffers(m, ref, n, s, f"pipelined primary rays x{bands} ")
+    assert sum(c.prepasses_pipelined() for c in m.contexts) >= bands * 4
