@@ -31,7 +31,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, nargs="+", default=[2, 4])
     ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--single", action="store_true", help="(internal) only the whole frame of the one config, in this process: prints {single_ms}")
     args = ap.parse_args()
+    if len(args.configs) > 1 and not args.single:
+        # one process per config: the band context must be its process's first and only one (see below)
+        import subprocess
+
+        merged = None
+        for cfg in args.configs:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--configs", str(cfg), "--frames", str(args.frames)], check=True, capture_output=True, text=True)
+            d = json.loads(r.stdout)
+            if merged is None:
+                merged = d
+            else:
+                merged["configs"].update(d["configs"])
+        print(json.dumps(merged, indent=1))
+        return
     out = {"assumptions": {"link_gbs_one_direction": LINK_GBS, "exchange_fixed_us": EXCHANGE_US,
                            "method": "every band rendered alone on one MI355X (hk_set_band), wall clock over K frames after a full-frame warm-up; "
                                      "predicted N-GPU frame = max over bands + sum over the frame's exchanges (two halo exchanges + the gather of the tone-mapped image on rank 0) of (fixed + largest transfer "
@@ -47,11 +62,38 @@ def main():
         W, H = camera.width, camera.height
         sc = settings.to_c()
         view, pview = camera.view_uniform(), camera.previous_view_uniform()
-        e = hk.Engine(device=0)
-        e.upload_noise()
-        e.upload_scene(scene)
-        e.resize(W, H, 1.0)
+        # The single-GPU frame comes from a process of its own (`--single`), the bands from a context that sees a BAND at its first frame, as
+        # a rank's context does - which stream priorities and whether the primary rays get their own stream is decided there (round 6) - and
+        # that is the first and only context of THIS process: a process has few hardware queues per stream priority, and a context
+        # created after another one died measured twice a band's time.
+        def make(first_band):
+            x = hk.Engine(device=0)
+            x.upload_noise()
+            x.upload_scene(scene)
+            x.resize(W, H, 1.0)
+            if first_band:
+                x.set_band(*first_band)
+            return x
+
         K = args.frames if config == 2 else max(10, args.frames // 2)
+        if args.single:
+            whole = make(None)
+            single_ms, kf = [], 0
+            for rep_ in range(3):
+                t0 = time.perf_counter()
+                for _ in range(12 if rep_ == 0 else K):
+                    kf += 1
+                    whole.frame_render(hk.frame_uniform(settings, kf), view, pview, lights, sc)
+                whole.wait()
+                if rep_:
+                    single_ms.append((time.perf_counter() - t0) / K * 1e3)
+            print(json.dumps({"single_ms": min(single_ms)}))
+            return
+        import subprocess
+
+        single_ms = [json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), "--single", "--configs", str(config), "--frames", str(args.frames)],
+                                               check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])["single_ms"]]
+        e = make((0, 2))
         n = 0
 
         def frames(count):
@@ -119,6 +161,8 @@ def main():
                     if step < 8:   # (damping 0.6, then 0.35 once the boundaries move by a few rows only: the times are noisy to ~1 %)
                         bounds = rebalanced_band_bounds(bounds, ms, H, None, min_rows=8, max_shift=0, damping=0.6 if step < 4 else 0.35)
                 bounds, per_band = best
+            elif bands == 1:   # the single-GPU frame: the context that rendered whole frames from the start (measured above)
+                per_band = [min(single_ms)]
             else:
                 per_band = measure_bands(bands, bounds)
             for b in range(bands):
