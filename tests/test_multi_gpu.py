@@ -482,8 +482,8 @@ def test_multi_engine_device_motion_reaches_every_band():
         assert st.scene_device_refits == 5 and st.scene_device_tree_builds == 1
 
 
-@pytest.mark.parametrize("bands", [3, 8])
-def test_bands_with_pipelined_primary_rays_equal_the_single_context(bands):
+@pytest.mark.parametrize("bands,which", [(3, "large"), (8, "large"), (8, "lds")])
+def test_bands_with_pipelined_primary_rays_equal_the_single_context(bands, which):
     """Round 6: a band's context pipelines its primary rays like a single one (context.hip stage TEMPORAL; its fourth stream in the chain's
     queue pool, the default pool being full with the communicator lanes).  A scene beyond the LDS copy, camera AND instances moving
     (device refits between frames: those frames take the serial order), frames enqueued in bursts - a read waits for the post stream,
@@ -492,12 +492,20 @@ def test_bands_with_pipelined_primary_rays_equal_the_single_context(bands):
     from bevy_hikari_amd.scenes import synthetic_large
     from cases import product_default_traversal
 
-    multi_scene, sun = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
-    single_scene, _ = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
+    if which == "large":
+        multi_scene, sun = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
+        single_scene, _ = synthetic_large(0x5EED0003, 40, 40, 80, 400, 50, 8, 12.0)
+    else:   # a scene every kernel walks from its LDS copy: pipelined only where a band leaves most of the chip idle (the rule counts the band's pixels)
+        from bevy_hikari_amd.scenes import synthetic_scene
+        from test_device_refit import LARGE
+
+        multi_scene, sun = synthetic_scene(**LARGE)
+        single_scene, _ = synthetic_scene(**LARGE)
     s = hk.HikariSettings(indirect_bounces=2, upscale=hk.Upscale.SMAA_TU_1_0)
     w, h, frames = 256, 144, 18
     lights = hk.lights_uniform(directional=sun)
-    cams = [hk.Camera(hk.look_at_transform((1.6 * 9.0 + 0.04 * n, 1.1 * 9.0 + 0.03 * n, 2.0 * 9.0), (0.0, 0.6, 0.0)), w, h) for n in range(frames + 1)]
+    eye = (1.6 * 9.0, 1.1 * 9.0, 2.0 * 9.0) if which == "large" else (6.4, 4.4, 8.0)
+    cams = [hk.Camera(hk.look_at_transform((eye[0] + 0.04 * n, eye[1] + 0.03 * n, eye[2]), (0.0, 0.6, 0.0)), w, h) for n in range(frames + 1)]
     with product_default_traversal():
         m = MultiEngine([0] * bands)
         ref = hk.Engine(device=0, flags=F.CTX_DETERMINISTIC_SCATTER)
@@ -507,7 +515,7 @@ def test_bands_with_pipelined_primary_rays_equal_the_single_context(bands):
     rest = np.array([np.ctypeslib.as_array(i.model).copy() for i in single_scene.instances], dtype=np.float32)
     for n in range(1, frames + 1):
         if n in (5, 6, 13):
-            for k in range(0, len(rest), 41):
+            for k in range(0, len(rest), 41 if which == "large" else 5):
                 mm = rest[k].reshape(4, 4).T.copy()
                 mm[0, 3] += 0.02 * n
                 for scene in (multi_scene, single_scene):
