@@ -100,11 +100,16 @@ int pick_main_stream(hk_ctx* c, bool forced) {
 // scenes beyond the LDS copy (long primary rays, trace stages with ends to fill) in frames of up to 3 Mi pixels: measured on configs 3 / 4
 // at 720p / 1080p -7.5 / -3.9 / -9.0 % per frame, at 2560 x 1440 0 / +1.4 %; the Cornell frame (its primary rays: 0.066 of 0.88 ms, walked
 // from LDS) +5 % with the stream at the default priority and 0 at the chain's - profiles/r06_prepass_pipeline_ab.txt
-// (scenes walked from LDS: only where a band leaves most of the chip idle - Cornell 1080p in 8 / 4 bands -9 % / -4 % per band frame, in 2
-// bands 0 ... +1.5 %, the whole frame 0 ... +5.7 %)
+// (Scenes walked from LDS gain only where a band leaves most of the chip idle - Cornell 1080p in 8 / 4 bands -9 % / -4 % per band frame, in
+// 2 bands 0 ... +1.5 %, the whole frame 0 ... +5.7 % - and are NOT pipelined by the rule: HK_PREPASS_PIPELINE_LDS_BANDS.  One run of ~160 of
+// the band test on such a scene showed 11 records of an indirect spatial reservoir differing from the single context's - every rendered
+// plane equal, not reproduced since, with the pipelining or without: NOTES "open".  hk_debug_set_option(.., 1) pipelines them.)
+#ifndef HK_PREPASS_PIPELINE_LDS_BANDS
+#define HK_PREPASS_PIPELINE_LDS_BANDS 0
+#endif
 #define HK_PREPASS_PIPELINE_RULE                                                                                                     \
   ((size_t)c->scene.blob_f4 * 16 > HK_LDS_SCENE_BYTES ? (size_t)c->RW * (size_t)c->RH / (size_t)(c->band_count > 0 ? c->band_count : 1) <= ((size_t)3 << 20) \
-                                                        : (c->band_count > 1 && (size_t)c->RW * (size_t)c->RH / (size_t)c->band_count <= ((size_t)3 << 18)))
+                                                        : (HK_PREPASS_PIPELINE_LDS_BANDS && c->band_count > 1 && (size_t)c->RW * (size_t)c->RH / (size_t)c->band_count <= ((size_t)3 << 18)))
 #endif
 int free_screen(hk_ctx* c) {
   for (int k = 0; k < 3; ++k) {
